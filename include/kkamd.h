@@ -1,0 +1,160 @@
+/* kkamd.h -- C ABI of libkkamd.so: the MI355X (gfx950) native implementation of the
+ * KokkosSparse::spmv / KokkosSparse::spgemm hot path.
+ *
+ * This is the drop-in boundary.  It sits exactly where kokkos-kernels plugs vendor libraries in
+ * today -- the "TPL specialisation" layer -- and takes what those specialisations hand over:
+ * raw device pointers unwrapped from Kokkos::Views, extents, and the execution-space instance's
+ * HIP stream.  Each entry point cites the reference interface it replaces (paths relative to the
+ * kokkos-kernels 4.7.00 tree).  INTEGRATION.md shows the *_tpl_spec_{avail,decl}.hpp siblings a
+ * maintainer adds on the reference side to bind them.
+ *
+ * Conventions
+ *   - plain C, no C++/torch/Kokkos types; every pointer named d_* is a DEVICE pointer, borrowed
+ *     for the duration of the call (the reference's Unmanaged views);
+ *   - every function returns a kkamd_status (0 = ok) and never throws; kkamd_last_error() gives the
+ *     message for the calling thread.  The C++ shim turns non-zero into the exception type the
+ *     reference would throw (std::runtime_error / std::invalid_argument);
+ *   - kkamd_stream_t is hipStream_t (a pointer to the opaque ihipStream_t); SpMV entry points are
+ *     asynchronous on that stream, SpGEMM phases synchronise it where they must return counts;
+ *   - CSR: zero-based, row_map has num_rows+1 offsets (int32 or int64), entries are int32 ordinals
+ *     (the reference requires a signed ordinal: sparse/src/KokkosSparse_CrsMatrix.hpp:320),
+ *     values float or double.
+ */
+#ifndef KKAMD_H
+#define KKAMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KKAMD_VERSION 100
+
+typedef struct ihipStream_t* kkamd_stream_t;
+
+typedef enum {
+  KKAMD_OK               = 0,
+  KKAMD_ERR_INVALID_ARG  = 1, /* dimension/type/pointer problems (reference: std::runtime_error)        */
+  KKAMD_ERR_UNSUPPORTED  = 2, /* type tuple or mode not implemented here: caller diverts to native path  */
+  KKAMD_ERR_HIP          = 3, /* a HIP runtime call failed (reference: *_SAFE_CALL -> std::runtime_error)*/
+  KKAMD_ERR_ALLOC        = 4,
+  KKAMD_ERR_STATE        = 5  /* handle misuse, e.g. numeric before symbolic (std::invalid_argument)    */
+} kkamd_status;
+
+typedef enum { KKAMD_F32 = 0, KKAMD_F64 = 1 } kkamd_scalar_type;
+typedef enum { KKAMD_I32 = 0, KKAMD_I64 = 1 } kkamd_offset_type;
+
+/* KokkosSparse::SPMVAlgorithm (sparse/src/KokkosSparse_spmv_handle.hpp:32-47), CRS subset. */
+typedef enum {
+  KKAMD_SPMV_DEFAULT           = 0,
+  KKAMD_SPMV_FAST_SETUP        = 1,
+  KKAMD_SPMV_NATIVE            = 2,
+  KKAMD_SPMV_MERGE_PATH        = 3,
+  KKAMD_SPMV_NATIVE_MERGE_PATH = 4
+} kkamd_spmv_algorithm;
+
+/* CrsMatrix as the TPL layer sees it: (numRows, numCols, nnz, graph.row_map.data(),
+ * graph.entries.data(), values.data()) -- sparse/tpls/KokkosSparse_spmv_tpl_spec_decl.hpp:332-338. */
+typedef struct {
+  int64_t num_rows;
+  int64_t num_cols;
+  int64_t nnz;
+  const void* d_row_map; /* offset_type[num_rows + 1] */
+  const void* d_entries; /* int32_t[nnz]              */
+  const void* d_values;  /* value_type[nnz]           */
+  int offset_type;       /* kkamd_offset_type         */
+  int value_type;        /* kkamd_scalar_type         */
+} kkamd_crs_t;
+
+const char* kkamd_last_error(void);
+int kkamd_version(void);
+/* name of the device the library is running on and whether it is gfx950; used by tests. */
+int kkamd_device_info(char* name, int name_len, int* is_gfx950, int* num_cus);
+
+/* ------------------------------------------------------------------------------------------------
+ * SpMV.  Replaces Impl::SPMV<Kokkos::HIP,...>::spmv and Impl::SPMV_MV<...>::spmv_mv
+ * (sparse/impl/KokkosSparse_spmv_spec.hpp:92-135; vendor precedent
+ * sparse/tpls/KokkosSparse_spmv_tpl_spec_decl.hpp:278-425 and ..._spmv_mv_tpl_spec_decl.hpp:284-430).
+ *
+ * A plan is the analogue of SPMVHandleImpl::tpl_rank1 / tpl_rank2
+ * (sparse/src/KokkosSparse_spmv_handle.hpp:241-242): created lazily on the first call with a handle,
+ * bound to ONE matrix for life (:273-277), destroyed with the handle.  plan == NULL is the
+ * handle-less / SPMV_FAST_SETUP route: no analysis, no workspace.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct kkamd_spmv_plan kkamd_spmv_plan_t;
+
+int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int algorithm, kkamd_stream_t stream);
+int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan);
+
+/* y := alpha*op(A)*x + beta*y.  mode 'N','C' (== 'N' for real scalars), 'T','H' (== 'T').
+ * vector_type is the scalar type of x and y (and of alpha/beta, the reference's coefficient_type);
+ * supported (value_type, vector_type) pairs: (F64,F64), (F32,F32), (F32,F64).
+ * beta == 0 overwrites y (NaN/Inf in the old y are discarded: sparse/src/KokkosSparse_spmv.hpp:145-154,
+ * sparse/impl/KokkosSparse_spmv_impl.hpp:127-131).  alpha == 0 / empty A reduce to the y scaling. */
+int kkamd_spmv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double alpha, const void* d_x, double beta,
+               void* d_y, int vector_type, kkamd_stream_t stream);
+
+/* Rank-2: X is (num_cols x nvec), Y is (num_rows x nvec) for 'N'; element (i,j) lives at
+ * i*stride0 + j*stride1 (in elements), which covers LayoutLeft (1, ld), LayoutRight (ld, 1) and the
+ * mixed pairs the rocSPARSE plug-in accepts (sparse/tpls/KokkosSparse_spmv_mv_tpl_spec_avail.hpp:108-134). */
+int kkamd_spmv_mv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double alpha, const void* d_X,
+                  int64_t x_stride0, int64_t x_stride1, double beta, void* d_Y, int64_t y_stride0, int64_t y_stride1,
+                  int64_t nvec, int vector_type, kkamd_stream_t stream);
+
+/* Expert knobs, the analogue of SPMVHandleImpl's public tuning members
+ * (sparse/src/KokkosSparse_spmv_handle.hpp:243-252).  key: "kernel" (0 auto, 1 vector, 2 stream),
+ * "lanes_per_row", "nnz_per_thread", "xcd_remap", "nontemporal", "mv_kernel".  Used by bench sweeps. */
+int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);
+int kkamd_set_default(const char* key, int value);
+
+/* ------------------------------------------------------------------------------------------------
+ * SpGEMM.  Replaces Impl::SPGEMM_SYMBOLIC<...>::spgemm_symbolic and
+ * Impl::SPGEMM_NUMERIC<...>::spgemm_numeric (sparse/impl/KokkosSparse_spgemm_symbolic_spec.hpp:72-126,
+ * ..._numeric_spec.hpp:91-145; vendor precedent sparse/tpls/KokkosSparse_spgemm_symbolic_tpl_spec_decl.hpp:367-,
+ * ..._numeric_tpl_spec_decl.hpp:259-).  A is m x n, B is n x k, C is m x k.
+ *
+ * The handle is the analogue of SPGEMMHandle's cross-phase state (c_nnz, row flops, max nnz per row:
+ * sparse/src/KokkosSparse_spgemm_handle.hpp:231-247).  Contract honoured: symbolic fills row_map C and
+ * returns nnz(C); the caller allocates entries/values of that size; numeric fills both, with every row's
+ * columns in ascending order (the reference sorts after numeric:
+ * sparse/impl/KokkosSparse_spgemm_numeric_spec.hpp:138-140); numeric may be repeated with new values.
+ * Inputs need not be sorted or merged.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct kkamd_spgemm_handle kkamd_spgemm_handle_t;
+
+int kkamd_spgemm_create(kkamd_spgemm_handle_t** handle);
+int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* handle);
+
+int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* handle, int64_t m, int64_t n, int64_t k, const void* d_row_mapA,
+                          const int32_t* d_entriesA, const void* d_row_mapB, const int32_t* d_entriesB,
+                          void* d_row_mapC, int offset_type, int64_t* c_nnz, kkamd_stream_t stream);
+
+int kkamd_spgemm_numeric(kkamd_spgemm_handle_t* handle, int64_t m, int64_t n, int64_t k, const void* d_row_mapA,
+                         const int32_t* d_entriesA, const void* d_valuesA, const void* d_row_mapB,
+                         const int32_t* d_entriesB, const void* d_valuesB, const void* d_row_mapC,
+                         int32_t* d_entriesC, void* d_valuesC, int offset_type, int value_type,
+                         kkamd_stream_t stream);
+
+/* what: 0 c_nnz, 1 total multiplications (the reference's original_overall_flops / 2),
+ * 2 max row flops, 3 max nnz in a row of C, 4 symbolic called, 5 numeric called. */
+int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);
+
+/* ------------------------------------------------------------------------------------------------
+ * Helpers either side of the path (KokkosSparse::sort_crs_matrix, sparse/src/KokkosSparse_SortCrs.hpp:43-120;
+ * kk_exclusive_parallel_prefix_sum, common/src/KokkosKernels_SimpleUtils.hpp:86-135) and the synthetic
+ * inputs of the benchmark configurations, generated in place in HBM
+ * (test_common/KokkosKernels_Test_Structured_Matrix.hpp, BC = 1 on every face).
+ * ------------------------------------------------------------------------------------------------ */
+int kkamd_sort_crs(int64_t num_rows, const void* d_row_map, int32_t* d_entries, void* d_values, int offset_type,
+                   int value_type, kkamd_stream_t stream);
+int kkamd_exclusive_scan(void* d_data, int64_t n, int offset_type, kkamd_stream_t stream);
+
+/* dim = 2 or 3; stencil 0 = FD (5/7-pt), 1 = FE (9/27-pt).  With d_entries == NULL only row_map is
+ * filled (and *nnz returned), so the caller can size entries/values. */
+int kkamd_gen_laplace(int dim, int stencil, int64_t nx, int64_t ny, int64_t nz, void* d_row_map, int32_t* d_entries,
+                      void* d_values, int offset_type, int value_type, int64_t* nnz, kkamd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KKAMD_H */

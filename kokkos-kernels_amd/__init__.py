@@ -1,0 +1,40 @@
+"""kokkos-kernels_amd -- MI355X (gfx950) native KokkosSparse::spmv / spgemm hot path.
+
+The product is libkkamd.so (hand-written HIP, C ABI in include/kkamd.h) plus the C++ drop-in headers
+under host/.  This Python package is plumbing for tests and benchmarks: it loads the library, keeps
+arrays in HBM as torch tensors, hands raw device pointers across the C ABI, and runs the 1-D
+row-partitioned multi-GPU SpMV over torch.distributed (RCCL).  It contains no CPU implementation and
+fails loudly when the HIP library is missing.
+"""
+import ctypes as _C
+import os as _os
+
+from . import _capi
+from ._capi import KkamdError  # noqa: F401
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+LIB_PATH = _os.path.join(_HERE, "libkkamd.so")
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libkkamd.so (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    cmd = ["make", "-C", _os.path.join(_HERE, "csrc"), "-j4"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded HIP library.  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not _os.path.exists(LIB_PATH):
+            raise RuntimeError("libkkamd.so is missing (%s): run __graft_entry__.build(); "
+                               "kokkos-kernels_amd has no CPU fallback" % LIB_PATH)
+        _lib = _capi.bind(_C.CDLL(LIB_PATH))
+    return _lib
+
+
+from .sparse import (CrsMatrix, SPMVHandle, KokkosKernelsHandle, spmv, spgemm_symbolic, spgemm_numeric, spgemm,  # noqa: E402,F401
+                     sort_crs_matrix, laplace_matrix, Backend, torch_backend)

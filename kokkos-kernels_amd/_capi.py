@@ -1,0 +1,60 @@
+"""ctypes signatures of libkkamd.so (include/kkamd.h).  Pointer plumbing only: every compute call
+goes to the HIP library; there is no Python or CPU implementation behind these functions."""
+import ctypes as C
+
+F32, F64 = 0, 1
+I32, I64 = 0, 1
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_ALLOC, ERR_STATE = range(6)
+SPMV_DEFAULT, SPMV_FAST_SETUP, SPMV_NATIVE, SPMV_MERGE_PATH, SPMV_NATIVE_MERGE_PATH = range(5)
+
+EXPORTS = [
+    "kkamd_last_error", "kkamd_version", "kkamd_device_info", "kkamd_spmv_plan_create", "kkamd_spmv_plan_destroy",
+    "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_plan_set", "kkamd_set_default", "kkamd_spgemm_create",
+    "kkamd_spgemm_destroy", "kkamd_spgemm_symbolic", "kkamd_spgemm_numeric", "kkamd_spgemm_get", "kkamd_sort_crs",
+    "kkamd_exclusive_scan", "kkamd_gen_laplace",
+]
+
+
+class CrsDesc(C.Structure):
+    _fields_ = [("num_rows", C.c_int64), ("num_cols", C.c_int64), ("nnz", C.c_int64), ("d_row_map", C.c_void_p),
+                ("d_entries", C.c_void_p), ("d_values", C.c_void_p), ("offset_type", C.c_int), ("value_type", C.c_int)]
+
+
+class KkamdError(RuntimeError):
+    """Non-zero kkamd_status.  .status holds the code; the C++ shim maps INVALID_ARG/HIP to
+    std::runtime_error and STATE to std::invalid_argument like the reference."""
+
+    def __init__(self, status, msg):
+        super().__init__("kkamd status %d: %s" % (status, msg))
+        self.status = status
+
+
+def bind(lib):
+    vp, i64, ci, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+    lib.kkamd_last_error.restype = C.c_char_p
+    lib.kkamd_version.restype = ci
+    lib.kkamd_device_info.argtypes = [C.c_char_p, ci, C.POINTER(ci), C.POINTER(ci)]
+    lib.kkamd_spmv_plan_create.argtypes = [C.POINTER(vp), C.POINTER(CrsDesc), ci, vp]
+    lib.kkamd_spmv_plan_destroy.argtypes = [vp]
+    lib.kkamd_spmv.argtypes = [vp, C.POINTER(CrsDesc), C.c_char, dbl, vp, dbl, vp, ci, vp]
+    lib.kkamd_spmv_mv.argtypes = [vp, C.POINTER(CrsDesc), C.c_char, dbl, vp, i64, i64, dbl, vp, i64, i64, i64, ci, vp]
+    lib.kkamd_spmv_plan_set.argtypes = [vp, C.c_char_p, ci]
+    lib.kkamd_set_default.argtypes = [C.c_char_p, ci]
+    lib.kkamd_spgemm_create.argtypes = [C.POINTER(vp)]
+    lib.kkamd_spgemm_destroy.argtypes = [vp]
+    lib.kkamd_spgemm_symbolic.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, ci, C.POINTER(i64), vp]
+    lib.kkamd_spgemm_numeric.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
+    lib.kkamd_spgemm_get.argtypes = [vp, ci, C.POINTER(i64)]
+    lib.kkamd_sort_crs.argtypes = [i64, vp, vp, vp, ci, ci, vp]
+    lib.kkamd_exclusive_scan.argtypes = [vp, i64, ci, vp]
+    lib.kkamd_gen_laplace.argtypes = [ci, ci, i64, i64, i64, vp, vp, vp, ci, ci, C.POINTER(i64), vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("kkamd_last_error",):
+            fn.restype = ci
+    return lib
+
+
+def check(lib, status):
+    if status != OK:
+        raise KkamdError(status, lib.kkamd_last_error().decode(errors="replace"))

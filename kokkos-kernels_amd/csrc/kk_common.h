@@ -1,0 +1,54 @@
+// kk_common.h -- shared host/device helpers of libkkamd (status + error text, launch geometry,
+// wave-level reductions).  gfx950 facts used here: 64-lane wavefronts, 256 CUs in 8 XCDs with the
+// dispatcher placing workgroup b on XCD b % 8 (speed only -- never relied on for correctness).
+#pragma once
+#include "kk_rt.h"
+#include "../../include/kkamd.h"
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <string>
+
+namespace kk {
+
+constexpr int kWave    = 64;
+constexpr int kNumXcd  = 8;
+constexpr int kBlock   = 256;   // 4 waves: one per SIMD of a CU
+
+inline std::string& last_error_ref() { static thread_local std::string e; return e; }
+inline int fail(int code, const char* fmt, ...) {
+  char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  last_error_ref() = buf; return code;
+}
+#define KK_HIP(expr)                                                                            \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return kk::fail(KKAMD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define KK_LAUNCH_CHECK() KK_HIP(hipGetLastError())
+
+inline hipStream_t to_hip(kkamd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Logical work-item id for physical workgroup `pid` out of `nwg`: each XCD (own 4 MiB L2) walks one
+// contiguous eighth of the logical range, so neighbouring logical tiles -- which share x-vector lines
+// and B rows -- hit the same L2.  Bijective for any nwg (the first nwg % 8 XCDs take one extra).
+__host__ __device__ __forceinline__ int64_t xcd_remap(int64_t pid, int64_t nwg) {
+  const int64_t q = nwg / kNumXcd, rem = nwg % kNumXcd;
+  const int64_t x = pid % kNumXcd, i = pid / kNumXcd;
+  return x * q + (x < rem ? x : rem) + i;
+}
+
+// sum across the `width` lanes (power of two, <= 64) of an aligned lane group; result in every lane.
+template <class T> __device__ __forceinline__ T group_sum(T v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <class T> struct scalar_tag;
+template <> struct scalar_tag<float>  { static constexpr int value = KKAMD_F32; };
+template <> struct scalar_tag<double> { static constexpr int value = KKAMD_F64; };
+
+}  // namespace kk

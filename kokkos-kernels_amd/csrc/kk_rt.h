@@ -1,0 +1,23 @@
+// kk_rt.h -- the one place the kernels' execution vocabulary comes from.
+// Product build (hipcc --offload-arch=gfx950): the HIP runtime.  There is no CPU path.
+// -DKK_EMU (tests/emu only): the fiber-based SIMT emulator used by `-m "not gpu"` logic tests.
+#pragma once
+#ifdef KK_EMU
+#include "kk_emu.h"
+#define KK_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  kk_emu::launch(dim3(grid), dim3(block), (size_t)(smem), [=]() { kernel(__VA_ARGS__); })
+#define KK_NT_LOAD(p) (*(p))
+#define KK_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(kk_emu::S().dyn_smem)
+#define KK_DEVICE_ONLY(...)
+#define KK_UNROLL
+#else
+#include <hip/hip_runtime.h>
+#define KK_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (size_t)(smem), stream, __VA_ARGS__)
+#define KK_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define KK_DYN_SMEM(T, name)                                            \
+  extern __shared__ __attribute__((aligned(16))) char kk_dyn_smem_[];   \
+  T* name = reinterpret_cast<T*>(kk_dyn_smem_)
+#define KK_DEVICE_ONLY(...) __VA_ARGS__
+#define KK_UNROLL _Pragma("unroll")
+#endif

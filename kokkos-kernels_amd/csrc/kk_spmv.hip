@@ -1,0 +1,646 @@
+// kk_spmv.hip -- CSR SpMV for gfx950 (MI355X), rank-1 and rank-2.
+//
+// What the reference does on a GPU (sparse/impl/KokkosSparse_spmv_impl.hpp:86-166,337-379): one
+// Kokkos "thread" of vl lanes per row, 256/vl rows per team, x gathered through the texture path, no
+// LDS.  For the 27-pt Laplacian that is 8 lanes x 4 strided trips per row and 843,750 tiny teams.
+//
+// What this file does instead (both memory-bound; roofline = HBM):
+//   spmv_stream_kernel  -- the planned path.  The nnz stream is cut into fixed TILE-sized pieces, one
+//       workgroup each, so col_idx/values are read with perfectly aligned, fully coalesced 16 B / 8 B
+//       per-lane loads no matter how rows fall; val*x[col] products are staged in LDS; rows are then
+//       reduced out of LDS by lane groups sized to the tile's row count (wave shuffles for the
+//       cross-lane part).  Rows that straddle tiles leave a head/tail partial in a carry array and a
+//       tiny fix-up kernel finishes them -- no fp64 atomics, no beta pre-pass over y
+//       (the reference's merge path needs both: sparse/impl/KokkosSparse_spmv_impl_merge.hpp:278-282).
+//       Workgroup -> tile mapping is XCD-aware so each XCD's 4 MiB L2 keeps its own window of x.
+//   spmv_vector_kernel  -- the no-analysis path (handle-less calls / SPMV_FAST_SETUP): LPR lanes per
+//       row, LPR chosen from nnz/row.
+//   spmv_transpose_kernel -- op(A) = A^T via fp64/fp32 hardware atomics after a beta pass (same
+//       structure as the reference's SPMV_Transpose_Functor, :36-84; "functional, not performant").
+//   spmv_mv_kernel      -- rank-2: A rows staged through LDS once per 16-column strip, one lane per
+//       right-hand side, X rows read as contiguous 128 B when X is row-major.
+#include "kk_common.h"
+#include <new>
+#include <cstring>
+
+namespace kk {
+
+struct SpmvTuning {
+  int kernel         = 0;  // 0 auto, 1 vector, 2 stream
+  int lanes_per_row  = 0;  // vector kernel, 0 = auto
+  int nnz_per_thread = 0;  // stream kernel: 4, 8 or 16 (0 = 8)
+  int xcd_remap      = 1;
+  int nontemporal    = 1;
+  int mv_kernel      = 0;  // reserved for rank-2 variants
+};
+static SpmvTuning g_spmv_default;
+
+}  // namespace kk
+
+struct kkamd_spmv_plan {
+  int64_t num_rows = 0, num_cols = 0, nnz = 0;
+  const void* row_map = nullptr;
+  int offset_type = 0, algorithm = 0;
+  kk::SpmvTuning tune;
+  int tile = 0;             // nnz per workgroup of the analysed tiling (0 = no stream analysis)
+  int64_t nblocks = 0;
+  int32_t* d_blk_row = nullptr;  // [nblocks+1] first row starting at or after b*tile
+  void* d_carry = nullptr;       // [2*nblocks] 8-byte slots: head partials, then tail partials
+};
+
+namespace kk {
+
+// ------------------------------------------------------------------------------------------------
+template <class YT> __global__ void scale_kernel(YT* __restrict__ y, int64_t n, int64_t s0, int64_t ncol, int64_t s1, YT beta) {
+  // y(i,j) at i*s0 + j*s1; beta == 0 writes exact zeros (KokkosBlas::scal semantics)
+  const int64_t total = n * ncol;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = g / ncol, j = g % ncol;
+    YT* p = y + i * s0 + j * s1;
+    *p = (beta == YT(0)) ? YT(0) : beta * (*p);
+  }
+}
+
+template <class YT> static int launch_scale(YT* y, int64_t n, int64_t s0, int64_t ncol, int64_t s1, YT beta, hipStream_t st) {
+  if (n * ncol == 0 || beta == YT(1)) return KKAMD_OK;
+  const int64_t nb = ceil_div(n * ncol, kBlock);
+  KK_LAUNCH((scale_kernel<YT>), (unsigned)(nb < 8192 ? nb : 8192), kBlock, 0, st, y, n, s0, ncol, s1, beta);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector kernel: LPR lanes cooperate on a row (K1 analogue).
+template <class OffT, class AT, class YT, int LPR>
+__global__ __launch_bounds__(kBlock) void spmv_vector_kernel(int64_t nrows, const OffT* __restrict__ row_map,
+                                                             const int32_t* __restrict__ entries,
+                                                             const AT* __restrict__ values, const YT* __restrict__ x,
+                                                             YT* __restrict__ y, YT alpha, YT beta, int remap) {
+  constexpr int RPB = kBlock / LPR;
+  const int64_t wg  = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t row = wg * RPB + threadIdx.x / LPR;
+  const int lane    = threadIdx.x % LPR;
+  YT sum            = YT(0);
+  if (row < nrows) {
+    const OffT s = row_map[row], e = row_map[row + 1];
+    for (OffT j = s + lane; j < e; j += LPR) sum += (YT)values[j] * x[entries[j]];
+  }
+  sum = group_sum(sum, LPR);
+  if (row < nrows && lane == 0) {
+    sum *= alpha;
+    y[row] = (beta == YT(0)) ? sum : beta * y[row] + sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan analysis: blk_row[b] = first row whose start offset is >= b*tile (lower bound over row_map).
+template <class OffT>
+__global__ void spmv_plan_kernel(int64_t nrows, const OffT* __restrict__ row_map, int64_t nblocks, int64_t tile,
+                                 int32_t* __restrict__ blk_row) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nblocks) return;
+  if (b == nblocks) { blk_row[b] = (int32_t)nrows; return; }
+  const int64_t target = b * tile;
+  int64_t lo = 0, hi = nrows + 1;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)row_map[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  blk_row[b] = (int32_t)lo;
+}
+
+// native 2-element vectors (accepted by __builtin_nontemporal_load; same syntax under clang and gcc)
+typedef double kk_f64x2 __attribute__((vector_size(16)));
+typedef float  kk_f32x2 __attribute__((vector_size(8)));
+typedef int    kk_i32x2 __attribute__((vector_size(8)));
+template <class T> struct vec2;
+template <> struct vec2<double> { using type = kk_f64x2; };
+template <> struct vec2<float>  { using type = kk_f32x2; };
+
+// stream kernel: workgroup b owns nnz [b*TILE, (b+1)*TILE).
+template <class OffT, class AT, class YT, int NPT, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(int64_t nnz, const OffT* __restrict__ row_map,
+                                                             const int32_t* __restrict__ entries,
+                                                             const AT* __restrict__ values, const YT* __restrict__ x,
+                                                             YT* __restrict__ y, YT alpha, YT beta,
+                                                             const int32_t* __restrict__ blk_row,
+                                                             YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
+                                                             int remap) {
+  constexpr int TILE  = kBlock * NPT;
+  constexpr int STEPS = NPT / 2;      // two consecutive nnz per lane per step: 16 B of fp64 values + 8 B of columns
+  constexpr int SPAN  = kBlock * 2;   // nnz covered by the workgroup per step
+  using AV = typename vec2<AT>::type;
+  __shared__ YT prod[TILE];
+
+  const int t     = threadIdx.x;
+  const int64_t b = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t s = b * TILE;
+  const int64_t e = (s + TILE < nnz) ? s + TILE : nnz;
+
+  // 1. issue every streaming load of the tile up front (all independent, all aligned)
+  AT v0[STEPS], v1[STEPS];
+  int c0[STEPS], c1[STEPS];
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t idx = s + (int64_t)k * SPAN + t * 2;
+    if (idx + 1 < e) {
+      const AV* vp   = reinterpret_cast<const AV*>(values + idx);
+      const kk_i32x2* cp = reinterpret_cast<const kk_i32x2*>(entries + idx);
+      const AV vv       = NT ? KK_NT_LOAD(vp) : *vp;
+      const kk_i32x2 cc = NT ? KK_NT_LOAD(cp) : *cp;
+      v0[k] = vv[0]; v1[k] = vv[1]; c0[k] = cc[0]; c1[k] = cc[1];
+    } else if (idx < e) {
+      v0[k] = values[idx]; c0[k] = entries[idx]; v1[k] = AT(0); c1[k] = c0[k];
+    } else {
+      v0[k] = v1[k] = AT(0); c0[k] = c1[k] = -1;
+    }
+  }
+  // 2. gather x (L2-resident window thanks to the XCD-contiguous tile order), multiply, stage in LDS
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const YT x0 = (c0[k] >= 0) ? x[c0[k]] : YT(0);
+    const YT x1 = (c1[k] >= 0) ? x[c1[k]] : YT(0);
+    const int li = k * SPAN + t * 2;
+    prod[li]     = (YT)v0[k] * x0;
+    prod[li + 1] = (YT)v1[k] * x1;
+  }
+  __syncthreads();
+
+  // 3. per-row reduction out of LDS.  "Virtual rows" of this tile: an optional head (the row that
+  //    started in an earlier tile) followed by the rows that start here; only the last may be cut.
+  const int64_t ra         = blk_row[b];
+  const int64_t rb         = blk_row[b + 1];
+  const int64_t first_start = (int64_t)row_map[ra];
+  const bool has_head      = first_start > s;
+  const int64_t nv         = (rb - ra) + (has_head ? 1 : 0);
+  int G = 1;
+  while (G < kWave && nv * (G * 2) <= kBlock) G *= 2;
+  const int lane = t & (G - 1), grp = t / G, ngrp = kBlock / G;
+  for (int64_t base = 0; base < nv; base += ngrp) {
+    const int64_t j  = base + grp;
+    const bool valid = j < nv;
+    YT sum           = YT(0);
+    int64_t r        = -1;
+    bool is_head = false, complete = false;
+    if (valid) {
+      const int64_t jj = has_head ? j - 1 : j;
+      int64_t seg_s, seg_e;
+      if (jj < 0) {
+        is_head = true; seg_s = s; seg_e = first_start < e ? first_start : e;
+      } else {
+        r                = ra + jj;
+        seg_s            = (int64_t)row_map[r];
+        const int64_t re = (int64_t)row_map[r + 1];
+        complete         = re <= e;
+        seg_e            = complete ? re : e;
+      }
+      for (int i = (int)(seg_s - s) + lane; i < (int)(seg_e - s); i += G) sum += prod[i];
+    }
+    sum = group_sum(sum, G);
+    if (valid && lane == 0) {
+      if (is_head) carry_head[b] = sum;
+      else if (!complete) carry_tail[b] = sum;
+      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
+    }
+  }
+}
+
+// finishes the rows cut by tile boundaries: thread b owns the row that starts in tile b and ends later.
+template <class OffT, class YT>
+__global__ void spmv_stream_fixup_kernel(int64_t nblocks, int64_t nnz, int64_t tile, const OffT* __restrict__ row_map,
+                                         const int32_t* __restrict__ blk_row, const YT* __restrict__ carry_head,
+                                         const YT* __restrict__ carry_tail, YT* __restrict__ y, YT alpha, YT beta) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const int64_t ra = blk_row[b], rb = blk_row[b + 1];
+  if (rb == ra) return;
+  const int64_t e  = ((b + 1) * tile < nnz) ? (b + 1) * tile : nnz;
+  const int64_t R  = rb - 1;
+  const int64_t re = (int64_t)row_map[R + 1];
+  if (re <= e) return;
+  YT total = carry_tail[b];
+  for (int64_t b2 = b + 1; b2 < nblocks && b2 * tile < re; ++b2) total += carry_head[b2];
+  total *= alpha;
+  y[R] = (beta == YT(0)) ? total : beta * y[R] + total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y += alpha * A^T x after y := beta*y; LPR lanes per row, hardware float atomics.
+template <class OffT, class AT, class YT, int LPR>
+__global__ __launch_bounds__(kBlock) void spmv_transpose_kernel(int64_t nrows, const OffT* __restrict__ row_map,
+                                                                const int32_t* __restrict__ entries,
+                                                                const AT* __restrict__ values,
+                                                                const YT* __restrict__ x, YT* __restrict__ y, YT alpha) {
+  constexpr int RPB = kBlock / LPR;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  const int lane    = threadIdx.x % LPR;
+  if (row >= nrows) return;
+  const YT xv  = alpha * x[row];
+  const OffT s = row_map[row], e = row_map[row + 1];
+  for (OffT j = s + lane; j < e; j += LPR) atomicAdd(&y[entries[j]], (YT)values[j] * xv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rank-2, no transpose.  A workgroup takes RPB = 256/SW consecutive rows; SW lanes (one per right-hand
+// side of the current strip) form a row group.  The rows' nnz range is contiguous in CSR, so the
+// workgroup streams it through LDS in CH-sized chunks with coalesced loads (A is read once per strip),
+// and each group walks its own row's part of the chunk: LDS broadcast of (val, col), then one
+// X(col, strip) access per lane -- a contiguous 8*SW bytes when X is row-major.
+template <class OffT, class AT, class YT, int SW>
+__global__ __launch_bounds__(kBlock) void spmv_mv_kernel(int64_t nrows, const OffT* __restrict__ row_map,
+                                                         const int32_t* __restrict__ entries,
+                                                         const AT* __restrict__ values, const YT* __restrict__ X,
+                                                         int64_t xs0, int64_t xs1, YT* __restrict__ Y, int64_t ys0,
+                                                         int64_t ys1, int64_t nvec, YT alpha, YT beta, int remap) {
+  constexpr int RPB = kBlock / SW;
+  constexpr int CH  = 2048;
+  __shared__ AT s_val[CH];
+  __shared__ int s_col[CH];
+  const int t        = threadIdx.x;
+  const int64_t wg   = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t row0 = wg * RPB;
+  const int64_t rowN = (row0 + RPB < nrows) ? row0 + RPB : nrows;
+  const int64_t row  = row0 + t / SW;
+  const int k        = t % SW;
+  const int64_t lo   = (int64_t)row_map[row0];
+  const int64_t hi   = (int64_t)row_map[rowN];
+  int64_t rs = 0, re = 0;
+  if (row < nrows) { rs = (int64_t)row_map[row]; re = (int64_t)row_map[row + 1]; }
+  for (int64_t kk = 0; kk < nvec; kk += SW) {
+    const bool col_ok = (kk + k) < nvec;
+    YT acc            = YT(0);
+    for (int64_t c = lo; c < hi; c += CH) {
+      const int64_t ce = (c + CH < hi) ? c + CH : hi;
+      __syncthreads();
+      for (int64_t i = c + t; i < ce; i += kBlock) { s_val[i - c] = values[i]; s_col[i - c] = entries[i]; }
+      __syncthreads();
+      if (col_ok) {
+        const int64_t a = rs > c ? rs : c, z = re < ce ? re : ce;
+        const YT* xp    = X + (kk + k) * xs1;
+        for (int64_t i = a; i < z; ++i) acc += (YT)s_val[i - c] * xp[(int64_t)s_col[i - c] * xs0];
+      }
+    }
+    if (col_ok && row < nrows) {
+      acc *= alpha;
+      YT* yp = Y + row * ys0 + (kk + k) * ys1;
+      *yp    = (beta == YT(0)) ? acc : beta * (*yp) + acc;
+    }
+  }
+}
+
+// rank-2 transpose: Y(col, k) += alpha * val * X(row, k) after Y := beta*Y (K6 analogue).
+template <class OffT, class AT, class YT>
+__global__ __launch_bounds__(kBlock) void spmv_mv_transpose_kernel(int64_t nrows, const OffT* __restrict__ row_map,
+                                                                   const int32_t* __restrict__ entries,
+                                                                   const AT* __restrict__ values,
+                                                                   const YT* __restrict__ X, int64_t xs0, int64_t xs1,
+                                                                   YT* __restrict__ Y, int64_t ys0, int64_t ys1,
+                                                                   int64_t nvec, YT alpha) {
+  constexpr int SW  = 16;
+  constexpr int RPB = kBlock / SW;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / SW;
+  const int k0      = threadIdx.x % SW;
+  if (row >= nrows) return;
+  const OffT s = row_map[row], e = row_map[row + 1];
+  for (int64_t k = k0; k < nvec; k += SW) {
+    const YT xv = alpha * X[row * xs0 + k * xs1];
+    for (OffT j = s; j < e; ++j) atomicAdd(&Y[(int64_t)entries[j] * ys0 + k * ys1], (YT)values[j] * xv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+static int pick_lpr(int64_t nrows, int64_t nnz, int forced) {
+  if (forced > 0) { int l = 1; while (l < forced && l < 64) l *= 2; return l; }
+  const int64_t avg = nrows > 0 ? nnz / nrows : 1;
+  int l = 1;
+  while (l < 64 && l * 2 <= avg) l *= 2;   // largest power of two <= nnz/row: one trip for most rows
+  return l;
+}
+
+template <class OffT, class AT, class YT, int LPR>
+static int launch_vector(const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, int remap, hipStream_t st) {
+  const int64_t nwg = ceil_div(A->num_rows, kBlock / LPR);
+  KK_LAUNCH((spmv_vector_kernel<OffT, AT, YT, LPR>), (unsigned)nwg, kBlock, 0, st, A->num_rows,
+            (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta, remap);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+template <class OffT, class AT, class YT>
+static int run_vector(const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, const SpmvTuning& tn, hipStream_t st) {
+  const int remap = tn.xcd_remap;
+  switch (pick_lpr(A->num_rows, A->nnz, tn.lanes_per_row)) {
+    case 1:  return launch_vector<OffT, AT, YT, 1>(A, x, y, alpha, beta, remap, st);
+    case 2:  return launch_vector<OffT, AT, YT, 2>(A, x, y, alpha, beta, remap, st);
+    case 4:  return launch_vector<OffT, AT, YT, 4>(A, x, y, alpha, beta, remap, st);
+    case 8:  return launch_vector<OffT, AT, YT, 8>(A, x, y, alpha, beta, remap, st);
+    case 16: return launch_vector<OffT, AT, YT, 16>(A, x, y, alpha, beta, remap, st);
+    case 32: return launch_vector<OffT, AT, YT, 32>(A, x, y, alpha, beta, remap, st);
+    default: return launch_vector<OffT, AT, YT, 64>(A, x, y, alpha, beta, remap, st);
+  }
+}
+
+template <class OffT, class AT, class YT, int NPT, bool NT>
+static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta,
+                         hipStream_t st) {
+  YT* ch = reinterpret_cast<YT*>(p->d_carry);
+  YT* ct = reinterpret_cast<YT*>(reinterpret_cast<char*>(p->d_carry) + 8 * p->nblocks);
+  KK_LAUNCH((spmv_stream_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+            (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+            (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
+  KK_LAUNCH_CHECK();
+  KK_LAUNCH((spmv_stream_fixup_kernel<OffT, YT>), (unsigned)ceil_div(p->nblocks, kBlock), kBlock, 0, st, p->nblocks,
+            A->nnz, (int64_t)p->tile, (const OffT*)A->d_row_map, (const int32_t*)p->d_blk_row, (const YT*)ch,
+            (const YT*)ct, y, alpha, beta);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+template <class OffT, class AT, class YT> struct StreamDispatch {
+  // sweep variants (tile size, non-temporal loads) exist for the fp64 headline type; others use 8 / NT
+  static int run(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, hipStream_t st) {
+    return launch_stream<OffT, AT, YT, 8, true>(p, A, x, y, alpha, beta, st);
+  }
+};
+template <class OffT> struct StreamDispatch<OffT, double, double> {
+  static int run(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const double* x, double* y, double alpha, double beta,
+                 hipStream_t st) {
+    const int npt = p->tile / kBlock;
+    const bool nt = p->tune.nontemporal != 0;
+    if (npt == 4)  return nt ? launch_stream<OffT, double, double, 4, true>(p, A, x, y, alpha, beta, st)
+                             : launch_stream<OffT, double, double, 4, false>(p, A, x, y, alpha, beta, st);
+    if (npt == 16) return nt ? launch_stream<OffT, double, double, 16, true>(p, A, x, y, alpha, beta, st)
+                             : launch_stream<OffT, double, double, 16, false>(p, A, x, y, alpha, beta, st);
+    return nt ? launch_stream<OffT, double, double, 8, true>(p, A, x, y, alpha, beta, st)
+              : launch_stream<OffT, double, double, 8, false>(p, A, x, y, alpha, beta, st);
+  }
+};
+
+template <class OffT, class AT, class YT>
+static int run_transpose(const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, hipStream_t st) {
+  int rc = launch_scale<YT>(y, A->num_cols, 1, 1, 1, beta, st);
+  if (rc) return rc;
+  const int64_t avg = A->nnz / A->num_rows;
+  if (avg >= 32) {
+    KK_LAUNCH((spmv_transpose_kernel<OffT, AT, YT, 32>), (unsigned)ceil_div(A->num_rows, kBlock / 32), kBlock, 0, st,
+              A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha);
+  } else if (avg >= 6) {
+    KK_LAUNCH((spmv_transpose_kernel<OffT, AT, YT, 8>), (unsigned)ceil_div(A->num_rows, kBlock / 8), kBlock, 0, st,
+              A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha);
+  } else {
+    KK_LAUNCH((spmv_transpose_kernel<OffT, AT, YT, 1>), (unsigned)ceil_div(A->num_rows, kBlock), kBlock, 0, st,
+              A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha);
+  }
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+static bool stream_usable(const kkamd_spmv_plan* p, const kkamd_crs_t* A, int elem_size) {
+  if (!p || p->tile == 0 || p->tune.kernel == 1) return false;
+  // aligned 2-element vector loads need 2*sizeof(value) / 8-byte alignment of the array bases
+  if (((uintptr_t)A->d_values % (uintptr_t)(2 * elem_size)) != 0 || ((uintptr_t)A->d_entries % 8) != 0) return false;
+  return true;
+}
+
+template <class OffT, class AT, class YT>
+static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dx,
+                      double beta_d, void* dy, hipStream_t st) {
+  const YT alpha = (YT)alpha_d, beta = (YT)beta_d;
+  const YT* x    = (const YT*)dx;
+  YT* y          = (YT*)dy;
+  if (trans) return run_transpose<OffT, AT, YT>(A, x, y, alpha, beta, st);
+  if (stream_usable(plan, A, (int)sizeof(AT))) return StreamDispatch<OffT, AT, YT>::run(plan, A, x, y, alpha, beta, st);
+  return run_vector<OffT, AT, YT>(A, x, y, alpha, beta, plan ? plan->tune : g_spmv_default, st);
+}
+
+template <class OffT, class AT, class YT, int SW>
+static int launch_mv(const kkamd_crs_t* A, const YT* X, int64_t xs0, int64_t xs1, YT* Y, int64_t ys0, int64_t ys1,
+                     int64_t nvec, YT alpha, YT beta, int remap, hipStream_t st) {
+  KK_LAUNCH((spmv_mv_kernel<OffT, AT, YT, SW>), (unsigned)ceil_div(A->num_rows, kBlock / SW), kBlock, 0, st,
+            A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1,
+            Y, ys0, ys1, nvec, alpha, beta, remap);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+template <class OffT, class AT, class YT>
+static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dX,
+                         int64_t xs0, int64_t xs1, double beta_d, void* dY, int64_t ys0, int64_t ys1, int64_t nvec,
+                         hipStream_t st) {
+  const YT alpha = (YT)alpha_d, beta = (YT)beta_d;
+  const YT* X    = (const YT*)dX;
+  YT* Y          = (YT*)dY;
+  const int remap = plan ? plan->tune.xcd_remap : g_spmv_default.xcd_remap;
+  if (trans) {
+    int rc = launch_scale<YT>(Y, A->num_cols, ys0, nvec, ys1, beta, st);
+    if (rc) return rc;
+    KK_LAUNCH((spmv_mv_transpose_kernel<OffT, AT, YT>), (unsigned)ceil_div(A->num_rows, kBlock / 16), kBlock, 0, st,
+              A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1,
+              Y, ys0, ys1, nvec, alpha);
+    KK_LAUNCH_CHECK();
+    return KKAMD_OK;
+  }
+  if (nvec >= 12) return launch_mv<OffT, AT, YT, 16>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
+  if (nvec >= 6)  return launch_mv<OffT, AT, YT, 8>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
+  if (nvec >= 3)  return launch_mv<OffT, AT, YT, 4>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
+  return launch_mv<OffT, AT, YT, 2>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
+}
+
+static int check_crs(const kkamd_crs_t* A) {
+  if (!A) return fail(KKAMD_ERR_INVALID_ARG, "kkamd: null matrix descriptor");
+  if (A->num_rows < 0 || A->num_cols < 0 || A->nnz < 0)
+    return fail(KKAMD_ERR_INVALID_ARG, "kkamd: negative matrix dimension");
+  if (A->num_rows > INT32_MAX || A->num_cols > INT32_MAX)
+    return fail(KKAMD_ERR_INVALID_ARG, "kkamd: dimensions exceed the int32 ordinal range");
+  if (A->offset_type != KKAMD_I32 && A->offset_type != KKAMD_I64)
+    return fail(KKAMD_ERR_INVALID_ARG, "kkamd: unknown offset_type %d", A->offset_type);
+  if (A->value_type != KKAMD_F32 && A->value_type != KKAMD_F64)
+    return fail(KKAMD_ERR_UNSUPPORTED, "kkamd: unsupported value_type %d", A->value_type);
+  if (A->offset_type == KKAMD_I32 && A->nnz > INT32_MAX)
+    return fail(KKAMD_ERR_INVALID_ARG, "kkamd: nnz does not fit 32-bit offsets");
+  if (A->num_rows > 0 && !A->d_row_map) return fail(KKAMD_ERR_INVALID_ARG, "kkamd: null row_map");
+  if (A->nnz > 0 && (!A->d_entries || !A->d_values)) return fail(KKAMD_ERR_INVALID_ARG, "kkamd: null entries/values");
+  return KKAMD_OK;
+}
+
+static int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
+  if (!p) return KKAMD_OK;
+  if (p->num_rows != A->num_rows || p->num_cols != A->num_cols || p->nnz != A->nnz || p->row_map != A->d_row_map ||
+      p->offset_type != A->offset_type)
+    return fail(KKAMD_ERR_STATE, "kkamd_spmv: plan was created for a different matrix (a handle is bound to one matrix)");
+  return KKAMD_OK;
+}
+
+static int parse_mode(char mode, bool* trans) {
+  switch (mode) {
+    case 'N': case 'n': case 'C': case 'c': *trans = false; return KKAMD_OK;
+    case 'T': case 't': case 'H': case 'h': *trans = true; return KKAMD_OK;
+    default: return fail(KKAMD_ERR_INVALID_ARG, "Invalid transpose mode %c for KokkosSparse::spmv()", mode);
+  }
+}
+
+#define KK_DISPATCH_TYPES(FN, ...)                                                                        \
+  do {                                                                                                    \
+    const bool o64 = A->offset_type == KKAMD_I64;                                                         \
+    if (A->value_type == KKAMD_F64 && vector_type == KKAMD_F64)                                           \
+      return o64 ? FN<int64_t, double, double>(__VA_ARGS__) : FN<int32_t, double, double>(__VA_ARGS__);   \
+    if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F32)                                           \
+      return o64 ? FN<int64_t, float, float>(__VA_ARGS__) : FN<int32_t, float, float>(__VA_ARGS__);       \
+    if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F64)                                           \
+      return o64 ? FN<int64_t, float, double>(__VA_ARGS__) : FN<int32_t, float, double>(__VA_ARGS__);     \
+    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv: unsupported (value,vector) type pair (%d,%d)",        \
+                A->value_type, vector_type);                                                              \
+  } while (0)
+
+static int set_tuning(SpmvTuning& t, const char* key, int value) {
+  if (!key) return fail(KKAMD_ERR_INVALID_ARG, "null key");
+  const std::string k(key);
+  if (k == "kernel") t.kernel = value;
+  else if (k == "lanes_per_row") t.lanes_per_row = value;
+  else if (k == "nnz_per_thread") t.nnz_per_thread = value;
+  else if (k == "xcd_remap") t.xcd_remap = value;
+  else if (k == "nontemporal") t.nontemporal = value;
+  else if (k == "mv_kernel") t.mv_kernel = value;
+  else return fail(KKAMD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
+  return KKAMD_OK;
+}
+
+template <class OffT>
+static int analyse(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
+  KK_LAUNCH((spmv_plan_kernel<OffT>), (unsigned)ceil_div(p->nblocks + 1, kBlock), kBlock, 0, st, A->num_rows,
+            (const OffT*)A->d_row_map, p->nblocks, (int64_t)p->tile, p->d_blk_row);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
+  if (p->d_blk_row) { KK_HIP(hipStreamSynchronize(st)); KK_HIP(hipFree(p->d_blk_row)); p->d_blk_row = nullptr; }
+  if (p->d_carry) { KK_HIP(hipFree(p->d_carry)); p->d_carry = nullptr; }
+  p->tile = 0; p->nblocks = 0;
+  if (p->algorithm == KKAMD_SPMV_FAST_SETUP || p->tune.kernel == 1 || A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
+  int npt = p->tune.nnz_per_thread;
+  if (npt != 4 && npt != 8 && npt != 16) npt = 8;
+  if (!(A->value_type == KKAMD_F64)) npt = 8;
+  p->tile    = kBlock * npt;
+  p->nblocks = ceil_div(A->nnz, p->tile);
+  KK_HIP(hipMalloc((void**)&p->d_blk_row, sizeof(int32_t) * (size_t)(p->nblocks + 1)));
+  KK_HIP(hipMalloc(&p->d_carry, (size_t)16 * (size_t)p->nblocks));
+  const int rc = A->offset_type == KKAMD_I64 ? analyse<int64_t>(p, A, st) : analyse<int32_t>(p, A, st);
+  if (rc) return rc;
+  KK_HIP(hipStreamSynchronize(st));   // setup is synchronous, like the vendor analysis it replaces
+  return KKAMD_OK;
+}
+
+}  // namespace kk
+
+// ================================================================================================
+extern "C" {
+
+const char* kkamd_last_error(void) { return kk::last_error_ref().c_str(); }
+int kkamd_version(void) { return KKAMD_VERSION; }
+
+int kkamd_device_info(char* name, int name_len, int* is_gfx950, int* num_cus) {
+  int dev = 0;
+  KK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  KK_HIP(hipGetDeviceProperties(&prop, dev));
+  if (name && name_len > 0) { snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+  if (is_gfx950) *is_gfx950 = (strncmp(prop.gcnArchName, "gfx950", 6) == 0);
+  if (num_cus) *num_cus = prop.multiProcessorCount;
+  return KKAMD_OK;
+}
+
+int kkamd_set_default(const char* key, int value) { return kk::set_tuning(kk::g_spmv_default, key, value); }
+
+int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int algorithm, kkamd_stream_t stream) {
+  if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_create: null output pointer");
+  *plan = nullptr;
+  int rc = kk::check_crs(A);
+  if (rc) return rc;
+  if (algorithm < KKAMD_SPMV_DEFAULT || algorithm > KKAMD_SPMV_NATIVE_MERGE_PATH)
+    return kk::fail(KKAMD_ERR_INVALID_ARG, "SPMVHandle: algorithm %d cannot be used if A is a CrsMatrix", algorithm);
+  kkamd_spmv_plan* p = new (std::nothrow) kkamd_spmv_plan();
+  if (!p) return kk::fail(KKAMD_ERR_ALLOC, "kkamd_spmv_plan_create: out of host memory");
+  p->num_rows = A->num_rows; p->num_cols = A->num_cols; p->nnz = A->nnz; p->row_map = A->d_row_map;
+  p->offset_type = A->offset_type; p->algorithm = algorithm; p->tune = kk::g_spmv_default;
+  rc = kk::build_analysis(p, A, kk::to_hip(stream));
+  if (rc) { kkamd_spmv_plan_destroy(p); return rc; }
+  *plan = p;
+  return KKAMD_OK;
+}
+
+int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
+  if (!plan) return KKAMD_OK;
+  // hipFree synchronises the device, so kernels still using the buffers have finished
+  // (the reference's rocSPARSE sub-handle relies on the same property, spmv_handle.hpp:148-152)
+  if (plan->d_blk_row) (void)hipFree(plan->d_blk_row);
+  if (plan->d_carry) (void)hipFree(plan->d_carry);
+  delete plan;
+  return KKAMD_OK;
+}
+
+int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
+  if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_set: null plan");
+  const int old_npt = plan->tune.nnz_per_thread, old_kernel = plan->tune.kernel;
+  int rc = kk::set_tuning(plan->tune, key, value);
+  if (rc) return rc;
+  if (plan->tune.nnz_per_thread != old_npt || plan->tune.kernel != old_kernel) {
+    // tiling changed: redo the analysis (needs the matrix again; rebuilt lazily from the stored row_map)
+    kkamd_crs_t A{};
+    A.num_rows = plan->num_rows; A.num_cols = plan->num_cols; A.nnz = plan->nnz; A.d_row_map = plan->row_map;
+    A.offset_type = plan->offset_type; A.value_type = KKAMD_F64;
+    return kk::build_analysis(plan, &A, nullptr);
+  }
+  return KKAMD_OK;
+}
+
+int kkamd_spmv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double alpha, const void* d_x, double beta,
+               void* d_y, int vector_type, kkamd_stream_t stream) {
+  int rc = kk::check_crs(A);
+  if (rc) return rc;
+  bool trans = false;
+  if ((rc = kk::parse_mode(mode, &trans))) return rc;
+  if ((rc = kk::check_plan(plan, A))) return rc;
+  if (vector_type != KKAMD_F32 && vector_type != KKAMD_F64)
+    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv: unsupported vector_type %d", vector_type);
+  hipStream_t st     = kk::to_hip(stream);
+  const int64_t ylen = trans ? A->num_cols : A->num_rows;
+  const int64_t xlen = trans ? A->num_rows : A->num_cols;
+  if (ylen > 0 && !d_y) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv: null y");
+  // alpha*op(A) == 0: only the y scaling happens (sparse/src/KokkosSparse_spmv.hpp:145-154)
+  if (alpha == 0.0 || A->num_rows == 0 || A->num_cols == 0 || A->nnz == 0) {
+    if (vector_type == KKAMD_F64) return kk::launch_scale<double>((double*)d_y, ylen, 1, 1, 1, beta, st);
+    return kk::launch_scale<float>((float*)d_y, ylen, 1, 1, 1, (float)beta, st);
+  }
+  if (xlen > 0 && !d_x) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv: null x");
+  KK_DISPATCH_TYPES(kk::spmv_typed, plan, A, trans, alpha, d_x, beta, d_y, st);
+}
+
+int kkamd_spmv_mv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double alpha, const void* d_X,
+                  int64_t x_stride0, int64_t x_stride1, double beta, void* d_Y, int64_t y_stride0, int64_t y_stride1,
+                  int64_t nvec, int vector_type, kkamd_stream_t stream) {
+  int rc = kk::check_crs(A);
+  if (rc) return rc;
+  bool trans = false;
+  if ((rc = kk::parse_mode(mode, &trans))) return rc;
+  if ((rc = kk::check_plan(plan, A))) return rc;
+  if (nvec < 0) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: negative number of vectors");
+  if (vector_type != KKAMD_F32 && vector_type != KKAMD_F64)
+    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv_mv: unsupported vector_type %d", vector_type);
+  hipStream_t st     = kk::to_hip(stream);
+  const int64_t ylen = trans ? A->num_cols : A->num_rows;
+  if (nvec == 0 || ylen == 0) return KKAMD_OK;
+  if (!d_Y) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: null Y");
+  if (alpha == 0.0 || A->num_rows == 0 || A->num_cols == 0 || A->nnz == 0) {
+    if (vector_type == KKAMD_F64) return kk::launch_scale<double>((double*)d_Y, ylen, y_stride0, nvec, y_stride1, beta, st);
+    return kk::launch_scale<float>((float*)d_Y, ylen, y_stride0, nvec, y_stride1, (float)beta, st);
+  }
+  if (!d_X) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: null X");
+  // one contiguous column: the rank-1 path (sparse/src/KokkosSparse_spmv.hpp:203-217)
+  if (nvec == 1 && x_stride0 == 1 && y_stride0 == 1) return kkamd_spmv(plan, A, mode, alpha, d_X, beta, d_Y, vector_type, stream);
+  KK_DISPATCH_TYPES(kk::spmv_mv_typed, plan, A, trans, alpha, d_X, x_stride0, x_stride1, beta, d_Y, y_stride0,
+                    y_stride1, nvec, st);
+}
+
+}  // extern "C"

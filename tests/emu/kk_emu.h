@@ -1,0 +1,247 @@
+// kk_emu.h -- TEST INFRASTRUCTURE: a tiny SIMT emulator so the kernel *logic* in
+// kokkos-kernels_amd/csrc/*.hip (index math, LDS layouts, carries, hash tables, scans) can be
+// exercised on the build container, which has no GPU.  It is never part of the product: the
+// product library (libkkamd.so) is built by hipcc for gfx950 only and has no CPU path; this header
+// is only reachable with -DKK_EMU from tests/emu/Makefile, producing tests/emu/libkkamd_emu.so,
+// which only `-m "not gpu"` tests named test_emu_* load.
+//
+// Model: one workgroup at a time; every work-item is a ucontext fiber; __syncthreads() and the
+// wave-level primitives (__shfl*, __ballot) are rendezvous points among the fibers of the block /
+// of a 64-lane wave.  Scheduling is round-robin and deterministic, so this checks logic, not races.
+// A rendezvous that can never complete (divergent barrier/shuffle) aborts with a message.
+#pragma once
+#include <ucontext.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <functional>
+#include <algorithm>
+
+// ---------------------------------------------------------------- HIP host API subset
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+typedef struct ihipStream_t* hipStream_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = *t = (size_t)8 << 30; return hipSuccess; }
+struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  std::strcpy(p->name, "kk_emu"); std::strcpy(p->gcnArchName, "emu"); p->multiProcessorCount = 4; return hipSuccess;
+}
+
+// ---------------------------------------------------------------- device-side vocabulary
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+#define __shared__ static
+#define KK_EMU_WAVE 64
+
+namespace kk_emu {
+struct Fiber { ucontext_t ctx; char* stack; bool done; };
+struct State {
+  ucontext_t main_ctx;
+  std::vector<Fiber> fibers;
+  std::vector<char*> stacks;
+  unsigned nthreads = 0, cur = 0;
+  // block barrier
+  unsigned long blk_gen = 0; unsigned blk_count = 0;
+  // wave rendezvous: per wave generation + count + exchange slots (16 bytes per lane)
+  std::vector<unsigned long> wave_gen; std::vector<unsigned> wave_count;
+  std::vector<unsigned char> slots;   // nthreads * 16
+  std::vector<unsigned char> pred;    // ballot predicate per lane
+  unsigned alive = 0;
+  unsigned long progress = 0;
+  std::function<void()> body;
+  dim3 grid, block, bidx;
+  char* dyn_smem = nullptr;
+};
+inline State& S() { static State s; return s; }
+inline unsigned tid_flat() { return S().cur; }
+
+inline void yield() { State& s = S(); swapcontext(&s.fibers[s.cur].ctx, &s.main_ctx); }
+inline unsigned wave_alive(unsigned w) {
+  State& s = S(); unsigned n = 0;
+  for (unsigned t = w * KK_EMU_WAVE; t < std::min(s.nthreads, (w + 1) * KK_EMU_WAVE); ++t) n += !s.fibers[t].done;
+  return n;
+}
+inline void sync_block() {
+  State& s = S(); unsigned long g = s.blk_gen;
+  if (++s.blk_count >= s.alive) { s.blk_count = 0; s.blk_gen++; s.progress++; return; }
+  while (s.blk_gen == g) yield();
+}
+inline void sync_wave() {
+  State& s = S(); unsigned w = s.cur / KK_EMU_WAVE; unsigned long g = s.wave_gen[w];
+  if (++s.wave_count[w] >= wave_alive(w)) { s.wave_count[w] = 0; s.wave_gen[w]++; s.progress++; return; }
+  while (s.wave_gen[w] == g) yield();
+}
+inline void trampoline() {
+  State& s = S();
+  s.body();
+  s.fibers[s.cur].done = true; s.alive--; s.progress++;
+  // a fiber leaving may complete a pending rendezvous of the others
+  if (s.alive && s.blk_count >= s.alive && s.blk_count) { s.blk_count = 0; s.blk_gen++; }
+  unsigned w = s.cur / KK_EMU_WAVE;
+  if (s.wave_count[w] && s.wave_count[w] >= wave_alive(w)) { s.wave_count[w] = 0; s.wave_gen[w]++; }
+  swapcontext(&s.fibers[s.cur].ctx, &s.main_ctx);
+}
+inline void run_block() {
+  State& s = S();
+  const size_t STK = 256 * 1024;
+  while (s.stacks.size() < s.nthreads) s.stacks.push_back((char*)std::malloc(STK));
+  s.fibers.assign(s.nthreads, Fiber());
+  unsigned nw = (s.nthreads + KK_EMU_WAVE - 1) / KK_EMU_WAVE;
+  s.wave_gen.assign(nw, 0); s.wave_count.assign(nw, 0);
+  s.slots.assign((size_t)s.nthreads * 16, 0); s.pred.assign(s.nthreads, 0);
+  s.blk_gen = 0; s.blk_count = 0; s.alive = s.nthreads;
+  for (unsigned t = 0; t < s.nthreads; ++t) {
+    Fiber& f = s.fibers[t]; f.done = false; f.stack = s.stacks[t];
+    getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STK; f.ctx.uc_link = &s.main_ctx;
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+  }
+  while (s.alive) {
+    unsigned long before = s.progress;
+    for (unsigned t = 0; t < s.nthreads; ++t) {
+      if (s.fibers[t].done) continue;
+      s.cur = t; swapcontext(&s.main_ctx, &s.fibers[t].ctx);
+    }
+    if (s.alive && s.progress == before) {
+      std::fprintf(stderr, "kk_emu: deadlock (divergent barrier/shuffle) in block (%u,%u)\n", s.bidx.x, s.bidx.y);
+      std::abort();
+    }
+  }
+}
+template <class F> inline void launch(dim3 grid, dim3 block, size_t smem, F f) {
+  State& s = S();
+  s.grid = grid; s.block = block; s.nthreads = block.x * block.y * block.z;
+  std::vector<char> dyn(smem + 16); s.dyn_smem = dyn.data();
+  s.body = f;
+  for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+    s.bidx = dim3(bx, by, bz); run_block();
+  }
+}
+struct TidProxy { struct C { operator unsigned() const; int which; }; };
+}  // namespace kk_emu
+
+struct kk_emu_tid {
+  struct X { operator unsigned() const { auto& s = kk_emu::S(); return s.cur % s.block.x; } } x;
+  struct Y { operator unsigned() const { auto& s = kk_emu::S(); return (s.cur / s.block.x) % s.block.y; } } y;
+  struct Z { operator unsigned() const { auto& s = kk_emu::S(); return s.cur / (s.block.x * s.block.y); } } z;
+};
+struct kk_emu_bid {
+  struct X { operator unsigned() const { return kk_emu::S().bidx.x; } } x;
+  struct Y { operator unsigned() const { return kk_emu::S().bidx.y; } } y;
+  struct Z { operator unsigned() const { return kk_emu::S().bidx.z; } } z;
+};
+struct kk_emu_bdim {
+  struct X { operator unsigned() const { return kk_emu::S().block.x; } } x;
+  struct Y { operator unsigned() const { return kk_emu::S().block.y; } } y;
+  struct Z { operator unsigned() const { return kk_emu::S().block.z; } } z;
+};
+struct kk_emu_gdim {
+  struct X { operator unsigned() const { return kk_emu::S().grid.x; } } x;
+  struct Y { operator unsigned() const { return kk_emu::S().grid.y; } } y;
+  struct Z { operator unsigned() const { return kk_emu::S().grid.z; } } z;
+};
+static kk_emu_tid threadIdx; static kk_emu_bid blockIdx; static kk_emu_bdim blockDim; static kk_emu_gdim gridDim;
+static const int warpSize = 64;
+
+inline void __syncthreads() { kk_emu::sync_block(); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+namespace kk_emu {
+template <class T> inline T exchange(T v, int src_lane_in_wave) {
+  static_assert(sizeof(T) <= 16, "shuffle payload too large");
+  State& s = S(); unsigned me = s.cur, w = me / KK_EMU_WAVE;
+  std::memcpy(&s.slots[(size_t)me * 16], &v, sizeof(T));
+  sync_wave();
+  unsigned src = w * KK_EMU_WAVE + (unsigned)src_lane_in_wave;
+  T out = v;
+  if (src_lane_in_wave >= 0 && src_lane_in_wave < KK_EMU_WAVE && src < s.nthreads && !s.fibers[src].done)
+    std::memcpy(&out, &s.slots[(size_t)src * 16], sizeof(T));
+  sync_wave();
+  return out;
+}
+inline int lane() { return (int)(S().cur % KK_EMU_WAVE); }
+}  // namespace kk_emu
+
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+  int l = kk_emu::lane(); int base = l & ~(width - 1); return kk_emu::exchange(v, base + (src & (width - 1)));
+}
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
+  int l = kk_emu::lane(); int t = l ^ mask; int base = l & ~(width - 1);
+  return kk_emu::exchange(v, (t >= base && t < base + width) ? t : l);
+}
+template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
+  int l = kk_emu::lane(); int base = l & ~(width - 1); int t = l + (int)d;
+  return kk_emu::exchange(v, (t < base + width) ? t : l);
+}
+template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
+  int l = kk_emu::lane(); int base = l & ~(width - 1); int t = l - (int)d;
+  return kk_emu::exchange(v, (t >= base) ? t : l);
+}
+inline unsigned long long __ballot(int p) {
+  auto& s = kk_emu::S(); unsigned me = s.cur, w = me / KK_EMU_WAVE;
+  s.pred[me] = p ? 1 : 0; kk_emu::sync_wave();
+  unsigned long long m = 0;
+  for (unsigned t = w * KK_EMU_WAVE; t < std::min(s.nthreads, (w + 1) * KK_EMU_WAVE); ++t)
+    if (!s.fibers[t].done && s.pred[t]) m |= 1ull << (t % KK_EMU_WAVE);
+  kk_emu::sync_wave();
+  return m;
+}
+inline int __any(int p) { return __ballot(p) != 0; }
+inline int __all(int p) { auto& s = kk_emu::S(); unsigned w = s.cur / KK_EMU_WAVE; unsigned long long m = __ballot(p);
+  unsigned long long full = 0; for (unsigned t = w * KK_EMU_WAVE; t < std::min(s.nthreads, (w + 1) * KK_EMU_WAVE); ++t) if (!s.fibers[t].done) full |= 1ull << (t % 64);
+  return m == full; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+
+// atomics: fibers are sequential, plain read-modify-write is atomic here
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { auto o = *p; *p = o + v; return o; }
+template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+
+// vector types used by the kernels
+struct alignas(16) double2 { double x, y; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) float4 { float x, y, z, w; };
+inline double2 make_double2(double a, double b) { return double2{a, b}; }
+inline float2 make_float2(float a, float b) { return float2{a, b}; }
+inline int2 make_int2(int a, int b) { return int2{a, b}; }
+
+inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
+inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
+inline float __int_as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
+inline int __float_as_int(float f) { int v; std::memcpy(&v, &f, 4); return v; }
+inline double fma(double a, double b, double c, int) { return a * b + c; }

@@ -1,0 +1,152 @@
+"""Parity checks shared by the emulator tests (CPU, small sizes) and the GPU tests (`-m gpu`, through
+the C ABI of libkkamd.so).  Every check compares the library under test with the CPU oracle on the same
+seeded inputs, with the reference's own comparators and tolerances:
+  SpMV   |expected - y| <= 10*eps*(beta*max_y + alpha*max_row*max_val*max_x), NaN mismatch fails
+         (sparse/unit_test/Test_Sparse_spmv.hpp:84-91,181,432)
+  SpGEMM row_map and entries IDENTICAL, values |a-b|/(|a|+|b|) <= 1e-7
+         (sparse/unit_test/Test_Sparse_Utils.hpp:39-127)
+"""
+import numpy as np
+
+import kk_loader
+import oracle
+
+kk = kk_loader.load()
+EPS_F = float(np.finfo(np.float32).eps)
+
+
+def dev(be, A0, offset_dtype=np.int32, value_dtype=None):
+    vals = A0.values if value_dtype is None else A0.values.astype(value_dtype)
+    return kk.CrsMatrix.from_host(A0.nrows, A0.ncols, A0.row_map, A0.entries, vals, offset_dtype=offset_dtype, backend=be)
+
+
+def fspmv_ok(expected, got, tol):
+    nan_mismatch = np.isnan(expected) ^ np.isnan(got)
+    err = np.abs(expected - got)
+    bad = nan_mismatch | (err > tol)
+    return not bad.any(), (float(np.nanmax(err)) if err.size else 0.0)
+
+
+def check_spmv(be, A0, mode="N", alpha=1.0, beta=0.0, algo=None, nans=False, seed=0, offset_dtype=np.int32,
+               max_val=1.0, knobs=None, value_dtype=None, vec_dtype=np.float64):
+    """one check_spmv() of the reference test (Test_Sparse_spmv.hpp:168-216)"""
+    rng = np.random.default_rng(seed)
+    trans = mode in "TH"
+    nin, nout = (A0.nrows, A0.ncols) if trans else (A0.ncols, A0.nrows)
+    x = rng.random(nin).astype(vec_dtype)
+    y0 = rng.random(nout).astype(vec_dtype)
+    if nans:
+        y0[::19] = np.nan
+    A = dev(be, A0, offset_dtype, value_dtype)
+    xd, yd = be.from_numpy(x), be.from_numpy(y0)
+    if algo is None:
+        kk.spmv(mode, alpha, A, xd, beta, yd)
+    else:
+        h = kk.SPMVHandle(algo)
+        for k_, v_ in (knobs or {}).items():
+            h.set(k_, v_)
+        kk.spmv(h, mode, alpha, A, xd, beta, yd)
+        kk.spmv(h, mode, alpha, A, xd, beta, yd) if beta == 0.0 else None   # handle reuse
+    got = be.to_numpy(yd).astype(np.float64)
+    Ao = A0 if value_dtype is None else oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, A0.values.astype(value_dtype))
+    if vec_dtype == np.float64:
+        exp = oracle.spmv_serial(mode, Ao, alpha, x, beta, y0.copy())
+        eps_scale = 1.0
+    else:
+        exp = oracle.spmv_serial(mode, Ao, alpha, x, beta, y0.copy()).astype(np.float64)
+        eps_scale = EPS_F / np.finfo(np.float64).eps
+    tol = oracle.spmv_max_error(A0, alpha, beta, max_val=max_val) * eps_scale
+    ok, err = fspmv_ok(exp, got, max(tol, 1e-300))
+    assert ok, "spmv mismatch mode=%s alpha=%g beta=%g algo=%s: max err %g > tol %g" % (mode, alpha, beta, algo, err, tol)
+
+
+def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_order="F", algo=None, seed=0):
+    rng = np.random.default_rng(seed)
+    trans = mode in "TH"
+    nin, nout = (A0.nrows, A0.ncols) if trans else (A0.ncols, A0.nrows)
+    X = np.asarray(rng.random((nin, nvec)), order=x_order)
+    Y0 = np.asarray(rng.random((nout, nvec)), order=y_order)
+    A = dev(be, A0)
+    Xd, Yd = _to_dev_2d(be, X), _to_dev_2d(be, Y0)
+    if algo is None:
+        kk.spmv(mode, alpha, A, Xd, beta, Yd)
+    else:
+        kk.spmv(kk.SPMVHandle(algo), mode, alpha, A, Xd, beta, Yd)
+    got = _to_host_2d(be, Yd)
+    exp = oracle.spmv_mv_serial(mode, A0, alpha, X, beta, Y0.copy(order="K"))
+    tol = oracle.spmv_max_error(A0, alpha, beta)
+    err = np.abs(exp - got).max() if got.size else 0.0
+    assert err <= max(tol, 1e-300), "spmv_mv mismatch nvec=%d mode=%s orders=%s%s: %g > %g" % (nvec, mode, x_order, y_order, err, tol)
+
+
+def _to_dev_2d(be, M):
+    """device 2-D array with the same logical layout (Fortran order kept through a transposed view)"""
+    if be.name == "emu":
+        return np.array(M, order="K", copy=True)
+    import torch
+    if M.flags.f_contiguous and not M.flags.c_contiguous:
+        return torch.from_numpy(np.ascontiguousarray(M.T)).to("cuda").t()
+    return torch.from_numpy(np.ascontiguousarray(M)).to("cuda")
+
+
+def _to_host_2d(be, M):
+    if be.name == "emu":
+        return np.asarray(M)
+    return M.detach().cpu().numpy()
+
+
+def check_spgemm(be, A0, B0, offset_dtype=np.int32, reuse=True, value_dtype=np.float64):
+    A, B = dev(be, A0, offset_dtype, value_dtype), dev(be, B0, offset_dtype, value_dtype)
+    kh = kk.KokkosKernelsHandle(be)
+    kh.create_spgemm_handle()
+    Cm = kk.spgemm_symbolic(kh, A, False, B, False)
+    Cgold = oracle.spgemm(A0, B0)
+    rmC = be.to_numpy(Cm.graph.row_map).astype(np.int64)
+    assert kh.get_spgemm_handle().get_c_nnz() == Cgold.nnz
+    assert np.array_equal(rmC, Cgold.row_map), "symbolic row_map differs"
+    kk.spgemm_numeric(kh, A, False, B, False, Cm)
+    rm, ent, val = Cm.to_host()
+    got = oracle.Crs(A0.nrows, B0.ncols, rm.astype(np.int64), ent, val.astype(np.float64))
+    eps = 1e-7 if value_dtype == np.float64 else 3.7e-3
+    if value_dtype != np.float64:
+        Ag = oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, A0.values.astype(np.float32).astype(np.float64))
+        Bg = oracle.Crs(B0.nrows, B0.ncols, B0.row_map, B0.entries, B0.values.astype(np.float32).astype(np.float64))
+        Cgold = oracle.spgemm(Ag, Bg)
+    ok, msg = oracle.is_same_matrix(got, Cgold, eps)
+    assert ok, "spgemm: " + msg
+    if reuse and A0.nnz and B0.nnz:
+        # numeric again with new values on the same handle (Test_Sparse_spgemm.hpp:243-252)
+        rng = np.random.default_rng(99)
+        A2 = oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, 1 + 49 * rng.random(A0.nnz))
+        Ad2 = kk.CrsMatrix(A0.nrows, A0.ncols, A.graph.row_map, A.graph.entries, be.from_numpy(A2.values.astype(value_dtype)), backend=be)
+        kk.spgemm_numeric(kh, Ad2, False, B, False, Cm)
+        rm, ent, val = Cm.to_host()
+        got = oracle.Crs(A0.nrows, B0.ncols, rm.astype(np.int64), ent, val.astype(np.float64))
+        if value_dtype != np.float64:
+            A2 = oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, A2.values.astype(np.float32).astype(np.float64))
+            Cg2 = oracle.spgemm(A2, Bg)
+        else:
+            Cg2 = oracle.spgemm(A2, B0)
+        ok, msg = oracle.is_same_matrix(got, Cg2, eps)
+        assert ok, "spgemm numeric reuse: " + msg
+    kh.destroy_spgemm_handle()
+    return got
+
+
+def randomized(A0, seed=5):
+    """values re-drawn in [1,50) as the reference's SpGEMM tests do (Test_Sparse_spgemm.hpp:62-72)"""
+    rng = np.random.default_rng(seed)
+    return oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, 1 + 49 * rng.random(A0.nnz))
+
+
+def hub_matrix(n, ncols, base_nnz, hubs, seed=0):
+    """sorted random matrix with a few very long rows: rows i in `hubs` get hubs[i] entries"""
+    rng = np.random.default_rng(seed)
+    lens = np.full(n, base_nnz)
+    for i, l in hubs.items():
+        lens[i] = l
+    rm = np.zeros(n + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    ent = np.empty(rm[-1], dtype=np.int32)
+    for i in range(n):
+        ent[rm[i]:rm[i + 1]] = np.sort(rng.choice(ncols, size=lens[i], replace=False))
+    return oracle.Crs(n, ncols, rm, ent, 1 + 49 * rng.random(rm[-1]))

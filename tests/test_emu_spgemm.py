@@ -1,0 +1,139 @@
+"""Kernel-LOGIC tests of the SpGEMM / scan / sort / generator kernels under the SIMT emulator (no GPU)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import parity_cases as pc
+from emu import emu_backend
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def be():
+    return emu_backend.backend()
+
+
+def test_exclusive_scan(be):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 255, 256, 257, 2048, 2049, 5000, 2048 * 3 + 17):
+        for dt, code in ((np.int32, 0), (np.int64, 1)):
+            a = rng.integers(0, 50, size=n).astype(dt)
+            ref = np.concatenate([[0], np.cumsum(a)[:-1]]).astype(dt)
+            d = a.copy()
+            pc.kk._capi.check(be.lib, be.lib.kkamd_exclusive_scan(d.ctypes.data, n, code, None))
+            assert np.array_equal(d, ref)
+    big = np.ones(2048 * 2048 + 5, dtype=np.int64)     # three-level scan
+    pc.kk._capi.check(be.lib, be.lib.kkamd_exclusive_scan(big.ctypes.data, len(big), 1, None))
+    assert np.array_equal(big, np.arange(len(big)))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "structured_*bc1.npz"))))
+def test_device_generators_match_reference(be, path):
+    g = np.load(path)
+    kind, stencil, dims, _ = os.path.basename(path)[len("structured_"):-4].split("_")
+    dims = [int(v) for v in dims.split("x")]
+    for odt in (np.int32, np.int64):
+        A = pc.kk.laplace_matrix(stencil.upper(), *dims, offset_dtype=odt, backend=be)
+        rm, ent, val = A.to_host()
+        assert np.array_equal(rm, g["row_map"]) and np.array_equal(ent, g["entries"]) and np.array_equal(val, g["values"])
+
+
+def test_sort_crs(be):
+    A0 = oracle.random_crs(300, 5000, 40, variance=39, seed=5)           # unsorted, with duplicate columns
+    long_row = oracle.random_crs(3, 100000, 3000, variance=2500, seed=6)
+    for M in (A0, long_row):
+        A = pc.dev(be, M)
+        pc.kk.sort_crs_matrix(A)
+        gold = oracle.Crs(M.nrows, M.ncols, M.row_map, M.entries.copy(), M.values.copy())
+        oracle.sort_crs(gold)
+        rm, ent, val = A.to_host()
+        assert np.array_equal(ent, gold.entries) and np.array_equal(val, gold.values)     # stable like the oracle
+
+
+@pytest.mark.parametrize("m,n,k,nnzA,nnzB", [
+    (0, 0, 0, 0, 0), (0, 12, 5, 0, 20), (10, 10, 0, 20, 0), (10, 0, 10, 0, 0),
+    (10, 10, 10, 0, 0), (10, 10, 10, 20, 0), (10, 10, 10, 0, 20)])
+def test_spgemm_degenerate(be, m, n, k, nnzA, nnzB):
+    # the seven empties of sparse/unit_test/Test_Sparse_spgemm.hpp:491-504
+    A0 = pc.randomized(oracle.random_crs(m, n, nnzA // m if m else 0, seed=1, sorted_rows=True))
+    B0 = pc.randomized(oracle.random_crs(n, k, nnzB // n if n else 0, seed=2, sorted_rows=True))
+    got = pc.check_spgemm(be, A0, B0)
+    assert got.nnz == 0
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64])
+def test_spgemm_random_shapes(be, odt):
+    # scaled-down versions of Test_Sparse_spgemm.hpp:485-490 (10000x8000x6000 @160k, 1000x500x1600)
+    A0 = pc.randomized(oracle.random_crs(400, 320, 16, variance=10, seed=3, sorted_rows=True))
+    B0 = pc.randomized(oracle.random_crs(320, 240, 20, variance=12, seed=4, sorted_rows=True))
+    pc.check_spgemm(be, A0, B0, offset_dtype=odt)
+    A1 = pc.randomized(oracle.random_crs(100, 50, 8, seed=5))            # unsorted inputs with duplicates are legal
+    B1 = pc.randomized(oracle.random_crs(50, 160, 30, seed=6))
+    pc.check_spgemm(be, A1, B1, offset_dtype=odt)
+
+
+def test_spgemm_float(be):
+    A0 = pc.randomized(oracle.random_crs(120, 100, 9, variance=4, seed=13, sorted_rows=True))
+    pc.check_spgemm(be, A0, pc.randomized(oracle.random_crs(100, 90, 7, seed=14, sorted_rows=True)), value_dtype=np.float32)
+
+
+def test_spgemm_all_bins(be):
+    # rows landing in every launch shape of both phases: flops 0 / <=256 / <=2048 / <=16384 / dense,
+    # and nnz(C row) <=256 / <=2048 / <=5461 / dense
+    B0 = pc.hub_matrix(64, 30000, 40, {0: 9000, 1: 3000, 2: 600, 3: 120, 5: 20000}, seed=1)
+    lens = {0: 1, 1: 1, 2: 1, 3: 2, 4: 0, 5: 1, 6: 3, 7: 30}
+    rng = np.random.default_rng(2)
+    rows = []
+    cols_for = {0: [0], 1: [1], 2: [2], 3: [3, 7], 4: [], 5: [5], 6: [0, 1, 5], 7: list(range(6, 36))}
+    rm = [0]; ent = []
+    for i in range(8):
+        ent += cols_for[i]; rm.append(len(ent))
+    A0 = oracle.Crs(8, 64, np.array(rm), np.array(ent, dtype=np.int32), 1 + 49 * rng.random(len(ent)))
+    got = pc.check_spgemm(be, A0, B0)
+    sizes = np.diff(got.row_map)
+    assert sizes[4] == 0 and sizes[3] <= 256 and 256 < sizes[2] <= 2048 and 2048 < sizes[1] <= 5461 and sizes[0] > 5461
+    assert sizes[6] > 20000        # union of three hub rows: dense path with overlapping columns
+
+
+def test_spgemm_issue402(be):
+    g = np.load(os.path.join(GOLD, "matrix_issue402.npz"))
+    A0 = oracle.Crs(1813, 1813, g["row_map"], g["entries"], g["values"])
+    At = oracle.transpose(A0)
+    oracle.sort_crs(A0); oracle.sort_crs(At)
+    sub = 300    # leading principal block keeps the emulator run short; the GPU test uses the full matrix
+    def head(M, r):
+        return oracle.Crs(r, M.ncols, M.row_map[:r + 1], M.entries[:M.row_map[r]], M.values[:M.row_map[r]])
+    pc.check_spgemm(be, head(A0, sub), At, reuse=False)
+
+
+def test_spgemm_handle_contract(be):
+    A0 = pc.randomized(oracle.random_crs(40, 30, 5, seed=7, sorted_rows=True))
+    B0 = pc.randomized(oracle.random_crs(30, 20, 4, seed=8, sorted_rows=True))
+    A, B = pc.dev(be, A0), pc.dev(be, B0)
+    kh = pc.kk.KokkosKernelsHandle(be)
+    with pytest.raises(ValueError, match="does not have an SpGEMM handle"):
+        pc.kk.spgemm_symbolic(kh, A, False, B, False)
+    kh.create_spgemm_handle()
+    with pytest.raises(RuntimeError, match="transposing"):
+        pc.kk.spgemm_symbolic(kh, A, True, B, False)
+    # numeric before symbolic (Test_Sparse_spgemm.hpp:444-481)
+    Cfake = pc.kk.CrsMatrix(40, 20, be.empty(41, np.int32), be.empty(1, np.int32), be.empty(1, np.float64), backend=be)
+    with pytest.raises(ValueError, match="must first call spgemm_symbolic"):
+        pc.kk.spgemm_numeric(kh, A, False, B, False, Cfake)
+    C1 = pc.kk.spgemm_symbolic(kh, A, False, B, False)
+    C2 = pc.kk.spgemm_symbolic(kh, A, False, B, False)          # repeated symbolic is idempotent (:315-370)
+    assert np.array_equal(be.to_numpy(C1.graph.row_map), oracle.spgemm_symbolic(A0, B0)[0])
+    assert C2.nnz() == C1.nnz()
+    assert kh.get_spgemm_handle().is_symbolic_called() and not kh.get_spgemm_handle().is_numeric_called()
+    pc.kk.spgemm_numeric(kh, A, False, B, False, C1)
+    assert kh.get_spgemm_handle().is_numeric_called()
+    kh.destroy_spgemm_handle()
+    Cn = pc.kk.spgemm(A, False, B, False)                        # no-reuse interface
+    ok, msg = oracle.is_same_matrix(oracle.Crs(40, 20, *[np.asarray(v) for v in Cn.to_host()]), oracle.spgemm(A0, B0))
+    assert ok, msg
+    with pytest.raises(RuntimeError, match="numCols"):
+        pc.kk.spgemm(A, False, A, False)

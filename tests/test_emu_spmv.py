@@ -1,0 +1,147 @@
+"""Kernel-LOGIC tests of the SpMV kernels under the SIMT emulator (tests/emu): the same .hip sources as
+the product, compiled for the CPU against kk_emu.h.  These run without a GPU; the GPU parity tests
+(test_gpu_*.py) exercise the real gfx950 build through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle
+import parity_cases as pc
+from emu import emu_backend
+
+
+@pytest.fixture(scope="module")
+def be():
+    return emu_backend.backend()
+
+
+ALGOS = [None, "SPMV_DEFAULT", "SPMV_FAST_SETUP", "SPMV_NATIVE", "SPMV_MERGE_PATH", "SPMV_NATIVE_MERGE_PATH"]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("mode", ["N", "C", "T", "H"])
+def test_spmv_algorithms_modes_alpha_beta(be, algo, mode):
+    # Test_Sparse_spmv.hpp:415-451 (heavy sweep) on a 1000-row matrix with 3..20 nnz/row
+    A0 = oracle.random_crs(700, 650, 11, variance=8, seed=1)
+    for alpha in (0.0, 1.0, -1.0, 2.5):
+        for beta in (0.0, 1.0, -1.0, 2.5):
+            pc.check_spmv(be, A0, mode, alpha, beta, algo)
+            if beta == 0.0:
+                pc.check_spmv(be, A0, mode, alpha, beta, algo, nans=True)
+
+
+@pytest.mark.parametrize("npt", [4, 8, 16])
+def test_stream_kernel_tilings(be, npt):
+    # rows short and long relative to the tile, nnz not a multiple of the tile, rows straddling tiles
+    for nnz_row, var, n in ((27, 0, 600), (3, 2, 4000), (300, 250, 90), (1, 0, 5000)):
+        A0 = oracle.random_crs(n, n + 13, nnz_row, variance=var, seed=npt + nnz_row)
+        pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs={"nnz_per_thread": npt})
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"nnz_per_thread": npt, "xcd_remap": 0, "nontemporal": 0})
+
+
+def _custom(lens, ncols, seed=0):
+    rng = np.random.default_rng(seed)
+    lens = np.asarray(lens)
+    rm = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    ent = rng.integers(0, ncols, size=rm[-1]).astype(np.int32)
+    return oracle.Crs(len(lens), ncols, rm, ent, rng.random(rm[-1]))
+
+
+@pytest.mark.parametrize("algo", ["SPMV_DEFAULT", "SPMV_FAST_SETUP"])
+def test_spmv_row_shapes(be, algo):
+    cases = {
+        "one_row_many_tiles": [9000],
+        "long_rows_span_tiles": [5000, 1, 0, 4100, 2048, 2048, 3],
+        "empty_rows_everywhere": [0, 0, 5, 0, 0, 0, 7, 0, 2047, 1, 0, 0],
+        "all_empty_but_one": [0] * 300 + [4] + [0] * 300,
+        "exact_tile_multiple": [1024, 1024, 2048, 0, 0],
+        "leading_trailing_empty": [0] * 50 + [30] * 200 + [0] * 70,
+        "single_entry": [1],
+    }
+    for name, lens in cases.items():
+        A0 = _custom(lens, 977, seed=len(lens))
+        for beta in (0.0, 2.0):
+            pc.check_spmv(be, A0, "N", -1.5, beta, algo, nans=(beta == 0.0))
+
+
+def test_spmv_int64_offsets_and_float(be):
+    A0 = oracle.random_crs(500, 480, 9, variance=5, seed=3)
+    pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_DEFAULT", offset_dtype=np.int64)
+    pc.check_spmv(be, A0, "T", 1.0, 1.0, None, offset_dtype=np.int64)
+    pc.check_spmv(be, A0, "N", 2.0, 0.5, "SPMV_DEFAULT", value_dtype=np.float32, vec_dtype=np.float32)
+    pc.check_spmv(be, A0, "N", 2.0, 0.5, None, value_dtype=np.float32, vec_dtype=np.float32)
+    pc.check_spmv(be, A0, "N", 2.0, 0.5, "SPMV_DEFAULT", value_dtype=np.float32)       # float matrix, double vectors
+
+
+def test_github_issue_101(be):
+    # Test_Sparse_spmv.hpp:823-961 -- exact known answer, rank-1 and 1..22 right-hand sides, double and mixed
+    expected = 1.0 + pc.EPS_F / 2.0
+    for vdt in (np.float64, np.float32):
+        A = pc.kk.CrsMatrix.from_host(1, 2, [0, 2], [0, 1], np.array([1.0, pc.EPS_F / 2.0], dtype=vdt), backend=be)
+        for h in (None, pc.kk.SPMVHandle("SPMV_DEFAULT")):
+            y = be.from_numpy(np.zeros(1))
+            args = ("N", 1.0, A, be.from_numpy(np.ones(2)), 0.0, y)
+            pc.kk.spmv(*args) if h is None else pc.kk.spmv(h, *args)
+            assert be.to_numpy(y)[0] == expected
+        for nv in range(1, 23):
+            X = np.ones((2, nv), order="F"); Y = np.zeros((1, nv), order="F")
+            pc.kk.spmv("N", 1.0, A, X, 0.0, Y)
+            assert (Y == expected).all()
+
+
+def test_wiki_example_and_structured(be):
+    A0 = oracle.laplace2d("FD", 10, 10, bc=(0, 0, 0, 0))
+    A = pc.dev(be, A0)
+    y = be.from_numpy(np.full(100, 2.0))
+    pc.kk.spmv("N", 1.0, A, be.from_numpy(np.ones(100)), 1.0, y)
+    assert (be.to_numpy(y) == 2.0).all()      # example/wiki/sparse/KokkosSparse_wiki_spmv.cpp:66-95
+    for A0 in (oracle.laplace2d("FD", 40, 30), oracle.laplace2d("FE", 25, 31), oracle.laplace3d("FD", 9, 8, 10),
+               oracle.laplace3d("FE", 11, 9, 8)):
+        for algo in ("SPMV_DEFAULT", "SPMV_FAST_SETUP"):
+            pc.check_spmv(be, A0, "N", 1.0, 1.0, algo, max_val=32.0)
+
+
+@pytest.mark.parametrize("orders", ["FF", "CC", "FC", "CF"])
+def test_spmv_mv_layouts(be, orders):
+    # Test_Sparse_spmv.hpp:1075-1092: layouts Left/Right/mixed, 1..30 vectors, incl. the 2x3 matrix
+    A0 = oracle.random_crs(260, 240, 8, variance=5, seed=7)
+    for nv in (1, 2, 3, 5, 8, 10, 16, 17, 30):
+        pc.check_spmv_mv(be, A0, nv, "N", 2.5, -1.0, orders[0], orders[1])
+    pc.check_spmv_mv(be, A0, 5, "T", 2.5, 0.0, orders[0], orders[1])
+    pc.check_spmv_mv(be, A0, 4, "N", 0.0, 2.0, orders[0], orders[1])
+    A23 = oracle.random_crs(2, 3, 2, seed=1)
+    for nv in (1, 4, 16):
+        pc.check_spmv_mv(be, A23, nv, "N", 1.0, 0.0, orders[0], orders[1], algo="SPMV_DEFAULT")
+
+
+def test_mv_long_rows_chunked_staging(be):
+    A0 = _custom([5000, 0, 3, 2500, 1, 1, 0, 40], 300, seed=4)     # rows longer than the 2048-entry LDS chunk
+    pc.check_spmv_mv(be, A0, 16, "N", 1.0, 1.0, "C", "C")
+    pc.check_spmv_mv(be, A0, 3, "N", 1.0, 0.0, "F", "F")
+
+
+def test_error_behaviour(be):
+    A0 = oracle.random_crs(20, 30, 3, seed=2)
+    A = pc.dev(be, A0)
+    with pytest.raises(RuntimeError, match="Dimensions do not match"):
+        pc.kk.spmv("N", 1.0, A, be.from_numpy(np.ones(29)), 0.0, be.from_numpy(np.ones(20)))
+    with pytest.raises(RuntimeError, match="Dimensions do not match \\(transpose\\)"):
+        pc.kk.spmv("T", 1.0, A, be.from_numpy(np.ones(30)), 0.0, be.from_numpy(np.ones(30)))
+    with pytest.raises(RuntimeError, match="Invalid transpose mode"):
+        pc.kk.spmv("X", 1.0, A, be.from_numpy(np.ones(30)), 0.0, be.from_numpy(np.ones(20)))
+    with pytest.raises(ValueError):
+        pc.kk.SPMVHandle("SPMV_BSR_TC")
+    # a handle is bound to one matrix for life (spmv_handle.hpp:273-277)
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT")
+    pc.kk.spmv(h, "N", 1.0, A, be.from_numpy(np.ones(30)), 0.0, be.from_numpy(np.ones(20)))
+    B = pc.dev(be, oracle.random_crs(20, 30, 4, seed=3))
+    with pytest.raises(pc.kk.KkamdError) as ei:
+        pc.kk.spmv(h, "N", 1.0, B, be.from_numpy(np.ones(30)), 0.0, be.from_numpy(np.ones(20)))
+    assert ei.value.status == pc.kk._capi.ERR_STATE
+
+
+def test_degenerate_dimensions(be):
+    for nrows, ncols, per in ((0, 0, 0), (0, 7, 0), (7, 0, 0), (9, 9, 0)):
+        A0 = oracle.random_crs(nrows, ncols, per, seed=1)
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, None, nans=True)
+        pc.check_spmv(be, A0, "N", 1.0, 2.0, "SPMV_DEFAULT")
+        pc.check_spmv(be, A0, "T", 1.0, 0.0, None, nans=True)
