@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement (BASELINE.json): CSR SpMV GFLOP/s + achieved HBM GB/s on the
+27-point 3-D FE Laplacian, fp64, 1/2/4/8 MI355X.
+
+  N = 1   workload C2: 300^3 grid (27,000,000 rows, 724,150,792 stored nnz), one planned SpMV per step.
+  N > 1   workload C5 family: 600 x 600 x (75*N) grid, 1-D row slabs of 75 z-planes (27,000,000 rows,
+          ~7.27e8 nnz) per GPU, so N = 8 is exactly the 600^3 case; a step = RCCL all-gather of the x shards
+          over xGMI + the local planned SpMV.  Per-GPU work is fixed: "scaling": "weak".
+
+Protocol (mirrors perf_test/sparse/KokkosSparse_kk_spmv.cpp:121-167): inputs generated in HBM, handle/plan
+creation outside the timed region, W warm-ups, then exactly K steps bracketed by barrier + device sync,
+max over ranks.  alpha = 1, beta = 0 (the driver's default), x/y = integers in [-20, 20) as fp64.
+GFLOP/s = 2 * stored nnz / t (stored zeros counted, like the reference's drivers).
+
+The JSON line also carries
+  roofline     algorithmic bytes of ONE local SpMV (nnz*12 + (rows+1)*4 + x touched*8 + rows*8)
+               / the SpMV's average duration measured with HIP events on the launch stream, vs 8 TB/s HBM3E;
+  cpu_baseline the OpenMP port of the reference's host SpMV (oracle/kk_oracle_omp.c) on a bounded sample
+               of the same workload, timed on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a plain copy reaches
+
+
+def cpu_baseline(sample_n=160, min_seconds=6.0):
+    """Reference host path (port) on a bounded sample: 27-pt FE Laplacian sample_n^3, all host cores."""
+    import numpy as np
+    import oracle
+    A = oracle.laplace3d("FE", sample_n, sample_n, sample_n)
+    rm32 = A.row_map.astype(np.int32)
+    rng = np.random.default_rng(17312837)
+    x = rng.integers(-20, 20, size=A.ncols).astype(np.float64)
+    y = np.zeros(A.nrows)
+    oracle.spmv_omp(rm32, A.entries, A.values, 1.0, x, 0.0, y)        # warm-up / first touch
+    t0 = time.perf_counter(); it = 0
+    while True:
+        oracle.spmv_omp(rm32, A.entries, A.values, 1.0, x, 0.0, y); it += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds and it >= 5:
+            break
+    gflops = 2.0 * A.nnz * it / el / 1e9
+    gbps = (A.nnz * 12 + (A.nrows + 1) * 4 + A.ncols * 8 + A.nrows * 8) * it / el / 1e9
+    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": oracle.omp_threads(), "kind": "port",
+            "sample": "27-pt FE Laplacian %d^3 (%d rows, %d nnz), fp64, OpenMP dynamic schedule (nnz > 1e7), %d iterations, %.1f algorithmic GB/s"
+                      % (sample_n, A.nrows, A.nnz, it, gbps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=0, help="override the grid edge (debug: smaller problem)")
+    ap.add_argument("--beta", type=float, default=0.0)
+    ap.add_argument("--algo", default="SPMV_DEFAULT")
+    ap.add_argument("--knob", action="append", default=[], help="key=value expert knob for the SpMV plan")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import kk_loader
+    kk = kk_loader.load()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload ---------------------------------------------------------------------------
+    if world == 1:
+        n = args.n or 300
+        nx = ny = nz = n
+        planes_per_rank = nz
+        workload = "spmv_crs_27pt_FE_laplacian_%d^3_fp64" % n
+    else:
+        n = args.n or 600
+        nx = ny = n
+        planes_per_rank = (args.n // 8) if args.n else 75
+        nz = planes_per_rank * world
+        workload = "spmv_crs_27pt_FE_laplacian_%dx%dx%d_fp64_row_slabs_%d_planes_per_gpu" % (nx, ny, nz, planes_per_rank)
+    rows_per_rank = nx * ny * planes_per_rank
+    nrows_global = nx * ny * nz
+    A = kk.laplace_matrix("FE", nx, ny, nz, rows=(rank * rows_per_rank, rows_per_rank))
+    nnz_local = A.nnz()
+    g = torch.Generator(device="cuda"); g.manual_seed(17312837 + rank)
+    x_shard = torch.randint(-20, 20, (rows_per_rank,), device="cuda", generator=g).double()
+    y_shard = torch.randint(-20, 20, (rows_per_rank,), device="cuda", generator=g).double()
+    alpha, beta = 1.0, args.beta
+
+    if world == 1:
+        handle = kk.SPMVHandle(args.algo)
+        for kv in args.knob:
+            k, v = kv.split("="); handle.set(k, int(v))
+        def spmv_only(): kk.spmv(handle, "N", alpha, A, x_shard, beta, y_shard)
+        def step(ev0, ev1):
+            ev0.record(); spmv_only(); ev1.record()
+    else:
+        from kokkos_kernels_amd.dist import DistSpmv
+        offsets = [r * rows_per_rank for r in range(world + 1)]
+        op = DistSpmv(A, offsets, rank, algo=args.algo)
+        for kv in args.knob:
+            k, v = kv.split("="); op.handle.set(k, int(v))
+        def step(ev0, ev1):
+            xf = op.gather_x(x_shard)
+            ev0.record(); kk.spmv(op.handle, "N", alpha, A, xf, beta, y_shard); ev1.record()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(args.warmup):
+        step(w0, w1)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(*evs[i])
+    barrier()
+    t1 = time.perf_counter()
+    ms_step = (t1 - t0) * 1e3 / args.steps
+    kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps      # local SpMV only (no all-gather)
+
+    nnz_total = torch.tensor([float(nnz_local)], device="cuda", dtype=torch.float64)
+    tmax = torch.tensor([ms_step, kern_ms], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(nnz_total, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    nnz_global = int(nnz_total.item()); ms_step, kern_ms = tmax.tolist()
+
+    # ---- sanity inside the bench: A*1 over the slab must be the row-sum vector (0 interior, 1 boundary) ----
+    ones = torch.ones(nrows_global, dtype=torch.float64, device="cuda")
+    chk = torch.empty(rows_per_rank, dtype=torch.float64, device="cuda")
+    kk.spmv(handle if world == 1 else op.handle, "N", 1.0, A, ones, 0.0, chk)
+    lens = A.graph.row_map[1:] - A.graph.row_map[:-1]
+    assert bool((chk[lens == 27] == 0).all()) and bool((chk[lens < 27] == 1).all()), "bench self-check failed"
+
+    # ---- roofline of the dominant kernel (local SpMV) -------------------------------------------
+    if world == 1:
+        x_touched = nrows_global
+    else:
+        lo = max(0, rank * planes_per_rank - 1); hi = min(nz, (rank + 1) * planes_per_rank + 1)
+        x_touched = (hi - lo) * nx * ny
+    alg_bytes = nnz_local * 12 + (rows_per_rank + 1) * 4 + x_touched * 8 + rows_per_rank * 8 + (rows_per_rank * 8 if beta != 0 else 0)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    gflops = 2.0 * nnz_global / (ms_step * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "SpMV GFLOP/s (CSR, 27-pt 3-D FE Laplacian, fp64)", "value": round(gflops, 2), "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "rows": nrows_global, "nnz": nnz_global, "rows_per_gpu": rows_per_rank,
+                       "alpha": alpha, "beta": beta, "offsets": "int32", "ordinals": "int32", "algorithm": args.algo,
+                       "partition": "1-D row slabs + all-gather(x) over RCCL" if world > 1 else "single GPU",
+                       "knobs": args.knob},
+            "achieved_hbm_GBps_per_gpu": round(achieved, 1),
+            "spmv_kernel_ms": round(kern_ms, 5),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "kk::spmv_stream_kernel (+ fix-up kernel), HIP events around the launch",
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,6 +153,11 @@ int kkamd_exclusive_scan(void* d_data, int64_t n, int offset_type, kkamd_stream_
  * filled (and *nnz returned), so the caller can size entries/values. */
 int kkamd_gen_laplace(int dim, int stencil, int64_t nx, int64_t ny, int64_t nz, void* d_row_map, int32_t* d_entries,
                       void* d_values, int offset_type, int value_type, int64_t* nnz, kkamd_stream_t stream);
+/* One contiguous row slab [row_begin, row_begin+row_count) of the same matrix: local row_map (starting
+ * at 0), GLOBAL column indices -- the per-GPU piece of the 1-D row partition. */
+int kkamd_gen_laplace_rows(int dim, int stencil, int64_t nx, int64_t ny, int64_t nz, int64_t row_begin,
+                           int64_t row_count, void* d_row_map, int32_t* d_entries, void* d_values, int offset_type,
+                           int value_type, int64_t* nnz, kkamd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,23 +24,27 @@ __host__ __device__ __forceinline__ int row_len(const Grid& g, int64_t i, int64_
 }
 
 template <class OffT>
-__global__ void laplace_len_kernel(Grid g, int64_t nrows, OffT* __restrict__ row_map) {
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= nrows; r += (int64_t)gridDim.x * blockDim.x) {
-    if (r == nrows) { row_map[r] = 0; continue; }
+__global__ void laplace_len_kernel(Grid g, int64_t row_begin, int64_t nrows, OffT* __restrict__ row_map) {
+  for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l <= nrows; l += (int64_t)gridDim.x * blockDim.x) {
+    if (l == nrows) { row_map[l] = 0; continue; }
+    const int64_t r = row_begin + l;
     const int64_t i = r % g.nx, j = (r / g.nx) % g.ny, k = r / (g.nx * g.ny);
-    row_map[r] = (OffT)row_len(g, i, j, k);
+    row_map[l] = (OffT)row_len(g, i, j, k);
   }
 }
 
 template <class OffT, class VT>
-__global__ void laplace_fill_kernel(Grid g, int64_t nrows, const OffT* __restrict__ row_map,
+__global__ void laplace_fill_kernel(Grid g, int64_t row_begin, int64_t nrows, const OffT* __restrict__ row_map,
                                     int32_t* __restrict__ entries, VT* __restrict__ values) {
+  // local row l of the slab is global grid row r = row_begin + l; row_map is local (starts at 0),
+  // column indices stay global (the 1-D row partition of the multi-GPU SpMV keeps global columns)
   const int64_t pl = g.nx * g.ny;
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < nrows; l += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = row_begin + l;
     const int64_t i = r % g.nx, j = (r / g.nx) % g.ny, k = r / pl;
     const bool boundary = (i == 0 || i == g.nx - 1 || j == 0 || j == g.ny - 1 ||
                            (g.dim == 3 && (k == 0 || k == g.nz - 1)));
-    const int64_t start = (int64_t)row_map[r];
+    const int64_t start = (int64_t)row_map[l];
     int64_t p = start;
     const int klo = (g.dim == 3) ? -1 : 0, khi = (g.dim == 3) ? 1 : 0;
     for (int dk = klo; dk <= khi; ++dk)
@@ -80,12 +84,12 @@ __global__ void laplace_fill_kernel(Grid g, int64_t nrows, const OffT* __restric
 }
 
 template <class OffT>
-static int gen_laplace_typed(const Grid& g, int64_t nrows, void* d_row_map, int32_t* d_entries, void* d_values,
-                             int value_type, int64_t* nnz, hipStream_t st) {
+static int gen_laplace_typed(const Grid& g, int64_t row_begin, int64_t nrows, void* d_row_map, int32_t* d_entries,
+                             void* d_values, int value_type, int64_t* nnz, hipStream_t st) {
   OffT* rm          = (OffT*)d_row_map;
   const int64_t nb  = ceil_div(nrows + 1, kBlock);
   const unsigned gr = (unsigned)(nb < 65536 ? nb : 65536);
-  KK_LAUNCH((laplace_len_kernel<OffT>), gr, kBlock, 0, st, g, nrows, rm);
+  KK_LAUNCH((laplace_len_kernel<OffT>), gr, kBlock, 0, st, g, row_begin, nrows, rm);
   KK_LAUNCH_CHECK();
   int rc = exclusive_scan_inplace<OffT>(rm, nrows + 1, st);
   if (rc) return rc;
@@ -96,9 +100,9 @@ static int gen_laplace_typed(const Grid& g, int64_t nrows, void* d_row_map, int3
   if (!d_entries) return KKAMD_OK;
   if (!d_values) return fail(KKAMD_ERR_INVALID_ARG, "kkamd_gen_laplace: entries given without values");
   if (value_type == KKAMD_F64) {
-    KK_LAUNCH((laplace_fill_kernel<OffT, double>), gr, kBlock, 0, st, g, nrows, (const OffT*)rm, d_entries, (double*)d_values);
+    KK_LAUNCH((laplace_fill_kernel<OffT, double>), gr, kBlock, 0, st, g, row_begin, nrows, (const OffT*)rm, d_entries, (double*)d_values);
   } else {
-    KK_LAUNCH((laplace_fill_kernel<OffT, float>), gr, kBlock, 0, st, g, nrows, (const OffT*)rm, d_entries, (float*)d_values);
+    KK_LAUNCH((laplace_fill_kernel<OffT, float>), gr, kBlock, 0, st, g, row_begin, nrows, (const OffT*)rm, d_entries, (float*)d_values);
   }
   KK_LAUNCH_CHECK();
   return KKAMD_OK;
@@ -213,8 +217,9 @@ int kkamd_sort_crs(int64_t num_rows, const void* d_row_map, int32_t* d_entries, 
   return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_sort_crs: unknown offset_type %d", offset_type);
 }
 
-int kkamd_gen_laplace(int dim, int stencil, int64_t nx, int64_t ny, int64_t nz, void* d_row_map, int32_t* d_entries,
-                      void* d_values, int offset_type, int value_type, int64_t* nnz, kkamd_stream_t stream) {
+int kkamd_gen_laplace_rows(int dim, int stencil, int64_t nx, int64_t ny, int64_t nz, int64_t row_begin, int64_t row_count,
+                           void* d_row_map, int32_t* d_entries, void* d_values, int offset_type, int value_type,
+                           int64_t* nnz, kkamd_stream_t stream) {
   if (dim != 2 && dim != 3) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_gen_laplace: dim must be 2 or 3");
   if (stencil != 0 && stencil != 1) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_gen_laplace: stencil must be 0 (FD) or 1 (FE)");
   if (dim == 2) nz = 1;
@@ -222,11 +227,19 @@ int kkamd_gen_laplace(int dim, int stencil, int64_t nx, int64_t ny, int64_t nz, 
     return kk::fail(KKAMD_ERR_INVALID_ARG, "You need at least two points per direction to obtain a valid discretization!");
   const int64_t nrows = nx * ny * nz;
   if (nrows > INT32_MAX) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_gen_laplace: grid exceeds the int32 ordinal range");
+  if (row_begin < 0 || row_count < 0 || row_begin + row_count > nrows)
+    return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_gen_laplace_rows: row range outside the grid");
   if (!d_row_map) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_gen_laplace: null row_map");
   kk::Grid g{nx, ny, nz, dim, stencil};
-  if (offset_type == KKAMD_I32) return kk::gen_laplace_typed<int32_t>(g, nrows, d_row_map, d_entries, d_values, value_type, nnz, kk::to_hip(stream));
-  if (offset_type == KKAMD_I64) return kk::gen_laplace_typed<int64_t>(g, nrows, d_row_map, d_entries, d_values, value_type, nnz, kk::to_hip(stream));
+  if (offset_type == KKAMD_I32) return kk::gen_laplace_typed<int32_t>(g, row_begin, row_count, d_row_map, d_entries, d_values, value_type, nnz, kk::to_hip(stream));
+  if (offset_type == KKAMD_I64) return kk::gen_laplace_typed<int64_t>(g, row_begin, row_count, d_row_map, d_entries, d_values, value_type, nnz, kk::to_hip(stream));
   return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_gen_laplace: unknown offset_type %d", offset_type);
+}
+
+int kkamd_gen_laplace(int dim, int stencil, int64_t nx, int64_t ny, int64_t nz, void* d_row_map, int32_t* d_entries,
+                      void* d_values, int offset_type, int value_type, int64_t* nnz, kkamd_stream_t stream) {
+  return kkamd_gen_laplace_rows(dim, stencil, nx, ny, nz, 0, nx * ny * (dim == 2 ? 1 : nz), d_row_map, d_entries, d_values,
+                                offset_type, value_type, nnz, stream);
 }
 
 }  // extern "C"

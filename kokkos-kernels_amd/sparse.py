@@ -313,21 +313,24 @@ def sort_crs_matrix(A):
     return A
 
 
-def laplace_matrix(stencil, nx, ny, nz=None, offset_dtype=np.int32, value_dtype=np.float64, backend=None):
+def laplace_matrix(stencil, nx, ny, nz=None, offset_dtype=np.int32, value_dtype=np.float64, backend=None, rows=None):
     """Structured Laplacian (every BC = 1) generated in place on the device; bit-identical to the
-    reference's generate_structured_matrix2D/3D (test_common/KokkosKernels_Test_Structured_Matrix.hpp)."""
+    reference's generate_structured_matrix2D/3D (test_common/KokkosKernels_Test_Structured_Matrix.hpp).
+    rows=(begin, count) builds only that row slab (local row_map, global columns)."""
     be = backend or torch_backend()
     lib = be.lib
     dim = 2 if nz is None else 3
     s = {"FD": 0, "FE": 1}[stencil]
     n = nx * ny * (nz or 1)
-    rm = be.empty(n + 1, offset_dtype)
+    r0, cnt = rows if rows is not None else (0, n)
+    rm = be.empty(cnt + 1, offset_dtype)
     nnz = C.c_int64()
     ot = I64 if np.dtype(offset_dtype) == np.dtype(np.int64) else I32
     vt = F64 if np.dtype(value_dtype) == np.dtype(np.float64) else F32
-    check(lib, lib.kkamd_gen_laplace(dim, s, nx, ny, nz or 1, be.ptr(rm), None, None, ot, vt, C.byref(nnz), be.stream()))
+    check(lib, lib.kkamd_gen_laplace_rows(dim, s, nx, ny, nz or 1, r0, cnt, be.ptr(rm), None, None, ot, vt, C.byref(nnz),
+                                          be.stream()))
     ent = be.empty(nnz.value, np.int32)
     val = be.empty(nnz.value, value_dtype)
-    check(lib, lib.kkamd_gen_laplace(dim, s, nx, ny, nz or 1, be.ptr(rm), be.ptr(ent), be.ptr(val), ot, vt,
-                                     C.byref(nnz), be.stream()))
-    return CrsMatrix(n, n, rm, ent, val, backend=be)
+    check(lib, lib.kkamd_gen_laplace_rows(dim, s, nx, ny, nz or 1, r0, cnt, be.ptr(rm), be.ptr(ent), be.ptr(val), ot, vt,
+                                          C.byref(nnz), be.stream()))
+    return CrsMatrix(cnt, n, rm, ent, val, backend=be)

@@ -1,0 +1,318 @@
+"""GPU parity tests (`-m gpu`): the gfx950 build of libkkamd.so, called through its C ABI, against the
+CPU oracle on the same seeded inputs; reference comparators and tolerances (see parity_cases.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def be():
+    import ctypes as C
+    b = pc.kk.torch_backend()
+    name = C.create_string_buffer(256); g = C.c_int(); cus = C.c_int()
+    pc.kk._capi.check(b.lib, b.lib.kkamd_device_info(name, 256, C.byref(g), C.byref(cus)))
+    print("device:", name.value.decode(), "CUs:", cus.value)
+    assert g.value == 1, "libkkamd.so is built for gfx950 only; found %s" % name.value.decode()
+    return b
+
+
+ALGOS = [None, "SPMV_DEFAULT", "SPMV_FAST_SETUP", "SPMV_NATIVE", "SPMV_MERGE_PATH", "SPMV_NATIVE_MERGE_PATH"]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_spmv_heavy(be, algo):
+    # Test_Sparse_spmv.hpp:1060-1068 "heavy": 1000 rows, 3..20 nnz/row, all modes, alpha/beta in {0,1,-1,2.5}
+    for nnz_row, var in ((3, 2), (10, 5), (20, 15)):
+        A0 = oracle.random_crs(1000, 1000, nnz_row, variance=var, seed=nnz_row)
+        for mode in ("N", "C", "T", "H"):
+            for alpha in (0.0, 1.0, -1.0, 2.5):
+                for beta in (0.0, 1.0, -1.0, 2.5):
+                    pc.check_spmv(be, A0, mode, alpha, beta, algo)
+                    if beta == 0.0:
+                        pc.check_spmv(be, A0, mode, alpha, beta, algo, nans=True)
+
+
+@pytest.mark.parametrize("algo", ["SPMV_DEFAULT", "SPMV_FAST_SETUP"])
+@pytest.mark.parametrize("n,nnz_row,var,bw", [(10000, 10, 5, 100), (50000, 10, 10, 500), (50000, 27, 0, None), (20000, 150, 140, None)])
+def test_spmv_light(be, algo, n, nnz_row, var, bw):
+    A0 = oracle.random_crs(n, n, nnz_row, variance=var, seed=n % 97, bandwidth=bw)
+    for mode in ("N", "T"):
+        for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (0.0, 1.0)):
+            pc.check_spmv(be, A0, mode, alpha, beta, algo, nans=(beta == 0.0))
+
+
+@pytest.mark.parametrize("npt", [4, 8, 16])
+@pytest.mark.parametrize("nt,remap", [(1, 1), (0, 0)])
+def test_stream_kernel_variants(be, npt, nt, remap):
+    for nnz_row, var, n in ((27, 0, 40000), (3, 2, 100000), (700, 650, 2000), (1, 0, 50000)):
+        A0 = oracle.random_crs(n, n + 13, nnz_row, variance=var, seed=npt + nnz_row)
+        knobs = {"nnz_per_thread": npt, "nontemporal": nt, "xcd_remap": remap}
+        pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=knobs)
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs=knobs)
+
+
+@pytest.mark.parametrize("lpr", [1, 2, 4, 8, 16, 32, 64])
+def test_vector_kernel_variants(be, lpr):
+    A0 = oracle.random_crs(30000, 29000, 27, variance=20, seed=lpr)
+    pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_FAST_SETUP", knobs={"lanes_per_row": lpr})
+
+
+def _custom(lens, ncols, seed=0):
+    rng = np.random.default_rng(seed)
+    lens = np.asarray(lens)
+    rm = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    ent = rng.integers(0, ncols, size=rm[-1]).astype(np.int32)
+    return oracle.Crs(len(lens), ncols, rm, ent, rng.random(rm[-1]))
+
+
+@pytest.mark.parametrize("algo", ["SPMV_DEFAULT", "SPMV_FAST_SETUP", None])
+def test_spmv_row_shapes(be, algo):
+    cases = {
+        "one_row_many_tiles": [200000],
+        "long_rows_span_tiles": [50000, 1, 0, 4100, 2048, 2048, 3, 100000],
+        "empty_rows_everywhere": [0, 0, 5, 0, 0, 0, 7, 0, 2047, 1, 0, 0] * 500,
+        "all_empty_but_one": [0] * 30000 + [4] + [0] * 30000,
+        "exact_tile_multiple": [1024, 1024, 2048, 0, 0] * 64,
+        "leading_trailing_empty": [0] * 5000 + [30] * 20000 + [0] * 7000,
+        "single_entry": [1],
+    }
+    for name, lens in cases.items():
+        A0 = _custom(lens, 9770, seed=len(lens))
+        for beta in (0.0, 2.0):
+            pc.check_spmv(be, A0, "N", -1.5, beta, algo, nans=(beta == 0.0))
+
+
+def test_spmv_types(be):
+    A0 = oracle.random_crs(20000, 19000, 12, variance=7, seed=3)
+    pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_DEFAULT", offset_dtype=np.int64)
+    pc.check_spmv(be, A0, "N", 1.0, 1.0, None, offset_dtype=np.int64)
+    pc.check_spmv(be, A0, "T", 1.0, 1.0, None, offset_dtype=np.int64)
+    pc.check_spmv(be, A0, "N", 2.0, 0.5, "SPMV_DEFAULT", value_dtype=np.float32, vec_dtype=np.float32)
+    pc.check_spmv(be, A0, "N", 2.0, 0.5, None, value_dtype=np.float32, vec_dtype=np.float32)
+    pc.check_spmv(be, A0, "N", 2.0, 0.5, "SPMV_DEFAULT", value_dtype=np.float32)
+
+
+def test_github_issue_101(be):
+    import torch
+    expected = 1.0 + pc.EPS_F / 2.0
+    for vdt in (np.float64, np.float32):
+        A = pc.kk.CrsMatrix.from_host(1, 2, [0, 2], [0, 1], np.array([1.0, pc.EPS_F / 2.0], dtype=vdt), backend=be)
+        for h in (None, pc.kk.SPMVHandle("SPMV_DEFAULT")):
+            y = torch.zeros(1, dtype=torch.float64, device="cuda")
+            args = ("N", 1.0, A, torch.ones(2, dtype=torch.float64, device="cuda"), 0.0, y)
+            pc.kk.spmv(*args) if h is None else pc.kk.spmv(h, *args)
+            assert y.item() == expected
+        for nv in range(1, 23):
+            for left in (True, False):
+                X = torch.ones((nv, 2) if left else (2, nv), dtype=torch.float64, device="cuda")
+                Y = torch.zeros((nv, 1) if left else (1, nv), dtype=torch.float64, device="cuda")
+                if left:
+                    X, Y = X.t(), Y.t()
+                pc.kk.spmv("N", 1.0, A, X, 0.0, Y)
+                assert (Y == expected).all().item()
+
+
+def test_wiki_example_and_structured(be):
+    import torch
+    A = pc.dev(be, oracle.laplace2d("FD", 10, 10, bc=(0, 0, 0, 0)))
+    y = torch.full((100,), 2.0, dtype=torch.float64, device="cuda")
+    pc.kk.spmv("N", 1.0, A, torch.ones(100, dtype=torch.float64, device="cuda"), 1.0, y)
+    assert (y == 2.0).all().item()
+    for A0 in (oracle.laplace2d("FD", 300, 200), oracle.laplace2d("FE", 250, 310), oracle.laplace3d("FD", 40, 30, 50),
+               oracle.laplace3d("FE", 41, 39, 38)):
+        for algo in ("SPMV_DEFAULT", "SPMV_FAST_SETUP"):
+            pc.check_spmv(be, A0, "N", 1.0, 1.0, algo, max_val=32.0)
+
+
+@pytest.mark.parametrize("orders", ["FF", "CC", "FC", "CF"])
+def test_spmv_mv_layouts(be, orders):
+    A0 = oracle.random_crs(6000, 5500, 10, variance=8, seed=7)
+    for nv in list(range(1, 31)):
+        pc.check_spmv_mv(be, A0, nv, "N", 2.5, -1.0, orders[0], orders[1])
+    for nv in (1, 5, 10):
+        pc.check_spmv_mv(be, A0, nv, "T", 2.5, 0.0, orders[0], orders[1])
+        pc.check_spmv_mv(be, A0, nv, "N", 0.0, 2.0, orders[0], orders[1])
+        pc.check_spmv_mv(be, A0, nv, "N", 1.0, 0.0, orders[0], orders[1], algo="SPMV_DEFAULT")
+    A23 = oracle.random_crs(2, 3, 2, seed=1)
+    for nv in (1, 4, 16):
+        pc.check_spmv_mv(be, A23, nv, "N", 1.0, 0.0, orders[0], orders[1])
+    long_rows = _custom([50000, 0, 3, 2500, 1, 1, 0, 40] * 3, 3000, seed=4)
+    pc.check_spmv_mv(be, long_rows, 16, "N", 1.0, 1.0, orders[0], orders[1])
+
+
+def test_error_behaviour(be):
+    import torch
+    A = pc.dev(be, oracle.random_crs(20, 30, 3, seed=2))
+    ones = lambda n: torch.ones(n, dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError, match="Dimensions do not match"):
+        pc.kk.spmv("N", 1.0, A, ones(29), 0.0, ones(20))
+    with pytest.raises(RuntimeError, match="Invalid transpose mode"):
+        pc.kk.spmv("X", 1.0, A, ones(30), 0.0, ones(20))
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT")
+    pc.kk.spmv(h, "N", 1.0, A, ones(30), 0.0, ones(20))
+    B = pc.dev(be, oracle.random_crs(20, 30, 4, seed=3))
+    with pytest.raises(pc.kk.KkamdError) as ei:
+        pc.kk.spmv(h, "N", 1.0, B, ones(30), 0.0, ones(20))
+    assert ei.value.status == pc.kk._capi.ERR_STATE
+
+
+def test_degenerate_dimensions(be):
+    for nrows, ncols, per in ((0, 0, 0), (0, 7, 0), (7, 0, 0), (9, 9, 0)):
+        A0 = oracle.random_crs(nrows, ncols, per, seed=1)
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, None, nans=True)
+        pc.check_spmv(be, A0, "N", 1.0, 2.0, "SPMV_DEFAULT")
+        pc.check_spmv(be, A0, "T", 1.0, 0.0, None, nans=True)
+
+
+# ------------------------------------------------------------------------------------------- utilities
+def test_exclusive_scan(be):
+    import torch
+    for n in (1, 255, 2049, 5_000_001):
+        for dt, code in ((torch.int32, 0), (torch.int64, 1)):
+            a = torch.randint(0, 50, (n,), dtype=dt, device="cuda")
+            ref = torch.cumsum(a, 0) - a
+            pc.kk._capi.check(be.lib, be.lib.kkamd_exclusive_scan(a.data_ptr(), n, code, be.stream()))
+            assert torch.equal(a, ref.to(dt))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "structured_*bc1.npz"))))
+def test_device_generators_match_reference(be, path):
+    g = np.load(path)
+    kind, stencil, dims, _ = os.path.basename(path)[len("structured_"):-4].split("_")
+    dims = [int(v) for v in dims.split("x")]
+    for odt in (np.int32, np.int64):
+        rm, ent, val = pc.kk.laplace_matrix(stencil.upper(), *dims, offset_dtype=odt).to_host()
+        assert np.array_equal(rm, g["row_map"]) and np.array_equal(ent, g["entries"]) and np.array_equal(val, g["values"])
+
+
+def test_device_generator_vs_oracle_medium(be):
+    for st, dims in (("FE", (37, 41, 29)), ("FD", (50, 20, 33)), ("FD", (301, 77)), ("FE", (64, 65))):
+        A0 = oracle.laplace3d(st, *dims) if len(dims) == 3 else oracle.laplace2d(st, *dims)
+        rm, ent, val = pc.kk.laplace_matrix(st, *dims).to_host()
+        assert np.array_equal(rm, A0.row_map) and np.array_equal(ent, A0.entries) and np.array_equal(val, A0.values)
+
+
+def test_sort_crs(be):
+    for M in (oracle.random_crs(3000, 50000, 40, variance=39, seed=5), oracle.random_crs(30, 1000000, 6000, variance=2000, seed=6)):
+        A = pc.dev(be, M)
+        pc.kk.sort_crs_matrix(A)
+        gold = oracle.Crs(M.nrows, M.ncols, M.row_map, M.entries.copy(), M.values.copy())
+        oracle.sort_crs(gold)
+        rm, ent, val = A.to_host()
+        assert np.array_equal(ent, gold.entries) and np.array_equal(val, gold.values)
+
+
+# ------------------------------------------------------------------------------------------- SpGEMM
+@pytest.mark.parametrize("m,n,k,nnzA,nnzB", [
+    (0, 0, 0, 0, 0), (0, 12, 5, 0, 20), (10, 10, 0, 20, 0), (10, 0, 10, 0, 0),
+    (10, 10, 10, 0, 0), (10, 10, 10, 20, 0), (10, 10, 10, 0, 20)])
+def test_spgemm_degenerate(be, m, n, k, nnzA, nnzB):
+    A0 = pc.randomized(oracle.random_crs(m, n, nnzA // m if m else 0, seed=1, sorted_rows=True))
+    B0 = pc.randomized(oracle.random_crs(n, k, nnzB // n if n else 0, seed=2, sorted_rows=True))
+    assert pc.check_spgemm(be, A0, B0).nnz == 0
+
+
+@pytest.mark.parametrize("odt", [np.int32, np.int64])
+def test_spgemm_reference_shapes(be, odt):
+    # Test_Sparse_spgemm.hpp:485-490: 10000 x 8000 x 6000 with 160k nnz each, and 1000 x 500 x 1600
+    A0 = pc.randomized(oracle.random_crs(10000, 8000, 16, variance=10, seed=3, sorted_rows=True))
+    B0 = pc.randomized(oracle.random_crs(8000, 6000, 20, variance=12, seed=4, sorted_rows=True))
+    pc.check_spgemm(be, A0, B0, offset_dtype=odt)
+    A1 = pc.randomized(oracle.random_crs(1000, 500, 16, seed=5))
+    B1 = pc.randomized(oracle.random_crs(500, 1600, 64, seed=6))
+    pc.check_spgemm(be, A1, B1, offset_dtype=odt)
+
+
+def test_spgemm_float_and_laplacian(be):
+    A0 = pc.randomized(oracle.random_crs(2000, 1800, 9, variance=4, seed=13, sorted_rows=True))
+    pc.check_spgemm(be, A0, pc.randomized(oracle.random_crs(1800, 900, 7, seed=14, sorted_rows=True)), value_dtype=np.float32)
+    L = pc.randomized(oracle.laplace3d("FE", 20, 19, 18))
+    pc.check_spgemm(be, L, L)                     # 27-pt squared: 125-pt rows
+    F = oracle.laplace2d("FD", 10, 10); E = oracle.laplace2d("FE", 10, 10)
+    pc.check_spgemm(be, F, E, reuse=False)        # example/wiki/sparse/KokkosSparse_wiki_spgemm.cpp:45-56
+
+
+def test_spgemm_all_bins(be):
+    B0 = pc.hub_matrix(64, 30000, 40, {0: 9000, 1: 3000, 2: 600, 3: 120, 5: 20000}, seed=1)
+    rng = np.random.default_rng(2)
+    cols_for = {0: [0], 1: [1], 2: [2], 3: [3, 7], 4: [], 5: [5], 6: [0, 1, 5], 7: list(range(6, 36))}
+    rm = [0]; ent = []
+    for i in range(8):
+        ent += cols_for[i]; rm.append(len(ent))
+    A0 = oracle.Crs(8, 64, np.array(rm), np.array(ent, dtype=np.int32), 1 + 49 * rng.random(len(ent)))
+    got = pc.check_spgemm(be, A0, B0)
+    sizes = np.diff(got.row_map)
+    assert sizes[4] == 0 and sizes[3] <= 256 and 256 < sizes[2] <= 2048 and 2048 < sizes[1] <= 5461 and sizes[0] > 5461
+
+
+def test_spgemm_rmat_square(be):
+    A0 = oracle.rmat(13, 8, seed=7)               # skewed: hub rows exercise the dense path on real structure
+    pc.check_spgemm(be, A0, A0)
+
+
+def test_spgemm_issue402(be):
+    g = np.load(os.path.join(GOLD, "matrix_issue402.npz"))
+    A0 = oracle.Crs(1813, 1813, g["row_map"], g["entries"], g["values"])
+    At = oracle.transpose(A0)
+    oracle.sort_crs(A0); oracle.sort_crs(At)
+    pc.check_spgemm(be, A0, At, reuse=False)      # Test_Sparse_spgemm.hpp:372-442
+
+
+def test_spgemm_handle_contract(be):
+    A0 = pc.randomized(oracle.random_crs(40, 30, 5, seed=7, sorted_rows=True))
+    B0 = pc.randomized(oracle.random_crs(30, 20, 4, seed=8, sorted_rows=True))
+    A, B = pc.dev(be, A0), pc.dev(be, B0)
+    kh = pc.kk.KokkosKernelsHandle(be)
+    with pytest.raises(ValueError, match="does not have an SpGEMM handle"):
+        pc.kk.spgemm_symbolic(kh, A, False, B, False)
+    kh.create_spgemm_handle()
+    Cfake = pc.kk.CrsMatrix(40, 20, be.empty(41, np.int32), be.empty(1, np.int32), be.empty(1, np.float64), backend=be)
+    with pytest.raises(ValueError, match="must first call spgemm_symbolic"):
+        pc.kk.spgemm_numeric(kh, A, False, B, False, Cfake)
+    C1 = pc.kk.spgemm_symbolic(kh, A, False, B, False)
+    C2 = pc.kk.spgemm_symbolic(kh, A, False, B, False)
+    assert np.array_equal(be.to_numpy(C1.graph.row_map), oracle.spgemm_symbolic(A0, B0)[0]) and C2.nnz() == C1.nnz()
+    pc.kk.spgemm_numeric(kh, A, False, B, False, C1)
+    kh.destroy_spgemm_handle()
+    Cn = pc.kk.spgemm(A, False, B, False)
+    ok, msg = oracle.is_same_matrix(oracle.Crs(40, 20, *[np.asarray(v) for v in Cn.to_host()]), oracle.spgemm(A0, B0))
+    assert ok, msg
+
+
+# ------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_27pt_properties(be):
+    """BASELINE config C2 (27-pt 300^3): size-independent checks -- nnz closed form, A*1 = row-sum vector
+    (interior rows 0, boundary rows 1), linearity, and agreement of the two kernels."""
+    import torch
+    n = 300
+    A = pc.kk.laplace_matrix("FE", n, n, n)
+    assert A.nnz() == 724_150_792 and A.numRows() == 27_000_000
+    ones = torch.ones(A.numCols(), dtype=torch.float64, device="cuda")
+    y = torch.full((A.numRows(),), float("nan"), dtype=torch.float64, device="cuda")
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT")
+    pc.kk.spmv(h, "N", 1.0, A, ones, 0.0, y)
+    lens = (A.graph.row_map[1:] - A.graph.row_map[:-1])
+    assert (y[lens == 27] == 0.0).all().item() and (y[lens < 27] == 1.0).all().item()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    x1 = torch.rand(A.numCols(), dtype=torch.float64, device="cuda", generator=g)
+    x2 = torch.rand(A.numCols(), dtype=torch.float64, device="cuda", generator=g)
+    y1 = torch.empty_like(y); y2 = torch.empty_like(y); y12 = torch.empty_like(y); yv = torch.empty_like(y)
+    pc.kk.spmv(h, "N", 1.0, A, x1, 0.0, y1)
+    pc.kk.spmv(h, "N", 1.0, A, x2, 0.0, y2)
+    pc.kk.spmv(h, "N", 1.0, A, x1 + 2.0 * x2, 0.0, y12)
+    tol = 10 * np.finfo(np.float64).eps * 27 * 32 * 3
+    assert (y12 - (y1 + 2.0 * y2)).abs().max().item() <= tol
+    pc.kk.spmv("N", 1.0, A, x1, 0.0, yv)                      # handle-less (vector kernel) vs planned (stream kernel)
+    assert (yv - y1).abs().max().item() <= tol
+    # beta path: y := 1*A*x + 1*y  ==  previous + y
+    yb = y2.clone()
+    pc.kk.spmv(h, "N", 1.0, A, x1, 1.0, yb)
+    assert (yb - (y1 + y2)).abs().max().item() <= tol
