@@ -159,6 +159,11 @@ int kkamd_gen_laplace_rows(int dim, int stencil, int64_t nx, int64_t ny, int64_t
                            int64_t row_count, void* d_row_map, int32_t* d_entries, void* d_values, int offset_type,
                            int value_type, int64_t* nnz, kkamd_stream_t stream);
 
+/* Device streaming-read microbenchmark (bench tooling): reads `bytes` from d_data with `loads` independent
+ * 16-byte loads in flight per lane; the measured HBM read ceiling quoted beside roofline fractions. */
+int kkamd_bench_read(const void* d_data, int64_t bytes, int loads, int nontemporal, int persistent, void* d_out,
+                     kkamd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

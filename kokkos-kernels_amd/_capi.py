@@ -11,7 +11,7 @@ EXPORTS = [
     "kkamd_last_error", "kkamd_version", "kkamd_device_info", "kkamd_spmv_plan_create", "kkamd_spmv_plan_destroy",
     "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_plan_set", "kkamd_set_default", "kkamd_spgemm_create",
     "kkamd_spgemm_destroy", "kkamd_spgemm_symbolic", "kkamd_spgemm_numeric", "kkamd_spgemm_get", "kkamd_sort_crs",
-    "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows",
+    "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows", "kkamd_bench_read",
 ]
 
 
@@ -49,6 +49,7 @@ def bind(lib):
     lib.kkamd_exclusive_scan.argtypes = [vp, i64, ci, vp]
     lib.kkamd_gen_laplace.argtypes = [ci, ci, i64, i64, i64, vp, vp, vp, ci, ci, C.POINTER(i64), vp]
     lib.kkamd_gen_laplace_rows.argtypes = [ci, ci, i64, i64, i64, i64, i64, vp, vp, vp, ci, ci, C.POINTER(i64), vp]
+    lib.kkamd_bench_read.argtypes = [vp, i64, ci, ci, ci, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("kkamd_last_error",):

@@ -28,10 +28,13 @@ namespace kk {
 struct SpmvTuning {
   int kernel         = 0;  // 0 auto, 1 vector, 2 stream
   int lanes_per_row  = 0;  // vector kernel, 0 = auto
-  int nnz_per_thread = 0;  // stream kernel: 4, 8 or 16 (0 = 8)
-  int xcd_remap      = 1;
-  int nontemporal    = 1;
+  int nnz_per_thread = 0;  // stream kernel: 4, 8 or 16 (0 = 16 for fp64, 8 otherwise)
+  int xcd_remap      = 0;  // measured: round-robin tile order (all XCDs sweep the same region) beats XCD-contiguous by ~3-8%
+  int nontemporal    = 0;  // measured: no consistent gain from nt loads on the value/column streams
   int mv_kernel      = 0;  // reserved for rank-2 variants
+  int stream_variant = 1;  // 1 lean kernel + quad-dealt gathers (default), 3 lean kernel natural layout, 0 first-generation, 2 wave-private
+  int wg_per_cu      = 0;  // unused (persistent variant measured slower and was removed)
+  int ablate         = 0;  // bench-only: 1 no x gather, 2 no LDS/reduce, 3 both
 };
 static SpmvTuning g_spmv_default;
 
@@ -44,6 +47,7 @@ struct kkamd_spmv_plan {
   kk::SpmvTuning tune;
   int tile = 0;             // nnz per workgroup of the analysed tiling (0 = no stream analysis)
   int64_t nblocks = 0;
+  int num_cus = 256;
   int32_t* d_blk_row = nullptr;  // [nblocks+1] first row starting at or after b*tile
   void* d_carry = nullptr;       // [2*nblocks] 8-byte slots: head partials, then tail partials
 };
@@ -106,7 +110,9 @@ __global__ void spmv_plan_kernel(int64_t nrows, const OffT* __restrict__ row_map
     const int64_t mid = (lo + hi) >> 1;
     if ((int64_t)row_map[mid] < target) lo = mid + 1; else hi = mid;
   }
-  blk_row[b] = (int32_t)lo;
+  // bit 31: the tile starts inside a row (row_map[lo] > target), i.e. it has a head segment
+  const bool head = (int64_t)row_map[lo] > target;
+  blk_row[b] = (int32_t)lo | (head ? (int32_t)0x80000000 : 0);
 }
 
 // native 2-element vectors (accepted by __builtin_nontemporal_load; same syntax under clang and gcc)
@@ -117,6 +123,101 @@ template <class T> struct vec2;
 template <> struct vec2<double> { using type = kk_f64x2; };
 template <> struct vec2<float>  { using type = kk_f32x2; };
 
+// Streaming loads of one tile into registers and staging of the val*x products in LDS.  FULL (the whole
+// tile lies inside [0, nnz): every tile but the last) is a workgroup-uniform property; its code path has
+// no per-lane guards, so all STEPS independent 16 B + 8 B loads are issued back to back and stay in
+// flight together (guarded loads made the compiler drain vmcnt between steps -- 4x fewer bytes in flight).
+template <class AT, int STEPS, bool NT, bool FULL>
+__device__ __forceinline__ void load_tile(const AT* __restrict__ values, const int32_t* __restrict__ entries, int64_t ts,
+                                          int64_t te, int t, AT (&v0)[STEPS], AT (&v1)[STEPS], int (&c0)[STEPS],
+                                          int (&c1)[STEPS]) {
+  using AV = typename vec2<AT>::type;
+  constexpr int SPAN = kBlock * 2;
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t idx = ts + (int64_t)k * SPAN + t * 2;
+    if (FULL || idx + 1 < te) {
+      const AV* vp       = reinterpret_cast<const AV*>(values + idx);
+      const kk_i32x2* cp = reinterpret_cast<const kk_i32x2*>(entries + idx);
+      const AV vv        = NT ? KK_NT_LOAD(vp) : *vp;
+      const kk_i32x2 cc  = NT ? KK_NT_LOAD(cp) : *cp;
+      v0[k] = vv[0]; v1[k] = vv[1]; c0[k] = cc[0]; c1[k] = cc[1];
+    } else if (idx < te) {
+      v0[k] = values[idx]; c0[k] = entries[idx]; v1[k] = AT(0); c1[k] = c0[k];
+    } else {
+      v0[k] = v1[k] = AT(0); c0[k] = c1[k] = -1;
+    }
+  }
+}
+
+// 32-bit halves of a scalar for lane permutes
+__device__ __forceinline__ int  bits_lo(double v) { return (int)(__double_as_longlong(v) & 0xffffffffll); }
+__device__ __forceinline__ int  bits_hi(double v) { return (int)(__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ double from_bits(int lo, int hi, double) { return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo); }
+__device__ __forceinline__ int  bits_lo(float v) { return __float_as_int(v); }
+__device__ __forceinline__ int  bits_hi(float) { return 0; }
+__device__ __forceinline__ float from_bits(int lo, int, float) { return __int_as_float(lo); }
+
+// value of nnz (8q + off + j) of the quad's eight consecutive nnz, delivered to lane 4q+j, given that lane
+// 4q+i holds nnz 8q+2i (a0) and 8q+2i+1 (a1).  ctrl = 0x50 (off 0: lanes 0,0,1,1) or 0xFA (off 4: lanes 2,2,3,3).
+template <int CTRL, class T> __device__ __forceinline__ T quad_pick(T a0, T a1, bool odd) {
+  // both permutes are executed by every lane (DPP reads the SOURCE lane's operand), then one is selected
+  const int l0 = KK_QUAD_PERM(bits_lo(a0), CTRL), l1 = KK_QUAD_PERM(bits_lo(a1), CTRL);
+  if (sizeof(T) == 8) {
+    const int h0 = KK_QUAD_PERM(bits_hi(a0), CTRL), h1 = KK_QUAD_PERM(bits_hi(a1), CTRL);
+    return from_bits(odd ? l1 : l0, odd ? h1 : h0, T());
+  }
+  return from_bits(odd ? l1 : l0, 0, T());
+}
+template <int CTRL> __device__ __forceinline__ int quad_pick_i(int a0, int a1, bool odd) {
+  const int p0 = KK_QUAD_PERM(a0, CTRL), p1 = KK_QUAD_PERM(a1, CTRL);
+  return odd ? p1 : p0;
+}
+
+// Stages val*x products of one tile in LDS.  The x gather is what saturates a CU here: the texture
+// addresser (TA/TCP) spends one cycle per DISTINCT cache line per 4-lane quad (rocprof: TA_BUSY ~ 100%,
+// TCP tag lookups ~ 1/cycle/CU, 3.2 lines per quad with the natural layout).  With QP the (value, column)
+// pairs are first re-dealt inside each quad with DPP moves so the four lanes of a quad gather four
+// CONSECUTIVE nnz -- columns of consecutive nnz cluster (27-pt: runs of three), ~2.0 lines per quad.
+template <class AT, class YT, int STEPS, bool FULL, bool QP>
+__device__ __forceinline__ void stage_products(const YT* __restrict__ x, YT* prod, int t, const AT (&v0)[STEPS],
+                                               const AT (&v1)[STEPS], const int (&c0)[STEPS], const int (&c1)[STEPS]) {
+  constexpr int SPAN = kBlock * 2;
+  if (FULL && QP) {
+    const bool odd = (t & 1) != 0;
+    const int j    = t & 3;
+    YT xa[STEPS], xb[STEPS];
+    AT va[STEPS], vb[STEPS];
+    KK_UNROLL
+    for (int k = 0; k < STEPS; ++k) {
+      const int ca = quad_pick_i<0x50>(c0[k], c1[k], odd);
+      const int cb = quad_pick_i<0xFA>(c0[k], c1[k], odd);
+      xa[k] = x[ca]; xb[k] = x[cb];
+      va[k] = quad_pick<0x50, AT>(v0[k], v1[k], odd);
+      vb[k] = quad_pick<0xFA, AT>(v0[k], v1[k], odd);
+    }
+    KK_UNROLL
+    for (int k = 0; k < STEPS; ++k) {
+      const int li = k * SPAN + t * 2 - j;      // = k*SPAN + 8*(t/4) + j
+      prod[li]     = (YT)va[k] * xa[k];
+      prod[li + 4] = (YT)vb[k] * xb[k];
+    }
+    return;
+  }
+  YT x0[STEPS], x1[STEPS];
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    x0[k] = (FULL || c0[k] >= 0) ? x[FULL ? c0[k] : (c0[k] >= 0 ? c0[k] : 0)] : YT(0);
+    x1[k] = (FULL || c1[k] >= 0) ? x[FULL ? c1[k] : (c1[k] >= 0 ? c1[k] : 0)] : YT(0);
+  }
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int li = k * SPAN + t * 2;
+    prod[li]     = (YT)v0[k] * x0[k];
+    prod[li + 1] = (YT)v1[k] * x1[k];
+  }
+}
+
 // stream kernel: workgroup b owns nnz [b*TILE, (b+1)*TILE).
 template <class OffT, class AT, class YT, int NPT, bool NT>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(int64_t nnz, const OffT* __restrict__ row_map,
@@ -125,11 +226,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(int64_t nnz, const 
                                                              YT* __restrict__ y, YT alpha, YT beta,
                                                              const int32_t* __restrict__ blk_row,
                                                              YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
-                                                             int remap) {
+                                                             int remap, int ablate) {
+  // ablate (bench-only diagnosis, 0 in production): bit 0 = no x gather, bit 1 = no LDS staging / row reduction
   constexpr int TILE  = kBlock * NPT;
   constexpr int STEPS = NPT / 2;      // two consecutive nnz per lane per step: 16 B of fp64 values + 8 B of columns
-  constexpr int SPAN  = kBlock * 2;   // nnz covered by the workgroup per step
-  using AV = typename vec2<AT>::type;
   __shared__ YT prod[TILE];
 
   const int t     = threadIdx.x;
@@ -140,36 +240,30 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(int64_t nnz, const 
   // 1. issue every streaming load of the tile up front (all independent, all aligned)
   AT v0[STEPS], v1[STEPS];
   int c0[STEPS], c1[STEPS];
-  KK_UNROLL
-  for (int k = 0; k < STEPS; ++k) {
-    const int64_t idx = s + (int64_t)k * SPAN + t * 2;
-    if (idx + 1 < e) {
-      const AV* vp   = reinterpret_cast<const AV*>(values + idx);
-      const kk_i32x2* cp = reinterpret_cast<const kk_i32x2*>(entries + idx);
-      const AV vv       = NT ? KK_NT_LOAD(vp) : *vp;
-      const kk_i32x2 cc = NT ? KK_NT_LOAD(cp) : *cp;
-      v0[k] = vv[0]; v1[k] = vv[1]; c0[k] = cc[0]; c1[k] = cc[1];
-    } else if (idx < e) {
-      v0[k] = values[idx]; c0[k] = entries[idx]; v1[k] = AT(0); c1[k] = c0[k];
-    } else {
-      v0[k] = v1[k] = AT(0); c0[k] = c1[k] = -1;
+  const bool full = (s + TILE <= nnz);
+  if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
+  else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
+  // 2. gather x (L2 / Infinity-Cache resident window), multiply, stage in LDS
+  if (ablate) {
+    YT acc = YT(0);
+    KK_UNROLL
+    for (int k = 0; k < STEPS; ++k) {
+      const YT x0 = (ablate & 1) ? (YT)(c0[k] & 3) : x[c0[k] < 0 ? 0 : c0[k]];
+      const YT x1 = (ablate & 1) ? (YT)(c1[k] & 3) : x[c1[k] < 0 ? 0 : c1[k]];
+      if (ablate & 2) { acc += (YT)v0[k] * x0 + (YT)v1[k] * x1; }
+      else { prod[k * kBlock * 2 + t * 2] = (YT)v0[k] * x0; prod[k * kBlock * 2 + t * 2 + 1] = (YT)v1[k] * x1; }
     }
-  }
-  // 2. gather x (L2-resident window thanks to the XCD-contiguous tile order), multiply, stage in LDS
-  KK_UNROLL
-  for (int k = 0; k < STEPS; ++k) {
-    const YT x0 = (c0[k] >= 0) ? x[c0[k]] : YT(0);
-    const YT x1 = (c1[k] >= 0) ? x[c1[k]] : YT(0);
-    const int li = k * SPAN + t * 2;
-    prod[li]     = (YT)v0[k] * x0;
-    prod[li + 1] = (YT)v1[k] * x1;
+    if (ablate & 2) { if (acc == (YT)1.2345e30) y[0] = acc; return; }
+  } else {
+    if (full) stage_products<AT, YT, STEPS, true, false>(x, prod, t, v0, v1, c0, c1);
+    else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
   }
   __syncthreads();
 
   // 3. per-row reduction out of LDS.  "Virtual rows" of this tile: an optional head (the row that
   //    started in an earlier tile) followed by the rows that start here; only the last may be cut.
-  const int64_t ra         = blk_row[b];
-  const int64_t rb         = blk_row[b + 1];
+  const int64_t ra         = blk_row[b] & 0x7fffffff;
+  const int64_t rb         = blk_row[b + 1] & 0x7fffffff;
   const int64_t first_start = (int64_t)row_map[ra];
   const bool has_head      = first_start > s;
   const int64_t nv         = (rb - ra) + (has_head ? 1 : 0);
@@ -205,6 +299,162 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(int64_t nnz, const 
   }
 }
 
+// Latency-lean stream kernel (the default).  Same tiling and carry protocol as spmv_stream_kernel; what
+// changes is the DEPENDENCY CHAIN each tile goes through, which is what bounds a kernel that needs ~100 KB
+// in flight per CU: the tile descriptor (first row + "starts inside a row" flag, one 8-byte scalar load) is
+// requested first, the streaming loads do not depend on it, and the per-lane row bounds
+// row_map[r], row_map[r+1] are requested together with the x gathers -- so a tile sees two memory
+// latencies (stream, then gather+bounds) instead of five (stream, gather, blk_row, row_map[ra], bounds).
+// After the barrier the row reduction touches only LDS and registers.
+template <class OffT, class AT, class YT, int NPT, bool NT, bool QP>
+__global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const OffT* __restrict__ row_map,
+                                                              const int32_t* __restrict__ entries,
+                                                              const AT* __restrict__ values, const YT* __restrict__ x,
+                                                              YT* __restrict__ y, YT alpha, YT beta,
+                                                              const int32_t* __restrict__ blk_info,
+                                                              YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
+                                                              int remap) {
+  constexpr int TILE  = kBlock * NPT;
+  constexpr int STEPS = NPT / 2;
+  __shared__ YT prod[TILE];
+  const int t     = threadIdx.x;
+  const int64_t b = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t s = b * TILE;
+  const bool full = (s + TILE <= nnz);
+  const int64_t e = full ? s + TILE : nnz;
+
+  // tile descriptor: bit 31 = the tile starts inside a row (a "head" segment exists)
+  const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
+
+  AT v0[STEPS], v1[STEPS];
+  int c0[STEPS], c1[STEPS];
+  if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
+  else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
+
+  const int64_t ra    = info0 & 0x7fffffff;
+  const int64_t rb    = info1 & 0x7fffffff;
+  const int has_head  = (info0 >> 31) & 1;
+  const int64_t nv    = (rb - ra) + has_head;          // virtual rows: [head] + rows starting in this tile
+  int G = 1;
+  while (G < kWave && nv * (G * 2) <= kBlock) G *= 2;
+  const int lane = t & (G - 1), grp = t / G, ngrp = kBlock / G;
+  // virtual row j -> matrix row r = ra + j - has_head (r = ra-1 is the head's row); bounds for the first pass
+  bool valid = grp < nv;
+  int64_t r  = ra + grp - has_head;
+  int64_t rs = 0, re = 0;
+  if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+
+  if (full) stage_products<AT, YT, STEPS, true, QP>(x, prod, t, v0, v1, c0, c1);
+  else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
+  __syncthreads();
+
+  for (int64_t base = 0; base < nv; base += ngrp) {
+    if (base > 0) {
+      valid = (base + grp) < nv;
+      r     = ra + base + grp - has_head;
+      if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+    }
+    const bool is_head  = r < ra;
+    const bool complete = !is_head && re <= e;
+    const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
+    YT sum = YT(0);
+    if (valid)
+      for (int i = i0 + lane; i < i1; i += G) sum += prod[i];
+    sum = group_sum(sum, G);
+    if (valid && lane == 0) {
+      if (is_head) carry_head[b] = sum;
+      else if (!complete) carry_tail[b] = sum;
+      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
+    }
+  }
+}
+
+// Wave-private variant: every 64-lane wave owns its own tile of 64*NPT nnz and its own slice of LDS, so the
+// kernel contains no workgroup barrier at all -- a wave's load -> gather -> LDS -> reduce chain never waits
+// for its three siblings, and a CU interleaves 32 independent chains instead of 8.  Same descriptor / carry
+// protocol with tile = 64*NPT.
+template <class OffT, class AT, class YT, int NPT, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_wave_kernel(int64_t nnz, int64_t ntiles, const OffT* __restrict__ row_map,
+                                                           const int32_t* __restrict__ entries,
+                                                           const AT* __restrict__ values, const YT* __restrict__ x,
+                                                           YT* __restrict__ y, YT alpha, YT beta,
+                                                           const int32_t* __restrict__ blk_info,
+                                                           YT* __restrict__ carry_head, YT* __restrict__ carry_tail) {
+  constexpr int WT    = kWave * NPT;
+  constexpr int STEPS = NPT / 2;
+  constexpr int SPAN  = kWave * 2;
+  using AV = typename vec2<AT>::type;
+  __shared__ YT prod_all[kBlock / kWave][WT];
+  const int lane64 = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b  = (int64_t)blockIdx.x * (kBlock / kWave) + w;
+  YT* prod         = prod_all[w];
+  const bool active = b < ntiles;          // wave-uniform
+  const int64_t s   = b * WT;
+  const bool full   = active && (s + WT <= nnz);
+  const int64_t e   = full ? s + WT : nnz;
+
+  AT v0[STEPS], v1[STEPS];
+  int c0[STEPS], c1[STEPS];
+  int32_t info0 = 0, info1 = 0;
+  if (active) { info0 = blk_info[b]; info1 = blk_info[b + 1]; }
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t idx = s + (int64_t)k * SPAN + lane64 * 2;
+    if (full) {
+      const AV* vp       = reinterpret_cast<const AV*>(values + idx);
+      const kk_i32x2* cp = reinterpret_cast<const kk_i32x2*>(entries + idx);
+      const AV vv        = NT ? KK_NT_LOAD(vp) : *vp;
+      const kk_i32x2 cc  = NT ? KK_NT_LOAD(cp) : *cp;
+      v0[k] = vv[0]; v1[k] = vv[1]; c0[k] = cc[0]; c1[k] = cc[1];
+    } else {
+      v0[k] = (active && idx < e) ? values[idx] : AT(0);         c0[k] = (active && idx < e) ? entries[idx] : 0;
+      v1[k] = (active && idx + 1 < e) ? values[idx + 1] : AT(0); c1[k] = (active && idx + 1 < e) ? entries[idx + 1] : 0;
+    }
+  }
+  const int64_t ra   = info0 & 0x7fffffff;
+  const int64_t rb   = info1 & 0x7fffffff;
+  const int has_head = (info0 >> 31) & 1;
+  const int64_t nv   = active ? (rb - ra) + has_head : 0;
+  int G = 1;
+  while (G < kWave && nv * (G * 2) <= kWave) G *= 2;
+  const int lane = lane64 & (G - 1), grp = lane64 / G, ngrp = kWave / G;
+  bool valid = grp < nv;
+  int64_t r  = ra + grp - has_head;
+  int64_t rs = 0, re = 0;
+  if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+
+  YT x0[STEPS], x1[STEPS];
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) { x0[k] = x[c0[k]]; x1[k] = x[c1[k]]; }     // masked lanes read x[0] times 0
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int li = k * SPAN + lane64 * 2;
+    prod[li]     = (YT)v0[k] * x0[k];
+    prod[li + 1] = (YT)v1[k] * x1[k];
+  }
+  KK_WAVE_SYNC();   // the wave's own LDS writes precede its reads (LDS is in-order per wave); no s_barrier
+
+  for (int64_t base = 0; base < nv; base += ngrp) {
+    if (base > 0) {
+      valid = (base + grp) < nv;
+      r     = ra + base + grp - has_head;
+      if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+    }
+    const bool is_head  = r < ra;
+    const bool complete = !is_head && re <= e;
+    const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
+    YT sum = YT(0);
+    if (valid)
+      for (int i = i0 + lane; i < i1; i += G) sum += prod[i];
+    sum = group_sum(sum, G);
+    if (valid && lane == 0) {
+      if (is_head) carry_head[b] = sum;
+      else if (!complete) carry_tail[b] = sum;
+      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
+    }
+  }
+}
+
 // finishes the rows cut by tile boundaries: thread b owns the row that starts in tile b and ends later.
 template <class OffT, class YT>
 __global__ void spmv_stream_fixup_kernel(int64_t nblocks, int64_t nnz, int64_t tile, const OffT* __restrict__ row_map,
@@ -212,7 +462,7 @@ __global__ void spmv_stream_fixup_kernel(int64_t nblocks, int64_t nnz, int64_t t
                                          const YT* __restrict__ carry_tail, YT* __restrict__ y, YT alpha, YT beta) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nblocks) return;
-  const int64_t ra = blk_row[b], rb = blk_row[b + 1];
+  const int64_t ra = blk_row[b] & 0x7fffffff, rb = blk_row[b + 1] & 0x7fffffff;
   if (rb == ra) return;
   const int64_t e  = ((b + 1) * tile < nnz) ? (b + 1) * tile : nnz;
   const int64_t R  = rb - 1;
@@ -346,9 +596,24 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
                          hipStream_t st) {
   YT* ch = reinterpret_cast<YT*>(p->d_carry);
   YT* ct = reinterpret_cast<YT*>(reinterpret_cast<char*>(p->d_carry) + 8 * p->nblocks);
-  KK_LAUNCH((spmv_stream_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
-            (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-            (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
+  const int variant = p->tune.stream_variant;
+  if (variant == 0) {
+    KK_LAUNCH((spmv_stream_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate);
+  } else if (variant == 2) {
+    KK_LAUNCH((spmv_wave_kernel<OffT, AT, YT, NPT, NT>), (unsigned)ceil_div(p->nblocks, kBlock / kWave), kBlock, 0, st, A->nnz,
+              p->nblocks, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+              (const int32_t*)p->d_blk_row, ch, ct);
+  } else if (variant == 3) {
+    KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, false>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
+  } else {
+    KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
+  }
   KK_LAUNCH_CHECK();
   KK_LAUNCH((spmv_stream_fixup_kernel<OffT, YT>), (unsigned)ceil_div(p->nblocks, kBlock), kBlock, 0, st, p->nblocks,
             A->nnz, (int64_t)p->tile, (const OffT*)A->d_row_map, (const int32_t*)p->d_blk_row, (const YT*)ch,
@@ -366,7 +631,7 @@ template <class OffT, class AT, class YT> struct StreamDispatch {
 template <class OffT> struct StreamDispatch<OffT, double, double> {
   static int run(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const double* x, double* y, double alpha, double beta,
                  hipStream_t st) {
-    const int npt = p->tile / kBlock;
+    const int npt = p->tile / (p->tune.stream_variant == 2 ? kWave : kBlock);
     const bool nt = p->tune.nontemporal != 0;
     if (npt == 4)  return nt ? launch_stream<OffT, double, double, 4, true>(p, A, x, y, alpha, beta, st)
                              : launch_stream<OffT, double, double, 4, false>(p, A, x, y, alpha, beta, st);
@@ -502,6 +767,9 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "xcd_remap") t.xcd_remap = value;
   else if (k == "nontemporal") t.nontemporal = value;
   else if (k == "mv_kernel") t.mv_kernel = value;
+  else if (k == "stream_variant") t.stream_variant = value;
+  else if (k == "wg_per_cu") t.wg_per_cu = value;
+  else if (k == "ablate") t.ablate = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
   return KKAMD_OK;
 }
@@ -520,9 +788,9 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
   p->tile = 0; p->nblocks = 0;
   if (p->algorithm == KKAMD_SPMV_FAST_SETUP || p->tune.kernel == 1 || A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
   int npt = p->tune.nnz_per_thread;
-  if (npt != 4 && npt != 8 && npt != 16) npt = 8;
+  if (npt != 4 && npt != 8 && npt != 16) npt = 16;
   if (!(A->value_type == KKAMD_F64)) npt = 8;
-  p->tile    = kBlock * npt;
+  p->tile    = (p->tune.stream_variant == 2 ? kWave : kBlock) * npt;
   p->nblocks = ceil_div(A->nnz, p->tile);
   KK_HIP(hipMalloc((void**)&p->d_blk_row, sizeof(int32_t) * (size_t)(p->nblocks + 1)));
   KK_HIP(hipMalloc(&p->d_carry, (size_t)16 * (size_t)p->nblocks));
@@ -564,6 +832,11 @@ int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int a
   if (!p) return kk::fail(KKAMD_ERR_ALLOC, "kkamd_spmv_plan_create: out of host memory");
   p->num_rows = A->num_rows; p->num_cols = A->num_cols; p->nnz = A->nnz; p->row_map = A->d_row_map;
   p->offset_type = A->offset_type; p->algorithm = algorithm; p->tune = kk::g_spmv_default;
+  {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      p->num_cus = prop.multiProcessorCount;
+  }
   rc = kk::build_analysis(p, A, kk::to_hip(stream));
   if (rc) { kkamd_spmv_plan_destroy(p); return rc; }
   *plan = p;
@@ -582,10 +855,11 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
 
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
   if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_set: null plan");
-  const int old_npt = plan->tune.nnz_per_thread, old_kernel = plan->tune.kernel;
+  const int old_npt = plan->tune.nnz_per_thread, old_kernel = plan->tune.kernel, old_var = plan->tune.stream_variant;
   int rc = kk::set_tuning(plan->tune, key, value);
   if (rc) return rc;
-  if (plan->tune.nnz_per_thread != old_npt || plan->tune.kernel != old_kernel) {
+  if (plan->tune.nnz_per_thread != old_npt || plan->tune.kernel != old_kernel ||
+      (plan->tune.stream_variant == 2) != (old_var == 2)) {
     // tiling changed: redo the analysis (needs the matrix again; rebuilt lazily from the stored row_map)
     kkamd_crs_t A{};
     A.num_rows = plan->num_rows; A.num_cols = plan->num_cols; A.nnz = plan->nnz; A.d_row_map = plan->row_map;

@@ -104,6 +104,7 @@ class CrsMatrix:
                 None if self.values is None else be.to_numpy(self.values))
 
 
+_PRE_KNOBS = {"kernel": 0, "nnz_per_thread": 0, "stream_variant": 1}   # knob -> library default
 _ALGOS = {"SPMV_DEFAULT": 0, "SPMV_FAST_SETUP": 1, "SPMV_NATIVE": 2, "SPMV_MERGE_PATH": 3, "SPMV_NATIVE_MERGE_PATH": 4}
 
 
@@ -132,7 +133,7 @@ class SPMVHandle:
         if self._plan is None:
             self.backend = A.backend
             lib = A.backend.lib
-            for k in ("kernel", "nnz_per_thread"):   # analysis-shaping knobs must precede the analysis
+            for k in _PRE_KNOBS:   # analysis-shaping knobs must precede the analysis
                 if k in self._pending:
                     check(lib, lib.kkamd_set_default(k.encode(), int(self._pending[k])))
             p = C.c_void_p()
@@ -140,12 +141,12 @@ class SPMVHandle:
             try:
                 check(lib, lib.kkamd_spmv_plan_create(C.byref(p), C.byref(d), _ALGOS[self.algo], A.backend.stream()))
             finally:
-                for k in ("kernel", "nnz_per_thread"):
+                for k in _PRE_KNOBS:
                     if k in self._pending:
-                        lib.kkamd_set_default(k.encode(), 0)
+                        lib.kkamd_set_default(k.encode(), _PRE_KNOBS[k])
             self._plan = p
             for k, v in self._pending.items():
-                if k not in ("kernel", "nnz_per_thread"):
+                if k not in _PRE_KNOBS:
                     check(lib, lib.kkamd_spmv_plan_set(p, k.encode(), int(v)))
         return self._plan
 

@@ -183,6 +183,7 @@ template <class T> inline T exchange(T v, int src_lane_in_wave) {
   return out;
 }
 inline int lane() { return (int)(S().cur % KK_EMU_WAVE); }
+inline int quad_perm(int v, int ctrl) { int l = lane(); return exchange(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3)); }
 }  // namespace kk_emu
 
 template <class T> inline T __shfl(T v, int src, int width = 64) {

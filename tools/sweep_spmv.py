@@ -51,6 +51,14 @@ def main():
         emit(kind="device_copy", bytes=2 * a.numel() * 8, ms_med=med, ms_min=mn, GBps=2 * a.numel() * 8 / med / 1e6)
         med, mn = timeit(lambda: torch.add(a, b, alpha=2.0, out=b), args.iters)
         emit(kind="device_triad_like", bytes=3 * a.numel() * 8, ms_med=med, ms_min=mn, GBps=3 * a.numel() * 8 / med / 1e6)
+        out = torch.zeros(8, dtype=torch.float64, device="cuda")
+        for loads in (2, 4, 8):
+            for nt in (0, 1):
+                for persist in (0, 1):
+                    fn = lambda: kk._capi.check(be.lib, be.lib.kkamd_bench_read(a.data_ptr(), a.numel() * 8, loads, nt, persist, out.data_ptr(), be.stream()))
+                    med, mn = timeit(fn, args.iters)
+                    emit(kind="device_read", loads=loads, nontemporal=nt, persistent=persist, bytes=a.numel() * 8, ms_med=med, ms_min=mn,
+                         GBps=a.numel() * 8 / med / 1e6, GBps_best=a.numel() * 8 / mn / 1e6)
         del a, b
 
     A = kk.laplace_matrix("FE", n, n, n)
@@ -63,25 +71,35 @@ def main():
     if "spmv" in what:
         ref = torch.empty_like(y)
         kk.spmv("N", 1.0, A, x, 0.0, ref)
-        for lpr in (4, 8, 16, 32):
-            for remap in (1, 0):
+        for lpr in (8, 16):
+            for remap in (0,):
                 h = kk.SPMVHandle("SPMV_FAST_SETUP"); h.set("lanes_per_row", lpr); h.set("xcd_remap", remap)
                 med, mn = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y), args.iters)
                 emit(kind="spmv_vector", n=n, lpr=lpr, xcd_remap=remap, ms_med=med, ms_min=mn, GBps=bytes0 / med / 1e6,
                      GFLOPs=2 * nnz / med / 1e6, maxdiff=float((y - ref).abs().max()))
+        variants = [(0, 0, 0), (3, 0, 0), (1, 0, 0)]
         for npt in (4, 8, 16):
-            for nt in (1, 0):
-                for remap in (1, 0):
+            for nt in (0, 1):
+                for var, wg, remap in variants:
                     h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("nnz_per_thread", npt); h.set("nontemporal", nt); h.set("xcd_remap", remap)
+                    h.set("stream_variant", var); h.set("wg_per_cu", wg)
                     for beta in (0.0, 1.0):
-                        if beta == 1.0 and not (nt == 1 and remap == 1):
+                        if beta == 1.0 and not (nt == 0 and npt == 8):
                             continue
                         med, mn = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, beta, y), args.iters)
                         by = bytes0 + (nr * 8 if beta else 0)
                         kk.spmv(h, "N", 1.0, A, x, 0.0, y)
-                        emit(kind="spmv_stream", n=n, nnz_per_thread=npt, nontemporal=nt, xcd_remap=remap, beta=beta, ms_med=med,
-                             ms_min=mn, GBps=by / med / 1e6, GFLOPs=2 * nnz / med / 1e6, frac_of_8TBps=by / med / 1e6 / 8000,
-                             maxdiff=float((y - ref).abs().max()))
+                        emit(kind="spmv_stream", n=n, nnz_per_thread=npt, nontemporal=nt, variant=var, wg_per_cu=wg, xcd_remap=remap, beta=beta,
+                             ms_med=round(med, 4), ms_min=round(mn, 4), GBps=round(by / med / 1e6, 1), GFLOPs=round(2 * nnz / med / 1e6, 1),
+                             frac_of_8TBps=round(by / med / 1e6 / 8000, 4), maxdiff=float((y - ref).abs().max()))
+
+    if "ablate" in what:
+        for npt in (8, 16):
+            for nt in (0, 1):
+                for abl in (0, 1, 2, 3):
+                    h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("nnz_per_thread", npt); h.set("nontemporal", nt); h.set("xcd_remap", 0); h.set("ablate", abl)
+                    med, mn = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y), args.iters)
+                    emit(kind="spmv_ablate", npt=npt, nt=nt, ablate=abl, ms_med=round(med, 4), ms_min=round(mn, 4), GBps=round(bytes0 / med / 1e6, 1))
 
     if "mv" in what:
         nv = 16
