@@ -32,14 +32,19 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is
 
 def cpu_baseline(sample_n=160, min_seconds=6.0):
     """Reference host path (port) on a bounded sample: 27-pt FE Laplacian sample_n^3, all host cores."""
+    # thread placement Kokkos recommends for its OpenMP backend; must be set before the OpenMP runtime starts
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "threads")
     import numpy as np
     import oracle
     A = oracle.laplace3d("FE", sample_n, sample_n, sample_n)
-    rm32 = A.row_map.astype(np.int32)
+    ft = oracle.first_touch          # pages spread over NUMA nodes the way a Kokkos::View's would be
+    rm32 = ft(A.row_map.astype(np.int32)); ent = ft(A.entries); val = ft(A.values)
     rng = np.random.default_rng(17312837)
-    x = rng.integers(-20, 20, size=A.ncols).astype(np.float64)
-    y = np.zeros(A.nrows)
-    oracle.spmv_omp(rm32, A.entries, A.values, 1.0, x, 0.0, y)        # warm-up / first touch
+    x = ft(rng.integers(-20, 20, size=A.ncols).astype(np.float64))
+    y = ft(np.zeros(A.nrows))
+    A.entries, A.values = ent, val
+    oracle.spmv_omp(rm32, A.entries, A.values, 1.0, x, 0.0, y)        # warm-up
     t0 = time.perf_counter(); it = 0
     while True:
         oracle.spmv_omp(rm32, A.entries, A.values, 1.0, x, 0.0, y); it += 1
@@ -175,9 +180,22 @@ def main():
             "spmv_kernel_ms": round(kern_ms, 5),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "kk::spmv_stream_kernel (+ fix-up kernel), HIP events around the launch",
+                         "kernel": "kk::spmv_stream3_kernel (+ fix-up kernel), HIP events around the launch",
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        # HBM traffic comes from the committed rocprofv3 PMC passes of this same command (it cannot be counted live)
+        pmc = os.path.join(ROOT, "profiles", "round1", "bench_n1_pmc_hbm.json")
+        if world == 1 and not args.n and not args.knob and os.path.exists(pmc):
+            try:
+                d = json.load(open(pmc)); rd = wr = None
+                for k, v in d.items():
+                    if "spmv_stream3_kernel" in k and "FETCH_SIZE" in k: rd = v["mean_KB"] * 1024 * 2   # gfx950 x2 correction
+                    if "spmv_stream3_kernel" in k and "WRITE_SIZE" in k: wr = v["mean_KB"] * 1024
+                if rd and wr:
+                    out["roofline"]["traffic"] = int(rd + wr)
+                    out["roofline"]["traffic_source"] = "profiles/round1/bench_n1_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

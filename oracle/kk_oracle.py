@@ -255,6 +255,13 @@ def random_crs(nrows, ncols, nnz_per_row, variance=0, seed=0, bandwidth=None, so
 
 
 # --------------------------------------------------------------------------- CPU baselines
+def first_touch(a):
+    """copy of `a` whose pages were first touched by the OpenMP team (NUMA spread, like a Kokkos::View)"""
+    out = np.empty_like(a)
+    lib().kko_first_touch_copy(_p(out), _p(np.ascontiguousarray(a)), _i64(a.nbytes))
+    return out
+
+
 def omp_threads():
     return int(lib().kko_omp_max_threads())
 

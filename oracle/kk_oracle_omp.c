@@ -10,6 +10,20 @@
 
 int kko_omp_max_threads(void) { return omp_get_max_threads(); }
 
+/* parallel first-touch copy: what Kokkos::View allocation + deep_copy do on the OpenMP backend (pages end up
+ * spread over the NUMA nodes of the threads that touch them), instead of one thread faulting everything in. */
+int kko_first_touch_copy(void* dst, const void* src, int64_t bytes) {
+  char* d = (char*)dst; const char* s = (const char*)src;
+  const int64_t chunk = 1 << 20;
+  const int64_t n = (bytes + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < n; ++c) {
+    const int64_t o = c * chunk, l = (o + chunk <= bytes) ? chunk : bytes - o;
+    for (int64_t i = 0; i < l; ++i) d[o + i] = s[o + i];
+  }
+  return 0;
+}
+
 /* Kokkos::RangePolicy's automatic chunk size (Kokkos core, un-vendored; restated
  * from its published RangePolicy::set_auto_chunk_size: grow a power of two until
  * chunk*100*concurrency covers the range, falling back to a 40x rule capped at
