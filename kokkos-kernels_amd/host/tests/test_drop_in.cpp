@@ -1,0 +1,194 @@
+// Host-side test of the drop-in headers (compiled with hipcc, run on the GPU by tests/test_gpu_host_api.py).
+// The cases mirror the reference's own unit tests for this path:
+//   test_github_issue_101            sparse/unit_test/Test_Sparse_spmv.hpp:823-961 (exact known answer)
+//   test_spmv_all_interfaces_light   :964-1055 (space/handle/neither x rank-1/rank-2 on 111 x 99)
+//   spgemm view/matrix/no-reuse APIs sparse/unit_test/Test_Sparse_spgemm.hpp:243-252,444-481
+// Expected values come from the test's own sequential loops, as in the reference's tests.
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <random>
+#include "KokkosSparse_spmv.hpp"
+#include "KokkosSparse_spgemm.hpp"
+
+using device = Kokkos::Device<Kokkos::HIP, Kokkos::HIPSpace>;
+static int failures = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); ++failures; } } while (0)
+
+template <class scalar, class size_type>
+KokkosSparse::CrsMatrix<scalar, int, device, void, size_type> make_random(int m, int n, int per_row, std::vector<size_type>& rm,
+                                                                          std::vector<int>& ent, std::vector<scalar>& val, unsigned seed) {
+  std::mt19937 g(seed); rm.assign(m + 1, 0); ent.clear(); val.clear();
+  for (int i = 0; i < m; ++i) {
+    const int len = n ? (int)(g() % (2 * per_row + 1)) : 0;
+    std::vector<int> cols;
+    for (int j = 0; j < len; ++j) cols.push_back((int)(g() % n));
+    std::sort(cols.begin(), cols.end()); cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    for (int c : cols) { ent.push_back(c); val.push_back((scalar)(1 + (g() % 4900) / 100.0)); }
+    rm[i + 1] = (size_type)ent.size();
+  }
+  using M = KokkosSparse::CrsMatrix<scalar, int, device, void, size_type>;
+  typename M::row_map_type::non_const_type d_rm("rm", m + 1);
+  typename M::index_type d_ent("ent", ent.size());
+  typename M::values_type d_val("val", val.size());
+  Kokkos::deep_copy(d_rm, Kokkos::View<size_type*, Kokkos::HostSpace>(rm.data(), rm.size()));
+  if (!ent.empty()) {
+    Kokkos::deep_copy(d_ent, Kokkos::View<int*, Kokkos::HostSpace>(ent.data(), ent.size()));
+    Kokkos::deep_copy(d_val, Kokkos::View<scalar*, Kokkos::HostSpace>(val.data(), val.size()));
+  }
+  return M("A", m, n, ent.size(), d_val, d_rm, d_ent);
+}
+
+void test_github_issue_101() {
+  using graph_type = KokkosSparse::CrsMatrix<double, int, device>::StaticCrsGraphType;
+  const float EPS_f = std::numeric_limits<float>::epsilon();
+  const double expected = 1.0 + (double)EPS_f / 2.0;
+  Kokkos::View<int*, device> colInds("colInds", 2);
+  Kokkos::View<int*, device> rowOffsets("rowOffsets", 2);
+  int h_c[2] = {0, 1}, h_r[2] = {0, 2};
+  Kokkos::deep_copy(colInds, Kokkos::View<int*, Kokkos::HostSpace>(h_c, 2));
+  Kokkos::deep_copy(rowOffsets, Kokkos::View<int*, Kokkos::HostSpace>(h_r, 2));
+  graph_type G(colInds, rowOffsets);
+  Kokkos::View<double*, device> x("x", 2), y("y", 1);
+  Kokkos::deep_copy(x, 1.0);
+  auto y_h = Kokkos::create_mirror_view(y);
+  {
+    KokkosSparse::CrsMatrix<double, int, device> A_d("A_d", G, 2);
+    double h_v[2] = {1.0, (double)EPS_f / 2.0};
+    Kokkos::deep_copy(A_d.values, Kokkos::View<double*, Kokkos::HostSpace>(h_v, 2));
+    Kokkos::deep_copy(y, 0.0);
+    KokkosSparse::spmv("N", 1.0, A_d, x, 0.0, y);
+    Kokkos::deep_copy(y_h, y);
+    EXPECT(y_h(0) == expected);
+    for (int nv = 1; nv <= 22; ++nv) {
+      Kokkos::View<double**, Kokkos::LayoutLeft, device> X("X", 2, nv), Y("Y", 1, nv);
+      Kokkos::deep_copy(X, 1.0);
+      KokkosSparse::spmv("N", 1.0, A_d, X, 0.0, Y);
+      auto Y_h = Kokkos::create_mirror_view(Y); Kokkos::deep_copy(Y_h, Y);
+      for (int j = 0; j < nv; ++j) EXPECT(Y_h(0, j) == expected);
+    }
+  }
+  {  // float matrix, double vectors
+    KokkosSparse::CrsMatrix<float, int, device> A_f("A_f", KokkosSparse::CrsMatrix<float, int, device>::StaticCrsGraphType(colInds, rowOffsets), 2);
+    float h_v[2] = {1.0f, EPS_f / 2.0f};
+    Kokkos::deep_copy(A_f.values, Kokkos::View<float*, Kokkos::HostSpace>(h_v, 2));
+    Kokkos::deep_copy(y, 0.0);
+    KokkosSparse::spmv("N", 1.0, A_f, x, 0.0, y);
+    Kokkos::deep_copy(y_h, y);
+    EXPECT(y_h(0) == expected);
+  }
+}
+
+template <class layout>
+void test_all_interfaces() {
+  using M  = KokkosSparse::CrsMatrix<double, int, device, void, int>;
+  using V1 = Kokkos::View<double*, device>;
+  using V2 = Kokkos::View<double**, layout, device>;
+  std::vector<int> rm, ent; std::vector<double> val;
+  const int m = 111, n = 99, nv = 7;
+  M A = make_random<double, int>(m, n, 10, rm, ent, val, 11);
+  std::vector<double> hx(n * nv), hy(m * nv, 0.0);
+  std::mt19937 g(3);
+  for (auto& v : hx) v = (g() % 1000) / 1000.0;
+  auto idx = [&](int i, int j, int rows) { return std::is_same<layout, Kokkos::LayoutLeft>::value ? i + (size_t)j * rows : (size_t)i * nv + j; };
+  for (int i = 0; i < m; ++i) for (int j = rm[i]; j < rm[i + 1]; ++j) for (int c = 0; c < nv; ++c)
+    hy[idx(i, c, m)] += 2.0 * val[j] * hx[idx(ent[j], c, n)];
+  V2 X("X", n, nv), Y("Y", m, nv);
+  Kokkos::deep_copy(X, Kokkos::View<double**, layout, Kokkos::HostSpace>(hx.data(), n, nv));
+  V1 x1("x1", n), y1("y1", m);
+  std::vector<double> hx1(n), hy1(m, 0.0);
+  for (int i = 0; i < n; ++i) hx1[i] = hx[idx(i, 0, n)];
+  for (int i = 0; i < m; ++i) for (int j = rm[i]; j < rm[i + 1]; ++j) hy1[i] += 2.0 * val[j] * hx1[ent[j]];
+  Kokkos::deep_copy(x1, Kokkos::View<double*, Kokkos::HostSpace>(hx1.data(), n));
+  auto check1 = [&]() { auto h = Kokkos::create_mirror_view(y1); Kokkos::deep_copy(h, y1); double e = 0; for (int i = 0; i < m; ++i) e = std::max(e, std::fabs(h(i) - hy1[i])); EXPECT(e < 1e-12); Kokkos::deep_copy(y1, -7.0); };
+  auto check2 = [&]() { auto h = Kokkos::create_mirror_view(Y); Kokkos::deep_copy(h, Y); double e = 0; for (int i = 0; i < m; ++i) for (int c = 0; c < nv; ++c) e = std::max(e, std::fabs(h(i, c) - hy[idx(i, c, m)])); EXPECT(e < 1e-12); Kokkos::deep_copy(Y, -7.0); };
+  Kokkos::HIP space;
+  KokkosSparse::SPMVHandle<device, M, V1, V1> h1(KokkosSparse::SPMV_DEFAULT);
+  KokkosSparse::SPMVHandle<device, M, V2, V2> h2(KokkosSparse::SPMV_MERGE_PATH);
+  KokkosSparse::spmv(space, &h1, "N", 2.0, A, x1, 0.0, y1); space.fence(); check1();
+  KokkosSparse::spmv(&h1, "N", 2.0, A, x1, 0.0, y1); Kokkos::fence(); check1();
+  KokkosSparse::spmv(space, "N", 2.0, A, x1, 0.0, y1); space.fence(); check1();
+  KokkosSparse::spmv("N", 2.0, A, x1, 0.0, y1); Kokkos::fence(); check1();
+  KokkosSparse::spmv(space, &h2, "N", 2.0, A, X, 0.0, Y); space.fence(); check2();
+  KokkosSparse::spmv(&h2, "N", 2.0, A, X, 0.0, Y); Kokkos::fence(); check2();
+  KokkosSparse::spmv(space, "N", 2.0, A, X, 0.0, Y); space.fence(); check2();
+  KokkosSparse::spmv("N", 2.0, A, X, 0.0, Y); Kokkos::fence(); check2();
+  // error behaviour: dimension mismatch and BSR-only algorithm on a CrsMatrix
+  bool threw = false;
+  try { V1 bad("bad", n + 1); KokkosSparse::spmv("N", 1.0, A, bad, 0.0, y1); } catch (const std::runtime_error& e) { threw = std::string(e.what()).find("Dimensions do not match") != std::string::npos; }
+  EXPECT(threw);
+  threw = false;
+  try { KokkosSparse::SPMVHandle<device, M, V1, V1> hb(KokkosSparse::SPMV_BSR_TC); } catch (const std::invalid_argument&) { threw = true; }
+  EXPECT(threw);
+  threw = false;
+  try { KokkosSparse::spmv("X", 1.0, A, x1, 0.0, y1); } catch (const std::runtime_error&) { threw = true; }
+  EXPECT(threw);
+}
+
+template <class size_type>
+void test_spgemm() {
+  using M  = KokkosSparse::CrsMatrix<double, int, device, void, size_type>;
+  using KH = KokkosKernels::Experimental::KokkosKernelsHandle<size_type, int, double, Kokkos::HIP, Kokkos::HIPSpace, Kokkos::HIPSpace>;
+  std::vector<size_type> rmA, rmB; std::vector<int> eA, eB; std::vector<double> vA, vB;
+  const int m = 300, n = 250, k = 200;
+  M A = make_random<double, size_type>(m, n, 8, rmA, eA, vA, 5), B = make_random<double, size_type>(n, k, 6, rmB, eB, vB, 6);
+  // host Gustavson with a dense accumulator, rows emitted sorted
+  std::vector<size_type> rmC(m + 1, 0); std::vector<int> eC; std::vector<double> vC;
+  std::vector<double> acc(k, 0.0); std::vector<char> flag(k, 0);
+  for (int i = 0; i < m; ++i) {
+    std::vector<int> cols;
+    for (size_type a = rmA[i]; a < rmA[i + 1]; ++a) for (size_type b = rmB[eA[a]]; b < rmB[eA[a] + 1]; ++b) {
+      if (!flag[eB[b]]) { flag[eB[b]] = 1; cols.push_back(eB[b]); }
+      acc[eB[b]] += vB[b] * vA[a];
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols) { eC.push_back(c); vC.push_back(acc[c]); acc[c] = 0; flag[c] = 0; }
+    rmC[i + 1] = (size_type)eC.size();
+  }
+  auto compare = [&](const M& C) {
+    EXPECT((size_t)C.nnz() == eC.size());
+    auto h_rm = Kokkos::create_mirror_view(C.graph.row_map); Kokkos::deep_copy(h_rm, C.graph.row_map);
+    auto h_e  = Kokkos::create_mirror_view(C.graph.entries); Kokkos::deep_copy(h_e, C.graph.entries);
+    auto h_v  = Kokkos::create_mirror_view(C.values);        Kokkos::deep_copy(h_v, C.values);
+    bool ok = true;
+    for (int i = 0; i <= m; ++i) ok = ok && (h_rm(i) == rmC[i]);
+    for (size_t j = 0; j < eC.size() && ok; ++j) ok = ok && (h_e(j) == eC[j]) && (std::fabs(h_v(j) - vC[j]) / (std::fabs(h_v(j)) + std::fabs(vC[j])) < 1e-7);
+    EXPECT(ok);
+  };
+  KH kh;
+  bool threw = false;
+  M C;
+  try { KokkosSparse::spgemm_symbolic(kh, A, false, B, false, C); } catch (const std::invalid_argument&) { threw = true; }
+  EXPECT(threw);                                   // no SpGEMM sub-handle yet
+  kh.create_spgemm_handle(KokkosSparse::SPGEMM_KK);
+  KokkosSparse::spgemm_symbolic(kh, A, false, B, false, C);
+  EXPECT((size_t)kh.get_spgemm_handle()->get_c_nnz() == eC.size());
+  EXPECT(kh.get_spgemm_handle()->is_symbolic_called() && !kh.get_spgemm_handle()->is_numeric_called());
+  KokkosSparse::spgemm_numeric(kh, A, false, B, false, C);
+  compare(C);
+  KokkosSparse::spgemm_numeric(kh, A, false, B, false, C);   // numeric reuse
+  compare(C);
+  kh.destroy_spgemm_handle();
+  M C2 = KokkosSparse::spgemm<M>(A, false, B, false);        // no-reuse interface
+  compare(C2);
+  threw = false;
+  try { KokkosSparse::spgemm<M>(A, false, A, false); } catch (const std::invalid_argument&) { threw = true; }
+  EXPECT(threw);
+  // numeric before symbolic on a fresh handle
+  KH kh2; kh2.create_spgemm_handle();
+  threw = false;
+  try { KokkosSparse::spgemm_numeric(kh2, A, false, B, false, C); } catch (const std::invalid_argument&) { threw = true; }
+  EXPECT(threw);
+}
+
+int main() {
+  Kokkos::initialize();
+  test_github_issue_101();
+  test_all_interfaces<Kokkos::LayoutLeft>();
+  test_all_interfaces<Kokkos::LayoutRight>();
+  test_spgemm<int>();
+  test_spgemm<size_t>();
+  Kokkos::finalize();
+  std::printf(failures ? "drop-in API tests: %d FAILED\n" : "drop-in API tests: all passed\n", failures);
+  return failures ? 1 : 0;
+}
