@@ -10,6 +10,7 @@
 #define KK_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(kk_emu::S().dyn_smem)
 #define KK_DEVICE_ONLY(...)
 #define KK_UNROLL
+#define KK_UNROLL4
 #define KK_WAVE_SYNC() kk_emu::sync_wave()
 #define KK_QUAD_PERM(v, ctrl) kk_emu::quad_perm((v), (ctrl))
 #else
@@ -22,6 +23,7 @@
   T* name = reinterpret_cast<T*>(kk_dyn_smem_)
 #define KK_DEVICE_ONLY(...) __VA_ARGS__
 #define KK_UNROLL _Pragma("unroll")
+#define KK_UNROLL4 _Pragma("unroll 4")
 #define KK_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // DPP quad permute of a 32-bit value: lane (4q+j) receives the value of lane 4q + ((ctrl >> 2j) & 3)
 #define KK_QUAD_PERM(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xf, 0xf, true)

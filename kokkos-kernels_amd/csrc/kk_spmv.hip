@@ -35,6 +35,7 @@ struct SpmvTuning {
   int stream_variant = 1;  // 1 lean kernel + quad-dealt gathers (default), 3 lean kernel natural layout, 0 first-generation, 2 wave-private
   int wg_per_cu      = 0;  // unused (persistent variant measured slower and was removed)
   int ablate         = 0;  // bench-only: 1 no x gather, 2 no LDS/reduce, 3 both
+  int mv_remap       = 1;  // rank-2: XCD-contiguous workgroup order (keeps shared X rows in one XCD's L2)
 };
 static SpmvTuning g_spmv_default;
 
@@ -50,6 +51,8 @@ struct kkamd_spmv_plan {
   int num_cus = 256;
   int32_t* d_blk_row = nullptr;  // [nblocks+1] first row starting at or after b*tile
   void* d_carry = nullptr;       // [2*nblocks] 8-byte slots: head partials, then tail partials
+  void* d_xpack = nullptr;       // rank-2: row-major packed copy of a column-major X (grown on demand)
+  size_t xpack_bytes = 0;
 };
 
 namespace kk {
@@ -299,6 +302,20 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(int64_t nnz, const 
   }
 }
 
+// sum of prod[i0+lane], prod[i0+lane+G], ... below i1: four independent partial sums so that four LDS reads are
+// in flight per lane (a plain loop waits out one LDS round trip per element: ~1.3 us per 4096-nnz tile)
+template <class YT> __device__ __forceinline__ YT strided_lds_sum(const YT* prod, int i0, int i1, int lane, int G) {
+  YT s0 = YT(0), s1 = YT(0), s2 = YT(0), s3 = YT(0);
+  int i = i0 + lane;
+  const int G2 = 2 * G, G3 = 3 * G, G4 = 4 * G;
+  for (; i + G3 < i1; i += G4) {
+    const YT a = prod[i], b = prod[i + G], c = prod[i + G2], d = prod[i + G3];
+    s0 += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; i < i1; i += G) s0 += prod[i];
+  return (s0 + s1) + (s2 + s3);
+}
+
 // Latency-lean stream kernel (the default).  Same tiling and carry protocol as spmv_stream_kernel; what
 // changes is the DEPENDENCY CHAIN each tile goes through, which is what bounds a kernel that needs ~100 KB
 // in flight per CU: the tile descriptor (first row + "starts inside a row" flag, one 8-byte scalar load) is
@@ -357,9 +374,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
     const bool is_head  = r < ra;
     const bool complete = !is_head && re <= e;
     const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
-    YT sum = YT(0);
-    if (valid)
-      for (int i = i0 + lane; i < i1; i += G) sum += prod[i];
+    YT sum = valid ? strided_lds_sum<YT>(prod, i0, i1, lane, G) : YT(0);
     sum = group_sum(sum, G);
     if (valid && lane == 0) {
       if (is_head) carry_head[b] = sum;
@@ -443,9 +458,7 @@ __global__ __launch_bounds__(kBlock) void spmv_wave_kernel(int64_t nnz, int64_t 
     const bool is_head  = r < ra;
     const bool complete = !is_head && re <= e;
     const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
-    YT sum = YT(0);
-    if (valid)
-      for (int i = i0 + lane; i < i1; i += G) sum += prod[i];
+    YT sum = valid ? strided_lds_sum<YT>(prod, i0, i1, lane, G) : YT(0);
     sum = group_sum(sum, G);
     if (valid && lane == 0) {
       if (is_head) carry_head[b] = sum;
@@ -534,6 +547,144 @@ __global__ __launch_bounds__(kBlock) void spmv_mv_kernel(int64_t nrows, const Of
       acc *= alpha;
       YT* yp = Y + row * ys0 + (kk + k) * ys1;
       *yp    = (beta == YT(0)) ? acc : beta * (*yp) + acc;
+    }
+  }
+}
+
+// rank-2, no transpose, row-major X (the fast path).  One 64-lane WAVE owns RW = 64/LPRW consecutive rows;
+// LPRW lanes form a row group and each lane carries TWO right-hand sides, so one X access is a 16-byte load and a
+// wave-level load instruction moves 64 x 16 B = 1 KB (the generic kernel above moves 512 B per instruction with
+// 4 rows in flight and is bound by the texture path at ~13 % of the HBM roofline).  The wave's contiguous CSR
+// range is staged through its private LDS slice with 16-byte loads (4-aligned windows), no workgroup barrier.
+typedef int kk_i32x4 __attribute__((vector_size(16)));
+template <class OffT, class AT, class YT, int LPRW, int RPL>
+__global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ row_map,
+                                                          const int32_t* __restrict__ entries,
+                                                          const AT* __restrict__ values, const YT* __restrict__ X,
+                                                          int64_t xs0, YT* __restrict__ Y, int64_t ys0, int64_t ys1,
+                                                          int64_t nvec, YT alpha, YT beta, int y_vec_ok, int remap) {
+  // XCD-contiguous workgroup order (remap): the 128-byte X rows a row block touches are shared with the blocks
+  // that handle rows i+-1, j+-1 (and k+-1); keeping neighbouring blocks on ONE XCD keeps those X rows in its
+  // 4 MiB L2.  With the dispatcher's round-robin order every XCD fetched every X row: rocprof showed 10.7
+  // memory fetches per X row (45 GB per launch on the 300^3 x 16 case against 12 GB of compulsory reads).
+  // LPRW lanes per row, RPL (2 or 4) right-hand sides per lane: strip width SW = LPRW*RPL, RW rows per wave.
+  // RPL = 4 halves the per-nnz LDS-read / address arithmetic per FMA; a quad of lanes then covers one 128 B X row.
+  constexpr int RW  = kWave / LPRW;
+  constexpr int SW  = RPL * LPRW;
+  constexpr int NV2 = RPL / 2;           // 16-byte pieces per lane
+  constexpr int CHW = 256;               // nnz staged per wave per pass
+  using AV = typename vec2<AT>::type;
+  using XV = typename vec2<YT>::type;
+  __shared__ AT s_val_all[kBlock / kWave][CHW];
+  __shared__ int s_col_all[kBlock / kWave][CHW];
+  const int lane64 = threadIdx.x & 63, w = threadIdx.x >> 6;
+  AT* s_val  = s_val_all[w];
+  int* s_col = s_col_all[w];
+  const int64_t wg   = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t row0 = (wg * (kBlock / kWave) + w) * RW;
+  if (row0 >= nrows) return;                                   // whole wave leaves together
+  const int64_t rowN = (row0 + RW < nrows) ? row0 + RW : nrows;
+  const int grp = lane64 / LPRW, l = lane64 % LPRW;
+  const int64_t row = row0 + grp;
+  const int64_t lo  = (int64_t)row_map[row0] & ~(int64_t)3;    // 4-aligned staging windows
+  const int64_t hi  = (int64_t)row_map[rowN];
+  int64_t rs = 0, re = 0;
+  if (row < rowN) { rs = (int64_t)row_map[row]; re = (int64_t)row_map[row + 1]; }
+  for (int64_t kk = 0; kk < nvec; kk += SW) {
+    const int64_t cA = kk + RPL * l;
+    const bool all_ok = cA + RPL <= nvec;
+    YT acc[RPL];
+    KK_UNROLL
+    for (int q = 0; q < RPL; ++q) acc[q] = YT(0);
+    for (int64_t c = lo; c < hi; c += CHW) {
+      KK_WAVE_SYNC();
+      if (c + CHW <= nnz) {   // whole window inside the arrays (wave-uniform): three unguarded 16-byte loads per lane
+        const kk_i32x4 cc = *reinterpret_cast<const kk_i32x4*>(entries + c + lane64 * 4);
+        const AV va = *reinterpret_cast<const AV*>(values + c + lane64 * 2);
+        const AV vb = *reinterpret_cast<const AV*>(values + c + 128 + lane64 * 2);
+        s_col[lane64 * 4] = cc[0]; s_col[lane64 * 4 + 1] = cc[1]; s_col[lane64 * 4 + 2] = cc[2]; s_col[lane64 * 4 + 3] = cc[3];
+        s_val[lane64 * 2] = va[0]; s_val[lane64 * 2 + 1] = va[1];
+        s_val[128 + lane64 * 2] = vb[0]; s_val[128 + lane64 * 2 + 1] = vb[1];
+      } else {
+        for (int q = 0; q < 4; ++q) {
+          const int64_t i = c + lane64 * 4 + q;
+          s_col[lane64 * 4 + q] = (i < nnz) ? entries[i] : 0;
+          s_val[lane64 * 4 + q] = (i < nnz) ? values[i] : AT(0);
+        }
+      }
+      KK_WAVE_SYNC();
+      const int64_t ce = c + CHW;
+      const int a = (int)((rs > c ? rs : c) - c), z = (int)((re < ce ? re : ce) - c);
+      if (all_ok) {
+        // batches of U entries: all U*NV2 16-byte X loads are issued before the first FMA consumes one
+        // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> fma per entry: one load in flight per wave)
+        constexpr int U = 8 / NV2 >= 4 ? 8 / NV2 : 4;
+        int i = a;
+        for (; i + U <= z; i += U) {
+          YT v[U]; XV xv[U][NV2];
+          KK_UNROLL
+          for (int u = 0; u < U; ++u) {
+            v[u] = (YT)s_val[i + u];
+            const XV* xp = reinterpret_cast<const XV*>(X + (int64_t)s_col[i + u] * xs0 + cA);
+            KK_UNROLL
+            for (int q = 0; q < NV2; ++q) xv[u][q] = xp[q];
+          }
+          KK_UNROLL
+          for (int u = 0; u < U; ++u) {
+            KK_UNROLL
+            for (int q = 0; q < NV2; ++q) { acc[2 * q] += v[u] * xv[u][q][0]; acc[2 * q + 1] += v[u] * xv[u][q][1]; }
+          }
+        }
+        for (; i < z; ++i) {
+          const YT v   = (YT)s_val[i];
+          const XV* xp = reinterpret_cast<const XV*>(X + (int64_t)s_col[i] * xs0 + cA);
+          KK_UNROLL
+          for (int q = 0; q < NV2; ++q) { const XV xq = xp[q]; acc[2 * q] += v * xq[0]; acc[2 * q + 1] += v * xq[1]; }
+        }
+      } else {
+        for (int i = a; i < z; ++i) {
+          const YT v = (YT)s_val[i];
+          const YT* xp = X + (int64_t)s_col[i] * xs0 + cA;
+          for (int q = 0; q < RPL; ++q) if (cA + q < nvec) acc[q] += v * xp[q];
+        }
+      }
+    }
+    if (row < rowN) {
+      YT* yp = Y + row * ys0 + cA * ys1;
+      if (all_ok && y_vec_ok) {
+        KK_UNROLL
+        for (int q = 0; q < NV2; ++q) {
+          XV out;
+          if (beta == YT(0)) { out[0] = alpha * acc[2 * q]; out[1] = alpha * acc[2 * q + 1]; }
+          else { const XV old = reinterpret_cast<const XV*>(yp)[q]; out[0] = beta * old[0] + alpha * acc[2 * q]; out[1] = beta * old[1] + alpha * acc[2 * q + 1]; }
+          reinterpret_cast<XV*>(yp)[q] = out;
+        }
+      } else {
+        for (int q = 0; q < RPL; ++q)
+          if (cA + q < nvec) { const YT r = alpha * acc[q]; yp[q * ys1] = (beta == YT(0)) ? r : beta * yp[q * ys1] + r; }
+      }
+    }
+  }
+}
+
+// X(ncols x nvec, column-major or any strides) -> row-major, leading dimension ldp (even): the packing step that
+// lets a LayoutLeft multivector use the 16-byte-per-lane row-major kernel.  32x32 LDS tile transpose.
+template <class YT>
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n, int64_t nvec, const YT* __restrict__ X, int64_t xs0,
+                                                           int64_t xs1, YT* __restrict__ Xp, int64_t ldp) {
+  __shared__ YT tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  const int64_t i0 = (int64_t)blockIdx.x * 32;
+  for (int64_t j0 = 0; j0 < nvec; j0 += 32) {
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {                             // read: consecutive lanes walk i (stride xs0)
+      const int64_t i = i0 + tx, j = j0 + q;
+      tile[q][tx] = (i < n && j < nvec) ? X[i * xs0 + j * xs1] : YT(0);
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {                             // write: consecutive lanes walk j (contiguous)
+      const int64_t i = i0 + q, j = j0 + tx;
+      if (i < n && j < ldp) Xp[i * ldp + j] = tile[tx][q];
     }
   }
 }
@@ -706,6 +857,45 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
     KK_LAUNCH_CHECK();
     return KKAMD_OK;
   }
+  const int mvk = plan ? plan->tune.mv_kernel : g_spmv_default.mv_kernel;      // 0 auto, 1 force generic, 2 force packed/row-major
+  const bool a_aligned = ((uintptr_t)A->d_values % 16 == 0) && ((uintptr_t)A->d_entries % 16 == 0);
+  if (mvk != 1 && a_aligned) {
+    const YT* Xr = nullptr; int64_t ldx = 0;
+    if (xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0)) { Xr = X; ldx = xs0; }
+    else if (plan && nvec >= 2) {
+      // pack X into a row-major workspace owned by the plan (the reference's rank-2 sub-handle tpl_rank2 plays this role)
+      const int64_t ldp = (nvec + 1) & ~(int64_t)1;
+      const size_t need = (size_t)A->num_cols * (size_t)ldp * sizeof(YT);
+      if (plan->xpack_bytes < need) {
+        if (plan->d_xpack) { KK_HIP(hipStreamSynchronize(st)); KK_HIP(hipFree(plan->d_xpack)); plan->d_xpack = nullptr; plan->xpack_bytes = 0; }
+        KK_HIP(hipMalloc(&plan->d_xpack, need));
+        plan->xpack_bytes = need;
+      }
+      KK_LAUNCH((pack_rows_kernel<YT>), (unsigned)ceil_div(A->num_cols, 32), kBlock, 0, st, A->num_cols, nvec, X, xs0, xs1,
+                (YT*)plan->d_xpack, ldp);
+      KK_LAUNCH_CHECK();
+      Xr = (const YT*)plan->d_xpack; ldx = ldp;
+    }
+    if (Xr) {
+      const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
+      const int mv_remap = plan ? plan->tune.mv_remap : g_spmv_default.mv_remap;
+#define KK_MV2(L, R)                                                                                                     \
+      do {                                                                                                               \
+        KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
+                  0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, \
+                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap);                                                        \
+        KK_LAUNCH_CHECK();                                                                                               \
+        return KKAMD_OK;                                                                                                 \
+      } while (0)
+      if (mvk == 3) { if (nvec >= 12) KK_MV2(8, 2); }                      // A/B: 8 lanes x 2 RHS
+      if (mvk == 4) { if (nvec >= 12) KK_MV2(2, 4); }                      // A/B: 2 lanes x 4 RHS (strips of 8)
+      if (nvec >= 12) KK_MV2(4, 4);
+      if (nvec >= 6) KK_MV2(2, 4);
+      if (nvec >= 3) KK_MV2(2, 2);
+      KK_MV2(1, 2);
+#undef KK_MV2
+    }
+  }
   if (nvec >= 12) return launch_mv<OffT, AT, YT, 16>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
   if (nvec >= 6)  return launch_mv<OffT, AT, YT, 8>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
   if (nvec >= 3)  return launch_mv<OffT, AT, YT, 4>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
@@ -770,6 +960,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "stream_variant") t.stream_variant = value;
   else if (k == "wg_per_cu") t.wg_per_cu = value;
   else if (k == "ablate") t.ablate = value;
+  else if (k == "mv_remap") t.mv_remap = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
   return KKAMD_OK;
 }
@@ -849,6 +1040,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   // (the reference's rocSPARSE sub-handle relies on the same property, spmv_handle.hpp:148-152)
   if (plan->d_blk_row) (void)hipFree(plan->d_blk_row);
   if (plan->d_carry) (void)hipFree(plan->d_carry);
+  if (plan->d_xpack) (void)hipFree(plan->d_xpack);
   delete plan;
   return KKAMD_OK;
 }

@@ -113,6 +113,19 @@ def test_spmv_mv_layouts(be, orders):
         pc.check_spmv_mv(be, A23, nv, "N", 1.0, 0.0, orders[0], orders[1], algo="SPMV_DEFAULT")
 
 
+def test_mv_row_major_fast_path_and_packing(be):
+    # row-major X with an even leading dimension -> 16-byte-per-lane kernel; column-major X with a handle -> packed copy
+    A0 = oracle.random_crs(300, 280, 9, variance=6, seed=21)
+    for nv in (2, 3, 4, 6, 7, 8, 12, 16, 17, 24):
+        for orders in ("CC", "CF", "FC", "FF"):
+            pc.check_spmv_mv(be, A0, nv, "N", 1.5, 0.5, orders[0], orders[1], algo="SPMV_DEFAULT")
+            pc.check_spmv_mv(be, A0, nv, "N", 1.0, 0.0, orders[0], orders[1])
+    rows = _custom([700, 0, 3, 300, 1, 1, 0, 40, 260, 255, 257, 5], 200, seed=9)   # rows longer than a 256-nnz staging window
+    for orders in ("CC", "FF"):
+        pc.check_spmv_mv(be, rows, 16, "N", 1.0, 1.0, orders[0], orders[1], algo="SPMV_DEFAULT")
+        pc.check_spmv_mv(be, rows, 5, "N", 2.0, 0.0, orders[0], orders[1], algo="SPMV_DEFAULT")
+
+
 def test_mv_long_rows_chunked_staging(be):
     A0 = _custom([5000, 0, 3, 2500, 1, 1, 0, 40], 300, seed=4)     # rows longer than the 2048-entry LDS chunk
     pc.check_spmv_mv(be, A0, 16, "N", 1.0, 1.0, "C", "C")

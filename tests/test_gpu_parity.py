@@ -148,6 +148,19 @@ def test_spmv_mv_layouts(be, orders):
     pc.check_spmv_mv(be, long_rows, 16, "N", 1.0, 1.0, orders[0], orders[1])
 
 
+def test_mv_row_major_fast_path_and_packing(be):
+    A0 = oracle.random_crs(8000, 7000, 12, variance=9, seed=21)
+    for nv in (2, 3, 4, 6, 7, 8, 12, 16, 17, 24):
+        for orders in ("CC", "CF", "FC", "FF"):
+            pc.check_spmv_mv(be, A0, nv, "N", 1.5, 0.5, orders[0], orders[1], algo="SPMV_DEFAULT")
+    rows = _custom([7000, 0, 3, 300, 1, 1, 0, 40, 260, 255, 257, 5] * 20, 2000, seed=9)
+    for orders in ("CC", "FF"):
+        pc.check_spmv_mv(be, rows, 16, "N", 1.0, 1.0, orders[0], orders[1], algo="SPMV_DEFAULT")
+    L = oracle.laplace3d("FE", 30, 31, 29)
+    for orders in ("CC", "FF"):
+        pc.check_spmv_mv(be, L, 16, "N", 1.0, 0.0, orders[0], orders[1], algo="SPMV_DEFAULT")
+
+
 def test_error_behaviour(be):
     import torch
     A = pc.dev(be, oracle.random_crs(20, 30, 3, seed=2))

@@ -108,12 +108,13 @@ def main():
                 X = torch.randint(-20, 20, (nr, nv), device="cuda", generator=g).double(); Y = torch.zeros(nr, nv, dtype=torch.float64, device="cuda")
             else:
                 X = torch.randint(-20, 20, (nv, nr), device="cuda", generator=g).double().t(); Y = torch.zeros(nv, nr, dtype=torch.float64, device="cuda").t()
-            h = kk.SPMVHandle("SPMV_DEFAULT")
-            med, mn = timeit(lambda: kk.spmv(h, "N", 1.0, A, X, 0.0, Y), max(5, args.iters // 4), warm=1)
-            by = nnz * 12 + (nr + 1) * 4 + 2 * nr * nv * 8
             y1 = torch.empty_like(y); kk.spmv("N", 1.0, A, X[:, 3].contiguous(), 0.0, y1)
-            emit(kind="spmv_mv", n=n, nvec=nv, layout=layout, ms_med=med, ms_min=mn, GBps=by / med / 1e6,
-                 GFLOPs=2 * nnz * nv / med / 1e6, frac_of_8TBps=by / med / 1e6 / 8000, maxdiff_col3=float((Y[:, 3] - y1).abs().max()))
+            by = nnz * 12 + (nr + 1) * 4 + 2 * nr * nv * 8
+            for mvk, rm in ((0, 0), (3, 0), (3, 1)):
+                h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("mv_kernel", mvk); h.set("mv_remap", rm)
+                med, mn = timeit(lambda: kk.spmv(h, "N", 1.0, A, X, 0.0, Y), max(5, args.iters // 4), warm=1)
+                emit(kind="spmv_mv", n=n, nvec=nv, layout=layout, mv_kernel=mvk, mv_remap=rm, ms_med=round(med, 3), ms_min=round(mn, 3), GBps=round(by / med / 1e6, 1),
+                     GFLOPs=round(2 * nnz * nv / med / 1e6, 1), frac_of_8TBps=round(by / med / 1e6 / 8000, 4), maxdiff_col3=float((Y[:, 3] - y1).abs().max()))
             del X, Y
 
     if "spgemm" in what:
