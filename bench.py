@@ -6,6 +6,8 @@
   N > 1   workload C5 family: 600 x 600 x (75*N) grid, 1-D row slabs of 75 z-planes (27,000,000 rows,
           ~7.27e8 nnz) per GPU, so N = 8 is exactly the 600^3 case; a step = RCCL all-gather of the x shards
           over xGMI + the local planned SpMV.  Per-GPU work is fixed: "scaling": "weak".
+          --exchange auto (default) sends only the column-range halo each slab references (one 600^2 plane per
+          neighbour, 5.8 MB per GPU); --exchange allgather moves every shard to every GPU (1.5 GB per GPU at N = 8).
 
 Protocol (mirrors perf_test/sparse/KokkosSparse_kk_spmv.cpp:121-167): inputs generated in HBM, handle/plan
 creation outside the timed region, W warm-ups, then exactly K steps bracketed by barrier + device sync,
@@ -68,6 +70,8 @@ def main():
     ap.add_argument("--algo", default="SPMV_DEFAULT")
     ap.add_argument("--knob", action="append", default=[], help="key=value expert knob for the SpMV plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"],
+                    help="N > 1: how the x entries a slab references reach it (auto = column-range halo when it is smaller)")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,7 +122,7 @@ def main():
     else:
         from kokkos_kernels_amd.dist import DistSpmv
         offsets = [r * rows_per_rank for r in range(world + 1)]
-        op = DistSpmv(A, offsets, rank, algo=args.algo)
+        op = DistSpmv(A, offsets, rank, algo=args.algo, exchange=args.exchange)
         for kv in args.knob:
             k, v = kv.split("="); op.handle.set(k, int(v))
         def step(ev0, ev1):
@@ -174,7 +178,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "rows": nrows_global, "nnz": nnz_global, "rows_per_gpu": rows_per_rank,
                        "alpha": alpha, "beta": beta, "offsets": "int32", "ordinals": "int32", "algorithm": args.algo,
-                       "partition": "1-D row slabs + all-gather(x) over RCCL" if world > 1 else "single GPU",
+                       "partition": ("1-D row slabs; x exchange = %s over RCCL/xGMI, %d bytes received per GPU per SpMV"
+                                     % (op._plan[0], op.exchange_bytes)) if world > 1 else "single GPU",
                        "knobs": args.knob},
             "achieved_hbm_GBps_per_gpu": round(achieved, 1),
             "spmv_kernel_ms": round(kern_ms, 5),

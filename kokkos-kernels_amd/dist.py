@@ -4,7 +4,15 @@ matching shard of x.  One exchange step per SpMV: an all-gather of the x shards 
 process group is "nccl"), then the local planned SpMV.  The reference has no distributed layer at all
 (SURVEY F2); this is the multi-GPU row of the scope table.
 
-One process per GPU (torch.distributed); no data-path collective other than the x all-gather.
+Exchange step.  "allgather": every rank receives every shard (what BASELINE.json's north star names).
+"halo" (default when it moves less than half of that): a rank only needs the x entries its slab's column
+indices reference -- for the column RANGE [cmin, cmax] of the slab it receives, from each peer, the piece of that
+range the peer owns (point-to-point RCCL send/recv, one batch per SpMV).  For a 1-D slab of a 3-D stencil that is
+one grid plane from each neighbour (2 x 600^2 x 8 B = 5.8 MB per rank at 600^3) instead of 1.5 GB; for a matrix
+whose slab touches every column it degenerates to the all-gather.  This is row N1 of SURVEY 8(f) (an importer
+built from the column set of each slab).
+
+One process per GPU (torch.distributed); no other data-path collective.
 """
 import numpy as np
 
@@ -23,7 +31,7 @@ def slab_offsets(nrows, world, align=1):
 
 
 class DistSpmv:
-    def __init__(self, A_local, offsets, rank, group=None, algo="SPMV_DEFAULT", to_backend=None):
+    def __init__(self, A_local, offsets, rank, group=None, algo="SPMV_DEFAULT", to_backend=None, exchange="auto"):
         """A_local: CrsMatrix slab (numRows = offsets[rank+1]-offsets[rank], numCols = global).
         to_backend: converts a torch tensor to what the backend's ptr() accepts (identity for HBM tensors;
         tests on CPU/gloo pass `lambda t: t.numpy()` for the emulator backend)."""
@@ -41,22 +49,79 @@ class DistSpmv:
         self.max_shard = int(sizes.max())
         self.x_full = None
         self._pad = None
+        self.exchange = exchange          # "auto" | "halo" | "allgather"
+        self._plan = None                 # (mode, send list, recv list)
+        self.exchange_bytes = None        # bytes this rank receives per SpMV
+
+    def _entries_minmax(self):
+        ent = self.A.graph.entries
+        if self.A.nnz() == 0:
+            return 0, -1
+        if hasattr(ent, "min") and not isinstance(ent, np.ndarray):
+            return int(ent.min().item()), int(ent.max().item())
+        return int(ent.min()), int(ent.max())
+
+    def _setup_exchange(self, like):
+        """decide halo vs all-gather and build the per-peer segment lists (once per operator)"""
+        torch, dist = self.torch, self.dist
+        n, me, offs = self.offsets[-1], self.rank, self.offsets
+        item = like.element_size()
+        full_bytes = (n - (offs[me + 1] - offs[me])) * item
+        if self.world == 1:
+            self._plan = ("local", [], []); self.exchange_bytes = 0
+            return
+        cmin, cmax = self._entries_minmax()
+        mine = torch.tensor([cmin, cmax], dtype=torch.int64, device=like.device)
+        allr = torch.empty(2 * self.world, dtype=torch.int64, device=like.device)
+        dist.all_gather_into_tensor(allr, mine, group=self.group)
+        allr = allr.cpu().tolist()
+        recv, send = [], []
+        for p in range(self.world):
+            if p == me:
+                continue
+            lo, hi = max(cmin, offs[p]), min(cmax + 1, offs[p + 1])          # what I need from p
+            if hi > lo:
+                recv.append((p, lo, hi))
+            plo, phi = allr[2 * p], allr[2 * p + 1]
+            lo, hi = max(plo, offs[me]), min(phi + 1, offs[me + 1])          # what p needs from me
+            if hi > lo:
+                send.append((p, lo - offs[me], hi - offs[me]))
+        halo_bytes = sum(hi - lo for _, lo, hi in recv) * item
+        # every rank must take the same decision: all-reduce the largest halo fraction
+        frac = torch.tensor([halo_bytes / max(full_bytes, 1)], dtype=torch.float64, device=like.device)
+        dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=self.group)
+        use_halo = self.exchange == "halo" or (self.exchange == "auto" and frac.item() < 0.5)
+        if use_halo:
+            self._plan = ("halo", send, recv); self.exchange_bytes = halo_bytes
+        else:
+            self._plan = ("allgather", [], []); self.exchange_bytes = full_bytes
 
     def _buffers(self, like):
         if self.x_full is None:
             n = self.offsets[-1]
-            if self.equal:
-                self.x_full = self.torch.empty(n, dtype=like.dtype, device=like.device)
-            else:
+            # zero-filled once: entries outside the slab's column range are never read, but must not be garbage NaNs
+            self.x_full = self.torch.zeros(n, dtype=like.dtype, device=like.device)
+            if not self.equal:
                 self._pad = self.torch.empty(self.world * self.max_shard, dtype=like.dtype, device=like.device)
-                self.x_full = self.torch.empty(n, dtype=like.dtype, device=like.device)
         return self.x_full
 
     def gather_x(self, x_shard):
-        """all-gather the shards of x into the full vector every rank needs for its slab"""
+        """make the x entries this rank's slab references available in the full-length buffer"""
         x_full = self._buffers(x_shard)
-        if self.world == 1:
+        if self._plan is None:
+            self._setup_exchange(x_shard)
+        mode, send, recv = self._plan
+        me0, me1 = self.offsets[self.rank], self.offsets[self.rank + 1]
+        if mode == "local":
             x_full.copy_(x_shard)
+        elif mode == "halo":
+            x_full[me0:me1].copy_(x_shard)
+            dist = self.dist
+            ops = [dist.P2POp(dist.isend, x_shard[lo:hi], p, group=self.group) for p, lo, hi in send]
+            ops += [dist.P2POp(dist.irecv, x_full[lo:hi], p, group=self.group) for p, lo, hi in recv]
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
         elif self.equal:
             self.dist.all_gather_into_tensor(x_full, x_shard, group=self.group)
         else:

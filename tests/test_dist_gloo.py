@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, ragged, ret):
+def _worker(rank, world, port, ragged, exchange, ret):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
@@ -39,31 +39,37 @@ def _worker(rank, world, port, ragged, ret):
     ok_gen = np.array_equal(g_rm, rm) and np.array_equal(g_ent, A0.entries[sl]) and np.array_equal(g_val, A0.values[sl])
     rng = np.random.default_rng(0)
     x = rng.random(n); y0 = rng.random(n)
-    op = DistSpmv(A, offs, rank, to_backend=lambda t: t.numpy())
+    op = DistSpmv(A, offs, rank, to_backend=lambda t: t.numpy(), exchange=exchange)
     xs = torch.from_numpy(x[r0:r1].copy()); ys = torch.from_numpy(y0[r0:r1].copy())
     op.apply(2.0, xs, 0.5, ys)
     op.apply(1.0, xs, 0.0, ys.clone())        # second call reuses the plan and gather buffers
     exp = oracle.spmv_serial("N", A0, 2.0, x, 0.5, y0.copy())[r0:r1]
     err = float(np.abs(ys.numpy() - exp).max())
     tol = oracle.spmv_max_error(A0, 2.0, 0.5, max_val=32.0)
-    ret[rank] = (ok_gen, err, tol)
+    ret[rank] = (ok_gen, err, tol, op._plan[0], op.exchange_bytes)
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["auto", "allgather"])
 @pytest.mark.parametrize("ragged", [False, True])
-def test_row_partitioned_spmv_world2(ragged):
+def test_row_partitioned_spmv_world2(ragged, exchange):
     import torch.multiprocessing as mp
     world = 2
-    port = 29500 + (os.getpid() % 2000) + (7 if ragged else 0)
+    port = 29500 + (os.getpid() % 2000) + (7 if ragged else 0) + (13 if exchange == "auto" else 0)
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, port, ragged, ret), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, ragged, exchange, ret), nprocs=world, join=True)
         assert len(ret) == world
         for r in range(world):
-            ok_gen, err, tol = ret[r]
+            ok_gen, err, tol, mode, nbytes = ret[r]
             assert ok_gen, "slab generator mismatch on rank %d" % r
             assert err <= tol, "rank %d: %g > %g" % (r, err, tol)
+            if exchange == "auto" and not ragged:
+                # 9x8x7 grid, slabs of 4 and 3 planes: each rank needs one 72-node plane of its neighbour
+                assert mode == "halo" and nbytes == 72 * 8, (mode, nbytes)
+            if exchange == "allgather":
+                assert mode == "allgather"
 
 
 def test_slab_offsets():
