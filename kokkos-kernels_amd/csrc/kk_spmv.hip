@@ -20,8 +20,10 @@
 //   spmv_mv_kernel      -- rank-2: A rows staged through LDS once per 16-column strip, one lane per
 //       right-hand side, X rows read as contiguous 128 B when X is row-major.
 #include "kk_common.h"
+#include "kk_scan.h"
 #include <new>
 #include <cstring>
+#include <climits>
 
 namespace kk {
 
@@ -32,9 +34,11 @@ struct SpmvTuning {
   int xcd_remap      = 0;  // measured: round-robin tile order (all XCDs sweep the same region) beats XCD-contiguous by ~3-8%
   int nontemporal    = 0;  // measured: no consistent gain from nt loads on the value/column streams
   int mv_kernel      = 0;  // reserved for rank-2 variants
-  int stream_variant = 1;  // 1 lean kernel + quad-dealt gathers (default), 3 lean kernel natural layout, 0 first-generation, 2 wave-private
+  int stream_variant = 1;  // 1 lean kernel + quad-dealt gathers (default), 3 same with natural gather layout,
+                           // 0 first-generation, 2 wave-private tiles, 4 tile-local column structure (kept for A/B)
   int wg_per_cu      = 0;  // unused (persistent variant measured slower and was removed)
   int ablate         = 0;  // bench-only: 1 no x gather, 2 no LDS/reduce, 3 both
+  int lds_pad_kb     = 0;  // bench-only: extra dynamic LDS per workgroup (caps workgroups per CU)
   int mv_remap       = 1;  // rank-2: XCD-contiguous workgroup order (keeps shared X rows in one XCD's L2)
 };
 static SpmvTuning g_spmv_default;
@@ -53,6 +57,13 @@ struct kkamd_spmv_plan {
   void* d_carry = nullptr;       // [2*nblocks] 8-byte slots: head partials, then tail partials
   void* d_xpack = nullptr;       // rank-2: row-major packed copy of a column-major X (grown on demand)
   size_t xpack_bytes = 0;
+  const void* entries = nullptr; // the matrix's column array (identity check + tile-local analysis)
+  // tile-local column structure ("TLC", stream_variant 4): per tile the sorted list of DISTINCT columns and, per
+  // nnz, a 16-bit index into that list.  Built once per matrix; values are still read from the caller's array.
+  int64_t* d_uoff = nullptr;     // [nblocks+1] offsets into d_ucols
+  int32_t* d_ucols = nullptr;    // distinct columns of every tile, ascending within a tile
+  uint16_t* d_lidx = nullptr;    // [nnz] position of each nnz's column in its tile's list
+  int64_t ucols_total = 0;
 };
 
 namespace kk {
@@ -330,7 +341,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
                                                               YT* __restrict__ y, YT alpha, YT beta,
                                                               const int32_t* __restrict__ blk_info,
                                                               YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
-                                                              int remap) {
+                                                              int remap, int ablate) {
+  // ablate (diagnosis knob, 0 in production; results in DESIGN.md 4.1): 4 = no y stores, 8 = no LDS reduction
+  // loop, 16 = synthetic row bounds (no row_map loads), 32 = no barrier
   constexpr int TILE  = kBlock * NPT;
   constexpr int STEPS = NPT / 2;
   __shared__ YT prod[TILE];
@@ -359,11 +372,14 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   bool valid = grp < nv;
   int64_t r  = ra + grp - has_head;
   int64_t rs = 0, re = 0;
-  if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+  if (valid) {
+    if (ablate & 16) { rs = s + (int64_t)grp * 27; re = rs + 27; }
+    else { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+  }
 
   if (full) stage_products<AT, YT, STEPS, true, QP>(x, prod, t, v0, v1, c0, c1);
   else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
-  __syncthreads();
+  if (!(ablate & 32)) __syncthreads();
 
   for (int64_t base = 0; base < nv; base += ngrp) {
     if (base > 0) {
@@ -374,12 +390,16 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
     const bool is_head  = r < ra;
     const bool complete = !is_head && re <= e;
     const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
-    YT sum = valid ? strided_lds_sum<YT>(prod, i0, i1, lane, G) : YT(0);
+    YT sum = valid ? ((ablate & 8) ? prod[i0 < TILE ? i0 : 0] : strided_lds_sum<YT>(prod, i0, i1, lane, G)) : YT(0);
     sum = group_sum(sum, G);
     if (valid && lane == 0) {
       if (is_head) carry_head[b] = sum;
       else if (!complete) carry_tail[b] = sum;
-      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
+      else if (!(ablate & 4)) {
+        sum *= alpha;
+        const YT out = (beta == YT(0)) ? sum : beta * y[r] + sum;
+        y[r] = out;
+      }
     }
   }
 }
@@ -448,6 +468,165 @@ __global__ __launch_bounds__(kBlock) void spmv_wave_kernel(int64_t nnz, int64_t 
     prod[li + 1] = (YT)v1[k] * x1[k];
   }
   KK_WAVE_SYNC();   // the wave's own LDS writes precede its reads (LDS is in-order per wave); no s_barrier
+
+  for (int64_t base = 0; base < nv; base += ngrp) {
+    if (base > 0) {
+      valid = (base + grp) < nv;
+      r     = ra + base + grp - has_head;
+      if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+    }
+    const bool is_head  = r < ra;
+    const bool complete = !is_head && re <= e;
+    const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
+    YT sum = valid ? strided_lds_sum<YT>(prod, i0, i1, lane, G) : YT(0);
+    sum = group_sum(sum, G);
+    if (valid && lane == 0) {
+      if (is_head) carry_head[b] = sum;
+      else if (!complete) carry_tail[b] = sum;
+      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
+    }
+  }
+}
+
+// ---- tile-local column structure (TLC) ----------------------------------------------------------------
+// Sorted distinct columns of tile b in LDS (uniq[0..nd)); returns nd.  keys/uniq: T ints each.
+template <int T>
+__device__ __forceinline__ int tile_sort_unique(const int32_t* __restrict__ entries, int64_t s, int64_t e, int* keys, int* uniq,
+                                                int* s_wave) {
+  const int t = threadIdx.x;
+  constexpr int PER = T / kBlock;
+  for (int i = t; i < T; i += kBlock) keys[i] = (s + i < e) ? entries[s + i] : INT_MAX;
+  __syncthreads();
+  for (int k = 2; k <= T; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < T; i += kBlock) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const int a = keys[i], b = keys[ixj];
+          if ((a > b) == ((i & k) == 0)) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  // each thread owns PER consecutive sorted keys; a key is kept when it differs from its predecessor
+  int cnt = 0;
+  for (int q = 0; q < PER; ++q) {
+    const int i = t * PER + q;
+    const int kv = keys[i];
+    if (kv != INT_MAX && (i == 0 || keys[i - 1] != kv)) ++cnt;
+  }
+  int total;
+  int pos = block_exclusive_scan<int>(cnt, &total, s_wave);
+  for (int q = 0; q < PER; ++q) {
+    const int i = t * PER + q;
+    const int kv = keys[i];
+    if (kv != INT_MAX && (i == 0 || keys[i - 1] != kv)) uniq[pos++] = kv;
+  }
+  __syncthreads();
+  return total;
+}
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void tlc_count_kernel(int64_t nnz, const int32_t* __restrict__ entries, int64_t* __restrict__ uoff) {
+  __shared__ int keys[T];
+  __shared__ int uniq[T];
+  __shared__ int s_wave[kBlock / 64];
+  const int64_t b = blockIdx.x, s = b * T, e = (s + T < nnz) ? s + T : nnz;
+  const int nd = tile_sort_unique<T>(entries, s, e, keys, uniq, s_wave);
+  if (threadIdx.x == 0) { uoff[b] = nd; if (b == (int64_t)gridDim.x - 1) uoff[b + 1] = 0; }
+}
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void tlc_build_kernel(int64_t nnz, const int32_t* __restrict__ entries,
+                                                           const int64_t* __restrict__ uoff, int32_t* __restrict__ ucols,
+                                                           uint16_t* __restrict__ lidx) {
+  __shared__ int keys[T];
+  __shared__ int uniq[T];
+  __shared__ int s_wave[kBlock / 64];
+  const int64_t b = blockIdx.x, s = b * T, e = (s + T < nnz) ? s + T : nnz;
+  const int nd = tile_sort_unique<T>(entries, s, e, keys, uniq, s_wave);
+  const int64_t u0 = uoff[b];
+  for (int j = threadIdx.x; j < nd; j += kBlock) ucols[u0 + j] = uniq[j];
+  for (int64_t i = s + threadIdx.x; i < e; i += kBlock) {
+    const int c = entries[i];
+    int lo = 0, hi = nd;                       // lower bound in uniq (c is present)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (uniq[mid] < c) lo = mid + 1; else hi = mid; }
+    lidx[i] = (uint16_t)lo;
+  }
+}
+
+// Stream kernel over the tile-local column structure: the tile's distinct x entries are fetched ONCE, through
+// an ascending (hence well-coalesced) index list, into an LDS window; the per-nnz gather then reads LDS with a
+// 16-bit local index.  Per nnz this moves 8 B (value) + 2 B (local index) + 4 B per DISTINCT column instead of
+// 8 + 4, and cuts the texture-path lookups ~2-3x on matrices whose neighbouring rows share columns.  A tile with
+// more than XCAP distinct columns (no reuse to exploit) falls back to direct gathers through `entries`.
+template <class OffT, class AT, class YT, int NPT, int XCAP>
+__global__ __launch_bounds__(kBlock) void spmv_stream5_kernel(int64_t nnz, const OffT* __restrict__ row_map,
+                                                              const int32_t* __restrict__ entries,
+                                                              const AT* __restrict__ values, const YT* __restrict__ x,
+                                                              YT* __restrict__ y, YT alpha, YT beta,
+                                                              const int32_t* __restrict__ blk_info,
+                                                              const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucols,
+                                                              const uint16_t* __restrict__ lidx,
+                                                              YT* __restrict__ carry_head, YT* __restrict__ carry_tail) {
+  constexpr int TILE  = kBlock * NPT;
+  constexpr int STEPS = NPT / 2;
+  constexpr int SPAN  = kBlock * 2;
+  using AV = typename vec2<AT>::type;
+  __shared__ YT prod[TILE];
+  __shared__ YT xw[XCAP];
+  const int t     = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int64_t s = b * TILE;
+  const bool full = (s + TILE <= nnz);
+  const int64_t e = full ? s + TILE : nnz;
+  const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
+  const int64_t u0 = uoff[b];
+  const int nd     = (int)(uoff[b + 1] - u0);
+  const bool windowed = full && nd <= XCAP;                // workgroup-uniform
+
+  AT v0[STEPS], v1[STEPS];
+  int c0[STEPS], c1[STEPS];                                // local indices (windowed) or global columns (fallback)
+  if (windowed) {
+    KK_UNROLL
+    for (int k = 0; k < STEPS; ++k) {
+      const int64_t idx = s + (int64_t)k * SPAN + t * 2;
+      const AV vv = *reinterpret_cast<const AV*>(values + idx);
+      const unsigned pr = *reinterpret_cast<const unsigned*>(lidx + idx);     // two 16-bit local indices
+      v0[k] = vv[0]; v1[k] = vv[1]; c0[k] = (int)(pr & 0xffffu); c1[k] = (int)(pr >> 16);
+    }
+    for (int j = t; j < nd; j += kBlock) xw[j] = x[ucols[u0 + j]];
+  } else if (full) {
+    load_tile<AT, STEPS, false, true>(values, entries, s, e, t, v0, v1, c0, c1);
+  } else {
+    load_tile<AT, STEPS, false, false>(values, entries, s, e, t, v0, v1, c0, c1);
+  }
+  const int64_t ra   = info0 & 0x7fffffff;
+  const int64_t rb   = info1 & 0x7fffffff;
+  const int has_head = (info0 >> 31) & 1;
+  const int64_t nv   = (rb - ra) + has_head;
+  int G = 1;
+  while (G < kWave && nv * (G * 2) <= kBlock) G *= 2;
+  const int lane = t & (G - 1), grp = t / G, ngrp = kBlock / G;
+  bool valid = grp < nv;
+  int64_t r  = ra + grp - has_head;
+  int64_t rs = 0, re = 0;
+  if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+
+  if (windowed) {
+    __syncthreads();                                       // x window complete
+    KK_UNROLL
+    for (int k = 0; k < STEPS; ++k) {
+      const int li = k * SPAN + t * 2;
+      prod[li]     = (YT)v0[k] * xw[c0[k]];
+      prod[li + 1] = (YT)v1[k] * xw[c1[k]];
+    }
+  } else if (full) {
+    stage_products<AT, YT, STEPS, true, true>(x, prod, t, v0, v1, c0, c1);
+  } else {
+    stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
+  }
+  __syncthreads();
 
   for (int64_t base = 0; base < nv; base += ngrp) {
     if (base > 0) {
@@ -756,14 +935,19 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
     KK_LAUNCH((spmv_wave_kernel<OffT, AT, YT, NPT, NT>), (unsigned)ceil_div(p->nblocks, kBlock / kWave), kBlock, 0, st, A->nnz,
               p->nblocks, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
               (const int32_t*)p->d_blk_row, ch, ct);
+  } else if (variant == 4 && p->d_lidx && (NPT == 8 || NPT == 4)) {
+    KK_LAUNCH((spmv_stream5_kernel<OffT, AT, YT, NPT, (NPT == 8 ? 1024 : 768)>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+              (const int32_t*)p->d_blk_row, (const int64_t*)p->d_uoff, (const int32_t*)p->d_ucols, (const uint16_t*)p->d_lidx,
+              ch, ct);
   } else if (variant == 3) {
     KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, false>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate);
   } else {
-    KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+    KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true>), (unsigned)p->nblocks, kBlock, (size_t)p->tune.lds_pad_kb * 1024, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate);
   }
   KK_LAUNCH_CHECK();
   KK_LAUNCH((spmv_stream_fixup_kernel<OffT, YT>), (unsigned)ceil_div(p->nblocks, kBlock), kBlock, 0, st, p->nblocks,
@@ -961,6 +1145,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "wg_per_cu") t.wg_per_cu = value;
   else if (k == "ablate") t.ablate = value;
   else if (k == "mv_remap") t.mv_remap = value;
+  else if (k == "lds_pad_kb") t.lds_pad_kb = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
   return KKAMD_OK;
 }
@@ -976,17 +1161,36 @@ static int analyse(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
 static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
   if (p->d_blk_row) { KK_HIP(hipStreamSynchronize(st)); KK_HIP(hipFree(p->d_blk_row)); p->d_blk_row = nullptr; }
   if (p->d_carry) { KK_HIP(hipFree(p->d_carry)); p->d_carry = nullptr; }
+  if (p->d_uoff) { KK_HIP(hipFree(p->d_uoff)); p->d_uoff = nullptr; }
+  if (p->d_ucols) { KK_HIP(hipFree(p->d_ucols)); p->d_ucols = nullptr; }
+  if (p->d_lidx) { KK_HIP(hipFree(p->d_lidx)); p->d_lidx = nullptr; }
   p->tile = 0; p->nblocks = 0;
   if (p->algorithm == KKAMD_SPMV_FAST_SETUP || p->tune.kernel == 1 || A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
   int npt = p->tune.nnz_per_thread;
-  if (npt != 4 && npt != 8 && npt != 16) npt = 16;
+  if (npt != 4 && npt != 8 && npt != 16) npt = (p->tune.stream_variant == 4) ? 8 : 16;
+  if (p->tune.stream_variant == 4 && npt == 16) npt = 8;     // the tile-local structure uses 2048- or 1024-nnz tiles
   if (!(A->value_type == KKAMD_F64)) npt = 8;
   p->tile    = (p->tune.stream_variant == 2 ? kWave : kBlock) * npt;
   p->nblocks = ceil_div(A->nnz, p->tile);
   KK_HIP(hipMalloc((void**)&p->d_blk_row, sizeof(int32_t) * (size_t)(p->nblocks + 1)));
   KK_HIP(hipMalloc(&p->d_carry, (size_t)16 * (size_t)p->nblocks));
-  const int rc = A->offset_type == KKAMD_I64 ? analyse<int64_t>(p, A, st) : analyse<int32_t>(p, A, st);
+  int rc = A->offset_type == KKAMD_I64 ? analyse<int64_t>(p, A, st) : analyse<int32_t>(p, A, st);
   if (rc) return rc;
+  if (p->tune.stream_variant == 4 && p->entries && (npt == 8 || npt == 4) && ((uintptr_t)p->entries % 8 == 0)) {
+    // tile-local column structure: count distinct columns per tile, scan, then emit lists + 16-bit local indices
+    KK_HIP(hipMalloc((void**)&p->d_uoff, sizeof(int64_t) * (size_t)(p->nblocks + 1)));
+    if (npt == 8) { KK_LAUNCH((tlc_count_kernel<2048>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_uoff); }
+    else          { KK_LAUNCH((tlc_count_kernel<1024>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_uoff); }
+    KK_LAUNCH_CHECK();
+    if ((rc = exclusive_scan_inplace<int64_t>(p->d_uoff, p->nblocks + 1, st))) return rc;
+    KK_HIP(hipMemcpyAsync(&p->ucols_total, p->d_uoff + p->nblocks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    KK_HIP(hipMalloc((void**)&p->d_ucols, sizeof(int32_t) * (size_t)(p->ucols_total > 0 ? p->ucols_total : 1)));
+    KK_HIP(hipMalloc((void**)&p->d_lidx, sizeof(uint16_t) * (size_t)(A->nnz + 8)));
+    if (npt == 8) { KK_LAUNCH((tlc_build_kernel<2048>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, (const int64_t*)p->d_uoff, p->d_ucols, p->d_lidx); }
+    else          { KK_LAUNCH((tlc_build_kernel<1024>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, (const int64_t*)p->d_uoff, p->d_ucols, p->d_lidx); }
+    KK_LAUNCH_CHECK();
+  }
   KK_HIP(hipStreamSynchronize(st));   // setup is synchronous, like the vendor analysis it replaces
   return KKAMD_OK;
 }
@@ -1022,6 +1226,7 @@ int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int a
   kkamd_spmv_plan* p = new (std::nothrow) kkamd_spmv_plan();
   if (!p) return kk::fail(KKAMD_ERR_ALLOC, "kkamd_spmv_plan_create: out of host memory");
   p->num_rows = A->num_rows; p->num_cols = A->num_cols; p->nnz = A->nnz; p->row_map = A->d_row_map;
+  p->entries = A->d_entries;
   p->offset_type = A->offset_type; p->algorithm = algorithm; p->tune = kk::g_spmv_default;
   {
     int dev = 0; hipDeviceProp_t prop;
@@ -1041,6 +1246,9 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_blk_row) (void)hipFree(plan->d_blk_row);
   if (plan->d_carry) (void)hipFree(plan->d_carry);
   if (plan->d_xpack) (void)hipFree(plan->d_xpack);
+  if (plan->d_uoff) (void)hipFree(plan->d_uoff);
+  if (plan->d_ucols) (void)hipFree(plan->d_ucols);
+  if (plan->d_lidx) (void)hipFree(plan->d_lidx);
   delete plan;
   return KKAMD_OK;
 }
@@ -1051,7 +1259,7 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
   int rc = kk::set_tuning(plan->tune, key, value);
   if (rc) return rc;
   if (plan->tune.nnz_per_thread != old_npt || plan->tune.kernel != old_kernel ||
-      (plan->tune.stream_variant == 2) != (old_var == 2)) {
+      (plan->tune.stream_variant == 2) != (old_var == 2) || (plan->tune.stream_variant == 4) != (old_var == 4)) {
     // tiling changed: redo the analysis (needs the matrix again; rebuilt lazily from the stored row_map)
     kkamd_crs_t A{};
     A.num_rows = plan->num_rows; A.num_cols = plan->num_cols; A.nnz = plan->nnz; A.d_row_map = plan->row_map;

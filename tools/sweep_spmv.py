@@ -77,9 +77,9 @@ def main():
                 med, mn = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y), args.iters)
                 emit(kind="spmv_vector", n=n, lpr=lpr, xcd_remap=remap, ms_med=med, ms_min=mn, GBps=bytes0 / med / 1e6,
                      GFLOPs=2 * nnz / med / 1e6, maxdiff=float((y - ref).abs().max()))
-        variants = [(0, 0, 0), (3, 0, 0), (1, 0, 0)]
-        for npt in (4, 8, 16):
-            for nt in (0, 1):
+        variants = [(1, 0, 0), (5, 4, 0), (5, 5, 0), (5, 6, 0), (5, 8, 0)]
+        for npt in (8, 16):
+            for nt in (0,):
                 for var, wg, remap in variants:
                     h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("nnz_per_thread", npt); h.set("nontemporal", nt); h.set("xcd_remap", remap)
                     h.set("stream_variant", var); h.set("wg_per_cu", wg)
@@ -95,11 +95,10 @@ def main():
 
     if "ablate" in what:
         for npt in (8, 16):
-            for nt in (0, 1):
-                for abl in (0, 1, 2, 3):
-                    h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("nnz_per_thread", npt); h.set("nontemporal", nt); h.set("xcd_remap", 0); h.set("ablate", abl)
-                    med, mn = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y), args.iters)
-                    emit(kind="spmv_ablate", npt=npt, nt=nt, ablate=abl, ms_med=round(med, 4), ms_min=round(mn, 4), GBps=round(bytes0 / med / 1e6, 1))
+            for abl in (0, 1024, 2048, 0):
+                h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("nnz_per_thread", npt); h.set("stream_variant", 1); h.set("ablate", abl)
+                med, mn = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y), args.iters)
+                emit(kind="spmv_ablate", npt=npt, ablate=abl, ms_med=round(med, 4), ms_min=round(mn, 4), GBps=round(bytes0 / med / 1e6, 1))
 
     if "mv" in what:
         nv = 16
