@@ -30,8 +30,11 @@
 
 #ifdef KK_EMU
 #define KK_ATOMIC_FADD(p, v) atomicAdd((p), (v))
+#define KK_LOAD_L2(p) (*(p))
 #else
 #define KK_ATOMIC_FADD(p, v) unsafeAtomicAdd((p), (v))   // hardware global_atomic_add_f64 / ds_add_f64
+// agent-scope relaxed load: global_load ... sc1, served by L2 (where the atomics were performed), never by a stale L1 line
+#define KK_LOAD_L2(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif
 
 namespace kk {
@@ -201,16 +204,19 @@ __global__ __launch_bounds__(kBlock) void spgemm_sym_block_kernel(int64_t nbin, 
   (void)nbin;
 }
 
-// dense rows: one k-bit bitmap per workgroup in HBM (zero on entry, zero again on exit).
+// dense rows: one k-bit bitmap per workgroup in HBM (zero on entry, zero again on exit).  Columns are set with L2
+// atomics; the count pass then reads the touched range with L2-served 64-bit loads (one contiguous chunk per lane,
+// no per-word atomics, one barrier) and clears what it found with plain stores.
+typedef unsigned long long kk_u64;
 template <class OffT>
 __global__ __launch_bounds__(kBlock) void spgemm_sym_dense_kernel(int64_t nbin, const int32_t* __restrict__ perm,
                                                                   const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                   const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
-                                                                  OffT* __restrict__ counts, unsigned* __restrict__ bitmaps,
+                                                                  OffT* __restrict__ counts, kk_u64* __restrict__ bitmaps,
                                                                   int64_t words, int sg_log2) {
   __shared__ int s_min, s_max, s_count;
-  const int t   = threadIdx.x;
-  unsigned* bm  = bitmaps + (int64_t)blockIdx.x * words;
+  const int t  = threadIdx.x;
+  kk_u64* bm   = bitmaps + (int64_t)blockIdx.x * words;
   for (int64_t ri = blockIdx.x; ri < nbin; ri += gridDim.x) {
     const int64_t row = perm[ri];
     if (t == 0) { s_min = INT_MAX; s_max = -1; s_count = 0; }
@@ -218,14 +224,20 @@ __global__ __launch_bounds__(kBlock) void spgemm_sym_dense_kernel(int64_t nbin, 
     int cmin = INT_MAX, cmax = -1;
     for_each_product<OffT>(row, rmA, entA, rmB, t, kBlock, sg_log2, [&](int64_t, int64_t j) {
       const int c = entB[j];
-      atomicOr(&bm[c >> 5], 1u << (c & 31));
+      atomicOr(&bm[c >> 6], 1ull << (c & 63));
       cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
     });
     if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
     __syncthreads();
     int cnt = 0;
-    if (s_max >= 0)
-      for (int64_t wd = (s_min >> 5) + t; wd <= (s_max >> 5); wd += kBlock) cnt += __popc(atomicExch(&bm[wd], 0u));
+    if (s_max >= 0) {
+      const int64_t w_lo = s_min >> 6, nw = (s_max >> 6) - w_lo + 1, per = (nw + kBlock - 1) / kBlock;
+      const int64_t a = w_lo + t * per, z = (a + per < w_lo + nw) ? a + per : w_lo + nw;
+      for (int64_t wd = a; wd < z; ++wd) {
+        const kk_u64 v = KK_LOAD_L2(&bm[wd]);
+        if (v) { cnt += __popcll(v); bm[wd] = 0ull; }
+      }
+    }
     cnt = group_sum(cnt, 64);
     if ((t & 63) == 0 && cnt) atomicAdd(&s_count, cnt);
     __syncthreads();
@@ -310,28 +322,31 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_block_kernel(int64_t nbin, 
   (void)nbin;
 }
 
-template <class VT> __device__ __forceinline__ VT atomic_take(VT* p);
-template <> __device__ __forceinline__ double atomic_take<double>(double* p) {
-  return __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(p), 0ull));
+// dense rows: bitmap + dense accumulator per workgroup in HBM.  Each lane owns one contiguous chunk of the touched
+// bitmap range: pass 1 counts its set bits, one workgroup scan turns the counts into output offsets, pass 2 walks
+// the chunk again and emits (column, value) pairs in ascending order -- sorted output without a sort.  Bitmap and
+// accumulator are read with L2-served loads (the atomics that built them were performed in L2) and cleared with
+// plain stores; the closing barrier (s_waitcnt vmcnt(0) + s_barrier) orders those stores before the next row.
+template <class VT> __device__ __forceinline__ VT load_l2(const VT* p);
+template <> __device__ __forceinline__ double load_l2<double>(const double* p) {
+  return __longlong_as_double((long long)KK_LOAD_L2(reinterpret_cast<const kk_u64*>(p)));
 }
-template <> __device__ __forceinline__ float atomic_take<float>(float* p) {
-  return __int_as_float((int)atomicExch(reinterpret_cast<unsigned*>(p), 0u));
+template <> __device__ __forceinline__ float load_l2<float>(const float* p) {
+  return __int_as_float((int)KK_LOAD_L2(reinterpret_cast<const unsigned*>(p)));
 }
-
-// dense rows: bitmap + dense accumulator per workgroup in HBM; the in-order bitmap walk emits sorted columns.
 template <class OffT, class VT>
 __global__ __launch_bounds__(kBlock) void spgemm_num_dense_kernel(int64_t nbin, const int32_t* __restrict__ perm,
                                                                   const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                   const VT* __restrict__ valA, const OffT* __restrict__ rmB,
                                                                   const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                   const OffT* __restrict__ rmC, int32_t* __restrict__ entC,
-                                                                  VT* __restrict__ valC, unsigned* __restrict__ bitmaps,
+                                                                  VT* __restrict__ valC, kk_u64* __restrict__ bitmaps,
                                                                   VT* __restrict__ accs, int64_t words, int64_t k, int sg_log2) {
   __shared__ int s_min, s_max;
   __shared__ int s_wave[kBlock / 64];
-  const int t  = threadIdx.x;
-  unsigned* bm = bitmaps + (int64_t)blockIdx.x * words;
-  VT* acc      = accs + (int64_t)blockIdx.x * k;
+  const int t = threadIdx.x;
+  kk_u64* bm  = bitmaps + (int64_t)blockIdx.x * words;
+  VT* acc     = accs + (int64_t)blockIdx.x * k;
   for (int64_t ri = blockIdx.x; ri < nbin; ri += gridDim.x) {
     const int64_t row = perm[ri];
     if (t == 0) { s_min = INT_MAX; s_max = -1; }
@@ -339,30 +354,34 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_dense_kernel(int64_t nbin, 
     int cmin = INT_MAX, cmax = -1;
     for_each_product<OffT>(row, rmA, entA, rmB, t, kBlock, sg_log2, [&](int64_t a, int64_t j) {
       const int c = entB[j];
-      atomicOr(&bm[c >> 5], 1u << (c & 31));
+      atomicOr(&bm[c >> 6], 1ull << (c & 63));
       KK_ATOMIC_FADD(&acc[c], valA[a] * valB[j]);
       cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
     });
     if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
     __syncthreads();
-    int64_t pos_base = (int64_t)rmC[row];
+    int64_t a = 0, z = 0;
+    int cnt = 0;
     if (s_max >= 0) {
-      const int64_t w_lo = s_min >> 5, w_hi = s_max >> 5;
-      for (int64_t w0 = w_lo; w0 <= w_hi; w0 += kBlock) {
-        const int64_t wd = w0 + t;
-        unsigned v       = (wd <= w_hi) ? atomicExch(&bm[wd], 0u) : 0u;
-        int tot;
-        const int excl = block_exclusive_scan<int>(__popc(v), &tot, s_wave);
-        int64_t pos    = pos_base + excl;
-        while (v) {
-          const int bit = __ffs(v) - 1;
-          const int c   = (int)(wd * 32 + bit);
-          entC[pos]     = c;
-          valC[pos]     = atomic_take<VT>(&acc[c]);
-          ++pos;
-          v &= v - 1;
-        }
-        pos_base += tot;
+      const int64_t w_lo = s_min >> 6, nw = (s_max >> 6) - w_lo + 1, per = (nw + kBlock - 1) / kBlock;
+      a = w_lo + t * per; z = (a + per < w_lo + nw) ? a + per : w_lo + nw;
+      for (int64_t wd = a; wd < z; ++wd) cnt += __popcll(KK_LOAD_L2(&bm[wd]));
+    }
+    int tot;
+    const int excl = block_exclusive_scan<int>(cnt, &tot, s_wave);
+    int64_t pos    = (int64_t)rmC[row] + excl;
+    for (int64_t wd = a; wd < z; ++wd) {
+      kk_u64 v = KK_LOAD_L2(&bm[wd]);
+      if (!v) continue;
+      bm[wd] = 0ull;
+      while (v) {
+        const int bit = __ffsll(v) - 1;
+        const int c   = (int)(wd * 64 + bit);
+        entC[pos]     = c;
+        valC[pos]     = load_l2<VT>(&acc[c]);
+        acc[c]        = VT(0);
+        ++pos;
+        v &= v - 1;
       }
     }
     __syncthreads();
@@ -413,13 +432,13 @@ static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLi
   return KKAMD_OK;
 }
 
-// number of dense-row workgroups and their workspace, bounded to 1/4 of free HBM (and 128 workgroups)
+// number of dense-row workgroups and their workspace, bounded to 1/4 of free HBM (and 2048 workgroups = 8 per CU)
 static int dense_geometry(int64_t nrows_dense, int64_t bytes_per_wg, int* nwg) {
   size_t free_b = 0, total_b = 0;
   KK_HIP(hipMemGetInfo(&free_b, &total_b));
   int64_t cap = (int64_t)(free_b / 4) / (bytes_per_wg > 0 ? bytes_per_wg : 1);
   if (cap < 1) return fail(KKAMD_ERR_ALLOC, "spgemm: not enough device memory for one dense accumulator (%lld bytes)", (long long)bytes_per_wg);
-  int64_t g = nrows_dense < 128 ? nrows_dense : 128;
+  int64_t g = nrows_dense < 2048 ? nrows_dense : 2048;
   if (g > cap) g = cap;
   *nwg = (int)g;
   return KKAMD_OK;
@@ -454,13 +473,13 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
                        (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
   if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL>), (unsigned)nb(3), kBlock, 0, st, nb(3),
                        (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
-  unsigned* d_bm = nullptr;
+  kk_u64* d_bm = nullptr;
   if (nb(4)) {
-    const int64_t words = ceil_div(k, 32);
+    const int64_t words = ceil_div(k, 64);
     int nwg = 1;
-    if ((rc = dense_geometry(nb(4), words * 4, &nwg))) return rc;
-    KK_HIP(hipMalloc((void**)&d_bm, (size_t)words * 4 * (size_t)nwg));
-    KK_HIP(hipMemsetAsync(d_bm, 0, (size_t)words * 4 * (size_t)nwg, st));
+    if ((rc = dense_geometry(nb(4), words * 8, &nwg))) return rc;
+    KK_HIP(hipMalloc((void**)&d_bm, (size_t)words * 8 * (size_t)nwg));
+    KK_HIP(hipMemsetAsync(d_bm, 0, (size_t)words * 8 * (size_t)nwg, st));
     KK_LAUNCH((spgemm_sym_dense_kernel<OffT>), (unsigned)nwg, kBlock, 0, st, nb(4), (const int32_t*)(h->d_perm + off.off[4]),
               rmA, entA, rmB, entB, rmC, d_bm, words, sg);
   }
@@ -500,14 +519,14 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
                        (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
   if (nb(3)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkL>), (unsigned)nb(3), kBlock, 0, st, nb(3),
                        (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
-  unsigned* d_bm = nullptr; VT* d_acc = nullptr;
+  kk_u64* d_bm = nullptr; VT* d_acc = nullptr;
   if (nb(4)) {
-    const int64_t words = ceil_div(k, 32);
+    const int64_t words = ceil_div(k, 64);
     int nwg = 1;
-    if ((rc = dense_geometry(nb(4), words * 4 + k * (int64_t)sizeof(VT), &nwg))) return rc;
-    KK_HIP(hipMalloc((void**)&d_bm, (size_t)words * 4 * (size_t)nwg));
+    if ((rc = dense_geometry(nb(4), words * 8 + k * (int64_t)sizeof(VT), &nwg))) return rc;
+    KK_HIP(hipMalloc((void**)&d_bm, (size_t)words * 8 * (size_t)nwg));
     KK_HIP(hipMalloc((void**)&d_acc, (size_t)k * sizeof(VT) * (size_t)nwg));
-    KK_HIP(hipMemsetAsync(d_bm, 0, (size_t)words * 4 * (size_t)nwg, st));
+    KK_HIP(hipMemsetAsync(d_bm, 0, (size_t)words * 8 * (size_t)nwg, st));
     KK_HIP(hipMemsetAsync(d_acc, 0, (size_t)k * sizeof(VT) * (size_t)nwg, st));
     KK_LAUNCH((spgemm_num_dense_kernel<OffT, VT>), (unsigned)nwg, kBlock, 0, st, nb(4), (const int32_t*)(h->d_perm + off.off[4]),
               rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, d_bm, d_acc, words, k, sg);
