@@ -47,6 +47,9 @@ template <class T> __device__ __forceinline__ T group_sum(T v, int width) {
   return v;
 }
 
+// knobs whose key starts with "spgemm_" (kk_spgemm.hip); reached through kkamd_set_default
+int spgemm_set_default(const char* key, int value);
+
 template <class T> struct scalar_tag;
 template <> struct scalar_tag<float>  { static constexpr int value = KKAMD_F32; };
 template <> struct scalar_tag<double> { static constexpr int value = KKAMD_F64; };

@@ -4,8 +4,11 @@
 #pragma once
 #ifdef KK_EMU
 #include "kk_emu.h"
-#define KK_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  kk_emu::launch(dim3(grid), dim3(block), (size_t)(smem), [=]() { kernel(__VA_ARGS__); })
+#define KK_LAUNCH(kernel, grid, block, smem, stream, ...)                                   \
+  do {                                                                                     \
+    if (std::getenv("KK_EMU_TRACE")) std::fprintf(stderr, "kk_emu: launch %s\n", #kernel); \
+    kk_emu::launch(dim3(grid), dim3(block), (size_t)(smem), [=]() { kernel(__VA_ARGS__); }); \
+  } while (0)
 #define KK_NT_LOAD(p) (*(p))
 #define KK_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(kk_emu::S().dyn_smem)
 #define KK_DEVICE_ONLY(...)

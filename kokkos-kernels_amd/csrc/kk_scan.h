@@ -5,9 +5,9 @@
 
 namespace kk {
 
-// Exclusive scan of one value per work-item across a 256-thread workgroup (4 waves of 64).
-// s_wave: 4 shared slots.  Every thread of the workgroup must call it.  *total = workgroup sum.
-template <class T> __device__ __forceinline__ T block_exclusive_scan(T v, T* total, T* s_wave) {
+// Exclusive scan of one value per work-item across an NT-thread workgroup (NT/64 waves).
+// s_wave: NT/64 shared slots.  Every thread of the workgroup must call it.  *total = workgroup sum.
+template <class T, int NT> __device__ __forceinline__ T block_exclusive_scan_n(T v, T* total, T* s_wave) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   T inc = v;
   for (int o = 1; o < 64; o <<= 1) {
@@ -18,9 +18,12 @@ template <class T> __device__ __forceinline__ T block_exclusive_scan(T v, T* tot
   if (lane == 63) s_wave[w] = inc;
   __syncthreads();
   T base = T(0), tot = T(0);
-  for (int i = 0; i < kBlock / 64; ++i) { const T sv = s_wave[i]; if (i < w) base += sv; tot += sv; }
+  for (int i = 0; i < NT / 64; ++i) { const T sv = s_wave[i]; if (i < w) base += sv; tot += sv; }
   *total = tot;
   return base + inc - v;
+}
+template <class T> __device__ __forceinline__ T block_exclusive_scan(T v, T* total, T* s_wave) {
+  return block_exclusive_scan_n<T, kBlock>(v, total, s_wave);
 }
 
 constexpr int kScanItems = 8;                      // consecutive items per thread

@@ -27,6 +27,7 @@
 #include "kk_scan.h"
 #include <climits>
 #include <new>
+#include <string>
 
 #ifdef KK_EMU
 #define KK_ATOMIC_FADD(p, v) atomicAdd((p), (v))
@@ -41,13 +42,30 @@ namespace kk {
 
 constexpr int kNumBins   = 5;      // 0 empty, 1 wave, 2 block-small, 3 block-large, 4 dense
 constexpr int kHashMul   = 107;
-constexpr int kWaveTable = 512;
+constexpr int kSymWaveTable = 2048;   // symbolic keys only: 8 KB per wave
+constexpr int kWaveTable = 512;       // numeric keys + values
 constexpr int kSymBlkS = 4096,  kSymBlkL = 32768;
 constexpr int kNumBlkS = 4096,  kNumBlkL = 8192;
+constexpr int kDenseBlock = 1024;     // dense-row column kernel: 16 waves around one LDS bitmap
+constexpr int kValBlock   = 512;      // dense-row value kernel
+constexpr int kValTable   = 4096;     // value-window hash table (16 KB keys + 32 KB fp64 sums in LDS: 3 workgroups per CU)
+constexpr int kValCap     = kValTable / 2;   // C entries per value window
+constexpr int kValLa      = 512;      // A entries of a row whose B cursors live in LDS (10 KB)
+constexpr int kValLong    = 128;      // B rows at least this long are streamed by a whole wave
+
+struct SpgemmTuning {
+  int win_bits       = 1 << 20;   // columns per LDS bitmap window (128 KB); rows wider than this take several passes
+  int val_cap        = kValCap;   // C entries per value window
+  int force_unsorted = 0;         // test hook: treat B as unsorted (dense rows accumulate in HBM)
+  int debug          = 0;         // bench-only ablation bits for the dense-row kernels
+};
+static SpgemmTuning g_spgemm;
 
 struct BinLimits { int64_t lim[kNumBins - 1]; };   // size <= lim[b] -> bin b  (lim[0] = 0)
-static const BinLimits kSymLimits = {{0, kWaveTable / 2, kSymBlkS / 2, kSymBlkL / 2}};
+static const BinLimits kSymLimits = {{0, (kSymWaveTable * 2) / 3, kSymBlkS / 2, kSymBlkL / 2}};
 static const BinLimits kNumLimits = {{0, kWaveTable / 2, kNumBlkS / 2, (kNumBlkL * 2) / 3}};
+// B sorted: everything above the small block table goes to the column + windowed value kernels (no 8192-slot bitonic sort)
+static const BinLimits kNumLimitsSorted = {{0, kWaveTable / 2, kNumBlkS / 2, kNumBlkS / 2}};
 
 __host__ __device__ __forceinline__ int bin_of(int64_t size, const BinLimits& L) {
   if (size <= L.lim[0]) return 0;
@@ -66,24 +84,47 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
                                                               const int32_t* __restrict__ entA,
                                                               const OffT* __restrict__ rmB, int64_t* __restrict__ flops,
                                                               unsigned long long* __restrict__ stats /*[0]=total,[1]=max*/) {
-  const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 8;
-  const int lane    = threadIdx.x & 7;
-  long long f       = 0;
-  if (row < m)
-    for (int64_t a = (int64_t)rmA[row] + lane; a < (int64_t)rmA[row + 1]; a += 8) {
-      const int32_t c = entA[a];
-      f += (long long)rmB[c + 1] - (long long)rmB[c];
-    }
-  f = group_sum(f, 8);
-  if (row < m && lane == 0) flops[row] = f;
-  long long contrib = (row < m && lane == 0) ? f : 0;
-  long long mx      = contrib;
-  contrib           = group_sum(contrib, 64);
+  __shared__ unsigned long long s_sum, s_max;
+  if (threadIdx.x == 0) { s_sum = 0; s_max = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 7;
+  long long sum = 0, mx = 0;      // per work-item partials over the grid-stride loop: two global atomics per workgroup
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 8);
+  for (int64_t r0 = (int64_t)blockIdx.x * (kBlock / 8); r0 < m; r0 += stride) {     // workgroup-uniform trip count
+    const int64_t row = r0 + threadIdx.x / 8;
+    long long f = 0;
+    if (row < m)
+      for (int64_t a = (int64_t)rmA[row] + lane; a < (int64_t)rmA[row + 1]; a += 8) {
+        const int32_t c = entA[a];
+        f += (long long)rmB[c + 1] - (long long)rmB[c];
+      }
+    f = group_sum(f, 8);
+    if (row < m && lane == 0) { flops[row] = f; sum += f; mx = f > mx ? f : mx; }
+  }
+  sum = group_sum(sum, 64);
   for (int o = 32; o > 0; o >>= 1) { const long long other = __shfl_xor(mx, o, 64); mx = other > mx ? other : mx; }
   if ((threadIdx.x & 63) == 0) {
-    if (contrib) atomicAdd(&stats[0], (unsigned long long)contrib);
-    if (mx) atomicMax(&stats[1], (unsigned long long)mx);
+    if (sum) atomicAdd(&s_sum, (unsigned long long)sum);
+    if (mx) atomicMax(&s_max, (unsigned long long)mx);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_sum) atomicAdd(&stats[0], s_sum);
+    if (s_max) atomicMax(&stats[1], s_max);
+  }
+}
+
+// are the rows of a CRS graph column-sorted (non-strict)?  8 lanes per row; *unsorted is set to 1 otherwise.
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void rows_sorted_kernel(int64_t n, const OffT* __restrict__ rm,
+                                                             const int32_t* __restrict__ ent, int* __restrict__ unsorted) {
+  const int lane = threadIdx.x & 7;
+  bool bad = false;
+  for (int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 8; row < n; row += (int64_t)gridDim.x * (kBlock / 8)) {
+    const int64_t e = (int64_t)rm[row + 1];
+    for (int64_t j = (int64_t)rm[row] + lane; j + 1 < e; j += 8) bad |= ent[j] > ent[j + 1];
+  }
+  if (bad) *unsorted = 1;
 }
 
 // row size of C from its row_map (numeric binning)
@@ -143,17 +184,55 @@ template <class VT> __device__ __forceinline__ void hash_accumulate(int* keys, V
   }
 }
 
-// Visit every product column of A(row,:)*B with `nthreads` cooperating work-items (id tid):
-// sub-groups of 2^sg_log2 lanes share an A entry and stride over that B row.
+// Visit every product column of A(row,:)*B with `nthreads` cooperating work-items (id tid): sub-groups of 2^s lanes
+// share an A entry and stride over that B row.  s is at least sg_log2 (the matrix-wide hint: average B row length) and
+// grows for rows of A with few entries so that the sub-groups (nthreads >> s of them) just cover the row -- a row with
+// 13 entries handled by 1024 work-items runs 16 sub-groups of 64 lanes instead of leaving 115 of 128 idle.
+// Each lane issues kProdUnroll independent B loads per step (a step is latency-bound otherwise): f(a, j, column).
+constexpr int kProdUnroll = 4;
 template <class OffT, class F>
 __device__ __forceinline__ void for_each_product(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
-                                                 const OffT* __restrict__ rmB, int tid, int nthreads, int sg_log2, F f) {
+                                                 const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, int tid,
+                                                 int nthreads, int sg_log2, F f) {
+  const int64_t a_beg = (int64_t)rmA[row], a_end = (int64_t)rmA[row + 1];
+  while ((int64_t)(nthreads >> (sg_log2 + 1)) >= a_end - a_beg && (2 << sg_log2) <= nthreads) ++sg_log2;
   const int sg = 1 << sg_log2, sub = tid >> sg_log2, nsub = nthreads >> sg_log2, sl = tid & (sg - 1);
-  const int64_t a_end = (int64_t)rmA[row + 1];
-  for (int64_t a = (int64_t)rmA[row] + sub; a < a_end; a += nsub) {
+  for (int64_t a = a_beg + sub; a < a_end; a += nsub) {
     const int32_t c    = entA[a];
     const int64_t b_end = (int64_t)rmB[c + 1];
-    for (int64_t j = (int64_t)rmB[c] + sl; j < b_end; j += sg) f(a, j);
+    for (int64_t j = (int64_t)rmB[c] + sl; j < b_end; j += (int64_t)sg * kProdUnroll) {
+      int col[kProdUnroll];
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u) { const int64_t ju = j + (int64_t)u * sg; col[u] = ju < b_end ? entB[ju] : -1; }
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u) if (col[u] >= 0) f(a, j + (int64_t)u * sg, col[u]);
+    }
+  }
+}
+// same with the B value loaded alongside the column: f(a, column, value of B)
+template <class OffT, class VT, class F>
+__device__ __forceinline__ void for_each_product_v(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                   const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                   const VT* __restrict__ valB, int tid, int nthreads, int sg_log2, F f) {
+  const int64_t a_beg = (int64_t)rmA[row], a_end = (int64_t)rmA[row + 1];
+  while ((int64_t)(nthreads >> (sg_log2 + 1)) >= a_end - a_beg && (2 << sg_log2) <= nthreads) ++sg_log2;
+  const int sg = 1 << sg_log2, sub = tid >> sg_log2, nsub = nthreads >> sg_log2, sl = tid & (sg - 1);
+  for (int64_t a = a_beg + sub; a < a_end; a += nsub) {
+    const int32_t c    = entA[a];
+    const int64_t b_end = (int64_t)rmB[c + 1];
+    for (int64_t j = (int64_t)rmB[c] + sl; j < b_end; j += (int64_t)sg * kProdUnroll) {
+      int col[kProdUnroll];
+      VT bv[kProdUnroll];
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u) {
+        const int64_t ju = j + (int64_t)u * sg;
+        const bool ok    = ju < b_end;
+        col[u] = ok ? entB[ju] : -1;
+        bv[u]  = ok ? valB[ju] : VT(0);
+      }
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u) if (col[u] >= 0) f(a, col[u], bv[u]);
+    }
   }
 }
 
@@ -164,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_sym_wave_kernel(int64_t nbin, c
                                                                  const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                  const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
                                                                  OffT* __restrict__ counts, int sg_log2) {
-  constexpr int H = kWaveTable;
+  constexpr int H = kSymWaveTable;
   __shared__ int tab[kBlock / 64][H];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
@@ -175,15 +254,15 @@ __global__ __launch_bounds__(kBlock) void spgemm_sym_wave_kernel(int64_t nbin, c
   if (idx < nbin) {
     row = perm[idx];
     int* mytab = tab[w];
-    for_each_product<OffT>(row, rmA, entA, rmB, lane, 64, sg_log2,
-                           [&](int64_t, int64_t j) { cnt += hash_insert_key(mytab, H - 1, entB[j]) ? 1 : 0; });
+    for_each_product<OffT>(row, rmA, entA, rmB, entB, lane, 64, sg_log2,
+                           [&](int64_t, int64_t, int c) { cnt += hash_insert_key(mytab, H - 1, c) ? 1 : 0; });
   }
   cnt = group_sum(cnt, 64);
   if (idx < nbin && lane == 0) counts[row] = (OffT)cnt;
 }
 
-template <class OffT, int H>
-__global__ __launch_bounds__(kBlock) void spgemm_sym_block_kernel(int64_t nbin, const int32_t* __restrict__ perm,
+template <class OffT, int H, int NT>
+__global__ __launch_bounds__(NT) void spgemm_sym_block_kernel(int64_t nbin, const int32_t* __restrict__ perm,
                                                                   const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                   const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
                                                                   OffT* __restrict__ counts, int sg_log2) {
@@ -191,12 +270,12 @@ __global__ __launch_bounds__(kBlock) void spgemm_sym_block_kernel(int64_t nbin, 
   __shared__ int s_count;
   const int t = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
-  for (int i = t; i < H; i += kBlock) tab[i] = -1;
+  for (int i = t; i < H; i += NT) tab[i] = -1;
   if (t == 0) s_count = 0;
   __syncthreads();
   int cnt = 0;
-  for_each_product<OffT>(row, rmA, entA, rmB, t, kBlock, sg_log2,
-                         [&](int64_t, int64_t j) { cnt += hash_insert_key(tab, H - 1, entB[j]) ? 1 : 0; });
+  for_each_product<OffT>(row, rmA, entA, rmB, entB, t, NT, sg_log2,
+                         [&](int64_t, int64_t, int c) { cnt += hash_insert_key(tab, H - 1, c) ? 1 : 0; });
   cnt = group_sum(cnt, 64);
   if ((t & 63) == 0 && cnt) atomicAdd(&s_count, cnt);
   __syncthreads();
@@ -204,46 +283,63 @@ __global__ __launch_bounds__(kBlock) void spgemm_sym_block_kernel(int64_t nbin, 
   (void)nbin;
 }
 
-// dense rows: one k-bit bitmap per workgroup in HBM (zero on entry, zero again on exit).  Columns are set with L2
-// atomics; the count pass then reads the touched range with L2-served 64-bit loads (one contiguous chunk per lane,
-// no per-word atomics, one barrier) and clears what it found with plain stores.
+// dense rows, columns: one workgroup of 16 waves per row around a k-bit bitmap in LDS (up to 2^20 columns = 128 KB
+// per pass; wider products take ceil(k / win_bits) passes over the row's products).  Columns are set with ds_or_b64,
+// then the touched word range is walked 1024 words at a time: popcount, workgroup scan, and -- when EMIT -- the set
+// bits are written out in ascending order, so entries(C) for the row leave the kernel column-sorted.  EMIT = false is
+// the symbolic count; EMIT = true fills entries(C) in the numeric phase (the value kernel below needs them).
 typedef unsigned long long kk_u64;
-template <class OffT>
-__global__ __launch_bounds__(kBlock) void spgemm_sym_dense_kernel(int64_t nbin, const int32_t* __restrict__ perm,
-                                                                  const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
-                                                                  const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
-                                                                  OffT* __restrict__ counts, kk_u64* __restrict__ bitmaps,
-                                                                  int64_t words, int sg_log2) {
-  __shared__ int s_min, s_max, s_count;
-  const int t  = threadIdx.x;
-  kk_u64* bm   = bitmaps + (int64_t)blockIdx.x * words;
-  for (int64_t ri = blockIdx.x; ri < nbin; ri += gridDim.x) {
-    const int64_t row = perm[ri];
-    if (t == 0) { s_min = INT_MAX; s_max = -1; s_count = 0; }
+template <class OffT, bool EMIT>
+__global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const int32_t* __restrict__ perm,
+                                                                        const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                        const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                                        OffT* __restrict__ counts, const OffT* __restrict__ rmC,
+                                                                        int32_t* __restrict__ entC, int64_t k, int win_bits,
+                                                                        int sg_log2, int debug) {
+  KK_DYN_SMEM(kk_u64, bm);
+  __shared__ int s_min, s_max;
+  __shared__ int s_wave[kDenseBlock / 64];
+  const int t       = threadIdx.x;
+  const int64_t row = perm[blockIdx.x];
+  int64_t total     = 0;
+  for (int64_t c0 = 0; c0 < k; c0 += win_bits) {
+    const int nbits  = (int)((k - c0 < (int64_t)win_bits) ? k - c0 : (int64_t)win_bits);
+    const int nwords = (nbits + 63) >> 6;
+    for (int i = t; i < nwords; i += kDenseBlock) bm[i] = 0ull;
+    if (t == 0) { s_min = INT_MAX; s_max = -1; }
     __syncthreads();
     int cmin = INT_MAX, cmax = -1;
-    for_each_product<OffT>(row, rmA, entA, rmB, t, kBlock, sg_log2, [&](int64_t, int64_t j) {
-      const int c = entB[j];
-      atomicOr(&bm[c >> 6], 1ull << (c & 63));
-      cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
+    if (!(debug & 2)) for_each_product<OffT>(row, rmA, entA, rmB, entB, t, kDenseBlock, sg_log2, [&](int64_t, int64_t, int cb) {
+      const int64_t c64 = (int64_t)cb - c0;
+      if (c64 >= 0 && c64 < nbits) {
+        const int c = (int)c64;
+        atomicOr(&bm[c >> 6], 1ull << (c & 63));
+        cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
+      }
     });
     if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
     __syncthreads();
-    int cnt = 0;
-    if (s_max >= 0) {
-      const int64_t w_lo = s_min >> 6, nw = (s_max >> 6) - w_lo + 1, per = (nw + kBlock - 1) / kBlock;
-      const int64_t a = w_lo + t * per, z = (a + per < w_lo + nw) ? a + per : w_lo + nw;
-      for (int64_t wd = a; wd < z; ++wd) {
-        const kk_u64 v = KK_LOAD_L2(&bm[wd]);
-        if (v) { cnt += __popcll(v); bm[wd] = 0ull; }
+    if (s_max >= 0 && !(debug & 4)) {
+      const int w_lo = s_min >> 6, w_hi = s_max >> 6;
+      for (int wb = w_lo; wb <= w_hi; wb += kDenseBlock) {
+        const int wd = wb + t;
+        kk_u64 v     = (wd <= w_hi) ? bm[wd] : 0ull;
+        int tot;
+        const int excl = block_exclusive_scan_n<int, kDenseBlock>(__popcll(v), &tot, s_wave);
+        if (EMIT && !(debug & 1)) {
+          int64_t pos = (int64_t)rmC[row] + total + excl;
+          while (v) {
+            const int bit = __ffsll(v) - 1;
+            entC[pos++]   = (int32_t)(c0 + (int64_t)wd * 64 + bit);
+            v &= v - 1;
+          }
+        }
+        total += tot;
       }
     }
-    cnt = group_sum(cnt, 64);
-    if ((t & 63) == 0 && cnt) atomicAdd(&s_count, cnt);
-    __syncthreads();
-    if (t == 0) counts[row] = (OffT)s_count;
     __syncthreads();
   }
+  if (!EMIT && t == 0) counts[row] = (OffT)total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -258,6 +354,8 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_wave_kernel(int64_t nbin, c
   constexpr int H = kWaveTable;
   __shared__ int keys[kBlock / 64][H];
   __shared__ VT vals[kBlock / 64][H];
+  __shared__ int ckey[kBlock / 64][H / 2];
+  __shared__ unsigned short cslot[kBlock / 64][H / 2];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
   for (int i = lane; i < H; i += 64) { keys[w][i] = -1; vals[w][i] = VT(0); }
@@ -265,21 +363,33 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_wave_kernel(int64_t nbin, c
   if (idx < nbin) {
     const int64_t row = perm[idx];
     int* mk = keys[w]; VT* mv = vals[w];
-    for_each_product<OffT>(row, rmA, entA, rmB, lane, 64, sg_log2,
-                           [&](int64_t a, int64_t j) { hash_accumulate<VT>(mk, mv, H - 1, entB[j], valA[a] * valB[j]); });
+    for_each_product_v<OffT, VT>(row, rmA, entA, rmB, entB, valB, lane, 64, sg_log2,
+                                 [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(mk, mv, H - 1, c, valA[a] * bv); });
   }
   __syncthreads();
+  // compact the occupied slots (ballot + prefix), then rank-by-counting over the compact list only: keys are unique,
+  // so rank = number of smaller keys.  ceil(n/64) * n compares per wave instead of 8 * 512 over the whole table.
+  int n = 0;
+  for (int s0 = 0; s0 < H; s0 += 64) {
+    const int key        = keys[w][s0 + lane];
+    const kk_u64 occ     = __ballot(key >= 0);
+    if (key >= 0) {
+      const int pos = n + __popcll(occ & ((1ull << lane) - 1ull));
+      ckey[w][pos]  = key;
+      cslot[w][pos] = (unsigned short)(s0 + lane);
+    }
+    n += __popcll(occ);
+  }
+  KK_WAVE_SYNC();
   if (idx < nbin) {
     const int64_t row  = perm[idx];
     const int64_t base = (int64_t)rmC[row];
-    // rank-by-counting over the table: keys are unique, so rank = number of smaller keys
-    for (int sI = lane; sI < H; sI += 64) {
-      const int key = keys[w][sI];
-      if (key < 0) continue;
+    for (int i = lane; i < n; i += 64) {
+      const int key = ckey[w][i];
       int rank = 0;
-      for (int q = 0; q < H; ++q) { const int o = keys[w][q]; rank += (o >= 0 && o < key) ? 1 : 0; }
+      for (int q = 0; q < n; ++q) rank += (ckey[w][q] < key) ? 1 : 0;
       entC[base + rank] = key;
-      valC[base + rank] = vals[w][sI];
+      valC[base + rank] = vals[w][cslot[w][i]];
     }
   }
 }
@@ -298,8 +408,8 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_block_kernel(int64_t nbin, 
   const int64_t row = perm[blockIdx.x];
   for (int i = t; i < H; i += kBlock) { keys[i] = -1; vals[i] = VT(0); }
   __syncthreads();
-  for_each_product<OffT>(row, rmA, entA, rmB, t, kBlock, sg_log2,
-                         [&](int64_t a, int64_t j) { hash_accumulate<VT>(keys, vals, H - 1, entB[j], valA[a] * valB[j]); });
+  for_each_product_v<OffT, VT>(row, rmA, entA, rmB, entB, valB, t, kBlock, sg_log2,
+                               [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(keys, vals, H - 1, c, valA[a] * bv); });
   __syncthreads();
   // bitonic network over (key, slot) with empties pushed to the end as INT_MAX
   for (int i = t; i < H; i += kBlock) { slot[i] = i; if (keys[i] < 0) keys[i] = INT_MAX; }
@@ -352,10 +462,9 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_dense_kernel(int64_t nbin, 
     if (t == 0) { s_min = INT_MAX; s_max = -1; }
     __syncthreads();
     int cmin = INT_MAX, cmax = -1;
-    for_each_product<OffT>(row, rmA, entA, rmB, t, kBlock, sg_log2, [&](int64_t a, int64_t j) {
-      const int c = entB[j];
+    for_each_product_v<OffT, VT>(row, rmA, entA, rmB, entB, valB, t, kBlock, sg_log2, [&](int64_t a, int c, VT bv) {
       atomicOr(&bm[c >> 6], 1ull << (c & 63));
-      KK_ATOMIC_FADD(&acc[c], valA[a] * valB[j]);
+      KK_ATOMIC_FADD(&acc[c], valA[a] * bv);
       cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
     });
     if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
@@ -388,6 +497,140 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_dense_kernel(int64_t nbin, 
   }
 }
 
+// dense rows, values (B rows column-sorted): entries(C) of the row are already in place and sorted
+// (spgemm_dense_cols_kernel<EMIT>), so the row is cut into windows of `cap` consecutive C entries.  A window's columns
+// are hashed into an LDS table with zeroed sums.  Sub-groups of 8..64 lanes (fewer A entries -> wider groups) each own
+// one A entry at a time and stream the part of that B row whose columns fall inside the window (coalesced, sg entries
+// per step), probe the table (the column is known to be present) and accumulate with ds_add; a sub-group that runs
+// out of in-window entries moves to its next A entry, so a wave keeps up to 8 independent B streams in flight.  The
+// resume point of every A entry (position in B, entries left, A value) lives in LDS for the first kValLa entries of
+// the row and in an int32 HBM cursor (indexed like entries(A)) beyond that, so every B entry is read exactly once.
+// Finally the sums are looked up in C order and leave coalesced.
+template <class OffT, class VT>
+__global__ __launch_bounds__(kValBlock) void spgemm_dense_vals_kernel(const int32_t* __restrict__ perm,
+                                                                      const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                      const VT* __restrict__ valA, const OffT* __restrict__ rmB,
+                                                                      const int32_t* __restrict__ entB, const VT* __restrict__ valB,
+                                                                      const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
+                                                                      VT* __restrict__ valC, int32_t* __restrict__ cursors, int cap) {
+  constexpr int H = kValTable;
+  __shared__ int hk[H];
+  __shared__ VT hv[H];
+  __shared__ long long s_cur[kValLa];
+  __shared__ int s_rem[kValLa];
+  __shared__ VT s_av[kValLa];
+  __shared__ unsigned char s_long[kValLa];
+  __shared__ int s_whi;
+  constexpr int UL = 4, US = 2;       // independent B loads per lane and step (long / short B rows)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t row = perm[blockIdx.x];
+  const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
+  const int64_t la_c = la < kValLa ? la : kValLa;
+  const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
+  int sg_log2 = 3;
+  while ((int64_t)(kValBlock >> (sg_log2 + 1)) >= la && sg_log2 < 6) ++sg_log2;
+  const int sg = 1 << sg_log2, sub = t >> sg_log2, nsub = kValBlock >> sg_log2, sl = t & (sg - 1);
+  const int sg_shift   = lane & ~(sg - 1);
+  const kk_u64 sg_mask = sg == 64 ? ~0ull : ((1ull << sg) - 1ull);
+  for (int64_t a = t; a < la_c; a += kValBlock) {
+    const int32_t kc = entA[a0 + a];
+    const int64_t b0 = (int64_t)rmB[kc];
+    const int len    = (int)((int64_t)rmB[kc + 1] - b0);
+    s_cur[a] = b0; s_rem[a] = len; s_av[a] = valA[a0 + a]; s_long[a] = len >= kValLong ? 1 : 0;
+  }
+  auto accumulate = [&](int c, VT v) {
+    int hh = (int)(((unsigned)c * (unsigned)kHashMul) & (unsigned)(H - 1));
+    int probes = 0;
+    while (hk[hh] != c && probes < H) { hh = (hh + 1) & (H - 1); ++probes; }
+    if (probes < H) KK_ATOMIC_FADD(&hv[hh], v);
+  };
+  for (int64_t done = 0; done < cnt; done += cap) {
+    const int n = (int)(cnt - done < (int64_t)cap ? cnt - done : (int64_t)cap);
+    for (int i = t; i < H; i += kValBlock) { hk[i] = -1; hv[i] = VT(0); }
+    __syncthreads();
+    for (int i = t; i < n; i += kValBlock) {
+      const int key = entC[base + done + i];
+      (void)hash_insert_key(hk, H - 1, key);
+      if (i == n - 1) s_whi = key;
+    }
+    __syncthreads();
+    const int whi    = s_whi;
+    const bool first = done == 0, last = done + n >= cnt;
+    // long B rows: one wave per A entry, UL * 64 consecutive B entries per step
+    for (int64_t a = wave; a < la_c; a += kValBlock / 64) {
+      if (!s_long[a]) continue;
+      int64_t p = s_cur[a];
+      int rem   = s_rem[a];
+      const VT av = s_av[a];
+      while (true) {
+        int c[UL];
+        KK_UNROLL
+        for (int u = 0; u < UL; ++u) { const int idx = u * 64 + lane; c[u] = idx < rem ? entB[p + idx] : INT_MAX; }
+        int nin = 0;
+        KK_UNROLL
+        for (int u = 0; u < UL; ++u) {
+          const bool in = c[u] <= whi;
+          if (in) accumulate(c[u], av * valB[p + u * 64 + lane]);
+          nin += __popcll(__ballot(in));
+        }
+        p += nin; rem -= nin;
+        if (nin < UL * 64) break;
+      }
+      if (!last && lane == 0) { s_cur[a] = p; s_rem[a] = rem; }
+    }
+    // short B rows (and every A entry beyond the LDS cursor cache): persistent sub-groups
+    int64_t a = sub, p = 0, b0 = 0;
+    int rem = 0;
+    VT av   = VT(0);
+    bool have = false;
+    auto fetch = [&]() {
+      while (a < la_c && s_long[a]) a += nsub;
+      have = a < la;
+      if (!have) return;
+      if (a < kValLa) { p = s_cur[a]; rem = s_rem[a]; av = s_av[a]; }
+      else {
+        const int32_t kc = entA[a0 + a];
+        b0               = (int64_t)rmB[kc];
+        const int off    = first ? 0 : cursors[a0 + a];
+        p = b0 + off; rem = (int)((int64_t)rmB[kc + 1] - b0) - off; av = valA[a0 + a];
+      }
+    };
+    fetch();
+    while (true) {
+      int c[US];
+      KK_UNROLL
+      for (int u = 0; u < US; ++u) { const int idx = u * sg + sl; c[u] = (have && idx < rem) ? entB[p + idx] : INT_MAX; }
+      int nin = 0;
+      KK_UNROLL
+      for (int u = 0; u < US; ++u) {
+        const bool in = c[u] <= whi;
+        if (in) accumulate(c[u], av * valB[p + u * sg + sl]);
+        nin += __popcll((__ballot(in) >> sg_shift) & sg_mask);
+      }
+      if (have) {
+        p += nin; rem -= nin;
+        if (nin < US * sg) {       // this A entry has nothing more inside the window: park it, take the next one
+          if (!last && sl == 0) {
+            if (a < kValLa) { s_cur[a] = p; s_rem[a] = rem; }
+            else cursors[a0 + a] = (int32_t)(p - b0);
+          }
+          a += nsub;
+          fetch();
+        }
+      }
+      if (__ballot(have) == 0ull) break;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += kValBlock) {
+      const int key = entC[base + done + i];
+      int hh = (int)(((unsigned)key * (unsigned)kHashMul) & (unsigned)(H - 1));
+      while (hk[hh] != key) hh = (hh + 1) & (H - 1);
+      valC[base + done + i] = hv[hh];
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 }  // namespace kk
 
@@ -401,6 +644,9 @@ struct kkamd_spgemm_handle {
   int32_t* d_perm  = nullptr;      // [m] rows grouped by numeric bin
   kk::BinOffsets num_off{};
   int sg_log2 = 0;
+  int64_t nnzA = 0;
+  bool b_sorted = false;           // rows of B column-sorted: dense rows may use the windowed LDS value kernel
+  bool dense_lds = false;          // decided when the numeric bins are made
 };
 
 namespace kk {
@@ -444,6 +690,22 @@ static int dense_geometry(int64_t nrows_dense, int64_t bytes_per_wg, int* nwg) {
   return KKAMD_OK;
 }
 
+// one workgroup per dense row; dynamic LDS = the bitmap window
+template <class OffT, bool EMIT>
+static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA, const int32_t* entA, const OffT* rmB,
+                             const int32_t* entB, OffT* counts, const OffT* rmC, int32_t* entC, int64_t k, int sg, hipStream_t st) {
+  int64_t win = g_spgemm.win_bits;
+  if (win > k) win = ceil_div(k, 64) * 64;
+  const size_t smem = (size_t)(win / 8);
+#ifndef KK_EMU
+  KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_dense_cols_kernel<OffT, EMIT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#endif
+  KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,
+            rmC, entC, k, (int)win, sg, g_spgemm.debug);
+  return KKAMD_OK;
+}
+
 template <class OffT>
 static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t k, const void* rmA_, const int32_t* entA,
                           const void* rmB_, const int32_t* entB, void* rmC_, int64_t nnzB, int64_t* c_nnz, hipStream_t st) {
@@ -454,7 +716,10 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   unsigned long long* d_stats = nullptr;
   KK_HIP(hipMalloc((void**)&d_stats, 2 * sizeof(unsigned long long)));
   KK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), st));
-  KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)ceil_div(m * 8, kBlock), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats);
+  {
+    const int64_t nbk = ceil_div(m * 8, kBlock);
+    KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbk < 4096 ? nbk : 4096), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats);
+  }
   unsigned long long h_stats[2] = {0, 0};
   KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
@@ -469,19 +734,25 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   auto nb = [&](int b) { return off.off[b + 1] - off.off[b]; };
   if (nb(1)) KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
                        (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, sg);
-  if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS>), (unsigned)nb(2), kBlock, 0, st, nb(2),
+  if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
                        (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
-  if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL>), (unsigned)nb(3), kBlock, 0, st, nb(3),
+  if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
                        (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
-  kk_u64* d_bm = nullptr;
   if (nb(4)) {
-    const int64_t words = ceil_div(k, 64);
-    int nwg = 1;
-    if ((rc = dense_geometry(nb(4), words * 8, &nwg))) return rc;
-    KK_HIP(hipMalloc((void**)&d_bm, (size_t)words * 8 * (size_t)nwg));
-    KK_HIP(hipMemsetAsync(d_bm, 0, (size_t)words * 8 * (size_t)nwg, st));
-    KK_LAUNCH((spgemm_sym_dense_kernel<OffT>), (unsigned)nwg, kBlock, 0, st, nb(4), (const int32_t*)(h->d_perm + off.off[4]),
-              rmA, entA, rmB, entB, rmC, d_bm, words, sg);
+    if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, entB, rmC, (const OffT*)nullptr,
+                                             (int32_t*)nullptr, k, sg, st))) return rc;
+  }
+  // sortedness of B decides how the numeric phase handles dense rows
+  {
+    int* d_flag = nullptr; int h_flag = 0;
+    KK_HIP(hipMalloc((void**)&d_flag, sizeof(int)));
+    KK_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    const int64_t nbk = ceil_div(n * 8, kBlock);
+    KK_LAUNCH((rows_sorted_kernel<OffT>), (unsigned)(nbk < 8192 ? nbk : 8192), kBlock, 0, st, n, rmB, entB, d_flag);
+    KK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    KK_HIP(hipFree(d_flag));
+    h->b_sorted = h_flag == 0;
   }
   hipError_t e = hipGetLastError();
   rc = (e == hipSuccess) ? exclusive_scan_inplace<OffT>(rmC, m + 1, st) : fail(KKAMD_ERR_HIP, "spgemm symbolic launch failed: %s", hipGetErrorString(e));
@@ -491,7 +762,6 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     hipError_t e2 = hipStreamSynchronize(st);
     if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(KKAMD_ERR_HIP, "spgemm symbolic failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   }
-  if (d_bm) (void)hipFree(d_bm);
   if (rc) return rc;
   *c_nnz = (int64_t)total;
   return KKAMD_OK;
@@ -507,7 +777,8 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   if (!h->numeric_bins_ready) {
     const int64_t nbk = ceil_div(m, kBlock);
     KK_LAUNCH((spgemm_rowsize_kernel<OffT>), (unsigned)(nbk < 65536 ? nbk : 65536), kBlock, 0, st, m, rmC, h->d_sizes);
-    if ((rc = make_bins(m, h->d_sizes, INT64_MAX, kNumLimits, h->d_perm, &h->num_off, st))) return rc;
+    h->dense_lds = h->b_sorted && !g_spgemm.force_unsorted;
+    if ((rc = make_bins(m, h->d_sizes, INT64_MAX, h->dense_lds ? kNumLimitsSorted : kNumLimits, h->d_perm, &h->num_off, st))) return rc;
     h->numeric_bins_ready = true;
   }
   const BinOffsets& off = h->num_off;
@@ -519,8 +790,17 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
                        (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
   if (nb(3)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkL>), (unsigned)nb(3), kBlock, 0, st, nb(3),
                        (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
-  kk_u64* d_bm = nullptr; VT* d_acc = nullptr;
-  if (nb(4)) {
+  kk_u64* d_bm = nullptr; VT* d_acc = nullptr; int32_t* d_cur = nullptr;
+  if (nb(4) && h->dense_lds) {
+    const int32_t* dperm = h->d_perm + off.off[4];
+    if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
+    KK_HIP(hipMalloc((void**)&d_cur, sizeof(int32_t) * (size_t)(h->nnzA > 0 ? h->nnzA : 1)));
+    int cap = g_spgemm.val_cap;
+    if (cap < 64) cap = 64;
+    if (cap > kValCap) cap = kValCap;
+    KK_LAUNCH((spgemm_dense_vals_kernel<OffT, VT>), (unsigned)nb(4), kValBlock, 0, st, dperm, rmA, entA, valA, rmB, entB, valB,
+              rmC, (const int32_t*)entC, valC, d_cur, cap);
+  } else if (nb(4)) {
     const int64_t words = ceil_div(k, 64);
     int nwg = 1;
     if ((rc = dense_geometry(nb(4), words * 8 + k * (int64_t)sizeof(VT), &nwg))) return rc;
@@ -535,6 +815,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   hipError_t e2 = hipStreamSynchronize(st);   // the reference's numeric phase fences too (impl_kkmem.hpp:1440,1467)
   if (d_bm) (void)hipFree(d_bm);
   if (d_acc) (void)hipFree(d_acc);
+  if (d_cur) (void)hipFree(d_cur);
   if (e != hipSuccess || e2 != hipSuccess) return fail(KKAMD_ERR_HIP, "spgemm numeric failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   return KKAMD_OK;
 }
@@ -547,6 +828,20 @@ template <class OffT> __global__ void max_diff_kernel(int64_t m, const OffT* __r
   }
   for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(mx, o, 64); mx = other > mx ? other : mx; }
   if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
+}
+
+int spgemm_set_default(const char* key, int value) {
+  const std::string k(key ? key : "");
+  if (k == "spgemm_win_bits") {
+    if (value < 64 || value > (1 << 20) || (value & 63)) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_win_bits must be a multiple of 64 in [64, 2^20]");
+    g_spgemm.win_bits = value;
+  } else if (k == "spgemm_val_cap") {
+    if (value < 64 || value > kValCap) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_cap must be in [64, %d]", kValCap);
+    g_spgemm.val_cap = value;
+  } else if (k == "spgemm_force_unsorted") g_spgemm.force_unsorted = value != 0;
+  else if (k == "spgemm_debug") g_spgemm.debug = value;
+  else return fail(KKAMD_ERR_INVALID_ARG, "kkamd_set_default: unknown key '%s'", k.c_str());
+  return KKAMD_OK;
 }
 
 }  // namespace kk
@@ -605,6 +900,7 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
     return KKAMD_OK;
   }
   if (!d_entriesA || !d_entriesB) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: null entries");
+  h->nnzA = nnzA;
   if (h->d_sizes) { (void)hipFree(h->d_sizes); h->d_sizes = nullptr; }
   if (h->d_perm) { (void)hipFree(h->d_perm); h->d_perm = nullptr; }
   KK_HIP(hipMalloc((void**)&h->d_sizes, sizeof(int64_t) * (size_t)m));

@@ -1214,7 +1214,10 @@ int kkamd_device_info(char* name, int name_len, int* is_gfx950, int* num_cus) {
   return KKAMD_OK;
 }
 
-int kkamd_set_default(const char* key, int value) { return kk::set_tuning(kk::g_spmv_default, key, value); }
+int kkamd_set_default(const char* key, int value) {
+  if (key && std::strncmp(key, "spgemm_", 7) == 0) return kk::spgemm_set_default(key, value);
+  return kk::set_tuning(kk::g_spmv_default, key, value);
+}
 
 int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int algorithm, kkamd_stream_t stream) {
   if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_create: null output pointer");

@@ -82,7 +82,7 @@ def test_spgemm_float(be):
 
 
 def test_spgemm_all_bins(be):
-    # rows landing in every launch shape of both phases: flops 0 / <=256 / <=2048 / <=16384 / dense,
+    # rows landing in every launch shape of both phases: flops 0 / <=1365 / <=2048 / <=16384 / dense,
     # and nnz(C row) <=256 / <=2048 / <=5461 / dense
     B0 = pc.hub_matrix(64, 30000, 40, {0: 9000, 1: 3000, 2: 600, 3: 120, 5: 20000}, seed=1)
     lens = {0: 1, 1: 1, 2: 1, 3: 2, 4: 0, 5: 1, 6: 3, 7: 30}
@@ -97,6 +97,45 @@ def test_spgemm_all_bins(be):
     sizes = np.diff(got.row_map)
     assert sizes[4] == 0 and sizes[3] <= 256 and 256 < sizes[2] <= 2048 and 2048 < sizes[1] <= 5461 and sizes[0] > 5461
     assert sizes[6] > 20000        # union of three hub rows: dense path with overlapping columns
+
+
+def _set(be, key, value):
+    pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(key.encode(), int(value)))
+
+
+def test_spgemm_dense_row_windows(be):
+    # dense rows with (a) the column bitmap cut into several LDS windows, (b) small value windows so the per-entry
+    # cursors are exercised across many passes, (c) the HBM-accumulator fallback taken when B is not sorted
+    B0 = pc.hub_matrix(48, 26000, 25, {0: 9000, 1: 7000, 2: 12000, 3: 300}, seed=11)
+    rm = [0, 3, 4, 8, 8, 11]
+    ent = np.array([0, 1, 2,   2,   0, 3, 5, 9,   1, 2, 30], dtype=np.int32)
+    rng = np.random.default_rng(3)
+    A0 = oracle.Crs(5, 48, np.array(rm), ent, 1 + 49 * rng.random(len(ent)))
+    # a row of A longer than the LDS cursor cache (512 entries): the HBM cursors carry the rest across windows
+    B1 = pc.randomized(oracle.random_crs(700, 20000, 12, variance=6, seed=21, sorted_rows=True))
+    cols = np.sort(rng.choice(700, size=650, replace=False)).astype(np.int32)
+    A1 = oracle.Crs(2, 700, np.array([0, 650, 653]), np.concatenate([cols, [1, 5, 9]]).astype(np.int32), 1 + 49 * rng.random(653))
+    try:
+        _set(be, "spgemm_win_bits", 4096); _set(be, "spgemm_val_cap", 192)
+        got = pc.check_spgemm(be, A0, B0)
+        assert np.diff(got.row_map).max() > 12000
+        got = pc.check_spgemm(be, A1, B1)
+        assert np.diff(got.row_map)[0] > 2048
+        _set(be, "spgemm_win_bits", 1 << 20); _set(be, "spgemm_val_cap", 2048)
+        pc.check_spgemm(be, A0, B0, offset_dtype=np.int64, value_dtype=np.float32)
+        _set(be, "spgemm_force_unsorted", 1)
+        pc.check_spgemm(be, A0, B0)
+    finally:
+        _set(be, "spgemm_win_bits", 1 << 20); _set(be, "spgemm_val_cap", 2048); _set(be, "spgemm_force_unsorted", 0)
+    ent, val = B0.entries.copy(), B0.values.copy()          # unsorted B: detected by the symbolic phase, dense rows fall back
+    for i in range(B0.nrows):
+        lo, hi = B0.row_map[i], B0.row_map[i + 1]
+        q = rng.permutation(hi - lo)
+        ent[lo:hi], val[lo:hi] = ent[lo:hi][q], val[lo:hi][q]
+    Bu = oracle.Crs(B0.nrows, B0.ncols, B0.row_map, ent, val)
+    pc.check_spgemm(be, A0, Bu)
+    with pytest.raises(pc.kk.KkamdError):
+        _set(be, "spgemm_win_bits", 100)
 
 
 def test_spgemm_issue402(be):
