@@ -52,12 +52,14 @@ constexpr int kValTable   = 4096;     // value-window hash table (16 KB keys + 3
 constexpr int kValCap     = kValTable / 2;   // C entries per value window
 constexpr int kValLa      = 512;      // A entries of a row whose B cursors live in LDS (10 KB)
 constexpr int kValLong    = 128;      // B rows at least this long are streamed by a whole wave
+constexpr int kHubLa      = 4096;     // A rows up to this long keep cursor + next column in LDS (hub value kernel)
 
 struct SpgemmTuning {
   int win_bits       = 1 << 20;   // columns per LDS bitmap window (128 KB); rows wider than this take several passes
   int val_cap        = kValCap;   // C entries per value window
   int force_unsorted = 0;         // test hook: treat B as unsorted (dense rows accumulate in HBM)
   int debug          = 0;         // bench-only ablation bits for the dense-row kernels
+  int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
 };
 static SpgemmTuning g_spgemm;
 
@@ -432,11 +434,11 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_block_kernel(int64_t nbin, 
   (void)nbin;
 }
 
-// dense rows: bitmap + dense accumulator per workgroup in HBM.  Each lane owns one contiguous chunk of the touched
-// bitmap range: pass 1 counts its set bits, one workgroup scan turns the counts into output offsets, pass 2 walks
-// the chunk again and emits (column, value) pairs in ascending order -- sorted output without a sort.  Bitmap and
-// accumulator are read with L2-served loads (the atomics that built them were performed in L2) and cleared with
-// plain stores; the closing barrier (s_waitcnt vmcnt(0) + s_barrier) orders those stores before the next row.
+// hub rows (more than kValLa entries in the A row, or any dense row when B is not column-sorted): the row is spread
+// over many workgroups, which accumulate with L2 atomics into a k-wide accumulator in HBM (one per row of the batch,
+// blockIdx.y); entries(C) are already in place, so the sums are then gathered in C order and the touched accumulator
+// cells are cleared for the next batch.  Accumulator cells are read with agent-scope loads (served by L2, where the
+// atomics were performed).
 template <class VT> __device__ __forceinline__ VT load_l2(const VT* p);
 template <> __device__ __forceinline__ double load_l2<double>(const double* p) {
   return __longlong_as_double((long long)KK_LOAD_L2(reinterpret_cast<const kk_u64*>(p)));
@@ -445,75 +447,72 @@ template <> __device__ __forceinline__ float load_l2<float>(const float* p) {
   return __int_as_float((int)KK_LOAD_L2(reinterpret_cast<const unsigned*>(p)));
 }
 template <class OffT, class VT>
-__global__ __launch_bounds__(kBlock) void spgemm_num_dense_kernel(int64_t nbin, const int32_t* __restrict__ perm,
-                                                                  const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
-                                                                  const VT* __restrict__ valA, const OffT* __restrict__ rmB,
-                                                                  const int32_t* __restrict__ entB, const VT* __restrict__ valB,
-                                                                  const OffT* __restrict__ rmC, int32_t* __restrict__ entC,
-                                                                  VT* __restrict__ valC, kk_u64* __restrict__ bitmaps,
-                                                                  VT* __restrict__ accs, int64_t words, int64_t k, int sg_log2) {
-  __shared__ int s_min, s_max;
-  __shared__ int s_wave[kBlock / 64];
-  const int t = threadIdx.x;
-  kk_u64* bm  = bitmaps + (int64_t)blockIdx.x * words;
-  VT* acc     = accs + (int64_t)blockIdx.x * k;
-  for (int64_t ri = blockIdx.x; ri < nbin; ri += gridDim.x) {
-    const int64_t row = perm[ri];
-    if (t == 0) { s_min = INT_MAX; s_max = -1; }
-    __syncthreads();
-    int cmin = INT_MAX, cmax = -1;
-    for_each_product_v<OffT, VT>(row, rmA, entA, rmB, entB, valB, t, kBlock, sg_log2, [&](int64_t a, int c, VT bv) {
-      atomicOr(&bm[c >> 6], 1ull << (c & 63));
-      KK_ATOMIC_FADD(&acc[c], valA[a] * bv);
-      cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
-    });
-    if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
-    __syncthreads();
-    int64_t a = 0, z = 0;
-    int cnt = 0;
-    if (s_max >= 0) {
-      const int64_t w_lo = s_min >> 6, nw = (s_max >> 6) - w_lo + 1, per = (nw + kBlock - 1) / kBlock;
-      a = w_lo + t * per; z = (a + per < w_lo + nw) ? a + per : w_lo + nw;
-      for (int64_t wd = a; wd < z; ++wd) cnt += __popcll(KK_LOAD_L2(&bm[wd]));
-    }
-    int tot;
-    const int excl = block_exclusive_scan<int>(cnt, &tot, s_wave);
-    int64_t pos    = (int64_t)rmC[row] + excl;
-    for (int64_t wd = a; wd < z; ++wd) {
-      kk_u64 v = KK_LOAD_L2(&bm[wd]);
-      if (!v) continue;
-      bm[wd] = 0ull;
-      while (v) {
-        const int bit = __ffsll(v) - 1;
-        const int c   = (int)(wd * 64 + bit);
-        entC[pos]     = c;
-        valC[pos]     = load_l2<VT>(&acc[c]);
-        acc[c]        = VT(0);
-        ++pos;
-        v &= v - 1;
-      }
-    }
-    __syncthreads();
+__global__ __launch_bounds__(kBlock) void spgemm_hub_acc_kernel(const int32_t* __restrict__ rows, const OffT* __restrict__ rmA,
+                                                                const int32_t* __restrict__ entA, const VT* __restrict__ valA,
+                                                                const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                                const VT* __restrict__ valB, VT* __restrict__ accs, int64_t k,
+                                                                int sg_log2) {
+  const int64_t row = rows[blockIdx.y];
+  VT* acc           = accs + (int64_t)blockIdx.y * k;
+  for_each_product_v<OffT, VT>(row, rmA, entA, rmB, entB, valB, (int)(blockIdx.x * kBlock + threadIdx.x), (int)(gridDim.x * kBlock),
+                               sg_log2, [&](int64_t a, int c, VT bv) { KK_ATOMIC_FADD(&acc[c], valA[a] * bv); });
+}
+template <class OffT, class VT>
+__global__ __launch_bounds__(kBlock) void spgemm_hub_extract_kernel(const int32_t* __restrict__ rows, const OffT* __restrict__ rmC,
+                                                                    const int32_t* __restrict__ entC, VT* __restrict__ valC,
+                                                                    VT* __restrict__ accs, int64_t k) {
+  const int64_t row  = rows[blockIdx.y];
+  VT* acc            = accs + (int64_t)blockIdx.y * k;
+  const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * kBlock) {
+    const int c   = entC[base + i];
+    valC[base + i] = load_l2<VT>(&acc[c]);
+    acc[c]         = VT(0);
   }
 }
 
-// dense rows, values (B rows column-sorted): entries(C) of the row are already in place and sorted
-// (spgemm_dense_cols_kernel<EMIT>), so the row is cut into windows of `cap` consecutive C entries.  A window's columns
-// are hashed into an LDS table with zeroed sums.  Sub-groups of 8..64 lanes (fewer A entries -> wider groups) each own
-// one A entry at a time and stream the part of that B row whose columns fall inside the window (coalesced, sg entries
-// per step), probe the table (the column is known to be present) and accumulate with ds_add; a sub-group that runs
-// out of in-window entries moves to its next A entry, so a wave keeps up to 8 independent B streams in flight.  The
-// resume point of every A entry (position in B, entries left, A value) lives in LDS for the first kValLa entries of
-// the row and in an int32 HBM cursor (indexed like entries(A)) beyond that, so every B entry is read exactly once.
-// Finally the sums are looked up in C order and leave coalesced.
-template <class OffT, class VT>
-__global__ __launch_bounds__(kValBlock) void spgemm_dense_vals_kernel(const int32_t* __restrict__ perm,
+// dense rows of the numeric phase are split once per handle: rows the windowed LDS value kernel takes first, hub rows
+// from the back (wave-aggregated cursors).
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_split_dense_kernel(int64_t nd, const int32_t* __restrict__ perm_in,
+                                                                    const OffT* __restrict__ rmA, int64_t la_max, int all_hub,
+                                                                    int32_t* __restrict__ perm_out,
+                                                                    unsigned long long* __restrict__ counters /*[2]*/) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane  = threadIdx.x & 63;
+  int32_t row = 0;
+  int cls     = -1;
+  if (i < nd) { row = perm_in[i]; cls = (all_hub || (int64_t)rmA[row + 1] - (int64_t)rmA[row] > la_max) ? 1 : 0; }
+  for (int c = 0; c < 2; ++c) {
+    const kk_u64 m = __ballot(cls == c);
+    unsigned long long start = 0;
+    if (lane == 0 && m) start = atomicAdd(&counters[c], (unsigned long long)__popcll(m));
+    start = __shfl(start, 0, 64);
+    if (cls == c) {
+      const int64_t r = (int64_t)start + __popcll(m & ((1ull << lane) - 1ull));
+      perm_out[c == 0 ? r : nd - 1 - r] = row;
+    }
+  }
+}
+
+// dense rows, values (B rows column-sorted, at most kValLa entries in the A row): entries(C) of the row are already
+// in place and sorted (spgemm_dense_cols_kernel<EMIT>), so the row is cut into windows of `cap` consecutive C entries.
+// A window's columns are hashed into a clean LDS table (each work-item keeps the slots of its columns in registers).
+// The resume point of every A entry (position in B, entries left, A value) lives in LDS, so every B entry is consumed
+// exactly once although the row is visited window by window:
+//   * B rows of >= kValLong entries: one wave per A entry, two entries in flight, 128 consecutive B entries per step;
+//   * shorter B rows: sub-groups of 8..64 lanes (fewer A entries -> wider groups) that each own one A entry at a time
+//     and move on when it has nothing left inside the window -- up to 8 independent B streams per wave.
+// Columns are probed (known to be present) and accumulated with ds_add.  The sums leave in C order, coalesced, and
+// every work-item clears its slots so the table is clean for the next window; the next window's columns are already
+// in flight while the current one streams.
+template <class OffT, class VT, int H, int NT>
+__global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __restrict__ perm,
                                                                       const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                       const VT* __restrict__ valA, const OffT* __restrict__ rmB,
                                                                       const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                       const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
-                                                                      VT* __restrict__ valC, int32_t* __restrict__ cursors, int cap) {
-  constexpr int H = kValTable;
+                                                                      VT* __restrict__ valC, int cap) {
   __shared__ int hk[H];
   __shared__ VT hv[H];
   __shared__ long long s_cur[kValLa];
@@ -521,99 +520,135 @@ __global__ __launch_bounds__(kValBlock) void spgemm_dense_vals_kernel(const int3
   __shared__ VT s_av[kValLa];
   __shared__ unsigned char s_long[kValLa];
   __shared__ int s_whi;
-  constexpr int UL = 4, US = 2;       // independent B loads per lane and step (long / short B rows)
+  constexpr int UL = 2, US = 2;       // independent B loads per lane and step (long / short B rows)
+  constexpr int KPT = (H / 2 + NT - 1) / NT;   // C entries of a window per work-item
+  constexpr int NW  = NT / 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t row = perm[blockIdx.x];
   const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
   const int64_t la_c = la < kValLa ? la : kValLa;
   const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
   int sg_log2 = 3;
-  while ((int64_t)(kValBlock >> (sg_log2 + 1)) >= la && sg_log2 < 6) ++sg_log2;
-  const int sg = 1 << sg_log2, sub = t >> sg_log2, nsub = kValBlock >> sg_log2, sl = t & (sg - 1);
+  while ((int64_t)(NT >> (sg_log2 + 1)) >= la && sg_log2 < 6) ++sg_log2;
+  const int sg = 1 << sg_log2, sub = t >> sg_log2, nsub = NT >> sg_log2, sl = t & (sg - 1);
   const int sg_shift   = lane & ~(sg - 1);
   const kk_u64 sg_mask = sg == 64 ? ~0ull : ((1ull << sg) - 1ull);
-  for (int64_t a = t; a < la_c; a += kValBlock) {
+  for (int64_t a = t; a < la_c; a += NT) {
     const int32_t kc = entA[a0 + a];
     const int64_t b0 = (int64_t)rmB[kc];
     const int len    = (int)((int64_t)rmB[kc + 1] - b0);
     s_cur[a] = b0; s_rem[a] = len; s_av[a] = valA[a0 + a]; s_long[a] = len >= kValLong ? 1 : 0;
   }
+  for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
   auto accumulate = [&](int c, VT v) {
     int hh = (int)(((unsigned)c * (unsigned)kHashMul) & (unsigned)(H - 1));
     int probes = 0;
     while (hk[hh] != c && probes < H) { hh = (hh + 1) & (H - 1); ++probes; }
     if (probes < H) KK_ATOMIC_FADD(&hv[hh], v);
   };
+  // one streaming step of a long B row by a whole wave: UL * 64 consecutive entries, columns and values loaded together
+  auto load_step = [&](int64_t p, int rem, int* c, VT* v) {
+    KK_UNROLL
+    for (int u = 0; u < UL; ++u) {
+      const int idx = u * 64 + lane;
+      const bool ok = idx < rem;
+      c[u] = ok ? entB[p + idx] : INT_MAX;
+      v[u] = ok ? valB[p + idx] : VT(0);
+    }
+  };
+  auto consume_step = [&](const int* c, const VT* v, VT av, int whi) -> int {
+    int nin = 0;
+    KK_UNROLL
+    for (int u = 0; u < UL; ++u) {
+      const bool in = c[u] <= whi;
+      if (in) accumulate(c[u], av * v[u]);
+      nin += __popcll(__ballot(in));
+    }
+    return nin;
+  };
+  int curk[KPT], slot[KPT];
+  KK_UNROLL
+  for (int q = 0; q < KPT; ++q) { const int i = t + q * NT; curk[q] = (i < cap && i < cnt) ? entC[base + i] : -1; }
+  __syncthreads();
   for (int64_t done = 0; done < cnt; done += cap) {
     const int n = (int)(cnt - done < (int64_t)cap ? cnt - done : (int64_t)cap);
-    for (int i = t; i < H; i += kValBlock) { hk[i] = -1; hv[i] = VT(0); }
-    __syncthreads();
-    for (int i = t; i < n; i += kValBlock) {
-      const int key = entC[base + done + i];
-      (void)hash_insert_key(hk, H - 1, key);
-      if (i == n - 1) s_whi = key;
+    // build: this window's columns into the (clean) table; the slot of every column stays in a register for the end
+    KK_UNROLL
+    for (int q = 0; q < KPT; ++q) {
+      slot[q] = -1;
+      if (curk[q] >= 0) {
+        int hh = (int)(((unsigned)curk[q] * (unsigned)kHashMul) & (unsigned)(H - 1));
+        while (atomicCAS(&hk[hh], -1, curk[q]) != -1) hh = (hh + 1) & (H - 1);
+        slot[q] = hh;
+        if (t + q * NT == n - 1) s_whi = curk[q];
+      }
+    }
+    int nxtk[KPT];        // next window's columns: in flight while this window streams
+    KK_UNROLL
+    for (int q = 0; q < KPT; ++q) {
+      const int i = t + q * NT;
+      nxtk[q]     = (i < cap && done + cap + i < cnt) ? entC[base + done + cap + i] : -1;
     }
     __syncthreads();
     const int whi    = s_whi;
-    const bool first = done == 0, last = done + n >= cnt;
-    // long B rows: one wave per A entry, UL * 64 consecutive B entries per step
-    for (int64_t a = wave; a < la_c; a += kValBlock / 64) {
-      if (!s_long[a]) continue;
-      int64_t p = s_cur[a];
-      int rem   = s_rem[a];
-      const VT av = s_av[a];
-      while (true) {
-        int c[UL];
-        KK_UNROLL
-        for (int u = 0; u < UL; ++u) { const int idx = u * 64 + lane; c[u] = idx < rem ? entB[p + idx] : INT_MAX; }
-        int nin = 0;
-        KK_UNROLL
-        for (int u = 0; u < UL; ++u) {
-          const bool in = c[u] <= whi;
-          if (in) accumulate(c[u], av * valB[p + u * 64 + lane]);
-          nin += __popcll(__ballot(in));
-        }
-        p += nin; rem -= nin;
-        if (nin < UL * 64) break;
+    const bool last = done + n >= cnt;
+    // long B rows: one wave per A entry, two entries in flight per wave
+    for (int64_t a = wave; a < la_c; a += 2 * NW) {
+      const int64_t a1 = a + NW;
+      const bool ok0 = s_long[a] != 0, ok1 = a1 < la_c && s_long[a1] != 0;
+      if (!ok0 && !ok1) continue;
+      int64_t p0 = 0, p1 = 0;
+      int rem0 = 0, rem1 = 0;
+      VT av0 = VT(0), av1 = VT(0);
+      int c0[UL], c1[UL];
+      VT v0[UL], v1[UL];
+      if (ok0) { p0 = s_cur[a]; rem0 = s_rem[a]; av0 = s_av[a]; load_step(p0, rem0, c0, v0); }
+      if (ok1) { p1 = s_cur[a1]; rem1 = s_rem[a1]; av1 = s_av[a1]; load_step(p1, rem1, c1, v1); }
+      if (ok0) {
+        int nin = consume_step(c0, v0, av0, whi);
+        p0 += nin; rem0 -= nin;
+        while (nin == UL * 64) { load_step(p0, rem0, c0, v0); nin = consume_step(c0, v0, av0, whi); p0 += nin; rem0 -= nin; }
+        if (!last && lane == 0) { s_cur[a] = p0; s_rem[a] = rem0; }
       }
-      if (!last && lane == 0) { s_cur[a] = p; s_rem[a] = rem; }
+      if (ok1) {
+        int nin = consume_step(c1, v1, av1, whi);
+        p1 += nin; rem1 -= nin;
+        while (nin == UL * 64) { load_step(p1, rem1, c1, v1); nin = consume_step(c1, v1, av1, whi); p1 += nin; rem1 -= nin; }
+        if (!last && lane == 0) { s_cur[a1] = p1; s_rem[a1] = rem1; }
+      }
     }
-    // short B rows (and every A entry beyond the LDS cursor cache): persistent sub-groups
-    int64_t a = sub, p = 0, b0 = 0;
+    // short B rows: persistent sub-groups
+    int64_t a = sub, p = 0;
     int rem = 0;
     VT av   = VT(0);
     bool have = false;
     auto fetch = [&]() {
       while (a < la_c && s_long[a]) a += nsub;
-      have = a < la;
-      if (!have) return;
-      if (a < kValLa) { p = s_cur[a]; rem = s_rem[a]; av = s_av[a]; }
-      else {
-        const int32_t kc = entA[a0 + a];
-        b0               = (int64_t)rmB[kc];
-        const int off    = first ? 0 : cursors[a0 + a];
-        p = b0 + off; rem = (int)((int64_t)rmB[kc + 1] - b0) - off; av = valA[a0 + a];
-      }
+      have = a < la_c;
+      if (have) { p = s_cur[a]; rem = s_rem[a]; av = s_av[a]; }
     };
     fetch();
     while (true) {
       int c[US];
+      VT v[US];
       KK_UNROLL
-      for (int u = 0; u < US; ++u) { const int idx = u * sg + sl; c[u] = (have && idx < rem) ? entB[p + idx] : INT_MAX; }
+      for (int u = 0; u < US; ++u) {
+        const int idx = u * sg + sl;
+        const bool ok = have && idx < rem;
+        c[u] = ok ? entB[p + idx] : INT_MAX;
+        v[u] = ok ? valB[p + idx] : VT(0);
+      }
       int nin = 0;
       KK_UNROLL
       for (int u = 0; u < US; ++u) {
         const bool in = c[u] <= whi;
-        if (in) accumulate(c[u], av * valB[p + u * sg + sl]);
+        if (in) accumulate(c[u], av * v[u]);
         nin += __popcll((__ballot(in) >> sg_shift) & sg_mask);
       }
       if (have) {
         p += nin; rem -= nin;
         if (nin < US * sg) {       // this A entry has nothing more inside the window: park it, take the next one
-          if (!last && sl == 0) {
-            if (a < kValLa) { s_cur[a] = p; s_rem[a] = rem; }
-            else cursors[a0 + a] = (int32_t)(p - b0);
-          }
+          if (!last && sl == 0) { s_cur[a] = p; s_rem[a] = rem; }
           a += nsub;
           fetch();
         }
@@ -621,12 +656,141 @@ __global__ __launch_bounds__(kValBlock) void spgemm_dense_vals_kernel(const int3
       if (__ballot(have) == 0ull) break;
     }
     __syncthreads();
-    for (int i = t; i < n; i += kValBlock) {
-      const int key = entC[base + done + i];
-      int hh = (int)(((unsigned)key * (unsigned)kHashMul) & (unsigned)(H - 1));
-      while (hk[hh] != key) hh = (hh + 1) & (H - 1);
-      valC[base + done + i] = hv[hh];
+    // sums leave in C order (coalesced); every work-item cleans the slots it filled, so the table is clean again
+    KK_UNROLL
+    for (int q = 0; q < KPT; ++q) {
+      if (slot[q] >= 0) {
+        valC[base + done + t + q * NT] = hv[slot[q]];
+        hk[slot[q]] = -1; hv[slot[q]] = VT(0);
+      }
+      curk[q] = nxtk[q];
     }
+    __syncthreads();
+  }
+}
+
+// dense rows, values, A rows of kValLa < entries <= kHubLa (B sorted): same windows and table as above, but with
+// thousands of A entries most of them have nothing inside a given window, so visiting each one per window (a global
+// load each) would dominate.  Here the NEXT unconsumed column of every A entry is cached in LDS next to its cursor:
+// a window starts with an LDS-only sweep that lists the entries whose next column falls inside the window, and only
+// those are streamed (sub-groups of 16 lanes, persistent over the list).  One workgroup of 16 waves per CU.
+template <class OffT, class VT>
+__global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int32_t* __restrict__ perm,
+                                                                      const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                      const VT* __restrict__ valA, const OffT* __restrict__ rmB,
+                                                                      const int32_t* __restrict__ entB, const VT* __restrict__ valB,
+                                                                      const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
+                                                                      VT* __restrict__ valC, int cap) {
+  constexpr int H = kValTable, NT = kDenseBlock, KPT = (H / 2 + NT - 1) / NT, SG = 16, NSUB = NT / SG, US = 2;
+  __shared__ int hk[H];
+  __shared__ VT hv[H];
+  __shared__ long long s_cur[kHubLa];
+  __shared__ int s_rem[kHubLa];
+  __shared__ int s_next[kHubLa];
+  __shared__ unsigned short s_list[kHubLa];
+  __shared__ int s_whi, s_nact;
+  const int t = threadIdx.x, lane = t & 63, sub = t / SG, sl = t & (SG - 1);
+  const int sg_shift = lane & ~(SG - 1);
+  const int64_t row = perm[blockIdx.x];
+  const int64_t a0 = (int64_t)rmA[row];
+  const int la     = (int)((int64_t)rmA[row + 1] - a0);
+  const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
+  for (int a = t; a < la; a += NT) {
+    const int32_t kc = entA[a0 + a];
+    const int64_t b0 = (int64_t)rmB[kc];
+    const int len    = (int)((int64_t)rmB[kc + 1] - b0);
+    s_cur[a] = b0; s_rem[a] = len; s_next[a] = len > 0 ? entB[b0] : INT_MAX;
+  }
+  for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
+  if (t == 0) s_nact = 0;
+  int curk[KPT], slot[KPT];
+  KK_UNROLL
+  for (int q = 0; q < KPT; ++q) { const int i = t + q * NT; curk[q] = (i < cap && i < cnt) ? entC[base + i] : -1; }
+  __syncthreads();
+  for (int64_t done = 0; done < cnt; done += cap) {
+    const int n = (int)(cnt - done < (int64_t)cap ? cnt - done : (int64_t)cap);
+    KK_UNROLL
+    for (int q = 0; q < KPT; ++q) {
+      slot[q] = -1;
+      if (curk[q] >= 0) {
+        int hh = (int)(((unsigned)curk[q] * (unsigned)kHashMul) & (unsigned)(H - 1));
+        while (atomicCAS(&hk[hh], -1, curk[q]) != -1) hh = (hh + 1) & (H - 1);
+        slot[q] = hh;
+        if (t + q * NT == n - 1) s_whi = curk[q];
+      }
+    }
+    int nxtk[KPT];
+    KK_UNROLL
+    for (int q = 0; q < KPT; ++q) {
+      const int i = t + q * NT;
+      nxtk[q]     = (i < cap && done + cap + i < cnt) ? entC[base + done + cap + i] : -1;
+    }
+    __syncthreads();
+    const int whi = s_whi;
+    // LDS-only sweep: which A entries have something inside this window?
+    for (int a0i = 0; a0i < la; a0i += NT) {
+      const int a      = a0i + t;
+      const bool act   = a < la && s_next[a] <= whi;
+      const kk_u64 m   = __ballot(act);
+      int start = 0;
+      if (lane == 0 && m) start = atomicAdd(&s_nact, __popcll(m));
+      start = __shfl(start, 0, 64);
+      if (act) s_list[start + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)a;
+    }
+    __syncthreads();
+    const int nact = s_nact;
+    int li = sub, a = 0, rem = 0;
+    int64_t p = 0;
+    VT av = VT(0);
+    bool have = false;
+    auto fetch = [&]() {
+      have = li < nact;
+      if (have) { a = s_list[li]; p = s_cur[a]; rem = s_rem[a]; av = valA[a0 + a]; }
+    };
+    fetch();
+    while (true) {
+      int c[US];
+      VT v[US];
+      KK_UNROLL
+      for (int u = 0; u < US; ++u) {
+        const int idx = u * SG + sl;
+        const bool ok = have && idx < rem;
+        c[u] = ok ? entB[p + idx] : INT_MAX;
+        v[u] = ok ? valB[p + idx] : VT(0);
+      }
+      int nin = 0;
+      KK_UNROLL
+      for (int u = 0; u < US; ++u) {
+        const bool in = c[u] <= whi;
+        if (in) {
+          int hh = (int)(((unsigned)c[u] * (unsigned)kHashMul) & (unsigned)(H - 1));
+          int probes = 0;
+          while (hk[hh] != c[u] && probes < H) { hh = (hh + 1) & (H - 1); ++probes; }
+          if (probes < H) KK_ATOMIC_FADD(&hv[hh], av * v[u]);
+        }
+        nin += __popcll((__ballot(in) >> sg_shift) & 0xffffull);
+      }
+      if (have) {
+        if (nin < US * SG) {       // done with this entry for the window: the first column left out becomes its next column
+          KK_UNROLL
+          for (int u = 0; u < US; ++u) if (u * SG + sl == nin) s_next[a] = c[u];
+          if (sl == 0) { s_cur[a] = p + nin; s_rem[a] = rem - nin; }
+          li += NSUB;
+          fetch();
+        } else { p += nin; rem -= nin; }
+      }
+      if (__ballot(have) == 0ull) break;
+    }
+    __syncthreads();
+    KK_UNROLL
+    for (int q = 0; q < KPT; ++q) {
+      if (slot[q] >= 0) {
+        valC[base + done + t + q * NT] = hv[slot[q]];
+        hk[slot[q]] = -1; hv[slot[q]] = VT(0);
+      }
+      curk[q] = nxtk[q];
+    }
+    if (t == 0) s_nact = 0;
     __syncthreads();
   }
 }
@@ -647,6 +811,8 @@ struct kkamd_spgemm_handle {
   int64_t nnzA = 0;
   bool b_sorted = false;           // rows of B column-sorted: dense rows may use the windowed LDS value kernel
   bool dense_lds = false;          // decided when the numeric bins are made
+  int64_t n_dense_lds = 0;         // leading rows of the dense bin taken by the LDS value kernel,
+  int64_t n_dense_hub_lds = 0;     // then rows for the LDS hub kernel; the rest accumulate in HBM
 };
 
 namespace kk {
@@ -675,18 +841,6 @@ static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLi
   hipError_t e2 = hipStreamSynchronize(st);
   (void)hipFree(d_cnt);
   if (e != hipSuccess || e2 != hipSuccess) return fail(KKAMD_ERR_HIP, "spgemm binning failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-  return KKAMD_OK;
-}
-
-// number of dense-row workgroups and their workspace, bounded to 1/4 of free HBM (and 2048 workgroups = 8 per CU)
-static int dense_geometry(int64_t nrows_dense, int64_t bytes_per_wg, int* nwg) {
-  size_t free_b = 0, total_b = 0;
-  KK_HIP(hipMemGetInfo(&free_b, &total_b));
-  int64_t cap = (int64_t)(free_b / 4) / (bytes_per_wg > 0 ? bytes_per_wg : 1);
-  if (cap < 1) return fail(KKAMD_ERR_ALLOC, "spgemm: not enough device memory for one dense accumulator (%lld bytes)", (long long)bytes_per_wg);
-  int64_t g = nrows_dense < 2048 ? nrows_dense : 2048;
-  if (g > cap) g = cap;
-  *nwg = (int)g;
   return KKAMD_OK;
 }
 
@@ -779,6 +933,30 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     KK_LAUNCH((spgemm_rowsize_kernel<OffT>), (unsigned)(nbk < 65536 ? nbk : 65536), kBlock, 0, st, m, rmC, h->d_sizes);
     h->dense_lds = h->b_sorted && !g_spgemm.force_unsorted;
     if ((rc = make_bins(m, h->d_sizes, INT64_MAX, h->dense_lds ? kNumLimitsSorted : kNumLimits, h->d_perm, &h->num_off, st))) return rc;
+    h->n_dense_lds = 0; h->n_dense_hub_lds = 0;
+    const int64_t nd = h->num_off.off[5] - h->num_off.off[4];
+    if (nd > 0) {
+      // dense bin -> [ A row <= kValLa | A row <= kHubLa | the rest ]; everything is "the rest" when B is not sorted
+      int32_t* d_tmp = nullptr; unsigned long long* d_cnt = nullptr; unsigned long long h_cnt[2] = {0, 0};
+      KK_HIP(hipMalloc((void**)&d_tmp, sizeof(int32_t) * (size_t)nd));
+      KK_HIP(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
+      int32_t* seg = h->d_perm + h->num_off.off[4];
+      int64_t lo = 0, len = nd;
+      const int64_t la_max[2] = {kValLa, kHubLa};
+      int64_t first[2] = {0, 0};
+      for (int pass = 0; pass < 2 && len > 0; ++pass) {
+        KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
+        KK_HIP(hipMemcpyAsync(d_tmp, seg + lo, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToDevice, st));
+        KK_LAUNCH((spgemm_split_dense_kernel<OffT>), (unsigned)ceil_div(len, kBlock), kBlock, 0, st, len, (const int32_t*)d_tmp, rmA,
+                  la_max[pass], h->dense_lds ? 0 : 1, seg + lo, d_cnt);
+        KK_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+        first[pass] = (int64_t)h_cnt[0];
+        lo += first[pass]; len -= first[pass];
+      }
+      KK_HIP(hipFree(d_tmp)); KK_HIP(hipFree(d_cnt));
+      h->n_dense_lds = first[0]; h->n_dense_hub_lds = first[1];
+    }
     h->numeric_bins_ready = true;
   }
   const BinOffsets& off = h->num_off;
@@ -790,32 +968,59 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
                        (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
   if (nb(3)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkL>), (unsigned)nb(3), kBlock, 0, st, nb(3),
                        (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
-  kk_u64* d_bm = nullptr; VT* d_acc = nullptr; int32_t* d_cur = nullptr;
-  if (nb(4) && h->dense_lds) {
+  VT* d_acc = nullptr;
+  if (nb(4)) {
     const int32_t* dperm = h->d_perm + off.off[4];
+    // entries(C) of every dense row, column-sorted
     if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
-    KK_HIP(hipMalloc((void**)&d_cur, sizeof(int32_t) * (size_t)(h->nnzA > 0 ? h->nnzA : 1)));
-    int cap = g_spgemm.val_cap;
-    if (cap < 64) cap = 64;
-    if (cap > kValCap) cap = kValCap;
-    KK_LAUNCH((spgemm_dense_vals_kernel<OffT, VT>), (unsigned)nb(4), kValBlock, 0, st, dperm, rmA, entA, valA, rmB, entB, valB,
-              rmC, (const int32_t*)entC, valC, d_cur, cap);
-  } else if (nb(4)) {
-    const int64_t words = ceil_div(k, 64);
-    int nwg = 1;
-    if ((rc = dense_geometry(nb(4), words * 8 + k * (int64_t)sizeof(VT), &nwg))) return rc;
-    KK_HIP(hipMalloc((void**)&d_bm, (size_t)words * 8 * (size_t)nwg));
-    KK_HIP(hipMalloc((void**)&d_acc, (size_t)k * sizeof(VT) * (size_t)nwg));
-    KK_HIP(hipMemsetAsync(d_bm, 0, (size_t)words * 8 * (size_t)nwg, st));
-    KK_HIP(hipMemsetAsync(d_acc, 0, (size_t)k * sizeof(VT) * (size_t)nwg, st));
-    KK_LAUNCH((spgemm_num_dense_kernel<OffT, VT>), (unsigned)nwg, kBlock, 0, st, nb(4), (const int32_t*)(h->d_perm + off.off[4]),
-              rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, d_bm, d_acc, words, k, sg);
+    const int64_t n_lds = h->n_dense_lds, n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_lds - n_hubl;
+    if (n_hubl) {      // heaviest rows first
+      int cap = g_spgemm.val_cap;
+      cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
+      KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)n_hubl, kDenseBlock, 0, st, dperm + n_lds, rmA, entA, valA, rmB, entB, valB,
+                rmC, (const int32_t*)entC, valC, cap);
+    }
+    if (n_lds) {
+      int cap = g_spgemm.val_cap;
+      if (cap < 64) cap = 64;
+#define KK_VALS(HH, NTT)                                                                                              \
+  do {                                                                                                                \
+    if (cap > HH / 2) cap = HH / 2;                                                                                   \
+    KK_LAUNCH((spgemm_dense_vals_kernel<OffT, VT, HH, NTT>), (unsigned)n_lds, NTT, 0, st, dperm, rmA, entA, valA, rmB, \
+              entB, valB, rmC, (const int32_t*)entC, valC, cap);                                                      \
+  } while (0)
+      switch (g_spgemm.val_shape) {
+        case 1: KK_VALS(8192, 1024); break;
+        case 2: KK_VALS(8192, 512); break;
+        case 3: KK_VALS(2048, 256); break;
+        case 4: KK_VALS(4096, 1024); break;
+        default: KK_VALS(kValTable, kValBlock); break;
+      }
+#undef KK_VALS
+    }
+    if (n_hub) {
+      // batches of G rows, each with its own k-wide accumulator (bounded to 1/8 of free HBM), ~256K work-items in flight
+      size_t free_b = 0, total_b = 0;
+      KK_HIP(hipMemGetInfo(&free_b, &total_b));
+      int64_t G = (int64_t)(free_b / 8) / (k * (int64_t)sizeof(VT));
+      if (G < 1) return fail(KKAMD_ERR_ALLOC, "spgemm: not enough device memory for one hub-row accumulator (%lld bytes)", (long long)(k * (int64_t)sizeof(VT)));
+      if (G > 1024) G = 1024;
+      if (G > n_hub) G = n_hub;
+      int64_t bx = 1024 / G;
+      bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+      KK_HIP(hipMalloc((void**)&d_acc, (size_t)k * sizeof(VT) * (size_t)G));
+      KK_HIP(hipMemsetAsync(d_acc, 0, (size_t)k * sizeof(VT) * (size_t)G, st));
+      for (int64_t r0 = 0; r0 < n_hub; r0 += G) {
+        const unsigned g = (unsigned)(n_hub - r0 < G ? n_hub - r0 : G);
+        const int32_t* rows = dperm + n_lds + n_hubl + r0;
+        KK_LAUNCH((spgemm_hub_acc_kernel<OffT, VT>), dim3((unsigned)bx, g), kBlock, 0, st, rows, rmA, entA, valA, rmB, entB, valB, d_acc, k, sg);
+        KK_LAUNCH((spgemm_hub_extract_kernel<OffT, VT>), dim3((unsigned)bx, g), kBlock, 0, st, rows, rmC, (const int32_t*)entC, valC, d_acc, k);
+      }
+    }
   }
   hipError_t e = hipGetLastError();
   hipError_t e2 = hipStreamSynchronize(st);   // the reference's numeric phase fences too (impl_kkmem.hpp:1440,1467)
-  if (d_bm) (void)hipFree(d_bm);
   if (d_acc) (void)hipFree(d_acc);
-  if (d_cur) (void)hipFree(d_cur);
   if (e != hipSuccess || e2 != hipSuccess) return fail(KKAMD_ERR_HIP, "spgemm numeric failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   return KKAMD_OK;
 }
@@ -836,10 +1041,11 @@ int spgemm_set_default(const char* key, int value) {
     if (value < 64 || value > (1 << 20) || (value & 63)) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_win_bits must be a multiple of 64 in [64, 2^20]");
     g_spgemm.win_bits = value;
   } else if (k == "spgemm_val_cap") {
-    if (value < 64 || value > kValCap) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_cap must be in [64, %d]", kValCap);
+    if (value < 64 || value > 4096) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_cap must be in [64, 4096]");
     g_spgemm.val_cap = value;
   } else if (k == "spgemm_force_unsorted") g_spgemm.force_unsorted = value != 0;
   else if (k == "spgemm_debug") g_spgemm.debug = value;
+  else if (k == "spgemm_val_shape") g_spgemm.val_shape = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "kkamd_set_default: unknown key '%s'", k.c_str());
   return KKAMD_OK;
 }

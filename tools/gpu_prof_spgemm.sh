@@ -8,7 +8,8 @@ import sys, time; sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, kk_loader, oracle
 kk = kk_loader.load()
 import os
-if os.environ.get("KK_SPGEMM_DEBUG"): kk._capi.check(kk.torch_backend().lib, kk.torch_backend().lib.kkamd_set_default(b"spgemm_debug", int(os.environ["KK_SPGEMM_DEBUG"])))
+for kv in os.environ.get("KK_SPGEMM_KNOBS", "").split(","):
+    if kv: kk._capi.check(kk.torch_backend().lib, kk.torch_backend().lib.kkamd_set_default(("spgemm_" + kv.split("=")[0]).encode(), int(kv.split("=")[1])))
 case = sys.argv[2]
 if case == "laplace":
     M = kk.laplace_matrix("FE", 100, 100, 100)
