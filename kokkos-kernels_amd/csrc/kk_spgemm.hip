@@ -28,6 +28,7 @@
 #include <climits>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #ifdef KK_EMU
 #define KK_ATOMIC_FADD(p, v) atomicAdd((p), (v))
@@ -59,6 +60,7 @@ struct SpgemmTuning {
   int val_cap        = kValCap;   // C entries per value window
   int force_unsorted = 0;         // test hook: treat B as unsorted (dense rows accumulate in HBM)
   int debug          = 0;         // bench-only ablation bits for the dense-row kernels
+  int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
 };
 static SpgemmTuning g_spgemm;
@@ -238,6 +240,83 @@ __device__ __forceinline__ void for_each_product_v(int64_t row, const OffT* __re
   }
 }
 
+// Workgroup-wide FLAT iteration over the products of one row (block-per-row kernels).  The row's A entries are taken
+// NT at a time: every work-item looks up one B row (start, length), a workgroup scan turns the lengths into product
+// offsets, and then product q of the chunk is handled by work-item q mod NT -- consecutive lanes read consecutive B
+// entries, all kProdUnroll loads of a lane are independent, and no lane waits on the entries(A) -> row_map(B) ->
+// entries(B) chain more than once per chunk.  (With sub-groups walking "their" B rows the kernels were bound by that
+// chain: ~135 G products/s on R-MAT; see DESIGN.md.)  A lane finds the B row of its product from the wave's first
+// product (one shared binary search) and only searches on its own when it falls outside that row.
+// Every work-item of the workgroup must call it.  f(a, j, column) with a, j indices into A's / B's entry arrays.
+template <int NT> struct FlatScratch {
+  long long pre[NT + 1];    // product offset of each A entry of the chunk
+  long long b0[NT];         // first B entry of each
+  long long wave[NT / 64];
+};
+struct NoVals {};
+template <int NT, class OffT, class VT, class F>
+__device__ __forceinline__ void flat_products_impl(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                   const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                   const VT* __restrict__ valB, FlatScratch<NT>& sc, F f) {
+  constexpr bool kVals = !std::is_same<VT, NoVals>::value;
+  const int t = threadIdx.x;
+  const int64_t a_beg = (int64_t)rmA[row], a_end = (int64_t)rmA[row + 1];
+  for (int64_t chunk = a_beg; chunk < a_end; chunk += NT) {
+    const int n = (int)(a_end - chunk < NT ? a_end - chunk : NT);
+    long long len = 0, b0 = 0;
+    if (t < n) { const int32_t c = entA[chunk + t]; b0 = (long long)rmB[c]; len = (long long)rmB[c + 1] - b0; }
+    long long tot;
+    const long long excl = block_exclusive_scan_n<long long, NT>(len, &tot, sc.wave);
+    if (t < n) { sc.pre[t] = excl; sc.b0[t] = b0; }
+    if (t == 0) sc.pre[n] = tot;
+    __syncthreads();
+    auto find = [&](long long q, int lo) {      // largest s in [lo, n) with pre[s] <= q
+      int len2 = n - lo;
+      while (len2 > 1) { const int half = len2 >> 1; lo += (sc.pre[lo + half] <= q) ? half : 0; len2 -= half; }
+      return lo;
+    };
+    for (long long base = 0; base < tot; base += (long long)NT * kProdUnroll) {
+      const int seg0 = find(base + (t & ~63), 0);        // the wave's first product (uniform across the wave)
+      int col[kProdUnroll], seg[kProdUnroll];
+      long long jj[kProdUnroll];
+      typename std::conditional<kVals, VT, int>::type bv[kProdUnroll];
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u) {
+        const long long q = base + (long long)u * NT + t;
+        col[u] = -1; seg[u] = 0; jj[u] = 0; bv[u] = 0;
+        if (q < tot) {
+          const int sg0 = u == 0 ? seg0 : seg[u - 1];
+          seg[u] = (q < sc.pre[sg0 + 1]) ? sg0 : find(q, sg0);
+          jj[u]  = sc.b0[seg[u]] + (q - sc.pre[seg[u]]);
+          col[u] = entB[jj[u]];
+          if constexpr (kVals) bv[u] = valB[jj[u]];
+        }
+      }
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u)
+        if (col[u] >= 0) {
+          if constexpr (kVals) f(chunk + seg[u], col[u], bv[u]);
+          else f(chunk + seg[u], (int64_t)jj[u], col[u]);
+        }
+    }
+    __syncthreads();
+  }
+}
+// f(a, j, column)
+template <int NT, class OffT, class F>
+__device__ __forceinline__ void flat_products(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                              const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                              FlatScratch<NT>& sc, F f) {
+  flat_products_impl<NT, OffT, NoVals>(row, rmA, entA, rmB, entB, (const NoVals*)nullptr, sc, f);
+}
+// f(a, column, value of B)
+template <int NT, class OffT, class VT, class F>
+__device__ __forceinline__ void flat_products_v(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                const VT* __restrict__ valB, FlatScratch<NT>& sc, F f) {
+  flat_products_impl<NT, OffT, VT>(row, rmA, entA, rmB, entB, valB, sc, f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3. symbolic kernels
 template <class OffT>
@@ -270,14 +349,16 @@ __global__ __launch_bounds__(NT) void spgemm_sym_block_kernel(int64_t nbin, cons
                                                                   OffT* __restrict__ counts, int sg_log2) {
   __shared__ int tab[H];
   __shared__ int s_count;
+  __shared__ FlatScratch<NT> s_flat;
   const int t = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
   for (int i = t; i < H; i += NT) tab[i] = -1;
   if (t == 0) s_count = 0;
   __syncthreads();
   int cnt = 0;
-  for_each_product<OffT>(row, rmA, entA, rmB, entB, t, NT, sg_log2,
-                         [&](int64_t, int64_t, int c) { cnt += hash_insert_key(tab, H - 1, c) ? 1 : 0; });
+  flat_products<NT, OffT>(row, rmA, entA, rmB, entB, s_flat,
+                          [&](int64_t, int64_t, int c) { cnt += hash_insert_key(tab, H - 1, c) ? 1 : 0; });
+  (void)sg_log2;
   cnt = group_sum(cnt, 64);
   if ((t & 63) == 0 && cnt) atomicAdd(&s_count, cnt);
   __syncthreads();
@@ -301,9 +382,11 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
   KK_DYN_SMEM(kk_u64, bm);
   __shared__ int s_min, s_max;
   __shared__ int s_wave[kDenseBlock / 64];
+  __shared__ FlatScratch<kDenseBlock> s_flat;
   const int t       = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
   int64_t total     = 0;
+  (void)sg_log2;
   for (int64_t c0 = 0; c0 < k; c0 += win_bits) {
     const int nbits  = (int)((k - c0 < (int64_t)win_bits) ? k - c0 : (int64_t)win_bits);
     const int nwords = (nbits + 63) >> 6;
@@ -311,32 +394,57 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
     if (t == 0) { s_min = INT_MAX; s_max = -1; }
     __syncthreads();
     int cmin = INT_MAX, cmax = -1;
-    if (!(debug & 2)) for_each_product<OffT>(row, rmA, entA, rmB, entB, t, kDenseBlock, sg_log2, [&](int64_t, int64_t, int cb) {
+    if (!(debug & 2)) flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int cb) {
       const int64_t c64 = (int64_t)cb - c0;
       if (c64 >= 0 && c64 < nbits) {
         const int c = (int)c64;
-        atomicOr(&bm[c >> 6], 1ull << (c & 63));
+        if (!(debug & 256)) atomicOr(&bm[c >> 6], 1ull << (c & 63));
         cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
       }
     });
     if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
     __syncthreads();
     if (s_max >= 0 && !(debug & 4)) {
-      const int w_lo = s_min >> 6, w_hi = s_max >> 6;
-      for (int wb = w_lo; wb <= w_hi; wb += kDenseBlock) {
-        const int wd = wb + t;
-        kk_u64 v     = (wd <= w_hi) ? bm[wd] : 0ull;
+      const int w_lo = s_min >> 6, w_hi = s_max >> 6, nw = w_hi - w_lo + 1;
+      // sparse bitmaps (fewer than 4 columns per touched word on average; always when only counting): every
+      // work-item takes one contiguous run of words -- one workgroup scan per window instead of one per 1024 words.
+      // Dense bitmaps keep the interleaved walk, whose stores to entries(C) coalesce.
+      const bool chunked = !EMIT || (debug & 128) || (int64_t)rmC[row + 1] - (int64_t)rmC[row] < 4 * (int64_t)nw;
+      if (chunked) {
+        const int per = (nw + kDenseBlock - 1) / kDenseBlock;
+        const int a = w_lo + t * per, z = (a + per <= w_hi + 1) ? a + per : w_hi + 1;
+        int cnt = 0;
+        for (int wd = a; wd < z; ++wd) cnt += __popcll(bm[wd]);
         int tot;
-        const int excl = block_exclusive_scan_n<int, kDenseBlock>(__popcll(v), &tot, s_wave);
+        const int excl = block_exclusive_scan_n<int, kDenseBlock>(cnt, &tot, s_wave);
         if (EMIT && !(debug & 1)) {
           int64_t pos = (int64_t)rmC[row] + total + excl;
-          while (v) {
-            const int bit = __ffsll(v) - 1;
-            entC[pos++]   = (int32_t)(c0 + (int64_t)wd * 64 + bit);
-            v &= v - 1;
+          for (int wd = a; wd < z; ++wd) {
+            kk_u64 v = bm[wd];
+            while (v) {
+              const int bit = __ffsll(v) - 1;
+              entC[pos++]   = (int32_t)(c0 + (int64_t)wd * 64 + bit);
+              v &= v - 1;
+            }
           }
         }
         total += tot;
+      } else {
+        for (int wb = w_lo; wb <= w_hi; wb += kDenseBlock) {
+          const int wd = wb + t;
+          kk_u64 v     = (wd <= w_hi) ? bm[wd] : 0ull;
+          int tot;
+          const int excl = block_exclusive_scan_n<int, kDenseBlock>(__popcll(v), &tot, s_wave);
+          if (EMIT && !(debug & 1)) {
+            int64_t pos = (int64_t)rmC[row] + total + excl;
+            while (v) {
+              const int bit = __ffsll(v) - 1;
+              entC[pos++]   = (int32_t)(c0 + (int64_t)wd * 64 + bit);
+              v &= v - 1;
+            }
+          }
+          total += tot;
+        }
       }
     }
     __syncthreads();
@@ -406,12 +514,14 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_block_kernel(int64_t nbin, 
   __shared__ int keys[H];
   __shared__ int slot[H];
   __shared__ VT vals[H];
+  __shared__ FlatScratch<kBlock> s_flat;
   const int t = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
   for (int i = t; i < H; i += kBlock) { keys[i] = -1; vals[i] = VT(0); }
   __syncthreads();
-  for_each_product_v<OffT, VT>(row, rmA, entA, rmB, entB, valB, t, kBlock, sg_log2,
-                               [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(keys, vals, H - 1, c, valA[a] * bv); });
+  flat_products_v<kBlock, OffT, VT>(row, rmA, entA, rmB, entB, valB, s_flat,
+                                    [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(keys, vals, H - 1, c, valA[a] * bv); });
+  (void)sg_log2;
   __syncthreads();
   // bitonic network over (key, slot) with empties pushed to the end as INT_MAX
   for (int i = t; i < H; i += kBlock) { slot[i] = i; if (keys[i] < 0) keys[i] = INT_MAX; }
@@ -512,7 +622,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
                                                                       const VT* __restrict__ valA, const OffT* __restrict__ rmB,
                                                                       const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                       const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
-                                                                      VT* __restrict__ valC, int cap) {
+                                                                      VT* __restrict__ valC, int cap, int debug) {
   __shared__ int hk[H];
   __shared__ VT hv[H];
   __shared__ long long s_cur[kValLa];
@@ -521,6 +631,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
   __shared__ unsigned char s_long[kValLa];
   __shared__ int s_whi;
   constexpr int UL = 2, US = 2;       // independent B loads per lane and step (long / short B rows)
+  constexpr int EL = 4;               // long B rows in flight per wave
   constexpr int KPT = (H / 2 + NT - 1) / NT;   // C entries of a window per work-item
   constexpr int NW  = NT / 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -592,29 +703,27 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
     __syncthreads();
     const int whi    = s_whi;
     const bool last = done + n >= cnt;
-    // long B rows: one wave per A entry, two entries in flight per wave
-    for (int64_t a = wave; a < la_c; a += 2 * NW) {
-      const int64_t a1 = a + NW;
-      const bool ok0 = s_long[a] != 0, ok1 = a1 < la_c && s_long[a1] != 0;
-      if (!ok0 && !ok1) continue;
-      int64_t p0 = 0, p1 = 0;
-      int rem0 = 0, rem1 = 0;
-      VT av0 = VT(0), av1 = VT(0);
-      int c0[UL], c1[UL];
-      VT v0[UL], v1[UL];
-      if (ok0) { p0 = s_cur[a]; rem0 = s_rem[a]; av0 = s_av[a]; load_step(p0, rem0, c0, v0); }
-      if (ok1) { p1 = s_cur[a1]; rem1 = s_rem[a1]; av1 = s_av[a1]; load_step(p1, rem1, c1, v1); }
-      if (ok0) {
-        int nin = consume_step(c0, v0, av0, whi);
-        p0 += nin; rem0 -= nin;
-        while (nin == UL * 64) { load_step(p0, rem0, c0, v0); nin = consume_step(c0, v0, av0, whi); p0 += nin; rem0 -= nin; }
-        if (!last && lane == 0) { s_cur[a] = p0; s_rem[a] = rem0; }
+    // long B rows: one wave per A entry, EL entries in flight per wave
+    if (!(debug & 32)) for (int64_t a = wave; a < la_c; a += EL * NW) {
+      bool ok[EL];
+      int64_t p[EL];
+      int rem[EL];
+      VT av[EL];
+      int c[EL][UL];
+      VT v[EL][UL];
+      KK_UNROLL
+      for (int e = 0; e < EL; ++e) {
+        const int64_t ae = a + e * NW;
+        ok[e] = ae < la_c && s_long[ae] != 0;
+        if (ok[e]) { p[e] = s_cur[ae]; rem[e] = s_rem[ae]; av[e] = s_av[ae]; load_step(p[e], rem[e], c[e], v[e]); }
       }
-      if (ok1) {
-        int nin = consume_step(c1, v1, av1, whi);
-        p1 += nin; rem1 -= nin;
-        while (nin == UL * 64) { load_step(p1, rem1, c1, v1); nin = consume_step(c1, v1, av1, whi); p1 += nin; rem1 -= nin; }
-        if (!last && lane == 0) { s_cur[a1] = p1; s_rem[a1] = rem1; }
+      KK_UNROLL
+      for (int e = 0; e < EL; ++e) {
+        if (!ok[e]) continue;
+        int nin = consume_step(c[e], v[e], av[e], whi);
+        p[e] += nin; rem[e] -= nin;
+        while (nin == UL * 64) { load_step(p[e], rem[e], c[e], v[e]); nin = consume_step(c[e], v[e], av[e], whi); p[e] += nin; rem[e] -= nin; }
+        if (!last && lane == 0) { s_cur[a + e * NW] = p[e]; s_rem[a + e * NW] = rem[e]; }
       }
     }
     // short B rows: persistent sub-groups
@@ -628,6 +737,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
       if (have) { p = s_cur[a]; rem = s_rem[a]; av = s_av[a]; }
     };
     fetch();
+    if (debug & 64) have = false;
     while (true) {
       int c[US];
       VT v[US];
@@ -942,7 +1052,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       KK_HIP(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
       int32_t* seg = h->d_perm + h->num_off.off[4];
       int64_t lo = 0, len = nd;
-      const int64_t la_max[2] = {kValLa, kHubLa};
+      const int64_t la_max[2] = {g_spgemm.val_la < kValLa ? g_spgemm.val_la : kValLa, kHubLa};
       int64_t first[2] = {0, 0};
       for (int pass = 0; pass < 2 && len > 0; ++pass) {
         KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
@@ -987,7 +1097,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   do {                                                                                                                \
     if (cap > HH / 2) cap = HH / 2;                                                                                   \
     KK_LAUNCH((spgemm_dense_vals_kernel<OffT, VT, HH, NTT>), (unsigned)n_lds, NTT, 0, st, dperm, rmA, entA, valA, rmB, \
-              entB, valB, rmC, (const int32_t*)entC, valC, cap);                                                      \
+              entB, valB, rmC, (const int32_t*)entC, valC, cap, g_spgemm.debug);                                      \
   } while (0)
       switch (g_spgemm.val_shape) {
         case 1: KK_VALS(8192, 1024); break;
@@ -1046,6 +1156,7 @@ int spgemm_set_default(const char* key, int value) {
   } else if (k == "spgemm_force_unsorted") g_spgemm.force_unsorted = value != 0;
   else if (k == "spgemm_debug") g_spgemm.debug = value;
   else if (k == "spgemm_val_shape") g_spgemm.val_shape = value;
+  else if (k == "spgemm_val_la") g_spgemm.val_la = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "kkamd_set_default: unknown key '%s'", k.c_str());
   return KKAMD_OK;
 }
