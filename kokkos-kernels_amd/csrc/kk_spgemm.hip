@@ -188,6 +188,26 @@ template <class VT> __device__ __forceinline__ void hash_accumulate(int* keys, V
   }
 }
 
+// Value-window tables (keys distinct, load <= 1/2, so an empty slot always ends a probe sequence): Fibonacci hashing on
+// the high bits and a probe loop with no trip counter -- the wave-wide loop runs as long as its slowest lane, so every
+// instruction in it counts.
+template <int H> __device__ __forceinline__ int vt_hash(int key) {
+  constexpr int kBits = H == 2048 ? 11 : (H == 4096 ? 12 : 13);
+  static_assert(H == 2048 || H == 4096 || H == 8192, "value table size");
+  return (int)(((unsigned)key * 0x9E3779B1u) >> (32 - kBits));
+}
+template <int H> __device__ __forceinline__ int vt_insert(int* hk, int key) {          // returns the slot
+  int hh = vt_hash<H>(key);
+  while (atomicCAS(&hk[hh], -1, key) != -1) hh = (hh + 1) & (H - 1);
+  return hh;
+}
+template <int H> __device__ __forceinline__ int vt_find(const int* hk, int key) {       // slot, or -1 if absent
+  int hh = vt_hash<H>(key);
+  int kq = hk[hh];
+  while (kq != key && kq != -1) { hh = (hh + 1) & (H - 1); kq = hk[hh]; }
+  return kq == key ? hh : -1;
+}
+
 // Visit every product column of A(row,:)*B with `nthreads` cooperating work-items (id tid): sub-groups of 2^s lanes
 // share an A entry and stride over that B row.  s is at least sg_log2 (the matrix-wide hint: average B row length) and
 // grows for rows of A with few entries so that the sub-groups (nthreads >> s of them) just cover the row -- a row with
@@ -652,17 +672,15 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
   }
   for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
   auto accumulate = [&](int c, VT v) {
-    int hh = (int)(((unsigned)c * (unsigned)kHashMul) & (unsigned)(H - 1));
-    int probes = 0;
-    while (hk[hh] != c && probes < H) { hh = (hh + 1) & (H - 1); ++probes; }
-    if (probes < H) KK_ATOMIC_FADD(&hv[hh], v);
+    const int hh = vt_find<H>(hk, c);
+    if (hh >= 0) KK_ATOMIC_FADD(&hv[hh], v);
   };
   // one streaming step of a long B row by a whole wave: UL * 64 consecutive entries, columns and values loaded together
   auto load_step = [&](int64_t p, int rem, int* c, VT* v) {
     KK_UNROLL
     for (int u = 0; u < UL; ++u) {
       const int idx = u * 64 + lane;
-      const bool ok = idx < rem;
+      const bool ok = idx < rem && !(debug & 1024);
       c[u] = ok ? entB[p + idx] : INT_MAX;
       v[u] = ok ? valB[p + idx] : VT(0);
     }
@@ -672,7 +690,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
     KK_UNROLL
     for (int u = 0; u < UL; ++u) {
       const bool in = c[u] <= whi;
-      if (in) accumulate(c[u], av * v[u]);
+      if (in && !(debug & 512)) accumulate(c[u], av * v[u]);
       nin += __popcll(__ballot(in));
     }
     return nin;
@@ -688,9 +706,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
     for (int q = 0; q < KPT; ++q) {
       slot[q] = -1;
       if (curk[q] >= 0) {
-        int hh = (int)(((unsigned)curk[q] * (unsigned)kHashMul) & (unsigned)(H - 1));
-        while (atomicCAS(&hk[hh], -1, curk[q]) != -1) hh = (hh + 1) & (H - 1);
-        slot[q] = hh;
+        slot[q] = vt_insert<H>(hk, curk[q]);
         if (t + q * NT == n - 1) s_whi = curk[q];
       }
     }
@@ -823,9 +839,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
     for (int q = 0; q < KPT; ++q) {
       slot[q] = -1;
       if (curk[q] >= 0) {
-        int hh = (int)(((unsigned)curk[q] * (unsigned)kHashMul) & (unsigned)(H - 1));
-        while (atomicCAS(&hk[hh], -1, curk[q]) != -1) hh = (hh + 1) & (H - 1);
-        slot[q] = hh;
+        slot[q] = vt_insert<H>(hk, curk[q]);
         if (t + q * NT == n - 1) s_whi = curk[q];
       }
     }
@@ -873,10 +887,8 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
       for (int u = 0; u < US; ++u) {
         const bool in = c[u] <= whi;
         if (in) {
-          int hh = (int)(((unsigned)c[u] * (unsigned)kHashMul) & (unsigned)(H - 1));
-          int probes = 0;
-          while (hk[hh] != c[u] && probes < H) { hh = (hh + 1) & (H - 1); ++probes; }
-          if (probes < H) KK_ATOMIC_FADD(&hv[hh], av * v[u]);
+          const int hh = vt_find<H>(hk, c[u]);
+          if (hh >= 0) KK_ATOMIC_FADD(&hv[hh], av * v[u]);
         }
         nin += __popcll((__ballot(in) >> sg_shift) & 0xffffull);
       }
