@@ -69,7 +69,7 @@ struct BinLimits { int64_t lim[kNumBins - 1]; };   // size <= lim[b] -> bin b  (
 static const BinLimits kSymLimits = {{0, (kSymWaveTable * 2) / 3, kSymBlkS / 2, kSymBlkL / 2}};
 static const BinLimits kNumLimits = {{0, kWaveTable / 2, kNumBlkS / 2, (kNumBlkL * 2) / 3}};
 // B sorted: everything above the small block table goes to the column + windowed value kernels (no 8192-slot bitonic sort)
-static const BinLimits kNumLimitsSorted = {{0, kWaveTable / 2, kNumBlkS / 2, kNumBlkS / 2}};
+static const BinLimits kNumLimitsSorted = {{0, kWaveTable / 2, kWaveTable / 2, kWaveTable / 2}};
 
 __host__ __device__ __forceinline__ int bin_of(int64_t size, const BinLimits& L) {
   if (size <= L.lim[0]) return 0;
