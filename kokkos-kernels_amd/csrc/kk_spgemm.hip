@@ -5,22 +5,32 @@
 // pooled global second level, one Kokkos thread per row (K10) -> prefix sum (K11) -> hash numeric in three
 // team shapes (K12-K14) -> a separate per-row sort pass over C (K17).
 //
-// gfx950-native structure here.  A CU has 160 KB of LDS, so whole per-row hash tables live in LDS and
-// no second level / memory pool exists:
-//   1. spgemm_flops_kernel      upper bound per row, total multiplications, max.
-//   2. rows are BINNED by that bound (symbolic) / by their exact nnz (numeric) and each bin gets the
-//      launch shape that fits it:
-//         wave  per row, 512-slot   LDS table  (4 rows per workgroup)        small rows
-//         block per row, 4096-slot  LDS table                                medium rows
-//         block per row, 32768-slot key table (symbolic) / 8192-slot key+value table (numeric)
-//         block per row, DENSE bitmap (+ dense accumulator) in HBM            hub rows (R-MAT)
-//      Open addressing, linear probing, hash (col*107) & mask, empty = -1 -- the same function as the
+// gfx950-native structure here.  A CU has 160 KB of LDS, so every per-row working set (hash table, column bitmap,
+// value window) lives in LDS and no second level / memory pool exists; HBM holds accumulators only for the few rows of
+// A with more than 4096 entries (or for dense rows when B is not column-sorted):
+//   1. spgemm_flops_kernel      upper bound per row, total multiplications, max; rows_sorted_kernel: is B sorted?
+//   2. rows are BINNED by that bound (symbolic) / by their exact nnz (numeric); each bin gets the launch shape
+//      that fits it:
+//      symbolic   flops <= 1365    wave per row, 2048-slot key table (4 rows per workgroup)
+//                 flops <= 2048    256-thread workgroup, 4096-slot table
+//                 flops <= 16384   1024-thread workgroup, 32768-slot table
+//                 above            1024-thread workgroup, k-bit column BITMAP in LDS (2^20 columns per pass), popcount
+//      numeric    nnz <= 256       wave per row, 512-slot key+value table, compaction + rank-by-counting -> sorted
+//                 nnz <= 2048/5461 (only when B is unsorted) workgroup per row, 4096/8192-slot table, bitonic network
+//                 above (dense)    a) the bitmap kernel again, now EMITTING entries(C) in ascending order;
+//                                  b) values: the sorted entries are cut into windows of 2048, each hashed into an LDS
+//                                     table; every A entry keeps a cursor into its (sorted) B row, so a window only
+//                                     streams the part of each B row that falls inside it (dense_vals / hub_vals);
+//                                  c) A rows > 4096 entries or unsorted B: many workgroups per row, L2 atomics into
+//                                     a k-wide HBM accumulator, gathered in C order (hub_acc / hub_extract).
+//      Block-per-row kernels walk the row's products FLAT (flat_products): a scan of the B row lengths lets work-item q
+//      take product q, so all loads of a lane are independent -- sub-groups chasing "their" B row were bound by the
+//      entries(A) -> row_map(B) -> entries(B) latency chain.
+//      Small tables: open addressing, linear probing, hash (col*107) & mask, empty = -1 -- the same function as the
 //      reference's linear-probe kernels (sparse/impl/KokkosSparse_spgemm_impl_kkmem.hpp:17,679).
 //   3. exclusive scan of the counts -> row_map C, nnz(C) returned to the host.
-//   4. numeric accumulates with LDS atomics (ds_cmpst / ds_add_f64), then orders each row INSIDE the
-//      same kernel (rank-by-counting for wave rows, bitonic network for block rows, in-order bitmap walk
-//      for dense rows), so C leaves the kernel column-sorted and the reference's extra sort pass over
-//      C (numeric_spec.hpp:138-140) disappears.
+//   4. every numeric kernel leaves its rows column-sorted, so the reference's extra sort pass over C
+//      (numeric_spec.hpp:138-140) disappears.
 // Symbolic results are exact (bit-identical row_map / entries to the SPGEMM_DEBUG oracle after its
 // sort); numeric sums are order-dependent (atomics) and compared at 1e-6 relative.
 #include "kk_common.h"
