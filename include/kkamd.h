@@ -101,6 +101,15 @@ int kkamd_spmv_mv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, doub
                   int64_t x_stride0, int64_t x_stride1, double beta, void* d_Y, int64_t y_stride0, int64_t y_stride1,
                   int64_t nvec, int vector_type, kkamd_stream_t stream);
 
+/* KokkosSparse::Experimental::spmv_struct (sparse/src/KokkosSparse_spmv.hpp:478-559, impl
+ * sparse/impl/KokkosSparse_spmv_struct_impl.hpp:640-705): y := alpha*op(A)*x + beta*y for a matrix that comes from a
+ * 3-pt (1-D), 5-/9-pt (2-D, stencil_type 1 = FD / 2 = FE) or 7-/27-pt (3-D) stencil on a structure[0] x structure[1] x
+ * structure[2] grid, rows numbered i fastest.  Interior rows never read entries(): their idx-th value multiplies
+ * x(row + offset(idx)); exterior rows take the CRS row.  Like the reference it evaluates beta*y + alpha*sum for every
+ * row (also when beta == 0) and modes 'T'/'H' ignore the structure.  structure is a HOST array of ndim extents. */
+int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndim, const int64_t* structure, double alpha,
+                      const void* d_x, double beta, void* d_y, int vector_type, kkamd_stream_t stream);
+
 /* Expert knobs, the analogue of SPMVHandleImpl's public tuning members
  * (sparse/src/KokkosSparse_spmv_handle.hpp:243-252).  key: "kernel" (0 auto, 1 vector, 2 stream),
  * "lanes_per_row", "nnz_per_thread", "xcd_remap", "nontemporal", "mv_kernel".  Used by bench sweeps. */

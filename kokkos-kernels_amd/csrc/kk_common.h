@@ -47,6 +47,10 @@ template <class T> __device__ __forceinline__ T group_sum(T v, int width) {
   return v;
 }
 
+// argument checks shared by the SpMV entry points (kk_spmv.hip)
+int check_crs(const kkamd_crs_t* A);
+int parse_mode(char mode, bool* trans);
+
 // knobs whose key starts with "spgemm_" (kk_spgemm.hip); reached through kkamd_set_default
 int spgemm_set_default(const char* key, int value);
 

@@ -1086,7 +1086,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
   return launch_mv<OffT, AT, YT, 2>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
 }
 
-static int check_crs(const kkamd_crs_t* A) {
+int check_crs(const kkamd_crs_t* A) {
   if (!A) return fail(KKAMD_ERR_INVALID_ARG, "kkamd: null matrix descriptor");
   if (A->num_rows < 0 || A->num_cols < 0 || A->nnz < 0)
     return fail(KKAMD_ERR_INVALID_ARG, "kkamd: negative matrix dimension");
@@ -1111,7 +1111,7 @@ static int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   return KKAMD_OK;
 }
 
-static int parse_mode(char mode, bool* trans) {
+int parse_mode(char mode, bool* trans) {
   switch (mode) {
     case 'N': case 'n': case 'C': case 'c': *trans = false; return KKAMD_OK;
     case 'T': case 't': case 'H': case 'h': *trans = true; return KKAMD_OK;

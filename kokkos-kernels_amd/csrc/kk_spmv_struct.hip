@@ -1,0 +1,291 @@
+// kk_spmv_struct.hip -- KokkosSparse::Experimental::spmv_struct for gfx950: SpMV on a CRS matrix that is known to
+// come from a 3/5/9/7/27-point stencil on an ni x nj x nk grid.
+//
+// Reference (sparse/impl/KokkosSparse_spmv_struct_impl.hpp): interior grid points never read entries(): the column of
+// the idx-th value of an interior row is row + columnOffsets(idx) (:236-242, :270-278, :308-320, :350-360, :392-420),
+// y(row) = beta*y(row) + alpha*sum (:264); exterior points take the ordinary CRS row (:508-618); modes T/H ignore the
+// structure altogether (:733-773).  On a GPU the reference maps ONE interior row to a few vector lanes and gathers x
+// through the texture path, like its CRS kernel.
+//
+// gfx950-native structure: 8 bytes per nonzero instead of 12, and NO gather at all --
+//   * a workgroup takes a run of R = 128 consecutive interior rows of one grid line ("pencil" along i).  Their values
+//     are one contiguous block of R*S doubles in values(): it is streamed into LDS with coalesced loads;
+//   * the x entries those rows need are NL grid lines (1 / 3 / 3 / 5 / 9 for 3/5/9/7/27-pt) of R+2 consecutive
+//     elements each: staged in LDS with coalesced loads as well (9.4 KB for 27-pt), every element reused up to 27 times;
+//   * two work-items per row walk the stencil out of LDS (values at stride S, x at unit stride across lanes), one
+//     shuffle combines them, y is written coalesced.
+//   The contiguity of the values block is CHECKED per workgroup from row_map (the reference reads row_map per row too);
+//   a run whose rows do not have exactly S entries each falls back to reading values through row_map.
+//   * exterior rows (2.4 % of the rows at 300^3) are enumerated arithmetically and take 8 lanes per CRS row.
+#include "kk_common.h"
+#include <climits>
+
+namespace kk {
+
+constexpr int kStructRows = 128;                 // interior rows per workgroup (2 work-items per row)
+constexpr int kMaxStencil = 27, kMaxLines = 9;
+
+struct StencilDesc {
+  int ndim, S, NL;
+  int64_t ni, nj, nk;
+  int line[kMaxStencil];       // idx -> which staged x line
+  int di[kMaxStencil];         // idx -> offset along i
+  int64_t line_off[kMaxLines]; // line -> offset of its row relative to the current row (multiple of ni)
+};
+
+static int make_stencil(int stencil_type, int ndim, const int64_t* st, StencilDesc* d) {
+  d->ndim = ndim; d->ni = st[0]; d->nj = ndim > 1 ? st[1] : 1; d->nk = ndim > 2 ? st[2] : 1;
+  const int64_t ni = d->ni, nj = d->nj;
+  int n = 0;
+  if (ndim == 1) {
+    d->NL = 1; d->line_off[0] = 0;
+    for (int i = -1; i <= 1; ++i) { d->line[n] = 0; d->di[n] = i; ++n; }
+  } else if (ndim == 2 && stencil_type == 1) {          // -ni, -1, 0, 1, ni
+    d->NL = 3; d->line_off[0] = -ni; d->line_off[1] = 0; d->line_off[2] = ni;
+    d->line[0] = 0; d->di[0] = 0;
+    for (int i = -1; i <= 1; ++i) { d->line[1 + (i + 1)] = 1; d->di[1 + (i + 1)] = i; }
+    d->line[4] = 2; d->di[4] = 0; n = 5;
+  } else if (ndim == 2) {
+    d->NL = 3;
+    for (int j = -1; j <= 1; ++j) {
+      d->line_off[j + 1] = j * ni;
+      for (int i = -1; i <= 1; ++i) { d->line[n] = j + 1; d->di[n] = i; ++n; }
+    }
+  } else if (stencil_type == 1) {                        // -ni*nj, -ni, -1, 0, 1, ni, ni*nj
+    d->NL = 5;
+    d->line_off[0] = -ni * nj; d->line_off[1] = -ni; d->line_off[2] = 0; d->line_off[3] = ni; d->line_off[4] = ni * nj;
+    d->line[0] = 0; d->di[0] = 0; d->line[1] = 1; d->di[1] = 0;
+    for (int i = -1; i <= 1; ++i) { d->line[2 + (i + 1)] = 2; d->di[2 + (i + 1)] = i; }
+    d->line[5] = 3; d->di[5] = 0; d->line[6] = 4; d->di[6] = 0; n = 7;
+  } else {
+    d->NL = 9;
+    for (int k = -1; k <= 1; ++k)
+      for (int j = -1; j <= 1; ++j) {
+        const int l   = (k + 1) * 3 + (j + 1);
+        d->line_off[l] = k * ni * nj + j * ni;
+        for (int i = -1; i <= 1; ++i) { d->line[n] = l; d->di[n] = i; ++n; }
+      }
+  }
+  d->S = n;
+  return KKAMD_OK;
+}
+
+// compile-time stencil tables: idx -> (staged x line, offset along i); line -> (dj, dk)
+template <int NDIM, int ST> struct Stencil;
+template <int ST> struct Stencil<1, ST> {
+  static constexpr int S = 3, NL = 1;
+  static constexpr int line(int) { return 0; }
+  static constexpr int di(int idx) { return idx - 1; }
+  static constexpr int dj(int) { return 0; }
+  static constexpr int dk(int) { return 0; }
+};
+template <> struct Stencil<2, 1> {
+  static constexpr int S = 5, NL = 3;
+  static constexpr int line(int idx) { return idx == 0 ? 0 : (idx == 4 ? 2 : 1); }
+  static constexpr int di(int idx) { return (idx >= 1 && idx <= 3) ? idx - 2 : 0; }
+  static constexpr int dj(int l) { return l - 1; }
+  static constexpr int dk(int) { return 0; }
+};
+template <> struct Stencil<2, 2> {
+  static constexpr int S = 9, NL = 3;
+  static constexpr int line(int idx) { return idx / 3; }
+  static constexpr int di(int idx) { return idx % 3 - 1; }
+  static constexpr int dj(int l) { return l - 1; }
+  static constexpr int dk(int) { return 0; }
+};
+template <> struct Stencil<3, 1> {
+  static constexpr int S = 7, NL = 5;
+  static constexpr int line(int idx) { return idx <= 1 ? idx : (idx <= 4 ? 2 : idx - 2); }
+  static constexpr int di(int idx) { return (idx >= 2 && idx <= 4) ? idx - 3 : 0; }
+  static constexpr int dj(int l) { return l == 1 ? -1 : (l == 3 ? 1 : 0); }
+  static constexpr int dk(int l) { return l == 0 ? -1 : (l == 4 ? 1 : 0); }
+};
+template <> struct Stencil<3, 2> {
+  static constexpr int S = 27, NL = 9;
+  static constexpr int line(int idx) { return idx / 3; }
+  static constexpr int di(int idx) { return idx % 3 - 1; }
+  static constexpr int dj(int l) { return l % 3 - 1; }
+  static constexpr int dk(int l) { return l / 3 - 1; }
+};
+
+// interior rows: blockIdx.x -> (pencil, chunk of kStructRows rows along i).  Work-item t: row r = t & 127, stencil
+// half h = t >> 7 (wave-uniform, so both halves are straight-line code over compile-time tables).
+template <class OffT, class AT, class YT, int NDIM, int ST>
+__global__ __launch_bounds__(kBlock) void spmv_struct_interior_kernel(int64_t ni, int64_t nj, int chunks_per_pencil,
+                                                                      const OffT* __restrict__ rm, const AT* __restrict__ val,
+                                                                      const YT* __restrict__ x, YT* __restrict__ y, YT alpha,
+                                                                      YT beta) {
+  using St = Stencil<NDIM, ST>;
+  constexpr int S = St::S, NL = St::NL, R = kStructRows;
+  constexpr int VPT = (R * S + kBlock - 1) / kBlock;          // values per work-item
+  constexpr int HS  = (S + 1) / 2;                             // first stencil half
+  __shared__ AT s_v[R * S];
+  __shared__ YT s_x[NL][R + 2];
+  __shared__ YT s_part[R];
+  const int t = threadIdx.x;
+  const int64_t pencil = blockIdx.x / chunks_per_pencil;
+  const int chunk      = (int)(blockIdx.x % chunks_per_pencil);
+  int64_t j = 0, k = 0;
+  if (NDIM == 2) j = pencil + 1;
+  else if (NDIM == 3) { k = pencil / (nj - 2) + 1; j = pencil % (nj - 2) + 1; }
+  const int64_t i0   = 1 + (int64_t)chunk * R;                 // first interior i of this chunk
+  const int nr       = (int)((ni - 1 - i0 < R) ? ni - 1 - i0 : R);
+  const int64_t row0 = (k * nj + j) * ni + i0;
+  const int r = t & (R - 1), h = t >> 7;
+  // everything that does not depend on row_map is requested first: the x lines and the old y
+  YT xl[NL];
+  KK_UNROLL
+  for (int l = 0; l < NL; ++l) {
+    const int64_t off = ((int64_t)St::dk(l) * nj + St::dj(l)) * ni;
+    xl[l] = (t < nr + 2) ? x[row0 - 1 + off + t] : YT(0);
+  }
+  YT yold = (h == 0 && r < nr) ? y[row0 + r] : YT(0);
+  const long long v0    = (long long)rm[row0];
+  const bool contiguous = (long long)rm[row0 + nr] - v0 == (long long)nr * S;     // rows of exactly S entries each
+  AT vv[VPT];
+  if (contiguous) {
+    KK_UNROLL
+    for (int u = 0; u < VPT; ++u) { const int q = u * kBlock + t; vv[u] = (q < nr * S) ? val[v0 + q] : AT(0); }
+    KK_UNROLL
+    for (int u = 0; u < VPT; ++u) { const int q = u * kBlock + t; if (q < R * S) s_v[q] = vv[u]; }
+  }
+  KK_UNROLL
+  for (int l = 0; l < NL; ++l) if (t < R + 2) s_x[l][t] = xl[l];
+  __syncthreads();
+  YT sum = YT(0);
+  if (r < nr) {
+    if (contiguous) {
+      if (h == 0) {
+        KK_UNROLL
+        for (int idx = 0; idx < HS; ++idx) sum += (YT)s_v[r * S + idx] * s_x[St::line(idx)][r + 1 + St::di(idx)];
+      } else {
+        KK_UNROLL
+        for (int idx = HS; idx < S; ++idx) sum += (YT)s_v[r * S + idx] * s_x[St::line(idx)][r + 1 + St::di(idx)];
+      }
+    } else {                                                   // general row_map: values straight from HBM
+      const long long ro = (long long)rm[row0 + r];
+      if (h == 0) {
+        KK_UNROLL
+        for (int idx = 0; idx < HS; ++idx) sum += (YT)val[ro + idx] * s_x[St::line(idx)][r + 1 + St::di(idx)];
+      } else {
+        KK_UNROLL
+        for (int idx = HS; idx < S; ++idx) sum += (YT)val[ro + idx] * s_x[St::line(idx)][r + 1 + St::di(idx)];
+      }
+    }
+  }
+  if (h == 1) s_part[r] = sum;
+  __syncthreads();
+  if (h == 0 && r < nr) y[row0 + r] = beta * yold + alpha * (sum + s_part[r]);
+}
+
+// exterior rows, 8 lanes per CRS row.  e -> row: bottom plane, then for every middle plane the j = 0 line, the
+// j = nj-1 line and the two end points of the lines between, then the top plane (1-D / 2-D: the same with fewer levels).
+__device__ __forceinline__ int64_t exterior_row(const StencilDesc& d, int64_t e) {
+  const int64_t ni = d.ni, nj = d.nj, nk = d.nk;
+  if (d.ndim == 1) return e * (ni - 1);
+  const int64_t per_plane = 2 * ni + 2 * (nj - 2);          // exterior points of one 2-D layer
+  int64_t kk2 = 0, r = e;
+  if (d.ndim == 3) {
+    const int64_t plane = ni * nj;
+    if (e < plane) return e;
+    const int64_t mid = (nk - 2) * per_plane;
+    if (e >= plane + mid) return (nk - 1) * plane + (e - plane - mid);
+    kk2 = 1 + (e - plane) / per_plane;
+    r   = (e - plane) % per_plane;
+  }
+  const int64_t base = kk2 * ni * nj;
+  if (r < ni) return base + r;
+  if (r < 2 * ni) return base + (nj - 1) * ni + (r - ni);
+  const int64_t r2 = r - 2 * ni;
+  return base + (1 + r2 / 2) * ni + ((r2 & 1) ? ni - 1 : 0);
+}
+template <class OffT, class AT, class YT>
+__global__ __launch_bounds__(kBlock) void spmv_struct_exterior_kernel(StencilDesc d, int64_t num_ext, const OffT* __restrict__ rm,
+                                                                      const int32_t* __restrict__ ent, const AT* __restrict__ val,
+                                                                      const YT* __restrict__ x, YT* __restrict__ y, YT alpha,
+                                                                      YT beta) {
+  const int64_t e = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 8;
+  const int lane  = threadIdx.x & 7;
+  int64_t row = 0;
+  YT sum      = YT(0);
+  if (e < num_ext) {
+    row = exterior_row(d, e);
+    for (int64_t q = (int64_t)rm[row] + lane; q < (int64_t)rm[row + 1]; q += 8) sum += (YT)val[q] * x[ent[q]];
+  }
+  sum = group_sum(sum, 8);
+  if (e < num_ext && lane == 0) y[row] = beta * y[row] + alpha * sum;
+}
+
+template <class OffT, class AT, class YT>
+static int spmv_struct_typed(const StencilDesc& d, const kkamd_crs_t* A, double alpha, const void* x_, double beta, void* y_,
+                             hipStream_t st) {
+  const OffT* rm = (const OffT*)A->d_row_map;
+  const AT* val  = (const AT*)A->d_values;
+  const YT* x    = (const YT*)x_;
+  YT* y          = (YT*)y_;
+  const int64_t ni = d.ni, nj = d.nj, nk = d.nk;
+  const int64_t pencils  = d.ndim == 1 ? 1 : d.ndim == 2 ? nj - 2 : (nj - 2) * (nk - 2);
+  const int64_t interior = ni - 2;
+  int64_t num_int = 0;
+  if (interior > 0 && pencils > 0) {
+    const int64_t cpp = ceil_div(interior, kStructRows);
+    if (pencils * cpp > INT32_MAX) return fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: grid too large");
+    num_int = interior * pencils;
+#define KK_STRUCT_LAUNCH(ND, STT)                                                                                         \
+  KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT>), (unsigned)(pencils * cpp), kBlock, 0, st, ni, nj, (int)cpp, rm, \
+            val, x, y, (YT)alpha, (YT)beta)
+    if (d.ndim == 1) KK_STRUCT_LAUNCH(1, 1);
+    else if (d.ndim == 2 && d.S == 5) KK_STRUCT_LAUNCH(2, 1);
+    else if (d.ndim == 2) KK_STRUCT_LAUNCH(2, 2);
+    else if (d.S == 7) KK_STRUCT_LAUNCH(3, 1);
+    else KK_STRUCT_LAUNCH(3, 2);
+#undef KK_STRUCT_LAUNCH
+  }
+  const int64_t num_ext = ni * nj * nk - num_int;
+  if (num_ext > 0)
+    KK_LAUNCH((spmv_struct_exterior_kernel<OffT, AT, YT>), (unsigned)ceil_div(num_ext * 8, kBlock), kBlock, 0, st, d, num_ext, rm,
+              (const int32_t*)A->d_entries, val, x, y, (YT)alpha, (YT)beta);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+}  // namespace kk
+
+extern "C" int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndim, const int64_t* structure,
+                                 double alpha, const void* d_x, double beta, void* d_y, int vector_type,
+                                 kkamd_stream_t stream) {
+  int rc = kk::check_crs(A);
+  if (rc) return rc;
+  bool trans = false;
+  if ((rc = kk::parse_mode(mode, &trans))) return rc;
+  // transpose modes ignore the structure (spmv_struct_beta_transpose, :733-773)
+  if (trans) return kkamd_spmv(nullptr, A, mode, alpha, d_x, beta, d_y, vector_type, stream);
+  if (A->num_rows <= 0) return KKAMD_OK;                       // :659-661
+  if (ndim < 1 || ndim > 3 || !structure) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: structure must have 1..3 extents");
+  if (stencil_type != 1 && stencil_type != 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: stencil_type must be 1 (FD) or 2 (FE)");
+  int64_t n = 1;
+  for (int q = 0; q < ndim; ++q) {
+    if (structure[q] < 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: every grid extent must be at least 2");
+    n *= structure[q];
+  }
+  if (n != A->num_rows || A->num_cols < A->num_rows)
+    return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: structure (%lld points) does not match the %lld x %lld matrix",
+                    (long long)n, (long long)A->num_rows, (long long)A->num_cols);
+  if (vector_type != KKAMD_F32 && vector_type != KKAMD_F64)
+    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv_struct: unsupported vector_type %d", vector_type);
+  if (!d_x || !d_y) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: null vector");
+  kk::StencilDesc d;
+  kk::make_stencil(stencil_type, ndim, structure, &d);
+  hipStream_t st = kk::to_hip(stream);
+  const bool o64 = A->offset_type == KKAMD_I64;
+  if (A->value_type == KKAMD_F64 && vector_type == KKAMD_F64)
+    return o64 ? kk::spmv_struct_typed<int64_t, double, double>(d, A, alpha, d_x, beta, d_y, st)
+               : kk::spmv_struct_typed<int32_t, double, double>(d, A, alpha, d_x, beta, d_y, st);
+  if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F32)
+    return o64 ? kk::spmv_struct_typed<int64_t, float, float>(d, A, alpha, d_x, beta, d_y, st)
+               : kk::spmv_struct_typed<int32_t, float, float>(d, A, alpha, d_x, beta, d_y, st);
+  if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F64)
+    return o64 ? kk::spmv_struct_typed<int64_t, float, double>(d, A, alpha, d_x, beta, d_y, st)
+               : kk::spmv_struct_typed<int32_t, float, double>(d, A, alpha, d_x, beta, d_y, st);
+  return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv_struct: unsupported (value,vector) type pair (%d,%d)", A->value_type, vector_type);
+}

@@ -109,4 +109,101 @@ void spmv(const char mode[], const AlphaType& alpha, const AMatrix& A, const XVe
   spmv(typename AMatrix::execution_space(), &handle, mode, alpha, A, x, beta, y);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// KokkosSparse::Experimental::spmv_struct (sparse/src/KokkosSparse_spmv.hpp:478-848): SpMV for a matrix that comes
+// from a 3/5/9/7/27-point stencil; `structure` is a HOST view of the grid extents.  Same overload set as the reference:
+// {space, no space} x {explicit RANK_ONE / RANK_TWO tag, rank deduced}.  Rank-2 with one column takes the structured
+// path, more columns fall through to spmv (:803-831).
+struct RANK_ONE {};
+struct RANK_TWO {};
+namespace Experimental {
+
+template <class ExecutionSpace, class AlphaType, class AMatrix, class XVector, class BetaType, class YVector>
+void spmv_struct(const ExecutionSpace& space, const char mode[], const int stencil_type,
+                 const Kokkos::View<typename AMatrix::non_const_ordinal_type*, Kokkos::HostSpace>& structure,
+                 const AlphaType& alpha, const AMatrix& A, const XVector& x, const BetaType& beta, const YVector& y,
+                 const RANK_ONE&) {
+  static_assert((int)XVector::rank() == (int)YVector::rank(), "KokkosSparse::spmv_struct: Vector ranks do not match.");
+  static_assert((int)XVector::rank() == 1,
+                "KokkosSparse::spmv_struct: Both Vector inputs must have rank 1 in order to call this specialization of spmv.");
+  static_assert(!std::is_const<typename YVector::value_type>::value, "KokkosSparse::spmv_struct: Output Vector must be non-const.");
+  // the reference only requires the vectors to be long enough (:504-523)
+  if ((mode[0] == NoTranspose[0]) || (mode[0] == Conjugate[0])) {
+    if ((x.extent(1) != y.extent(1)) || (static_cast<size_t>(A.numCols()) > static_cast<size_t>(x.extent(0))) ||
+        (static_cast<size_t>(A.numRows()) > static_cast<size_t>(y.extent(0)))) {
+      std::ostringstream os;
+      os << "KokkosSparse::spmv_struct: Dimensions do not match: "
+         << ", A: " << A.numRows() << " x " << A.numCols() << ", x: " << x.extent(0) << " x " << x.extent(1)
+         << ", y: " << y.extent(0) << " x " << y.extent(1);
+      KokkosKernels::Impl::throw_runtime_exception(os.str());
+    }
+  } else {
+    if ((x.extent(1) != y.extent(1)) || (static_cast<size_t>(A.numCols()) > static_cast<size_t>(y.extent(0))) ||
+        (static_cast<size_t>(A.numRows()) > static_cast<size_t>(x.extent(0)))) {
+      std::ostringstream os;
+      os << "KokkosSparse::spmv_struct: Dimensions do not match (transpose): "
+         << ", A: " << A.numRows() << " x " << A.numCols() << ", x: " << x.extent(0) << " x " << x.extent(1)
+         << ", y: " << y.extent(0) << " x " << y.extent(1);
+      KokkosKernels::Impl::throw_runtime_exception(os.str());
+    }
+  }
+  if (x.stride(0) != 1 || y.stride(0) != 1) {     // strided rank-1 views: the unstructured path handles them
+    KokkosSparse::spmv(space, mode, alpha, A, x, beta, y);
+    return;
+  }
+  kkamd_crs_t desc = Impl::make_crs_desc(A);
+  int64_t ext[3]   = {1, 1, 1};
+  const int ndim   = (int)structure.extent(0);
+  for (int q = 0; q < ndim && q < 3; ++q) ext[q] = (int64_t)structure(q);
+  constexpr int vt = Impl::kkamd_scalar<typename YVector::non_const_value_type>::value;
+  Kokkos::Profiling::pushRegion("KokkosSparse::spmv_struct[KKAMD]");
+  Impl::kkamd_check(kkamd_spmv_struct(&desc, mode[0], stencil_type, ndim, ext, (double)alpha, x.data(), (double)beta, y.data(), vt,
+                                      reinterpret_cast<kkamd_stream_t>(space.hip_stream())));
+  Kokkos::Profiling::popRegion();
+}
+
+template <class ExecutionSpace, class AlphaType, class AMatrix, class XVector, class BetaType, class YVector>
+void spmv_struct(const ExecutionSpace& space, const char mode[], const int stencil_type,
+                 const Kokkos::View<typename AMatrix::non_const_ordinal_type*, Kokkos::HostSpace>& structure,
+                 const AlphaType& alpha, const AMatrix& A, const XVector& x, const BetaType& beta, const YVector& y,
+                 const RANK_TWO&) {
+  static_assert(XVector::rank() == YVector::rank(), "KokkosSparse::spmv: Vector ranks do not match.");
+  static_assert(!std::is_const<typename YVector::value_type>::value, "KokkosSparse::spmv: Output Vector must be non-const.");
+  if (x.extent(1) == 1 && x.extent(1) == y.extent(1)) {
+    auto x0 = Kokkos::subview(x, Kokkos::ALL(), 0);
+    auto y0 = Kokkos::subview(y, Kokkos::ALL(), 0);
+    spmv_struct(space, mode, stencil_type, structure, alpha, A, x0, beta, y0, RANK_ONE());
+    return;
+  }
+  KokkosSparse::spmv(space, mode, alpha, A, x, beta, y);
+}
+
+template <class AlphaType, class AMatrix, class XVector, class BetaType, class YVector, class Tag,
+          class = std::enable_if_t<std::is_same<Tag, RANK_ONE>::value || std::is_same<Tag, RANK_TWO>::value>>
+void spmv_struct(const char mode[], const int stencil_type,
+                 const Kokkos::View<typename AMatrix::non_const_ordinal_type*, Kokkos::HostSpace>& structure,
+                 const AlphaType& alpha, const AMatrix& A, const XVector& x, const BetaType& beta, const YVector& y,
+                 const Tag& tag) {
+  spmv_struct(typename AMatrix::execution_space{}, mode, stencil_type, structure, alpha, A, x, beta, y, tag);
+}
+
+template <class AlphaType, class AMatrix, class XVector, class BetaType, class YVector>
+void spmv_struct(const char mode[], const int stencil_type,
+                 const Kokkos::View<typename AMatrix::non_const_ordinal_type*, Kokkos::HostSpace>& structure,
+                 const AlphaType& alpha, const AMatrix& A, const XVector& x, const BetaType& beta, const YVector& y) {
+  using RANK_SPECIALISE = typename std::conditional<XVector::rank() == 2, RANK_TWO, RANK_ONE>::type;
+  spmv_struct(mode, stencil_type, structure, alpha, A, x, beta, y, RANK_SPECIALISE());
+}
+
+template <class ExecutionSpace, class AlphaType, class AMatrix, class XVector, class BetaType, class YVector,
+          class = std::enable_if_t<std::is_same<typename ExecutionSpace::execution_space, ExecutionSpace>::value>>
+void spmv_struct(const ExecutionSpace& space, const char mode[], const int stencil_type,
+                 const Kokkos::View<typename AMatrix::non_const_ordinal_type*, Kokkos::HostSpace>& structure,
+                 const AlphaType& alpha, const AMatrix& A, const XVector& x, const BetaType& beta, const YVector& y) {
+  using RANK_SPECIALISE = typename std::conditional<XVector::rank() == 2, RANK_TWO, RANK_ONE>::type;
+  spmv_struct(space, mode, stencil_type, structure, alpha, A, x, beta, y, RANK_SPECIALISE());
+}
+
+}  // namespace Experimental
+
 }  // namespace KokkosSparse

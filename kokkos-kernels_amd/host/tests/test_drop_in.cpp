@@ -3,6 +3,7 @@
 //   test_github_issue_101            sparse/unit_test/Test_Sparse_spmv.hpp:823-961 (exact known answer)
 //   test_spmv_all_interfaces_light   :964-1055 (space/handle/neither x rank-1/rank-2 on 111 x 99)
 //   spgemm view/matrix/no-reuse APIs sparse/unit_test/Test_Sparse_spgemm.hpp:243-252,444-481
+//   spmv_struct (2-D 5-pt, every overload) sparse/unit_test/Test_Sparse_spmv.hpp:263-296,652-711
 // Expected values come from the test's own sequential loops, as in the reference's tests.
 #include <cmath>
 #include <cstdio>
@@ -181,8 +182,73 @@ void test_spgemm() {
   EXPECT(threw);
 }
 
+// 5-pt stencil on an ni x nj grid: interior rows hold -1 -1 4 -1 -1 in ascending column order, boundary rows the
+// identity (like the reference generator with every BC = 1); expected values from a sequential CRS loop.
+void test_spmv_struct() {
+  using M = KokkosSparse::CrsMatrix<double, int, device, void, int>;
+  const int ni = 37, nj = 11, n = ni * nj;
+  std::vector<int> rm(n + 1, 0), ent; std::vector<double> val;
+  for (int j = 0; j < nj; ++j)
+    for (int i = 0; i < ni; ++i) {
+      const int r = j * ni + i;
+      if (i == 0 || j == 0 || i == ni - 1 || j == nj - 1) { ent.push_back(r); val.push_back(1.0); }
+      else {
+        const int c[5] = {r - ni, r - 1, r, r + 1, r + ni};
+        const double v[5] = {-1.0, -1.5, 4.25, -0.5, -1.25};
+        for (int q = 0; q < 5; ++q) { ent.push_back(c[q]); val.push_back(v[q]); }
+      }
+      rm[r + 1] = (int)ent.size();
+    }
+  typename M::row_map_type::non_const_type d_rm("rm", n + 1);
+  typename M::index_type d_ent("ent", ent.size());
+  typename M::values_type d_val("val", val.size());
+  Kokkos::deep_copy(d_rm, Kokkos::View<int*, Kokkos::HostSpace>(rm.data(), rm.size()));
+  Kokkos::deep_copy(d_ent, Kokkos::View<int*, Kokkos::HostSpace>(ent.data(), ent.size()));
+  Kokkos::deep_copy(d_val, Kokkos::View<double*, Kokkos::HostSpace>(val.data(), val.size()));
+  M A("A", n, n, ent.size(), d_val, d_rm, d_ent);
+  Kokkos::View<int*, Kokkos::HostSpace> structure("structure", 2);
+  structure(0) = ni; structure(1) = nj;
+  std::mt19937 g(13718);
+  std::vector<double> hx(n), hy(n), expect(n);
+  for (int i = 0; i < n; ++i) { hx[i] = (g() % 1000) / 1000.0; hy[i] = (g() % 1000) / 1000.0; }
+  const double alpha = 1.5, beta = -0.5;
+  for (int r = 0; r < n; ++r) {
+    double sum = 0;
+    for (int q = rm[r]; q < rm[r + 1]; ++q) sum += val[q] * hx[ent[q]];
+    expect[r] = beta * hy[r] + alpha * sum;
+  }
+  auto check = [&](const double* got) {
+    bool ok = true;
+    for (int r = 0; r < n; ++r) ok = ok && std::fabs(got[r] - expect[r]) <= 1e-13 * 20;
+    EXPECT(ok);
+  };
+  Kokkos::View<double*, device> x("x", n), y("y", n);
+  auto y_h = Kokkos::create_mirror_view(y);
+  Kokkos::deep_copy(x, Kokkos::View<double*, Kokkos::HostSpace>(hx.data(), n));
+  auto reset = [&]() { Kokkos::deep_copy(y, Kokkos::View<double*, Kokkos::HostSpace>(hy.data(), n)); };
+  reset(); KokkosSparse::Experimental::spmv_struct("N", 1, structure, alpha, A, x, beta, y);
+  Kokkos::deep_copy(y_h, y); check(y_h.data());
+  reset(); KokkosSparse::Experimental::spmv_struct(Kokkos::HIP(), "N", 1, structure, alpha, A, x, beta, y);
+  Kokkos::deep_copy(y_h, y); check(y_h.data());
+  reset(); KokkosSparse::Experimental::spmv_struct("N", 1, structure, alpha, A, x, beta, y, KokkosSparse::RANK_ONE());
+  Kokkos::deep_copy(y_h, y); check(y_h.data());
+  // rank-2 with a single column takes the structured path as well (:803-826)
+  Kokkos::View<double**, Kokkos::LayoutLeft, device> X("X", n, 1), Y("Y", n, 1);
+  auto Y_h = Kokkos::create_mirror_view(Y);
+  Kokkos::deep_copy(Kokkos::subview(X, Kokkos::ALL(), 0), Kokkos::View<double*, Kokkos::HostSpace>(hx.data(), n));
+  Kokkos::deep_copy(Kokkos::subview(Y, Kokkos::ALL(), 0), Kokkos::View<double*, Kokkos::HostSpace>(hy.data(), n));
+  KokkosSparse::Experimental::spmv_struct("N", 1, structure, alpha, A, X, beta, Y);
+  Kokkos::deep_copy(Y_h, Y); check(Y_h.data());
+  // dimension check
+  bool threw = false;
+  Kokkos::View<double*, device> xs("xs", n - 1);
+  try { KokkosSparse::Experimental::spmv_struct("N", 1, structure, alpha, A, xs, beta, y); } catch (const std::runtime_error&) { threw = true; }
+  EXPECT(threw);
+}
+
 int main() {
   Kokkos::initialize();
+  test_spmv_struct();
   test_github_issue_101();
   test_all_interfaces<Kokkos::LayoutLeft>();
   test_all_interfaces<Kokkos::LayoutRight>();

@@ -200,6 +200,37 @@ def spmv(*args):
     return y
 
 
+def spmv_struct(mode, stencil_type, structure, alpha, A, x, beta, y):
+    """KokkosSparse::Experimental::spmv_struct (sparse/src/KokkosSparse_spmv.hpp:478-848).  structure: the grid extents
+    (ni[, nj[, nk]]) as a host sequence; stencil_type 1 = FD (3/5/7-pt), 2 = FE (3/9/27-pt).  Rank-2 x/y with one
+    column take the structured path, more columns fall through to spmv (:803-831)."""
+    be, lib = A.backend, A.backend.lib
+    if len(x.shape) != len(y.shape) or len(x.shape) not in (1, 2):
+        raise RuntimeError("KokkosSparse::spmv_struct: Vector ranks do not match.")
+    m, n = A.numRows(), A.numCols()
+    xr, yr = x.shape[0], y.shape[0]
+    xc = x.shape[1] if len(x.shape) == 2 else 1
+    yc = y.shape[1] if len(y.shape) == 2 else 1
+    if mode[0] not in "NnCcTtHh":
+        raise RuntimeError("Invalid transpose mode %s for KokkosSparse::spmv_struct()" % mode)
+    trans = mode[0] in "TtHh"
+    # the reference only requires the vectors to be long enough here (:504-523)
+    if xc != yc or (not trans and (n > xr or m > yr)) or (trans and (n > yr or m > xr)):
+        raise RuntimeError("KokkosSparse::spmv_struct: Dimensions do not match%s: , A: %d x %d, x: %d x %d, y: %d x %d"
+                           % (" (transpose)" if trans else "", m, n, xr, xc, yr, yc))
+    if len(x.shape) == 2:
+        if xc != 1:
+            return spmv(mode, alpha, A, x, beta, y)
+        xs, ys = _strides(x), _strides(y)
+        if xs[0] != 1 or ys[0] != 1:
+            return spmv(mode, alpha, A, x, beta, y)
+    st = (C.c_int64 * len(structure))(*[int(v) for v in structure])
+    d = A.desc()
+    check(lib, lib.kkamd_spmv_struct(C.byref(d), mode[0].encode(), int(stencil_type), len(structure), st, float(alpha),
+                                     be.ptr(x), float(beta), be.ptr(y), _scalar_type(y), be.stream()))
+    return y
+
+
 class _SpgemmHandle:
     def __init__(self, backend):
         self.backend = backend

@@ -106,6 +106,92 @@ int kko_spmv_sequential(char mode, int64_t nrows, int64_t ncols, const int64_t* 
   return 0;
 }
 
+/* Structured SpMV: KokkosSparse::Experimental::spmv_struct on a host execution space
+ * (sparse/impl/KokkosSparse_spmv_struct_impl.hpp).
+ *   'N'/'C': interior grid points (every coordinate in [1, n-2]) are computed WITHOUT reading entries():
+ *     sum_idx values(row_map(row)+idx) * x(row + columnOffsets(idx)) in idx order, columnOffsets as set up
+ *     per stencil at :236-242 (3pt), :270-278 (5pt), :308-320 (9pt), :350-360 (7pt), :392-420 (27pt);
+ *     row index from the interior index at :252,:286-288,:328-330,:370-374,:430-434; then
+ *     y(row) = beta*y(row) + alpha*sum (:264,:300 ...).  Exterior points go through the CRS row
+ *     (:508-523 1-D, :525-557 2-D, :560-618 3-D); their exteriorIdx -> row maps are restated verbatim.
+ *   'T'/'H': the structure is ignored, spmv_struct_beta_transpose (:733-773) = scale y then atomic adds.
+ * stencil_type 1 = FD (3/5/7-pt), 2 = FE (3/9/27-pt).  Returns -1 on a bad mode, -2 on a bad structure. */
+static void kko_struct_crs_row(int64_t row, const int64_t* row_map, const int32_t* entries, const double* values,
+                               double alpha, const double* x, double beta, double* y) {
+  double sum = 0.0;
+  for (int64_t j = row_map[row]; j < row_map[row + 1]; ++j) sum += values[j] * x[entries[j]];
+  y[row] = beta * y[row] + alpha * sum;
+}
+int kko_spmv_struct(char mode, int stencil_type, int ndim, const int64_t* structure, int64_t nrows, int64_t ncols,
+                    const int64_t* row_map, const int32_t* entries, const double* values, double alpha,
+                    const double* x, double beta, double* y) {
+  if (mode == 'T' || mode == 'H') return kko_spmv_sequential(mode, nrows, ncols, row_map, entries, values, alpha, x, beta, y);
+  if (mode != 'N' && mode != 'C') return -1;
+  if (nrows <= 0) return 0;
+  if (ndim < 1 || ndim > 3 || (stencil_type != 1 && stencil_type != 2)) return -2;
+  const int64_t ni = structure[0], nj = ndim > 1 ? structure[1] : 1, nk = ndim > 2 ? structure[2] : 1;
+  int64_t off[27];
+  int ns = 0;
+  if (ndim == 1) { off[0] = -1; off[1] = 0; off[2] = 1; ns = 3; }
+  else if (ndim == 2 && stencil_type == 1) { off[0] = -ni; off[1] = -1; off[2] = 0; off[3] = 1; off[4] = ni; ns = 5; }
+  else if (ndim == 2) {
+    for (int dj = -1; dj <= 1; ++dj) for (int di = -1; di <= 1; ++di) off[ns++] = dj * ni + di;
+  } else if (stencil_type == 1) {
+    off[0] = -ni * nj; off[1] = -ni; off[2] = -1; off[3] = 0; off[4] = 1; off[5] = ni; off[6] = ni * nj; ns = 7;
+  } else {
+    for (int dk = -1; dk <= 1; ++dk) for (int dj = -1; dj <= 1; ++dj) for (int di = -1; di <= 1; ++di)
+      off[ns++] = dk * ni * nj + dj * ni + di;
+  }
+  /* interior */
+  const int64_t numInterior = ndim == 1 ? ni - 2 : ndim == 2 ? (ni - 2) * (nj - 2) : (ni - 2) * (nj - 2) * (nk - 2);
+  for (int64_t q = 0; q < numInterior; ++q) {
+    int64_t row;
+    if (ndim == 1) row = q + 1;
+    else if (ndim == 2) { const int64_t j = q / (ni - 2), i = q % (ni - 2); row = (j + 1) * ni + i + 1; }
+    else {
+      const int64_t k = q / ((ni - 2) * (nj - 2)), rem = q % ((ni - 2) * (nj - 2));
+      const int64_t j = rem / (ni - 2), i = rem % (ni - 2);
+      row = (k + 1) * nj * ni + (j + 1) * ni + (i + 1);
+    }
+    const int64_t ro = row_map[row];
+    double sum = 0.0;
+    for (int idx = 0; idx < ns; ++idx) sum += values[ro + idx] * x[row + off[idx]];
+    y[row] = beta * y[row] + alpha * sum;
+  }
+  /* exterior */
+  if (ndim == 1) {
+    for (int64_t e = 0; e < 2; ++e) kko_struct_crs_row(e * (ni - 1), row_map, entries, values, alpha, x, beta, y);
+  } else if (ndim == 2) {
+    const int64_t numExterior = 2 * (nj + ni - 2);
+    for (int64_t e = 0; e < numExterior; ++e) {
+      const int64_t topFlag = e / (ni + 2 * nj - 4), bottomFlag = (e / ni) == 0;
+      int64_t row;
+      if (bottomFlag) row = e;
+      else if (topFlag == 1) row = e - (ni + 2 * nj - 4) + ni * (nj - 1);
+      else { const int64_t edgeIdx = (e - ni) / 2, edgeFlg = (e - ni) % 2; row = (edgeIdx + 1) * ni + edgeFlg * (ni - 1); }
+      kko_struct_crs_row(row, row_map, entries, values, alpha, x, beta, y);
+    }
+  } else {
+    const int64_t numExterior = ni * nj * nk - numInterior;
+    for (int64_t e = 0; e < numExterior; ++e) {
+      const int64_t topFlag = (numExterior - e - 1 < ni * nj), bottomFlag = (e / (ni * nj) == 0);
+      int64_t row = 0;
+      if (bottomFlag) row = e;
+      else if (topFlag) row = e - ni * nj - 2 * (nk - 2) * (nj + ni - 2) + (nk - 1) * ni * nj;
+      else {
+        const int64_t k = (e - ni * nj) / (2 * (ni - 1 + nj - 1)), rem = (e - ni * nj) % (2 * (ni - 1 + nj - 1));
+        if (rem < ni) row = (k + 1) * ni * nj + rem;
+        else if (rem < ni + 2 * (nj - 2)) {
+          const int64_t edgeIdx = (rem - ni) / 2, edgeFlg = (rem - ni) % 2;
+          row = edgeFlg == 0 ? (k + 1) * ni * nj + (edgeIdx + 1) * ni : (k + 1) * ni * nj + (edgeIdx + 2) * ni - 1;
+        } else row = (k + 1) * ni * nj + rem - ni - 2 * (nj - 2) + (nj - 1) * ni;
+      }
+      kko_struct_crs_row(row, row_map, entries, values, alpha, x, beta, y);
+    }
+  }
+  return 0;
+}
+
 /* Rank-2 SpMV on a host execution space.
  * No-transpose: SPMV_MV_LayoutLeft_Functor::strip_mine<UNROLL>(iRow, kk),
  * sparse/impl/KokkosSparse_spmv_impl.hpp:745-792 (per column k:
@@ -340,6 +426,27 @@ int kko_transpose(int32_t nrows, int32_t ncols, const int64_t* row_map, const in
  *   (Q4-Q6 found by comparing against the interpreted reference per node class,
  *   tests/golden/make_structured_golden.py; all three keep 1.0 on the diagonal.)
  */
+/* 1-D 3-pt matrix: Test::generate_structured_matrix1D / fill_1D_matrix_functor
+ * (test_common/KokkosKernels_Test_Structured_Matrix.hpp:52-131): interior rows -1, 2, -1; the two end rows hold
+ * (1, 0) / (0, 1) with a BC flag of 1 and (1, -1) / (-1, 1) otherwise.  nnz = 3*(nx-2) + 4. */
+int kko_gen_laplace1d(int64_t nx, int leftBC, int rightBC, int64_t* row_map, int32_t* entries, double* values) {
+  if (nx < 2) return -1; /* reference throws: :62-68 */
+  const int64_t nnz = 3 * (nx - 2) + 4;
+  row_map[0] = 0; row_map[1] = 2;
+  entries[0] = 0; entries[1] = 1;
+  values[0] = 1.0; values[1] = leftBC == 1 ? 0.0 : -1.0;
+  for (int64_t r = 1; r + 1 < nx; ++r) {
+    const int64_t o = r * 3 + 2;
+    row_map[r + 1] = o;
+    entries[o - 3] = (int32_t)(r - 1); entries[o - 2] = (int32_t)r; entries[o - 1] = (int32_t)(r + 1);
+    values[o - 3] = -1.0; values[o - 2] = 2.0; values[o - 1] = -1.0;
+  }
+  row_map[nx] = nnz;
+  entries[nnz - 2] = (int32_t)(nx - 2); entries[nnz - 1] = (int32_t)(nx - 1);
+  values[nnz - 2] = rightBC == 1 ? 0.0 : -1.0; values[nnz - 1] = 1.0;
+  return 0;
+}
+
 int64_t kko_laplace2d_nnz(int stencil, int64_t nx, int64_t ny) {
   const int64_t il = stencil ? 9 : 5, el = stencil ? 6 : 4, cl = stencil ? 4 : 3;
   return (nx - 2) * (ny - 2) * il + (2 * (nx - 2) + 2 * (ny - 2)) * el + 4 * cl;

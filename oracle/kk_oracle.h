@@ -39,6 +39,10 @@ int kko_spmv_serial_f32(char mode, int64_t nrows, int64_t ncols, const int64_t* 
 /* the unit test's own oracle (sequential_spmv) */
 int kko_spmv_sequential(char mode, int64_t nrows, int64_t ncols, const int64_t* row_map, const int32_t* entries,
                         const double* values, double alpha, const double* x, double beta, double* y);
+/* KokkosSparse::Experimental::spmv_struct (host path): ndim 1..3, structure = {ni[,nj[,nk]]}, stencil_type 1 FD / 2 FE */
+int kko_spmv_struct(char mode, int stencil_type, int ndim, const int64_t* structure, int64_t nrows, int64_t ncols,
+                    const int64_t* row_map, const int32_t* entries, const double* values, double alpha,
+                    const double* x, double beta, double* y);
 /* rank-2: X is ncols x nvec, Y is nrows x nvec; element (i,k) at i*xs0 + k*xs1. */
 int kko_spmv_mv_serial(char mode, int64_t nrows, int64_t ncols, int64_t nvec, const int64_t* row_map,
                        const int32_t* entries, const double* values, double alpha, const double* X, int64_t xs0,
@@ -65,6 +69,7 @@ int kko_transpose(int32_t nrows, int32_t ncols, const int64_t* row_map, const in
 /* stencil: 0 = FD (5-pt / 7-pt), 1 = FE (9-pt / 27-pt). */
 int64_t kko_laplace2d_nnz(int stencil, int64_t nx, int64_t ny);
 int64_t kko_laplace3d_nnz(int stencil, int64_t nx, int64_t ny, int64_t nz);
+int kko_gen_laplace1d(int64_t nx, int leftBC, int rightBC, int64_t* row_map, int32_t* entries, double* values);
 /* bc[4] = {left,right,bottom,top}; each 0 or 1. */
 int kko_gen_laplace2d(int stencil, int64_t nx, int64_t ny, const int* bc, int64_t* row_map, int32_t* entries,
                       double* values);

@@ -88,6 +88,17 @@ def spmv_sequential(mode, A, alpha, x, beta, y):
     return y
 
 
+def spmv_struct(mode, stencil_type, structure, A, alpha, x, beta, y):
+    """KokkosSparse::Experimental::spmv_struct, host path; structure = (ni[, nj[, nk]])."""
+    st = np.asarray(structure, dtype=np.int64)
+    rc = lib().kko_spmv_struct(C.c_char(mode.encode()), C.c_int(stencil_type), C.c_int(len(st)), _p(st), _i64(A.nrows),
+                               _i64(A.ncols), _p(A.row_map), _p(A.entries), _p(A.values), C.c_double(alpha), _p(x),
+                               C.c_double(beta), _p(y))
+    if rc != 0:
+        raise ValueError("kko_spmv_struct rc=%d" % rc)
+    return y
+
+
 def spmv_mv_serial(mode, A, alpha, X, beta, Y):
     """X: (ncols|nrows) x nvec, Y likewise; any strides (numpy order C or F)."""
     assert X.dtype == np.float64 and Y.dtype == np.float64 and X.ndim == 2 and Y.ndim == 2
@@ -174,6 +185,15 @@ def is_same_matrix(C1, C2, eps=1e-7):
 
 
 # --------------------------------------------------------------------------- generators
+def laplace1d(nx, bc=(1, 1)):
+    nnz = 3 * (nx - 2) + 4
+    rm = np.zeros(nx + 1, dtype=np.int64); ent = np.zeros(nnz, dtype=np.int32); val = np.zeros(nnz)
+    rc = lib().kko_gen_laplace1d(_i64(nx), C.c_int(bc[0]), C.c_int(bc[1]), _p(rm), _p(ent), _p(val))
+    if rc != 0:
+        raise ValueError("kko_gen_laplace1d rc=%d" % rc)
+    return Crs(nx, nx, rm, ent, val)
+
+
 def laplace2d(stencil, nx, ny, bc=(1, 1, 1, 1)):
     s = {"FD": 0, "FE": 1}[stencil]
     nnz = lib().kko_laplace2d_nnz(s, _i64(nx), _i64(ny))

@@ -150,3 +150,41 @@ def hub_matrix(n, ncols, base_nnz, hubs, seed=0):
     for i in range(n):
         ent[rm[i]:rm[i + 1]] = np.sort(rng.choice(ncols, size=lens[i], replace=False))
     return oracle.Crs(n, ncols, rm, ent, 1 + 49 * rng.random(rm[-1]))
+
+
+# --- spmv_struct: the reference's own cases (sparse/unit_test/Test_Sparse_spmv.hpp:609-768, 1096-1104) -----------------
+STRUCT_CASES_1D = [(10,)]
+STRUCT_CASES_2D = [(25, 21), (20, 25), (22, 22)]
+STRUCT_CASES_3D = [(20, 20, 20), (22, 22, 22), (25, 10, 20), (10, 20, 25), (10, 24, 20)]
+
+
+def struct_matrix(dims, stencil_type):
+    if len(dims) == 1:
+        return oracle.laplace1d(dims[0])
+    name = "FD" if stencil_type == 1 else "FE"
+    return oracle.laplace2d(name, *dims) if len(dims) == 2 else oracle.laplace3d(name, *dims)
+
+
+def check_spmv_struct(be, dims, stencil_type, mode="N", offset_dtype=np.int32, value_dtype=None, vec_dtype=np.float64,
+                      seed=13718, A0=None, rank2=False):
+    """check_spmv_struct of the reference test (:263-296): alpha/beta in (1,0), (0,1), (1,1) against the oracle's
+    restatement of the host path (itself checked against sequential_spmv in test_oracle.py)."""
+    A0 = A0 if A0 is not None else struct_matrix(dims, stencil_type)
+    rng = np.random.default_rng(seed)
+    trans = mode in "TH"
+    nin, nout = (A0.nrows, A0.ncols) if trans else (A0.ncols, A0.nrows)
+    x = rng.random(nin).astype(vec_dtype); y0 = rng.random(nout).astype(vec_dtype)
+    A = dev(be, A0, offset_dtype, value_dtype)
+    Ao = A0 if value_dtype is None else oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries,
+                                                   A0.values.astype(value_dtype).astype(np.float64))
+    max_val = float(np.abs(A0.values).max())
+    for alpha, beta in ((1.0, 0.0), (0.0, 1.0), (1.0, 1.0), (-2.5, 0.5)):
+        xd, yd = be.from_numpy(x.reshape(-1, 1) if rank2 else x), be.from_numpy(y0.reshape(-1, 1) if rank2 else y0)
+        kk.spmv_struct(mode, stencil_type, dims, alpha, A, xd, beta, yd)
+        got = be.to_numpy(yd).astype(np.float64).reshape(-1)
+        exp = oracle.spmv_struct(mode, stencil_type, dims, Ao, alpha, x.astype(np.float64), beta, y0.astype(np.float64).copy())
+        eps_scale = 1.0 if vec_dtype == np.float64 else EPS_F / np.finfo(np.float64).eps
+        tol = oracle.spmv_max_error(A0, alpha, beta, max_val=max_val) * eps_scale
+        ok, err = fspmv_ok(exp, got, max(tol, 1e-300))
+        assert ok, "spmv_struct mismatch dims=%s stencil=%d mode=%s alpha=%g beta=%g: max err %g > tol %g" % (
+            dims, stencil_type, mode, alpha, beta, err, tol)

@@ -142,6 +142,37 @@ def test_mv_long_rows_chunked_staging(be):
     pc.check_spmv_mv(be, A0, 3, "N", 1.0, 0.0, "F", "F")
 
 
+@pytest.mark.parametrize("dims,st", [(d, 1) for d in pc.STRUCT_CASES_1D + pc.STRUCT_CASES_2D + pc.STRUCT_CASES_3D[:3]] +
+                         [(d, 2) for d in pc.STRUCT_CASES_2D + pc.STRUCT_CASES_3D[2:]])
+def test_spmv_struct_reference_cases(be, dims, st):
+    pc.check_spmv_struct(be, dims, st)
+
+
+def test_spmv_struct_variants(be):
+    pc.check_spmv_struct(be, (140, 5, 4), 2)                       # more than one 128-row chunk per grid line
+    pc.check_spmv_struct(be, (131, 6), 1, offset_dtype=np.int64)
+    pc.check_spmv_struct(be, (3, 3, 3), 2)                         # a single interior point
+    pc.check_spmv_struct(be, (2, 7), 1)                            # no interior at all
+    pc.check_spmv_struct(be, (12, 9, 7), 2, value_dtype=np.float32, vec_dtype=np.float32)
+    pc.check_spmv_struct(be, (12, 9, 7), 1, value_dtype=np.float32)             # float matrix, double vectors
+    pc.check_spmv_struct(be, (9, 8, 7), 2, mode="T"); pc.check_spmv_struct(be, (9, 8), 2, mode="H")
+    pc.check_spmv_struct(be, (9, 8, 7), 2, mode="C", rank2=True)
+    # interior rows that do not have exactly S entries: the per-row path through row_map must take over
+    A0 = oracle.laplace2d("FE", 40, 6)
+    rm = A0.row_map.copy(); ent = A0.entries; val = A0.values
+    r = 1 * 40 + 7                                                  # an interior row: give it one extra explicit zero at the end
+    ent2 = np.insert(ent, rm[r + 1], ent[rm[r + 1] - 1]); val2 = np.insert(val, rm[r + 1], 0.0); rm[r + 1:] += 1
+    pc.check_spmv_struct(be, (40, 6), 2, A0=oracle.Crs(A0.nrows, A0.ncols, rm, ent2.astype(np.int32), val2))
+    A = pc.dev(be, oracle.laplace2d("FD", 8, 8))
+    x = be.from_numpy(np.ones(64)); y = be.from_numpy(np.zeros(64))
+    with pytest.raises(pc.kk.KkamdError, match="does not match"):
+        pc.kk.spmv_struct("N", 1, (8, 9), 1.0, A, x, 0.0, y)
+    with pytest.raises(pc.kk.KkamdError, match="stencil_type"):
+        pc.kk.spmv_struct("N", 3, (8, 8), 1.0, A, x, 0.0, y)
+    with pytest.raises(RuntimeError, match="Dimensions do not match"):
+        pc.kk.spmv_struct("N", 1, (8, 8), 1.0, A, be.from_numpy(np.ones(60)), 0.0, y)
+
+
 def test_error_behaviour(be):
     A0 = oracle.random_crs(20, 30, 3, seed=2)
     A = pc.dev(be, A0)

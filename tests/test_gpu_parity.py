@@ -171,6 +171,27 @@ def test_mv_row_major_fast_path_and_packing(be):
         pc.check_spmv_mv(be, L, 16, "N", 1.0, 0.0, orders[0], orders[1], algo="SPMV_DEFAULT")
 
 
+@pytest.mark.parametrize("dims,st", [(d, 1) for d in pc.STRUCT_CASES_1D + pc.STRUCT_CASES_2D + pc.STRUCT_CASES_3D] +
+                         [(d, 2) for d in pc.STRUCT_CASES_2D + pc.STRUCT_CASES_3D])
+def test_spmv_struct_reference_cases(be, dims, st):
+    pc.check_spmv_struct(be, dims, st)
+
+
+def test_spmv_struct_variants(be):
+    pc.check_spmv_struct(be, (300, 40, 7), 2)                      # three 128-row chunks per grid line
+    pc.check_spmv_struct(be, (515, 33), 1, offset_dtype=np.int64)
+    pc.check_spmv_struct(be, (1000,), 1)
+    pc.check_spmv_struct(be, (3, 3, 3), 2); pc.check_spmv_struct(be, (2, 7), 1)
+    pc.check_spmv_struct(be, (40, 30, 20), 2, value_dtype=np.float32, vec_dtype=np.float32)
+    pc.check_spmv_struct(be, (40, 30, 20), 1, value_dtype=np.float32)
+    pc.check_spmv_struct(be, (30, 20, 10), 2, mode="T"); pc.check_spmv_struct(be, (30, 20), 2, mode="H")
+    pc.check_spmv_struct(be, (30, 20, 10), 2, mode="C", rank2=True)
+    A0 = oracle.laplace2d("FE", 200, 6)                            # an interior row with one extra entry: row_map path
+    rm = A0.row_map.copy(); r = 1 * 200 + 77
+    ent2 = np.insert(A0.entries, rm[r + 1], A0.entries[rm[r + 1] - 1]); val2 = np.insert(A0.values, rm[r + 1], 0.0); rm[r + 1:] += 1
+    pc.check_spmv_struct(be, (200, 6), 2, A0=oracle.Crs(A0.nrows, A0.ncols, rm, ent2.astype(np.int32), val2))
+
+
 def test_error_behaviour(be):
     import torch
     A = pc.dev(be, oracle.random_crs(20, 30, 3, seed=2))
@@ -339,3 +360,7 @@ def test_full_size_27pt_properties(be):
     yb = y2.clone()
     pc.kk.spmv(h, "N", 1.0, A, x1, 1.0, yb)
     assert (yb - (y1 + y2)).abs().max().item() <= tol
+    # structured path on the same matrix == CRS path
+    ys = torch.zeros_like(y)
+    pc.kk.spmv_struct("N", 2, (n, n, n), 1.0, A, x1, 0.0, ys)
+    assert (ys - y1).abs().max().item() <= tol

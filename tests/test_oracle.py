@@ -95,6 +95,36 @@ def test_spmv_serial_vs_sequential_and_scipy(mode, alpha, beta):
     assert np.abs(y1 - ys).max() <= tol
 
 
+@pytest.mark.parametrize("dims", pc_dims := [(10,), (25, 21), (20, 25), (22, 22), (20, 20, 20), (22, 22, 22), (25, 10, 20),
+                                             (10, 20, 25), (10, 24, 20), (3, 3), (3, 3, 3), (2, 9)])
+def test_spmv_struct_restatement_vs_sequential(dims):
+    """The reference's own check (Test_Sparse_spmv.hpp:263-296): spmv_struct against sequential_spmv on its generator's
+    matrices, all its sizes (:1096-1104).  Equality also proves the restated exterior index maps cover every
+    non-interior row exactly once."""
+    rng = np.random.default_rng(13718)
+    for st in ((1,) if len(dims) == 1 else (1, 2)):
+        if len(dims) == 1:
+            A = oracle.laplace1d(dims[0])
+        else:
+            A = (oracle.laplace2d if len(dims) == 2 else oracle.laplace3d)("FD" if st == 1 else "FE", *dims)
+        x = rng.random(A.ncols); y0 = rng.random(A.nrows)
+        for mode in "NCTH":
+            for alpha, beta in ((1.0, 0.0), (0.0, 1.0), (1.0, 1.0)):
+                y = oracle.spmv_struct(mode, st, dims, A, alpha, x, beta, y0.copy())
+                ye = oracle.spmv_sequential(mode, A, alpha, x, beta, y0.copy())
+                tol = 10 * np.finfo(float).eps * (abs(beta) + abs(alpha) * 27 * 26)
+                assert np.abs(y - ye).max() <= tol
+
+
+def test_laplace1d_matches_reference_fill():
+    A = oracle.laplace1d(6)
+    assert A.row_map.tolist() == [0, 2, 5, 8, 11, 14, 16]
+    assert A.entries.tolist() == [0, 1, 0, 1, 2, 1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5]
+    assert A.values.tolist() == [1, 0, -1, 2, -1, -1, 2, -1, -1, 2, -1, -1, 2, -1, 0, 1]
+    B = oracle.laplace1d(4, bc=(0, 0))
+    assert B.values.tolist() == [1, -1, -1, 2, -1, -1, 2, -1, -1, 1]
+
+
 def test_spmv_mv_serial_layouts():
     A = oracle.random_crs(300, 280, 9, variance=4, seed=11)
     rng = np.random.default_rng(2)
