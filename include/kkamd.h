@@ -156,6 +156,23 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);
  * ------------------------------------------------------------------------------------------------ */
 int kkamd_sort_crs(int64_t num_rows, const void* d_row_map, int32_t* d_entries, void* d_values, int offset_type,
                    int value_type, kkamd_stream_t stream);
+
+/* KokkosSparse::sort_and_merge_matrix (sparse/src/KokkosSparse_SortCrs.hpp:304-363): sort every row by column and
+ * collapse runs of equal columns into one entry whose value is the sum of the run (left to right).  Two calls:
+ *   1. d_entries_out == NULL: sorts (d_entries, d_values) IN PLACE, writes the merged row_map to d_row_map_out
+ *      (num_rows + 1 offsets) and the merged entry count to *nnz_out;
+ *   2. d_entries_out / d_values_out sized *nnz_out: fills them (the inputs must be the ones sorted by call 1).
+ * d_values may be NULL (graph only). */
+int kkamd_sort_and_merge(int64_t num_rows, const void* d_row_map, int32_t* d_entries, void* d_values, int offset_type,
+                         int value_type, void* d_row_map_out, int32_t* d_entries_out, void* d_values_out, int64_t* nnz_out,
+                         kkamd_stream_t stream);
+
+/* KokkosSparse::Impl::transpose_matrix (sparse/src/KokkosSparse_Utils.hpp:338-400): CRS of the transpose into
+ * preallocated d_t_row_map (num_cols + 1), d_t_entries / d_t_values (nnz).  Rows of the result are column-sorted (the
+ * reference leaves the order to its atomics).  d_values may be NULL (transpose_graph, :402-440). */
+int kkamd_transpose(int64_t num_rows, int64_t num_cols, int64_t nnz, const void* d_row_map, const int32_t* d_entries,
+                    const void* d_values, int offset_type, int value_type, void* d_t_row_map, int32_t* d_t_entries,
+                    void* d_t_values, kkamd_stream_t stream);
 int kkamd_exclusive_scan(void* d_data, int64_t n, int offset_type, kkamd_stream_t stream);
 
 /* dim = 2 or 3; stencil 0 = FD (5/7-pt), 1 = FE (9/27-pt).  With d_entries == NULL only row_map is

@@ -9,7 +9,7 @@ SPMV_DEFAULT, SPMV_FAST_SETUP, SPMV_NATIVE, SPMV_MERGE_PATH, SPMV_NATIVE_MERGE_P
 
 EXPORTS = [
     "kkamd_last_error", "kkamd_version", "kkamd_device_info", "kkamd_spmv_plan_create", "kkamd_spmv_plan_destroy",
-    "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_spmv_plan_set", "kkamd_set_default", "kkamd_spgemm_create",
+    "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_sort_and_merge", "kkamd_transpose", "kkamd_spmv_plan_set", "kkamd_set_default", "kkamd_spgemm_create",
     "kkamd_spgemm_destroy", "kkamd_spgemm_symbolic", "kkamd_spgemm_numeric", "kkamd_spgemm_get", "kkamd_sort_crs",
     "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows", "kkamd_bench_read",
 ]
@@ -48,6 +48,8 @@ def bind(lib):
     lib.kkamd_spgemm_get.argtypes = [vp, ci, C.POINTER(i64)]
     lib.kkamd_sort_crs.argtypes = [i64, vp, vp, vp, ci, ci, vp]
     lib.kkamd_exclusive_scan.argtypes = [vp, i64, ci, vp]
+    lib.kkamd_sort_and_merge.argtypes = [i64, vp, vp, vp, ci, ci, vp, vp, vp, C.POINTER(i64), vp]
+    lib.kkamd_transpose.argtypes = [i64, i64, i64, vp, vp, vp, ci, ci, vp, vp, vp, vp]
     lib.kkamd_gen_laplace.argtypes = [ci, ci, i64, i64, i64, vp, vp, vp, ci, ci, C.POINTER(i64), vp]
     lib.kkamd_gen_laplace_rows.argtypes = [ci, ci, i64, i64, i64, i64, i64, vp, vp, vp, ci, ci, C.POINTER(i64), vp]
     lib.kkamd_bench_read.argtypes = [vp, i64, ci, ci, ci, vp, vp]

@@ -8,6 +8,7 @@
 #include "kk_common.h"
 #include "kk_scan.h"
 #include <climits>
+#include <utility>
 
 namespace kk {
 
@@ -109,52 +110,134 @@ static int gen_laplace_typed(const Grid& g, int64_t row_begin, int64_t nrows, vo
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-row sort of (entries, values): one wave per row, stable rank sort for rows up to 1024 entries
-// (rank = #smaller keys + #equal keys with a smaller index), longer rows in 1024-entry LDS passes of
-// a block-wide bitonic network.
+// per-row sort of (entries, values) -- sort_crs_matrix, sparse/src/KokkosSparse_SortCrs.hpp:43-120.
+// A segment of up to 8192 entries is sorted by one workgroup in LDS: bitonic network over (key, original index) pairs,
+// the index breaking ties, so the sort is STABLE (values of duplicate columns keep their order, like the oracle).
+// Rows up to 8192 entries are one segment.  Longer rows (hub rows of a transposed R-MAT matrix reach 5e5) are sorted in
+// 8192-entry chunks and then merged pairwise, log2(len/8192) passes of a merge-path kernel over a ping-pong buffer.
+constexpr int kSortCap = 8192;
+constexpr int kMergePerThread = 8;
+
+template <class VT, bool HAS_VAL>
+__device__ __forceinline__ void sort_segment_lds(int64_t s, int len, int32_t* __restrict__ entries, VT* __restrict__ values,
+                                                 int* s_key, int* s_idx) {
+  const int t = threadIdx.x;
+  int n2 = 1;
+  while (n2 < len) n2 <<= 1;
+  __syncthreads();
+  for (int i = t; i < n2; i += kBlock) { s_key[i] = (i < len) ? entries[s + i] : INT_MAX; s_idx[i] = i; }
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < n2; i += kBlock) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const int ka = s_key[i], kb = s_key[ixj], ia = s_idx[i], ib = s_idx[ixj];
+          const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);   // index tie-break keeps it stable
+          const bool up     = ((i & k) == 0);
+          if (a_gt_b == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  // permute values through registers: read all, barrier, write
+  VT tmp[kSortCap / kBlock];
+  if (HAS_VAL) {
+    KK_UNROLL
+    for (int q = 0; q < kSortCap / kBlock; ++q) { const int i = t + q * kBlock; if (i < len) tmp[q] = values[s + s_idx[i]]; }
+  }
+  __syncthreads();
+  KK_UNROLL
+  for (int q = 0; q < kSortCap / kBlock; ++q) {
+    const int i = t + q * kBlock;
+    if (i < len) { entries[s + i] = s_key[i]; if (HAS_VAL) values[s + i] = tmp[q]; }
+  }
+}
+
 template <class OffT, class VT, bool HAS_VAL>
 __global__ __launch_bounds__(kBlock) void sort_rows_kernel(int64_t nrows, const OffT* __restrict__ row_map,
-                                                           int32_t* __restrict__ entries, VT* __restrict__ values,
-                                                           int max_len_cap) {
-  // workgroup per row, bitonic sort of (key, original index) pairs in LDS, capacity SORT_CAP
-  constexpr int SORT_CAP = 8192;
-  __shared__ int s_key[SORT_CAP];
-  __shared__ int s_idx[SORT_CAP];
-  const int t = threadIdx.x;
+                                                           int32_t* __restrict__ entries, VT* __restrict__ values) {
+  __shared__ int s_key[kSortCap];
+  __shared__ int s_idx[kSortCap];
   for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
-    const int64_t s = (int64_t)row_map[r];
-    const int len   = (int)((int64_t)row_map[r + 1] - s);
-    if (len < 2 || len > max_len_cap) continue;
-    int n2 = 1;
-    while (n2 < len) n2 <<= 1;
-    __syncthreads();
-    for (int i = t; i < n2; i += kBlock) { s_key[i] = (i < len) ? entries[s + i] : INT_MAX; s_idx[i] = i; }
-    __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = t; i < n2; i += kBlock) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const int ka = s_key[i], kb = s_key[ixj], ia = s_idx[i], ib = s_idx[ixj];
-            const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);   // index tie-break keeps it stable
-            const bool up     = ((i & k) == 0);
-            if (a_gt_b == up) { s_key[i] = kb; s_key[ixj] = ka; s_idx[i] = ib; s_idx[ixj] = ia; }
-          }
-        }
-        __syncthreads();
-      }
-    // permute values through registers: read all, barrier, write
-    VT tmp[SORT_CAP / kBlock];
-    if (HAS_VAL) {
-      KK_UNROLL
-      for (int q = 0; q < SORT_CAP / kBlock; ++q) { const int i = t + q * kBlock; if (i < len) tmp[q] = values[s + s_idx[i]]; }
+    const int64_t s   = (int64_t)row_map[r];
+    const int64_t len = (int64_t)row_map[r + 1] - s;
+    if (len < 2 || len > kSortCap) continue;                 // long rows: sort_long_chunks_kernel + merge passes
+    sort_segment_lds<VT, HAS_VAL>(s, (int)len, entries, values, s_key, s_idx);
+  }
+}
+
+// rows longer than kSortCap, compacted (order irrelevant)
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void long_rows_kernel(int64_t nrows, const OffT* __restrict__ row_map, int32_t* __restrict__ list,
+                                                           unsigned long long* __restrict__ count) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane  = threadIdx.x & 63;
+  const bool is_long = r < nrows && (int64_t)row_map[r + 1] - (int64_t)row_map[r] > kSortCap;
+  const unsigned long long m = __ballot(is_long);
+  unsigned long long start = 0;
+  if (lane == 0 && m) start = atomicAdd(count, (unsigned long long)__popcll(m));
+  start = __shfl(start, 0, 64);
+  if (is_long) list[start + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)r;
+}
+
+template <class OffT, class VT, bool HAS_VAL>
+__global__ __launch_bounds__(kBlock) void sort_long_chunks_kernel(const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
+                                                                  int32_t* __restrict__ entries, VT* __restrict__ values) {
+  __shared__ int s_key[kSortCap];
+  __shared__ int s_idx[kSortCap];
+  const int64_t r = list[blockIdx.y];
+  const int64_t s = (int64_t)row_map[r], len = (int64_t)row_map[r + 1] - s;
+  for (int64_t c0 = (int64_t)blockIdx.x * kSortCap; c0 < len; c0 += (int64_t)gridDim.x * kSortCap) {
+    const int n = (int)(len - c0 < kSortCap ? len - c0 : kSortCap);
+    if (n > 1) sort_segment_lds<VT, HAS_VAL>(s + c0, n, entries, values, s_key, s_idx);
+  }
+}
+
+// one merge pass over every long row: runs of w sorted entries -> runs of 2w.  Each work-item produces kMergePerThread
+// consecutive outputs: a merge-path binary search (ties go to the left run: stable) finds where they start in the two
+// input runs, then it merges sequentially.
+template <class OffT, class VT, bool HAS_VAL>
+__global__ __launch_bounds__(kBlock) void merge_pass_kernel(const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
+                                                            const int32_t* __restrict__ src_e, const VT* __restrict__ src_v,
+                                                            int32_t* __restrict__ dst_e, VT* __restrict__ dst_v, int64_t w) {
+  const int64_t r = list[blockIdx.y];
+  const int64_t s = (int64_t)row_map[r], len = (int64_t)row_map[r + 1] - s;
+  for (int64_t o0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kMergePerThread; o0 < len;
+       o0 += (int64_t)gridDim.x * kBlock * kMergePerThread) {
+    const int64_t pbase = (o0 / (2 * w)) * (2 * w);
+    const int64_t a_n = (len - pbase < w) ? len - pbase : w;
+    const int64_t b_lo = pbase + w;
+    const int64_t b_n = (len - b_lo <= 0) ? 0 : ((len - b_lo < w) ? len - b_lo : w);
+    const int32_t* A = src_e + s + pbase;
+    const int32_t* B = src_e + s + b_lo;
+    const int64_t d  = o0 - pbase;
+    int64_t lo = d - b_n > 0 ? d - b_n : 0, hi = d < a_n ? d : a_n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (A[mid] <= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
     }
-    __syncthreads();
-    KK_UNROLL
-    for (int q = 0; q < SORT_CAP / kBlock; ++q) {
-      const int i = t + q * kBlock;
-      if (i < len) { entries[s + i] = s_key[i]; if (HAS_VAL) values[s + i] = tmp[q]; }
+    int64_t ia = lo, ib = d - lo;
+    const int64_t o_end = (o0 + kMergePerThread < pbase + a_n + b_n) ? o0 + kMergePerThread : pbase + a_n + b_n;
+    for (int64_t o = o0; o < o_end; ++o) {
+      const bool take_a = ib >= b_n || (ia < a_n && A[ia] <= B[ib]);
+      const int64_t src = take_a ? pbase + ia : b_lo + ib;
+      dst_e[s + o] = src_e[s + src];
+      if (HAS_VAL) dst_v[s + o] = src_v[s + src];
+      if (take_a) ++ia; else ++ib;
     }
+  }
+}
+
+template <class OffT, class VT, bool HAS_VAL>
+__global__ __launch_bounds__(kBlock) void copy_long_rows_kernel(const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
+                                                                const int32_t* __restrict__ src_e, const VT* __restrict__ src_v,
+                                                                int32_t* __restrict__ dst_e, VT* __restrict__ dst_v) {
+  const int64_t r = list[blockIdx.y];
+  const int64_t s = (int64_t)row_map[r], len = (int64_t)row_map[r + 1] - s;
+  for (int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x; o < len; o += (int64_t)gridDim.x * kBlock) {
+    dst_e[s + o] = src_e[s + o];
+    if (HAS_VAL) dst_v[s + o] = src_v[s + o];
   }
 }
 
@@ -169,29 +252,144 @@ template <class OffT> __global__ void max_row_len_kernel(int64_t nrows, const Of
   if ((threadIdx.x & 63) == 0) atomicMax(out, mx);
 }
 
-template <class OffT>
-static int sort_typed(int64_t nrows, const void* d_row_map, int32_t* d_entries, void* d_values, int value_type, hipStream_t st) {
+template <class OffT, class VT, bool HAS_VAL>
+static int sort_vt(int64_t nrows, const OffT* rm, int32_t* d_entries, VT* d_values, hipStream_t st) {
   int* d_max = nullptr;
   KK_HIP(hipMalloc((void**)&d_max, sizeof(int)));
   KK_HIP(hipMemsetAsync(d_max, 0, sizeof(int), st));
   const int64_t nb = ceil_div(nrows, kBlock);
-  KK_LAUNCH((max_row_len_kernel<OffT>), (unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st, nrows, (const OffT*)d_row_map, d_max);
+  KK_LAUNCH((max_row_len_kernel<OffT>), (unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st, nrows, rm, d_max);
   int h_max = 0;
   KK_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
   KK_HIP(hipFree(d_max));
-  if (h_max > 8192)
-    return fail(KKAMD_ERR_UNSUPPORTED, "kkamd_sort_crs: a row has %d entries; rows longer than 8192 are not supported yet", h_max);
-  const unsigned grid = (unsigned)(nrows < 65536 ? nrows : 65536);
-  if (!d_values) {
-    KK_LAUNCH((sort_rows_kernel<OffT, float, false>), grid, kBlock, 0, st, nrows, (const OffT*)d_row_map, d_entries, (float*)nullptr, 8192);
-  } else if (value_type == KKAMD_F64) {
-    KK_LAUNCH((sort_rows_kernel<OffT, double, true>), grid, kBlock, 0, st, nrows, (const OffT*)d_row_map, d_entries, (double*)d_values, 8192);
-  } else {
-    KK_LAUNCH((sort_rows_kernel<OffT, float, true>), grid, kBlock, 0, st, nrows, (const OffT*)d_row_map, d_entries, (float*)d_values, 8192);
-  }
+  KK_LAUNCH((sort_rows_kernel<OffT, VT, HAS_VAL>), (unsigned)(nrows < 65536 ? nrows : 65536), kBlock, 0, st, nrows, rm, d_entries, d_values);
   KK_LAUNCH_CHECK();
-  return KKAMD_OK;
+  if (h_max <= kSortCap) return KKAMD_OK;
+  // long rows
+  int32_t* d_list = nullptr; unsigned long long* d_cnt = nullptr; unsigned long long h_cnt = 0;
+  OffT h_nnz = 0;
+  KK_HIP(hipMalloc((void**)&d_list, sizeof(int32_t) * (size_t)nrows));
+  KK_HIP(hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
+  KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+  KK_LAUNCH((long_rows_kernel<OffT>), (unsigned)nb, kBlock, 0, st, nrows, rm, d_list, d_cnt);
+  KK_HIP(hipMemcpyAsync(&h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipMemcpyAsync(&h_nnz, rm + nrows, sizeof(OffT), hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  KK_HIP(hipFree(d_cnt));
+  const unsigned L = (unsigned)h_cnt;
+  int rc = KKAMD_OK;
+  int32_t* t_e = nullptr; VT* t_v = nullptr;
+  if (L > 65535) rc = fail(KKAMD_ERR_UNSUPPORTED, "kkamd_sort_crs: more than 65535 rows longer than %d entries", kSortCap);
+  if (rc == KKAMD_OK && hipMalloc((void**)&t_e, sizeof(int32_t) * (size_t)h_nnz) != hipSuccess) rc = fail(KKAMD_ERR_ALLOC, "kkamd_sort_crs: out of device memory");
+  if (rc == KKAMD_OK && HAS_VAL && hipMalloc((void**)&t_v, sizeof(VT) * (size_t)h_nnz) != hipSuccess) rc = fail(KKAMD_ERR_ALLOC, "kkamd_sort_crs: out of device memory");
+  if (rc == KKAMD_OK) {
+    const unsigned chunks = (unsigned)ceil_div(h_max, kSortCap);
+    KK_LAUNCH((sort_long_chunks_kernel<OffT, VT, HAS_VAL>), dim3(chunks < 1024 ? chunks : 1024, L), kBlock, 0, st, (const int32_t*)d_list,
+              rm, d_entries, d_values);
+    const int64_t tiles = ceil_div(h_max, (int64_t)kBlock * kMergePerThread);
+    const unsigned gx   = (unsigned)(tiles < 4096 ? tiles : 4096);
+    int32_t *se = d_entries, *de = t_e;
+    VT *sv = d_values, *dv = t_v;
+    for (int64_t w = kSortCap; w < h_max; w *= 2) {
+      KK_LAUNCH((merge_pass_kernel<OffT, VT, HAS_VAL>), dim3(gx, L), kBlock, 0, st, (const int32_t*)d_list, rm, (const int32_t*)se,
+                (const VT*)sv, de, dv, w);
+      std::swap(se, de); std::swap(sv, dv);
+    }
+    if (se != d_entries)
+      KK_LAUNCH((copy_long_rows_kernel<OffT, VT, HAS_VAL>), dim3(gx, L), kBlock, 0, st, (const int32_t*)d_list, rm, (const int32_t*)se,
+                (const VT*)sv, d_entries, d_values);
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);
+    if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(KKAMD_ERR_HIP, "kkamd_sort_crs: long-row merge failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  }
+  if (t_e) (void)hipFree(t_e);
+  if (t_v) (void)hipFree(t_v);
+  (void)hipFree(d_list);
+  return rc;
+}
+
+template <class OffT>
+static int sort_typed(int64_t nrows, const void* d_row_map, int32_t* d_entries, void* d_values, int value_type, hipStream_t st) {
+  const OffT* rm = (const OffT*)d_row_map;
+  if (!d_values) return sort_vt<OffT, float, false>(nrows, rm, d_entries, (float*)nullptr, st);
+  if (value_type == KKAMD_F64) return sort_vt<OffT, double, true>(nrows, rm, d_entries, (double*)d_values, st);
+  return sort_vt<OffT, float, true>(nrows, rm, d_entries, (float*)d_values, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sort_and_merge_matrix (sparse/src/KokkosSparse_SortCrs.hpp:304-363, MergedRowmapFunctor / MatrixMergedEntriesFunctor in
+// sparse/impl/KokkosSparse_sort_crs_impl.hpp:120-216): after the row sort, runs of equal columns collapse into one entry
+// whose value is the sum of the run taken left to right.
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void merged_count_kernel(int64_t nrows, const OffT* __restrict__ rm, const int32_t* __restrict__ ent,
+                                                              OffT* __restrict__ out_rm) {
+  const int lane = threadIdx.x & 7;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 8);
+  for (int64_t r0 = (int64_t)blockIdx.x * (kBlock / 8); r0 <= nrows; r0 += stride) {      // workgroup-uniform trip count
+    const int64_t r = r0 + threadIdx.x / 8;
+    int cnt = 0;
+    if (r < nrows) {
+      const int64_t s = (int64_t)rm[r], e = (int64_t)rm[r + 1];
+      for (int64_t j = s + lane; j < e; j += 8) cnt += (j == s || ent[j] != ent[j - 1]) ? 1 : 0;
+    }
+    cnt = group_sum(cnt, 8);
+    if (r <= nrows && lane == 0) out_rm[r] = (OffT)(r < nrows ? cnt : 0);
+  }
+}
+template <class OffT, class VT>
+__global__ __launch_bounds__(kBlock) void merged_fill_kernel(int64_t nrows, const OffT* __restrict__ rm, const int32_t* __restrict__ ent,
+                                                             const VT* __restrict__ val, const OffT* __restrict__ out_rm,
+                                                             int32_t* __restrict__ out_ent, VT* __restrict__ out_val) {
+  // one work-item per input entry that STARTS a run: it sums its run (runs are short) and knows its output slot from
+  // the number of run starts before it in the row, counted by the 8 lanes of the row in chunks
+  const int lane = threadIdx.x & 7;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 8);
+  for (int64_t r0 = (int64_t)blockIdx.x * (kBlock / 8); r0 < nrows; r0 += stride) {
+    const int64_t r = r0 + threadIdx.x / 8;
+    const int64_t s = r < nrows ? (int64_t)rm[r] : 0, e = r < nrows ? (int64_t)rm[r + 1] : 0;
+    int64_t pos = r < nrows ? (int64_t)out_rm[r] : 0;
+    // all 8-lane groups of the wave iterate as long as the longest row of the wave needs (uniform ballots)
+    int64_t wave_span = e - s;
+    for (int o = 32; o >= 8; o >>= 1) { const int64_t other = __shfl_xor(wave_span, o, 64); wave_span = other > wave_span ? other : wave_span; }
+    for (int64_t j0 = 0; j0 < wave_span; j0 += 8) {
+      const int64_t j   = s + j0 + lane;
+      const bool start  = j < e && (j == s || ent[j] != ent[j - 1]);
+      const unsigned long long m = __ballot(start);
+      const unsigned long long mine = (m >> ((threadIdx.x & 63) & ~7)) & 0xffull;
+      if (start) {
+        const int64_t slot = pos + __popcll(mine & ((1ull << lane) - 1ull));
+        VT acc = val ? val[j] : VT(0);
+        int64_t q = j + 1;
+        while (q < e && ent[q] == ent[j]) { if (val) acc += val[q]; ++q; }
+        out_ent[slot] = ent[j];
+        if (val) out_val[slot] = acc;
+      }
+      pos += __popcll(mine);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose_matrix (sparse/src/KokkosSparse_Utils.hpp:338-400: count per column with atomics, prefix sum, fill through
+// atomic cursors).  The fill order inside a transposed row is whatever the atomics produce -- as in the reference --
+// so the rows are sorted afterwards and the result is deterministic for matrices without duplicate entries.
+__device__ __forceinline__ int32_t fetch_inc(int32_t* p) { return atomicAdd(p, 1); }
+__device__ __forceinline__ int64_t fetch_inc(int64_t* p) { return (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(p), 1ull); }
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void transpose_count_kernel(int64_t nnz, const int32_t* __restrict__ ent, OffT* __restrict__ t_rm) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * kBlock) (void)fetch_inc(&t_rm[ent[j]]);
+}
+template <class OffT, class VT>
+__global__ __launch_bounds__(kBlock) void transpose_fill_kernel(int64_t nrows, const OffT* __restrict__ rm, const int32_t* __restrict__ ent,
+                                                                const VT* __restrict__ val, OffT* __restrict__ cursor,
+                                                                int32_t* __restrict__ t_ent, VT* __restrict__ t_val) {
+  const int lane = threadIdx.x & 7;
+  for (int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 8; r < nrows; r += (int64_t)gridDim.x * (kBlock / 8))
+    for (int64_t j = (int64_t)rm[r] + lane; j < (int64_t)rm[r + 1]; j += 8) {
+      const OffT p = fetch_inc(&cursor[ent[j]]);
+      t_ent[p] = (int32_t)r;
+      if (val) t_val[p] = val[j];
+    }
 }
 
 }  // namespace kk
@@ -215,6 +413,92 @@ int kkamd_sort_crs(int64_t num_rows, const void* d_row_map, int32_t* d_entries, 
   if (offset_type == KKAMD_I32) return kk::sort_typed<int32_t>(num_rows, d_row_map, d_entries, d_values, value_type, kk::to_hip(stream));
   if (offset_type == KKAMD_I64) return kk::sort_typed<int64_t>(num_rows, d_row_map, d_entries, d_values, value_type, kk::to_hip(stream));
   return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_sort_crs: unknown offset_type %d", offset_type);
+}
+
+int kkamd_sort_and_merge(int64_t num_rows, const void* d_row_map, int32_t* d_entries, void* d_values, int offset_type,
+                         int value_type, void* d_row_map_out, int32_t* d_entries_out, void* d_values_out, int64_t* nnz_out,
+                         kkamd_stream_t stream) {
+  if (num_rows < 0) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_sort_and_merge: negative row count");
+  if (offset_type != KKAMD_I32 && offset_type != KKAMD_I64) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_sort_and_merge: unknown offset_type %d", offset_type);
+  if (!d_row_map_out || !nnz_out) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_sort_and_merge: null output");
+  hipStream_t st = kk::to_hip(stream);
+  const size_t osz = offset_type == KKAMD_I64 ? 8 : 4;
+  if (num_rows == 0) { KK_HIP(hipMemsetAsync(d_row_map_out, 0, osz, st)); *nnz_out = 0; return KKAMD_OK; }
+  if (!d_row_map) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_sort_and_merge: null row_map");
+  const int64_t nbk  = kk::ceil_div(num_rows + 1, kk::kBlock / 8);
+  const unsigned grid = (unsigned)(nbk < 65536 ? nbk : 65536);
+  if (!d_entries_out) {
+    // phase 1: sort in place, merged row_map and nnz
+    if (!d_entries) { KK_HIP(hipMemsetAsync(d_row_map_out, 0, osz * (size_t)(num_rows + 1), st)); *nnz_out = 0; return KKAMD_OK; }
+    int rc = kkamd_sort_crs(num_rows, d_row_map, d_entries, d_values, offset_type, value_type, stream);
+    if (rc) return rc;
+    if (offset_type == KKAMD_I64) {
+      KK_LAUNCH((kk::merged_count_kernel<int64_t>), grid, kk::kBlock, 0, st, num_rows, (const int64_t*)d_row_map, (const int32_t*)d_entries, (int64_t*)d_row_map_out);
+      if ((rc = kk::exclusive_scan_inplace<int64_t>((int64_t*)d_row_map_out, num_rows + 1, st))) return rc;
+      int64_t total = 0;
+      KK_HIP(hipMemcpyAsync(&total, (int64_t*)d_row_map_out + num_rows, 8, hipMemcpyDeviceToHost, st));
+      KK_HIP(hipStreamSynchronize(st));
+      *nnz_out = total;
+    } else {
+      KK_LAUNCH((kk::merged_count_kernel<int32_t>), grid, kk::kBlock, 0, st, num_rows, (const int32_t*)d_row_map, (const int32_t*)d_entries, (int32_t*)d_row_map_out);
+      if ((rc = kk::exclusive_scan_inplace<int32_t>((int32_t*)d_row_map_out, num_rows + 1, st))) return rc;
+      int32_t total = 0;
+      KK_HIP(hipMemcpyAsync(&total, (int32_t*)d_row_map_out + num_rows, 4, hipMemcpyDeviceToHost, st));
+      KK_HIP(hipStreamSynchronize(st));
+      *nnz_out = total;
+    }
+    return KKAMD_OK;
+  }
+  // phase 2: fill (inputs already sorted by phase 1)
+  if (*nnz_out == 0) return KKAMD_OK;
+  if (offset_type == KKAMD_I64) {
+    if (!d_values) KK_LAUNCH((kk::merged_fill_kernel<int64_t, float>), grid, kk::kBlock, 0, st, num_rows, (const int64_t*)d_row_map, (const int32_t*)d_entries, (const float*)nullptr, (const int64_t*)d_row_map_out, d_entries_out, (float*)nullptr);
+    else if (value_type == KKAMD_F64) KK_LAUNCH((kk::merged_fill_kernel<int64_t, double>), grid, kk::kBlock, 0, st, num_rows, (const int64_t*)d_row_map, (const int32_t*)d_entries, (const double*)d_values, (const int64_t*)d_row_map_out, d_entries_out, (double*)d_values_out);
+    else KK_LAUNCH((kk::merged_fill_kernel<int64_t, float>), grid, kk::kBlock, 0, st, num_rows, (const int64_t*)d_row_map, (const int32_t*)d_entries, (const float*)d_values, (const int64_t*)d_row_map_out, d_entries_out, (float*)d_values_out);
+  } else {
+    if (!d_values) KK_LAUNCH((kk::merged_fill_kernel<int32_t, float>), grid, kk::kBlock, 0, st, num_rows, (const int32_t*)d_row_map, (const int32_t*)d_entries, (const float*)nullptr, (const int32_t*)d_row_map_out, d_entries_out, (float*)nullptr);
+    else if (value_type == KKAMD_F64) KK_LAUNCH((kk::merged_fill_kernel<int32_t, double>), grid, kk::kBlock, 0, st, num_rows, (const int32_t*)d_row_map, (const int32_t*)d_entries, (const double*)d_values, (const int32_t*)d_row_map_out, d_entries_out, (double*)d_values_out);
+    else KK_LAUNCH((kk::merged_fill_kernel<int32_t, float>), grid, kk::kBlock, 0, st, num_rows, (const int32_t*)d_row_map, (const int32_t*)d_entries, (const float*)d_values, (const int32_t*)d_row_map_out, d_entries_out, (float*)d_values_out);
+  }
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+int kkamd_transpose(int64_t num_rows, int64_t num_cols, int64_t nnz, const void* d_row_map, const int32_t* d_entries,
+                    const void* d_values, int offset_type, int value_type, void* d_t_row_map, int32_t* d_t_entries,
+                    void* d_t_values, kkamd_stream_t stream) {
+  if (num_rows < 0 || num_cols < 0 || nnz < 0) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_transpose: negative dimension");
+  if (offset_type != KKAMD_I32 && offset_type != KKAMD_I64) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_transpose: unknown offset_type %d", offset_type);
+  if (!d_t_row_map) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_transpose: null output row_map");
+  hipStream_t st   = kk::to_hip(stream);
+  const size_t osz = offset_type == KKAMD_I64 ? 8 : 4;
+  KK_HIP(hipMemsetAsync(d_t_row_map, 0, osz * (size_t)(num_cols + 1), st));
+  if (nnz == 0 || num_rows == 0 || num_cols == 0) return KKAMD_OK;
+  if (!d_row_map || !d_entries || !d_t_entries || (d_values && !d_t_values)) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_transpose: null pointer");
+  const int64_t nb1 = kk::ceil_div(nnz, kk::kBlock), nb2 = kk::ceil_div(num_rows * 8, kk::kBlock);
+  const unsigned g1 = (unsigned)(nb1 < 65536 ? nb1 : 65536), g2 = (unsigned)(nb2 < 65536 ? nb2 : 65536);
+  void* d_cursor = nullptr;
+  KK_HIP(hipMalloc(&d_cursor, osz * (size_t)(num_cols + 1)));
+  int rc = KKAMD_OK;
+#define KK_TR(OT)                                                                                                              \
+  do {                                                                                                                         \
+    KK_LAUNCH((kk::transpose_count_kernel<OT>), g1, kk::kBlock, 0, st, nnz, d_entries, (OT*)d_t_row_map);                       \
+    rc = kk::exclusive_scan_inplace<OT>((OT*)d_t_row_map, num_cols + 1, st);                                                   \
+    if (rc == KKAMD_OK) {                                                                                                      \
+      (void)hipMemcpyAsync(d_cursor, d_t_row_map, osz * (size_t)(num_cols + 1), hipMemcpyDeviceToDevice, st);                  \
+      if (!d_values) KK_LAUNCH((kk::transpose_fill_kernel<OT, float>), g2, kk::kBlock, 0, st, num_rows, (const OT*)d_row_map, d_entries, (const float*)nullptr, (OT*)d_cursor, d_t_entries, (float*)nullptr); \
+      else if (value_type == KKAMD_F64) KK_LAUNCH((kk::transpose_fill_kernel<OT, double>), g2, kk::kBlock, 0, st, num_rows, (const OT*)d_row_map, d_entries, (const double*)d_values, (OT*)d_cursor, d_t_entries, (double*)d_t_values); \
+      else KK_LAUNCH((kk::transpose_fill_kernel<OT, float>), g2, kk::kBlock, 0, st, num_rows, (const OT*)d_row_map, d_entries, (const float*)d_values, (OT*)d_cursor, d_t_entries, (float*)d_t_values); \
+    }                                                                                                                          \
+  } while (0)
+  if (offset_type == KKAMD_I64) KK_TR(int64_t); else KK_TR(int32_t);
+#undef KK_TR
+  hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);
+  (void)hipFree(d_cursor);
+  if (rc) return rc;
+  if (e1 != hipSuccess || e2 != hipSuccess) return kk::fail(KKAMD_ERR_HIP, "kkamd_transpose failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  // deterministic order inside every transposed row
+  return kkamd_sort_crs(num_cols, d_t_row_map, d_t_entries, d_values ? d_t_values : nullptr, offset_type, value_type, stream);
 }
 
 int kkamd_gen_laplace_rows(int dim, int stencil, int64_t nx, int64_t ny, int64_t nz, int64_t row_begin, int64_t row_count,

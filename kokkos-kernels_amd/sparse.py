@@ -345,6 +345,39 @@ def sort_crs_matrix(A):
     return A
 
 
+def sort_and_merge_matrix(A):
+    """KokkosSparse::sort_and_merge_matrix (sparse/src/KokkosSparse_SortCrs.hpp:304-400): returns a new matrix whose rows
+    are sorted with duplicate columns summed; A itself is left sorted (as in the reference, which sorts its input views)."""
+    be, lib = A.backend, A.backend.lib
+    m = A.numRows()
+    rm_out = be.empty(m + 1, _np_dtype(A.graph.row_map))
+    ot = _offset_type(A.graph.row_map)
+    vt = _scalar_type(A.values) if A.values is not None else F64
+    n = C.c_int64()
+    vals = be.ptr(A.values) if A.values is not None else None
+    check(lib, lib.kkamd_sort_and_merge(m, be.ptr(A.graph.row_map), be.ptr(A.graph.entries), vals, ot, vt, be.ptr(rm_out), None, None,
+                                        C.byref(n), be.stream()))
+    ent = be.empty(max(n.value, 1), np.int32)
+    val = be.empty(max(n.value, 1), _np_dtype(A.values)) if A.values is not None else None
+    check(lib, lib.kkamd_sort_and_merge(m, be.ptr(A.graph.row_map), be.ptr(A.graph.entries), vals, ot, vt, be.ptr(rm_out), be.ptr(ent),
+                                        be.ptr(val) if val is not None else None, C.byref(n), be.stream()))
+    return CrsMatrix(m, A.numCols(), rm_out, ent[:n.value], val[:n.value] if val is not None else None, backend=be)
+
+
+def transpose_matrix(A):
+    """KokkosSparse::Impl::transpose_matrix (sparse/src/KokkosSparse_Utils.hpp:381-398); rows of the result are sorted."""
+    be, lib = A.backend, A.backend.lib
+    m, n, nnz = A.numRows(), A.numCols(), A.nnz()
+    t_rm = be.empty(n + 1, _np_dtype(A.graph.row_map))
+    t_ent = be.empty(max(nnz, 1), np.int32)
+    t_val = be.empty(max(nnz, 1), _np_dtype(A.values)) if A.values is not None else None
+    check(lib, lib.kkamd_transpose(m, n, nnz, be.ptr(A.graph.row_map), be.ptr(A.graph.entries),
+                                   be.ptr(A.values) if A.values is not None else None, _offset_type(A.graph.row_map),
+                                   _scalar_type(A.values) if A.values is not None else F64, be.ptr(t_rm), be.ptr(t_ent),
+                                   be.ptr(t_val) if t_val is not None else None, be.stream()))
+    return CrsMatrix(n, m, t_rm, t_ent[:nnz], t_val[:nnz] if t_val is not None else None, backend=be)
+
+
 def laplace_matrix(stencil, nx, ny, nz=None, offset_dtype=np.int32, value_dtype=np.float64, backend=None, rows=None):
     """Structured Laplacian (every BC = 1) generated in place on the device; bit-identical to the
     reference's generate_structured_matrix2D/3D (test_common/KokkosKernels_Test_Structured_Matrix.hpp).

@@ -362,6 +362,37 @@ int kko_sort_crs(int64_t nrows, const int64_t* row_map, int32_t* entries, double
 /* compute_row_flops / PredicMaxRowNNZ: sparse/impl/KokkosSparse_spgemm_impl.hpp:675-701,
  * sparse/impl/KokkosSparse_spgemm_impl_symbolic.hpp:1108-1185 -- per A row the
  * sum of nnz(B(k,:)) over its entries; returns the total ("mults"), and the max. */
+/* sort_and_merge_matrix: sparse/src/KokkosSparse_SortCrs.hpp:304-363 with MergedRowmapFunctor /
+ * MatrixMergedEntriesFunctor (sparse/impl/KokkosSparse_sort_crs_impl.hpp:120-216): sort the rows, then per row
+ * accumVal = values(begin); for j > begin: equal column -> accumVal += values(j), else write out and reset.
+ * Sorts (entries, values) in place; fills out_row_map (nrows+1) and, when out_entries != NULL, the merged arrays.
+ * Returns the merged entry count.                                                                            */
+int64_t kko_sort_and_merge(int64_t nrows, const int64_t* row_map, int32_t* entries, double* values, int64_t* out_row_map,
+                           int32_t* out_entries, double* out_values) {
+  if (kko_sort_crs(nrows, row_map, entries, values) != 0) return -1;
+  int64_t pos = 0;
+  out_row_map[0] = 0;
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int64_t b = row_map[r], e = row_map[r + 1];
+    if (e > b) {
+      double accumVal  = values ? values[b] : 0.0;
+      int32_t accumCol = entries[b];
+      for (int64_t j = b + 1; j < e; ++j) {
+        if (accumCol == entries[j]) { if (values) accumVal += values[j]; }
+        else {
+          if (out_entries) { out_entries[pos] = accumCol; if (out_values) out_values[pos] = accumVal; }
+          ++pos;
+          accumVal = values ? values[j] : 0.0; accumCol = entries[j];
+        }
+      }
+      if (out_entries) { out_entries[pos] = accumCol; if (out_values) out_values[pos] = accumVal; }
+      ++pos;
+    }
+    out_row_map[r + 1] = pos;
+  }
+  return pos;
+}
+
 int64_t kko_spgemm_mults(int32_t m, const int64_t* row_mapA, const int32_t* entriesA, const int64_t* row_mapB,
                          int64_t* max_row_flops) {
   int64_t total = 0, mx = 0;

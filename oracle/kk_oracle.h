@@ -58,6 +58,9 @@ int kko_spgemm_numeric(int32_t m, int32_t n, int32_t k, const int64_t* row_mapA,
                        const int64_t* row_mapC, int32_t* entriesC, double* valuesC);
 /* sort_crs_matrix: per-row ascending columns, values permuted alongside (stable). */
 int kko_sort_crs(int64_t nrows, const int64_t* row_map, int32_t* entries, double* values);
+/* sort_and_merge_matrix: sorts in place, merged row_map always, merged entries/values when out_entries != NULL */
+int64_t kko_sort_and_merge(int64_t nrows, const int64_t* row_map, int32_t* entries, double* values, int64_t* out_row_map,
+                           int32_t* out_entries, double* out_values);
 /* sum over rows of sum over A(i,:) of nnz(B(k,:)) -- the reference's original_overall_flops / 2 */
 int64_t kko_spgemm_mults(int32_t m, const int64_t* row_mapA, const int32_t* entriesA, const int64_t* row_mapB,
                          int64_t* max_row_flops);

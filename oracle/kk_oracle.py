@@ -27,6 +27,7 @@ def lib():
         _LIB = C.CDLL(so)
         _LIB.kko_spgemm_symbolic.restype = C.c_int64
         _LIB.kko_spgemm_mults.restype = C.c_int64
+        _LIB.kko_sort_and_merge.restype = C.c_int64
         _LIB.kko_laplace2d_nnz.restype = C.c_int64
         _LIB.kko_laplace3d_nnz.restype = C.c_int64
         _LIB.kko_hash_value_1_50.restype = C.c_double
@@ -148,6 +149,15 @@ def sort_crs(A):
                             _p(A.values) if A.values is not None else None)
     assert rc == 0
     return A
+
+
+def sort_and_merge(A):
+    """KokkosSparse::sort_and_merge_matrix: a new Crs with sorted rows and duplicate columns summed (A is sorted in place)."""
+    rm_out = np.zeros(A.nrows + 1, dtype=np.int64)
+    n = lib().kko_sort_and_merge(_i64(A.nrows), _p(A.row_map), _p(A.entries), _p(A.values), _p(rm_out), None, None)
+    ent = np.zeros(n, dtype=np.int32); val = np.zeros(n)
+    lib().kko_sort_and_merge(_i64(A.nrows), _p(A.row_map), _p(A.entries), _p(A.values), _p(rm_out), _p(ent), _p(val))
+    return Crs(A.nrows, A.ncols, rm_out, ent, val)
 
 
 def spgemm_mults(A, B):

@@ -54,6 +54,41 @@ def test_sort_crs(be):
         assert np.array_equal(ent, gold.entries) and np.array_equal(val, gold.values)     # stable like the oracle
 
 
+def test_sort_long_rows_merge_transpose(be):
+    # rows longer than one 8192-entry LDS segment: chunk sort + merge passes (1, 2 and 3 passes), with duplicate columns
+    rng = np.random.default_rng(8)
+    lens = [20000, 3, 8193, 0, 70000, 8192, 16384]
+    rm = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    ent = rng.integers(0, 30000, size=rm[-1]).astype(np.int32)
+    M = oracle.Crs(len(lens), 30000, rm, ent, 1 + 49 * rng.random(rm[-1]))
+    for odt in (np.int32, np.int64):
+        A = pc.dev(be, M, odt)
+        pc.kk.sort_crs_matrix(A)
+        gold = oracle.Crs(M.nrows, M.ncols, M.row_map, M.entries.copy(), M.values.copy()); oracle.sort_crs(gold)
+        _, e, v = A.to_host()
+        assert np.array_equal(e, gold.entries) and np.array_equal(v, gold.values)          # stable like the oracle
+    # sort_and_merge_matrix: duplicates summed left to right
+    A = pc.dev(be, M)
+    Cm = pc.kk.sort_and_merge_matrix(A)
+    gm = oracle.sort_and_merge(oracle.Crs(M.nrows, M.ncols, M.row_map, M.entries.copy(), M.values.copy()))
+    r, e, v = Cm.to_host()
+    assert np.array_equal(r, gm.row_map) and np.array_equal(e, gm.entries) and np.allclose(v, gm.values, rtol=1e-13, atol=0)
+    small = pc.randomized(oracle.random_crs(50, 40, 6, seed=3))                              # short rows with duplicates, graph-only too
+    gs = oracle.sort_and_merge(oracle.Crs(small.nrows, small.ncols, small.row_map, small.entries.copy(), small.values.copy()))
+    r, e, v = pc.kk.sort_and_merge_matrix(pc.dev(be, small, np.int64)).to_host()
+    assert np.array_equal(r, gs.row_map) and np.array_equal(e, gs.entries) and np.allclose(v, gs.values, rtol=1e-13, atol=0)
+    # transpose_matrix against the oracle's transpose (no duplicates -> deterministic), including a hub column
+    T0 = pc.hub_matrix(300, 200, 5, {7: 150}, seed=4)
+    At = pc.kk.transpose_matrix(pc.dev(be, T0))
+    gt = oracle.transpose(T0)
+    r, e, v = At.to_host()
+    assert np.array_equal(r, gt.row_map) and np.array_equal(e, gt.entries) and np.array_equal(v, gt.values)
+    big = oracle.Crs(1, 30000, np.array([0, 9000]), np.sort(rng.choice(30000, 9000, replace=False)).astype(np.int32), rng.random(9000))
+    Bt = pc.kk.transpose_matrix(pc.kk.transpose_matrix(pc.dev(be, big)))                       # (A^T)^T == A, long row on the way back
+    r, e, v = Bt.to_host()
+    assert np.array_equal(e, big.entries) and np.array_equal(v, big.values)
+
+
 @pytest.mark.parametrize("m,n,k,nnzA,nnzB", [
     (0, 0, 0, 0, 0), (0, 12, 5, 0, 20), (10, 10, 0, 20, 0), (10, 0, 10, 0, 0),
     (10, 10, 10, 0, 0), (10, 10, 10, 20, 0), (10, 10, 10, 0, 20)])

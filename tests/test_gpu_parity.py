@@ -255,6 +255,35 @@ def test_sort_crs(be):
 
 
 # ------------------------------------------------------------------------------------------- SpGEMM
+def test_sort_long_rows_merge_transpose(be):
+    rng = np.random.default_rng(8)
+    lens = [20000, 3, 8193, 0, 600000, 8192, 16384, 131072]
+    rm = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    ent = rng.integers(0, 250000, size=rm[-1]).astype(np.int32)
+    M = oracle.Crs(len(lens), 250000, rm, ent, 1 + 49 * rng.random(rm[-1]))
+    for odt in (np.int32, np.int64):
+        A = pc.dev(be, M, odt)
+        pc.kk.sort_crs_matrix(A)
+        gold = oracle.Crs(M.nrows, M.ncols, M.row_map, M.entries.copy(), M.values.copy()); oracle.sort_crs(gold)
+        _, e, v = A.to_host()
+        assert np.array_equal(e, gold.entries) and np.array_equal(v, gold.values)
+    Cm = pc.kk.sort_and_merge_matrix(pc.dev(be, M))
+    gm = oracle.sort_and_merge(oracle.Crs(M.nrows, M.ncols, M.row_map, M.entries.copy(), M.values.copy()))
+    r, e, v = Cm.to_host()
+    assert np.array_equal(r, gm.row_map) and np.array_equal(e, gm.entries) and np.allclose(v, gm.values, rtol=1e-13, atol=0)
+    # transpose of an R-MAT matrix (hub columns become rows far longer than one LDS segment) against the oracle
+    R = oracle.rmat(15, 16)
+    At = pc.kk.transpose_matrix(pc.dev(be, R, np.int64))
+    gt = oracle.transpose(R)
+    r, e, v = At.to_host()
+    assert np.array_equal(r, gt.row_map) and np.array_equal(e, gt.entries) and np.array_equal(v, gt.values)
+    # SpGEMM with an explicitly transposed operand: A^T * A is symmetric
+    S = pc.kk.spgemm(At, False, pc.dev(be, R, np.int64), False)
+    St = pc.kk.transpose_matrix(S)
+    r1, e1, v1 = S.to_host(); r2, e2, v2 = St.to_host()
+    assert np.array_equal(r1, r2) and np.array_equal(e1, e2) and np.allclose(v1, v2, rtol=1e-12)
+
+
 @pytest.mark.parametrize("m,n,k,nnzA,nnzB", [
     (0, 0, 0, 0, 0), (0, 12, 5, 0, 20), (10, 10, 0, 20, 0), (10, 0, 10, 0, 0),
     (10, 10, 10, 0, 0), (10, 10, 10, 20, 0), (10, 10, 10, 0, 20)])

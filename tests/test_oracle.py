@@ -189,6 +189,15 @@ def test_sort_crs_and_first_touch_order():
         assert np.array_equal(C.values[s:e][order], Cs.values[s:e])
 
 
+def test_sort_and_merge_vs_scipy():
+    import scipy.sparse as sp
+    A = oracle.random_crs(200, 50, 30, variance=20, seed=12)                 # many duplicate columns per row
+    S = sp.csr_matrix((A.values.copy(), A.entries.copy(), A.row_map.copy()), shape=(A.nrows, A.ncols))
+    S.sum_duplicates(); S.sort_indices()
+    G = oracle.sort_and_merge(oracle.Crs(A.nrows, A.ncols, A.row_map, A.entries.copy(), A.values.copy()))
+    assert np.array_equal(G.row_map, S.indptr) and np.array_equal(G.entries, S.indices) and np.allclose(G.values, S.data, rtol=1e-13)
+
+
 def test_rmat_is_deterministic_and_well_formed():
     A = oracle.rmat(10, 8, seed=7)
     B = oracle.rmat(10, 8, seed=7)
