@@ -12,6 +12,12 @@ one grid plane from each neighbour (2 x 600^2 x 8 B = 5.8 MB per rank at 600^3) 
 whose slab touches every column it degenerates to the all-gather.  This is row N1 of SURVEY 8(f) (an importer
 built from the column set of each slab).
 
+Overlap (halo mode): rows whose columns all lie in the rank's own x range form the INTERIOR -- the longest contiguous
+run of such rows; the rows before and after it (one grid plane each for a stencil slab) are the boundary.  Interior,
+head and tail are zero-copy row-range views of the slab (rebased row_map, offset entries/values) with their own SpMV
+plans.  Per SpMV: start the point-to-point exchange, run the interior SpMV while the halo is in flight, wait, run the
+two boundary SpMVs.
+
 One process per GPU (torch.distributed); no other data-path collective.
 """
 import numpy as np
@@ -31,7 +37,8 @@ def slab_offsets(nrows, world, align=1):
 
 
 class DistSpmv:
-    def __init__(self, A_local, offsets, rank, group=None, algo="SPMV_DEFAULT", to_backend=None, exchange="auto"):
+    def __init__(self, A_local, offsets, rank, group=None, algo="SPMV_DEFAULT", to_backend=None, exchange="auto",
+                 overlap=True):
         """A_local: CrsMatrix slab (numRows = offsets[rank+1]-offsets[rank], numCols = global).
         to_backend: converts a torch tensor to what the backend's ptr() accepts (identity for HBM tensors;
         tests on CPU/gloo pass `lambda t: t.numpy()` for the emulator backend)."""
@@ -52,6 +59,9 @@ class DistSpmv:
         self.exchange = exchange          # "auto" | "halo" | "allgather"
         self._plan = None                 # (mode, send list, recv list)
         self.exchange_bytes = None        # bytes this rank receives per SpMV
+        self.algo = algo
+        self.overlap = overlap            # halo mode: interior rows computed while the halo is in flight
+        self._split = None                # [(handle, sub-matrix, row_begin, row_end)]: interior first, then boundary parts
 
     def _entries_minmax(self):
         ent = self.A.graph.entries
@@ -93,8 +103,54 @@ class DistSpmv:
         use_halo = self.exchange == "halo" or (self.exchange == "auto" and frac.item() < 0.5)
         if use_halo:
             self._plan = ("halo", send, recv); self.exchange_bytes = halo_bytes
+            if self.overlap:
+                self._setup_overlap()
         else:
             self._plan = ("allgather", [], []); self.exchange_bytes = full_bytes
+
+    def _setup_overlap(self):
+        """interior = longest contiguous run of rows that reference only this rank's own x entries"""
+        from .sparse import CrsMatrix
+        A, me0, me1 = self.A, self.offsets[self.rank], self.offsets[self.rank + 1]
+        m = A.numRows()
+        rm, ent = A.graph.row_map, A.graph.entries
+        is_np = isinstance(ent, np.ndarray)
+        if m == 0 or A.nnz() == 0:
+            return
+        outside = (ent < me0) | (ent >= me1)
+        if is_np:
+            cs = np.concatenate([[0], np.cumsum(outside, dtype=np.int64)])
+            per_row = cs[np.asarray(rm[1:], dtype=np.int64)] - cs[np.asarray(rm[:-1], dtype=np.int64)]
+            bad = np.nonzero(per_row)[0]
+        else:
+            torch = self.torch
+            cs = torch.zeros(ent.numel() + 1, dtype=torch.int32, device=ent.device)
+            torch.cumsum(outside, 0, dtype=torch.int32, out=cs[1:])
+            rml = rm.long()
+            per_row = cs[rml[1:]] - cs[rml[:-1]]
+            bad = torch.nonzero(per_row).flatten().cpu().numpy()
+            del cs, outside, per_row
+        if bad.size == 0:
+            return                                   # nothing depends on the halo
+        edges = np.concatenate([[-1], bad, [m]])
+        gaps = np.diff(edges) - 1
+        g = int(np.argmax(gaps))
+        r_lo, r_hi = int(edges[g]) + 1, int(edges[g + 1])
+        if r_hi - r_lo < m // 2:
+            return                                   # not worth splitting
+        parts = []
+        for a, b in ((r_lo, r_hi), (0, r_lo), (r_hi, m)):
+            if b <= a:
+                continue
+            if is_np:
+                p0, p1 = int(rm[a]), int(rm[b])
+                sub_rm = (rm[a:b + 1] - rm[a]).astype(rm.dtype)
+            else:
+                p0, p1 = int(rm[a].item()), int(rm[b].item())
+                sub_rm = (rm[a:b + 1] - rm[a]).contiguous()
+            sub = CrsMatrix(b - a, A.numCols(), sub_rm, ent[p0:p1], A.values[p0:p1], backend=A.backend)
+            parts.append((SPMVHandle(self.algo), sub, a, b))
+        self._split = parts
 
     def _buffers(self, like):
         if self.x_full is None:
@@ -133,8 +189,37 @@ class DistSpmv:
                 x_full[self.offsets[r]: self.offsets[r + 1]] = self._pad[r * self.max_shard: r * self.max_shard + n]
         return x_full
 
-    def apply(self, alpha, x_shard, beta, y_shard):
-        """y_shard := alpha * A_local * allgather(x) + beta * y_shard"""
+    def apply(self, alpha, x_shard, beta, y_shard, events=None):
+        """y_shard := alpha * A_local * exchanged(x) + beta * y_shard.  events = (start, end): recorded around the
+        compute part (local SpMV kernels) when given."""
+        if self._plan is None:
+            self._buffers(x_shard)
+            self._setup_exchange(x_shard)
+        if self._plan[0] == "halo" and self._split:
+            x_full = self._buffers(x_shard)
+            _, send, recv = self._plan
+            me0, me1 = self.offsets[self.rank], self.offsets[self.rank + 1]
+            x_full[me0:me1].copy_(x_shard)
+            dist = self.dist
+            ops = [dist.P2POp(dist.isend, x_shard[lo:hi], p, group=self.group) for p, lo, hi in send]
+            ops += [dist.P2POp(dist.irecv, x_full[lo:hi], p, group=self.group) for p, lo, hi in recv]
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            xb = self.to_backend(x_full)
+            if events:
+                events[0].record()
+            h, sub, a, b = self._split[0]                        # interior: needs no halo entry
+            spmv(h, "N", alpha, sub, xb, beta, self.to_backend(y_shard[a:b]))
+            for req in reqs:
+                req.wait()
+            for h, sub, a, b in self._split[1:]:
+                spmv(h, "N", alpha, sub, xb, beta, self.to_backend(y_shard[a:b]))
+            if events:
+                events[1].record()
+            return y_shard
         x_full = self.gather_x(x_shard)
+        if events:
+            events[0].record()
         spmv(self.handle, "N", alpha, self.A, self.to_backend(x_full), beta, self.to_backend(y_shard))
+        if events:
+            events[1].record()
         return y_shard

@@ -46,7 +46,7 @@ def _worker(rank, world, port, ragged, exchange, ret):
     exp = oracle.spmv_serial("N", A0, 2.0, x, 0.5, y0.copy())[r0:r1]
     err = float(np.abs(ys.numpy() - exp).max())
     tol = oracle.spmv_max_error(A0, 2.0, 0.5, max_val=32.0)
-    ret[rank] = (ok_gen, err, tol, op._plan[0], op.exchange_bytes)
+    ret[rank] = (ok_gen, err, tol, op._plan[0], op.exchange_bytes, [(a, b) for _, _, a, b in (op._split or [])])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,12 +62,15 @@ def test_row_partitioned_spmv_world2(ragged, exchange):
         mp.spawn(_worker, args=(world, port, ragged, exchange, ret), nprocs=world, join=True)
         assert len(ret) == world
         for r in range(world):
-            ok_gen, err, tol, mode, nbytes = ret[r]
+            ok_gen, err, tol, mode, nbytes, split = ret[r]
             assert ok_gen, "slab generator mismatch on rank %d" % r
             assert err <= tol, "rank %d: %g > %g" % (r, err, tol)
             if exchange == "auto" and not ragged:
                 # 9x8x7 grid, slabs of 4 and 3 planes: each rank needs one 72-node plane of its neighbour
                 assert mode == "halo" and nbytes == 72 * 8, (mode, nbytes)
+                # interior = every plane that does not touch the neighbour's plane, computed while the halo is in flight
+                planes = 4 if r == 0 else 3
+                assert split and split[0] == ((0, (planes - 1) * 72) if r == 0 else (72, planes * 72)), split
             if exchange == "allgather":
                 assert mode == "allgather"
 

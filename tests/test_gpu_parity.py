@@ -192,6 +192,34 @@ def test_spmv_struct_variants(be):
     pc.check_spmv_struct(be, (200, 6), 2, A0=oracle.Crs(A0.nrows, A0.ncols, rm, ent2.astype(np.int32), val2))
 
 
+def test_row_range_views_with_unaligned_offsets(be):
+    """The multi-GPU overlap path (dist.py) runs planned SpMVs on zero-copy row-range views of a slab: rebased row_map,
+    entries / values pointers offset by an arbitrary (odd) number of elements, y offset too."""
+    import torch
+    n = 48
+    A = pc.kk.laplace_matrix("FE", n, n, n)
+    rm = A.graph.row_map
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.rand(A.numCols(), dtype=torch.float64, device="cuda", generator=g)
+    y_full = torch.zeros(A.numRows(), dtype=torch.float64, device="cuda")
+    pc.kk.spmv(pc.kk.SPMVHandle("SPMV_DEFAULT"), "N", 1.0, A, x, 0.0, y_full)
+    tol = 10 * np.finfo(np.float64).eps * 27 * 26
+    tried_odd = False
+    odd = torch.nonzero(rm[n * n:2 * n * n] % 2 == 1).flatten()            # a row whose first entry sits at an odd offset
+    a_odd = n * n + int(odd[0].item())
+    for a, b in ((a_odd, n * n * (n - 1) - 3), (1, 7 * n * n + 5), (n * n * (n - 1) + 2, n ** 3)):
+        p0, p1 = int(rm[a].item()), int(rm[b].item())
+        tried_odd |= (p0 % 2 == 1)
+        sub = pc.kk.CrsMatrix(b - a, A.numCols(), (rm[a:b + 1] - rm[a]).contiguous(), A.graph.entries[p0:p1], A.values[p0:p1], backend=be)
+        y = torch.full((A.numRows(),), 7.0, dtype=torch.float64, device="cuda")
+        h = pc.kk.SPMVHandle("SPMV_DEFAULT")
+        pc.kk.spmv(h, "N", 1.0, sub, x, 0.0, y[a:b])
+        pc.kk.spmv(h, "N", 2.0, sub, x, -1.0, y[a:b])          # y := 2Ax - Ax
+        assert (y[a:b] - y_full[a:b]).abs().max().item() <= 3 * tol
+        assert (y[:a] == 7.0).all().item() and (y[b:] == 7.0).all().item()
+    assert tried_odd
+
+
 def test_error_behaviour(be):
     import torch
     A = pc.dev(be, oracle.random_crs(20, 30, 3, seed=2))
