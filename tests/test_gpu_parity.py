@@ -220,6 +220,30 @@ def test_row_range_views_with_unaligned_offsets(be):
     assert tried_odd
 
 
+def test_dist_overlap_split_on_device_tensors(be):
+    """dist.py's interior / boundary split with torch tensors in HBM (the gloo test covers it with numpy arrays):
+    rank 1 of 3 of a 20x20x30 grid, no process group needed for the split itself."""
+    import torch
+    from kokkos_kernels_amd.dist import DistSpmv
+    nx, ny, nz, world, rank = 20, 20, 30, 3, 1
+    rows = nx * ny * (nz // world)
+    offsets = [r * rows for r in range(world + 1)]
+    A = pc.kk.laplace_matrix("FE", nx, ny, nz, rows=(rank * rows, rows))
+    op = DistSpmv(A, offsets, rank)
+    op._setup_overlap()
+    assert [(a, b) for _, _, a, b in op._split] == [(nx * ny, rows - nx * ny), (0, nx * ny), (rows - nx * ny, rows)]
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    x = torch.rand(nx * ny * nz, dtype=torch.float64, device="cuda", generator=g)
+    y_ref = torch.zeros(rows, dtype=torch.float64, device="cuda"); y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    pc.kk.spmv(pc.kk.SPMVHandle("SPMV_DEFAULT"), "N", 1.0, A, x, 0.0, y_ref)
+    for h, sub, a, b in op._split:
+        pc.kk.spmv(h, "N", 1.0, sub, x, 0.0, y[a:b])
+    assert (y - y_ref).abs().max().item() <= 10 * np.finfo(np.float64).eps * 27 * 26
+    # interior rows must not reference anything outside the rank's own x range
+    _, sub, a, b = op._split[0]
+    assert int(sub.graph.entries.min().item()) >= offsets[rank] and int(sub.graph.entries.max().item()) < offsets[rank + 1]
+
+
 def test_error_behaviour(be):
     import torch
     A = pc.dev(be, oracle.random_crs(20, 30, 3, seed=2))
