@@ -40,6 +40,7 @@ struct SpmvTuning {
   int ablate         = 0;  // bench-only: 1 no x gather, 2 no LDS/reduce, 3 both
   int lds_pad_kb     = 0;  // bench-only: extra dynamic LDS per workgroup (caps workgroups per CU)
   int mv_remap       = 1;  // rank-2: XCD-contiguous workgroup order (keeps shared X rows in one XCD's L2)
+  int transient_min_knnz = 10000;  // handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 = never)
 };
 static SpmvTuning g_spmv_default;
 
@@ -1003,6 +1004,60 @@ static bool stream_usable(const kkamd_spmv_plan* p, const kkamd_crs_t* A, int el
   return true;
 }
 
+template <class OffT> static int analyse(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st);
+
+// per-host-thread scratch plan for calls without an analysed handle; grown on demand, never shrunk.  Work is stream
+// ordered: consecutive calls on one stream may share the scratch; a change of stream (or device) drains the old one.
+struct TransientPlan {
+  kkamd_spmv_plan plan;
+  size_t cap_blk = 0, cap_carry = 0;
+  int device = -1;
+  hipStream_t last_stream = nullptr;
+  bool used = false;
+};
+template <class OffT>
+static kkamd_spmv_plan* transient_plan(const kkamd_crs_t* A, const SpmvTuning& tn, int elem_size, hipStream_t st) {
+  static thread_local TransientPlan tp;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  kkamd_spmv_plan& p = tp.plan;
+  if (tp.used && (tp.device != dev || tp.last_stream != st)) {
+    (void)hipStreamSynchronize(tp.last_stream);
+    if (tp.device != dev) { p.d_blk_row = nullptr; p.d_carry = nullptr; tp.cap_blk = tp.cap_carry = 0; }   // other device's buffers are abandoned
+  }
+  p.num_rows = A->num_rows; p.num_cols = A->num_cols; p.nnz = A->nnz; p.row_map = A->d_row_map; p.entries = A->d_entries;
+  p.offset_type = A->offset_type; p.algorithm = KKAMD_SPMV_FAST_SETUP; p.tune = tn;
+  p.tune.stream_variant = 1;
+  int npt = (elem_size == 8) ? 16 : 8;
+  if (elem_size == 8 && (tn.nnz_per_thread == 4 || tn.nnz_per_thread == 8)) npt = tn.nnz_per_thread;
+  p.tile    = kBlock * npt;
+  p.nblocks = ceil_div(A->nnz, p.tile);
+  const size_t need_blk = sizeof(int32_t) * (size_t)(p.nblocks + 1), need_carry = (size_t)16 * (size_t)p.nblocks;
+  if (need_blk > tp.cap_blk || need_carry > tp.cap_carry) {
+    if (tp.used) (void)hipStreamSynchronize(st);
+    if (p.d_blk_row) (void)hipFree(p.d_blk_row);
+    if (p.d_carry) (void)hipFree(p.d_carry);
+    p.d_blk_row = nullptr; p.d_carry = nullptr; tp.cap_blk = tp.cap_carry = 0;
+    const size_t cb = need_blk + need_blk / 4, cc = need_carry + need_carry / 4;
+    if (hipMalloc((void**)&p.d_blk_row, cb) != hipSuccess || hipMalloc(&p.d_carry, cc) != hipSuccess) {
+      if (p.d_blk_row) (void)hipFree(p.d_blk_row);
+      p.d_blk_row = nullptr; p.d_carry = nullptr; p.tile = 0;
+      (void)hipGetLastError();
+      return nullptr;                        // out of memory: the no-analysis kernel still works
+    }
+    tp.cap_blk = cb; tp.cap_carry = cc;
+  }
+  tp.device = dev; tp.last_stream = st; tp.used = true;
+  {
+    hipDeviceProp_t prop;
+    static thread_local int cus = 0;
+    if (!cus) cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    p.num_cus = cus;
+  }
+  if (analyse<OffT>(&p, A, st) != KKAMD_OK) return nullptr;
+  return &p;
+}
+
 template <class OffT, class AT, class YT>
 static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dx,
                       double beta_d, void* dy, hipStream_t st) {
@@ -1011,7 +1066,15 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
   YT* y          = (YT*)dy;
   if (trans) return run_transpose<OffT, AT, YT>(A, x, y, alpha, beta, st);
   if (stream_usable(plan, A, (int)sizeof(AT))) return StreamDispatch<OffT, AT, YT>::run(plan, A, x, y, alpha, beta, st);
-  return run_vector<OffT, AT, YT>(A, x, y, alpha, beta, plan ? plan->tune : g_spmv_default, st);
+  // No analysed plan (handle-less overloads, SPMV_FAST_SETUP): a large matrix is still worth the nnz-split kernel --
+  // its "analysis" is one tiny kernel (a binary search per 4096-nnz tile) into a per-thread scratch that is reused
+  // from call to call, so nothing is allocated or kept per matrix and the call stays asynchronous.
+  const SpmvTuning& tn = plan ? plan->tune : g_spmv_default;
+  if (tn.kernel != 1 && tn.transient_min_knnz > 0 && A->nnz >= (int64_t)tn.transient_min_knnz * 1000 && A->num_rows > 0) {
+    kkamd_spmv_plan* tp = transient_plan<OffT>(A, tn, (int)sizeof(AT), st);
+    if (tp && stream_usable(tp, A, (int)sizeof(AT))) return StreamDispatch<OffT, AT, YT>::run(tp, A, x, y, alpha, beta, st);
+  }
+  return run_vector<OffT, AT, YT>(A, x, y, alpha, beta, tn, st);
 }
 
 template <class OffT, class AT, class YT, int SW>
@@ -1145,6 +1208,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "wg_per_cu") t.wg_per_cu = value;
   else if (k == "ablate") t.ablate = value;
   else if (k == "mv_remap") t.mv_remap = value;
+  else if (k == "transient_min_knnz") t.transient_min_knnz = value;
   else if (k == "lds_pad_kb") t.lds_pad_kb = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
   return KKAMD_OK;

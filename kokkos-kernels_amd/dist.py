@@ -136,6 +136,16 @@ class DistSpmv:
         gaps = np.diff(edges) - 1
         g = int(np.argmax(gaps))
         r_lo, r_hi = int(edges[g]) + 1, int(edges[g + 1])
+        # the planned kernel wants 16-byte aligned entries / values: start the interior and the tail on rows whose
+        # first entry sits at a multiple of 4 (a misaligned view still works, through the slower no-analysis kernel)
+        def offset_of(r):
+            return int(rm[r]) if is_np else int(rm[r].item())
+        for _ in range(64):
+            if r_lo < r_hi and offset_of(r_lo) % 4:
+                r_lo += 1
+        for _ in range(64):
+            if r_hi > r_lo and offset_of(r_hi) % 4:
+                r_hi -= 1
         if r_hi - r_lo < m // 2:
             return                                   # not worth splitting
         parts = []

@@ -70,7 +70,9 @@ def test_row_partitioned_spmv_world2(ragged, exchange):
                 assert mode == "halo" and nbytes == 72 * 8, (mode, nbytes)
                 # interior = every plane that does not touch the neighbour's plane, computed while the halo is in flight
                 planes = 4 if r == 0 else 3
-                assert split and split[0] == ((0, (planes - 1) * 72) if r == 0 else (72, planes * 72)), split
+                lo, hi = (0, (planes - 1) * 72) if r == 0 else (72, planes * 72)
+                # (boundaries may move a few rows inward so the views start on 16-byte aligned entries)
+                assert split and 0 <= split[0][0] - lo <= 8 and 0 <= hi - split[0][1] <= 8, split
             if exchange == "allgather":
                 assert mode == "allgather"
 

@@ -173,6 +173,21 @@ def test_spmv_struct_variants(be):
         pc.kk.spmv_struct("N", 1, (8, 8), 1.0, A, be.from_numpy(np.ones(60)), 0.0, y)
 
 
+def test_handle_less_calls_analyse_on_the_fly(be):
+    """large matrices without an analysed handle (no handle, SPMV_FAST_SETUP) take the nnz-split kernel through a
+    per-thread scratch plan; matrices of different sizes alternate to exercise the scratch growth"""
+    pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(b"transient_min_knnz", 1))
+    try:
+        for A0 in (oracle.laplace2d("FE", 40, 30), oracle.laplace3d("FE", 14, 13, 12), pc._custom([0, 5000, 1, 0, 3, 900] * 3, 6000, seed=2) if hasattr(pc, "_custom") else oracle.laplace2d("FD", 50, 50)):
+            for algo in (None, "SPMV_FAST_SETUP"):
+                for alpha, beta in ((1.0, 0.0), (-2.0, 0.5)):
+                    pc.check_spmv(be, A0, "N", alpha, beta, algo=algo, max_val=32.0)
+        pc.check_spmv(be, oracle.laplace2d("FE", 40, 30), "N", 1.0, 1.0, algo=None, offset_dtype=np.int64, value_dtype=np.float32, vec_dtype=np.float32, max_val=32.0)
+        pc.check_spmv(be, oracle.laplace2d("FE", 40, 30), "T", 1.0, 0.0, algo=None, max_val=32.0)
+    finally:
+        pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(b"transient_min_knnz", 10000))
+
+
 def test_error_behaviour(be):
     A0 = oracle.random_crs(20, 30, 3, seed=2)
     A = pc.dev(be, A0)

@@ -231,7 +231,9 @@ def test_dist_overlap_split_on_device_tensors(be):
     A = pc.kk.laplace_matrix("FE", nx, ny, nz, rows=(rank * rows, rows))
     op = DistSpmv(A, offsets, rank)
     op._setup_overlap()
-    assert [(a, b) for _, _, a, b in op._split] == [(nx * ny, rows - nx * ny), (0, nx * ny), (rows - nx * ny, rows)]
+    (ia, ib), (ha, hb), (ta, tb) = [(a, b) for _, _, a, b in op._split]
+    assert 0 <= ia - nx * ny <= 8 and 0 <= (rows - nx * ny) - ib <= 8 and (ha, hb) == (0, ia) and (ta, tb) == (ib, rows)
+    assert int(A.graph.row_map[ia].item()) % 4 == 0 and int(A.graph.row_map[ib].item()) % 4 == 0
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     x = torch.rand(nx * ny * nz, dtype=torch.float64, device="cuda", generator=g)
     y_ref = torch.zeros(rows, dtype=torch.float64, device="cuda"); y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
@@ -242,6 +244,7 @@ def test_dist_overlap_split_on_device_tensors(be):
     # interior rows must not reference anything outside the rank's own x range
     _, sub, a, b = op._split[0]
     assert int(sub.graph.entries.min().item()) >= offsets[rank] and int(sub.graph.entries.max().item()) < offsets[rank + 1]
+    assert sub.graph.entries.data_ptr() % 16 == 0 and sub.values.data_ptr() % 16 == 0
 
 
 def test_error_behaviour(be):
