@@ -8,7 +8,7 @@
 // through the texture path, like its CRS kernel.
 //
 // gfx950-native structure: 8 bytes per nonzero instead of 12, and NO gather at all --
-//   * a workgroup takes a run of R = 128 consecutive interior rows of one grid line ("pencil" along i).  Their values
+//   * a workgroup takes a run of R = 64 or 128 consecutive interior rows of one grid line ("pencil" along i).  Their values
 //     are one contiguous block of R*S doubles in values(): it is streamed into LDS with coalesced loads;
 //   * the x entries those rows need are NL grid lines (1 / 3 / 3 / 5 / 9 for 3/5/9/7/27-pt) of R+2 consecutive
 //     elements each: staged in LDS with coalesced loads as well (9.4 KB for 27-pt), every element reused up to 27 times;
@@ -22,7 +22,6 @@
 
 namespace kk {
 
-constexpr int kStructRows = 128;                 // interior rows per workgroup (2 work-items per row)
 constexpr int kMaxStencil = 27, kMaxLines = 9;
 
 struct StencilDesc {
@@ -108,16 +107,17 @@ template <> struct Stencil<3, 2> {
   static constexpr int dk(int l) { return l / 3 - 1; }
 };
 
-// interior rows: blockIdx.x -> (pencil, chunk of kStructRows rows along i).  Work-item t: row r = t & 127, stencil
-// half h = t >> 7 (wave-uniform, so both halves are straight-line code over compile-time tables).
-template <class OffT, class AT, class YT, int NDIM, int ST>
-__global__ __launch_bounds__(kBlock) void spmv_struct_interior_kernel(int64_t ni, int64_t nj, int chunks_per_pencil,
+// interior rows: blockIdx.x -> (pencil, chunk of R rows along i), R = 64 or 128 picked per launch for the better fill of
+// the last chunk of a grid line.  Work-item t of 2R: row r = t mod R, stencil half h = t / R (wave-uniform, so both halves
+// are straight-line code over compile-time tables).
+template <class OffT, class AT, class YT, int NDIM, int ST, int R>
+__global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni, int64_t nj, int chunks_per_pencil,
                                                                       const OffT* __restrict__ rm, const AT* __restrict__ val,
                                                                       const YT* __restrict__ x, YT* __restrict__ y, YT alpha,
                                                                       YT beta) {
   using St = Stencil<NDIM, ST>;
-  constexpr int S = St::S, NL = St::NL, R = kStructRows;
-  constexpr int VPT = (R * S + kBlock - 1) / kBlock;          // values per work-item
+  constexpr int S = St::S, NL = St::NL, NT = 2 * R;
+  constexpr int VPT = (R * S + NT - 1) / NT;                   // values per work-item
   constexpr int HS  = (S + 1) / 2;                             // first stencil half
   __shared__ AT s_v[R * S];
   __shared__ YT s_x[NL][R + 2];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void spmv_struct_interior_kernel(int64_t ni
   const int64_t i0   = 1 + (int64_t)chunk * R;                 // first interior i of this chunk
   const int nr       = (int)((ni - 1 - i0 < R) ? ni - 1 - i0 : R);
   const int64_t row0 = (k * nj + j) * ni + i0;
-  const int r = t & (R - 1), h = t >> 7;
+  const int r = t & (R - 1), h = t / R;
   // everything that does not depend on row_map is requested first: the x lines and the old y
   YT xl[NL];
   KK_UNROLL
@@ -145,9 +145,9 @@ __global__ __launch_bounds__(kBlock) void spmv_struct_interior_kernel(int64_t ni
   AT vv[VPT];
   if (contiguous) {
     KK_UNROLL
-    for (int u = 0; u < VPT; ++u) { const int q = u * kBlock + t; vv[u] = (q < nr * S) ? val[v0 + q] : AT(0); }
+    for (int u = 0; u < VPT; ++u) { const int q = u * NT + t; vv[u] = (q < nr * S) ? val[v0 + q] : AT(0); }
     KK_UNROLL
-    for (int u = 0; u < VPT; ++u) { const int q = u * kBlock + t; if (q < R * S) s_v[q] = vv[u]; }
+    for (int u = 0; u < VPT; ++u) { const int q = u * NT + t; if (q < R * S) s_v[q] = vv[u]; }
   }
   KK_UNROLL
   for (int l = 0; l < NL; ++l) if (t < R + 2) s_x[l][t] = xl[l];
@@ -228,12 +228,19 @@ static int spmv_struct_typed(const StencilDesc& d, const kkamd_crs_t* A, double 
   const int64_t interior = ni - 2;
   int64_t num_int = 0;
   if (interior > 0 && pencils > 0) {
-    const int64_t cpp = ceil_div(interior, kStructRows);
+    // rows per workgroup: whichever of 64 / 128 leaves less of a grid line's last chunk empty (ties: 128)
+    const int64_t c128 = ceil_div(interior, 128), c64 = ceil_div(interior, 64);
+    const bool use64  = c64 * 64 < c128 * 128;
+    const int64_t cpp = use64 ? c64 : c128;
     if (pencils * cpp > INT32_MAX) return fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: grid too large");
     num_int = interior * pencils;
-#define KK_STRUCT_LAUNCH(ND, STT)                                                                                         \
-  KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT>), (unsigned)(pencils * cpp), kBlock, 0, st, ni, nj, (int)cpp, rm, \
-            val, x, y, (YT)alpha, (YT)beta)
+#define KK_STRUCT_LAUNCH(ND, STT)                                                                                          \
+  do {                                                                                                                     \
+    if (use64) KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 64>), (unsigned)(pencils * cpp), 128, 0, st, ni, nj, \
+                         (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta);                                                    \
+    else KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 128>), (unsigned)(pencils * cpp), 256, 0, st, ni, nj,      \
+                   (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta);                                                          \
+  } while (0)
     if (d.ndim == 1) KK_STRUCT_LAUNCH(1, 1);
     else if (d.ndim == 2 && d.S == 5) KK_STRUCT_LAUNCH(2, 1);
     else if (d.ndim == 2) KK_STRUCT_LAUNCH(2, 2);
