@@ -38,3 +38,4 @@ def lib():
 
 from .sparse import (CrsMatrix, SPMVHandle, KokkosKernelsHandle, spmv, spmv_struct, sort_and_merge_matrix, transpose_matrix, spgemm_symbolic, spgemm_numeric, spgemm,  # noqa: E402,F401
                      sort_crs_matrix, laplace_matrix, Backend, torch_backend)
+from . import io  # noqa: E402,F401  (matrix file formats: .mtx / .bin / .crs)

@@ -3,6 +3,8 @@
 //   test_github_issue_101            sparse/unit_test/Test_Sparse_spmv.hpp:823-961 (exact known answer)
 //   test_spmv_all_interfaces_light   :964-1055 (space/handle/neither x rank-1/rank-2 on 111 x 99)
 //   spgemm view/matrix/no-reuse APIs sparse/unit_test/Test_Sparse_spgemm.hpp:243-252,444-481
+//   matrix files: the 6x6 fixtures of sparse/unit_test/Test_Sparse_IOUtils.hpp:39-54 written as general / symmetric /
+//   hermitian / skew-symmetric .mtx and read back (:129-163), plus .bin / .crs / .mtx round trips
 //   spmv_struct (2-D 5-pt, every overload) sparse/unit_test/Test_Sparse_spmv.hpp:263-296,652-711
 // Expected values come from the test's own sequential loops, as in the reference's tests.
 #include <cmath>
@@ -11,6 +13,7 @@
 #include <random>
 #include "KokkosSparse_spmv.hpp"
 #include "KokkosSparse_spgemm.hpp"
+#include "KokkosSparse_IOUtils.hpp"
 
 using device = Kokkos::Device<Kokkos::HIP, Kokkos::HIPSpace>;
 static int failures = 0;
@@ -246,8 +249,61 @@ void test_spmv_struct() {
   EXPECT(threw);
 }
 
+void test_ioutils() {
+  using M = KokkosSparse::CrsMatrix<double, int, device, void, int>;
+  const double sym[6][6]  = {{11, 12, 13, 14, 15, 16}, {12, 2, 0, 0, 0, 0}, {13, 0, 0, 0, 0, 0}, {14, 0, 0, 4, 0, 0}, {15, 0, 0, 0, 5, 0}, {16, 0, 0, 0, 0, 6}};
+  const double asym[6][6] = {{1, 0, 0, 9, 0, 0}, {0, 2, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 8}, {0, 0, 0, 4, 0, 0}, {0, 7, 0, 0, 5, 0}, {0, 0, 0, 0, 0, 6}};
+  auto check = [&](const char* kind, const double (*D)[6], bool lower_only, double upper_sign) {
+    const std::string file = std::string("kkamd_test_io_") + kind + ".mtx";
+    {
+      std::ofstream out(file);
+      size_t n = 0;
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) if (D[r][c] != 0 && (!lower_only || c <= r)) ++n;
+      out << "%%MatrixMarket matrix coordinate real " << kind << "\n% written by test_drop_in.cpp\n6 6 " << n << "\n";
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) if (D[r][c] != 0 && (!lower_only || c <= r)) out << r + 1 << " " << c + 1 << " " << D[r][c] << "\n";
+    }
+    M A = KokkosSparse::Impl::read_kokkos_crst_matrix<M>(file.c_str());
+    auto rm = Kokkos::create_mirror_view(A.graph.row_map); Kokkos::deep_copy(rm, A.graph.row_map);
+    auto en = Kokkos::create_mirror_view(A.graph.entries); Kokkos::deep_copy(en, A.graph.entries);
+    auto va = Kokkos::create_mirror_view(A.values);        Kokkos::deep_copy(va, A.values);
+    bool ok = A.numRows() == 6 && A.numCols() == 6;
+    int pos = 0;
+    for (int r = 0; r < 6 && ok; ++r) {
+      ok = ok && rm(r) == pos;
+      for (int c = 0; c < 6; ++c) {
+        const double e = (c > r && lower_only) ? upper_sign * D[c][r] : D[r][c];
+        if (e != 0) { ok = ok && pos < (int)A.nnz() && en(pos) == c && va(pos) == e; ++pos; }
+      }
+    }
+    EXPECT(ok && rm(6) == pos);
+    // every format round-trips
+    for (const char* ext : {".mtx", ".bin", ".crs"}) {
+      const std::string f2 = std::string("kkamd_test_io_rt") + ext;
+      KokkosSparse::Impl::write_kokkos_crst_matrix(A, f2.c_str());
+      M B = KokkosSparse::Impl::read_kokkos_crst_matrix<M>(f2.c_str());
+      auto rm2 = Kokkos::create_mirror_view(B.graph.row_map); Kokkos::deep_copy(rm2, B.graph.row_map);
+      auto en2 = Kokkos::create_mirror_view(B.graph.entries); Kokkos::deep_copy(en2, B.graph.entries);
+      auto va2 = Kokkos::create_mirror_view(B.values);        Kokkos::deep_copy(va2, B.values);
+      bool same = B.numRows() == 6 && B.numCols() == 6 && B.nnz() == A.nnz();
+      for (int i = 0; i <= 6 && same; ++i) same = rm2(i) == rm(i);
+      for (size_t j = 0; j < (size_t)A.nnz() && same; ++j) same = en2(j) == en(j) && va2(j) == va(j);
+      EXPECT(same);
+      std::remove(f2.c_str());
+    }
+    std::remove(file.c_str());
+  };
+  check("general", asym, false, 1.0);
+  check("symmetric", sym, true, 1.0);
+  check("hermitian", sym, true, 1.0);
+  check("skew-symmetric", sym, true, -1.0);
+  bool threw = false;
+  try { KokkosSparse::Impl::read_kokkos_crst_matrix<M>("no_such_file.mtx"); } catch (const std::runtime_error&) { threw = true; }
+  EXPECT(threw);
+}
+
 int main() {
   Kokkos::initialize();
+  test_ioutils();
   test_spmv_struct();
   test_github_issue_101();
   test_all_interfaces<Kokkos::LayoutLeft>();
