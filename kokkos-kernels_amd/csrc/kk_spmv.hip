@@ -40,6 +40,9 @@ struct SpmvTuning {
   int ablate         = 0;  // bench-only: 1 no x gather, 2 no LDS/reduce, 3 both
   int lds_pad_kb     = 0;  // bench-only: extra dynamic LDS per workgroup (caps workgroups per CU)
   int mv_remap       = 1;  // rank-2: XCD-contiguous workgroup order (keeps shared X rows in one XCD's L2)
+  int explicit_transpose = 0;   // modes T/H with an analysed handle: 1 = cache A^T (structure + permutation) in the plan, refresh its
+                                // values every call and run the N kernel on it; 2 = same, the caller promises constant values (no refresh)
+  int explicit_transpose_min_knnz = 1000;   // ... from this many thousand nnz
   int transient_min_knnz = 10000;  // handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 = never)
 };
 static SpmvTuning g_spmv_default;
@@ -65,6 +68,10 @@ struct kkamd_spmv_plan {
   int32_t* d_ucols = nullptr;    // distinct columns of every tile, ascending within a tile
   uint16_t* d_lidx = nullptr;    // [nnz] position of each nnz's column in its tile's list
   int64_t ucols_total = 0;
+  // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
+  void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr;
+  kkamd_spmv_plan* t_plan = nullptr;
+  bool t_ready = false, t_failed = false, t_values_valid = false;
 };
 
 namespace kk {
@@ -1004,6 +1011,63 @@ static bool stream_usable(const kkamd_spmv_plan* p, const kkamd_crs_t* A, int el
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Modes T / H: the reference scatters with atomics (spmv_impl.hpp:305-420) and so does the default here (11.1 ms on
+// 27-pt 300^3).  Opt-in (knob explicit_transpose): the plan caches the TRANSPOSE once -- structure plus, for
+// every entry of A^T, the position of its value in A -- and runs the planned N kernel on A^T: deterministic, no atomics.
+//   explicit_transpose = 1: the transposed values are refreshed with one gather per call (the matrix values may change
+//     between calls, the structure may not): 8.0 ms (the gather pulls a 64 B sector per 8 B value);
+//   explicit_transpose = 2: the caller promises constant values, no refresh: 1.7 ms.
+// Costs nnz * (4 + sizeof(offset) + sizeof(value)) bytes of plan memory -- which is why it is not the default -- and
+// 0.3 s once for the transpose; falls back to the atomic kernel if the memory cannot be had.
+__global__ void iota_f64_kernel(double* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (double)i;
+}
+template <class OffT> __global__ void perm_from_f64_kernel(const double* __restrict__ src, OffT* __restrict__ perm, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) perm[i] = (OffT)src[i];
+}
+template <class OffT, class AT>
+__global__ void gather_values_kernel(const AT* __restrict__ val, const OffT* __restrict__ perm, AT* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = val[perm[i]];
+}
+template <class OffT, class AT>
+static int ensure_transpose(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
+  if (p->t_ready) return KKAMD_OK;
+  if (p->t_failed) return KKAMD_ERR_ALLOC;
+  const size_t nnz = (size_t)A->nnz;
+  double *d_iota = nullptr, *d_tmp = nullptr;
+  auto fail_clean = [&]() {
+    (void)hipGetLastError();
+    if (d_iota) (void)hipFree(d_iota);
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (p->d_t_rm) (void)hipFree(p->d_t_rm);
+    if (p->d_t_ent) (void)hipFree(p->d_t_ent);
+    if (p->d_t_perm) (void)hipFree(p->d_t_perm);
+    if (p->d_t_val) (void)hipFree(p->d_t_val);
+    p->d_t_rm = nullptr; p->d_t_ent = nullptr; p->d_t_perm = nullptr; p->d_t_val = nullptr;
+    p->t_failed = true;
+    return KKAMD_ERR_ALLOC;
+  };
+  if (hipMalloc(&p->d_t_rm, sizeof(OffT) * (size_t)(A->num_cols + 1)) != hipSuccess || hipMalloc((void**)&p->d_t_ent, sizeof(int32_t) * nnz) != hipSuccess ||
+      hipMalloc(&p->d_t_perm, sizeof(OffT) * nnz) != hipSuccess || hipMalloc(&p->d_t_val, sizeof(AT) * nnz) != hipSuccess ||
+      hipMalloc((void**)&d_iota, sizeof(double) * nnz) != hipSuccess || hipMalloc((void**)&d_tmp, sizeof(double) * nnz) != hipSuccess)
+    return fail_clean();
+  const unsigned grid = (unsigned)(ceil_div(A->nnz, kBlock) < 65536 ? ceil_div(A->nnz, kBlock) : 65536);
+  KK_LAUNCH(iota_f64_kernel, grid, kBlock, 0, st, d_iota, A->nnz);
+  // positions are exact in fp64 (nnz < 2^53), so the transpose of the "values" 0..nnz-1 IS the permutation
+  int rc = kkamd_transpose(A->num_rows, A->num_cols, A->nnz, A->d_row_map, (const int32_t*)A->d_entries, d_iota, A->offset_type, KKAMD_F64,
+                           p->d_t_rm, p->d_t_ent, d_tmp, reinterpret_cast<kkamd_stream_t>(st));
+  if (rc != KKAMD_OK) { fail_clean(); return rc; }
+  KK_LAUNCH((perm_from_f64_kernel<OffT>), grid, kBlock, 0, st, (const double*)d_tmp, (OffT*)p->d_t_perm, A->nnz);
+  if (hipStreamSynchronize(st) != hipSuccess) return fail_clean();
+  (void)hipFree(d_iota); (void)hipFree(d_tmp); d_iota = d_tmp = nullptr;
+  kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, p->d_t_rm, p->d_t_ent, p->d_t_val, A->offset_type, A->value_type};
+  rc = kkamd_spmv_plan_create(&p->t_plan, &At, p->algorithm, reinterpret_cast<kkamd_stream_t>(st));
+  if (rc != KKAMD_OK) { fail_clean(); return rc; }
+  p->t_ready = true;
+  return KKAMD_OK;
+}
+
 template <class OffT> static int analyse(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st);
 
 // per-host-thread scratch plan for calls without an analysed handle; grown on demand, never shrunk.  Work is stream
@@ -1064,7 +1128,19 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
   const YT alpha = (YT)alpha_d, beta = (YT)beta_d;
   const YT* x    = (const YT*)dx;
   YT* y          = (YT*)dy;
-  if (trans) return run_transpose<OffT, AT, YT>(A, x, y, alpha, beta, st);
+  if (trans) {
+    if (plan && plan->tile != 0 && plan->tune.explicit_transpose && A->nnz >= (int64_t)plan->tune.explicit_transpose_min_knnz * 1000 &&
+        ensure_transpose<OffT, AT>(plan, A, st) == KKAMD_OK) {
+      if (plan->tune.explicit_transpose != 2 || !plan->t_values_valid) {
+        const unsigned grid = (unsigned)(ceil_div(A->nnz, kBlock) < 65536 ? ceil_div(A->nnz, kBlock) : 65536);
+        KK_LAUNCH((gather_values_kernel<OffT, AT>), grid, kBlock, 0, st, (const AT*)A->d_values, (const OffT*)plan->d_t_perm, (AT*)plan->d_t_val, A->nnz);
+        plan->t_values_valid = true;
+      }
+      kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, plan->d_t_rm, plan->d_t_ent, plan->d_t_val, A->offset_type, A->value_type};
+      return spmv_typed<OffT, AT, YT>(plan->t_plan, &At, false, alpha_d, dx, beta_d, dy, st);
+    }
+    return run_transpose<OffT, AT, YT>(A, x, y, alpha, beta, st);
+  }
   if (stream_usable(plan, A, (int)sizeof(AT))) return StreamDispatch<OffT, AT, YT>::run(plan, A, x, y, alpha, beta, st);
   // No analysed plan (handle-less overloads, SPMV_FAST_SETUP): a large matrix is still worth the nnz-split kernel --
   // its "analysis" is one tiny kernel (a binary search per 4096-nnz tile) into a per-thread scratch that is reused
@@ -1209,6 +1285,8 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "ablate") t.ablate = value;
   else if (k == "mv_remap") t.mv_remap = value;
   else if (k == "transient_min_knnz") t.transient_min_knnz = value;
+  else if (k == "explicit_transpose") t.explicit_transpose = value;
+  else if (k == "explicit_transpose_min_knnz") t.explicit_transpose_min_knnz = value;
   else if (k == "lds_pad_kb") t.lds_pad_kb = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
   return KKAMD_OK;
@@ -1316,6 +1394,11 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_uoff) (void)hipFree(plan->d_uoff);
   if (plan->d_ucols) (void)hipFree(plan->d_ucols);
   if (plan->d_lidx) (void)hipFree(plan->d_lidx);
+  if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
+  if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
+  if (plan->d_t_perm) (void)hipFree(plan->d_t_perm);
+  if (plan->d_t_val) (void)hipFree(plan->d_t_val);
+  if (plan->t_plan) kkamd_spmv_plan_destroy(plan->t_plan);
   delete plan;
   return KKAMD_OK;
 }

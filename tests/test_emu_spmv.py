@@ -188,6 +188,34 @@ def test_handle_less_calls_analyse_on_the_fly(be):
         pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(b"transient_min_knnz", 10000))
 
 
+def test_transposed_modes_through_cached_explicit_transpose(be):
+    """modes T / H with an analysed handle: the plan caches A^T once and refreshes its values on every call"""
+    pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(b"explicit_transpose_min_knnz", 0))
+    try:
+        for A0 in (oracle.laplace3d("FE", 9, 8, 7), oracle.random_crs(120, 75, 9, variance=6, seed=4), oracle.random_crs(40, 300, 30, variance=25, seed=5)):
+            for mode in "TH":
+                for alpha, beta in ((1.0, 0.0), (-1.5, 0.5)):
+                    pc.check_spmv(be, A0, mode, alpha, beta, algo="SPMV_DEFAULT", knobs={"explicit_transpose": 1 + (alpha < 0)}, max_val=32.0)
+        pc.check_spmv(be, oracle.laplace2d("FD", 30, 20), "T", 2.0, 1.0, algo="SPMV_DEFAULT", offset_dtype=np.int64, value_dtype=np.float32,
+                      vec_dtype=np.float32, knobs={"explicit_transpose": 1}, max_val=8.0)
+        # values change between calls on the same handle; the structure does not
+        A0 = oracle.random_crs(60, 50, 7, variance=3, seed=6, sorted_rows=True)
+        A = pc.dev(be, A0)
+        h = pc.kk.SPMVHandle("SPMV_DEFAULT"); h.set("explicit_transpose", 1)
+        rng = np.random.default_rng(2)
+        x = rng.random(A0.nrows)
+        for rep in range(3):
+            y = be.from_numpy(np.zeros(A0.ncols))
+            pc.kk.spmv(h, "T", 1.0, A, be.from_numpy(x), 0.0, y)
+            exp = oracle.spmv_sequential("T", oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, be.to_numpy(A.values).copy()), 1.0, x, 0.0, np.zeros(A0.ncols))
+            assert np.allclose(be.to_numpy(y), exp, rtol=1e-13, atol=1e-13)
+            A.values[:] = rng.random(A0.nnz) + rep                          # in place: same device array, new numbers
+        # the atomic kernel stays reachable
+        pc.check_spmv(be, oracle.laplace3d("FE", 9, 8, 7), "T", 1.0, 0.0, algo="SPMV_DEFAULT", knobs={"explicit_transpose": 0}, max_val=32.0)
+    finally:
+        pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(b"explicit_transpose_min_knnz", 1000))
+
+
 def test_error_behaviour(be):
     A0 = oracle.random_crs(20, 30, 3, seed=2)
     A = pc.dev(be, A0)

@@ -247,6 +247,24 @@ def test_dist_overlap_split_on_device_tensors(be):
     assert sub.graph.entries.data_ptr() % 16 == 0 and sub.values.data_ptr() % 16 == 0
 
 
+def test_transposed_modes_through_cached_explicit_transpose(be):
+    import torch
+    for A0 in (oracle.laplace3d("FE", 60, 50, 40), oracle.rmat(14, 16)):                  # >= 1e6 nnz: the cached-transpose path
+        for mode in "TH":
+            pc.check_spmv(be, A0, mode, -1.5, 0.5, algo="SPMV_DEFAULT", knobs={"explicit_transpose": 1 if mode == "T" else 2}, max_val=50.0)
+    pc.check_spmv(be, oracle.laplace3d("FE", 60, 50, 40), "T", 1.0, 0.0, algo="SPMV_DEFAULT", knobs={"explicit_transpose": 0}, max_val=50.0)
+    # values change between calls on the same handle
+    A = pc.kk.laplace_matrix("FE", 64, 64, 64)
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT"); h.set("explicit_transpose", 1); h0 = pc.kk.SPMVHandle("SPMV_DEFAULT")
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    x = torch.rand(A.numRows(), dtype=torch.float64, device="cuda", generator=g)
+    for rep in range(3):
+        y = torch.zeros(A.numCols(), dtype=torch.float64, device="cuda"); y0 = torch.zeros_like(y)
+        pc.kk.spmv(h, "T", 1.0, A, x, 0.0, y); pc.kk.spmv(h0, "T", 1.0, A, x, 0.0, y0)     # cached transpose vs atomics
+        assert (y - y0).abs().max().item() <= 10 * np.finfo(np.float64).eps * 27 * 30 * (rep + 1)
+        A.values.mul_(1.0 + rep).add_(0.25)
+
+
 def test_error_behaviour(be):
     import torch
     A = pc.dev(be, oracle.random_crs(20, 30, 3, seed=2))
