@@ -968,6 +968,8 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
 template <class OffT, class AT, class YT> struct StreamDispatch {
   // sweep variants (tile size, non-temporal loads) exist for the fp64 headline type; others use 8 / NT
   static int run(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, hipStream_t st) {
+    const int npt = p->tile / (p->tune.stream_variant == 2 ? kWave : kBlock);
+    if (npt == 16) return launch_stream<OffT, AT, YT, 16, false>(p, A, x, y, alpha, beta, st);
     return launch_stream<OffT, AT, YT, 8, true>(p, A, x, y, alpha, beta, st);
   }
 };
@@ -1311,7 +1313,7 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
   int npt = p->tune.nnz_per_thread;
   if (npt != 4 && npt != 8 && npt != 16) npt = (p->tune.stream_variant == 4) ? 8 : 16;
   if (p->tune.stream_variant == 4 && npt == 16) npt = 8;     // the tile-local structure uses 2048- or 1024-nnz tiles
-  if (!(A->value_type == KKAMD_F64)) npt = 8;
+  if (!(A->value_type == KKAMD_F64) && p->tune.nnz_per_thread != 16) npt = 8;   // fp32 values: 2048-nnz tiles unless asked
   p->tile    = (p->tune.stream_variant == 2 ? kWave : kBlock) * npt;
   p->nblocks = ceil_div(A->nnz, p->tile);
   KK_HIP(hipMalloc((void**)&p->d_blk_row, sizeof(int32_t) * (size_t)(p->nblocks + 1)));
