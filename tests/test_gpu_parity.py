@@ -399,6 +399,17 @@ def test_spgemm_all_bins(be):
     assert sizes[4] == 0 and sizes[3] <= 256 and 256 < sizes[2] <= 2048 and 2048 < sizes[1] <= 5461 and sizes[0] > 5461
 
 
+def test_spgemm_more_than_2p20_columns(be):
+    # dense rows of C wider than one LDS bitmap window (2^20 columns): the column kernel takes several passes
+    B0 = pc.hub_matrix(40, 2_600_000, 30, {0: 300_000, 1: 120_000, 2: 9_000}, seed=21)
+    rm = [0, 2, 3, 6, 6, 8]
+    ent = np.array([0, 1,   2,   0, 2, 9,   1, 30], dtype=np.int32)
+    rng = np.random.default_rng(5)
+    A0 = oracle.Crs(5, 40, np.array(rm), ent, 1 + 49 * rng.random(len(ent)))
+    got = pc.check_spgemm(be, A0, B0, offset_dtype=np.int64)
+    assert np.diff(got.row_map).max() > 300_000 and got.ncols == 2_600_000
+
+
 def test_spgemm_rmat_square(be):
     A0 = oracle.rmat(13, 8, seed=7)               # skewed: hub rows exercise the dense path on real structure
     pc.check_spgemm(be, A0, A0)
