@@ -280,9 +280,10 @@ class KokkosKernelsHandle:
         self._spgemm = None
 
 
-def spgemm_symbolic(kh, A, transposeA, B, transposeB, Cmat=None):
+def spgemm_symbolic(kh, A, transposeA, B, transposeB, Cmat=None, allocate=True):
     """Matrix-level KokkosSparse::spgemm_symbolic (sparse/src/KokkosSparse_spgemm.hpp:40-61): allocates
-    row_map C, runs the symbolic phase, allocates entries/values of get_c_nnz() and returns C."""
+    row_map C, runs the symbolic phase, allocates entries/values of get_c_nnz() and returns C.
+    allocate=False (view-level behaviour, :spgemm_symbolic with row maps only) returns the row_map of C alone."""
     if transposeA or transposeB:
         raise RuntimeError("KokkosSparse::spgemm_symbolic: transposing A or B is not yet supported")
     sh = kh.get_spgemm_handle() if kh is not None else None
@@ -299,6 +300,8 @@ def spgemm_symbolic(kh, A, transposeA, B, transposeB, Cmat=None):
     check(lib, lib.kkamd_spgemm_symbolic(sh.h, m, n, k, be.ptr(A.graph.row_map), be.ptr(A.graph.entries),
                                          be.ptr(B.graph.row_map), be.ptr(B.graph.entries), be.ptr(rmC),
                                          _offset_type(A.graph.row_map), C.byref(nnz), be.stream()))
+    if not allocate:
+        return rmC
     vdt = _np_dtype(A.values) if A.values is not None else np.dtype(np.float64)
     return CrsMatrix(m, k, rmC, be.empty(nnz.value, np.int32), be.empty(nnz.value, vdt), backend=be)
 

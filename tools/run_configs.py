@@ -188,6 +188,25 @@ def c4_laplace(n=100):
          gather_model_GBps_numeric=b_num / best[2] / 1e9)
 
 
+def c4_symbolic_only(scale=22):
+    """C4 as specified (R-MAT scale 22): the numeric phase does not fit one GPU (nnz(C) ~ 7e10), the symbolic phase does."""
+    t0 = time.perf_counter(); R = oracle.rmat(scale, 16); tgen = time.perf_counter() - t0
+    M = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, offset_dtype=np.int64)
+    best = None
+    for rep in range(2):
+        kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        Cm = kk.spgemm_symbolic(kh, M, False, M, False, allocate=False)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        sh = kh.get_spgemm_handle(); mults = sh.get(1); nnzC = sh.get_c_nnz(); mx = (sh.get(2), sh.get(3))
+        best = (t1 - t0) if best is None or (t1 - t0) < best else best
+        kh.destroy_spgemm_handle(); del Cm
+    b_sym = R.nnz * 4 + (R.nrows + 1) * 8 + mults * 4 + (R.nrows + 1) * 8
+    emit(config="C4", device="1x MI355X", case="R-MAT scale %d ef 16, C = A*A, SYMBOLIC PHASE ONLY" % scale, rows=R.nrows, nnzA=R.nnz, nnzC=nnzC,
+         mults=mults, max_row_flops=mx[0], max_row_nnz=mx[1], symbolic_ms=best * 1e3, gather_model_GBps_symbolic=b_sym / best / 1e9,
+         bytes_of_C_if_numeric_ran=nnzC * 12, host_generation_s=tgen)
+
+
 if __name__ == "__main__":
     what = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c1", "c2", "c4"]
     torch.cuda.set_device(0)
@@ -195,3 +214,4 @@ if __name__ == "__main__":
     if "c2" in what: c2_c3()
     if "c4" in what: c4(tuple(int(v) for v in os.environ.get("KK_C4_SCALES", "14,16,18,20").split(",")))
     if "c4lap" in what: c4_laplace()
+    if "c4s22" in what: c4_symbolic_only(22)
