@@ -36,6 +36,27 @@ def slab_offsets(nrows, world, align=1):
     return offs
 
 
+def work_balanced_offsets(work_per_row, world):
+    """contiguous row slabs of near-equal total work (e.g. SpGEMM multiplications per row of A)"""
+    w = np.asarray(work_per_row, dtype=np.float64)
+    cs = np.concatenate([[0.0], np.cumsum(w)])
+    targets = cs[-1] * np.arange(1, world) / world
+    cuts = np.searchsorted(cs, targets, side="left")
+    offs = [0] + [int(c) for c in cuts] + [len(w)]
+    for i in range(1, len(offs)):
+        offs[i] = max(offs[i], offs[i - 1])
+    return offs
+
+
+def spgemm_row_slab(A_slab, B):
+    """Row-partitioned SpGEMM: rank r owns a contiguous row slab of A (local row_map) and the matching row slab of
+    C = A * B; B is replicated, so there is NO data-path communication (partition where the path shards).
+    With slabs balanced by multiplications (work_balanced_offsets) this is what makes BASELINE config C4 as specified
+    (R-MAT scale 22: nnz(C) = 7.2e10 = 863 GB) fit: 108 GB of C per GPU on eight GPUs."""
+    from .sparse import spgemm
+    return spgemm(A_slab, False, B, False)
+
+
 class DistSpmv:
     def __init__(self, A_local, offsets, rank, group=None, algo="SPMV_DEFAULT", to_backend=None, exchange="auto",
                  overlap=True):

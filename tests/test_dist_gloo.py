@@ -77,6 +77,37 @@ def test_row_partitioned_spmv_world2(ragged, exchange):
                 assert mode == "allgather"
 
 
+def test_row_partitioned_spgemm_slabs():
+    """SpGEMM shards by rows of A with B replicated and no exchange at all: the slabs of C, computed independently
+    (here one after the other under the emulator), concatenate to the full product; slabs are balanced by work."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import kk_loader
+    import oracle
+    from emu import emu_backend
+    kk = kk_loader.load()
+    from kokkos_kernels_amd.dist import work_balanced_offsets, spgemm_row_slab
+    be = emu_backend.backend()
+    R = oracle.rmat(9, 8)
+    lenB = np.diff(R.row_map)
+    flops = np.array([lenB[R.entries[R.row_map[i]:R.row_map[i + 1]]].sum() for i in range(R.nrows)])
+    offs = work_balanced_offsets(flops, 4)
+    assert offs[0] == 0 and offs[-1] == R.nrows and all(a <= b for a, b in zip(offs, offs[1:]))
+    per = [flops[a:b].sum() for a, b in zip(offs, offs[1:])]
+    assert max(per) <= 1.5 * flops.sum() / 4 + flops.max()
+    B = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, backend=be)
+    gold = oracle.spgemm(R, R)
+    rm_all, ent_all, val_all = [0], [], []
+    for a, b in zip(offs, offs[1:]):
+        sl = slice(R.row_map[a], R.row_map[b])
+        A_slab = kk.CrsMatrix.from_host(b - a, R.ncols, R.row_map[a:b + 1] - R.row_map[a], R.entries[sl], R.values[sl], backend=be)
+        Cs = spgemm_row_slab(A_slab, B)
+        r, e, v = Cs.to_host()
+        rm_all += list(np.asarray(r[1:], dtype=np.int64) + rm_all[-1]); ent_all.append(e); val_all.append(v)
+    got = oracle.Crs(R.nrows, R.ncols, np.array(rm_all), np.concatenate(ent_all), np.concatenate(val_all))
+    ok, msg = oracle.is_same_matrix(got, gold)
+    assert ok, msg
+
+
 def test_slab_offsets():
     sys.path.insert(0, ROOT)
     import kk_loader

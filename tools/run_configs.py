@@ -207,6 +207,43 @@ def c4_symbolic_only(scale=22):
          bytes_of_C_if_numeric_ran=nnzC * 12, host_generation_s=tgen)
 
 
+def c4_slab(scale=22, world=8, ranks=(0, 7)):
+    """C4 as specified, the way it fits: rows of A in `world` slabs of equal multiplication count, B replicated, no
+    communication.  One GPU is available here, so the slabs of the chosen ranks run one after the other: each line is
+    what ONE of the eight GPUs does (symbolic + numeric on its slab, C slab resident in its HBM)."""
+    from kokkos_kernels_amd.dist import work_balanced_offsets
+    R = oracle.rmat(scale, 16)
+    lenB = np.diff(R.row_map)
+    cs = np.concatenate([[0], np.cumsum(lenB[R.entries], dtype=np.int64)])
+    flops = cs[R.row_map[1:]] - cs[R.row_map[:-1]]
+    offs = work_balanced_offsets(flops, world)
+    B = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, offset_dtype=np.int64)
+    for r in ranks:
+        a, b = offs[r], offs[r + 1]
+        sl = slice(R.row_map[a], R.row_map[b])
+        A = kk.CrsMatrix.from_host(b - a, R.ncols, R.row_map[a:b + 1] - R.row_map[a], R.entries[sl], R.values[sl], offset_dtype=np.int64)
+        kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        Cm = kk.spgemm_symbolic(kh, A, False, B, False)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        kk.spgemm_numeric(kh, A, False, B, False, Cm)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        sh = kh.get_spgemm_handle(); mults = sh.get(1); nnzC = Cm.nnz()
+        # size-independent check of the slab: every row sorted and duplicate-free, row sums of C == A * (B * 1)
+        ent = Cm.graph.entries; rm = Cm.graph.row_map
+        sorted_ok = bool(((ent[1:] > ent[:-1]) | torch.isin(torch.arange(1, nnzC, device="cuda"), rm[1:-1])).all().item()) if nnzC < 2**31 else None
+        ones = torch.ones(R.ncols, dtype=torch.float64, device="cuda")
+        b1 = torch.zeros(R.nrows, dtype=torch.float64, device="cuda"); kk.spmv("N", 1.0, B, ones, 0.0, b1)
+        ab1 = torch.zeros(b - a, dtype=torch.float64, device="cuda"); kk.spmv("N", 1.0, A, b1, 0.0, ab1)
+        c1 = torch.zeros(b - a, dtype=torch.float64, device="cuda"); kk.spmv("N", 1.0, Cm, ones, 0.0, c1)
+        rel = float(((c1 - ab1).abs() / ab1.abs().clamp_min(1.0)).max().item())
+        emit(config="C4", device="1x MI355X = rank %d of %d" % (r, world), case="R-MAT scale %d ef 16, row slab [%d, %d) of A times all of B" % (scale, a, b),
+             rows=b - a, mults=mults, nnzC_slab=nnzC, C_slab_GB=nnzC * 12 / 1e9, symbolic_ms=(t1 - t0) * 1e3, numeric_ms=(t2 - t1) * 1e3,
+             GFLOPs_numeric=2 * mults / (t2 - t1) / 1e9, rows_sorted_unique=sorted_ok, rowsum_identity_max_rel_err=rel)
+        kh.destroy_spgemm_handle(); del Cm, A
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
     what = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c1", "c2", "c4"]
     torch.cuda.set_device(0)
@@ -215,3 +252,4 @@ if __name__ == "__main__":
     if "c4" in what: c4(tuple(int(v) for v in os.environ.get("KK_C4_SCALES", "14,16,18,20").split(",")))
     if "c4lap" in what: c4_laplace()
     if "c4s22" in what: c4_symbolic_only(22)
+    if "c4slab" in what: c4_slab(int(os.environ.get("KK_C4_SLAB_SCALE", "22")))
