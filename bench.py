@@ -65,11 +65,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=0, help="override the grid edge (debug: smaller problem)")
+    ap.add_argument("--grid-edge", "--n", dest="n", type=int, default=0,
+                    help="override the grid edge (debug: smaller problem); spell it --grid-edge under torch.distributed.run, "
+                         "whose own parser claims every unambiguous prefix of its options")
     ap.add_argument("--beta", type=float, default=0.0)
     ap.add_argument("--algo", default="SPMV_DEFAULT")
     ap.add_argument("--knob", action="append", default=[], help="key=value expert knob for the SpMV plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate", action="store_true",
+                    help="debug / CI: run the whole flow on CPU -- gloo instead of RCCL, the kernels under the SIMT emulator of "
+                         "tests/emu, a tiny grid -- to exercise the multi-process control flow without GPUs (numbers are meaningless)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1, halo exchange: do not split the slab into interior / boundary rows (no compute-communication overlap)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"],
@@ -86,14 +91,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    emu = args.emulate
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu import emu_backend
+        be, dev, tb = emu_backend.backend(), "cpu", (lambda t: t.numpy())
+
+        class Event:                               # stands in for torch.cuda.Event
+            def __init__(self, enable_timing=True): self.t = 0.0
+            def record(self): self.t = time.perf_counter()
+            def elapsed_time(self, other): return (other.t - self.t) * 1e3
+        device_sync = lambda: None
+        args.no_cpu_baseline = True
+    else:
+        torch.cuda.set_device(local_rank)
+        be, dev, tb, Event, device_sync = None, "cuda", (lambda t: t), torch.cuda.Event, torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload ---------------------------------------------------------------------------
+    if emu and not args.n:
+        args.n = 16
     if world == 1:
         n = args.n or 300
         nx = ny = nz = n
@@ -107,24 +131,25 @@ def main():
         workload = "spmv_crs_27pt_FE_laplacian_%dx%dx%d_fp64_row_slabs_%d_planes_per_gpu" % (nx, ny, nz, planes_per_rank)
     rows_per_rank = nx * ny * planes_per_rank
     nrows_global = nx * ny * nz
-    A = kk.laplace_matrix("FE", nx, ny, nz, rows=(rank * rows_per_rank, rows_per_rank))
+    A = kk.laplace_matrix("FE", nx, ny, nz, rows=(rank * rows_per_rank, rows_per_rank), backend=be)
     nnz_local = A.nnz()
-    g = torch.Generator(device="cuda"); g.manual_seed(17312837 + rank)
-    x_shard = torch.randint(-20, 20, (rows_per_rank,), device="cuda", generator=g).double()
-    y_shard = torch.randint(-20, 20, (rows_per_rank,), device="cuda", generator=g).double()
+    g = torch.Generator(device=dev); g.manual_seed(17312837 + rank)
+    x_shard = torch.randint(-20, 20, (rows_per_rank,), device=dev, generator=g).double()
+    y_shard = torch.randint(-20, 20, (rows_per_rank,), device=dev, generator=g).double()
     alpha, beta = 1.0, args.beta
 
     if world == 1:
         handle = kk.SPMVHandle(args.algo)
         for kv in args.knob:
             k, v = kv.split("="); handle.set(k, int(v))
-        def spmv_only(): kk.spmv(handle, "N", alpha, A, x_shard, beta, y_shard)
+        def spmv_only(): kk.spmv(handle, "N", alpha, A, tb(x_shard), beta, tb(y_shard))
         def step(ev0, ev1):
             ev0.record(); spmv_only(); ev1.record()
     else:
         from kokkos_kernels_amd.dist import DistSpmv
         offsets = [r * rows_per_rank for r in range(world + 1)]
-        op = DistSpmv(A, offsets, rank, algo=args.algo, exchange=args.exchange, overlap=not args.no_overlap)
+        op = DistSpmv(A, offsets, rank, algo=args.algo, exchange=args.exchange, overlap=not args.no_overlap,
+                      to_backend=tb if emu else None)
         for kv in args.knob:
             k, v = kv.split("="); op.handle.set(k, int(v))
         def step(ev0, ev1):
@@ -133,10 +158,10 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [(Event(enable_timing=True), Event(enable_timing=True)) for _ in range(args.steps)]
+    w0, w1 = Event(enable_timing=True), Event(enable_timing=True)
     for _ in range(args.warmup):
         step(w0, w1)
     barrier()
@@ -148,18 +173,20 @@ def main():
     ms_step = (t1 - t0) * 1e3 / args.steps
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps      # local SpMV kernels (N > 1 with overlap: incl. the wait for the halo)
 
-    nnz_total = torch.tensor([float(nnz_local)], device="cuda", dtype=torch.float64)
-    tmax = torch.tensor([ms_step, kern_ms], device="cuda", dtype=torch.float64)
+    nnz_total = torch.tensor([float(nnz_local)], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([ms_step, kern_ms], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(nnz_total, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     nnz_global = int(nnz_total.item()); ms_step, kern_ms = tmax.tolist()
 
     # ---- sanity inside the bench: A*1 over the slab must be the row-sum vector (0 interior, 1 boundary) ----
-    ones = torch.ones(nrows_global, dtype=torch.float64, device="cuda")
-    chk = torch.empty(rows_per_rank, dtype=torch.float64, device="cuda")
-    kk.spmv(handle if world == 1 else op.handle, "N", 1.0, A, ones, 0.0, chk)
+    ones = torch.ones(nrows_global, dtype=torch.float64, device=dev)
+    chk = torch.empty(rows_per_rank, dtype=torch.float64, device=dev)
+    kk.spmv(handle if world == 1 else op.handle, "N", 1.0, A, tb(ones), 0.0, tb(chk))
     lens = A.graph.row_map[1:] - A.graph.row_map[:-1]
+    if emu:
+        lens = torch.from_numpy(np.asarray(lens))
     assert bool((chk[lens == 27] == 0).all()) and bool((chk[lens < 27] == 1).all()), "bench self-check failed"
 
     # ---- roofline of the dominant kernel (local SpMV) -------------------------------------------
@@ -176,7 +203,8 @@ def main():
         out = {
             "metric": "SpMV GFLOP/s (CSR, 27-pt 3-D FE Laplacian, fp64)", "value": round(gflops, 2), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not emu else "synthetic; EMULATED ON CPU (control-flow check only, not a measurement)",
             "config": {"workload": workload, "rows": nrows_global, "nnz": nnz_global, "rows_per_gpu": rows_per_rank,
                        "alpha": alpha, "beta": beta, "offsets": "int32", "ordinals": "int32", "algorithm": args.algo,
                        "partition": ("1-D row slabs; x exchange = %s over RCCL/xGMI, %d bytes received per GPU per SpMV%s"

@@ -108,6 +108,28 @@ def test_row_partitioned_spgemm_slabs():
     assert ok, msg
 
 
+def test_bench_two_process_flow_emulated():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with
+    --emulate: gloo instead of RCCL and the kernels under the SIMT emulator.  Checks the whole multi-process control
+    flow -- slab generation, halo plan, interior/boundary overlap, barriers, max-over-ranks timing, the A*1 self-check,
+    the single JSON line from rank 0 -- without a GPU."""
+    import json
+    import subprocess
+    port = 29900 + (os.getpid() % 500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--emulate", "--grid-edge", "32"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "GFLOP/s"
+    assert d["config"]["rows"] == 32 * 32 * 8 and d["config"]["rows_per_gpu"] == 32 * 32 * 4
+    assert "halo" in d["config"]["partition"] and "overlap" in d["config"]["partition"], d["config"]["partition"]
+    assert "%d bytes" % (32 * 32 * 8) in d["config"]["partition"]            # one 32x32 plane of doubles from the neighbour
+    assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+
+
 def test_slab_offsets():
     sys.path.insert(0, ROOT)
     import kk_loader
