@@ -117,7 +117,6 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
                                                                       YT beta) {
   using St = Stencil<NDIM, ST>;
   constexpr int S = St::S, NL = St::NL, NT = 2 * R;
-  constexpr int VPT = (R * S + NT - 1) / NT;                   // values per work-item
   constexpr int HS  = (S + 1) / 2;                             // first stencil half
   __shared__ AT s_v[R * S];
   __shared__ YT s_x[NL][R + 2];
@@ -142,12 +141,21 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
   YT yold = (h == 0 && r < nr) ? y[row0 + r] : YT(0);
   const long long v0    = (long long)rm[row0];
   const bool contiguous = (long long)rm[row0 + nr] - v0 == (long long)nr * S;     // rows of exactly S entries each
-  AT vv[VPT];
   if (contiguous) {
+    // the block of nr*S values, two per load (a pair starts at an even element of the block, i.e. at an 8-byte --
+    // not necessarily 16-byte -- aligned address: vec2 carries that alignment so one 128-bit load is emitted anyway)
+    constexpr int VP2 = ((R * S + 1) / 2 + NT - 1) / NT;
+    struct vec2 { AT x, y; };                                    // alignof(vec2) == sizeof(AT)
+    vec2 vv[VP2];
+    const int nval = nr * S, npair = nval >> 1;
     KK_UNROLL
-    for (int u = 0; u < VPT; ++u) { const int q = u * NT + t; vv[u] = (q < nr * S) ? val[v0 + q] : AT(0); }
+    for (int u = 0; u < VP2; ++u) {
+      const int q = u * NT + t;
+      if (q < npair) vv[u] = *reinterpret_cast<const vec2*>(val + v0 + 2 * q);
+      else { vv[u].x = (2 * q < nval) ? val[v0 + 2 * q] : AT(0); vv[u].y = AT(0); }      // the odd last value, if any
+    }
     KK_UNROLL
-    for (int u = 0; u < VPT; ++u) { const int q = u * NT + t; if (q < R * S) s_v[q] = vv[u]; }
+    for (int u = 0; u < VP2; ++u) { const int q = u * NT + t; if (q < (R * S + 1) / 2) { s_v[2 * q] = vv[u].x; if (2 * q + 1 < R * S) s_v[2 * q + 1] = vv[u].y; } }
   }
   KK_UNROLL
   for (int l = 0; l < NL; ++l) if (t < R + 2) s_x[l][t] = xl[l];
