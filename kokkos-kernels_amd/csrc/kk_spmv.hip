@@ -1094,8 +1094,8 @@ static kkamd_spmv_plan* transient_plan(const kkamd_crs_t* A, const SpmvTuning& t
   p.num_rows = A->num_rows; p.num_cols = A->num_cols; p.nnz = A->nnz; p.row_map = A->d_row_map; p.entries = A->d_entries;
   p.offset_type = A->offset_type; p.algorithm = KKAMD_SPMV_FAST_SETUP; p.tune = tn;
   p.tune.stream_variant = 1;
-  int npt = (elem_size == 8) ? 16 : 8;
-  if (elem_size == 8 && (tn.nnz_per_thread == 4 || tn.nnz_per_thread == 8)) npt = tn.nnz_per_thread;
+  int npt = (elem_size == 8 && A->nnz >= 200000000) ? 16 : 8;
+  if (elem_size == 8 && (tn.nnz_per_thread == 4 || tn.nnz_per_thread == 8 || tn.nnz_per_thread == 16)) npt = tn.nnz_per_thread;
   p.tile    = kBlock * npt;
   p.nblocks = ceil_div(A->nnz, p.tile);
   const size_t need_blk = sizeof(int32_t) * (size_t)(p.nblocks + 1), need_carry = (size_t)16 * (size_t)p.nblocks;
@@ -1311,7 +1311,9 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
   p->tile = 0; p->nblocks = 0;
   if (p->algorithm == KKAMD_SPMV_FAST_SETUP || p->tune.kernel == 1 || A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
   int npt = p->tune.nnz_per_thread;
-  if (npt != 4 && npt != 8 && npt != 16) npt = (p->tune.stream_variant == 4) ? 8 : 16;
+  // auto: 4096-nnz tiles once there are plenty of them (measured best from ~2e8 nnz up), 2048-nnz tiles below that
+  // (5-pt 1000^2: 19.2 vs 22.2 us)
+  if (npt != 4 && npt != 8 && npt != 16) npt = (p->tune.stream_variant == 4 || A->nnz < 200000000) ? 8 : 16;
   if (p->tune.stream_variant == 4 && npt == 16) npt = 8;     // the tile-local structure uses 2048- or 1024-nnz tiles
   if (!(A->value_type == KKAMD_F64) && p->tune.nnz_per_thread != 16) npt = 8;   // fp32 values: 2048-nnz tiles unless asked
   p->tile    = (p->tune.stream_variant == 2 ? kWave : kBlock) * npt;
