@@ -180,20 +180,30 @@ __global__ __launch_bounds__(kBlock) void spgemm_bin_scatter_kernel(int64_t m, c
 
 // ------------------------------------------------------------------------------------------------
 // LDS open-addressing helpers
+// A plain LDS read comes first: LDS atomics retire at about one lane per clock per CU (the wave-per-row kernels were
+// bound by exactly that), reads at 16+ lanes per clock, and most products hit a column that is already in the table.
 __device__ __forceinline__ bool hash_insert_key(int* tab, int mask, int key) {   // true if the key is new
   int h = (int)(((unsigned)key * (unsigned)kHashMul) & (unsigned)mask);
   while (true) {
-    const int old = atomicCAS(&tab[h], -1, key);
-    if (old == -1) return true;
-    if (old == key) return false;
+    const int k = tab[h];
+    if (k == key) return false;
+    if (k == -1) {
+      const int old = atomicCAS(&tab[h], -1, key);
+      if (old == -1) return true;
+      if (old == key) return false;
+    }
     h = (h + 1) & mask;
   }
 }
 template <class VT> __device__ __forceinline__ void hash_accumulate(int* keys, VT* vals, int mask, int key, VT v) {
   int h = (int)(((unsigned)key * (unsigned)kHashMul) & (unsigned)mask);
   while (true) {
-    const int old = atomicCAS(&keys[h], -1, key);
-    if (old == -1 || old == key) { KK_ATOMIC_FADD(&vals[h], v); return; }
+    const int k = keys[h];
+    if (k == key) { KK_ATOMIC_FADD(&vals[h], v); return; }
+    if (k == -1) {
+      const int old = atomicCAS(&keys[h], -1, key);
+      if (old == -1 || old == key) { KK_ATOMIC_FADD(&vals[h], v); return; }
+    }
     h = (h + 1) & mask;
   }
 }
@@ -347,6 +357,59 @@ __device__ __forceinline__ void flat_products_v(int64_t row, const OffT* __restr
   flat_products_impl<NT, OffT, VT>(row, rmA, entA, rmB, entB, valB, sc, f);
 }
 
+// Wave-wide flat iteration (wave-per-row kernels): the same idea as flat_products for one wave -- lane l looks up the
+// l-th A entry of the row (all B row lookups of up to 64 entries in ONE dependent chain instead of one chain per group
+// of entries), a shuffle scan turns the lengths into product offsets kept in wave-private LDS, then lane (q mod 64)
+// takes product q.  Every lane of the wave must call it (uniform trip counts; `active` masks idle waves).
+struct WaveFlatScratch { int pre[65]; long long b0[64]; };
+template <class OffT, class VT, class F>
+__device__ __forceinline__ void wave_flat_products(bool active, int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                   const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                   const VT* __restrict__ valB, int lane, WaveFlatScratch& sc, F f) {
+  constexpr bool kVals = !std::is_same<VT, NoVals>::value;
+  int64_t a_beg = 0, a_end = 0;
+  if (active) { a_beg = (int64_t)rmA[row]; a_end = (int64_t)rmA[row + 1]; }
+  for (int64_t chunk = a_beg; chunk < a_end; chunk += 64) {
+    const int n = (int)(a_end - chunk < 64 ? a_end - chunk : 64);
+    long long b0 = 0;
+    int len = 0;
+    if (lane < n) { const int32_t c = entA[chunk + lane]; b0 = (long long)rmB[c]; len = (int)((long long)rmB[c + 1] - b0); }
+    int inc = len;
+    for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(inc, (unsigned)o, 64); if (lane >= o) inc += nb; }
+    const int tot = __shfl(inc, 63, 64);
+    KK_WAVE_SYNC();                       // the previous chunk's readers are done
+    sc.pre[lane] = inc - len; sc.b0[lane] = b0;
+    if (lane == 0) sc.pre[64] = tot;
+    KK_WAVE_SYNC();
+    auto find = [&](int q, int lo) {      // largest s in [lo, n) with pre[s] <= q
+      int len2 = n - lo;
+      while (len2 > 1) { const int half = len2 >> 1; lo += (sc.pre[lo + half] <= q) ? half : 0; len2 -= half; }
+      return lo;
+    };
+    for (int base = 0; base < tot; base += 64 * kProdUnroll) {
+      int col[kProdUnroll], seg[kProdUnroll];
+      typename std::conditional<kVals, VT, int>::type bv[kProdUnroll];
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u) {
+        const int q = base + u * 64 + lane;
+        col[u] = -1; seg[u] = 0; bv[u] = 0;
+        if (q < tot) {
+          seg[u] = find(q, u == 0 ? 0 : seg[u - 1]);
+          const long long j = sc.b0[seg[u]] + (q - sc.pre[seg[u]]);
+          col[u] = entB[j];
+          if constexpr (kVals) bv[u] = valB[j];
+        }
+      }
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u)
+        if (col[u] >= 0) {
+          if constexpr (kVals) f(chunk + seg[u], col[u], bv[u]);
+          else f(chunk + seg[u], (int64_t)0, col[u]);
+        }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 3. symbolic kernels
 template <class OffT>
@@ -356,18 +419,18 @@ __global__ __launch_bounds__(kBlock) void spgemm_sym_wave_kernel(int64_t nbin, c
                                                                  OffT* __restrict__ counts, int sg_log2) {
   constexpr int H = kSymWaveTable;
   __shared__ int tab[kBlock / 64][H];
+  __shared__ WaveFlatScratch s_wf[kBlock / 64];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
   for (int i = lane; i < H; i += 64) tab[w][i] = -1;
   __syncthreads();
   int cnt = 0;
-  int64_t row = -1;
-  if (idx < nbin) {
-    row = perm[idx];
-    int* mytab = tab[w];
-    for_each_product<OffT>(row, rmA, entA, rmB, entB, lane, 64, sg_log2,
-                           [&](int64_t, int64_t, int c) { cnt += hash_insert_key(mytab, H - 1, c) ? 1 : 0; });
-  }
+  const bool active = idx < nbin;
+  const int64_t row = active ? (int64_t)perm[idx] : 0;
+  int* mytab = tab[w];
+  wave_flat_products<OffT, NoVals>(active, row, rmA, entA, rmB, entB, (const NoVals*)nullptr, lane, s_wf[w],
+                                   [&](int64_t, int64_t, int c) { cnt += hash_insert_key(mytab, H - 1, c) ? 1 : 0; });
+  (void)sg_log2;
   cnt = group_sum(cnt, 64);
   if (idx < nbin && lane == 0) counts[row] = (OffT)cnt;
 }
@@ -495,16 +558,19 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_wave_kernel(int64_t nbin, c
   __shared__ int keys[kBlock / 64][H];
   __shared__ VT vals[kBlock / 64][H];
   __shared__ int ckey[kBlock / 64][H / 2];
+  __shared__ WaveFlatScratch s_wf[kBlock / 64];
   __shared__ unsigned short cslot[kBlock / 64][H / 2];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
   for (int i = lane; i < H; i += 64) { keys[w][i] = -1; vals[w][i] = VT(0); }
   __syncthreads();
-  if (idx < nbin) {
-    const int64_t row = perm[idx];
+  {
+    const bool active = idx < nbin;
+    const int64_t row = active ? (int64_t)perm[idx] : 0;
     int* mk = keys[w]; VT* mv = vals[w];
-    for_each_product_v<OffT, VT>(row, rmA, entA, rmB, entB, valB, lane, 64, sg_log2,
+    wave_flat_products<OffT, VT>(active, row, rmA, entA, rmB, entB, valB, lane, s_wf[w],
                                  [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(mk, mv, H - 1, c, valA[a] * bv); });
+    (void)sg_log2;
   }
   __syncthreads();
   // compact the occupied slots (ballot + prefix), then rank-by-counting over the compact list only: keys are unique,

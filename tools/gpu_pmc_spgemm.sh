@@ -7,8 +7,11 @@ cat > /tmp/sg1.py <<'PY'
 import sys; sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, kk_loader, oracle
 kk = kk_loader.load()
-Rm = oracle.rmat(int(sys.argv[2][4:]), 16)
-M = kk.CrsMatrix.from_host(Rm.nrows, Rm.ncols, Rm.row_map, Rm.entries, Rm.values, offset_dtype=np.int64)
+if sys.argv[2] == "laplace":
+    M = kk.laplace_matrix("FE", 100, 100, 100)
+else:
+    Rm = oracle.rmat(int(sys.argv[2][4:]), 16)
+    M = kk.CrsMatrix.from_host(Rm.nrows, Rm.ncols, Rm.row_map, Rm.entries, Rm.values, offset_dtype=np.int64)
 kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle()
 C = kk.spgemm_symbolic(kh, M, False, M, False)
 kk.spgemm_numeric(kh, M, False, M, False, C); torch.cuda.synchronize()
