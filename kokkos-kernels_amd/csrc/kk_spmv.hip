@@ -39,7 +39,7 @@ struct SpmvTuning {
   int wg_per_cu      = 0;  // unused (persistent variant measured slower and was removed)
   int ablate         = 0;  // bench-only: 1 no x gather, 2 no LDS/reduce, 3 both
   int lds_pad_kb     = 0;  // bench-only: extra dynamic LDS per workgroup (caps workgroups per CU)
-  int mv_remap       = 1;  // rank-2: XCD-contiguous workgroup order (keeps shared X rows in one XCD's L2)
+  int mv_remap       = 0;  // rank-2: 1 = XCD-contiguous workgroup order (higher L2 hit rate, yet measured 5-7 % slower: 7.92 vs 7.36 ms on C3)
   int explicit_transpose = 0;   // modes T/H with an analysed handle: 1 = cache A^T (structure + permutation) in the plan, refresh its
                                 // values every call and run the N kernel on it; 2 = same, the caller promises constant values (no refresh)
   int explicit_transpose_min_knnz = 1000;   // ... from this many thousand nnz
