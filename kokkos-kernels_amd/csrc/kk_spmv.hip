@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
   const int lane64 = threadIdx.x & 63, w = threadIdx.x >> 6;
   AT* s_val  = s_val_all[w];
   int* s_col = s_col_all[w];
-  const int64_t wg   = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t wg   = (remap & 1) ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
   const int64_t row0 = (wg * (kBlock / kWave) + w) * RW;
   if (row0 >= nrows) return;                                   // whole wave leaves together
   const int64_t rowN = (row0 + RW < nrows) ? row0 + RW : nrows;
@@ -789,7 +789,8 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
         const kk_i32x4 cc = *reinterpret_cast<const kk_i32x4*>(entries + c + lane64 * 4);
         const AV va = *reinterpret_cast<const AV*>(values + c + lane64 * 2);
         const AV vb = *reinterpret_cast<const AV*>(values + c + 128 + lane64 * 2);
-        s_col[lane64 * 4] = cc[0]; s_col[lane64 * 4 + 1] = cc[1]; s_col[lane64 * 4 + 2] = cc[2]; s_col[lane64 * 4 + 3] = cc[3];
+        const int cm = (remap & 2) ? 255 : -1;       // bench-only ablation: every X access hits 256 rows that stay in L1
+        s_col[lane64 * 4] = cc[0] & cm; s_col[lane64 * 4 + 1] = cc[1] & cm; s_col[lane64 * 4 + 2] = cc[2] & cm; s_col[lane64 * 4 + 3] = cc[3] & cm;
         s_val[lane64 * 2] = va[0]; s_val[lane64 * 2 + 1] = va[1];
         s_val[128 + lane64 * 2] = vb[0]; s_val[128 + lane64 * 2 + 1] = vb[1];
       } else {

@@ -15,7 +15,7 @@ for nv in (16, 8, 4):
     X = torch.rand(A.numCols(), nv, dtype=torch.float64, device="cuda"); Y = torch.zeros(A.numRows(), nv, dtype=torch.float64, device="cuda")
     res = []
     for rep in range(3):
-        for rm in (1, 0):
+        for rm in (1, 0, 2):
             h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("mv_remap", rm)
             res.append((rm, timeit(lambda: kk.spmv(h, "N", 1.0, A, X, 0.0, Y))))
     print("nvec %2d:" % nv, " ".join("remap%d=%.3f" % r for r in res))
