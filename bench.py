@@ -39,6 +39,7 @@ def cpu_baseline(sample_n=160, min_seconds=6.0):
     os.environ.setdefault("OMP_PLACES", "threads")
     import numpy as np
     import oracle
+    oracle.set_omp_threads(oracle.usable_cpus())     # the cgroup CPU quota, not the visible core count (see usable_cpus)
     A = oracle.laplace3d("FE", sample_n, sample_n, sample_n)
     ft = oracle.first_touch          # pages spread over NUMA nodes the way a Kokkos::View's would be
     rm32 = ft(A.row_map.astype(np.int32)); ent = ft(A.entries); val = ft(A.values)

@@ -85,6 +85,7 @@ double kko_hash_value_1_50(uint64_t key, uint64_t seed);
 
 /* ---- CPU baselines (OpenMP restatements of the reference's host kernels) -- */
 int kko_omp_max_threads(void);
+int kko_omp_set_threads(int n);
 int kko_first_touch_copy(void* dst, const void* src, int64_t bytes);
 int kko_spmv_omp(int64_t nrows, const int64_t* row_map, const int32_t* entries, const double* values, double alpha,
                  const double* x, double beta, double* y);

@@ -296,6 +296,30 @@ def omp_threads():
     return int(lib().kko_omp_max_threads())
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container with
+    cpu.max = "1600000 100000" gets 16 CPUs' worth of time however many cores it can see -- 128 OpenMP threads under
+    such a quota run 8x SLOWER than 16)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
+def set_omp_threads(n):
+    return int(lib().kko_omp_set_threads(C.c_int(int(n))))
+
+
 def spmv_omp(A_row_map, entries, values, alpha, x, beta, y):
     L = lib()
     fn = L.kko_spmv_omp_i32 if A_row_map.dtype == np.int32 else L.kko_spmv_omp

@@ -9,6 +9,7 @@
 #include <omp.h>
 
 int kko_omp_max_threads(void) { return omp_get_max_threads(); }
+int kko_omp_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
 
 /* parallel first-touch copy: what Kokkos::View allocation + deep_copy do on the OpenMP backend (pages end up
  * spread over the NUMA nodes of the threads that touch them), instead of one thread faulting everything in. */

@@ -17,6 +17,7 @@ import kk_loader
 import oracle
 
 kk = kk_loader.load()
+oracle.set_omp_threads(oracle.usable_cpus())
 
 
 def emit(**kw):
