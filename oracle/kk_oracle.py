@@ -301,7 +301,11 @@ def usable_cpus():
     cpu.max = "1600000 100000" gets 16 CPUs' worth of time however many cores it can see -- 128 OpenMP threads under
     such a quota run 8x SLOWER than 16)."""
     import os
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = os.cpu_count() or 1
+    if hasattr(os, "sched_getaffinity"):
+        a = len(os.sched_getaffinity(0))
+        if a > 1:            # a mask of ONE cpu is what OMP_PROC_BIND leaves on the main thread once an OpenMP runtime
+            n = min(n, a)    # (e.g. torch's) has started -- not a limit of the process
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if quota != "max":
