@@ -14,6 +14,7 @@
 #include "KokkosSparse_spmv.hpp"
 #include "KokkosSparse_spgemm.hpp"
 #include "KokkosSparse_IOUtils.hpp"
+#include "KokkosSparse_SortCrs.hpp"
 
 using device = Kokkos::Device<Kokkos::HIP, Kokkos::HIPSpace>;
 static int failures = 0;
@@ -301,8 +302,76 @@ void test_ioutils() {
   EXPECT(threw);
 }
 
+// sort_crs_matrix / sort_and_merge_matrix / transpose_matrix on an unsorted matrix with duplicate columns
+// (sparse/unit_test/Test_Sparse_SortCrs.hpp style: compare with a host std::sort / merge of the same rows)
+void test_sort_merge_transpose() {
+  using M = KokkosSparse::CrsMatrix<double, int, device, void, int>;
+  const int m = 120, n = 90;
+  std::mt19937 g(77);
+  std::vector<int> rm(m + 1, 0), ent; std::vector<double> val;
+  for (int i = 0; i < m; ++i) {
+    const int len = (int)(g() % 25);
+    for (int j = 0; j < len; ++j) { ent.push_back((int)(g() % n)); val.push_back((double)(1 + g() % 9)); }
+    rm[i + 1] = (int)ent.size();
+  }
+  auto upload = [&]() {
+    typename M::row_map_type::non_const_type d_rm("rm", m + 1);
+    typename M::index_type d_ent("ent", ent.size());
+    typename M::values_type d_val("val", val.size());
+    Kokkos::deep_copy(d_rm, Kokkos::View<int*, Kokkos::HostSpace>(rm.data(), rm.size()));
+    Kokkos::deep_copy(d_ent, Kokkos::View<int*, Kokkos::HostSpace>(ent.data(), ent.size()));
+    Kokkos::deep_copy(d_val, Kokkos::View<double*, Kokkos::HostSpace>(val.data(), val.size()));
+    return M("A", m, n, ent.size(), d_val, d_rm, d_ent);
+  };
+  // expected: stable sort per row, then merged
+  std::vector<int> s_ent(ent), mrm(m + 1, 0), ment; std::vector<double> s_val(val), mval;
+  for (int i = 0; i < m; ++i) {
+    std::vector<std::pair<int, int>> key;
+    for (int j = rm[i]; j < rm[i + 1]; ++j) key.emplace_back(ent[j], j);
+    std::stable_sort(key.begin(), key.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (size_t q = 0; q < key.size(); ++q) { s_ent[rm[i] + q] = key[q].first; s_val[rm[i] + q] = val[key[q].second]; }
+    for (int j = rm[i]; j < rm[i + 1]; ++j) {
+      if (j > rm[i] && s_ent[j] == s_ent[j - 1]) mval.back() += s_val[j];
+      else { ment.push_back(s_ent[j]); mval.push_back(s_val[j]); }
+    }
+    mrm[i + 1] = (int)ment.size();
+  }
+  M A = upload();
+  KokkosSparse::sort_crs_matrix(A);
+  {
+    auto e = Kokkos::create_mirror_view(A.graph.entries); Kokkos::deep_copy(e, A.graph.entries);
+    auto v = Kokkos::create_mirror_view(A.values);        Kokkos::deep_copy(v, A.values);
+    bool ok = true;
+    for (size_t j = 0; j < ent.size(); ++j) ok = ok && e(j) == s_ent[j] && v(j) == s_val[j];
+    EXPECT(ok);
+  }
+  M B = upload();
+  M C = KokkosSparse::sort_and_merge_matrix(B);
+  {
+    auto r = Kokkos::create_mirror_view(C.graph.row_map); Kokkos::deep_copy(r, C.graph.row_map);
+    auto e = Kokkos::create_mirror_view(C.graph.entries); Kokkos::deep_copy(e, C.graph.entries);
+    auto v = Kokkos::create_mirror_view(C.values);        Kokkos::deep_copy(v, C.values);
+    bool ok = (size_t)C.nnz() == ment.size();
+    for (int i = 0; i <= m && ok; ++i) ok = r(i) == mrm[i];
+    for (size_t j = 0; j < ment.size() && ok; ++j) ok = e(j) == ment[j] && v(j) == mval[j];
+    EXPECT(ok);
+  }
+  M T = KokkosSparse::Impl::transpose_matrix(C);
+  M TT = KokkosSparse::Impl::transpose_matrix(T);        // (C^T)^T == C for a sorted, merged matrix
+  {
+    auto r = Kokkos::create_mirror_view(TT.graph.row_map); Kokkos::deep_copy(r, TT.graph.row_map);
+    auto e = Kokkos::create_mirror_view(TT.graph.entries); Kokkos::deep_copy(e, TT.graph.entries);
+    auto v = Kokkos::create_mirror_view(TT.values);        Kokkos::deep_copy(v, TT.values);
+    bool ok = T.numRows() == n && T.numCols() == m && (size_t)TT.nnz() == ment.size();
+    for (int i = 0; i <= m && ok; ++i) ok = r(i) == mrm[i];
+    for (size_t j = 0; j < ment.size() && ok; ++j) ok = e(j) == ment[j] && v(j) == mval[j];
+    EXPECT(ok);
+  }
+}
+
 int main() {
   Kokkos::initialize();
+  test_sort_merge_transpose();
   test_ioutils();
   test_spmv_struct();
   test_github_issue_101();
