@@ -111,8 +111,16 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
                       const void* d_x, double beta, void* d_y, int vector_type, kkamd_stream_t stream);
 
 /* Expert knobs, the analogue of SPMVHandleImpl's public tuning members
- * (sparse/src/KokkosSparse_spmv_handle.hpp:243-252).  key: "kernel" (0 auto, 1 vector, 2 stream),
- * "lanes_per_row", "nnz_per_thread", "xcd_remap", "nontemporal", "mv_kernel".  Used by bench sweeps. */
+ * (sparse/src/KokkosSparse_spmv_handle.hpp:243-252); per plan, or as defaults for plans created later.
+ *   SpMV   "kernel" (0 auto, 1 no-analysis vector kernel), "lanes_per_row", "nnz_per_thread" (4 | 8 | 16, 0 = by size),
+ *          "stream_variant", "xcd_remap", "nontemporal",
+ *          "transient_min_knnz"  handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 never),
+ *          "explicit_transpose"  modes T/H through a transpose cached in the plan: 0 off (atomic scatter, default),
+ *                                1 refresh the transposed values every call, 2 caller promises constant values,
+ *          "explicit_transpose_min_knnz",
+ *          "mv_kernel", "mv_remap" (rank-2 kernels); "ablate", "lds_pad_kb" are measurement aids.
+ *   SpGEMM (kkamd_set_default only) "spgemm_win_bits" (columns per LDS bitmap pass), "spgemm_val_cap", "spgemm_val_shape",
+ *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_debug" (ablation bits). */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);
 int kkamd_set_default(const char* key, int value);
 
