@@ -27,19 +27,20 @@ def hubby(rng, n, ncols, base, nhubs, hublen, sort=True):
 while time.time() < t_end:
     rng = np.random.default_rng(seed0 + case); kind = case % 7; case += 1
     odt = np.int64 if rng.random() < 0.5 else np.int32
+    vdt = np.float32 if rng.random() < 0.3 else np.float64
     try:
         if kind == 0:      # SpGEMM, skewed: few long rows of A against hub rows of B
             n = int(rng.integers(50, 400)); k = int(rng.integers(3000, 60000))
             B = hubby(rng, n, k, int(rng.integers(2, 30)), int(rng.integers(1, 6)), int(rng.integers(500, 20000)))
             A = hubby(rng, int(rng.integers(3, 60)), n, int(rng.integers(1, 8)), int(rng.integers(0, 3)), n)
-            pc.check_spgemm(be, A, B, offset_dtype=odt)
+            pc.check_spgemm(be, A, B, offset_dtype=odt, value_dtype=vdt)
         elif kind == 1:    # SpGEMM, R-MAT square
             s = int(rng.integers(8, 14)); R = oracle.rmat(s, int(rng.integers(4, 24)), seed=int(rng.integers(1, 1 << 30)))
-            pc.check_spgemm(be, R, R, offset_dtype=odt)
+            pc.check_spgemm(be, R, R, offset_dtype=odt, value_dtype=vdt)
         elif kind == 2:    # SpGEMM, unsorted inputs with duplicates (B unsorted -> HBM accumulators for dense rows)
             A = pc.randomized(oracle.random_crs(int(rng.integers(20, 200)), 150, int(rng.integers(2, 40)), seed=int(rng.integers(1, 1 << 30))))
             B = hubby(rng, 150, int(rng.integers(2000, 30000)), int(rng.integers(2, 20)), 3, 6000, sort=False)
-            pc.check_spgemm(be, A, B, offset_dtype=odt)
+            pc.check_spgemm(be, A, B, offset_dtype=odt, value_dtype=vdt)
         elif kind == 3:    # SpMV on irregular rows, every algorithm / mode
             M = hubby(rng, int(rng.integers(100, 5000)), int(rng.integers(100, 5000)), int(rng.integers(1, 40)), int(rng.integers(0, 4)), 3000, sort=bool(rng.integers(0, 2)))
             for algo in (None, "SPMV_DEFAULT", "SPMV_MERGE_PATH"):
@@ -59,7 +60,7 @@ while time.time() < t_end:
             n = int(rng.integers(700, 7000)); k = int(rng.integers(5000, 50000))
             B = hubby(rng, n, k, int(rng.integers(2, 12)), int(rng.integers(0, 4)), int(rng.integers(300, 3000)))
             A = hubby(rng, int(rng.integers(2, 12)), n, 3, int(rng.integers(1, 4)), int(rng.integers(600, min(n, 6500))))
-            pc.check_spgemm(be, A, B, offset_dtype=odt)
+            pc.check_spgemm(be, A, B, offset_dtype=odt, value_dtype=vdt)
         else:              # spmv_struct, random grids
             nd = int(rng.integers(1, 4)); dims = tuple(int(rng.integers(3, 300 if nd == 1 else (150 if nd == 2 else 40))) for _ in range(nd))
             pc.check_spmv_struct(be, dims, 1 if nd == 1 else int(rng.integers(1, 3)), offset_dtype=odt, seed=case)
