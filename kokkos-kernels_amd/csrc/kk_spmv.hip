@@ -744,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv_kernel(int64_t nrows, const Of
 // 4 rows in flight and is bound by the texture path at ~13 % of the HBM roofline).  The wave's contiguous CSR
 // range is staged through its private LDS slice with 16-byte loads (4-aligned windows), no workgroup barrier.
 typedef int kk_i32x4 __attribute__((vector_size(16)));
-template <class OffT, class AT, class YT, int LPRW, int RPL>
+template <class OffT, class AT, class YT, int LPRW, int RPL, int CHW>
 __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ row_map,
                                                           const int32_t* __restrict__ entries,
                                                           const AT* __restrict__ values, const YT* __restrict__ X,
@@ -759,7 +759,10 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
   constexpr int RW  = kWave / LPRW;
   constexpr int SW  = RPL * LPRW;
   constexpr int NV2 = RPL / 2;           // 16-byte pieces per lane
-  constexpr int CHW = 256;               // nnz staged per wave per pass
+  // CHW = nnz staged per wave per pass (256 / 512 / 1024, picked from the average row length): a window smaller than the
+  // RW rows of the wave makes every wave run several passes with part of its lanes idle -- with 256 on the 27-pt matrix
+  // (16 rows x 27 = 432 nnz) the kernel issued twice the X load instructions it needed and the texture addresser was busy
+  // 95 % of the time (rocprof TA_BUSY).
   using AV = typename vec2<AT>::type;
   using XV = typename vec2<YT>::type;
   __shared__ AT s_val_all[kBlock / kWave][CHW];
@@ -778,26 +781,33 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
   int64_t rs = 0, re = 0;
   if (row < rowN) { rs = (int64_t)row_map[row]; re = (int64_t)row_map[row + 1]; }
   for (int64_t kk = 0; kk < nvec; kk += SW) {
-    const int64_t cA = kk + RPL * l;
-    const bool all_ok = cA + RPL <= nvec;
+    // piece q of lane l covers right-hand sides kk + q*2*LPRW + 2l and +1: the LPRW lanes of a row then read ONE contiguous
+    // 16*LPRW-byte run per load instruction (one 64 B sector of the X row for LPRW = 4) instead of 16 B out of every
+    // 32 B, which made each of the two instructions pull both sectors of the 128 B line through the L1
+    const int64_t cA = kk + 2 * l;
+    constexpr int64_t PQ = 2 * LPRW;                 // column distance between a lane's pieces
+    const bool all_ok = kk + SW <= nvec;
     YT acc[RPL];
     KK_UNROLL
     for (int q = 0; q < RPL; ++q) acc[q] = YT(0);
     for (int64_t c = lo; c < hi; c += CHW) {
       KK_WAVE_SYNC();
-      if (c + CHW <= nnz) {   // whole window inside the arrays (wave-uniform): three unguarded 16-byte loads per lane
-        const kk_i32x4 cc = *reinterpret_cast<const kk_i32x4*>(entries + c + lane64 * 4);
-        const AV va = *reinterpret_cast<const AV*>(values + c + lane64 * 2);
-        const AV vb = *reinterpret_cast<const AV*>(values + c + 128 + lane64 * 2);
-        const int cm = (remap & 2) ? 255 : -1;       // bench-only ablation: every X access hits 256 rows that stay in L1
-        s_col[lane64 * 4] = cc[0] & cm; s_col[lane64 * 4 + 1] = cc[1] & cm; s_col[lane64 * 4 + 2] = cc[2] & cm; s_col[lane64 * 4 + 3] = cc[3] & cm;
-        s_val[lane64 * 2] = va[0]; s_val[lane64 * 2 + 1] = va[1];
-        s_val[128 + lane64 * 2] = vb[0]; s_val[128 + lane64 * 2 + 1] = vb[1];
+      if (c + CHW <= nnz) {   // whole window inside the arrays (wave-uniform): three unguarded 16-byte loads per lane and 256 nnz
+        KK_UNROLL
+        for (int sub = 0; sub < CHW; sub += 256) {
+          const kk_i32x4 cc = *reinterpret_cast<const kk_i32x4*>(entries + c + sub + lane64 * 4);
+          const AV va = *reinterpret_cast<const AV*>(values + c + sub + lane64 * 2);
+          const AV vb = *reinterpret_cast<const AV*>(values + c + sub + 128 + lane64 * 2);
+          const int cm = (remap & 2) ? 255 : -1;       // bench-only ablation: every X access hits 256 rows that stay in L1
+          s_col[sub + lane64 * 4] = cc[0] & cm; s_col[sub + lane64 * 4 + 1] = cc[1] & cm; s_col[sub + lane64 * 4 + 2] = cc[2] & cm; s_col[sub + lane64 * 4 + 3] = cc[3] & cm;
+          s_val[sub + lane64 * 2] = va[0]; s_val[sub + lane64 * 2 + 1] = va[1];
+          s_val[sub + 128 + lane64 * 2] = vb[0]; s_val[sub + 128 + lane64 * 2 + 1] = vb[1];
+        }
       } else {
-        for (int q = 0; q < 4; ++q) {
-          const int64_t i = c + lane64 * 4 + q;
-          s_col[lane64 * 4 + q] = (i < nnz) ? entries[i] : 0;
-          s_val[lane64 * 4 + q] = (i < nnz) ? values[i] : AT(0);
+        for (int q = 0; q < CHW / 64; ++q) {
+          const int64_t i = c + lane64 * (CHW / 64) + q;
+          s_col[lane64 * (CHW / 64) + q] = (i < nnz) ? entries[i] : 0;
+          s_val[lane64 * (CHW / 64) + q] = (i < nnz) ? values[i] : AT(0);
         }
       }
       KK_WAVE_SYNC();
@@ -806,34 +816,36 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
       if (all_ok) {
         // batches of U entries: all U*NV2 16-byte X loads are issued before the first FMA consumes one
         // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> fma per entry: one load in flight per wave)
-        constexpr int U = 8 / NV2 >= 4 ? 8 / NV2 : 4;
+        // batches of 8, then 4, 2, 1 entries: inside a batch all X loads are issued before the first FMA consumes one
+        // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> fma per entry: one load in flight per wave)
+#define KK_MV_BATCH(UU)                                                                                                  \
+        {                                                                                                                \
+          YT v[UU]; XV xv[UU][NV2];                                                                                      \
+          KK_UNROLL                                                                                                      \
+          for (int u = 0; u < UU; ++u) {                                                                                 \
+            v[u] = (YT)s_val[i + u];                                                                                     \
+            const YT* xp = X + (int64_t)s_col[i + u] * xs0 + cA;                                                         \
+            KK_UNROLL                                                                                                    \
+            for (int q = 0; q < NV2; ++q) xv[u][q] = *reinterpret_cast<const XV*>(xp + q * PQ);                          \
+          }                                                                                                              \
+          KK_UNROLL                                                                                                      \
+          for (int u = 0; u < UU; ++u) {                                                                                 \
+            KK_UNROLL                                                                                                    \
+            for (int q = 0; q < NV2; ++q) { acc[2 * q] += v[u] * xv[u][q][0]; acc[2 * q + 1] += v[u] * xv[u][q][1]; }    \
+          }                                                                                                              \
+          i += UU;                                                                                                       \
+        }
         int i = a;
-        for (; i + U <= z; i += U) {
-          YT v[U]; XV xv[U][NV2];
-          KK_UNROLL
-          for (int u = 0; u < U; ++u) {
-            v[u] = (YT)s_val[i + u];
-            const XV* xp = reinterpret_cast<const XV*>(X + (int64_t)s_col[i + u] * xs0 + cA);
-            KK_UNROLL
-            for (int q = 0; q < NV2; ++q) xv[u][q] = xp[q];
-          }
-          KK_UNROLL
-          for (int u = 0; u < U; ++u) {
-            KK_UNROLL
-            for (int q = 0; q < NV2; ++q) { acc[2 * q] += v[u] * xv[u][q][0]; acc[2 * q + 1] += v[u] * xv[u][q][1]; }
-          }
-        }
-        for (; i < z; ++i) {
-          const YT v   = (YT)s_val[i];
-          const XV* xp = reinterpret_cast<const XV*>(X + (int64_t)s_col[i] * xs0 + cA);
-          KK_UNROLL
-          for (int q = 0; q < NV2; ++q) { const XV xq = xp[q]; acc[2 * q] += v * xq[0]; acc[2 * q + 1] += v * xq[1]; }
-        }
+        while (i + 8 <= z) KK_MV_BATCH(8)
+        if (i + 4 <= z) KK_MV_BATCH(4)
+        if (i + 2 <= z) KK_MV_BATCH(2)
+        if (i < z) KK_MV_BATCH(1)
+#undef KK_MV_BATCH
       } else {
         for (int i = a; i < z; ++i) {
           const YT v = (YT)s_val[i];
           const YT* xp = X + (int64_t)s_col[i] * xs0 + cA;
-          for (int q = 0; q < RPL; ++q) if (cA + q < nvec) acc[q] += v * xp[q];
+          for (int q = 0; q < RPL; ++q) { const int64_t cq = (q >> 1) * PQ + (q & 1); if (cA + cq < nvec) acc[q] += v * xp[cq]; }
         }
       }
     }
@@ -843,13 +855,16 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
         KK_UNROLL
         for (int q = 0; q < NV2; ++q) {
           XV out;
+          XV* yq = reinterpret_cast<XV*>(yp + q * PQ);
           if (beta == YT(0)) { out[0] = alpha * acc[2 * q]; out[1] = alpha * acc[2 * q + 1]; }
-          else { const XV old = reinterpret_cast<const XV*>(yp)[q]; out[0] = beta * old[0] + alpha * acc[2 * q]; out[1] = beta * old[1] + alpha * acc[2 * q + 1]; }
-          reinterpret_cast<XV*>(yp)[q] = out;
+          else { const XV old = *yq; out[0] = beta * old[0] + alpha * acc[2 * q]; out[1] = beta * old[1] + alpha * acc[2 * q + 1]; }
+          *yq = out;
         }
       } else {
-        for (int q = 0; q < RPL; ++q)
-          if (cA + q < nvec) { const YT r = alpha * acc[q]; yp[q * ys1] = (beta == YT(0)) ? r : beta * yp[q * ys1] + r; }
+        for (int q = 0; q < RPL; ++q) {
+          const int64_t cq = (q >> 1) * PQ + (q & 1);
+          if (cA + cq < nvec) { const YT r = alpha * acc[q]; yp[cq * ys1] = (beta == YT(0)) ? r : beta * yp[cq * ys1] + r; }
+        }
       }
     }
   }
@@ -1205,13 +1220,21 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
     if (Xr) {
       const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
       const int mv_remap = plan ? plan->tune.mv_remap : g_spmv_default.mv_remap;
-#define KK_MV2(L, R)                                                                                                     \
+#define KK_MV2C(L, R, C)                                                                                                 \
       do {                                                                                                               \
-        KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
+        KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R, C>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
                   0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, \
                   Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap);                                                        \
         KK_LAUNCH_CHECK();                                                                                               \
         return KKAMD_OK;                                                                                                 \
+      } while (0)
+      // staging window: the nnz of the wave's kWave/L rows (+15 % and the 4-alignment slack), rounded up to 256 / 512 / 1024
+#define KK_MV2(L, R)                                                                                                     \
+      do {                                                                                                               \
+        const int64_t need = (int64_t)(1.15 * (double)(kWave / L) * (double)A->nnz / (double)A->num_rows) + 4;            \
+        if (need <= 256) KK_MV2C(L, R, 256);                                                                              \
+        if (need <= 512) KK_MV2C(L, R, 512);                                                                              \
+        KK_MV2C(L, R, 1024);                                                                                              \
       } while (0)
       if (mvk == 3) { if (nvec >= 12) KK_MV2(8, 2); }                      // A/B: 8 lanes x 2 RHS
       if (mvk == 4) { if (nvec >= 12) KK_MV2(2, 4); }                      // A/B: 2 lanes x 4 RHS (strips of 8)
@@ -1219,6 +1242,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
       if (nvec >= 6) KK_MV2(2, 4);
       if (nvec >= 3) KK_MV2(2, 2);
       KK_MV2(1, 2);
+#undef KK_MV2C
 #undef KK_MV2
     }
   }
