@@ -122,11 +122,12 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
   __shared__ YT s_x[NL][R + 2];
   __shared__ YT s_part[R];
   const int t = threadIdx.x;
-  const int64_t pencil = blockIdx.x / chunks_per_pencil;
-  const int chunk      = (int)(blockIdx.x % chunks_per_pencil);
+  // 32-bit index arithmetic on purpose: 64-bit divisions cost ~100 scalar instructions each at the start of every wave
+  const unsigned pencil = blockIdx.x / (unsigned)chunks_per_pencil;
+  const int chunk       = (int)(blockIdx.x - pencil * (unsigned)chunks_per_pencil);
   int64_t j = 0, k = 0;
-  if (NDIM == 2) j = pencil + 1;
-  else if (NDIM == 3) { k = pencil / (nj - 2) + 1; j = pencil % (nj - 2) + 1; }
+  if (NDIM == 2) j = (int64_t)pencil + 1;
+  else if (NDIM == 3) { const unsigned njm = (unsigned)(nj - 2), kq = pencil / njm; k = (int64_t)kq + 1; j = (int64_t)(pencil - kq * njm) + 1; }
   const int64_t i0   = 1 + (int64_t)chunk * R;                 // first interior i of this chunk
   const int nr       = (int)((ni - 1 - i0 < R) ? ni - 1 - i0 : R);
   const int64_t row0 = (k * nj + j) * ni + i0;
