@@ -412,6 +412,84 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   }
 }
 
+// Late-gather variant (stream_variant 5): the tile's (value, column) pairs are staged in LDS as they are, and x is
+// gathered in the ROW phase -- the lanes that sum a row read its entries back from LDS and fetch x there.  With one
+// lane per row, the lanes of a quad then gather the k-th entries of four CONSECUTIVE rows; on stencil-like matrices
+// those are adjacent columns, i.e. one cache line and one L1 tag look-up per quad instead of the ~2 the quad-dealt
+// layout of the default kernel needs (the tag look-up rate is what bounds the default kernel: 5.8e8 look-ups per
+// launch on the 27-pt 300^3 matrix, ~1 per clock per CU).
+template <class AT, class YT>
+__device__ __forceinline__ YT strided_lds_dot(const AT* s_val, const int* s_col, const YT* __restrict__ x, int i0, int i1, int lane, int G) {
+  YT s0 = YT(0), s1 = YT(0), s2 = YT(0), s3 = YT(0);
+  int i = i0 + lane;
+  const int G2 = 2 * G, G3 = 3 * G, G4 = 4 * G;
+  for (; i + G3 < i1; i += G4) {
+    const int ca = s_col[i], cb = s_col[i + G], cc = s_col[i + G2], cd = s_col[i + G3];
+    const YT xa = x[ca], xb = x[cb], xc = x[cc], xd = x[cd];
+    s0 += (YT)s_val[i] * xa; s1 += (YT)s_val[i + G] * xb; s2 += (YT)s_val[i + G2] * xc; s3 += (YT)s_val[i + G3] * xd;
+  }
+  for (; i < i1; i += G) s0 += (YT)s_val[i] * x[s_col[i]];
+  return (s0 + s1) + (s2 + s3);
+}
+template <class OffT, class AT, class YT, int NPT, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_stream6_kernel(int64_t nnz, const OffT* __restrict__ row_map,
+                                                              const int32_t* __restrict__ entries,
+                                                              const AT* __restrict__ values, const YT* __restrict__ x,
+                                                              YT* __restrict__ y, YT alpha, YT beta,
+                                                              const int32_t* __restrict__ blk_info,
+                                                              YT* __restrict__ carry_head, YT* __restrict__ carry_tail, int remap) {
+  constexpr int TILE  = kBlock * NPT;
+  constexpr int STEPS = NPT / 2;
+  constexpr int SPAN  = kBlock * 2;
+  __shared__ AT s_val[TILE];
+  __shared__ int s_col[TILE];
+  const int t     = threadIdx.x;
+  const int64_t b = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t s = b * TILE;
+  const bool full = (s + TILE <= nnz);
+  const int64_t e = full ? s + TILE : nnz;
+  const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
+  AT v0[STEPS], v1[STEPS];
+  int c0[STEPS], c1[STEPS];
+  if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
+  else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
+  const int64_t ra    = info0 & 0x7fffffff;
+  const int64_t rb    = info1 & 0x7fffffff;
+  const int has_head  = (info0 >> 31) & 1;
+  const int64_t nv    = (rb - ra) + has_head;
+  int G = 1;
+  while (G < kWave && nv * (G * 2) <= kBlock) G *= 2;
+  const int lane = t & (G - 1), grp = t / G, ngrp = kBlock / G;
+  bool valid = grp < nv;
+  int64_t r  = ra + grp - has_head;
+  int64_t rs = 0, re = 0;
+  if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int li = k * SPAN + t * 2;
+    s_val[li] = v0[k]; s_val[li + 1] = v1[k];
+    s_col[li] = c0[k] < 0 ? 0 : c0[k]; s_col[li + 1] = c1[k] < 0 ? 0 : c1[k];     // padding entries carry value 0
+  }
+  __syncthreads();
+  for (int64_t base = 0; base < nv; base += ngrp) {
+    if (base > 0) {
+      valid = (base + grp) < nv;
+      r     = ra + base + grp - has_head;
+      if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
+    }
+    const bool is_head  = r < ra;
+    const bool complete = !is_head && re <= e;
+    const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
+    YT sum = valid ? strided_lds_dot<AT, YT>(s_val, s_col, x, i0, i1, lane, G) : YT(0);
+    sum = group_sum(sum, G);
+    if (valid && lane == 0) {
+      if (is_head) carry_head[b] = sum;
+      else if (!complete) carry_tail[b] = sum;
+      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
+    }
+  }
+}
+
 // Wave-private variant: every 64-lane wave owns its own tile of 64*NPT nnz and its own slice of LDS, so the
 // kernel contains no workgroup barrier at all -- a wave's load -> gather -> LDS -> reduce chain never waits
 // for its three siblings, and a CU interleaves 32 independent chains instead of 8.  Same descriptor / carry
@@ -964,6 +1042,10 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
               (const int32_t*)p->d_blk_row, (const int64_t*)p->d_uoff, (const int32_t*)p->d_ucols, (const uint16_t*)p->d_lidx,
               ch, ct);
+  } else if (variant == 5) {
+    KK_LAUNCH((spmv_stream6_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
   } else if (variant == 3) {
     KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, false>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,

@@ -38,7 +38,7 @@ def test_stream_kernel_tilings(be, npt):
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"nnz_per_thread": npt, "xcd_remap": 0, "nontemporal": 0})
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 def test_stream_variants(be, variant):
     # every kept variant of the planned kernel (A/B knob "stream_variant"), incl. the tile-local column structure (4)
     mats = [oracle.laplace3d("FE", 12, 11, 10), oracle.random_crs(900, 880, 13, variance=9, seed=2), oracle.random_crs(2000, 2000, 25, variance=5, seed=3, bandwidth=40)]
