@@ -118,7 +118,7 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *          "explicit_transpose"  modes T/H through a transpose cached in the plan: 0 off (atomic scatter, default),
  *                                1 refresh the transposed values every call, 2 caller promises constant values,
  *          "explicit_transpose_min_knnz",
- *          "mv_kernel", "mv_remap" (rank-2 kernels); "ablate", "lds_pad_kb" are measurement aids.
+ *          "mv_kernel", "mv_remap" (rank-2 kernels); "struct_remap" (kkamd_spmv_struct, global only); "ablate", "lds_pad_kb" are measurement aids.
  *   SpGEMM (kkamd_set_default only) "spgemm_win_bits" (columns per LDS bitmap pass), "spgemm_val_cap", "spgemm_val_shape",
  *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_debug" (ablation bits). */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);

@@ -53,6 +53,8 @@ int parse_mode(char mode, bool* trans);
 
 // knobs whose key starts with "spgemm_" (kk_spgemm.hip); reached through kkamd_set_default
 int spgemm_set_default(const char* key, int value);
+// kk_spmv_struct.hip: 1 = XCD-contiguous workgroup order in the interior kernel (knob "struct_remap")
+extern int g_struct_remap;
 
 template <class T> struct scalar_tag;
 template <> struct scalar_tag<float>  { static constexpr int value = KKAMD_F32; };

@@ -32,6 +32,8 @@ struct StencilDesc {
   int64_t line_off[kMaxLines]; // line -> offset of its row relative to the current row (multiple of ni)
 };
 
+int g_struct_remap = 0;
+
 static int make_stencil(int stencil_type, int ndim, const int64_t* st, StencilDesc* d) {
   d->ndim = ndim; d->ni = st[0]; d->nj = ndim > 1 ? st[1] : 1; d->nk = ndim > 2 ? st[2] : 1;
   const int64_t ni = d->ni, nj = d->nj;
@@ -114,7 +116,7 @@ template <class OffT, class AT, class YT, int NDIM, int ST, int R>
 __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni, int64_t nj, int chunks_per_pencil,
                                                                       const OffT* __restrict__ rm, const AT* __restrict__ val,
                                                                       const YT* __restrict__ x, YT* __restrict__ y, YT alpha,
-                                                                      YT beta) {
+                                                                      YT beta, int remap) {
   using St = Stencil<NDIM, ST>;
   constexpr int S = St::S, NL = St::NL, NT = 2 * R;
   constexpr int HS  = (S + 1) / 2;                             // first stencil half
@@ -123,8 +125,13 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
   __shared__ YT s_part[R];
   const int t = threadIdx.x;
   // 32-bit index arithmetic on purpose: 64-bit divisions cost ~100 scalar instructions each at the start of every wave
-  const unsigned pencil = blockIdx.x / (unsigned)chunks_per_pencil;
-  const int chunk       = (int)(blockIdx.x - pencil * (unsigned)chunks_per_pencil);
+  unsigned bid = blockIdx.x;
+  if (remap) {  // XCD-contiguous order (knob struct_remap): workgroup b runs on XCD b % 8, give each XCD one slab of the grid
+    const unsigned q = gridDim.x / kNumXcd, rem = gridDim.x % kNumXcd, xc = bid % kNumXcd;
+    bid = xc * q + (xc < rem ? xc : rem) + bid / kNumXcd;
+  }
+  const unsigned pencil = bid / (unsigned)chunks_per_pencil;
+  const int chunk       = (int)(bid - pencil * (unsigned)chunks_per_pencil);
   int64_t j = 0, k = 0;
   if (NDIM == 2) j = (int64_t)pencil + 1;
   else if (NDIM == 3) { const unsigned njm = (unsigned)(nj - 2), kq = pencil / njm; k = (int64_t)kq + 1; j = (int64_t)(pencil - kq * njm) + 1; }
@@ -246,9 +253,9 @@ static int spmv_struct_typed(const StencilDesc& d, const kkamd_crs_t* A, double 
 #define KK_STRUCT_LAUNCH(ND, STT)                                                                                          \
   do {                                                                                                                     \
     if (use64) KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 64>), (unsigned)(pencils * cpp), 128, 0, st, ni, nj, \
-                         (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta);                                                    \
+                         (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap);                                                    \
     else KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 128>), (unsigned)(pencils * cpp), 256, 0, st, ni, nj,      \
-                   (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta);                                                          \
+                   (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap);                                                          \
   } while (0)
     if (d.ndim == 1) KK_STRUCT_LAUNCH(1, 1);
     else if (d.ndim == 2 && d.S == 5) KK_STRUCT_LAUNCH(2, 1);
