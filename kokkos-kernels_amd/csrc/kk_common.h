@@ -55,6 +55,7 @@ int parse_mode(char mode, bool* trans);
 int spgemm_set_default(const char* key, int value);
 // kk_spmv_struct.hip: 1 = XCD-contiguous workgroup order in the interior kernel (knob "struct_remap")
 extern int g_struct_remap;
+extern int g_struct_lds_pad_kb;  // measurement aid: extra dynamic LDS per interior workgroup (lowers occupancy)
 
 template <class T> struct scalar_tag;
 template <> struct scalar_tag<float>  { static constexpr int value = KKAMD_F32; };

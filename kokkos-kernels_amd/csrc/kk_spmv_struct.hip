@@ -3,7 +3,8 @@
 //
 // Reference (sparse/impl/KokkosSparse_spmv_struct_impl.hpp): interior grid points never read entries(): the column of
 // the idx-th value of an interior row is row + columnOffsets(idx) (:236-242, :270-278, :308-320, :350-360, :392-420),
-// y(row) = beta*y(row) + alpha*sum (:264); exterior points take the ordinary CRS row (:508-618); modes T/H ignore the
+// y(row) = beta*y(row) + alpha*sum (:264; here y is not read at all when beta == 0, the BLAS convention the reference's
+// CRS kernels follow -- the result differs from :264 only where the incoming y holds Inf/NaN); exterior points take the ordinary CRS row (:508-618); modes T/H ignore the
 // structure altogether (:733-773).  On a GPU the reference maps ONE interior row to a few vector lanes and gathers x
 // through the texture path, like its CRS kernel.
 //
@@ -33,6 +34,7 @@ struct StencilDesc {
 };
 
 int g_struct_remap = 0;
+int g_struct_lds_pad_kb = 0;
 
 static int make_stencil(int stencil_type, int ndim, const int64_t* st, StencilDesc* d) {
   d->ndim = ndim; d->ni = st[0]; d->nj = ndim > 1 ? st[1] : 1; d->nk = ndim > 2 ? st[2] : 1;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
   const int t = threadIdx.x;
   // 32-bit index arithmetic on purpose: 64-bit divisions cost ~100 scalar instructions each at the start of every wave
   unsigned bid = blockIdx.x;
-  if (remap) {  // XCD-contiguous order (knob struct_remap): workgroup b runs on XCD b % 8, give each XCD one slab of the grid
+  if (remap & 1) {  // XCD-contiguous order (knob struct_remap): workgroup b runs on XCD b % 8, give each XCD one slab of the grid
     const unsigned q = gridDim.x / kNumXcd, rem = gridDim.x % kNumXcd, xc = bid % kNumXcd;
     bid = xc * q + (xc < rem ? xc : rem) + bid / kNumXcd;
   }
@@ -140,13 +142,17 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
   const int64_t row0 = (k * nj + j) * ni + i0;
   const int r = t & (R - 1), h = t / R;
   // everything that does not depend on row_map is requested first: the x lines and the old y
-  YT xl[NL];
+  // the NL lines of R+2 x entries are dealt flat over the workgroup (element e -> line e / (R+2)), so every load
+  // instruction runs with full waves: ceil(NL*(R+2) / 2R) loads per work-item instead of NL with R+2 active lanes
+  constexpr int XW = R + 2, XN = NL * XW, XU = (XN + NT - 1) / NT;
+  YT xl[XU];
   KK_UNROLL
-  for (int l = 0; l < NL; ++l) {
+  for (int u = 0; u < XU; ++u) {
+    const int e = u * NT + t, l = e / XW, pos = e - l * XW;
     const int64_t off = ((int64_t)St::dk(l) * nj + St::dj(l)) * ni;
-    xl[l] = (t < nr + 2) ? x[row0 - 1 + off + t] : YT(0);
+    xl[u] = (e < XN && pos < nr + 2 && !(remap & 8)) ? x[row0 - 1 + off + pos] : YT(0);
   }
-  YT yold = (h == 0 && r < nr) ? y[row0 + r] : YT(0);
+  YT yold = (h == 0 && r < nr && beta != YT(0)) ? y[row0 + r] : YT(0);     // beta == 0: y is write-only (NaN-safe)
   const long long v0    = (long long)rm[row0];
   const bool contiguous = (long long)rm[row0 + nr] - v0 == (long long)nr * S;     // rows of exactly S entries each
   if (contiguous) {
@@ -166,10 +172,11 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
     for (int u = 0; u < VP2; ++u) { const int q = u * NT + t; if (q < (R * S + 1) / 2) { s_v[2 * q] = vv[u].x; if (2 * q + 1 < R * S) s_v[2 * q + 1] = vv[u].y; } }
   }
   KK_UNROLL
-  for (int l = 0; l < NL; ++l) if (t < R + 2) s_x[l][t] = xl[l];
+  for (int u = 0; u < XU; ++u) { const int e = u * NT + t; if (e < XN) (&s_x[0][0])[e] = xl[u]; }
   __syncthreads();
   YT sum = YT(0);
-  if (r < nr) {
+  if (remap & 16) sum = (YT)s_v[t];
+  else if (r < nr) {
     if (contiguous) {
       if (h == 0) {
         KK_UNROLL
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
   }
   if (h == 1) s_part[r] = sum;
   __syncthreads();
-  if (h == 0 && r < nr) y[row0 + r] = beta * yold + alpha * (sum + s_part[r]);
+  if (h == 0 && r < nr && (!(remap & 2) || sum == YT(1.2345e30))) y[row0 + r] = (beta == YT(0)) ? alpha * (sum + s_part[r]) : beta * yold + alpha * (sum + s_part[r]);
 }
 
 // exterior rows, 8 lanes per CRS row.  e -> row: bottom plane, then for every middle plane the j = 0 line, the
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(kBlock) void spmv_struct_exterior_kernel(StencilDes
     for (int64_t q = (int64_t)rm[row] + lane; q < (int64_t)rm[row + 1]; q += 8) sum += (YT)val[q] * x[ent[q]];
   }
   sum = group_sum(sum, 8);
-  if (e < num_ext && lane == 0) y[row] = beta * y[row] + alpha * sum;
+  if (e < num_ext && lane == 0) y[row] = (beta == YT(0)) ? alpha * sum : beta * y[row] + alpha * sum;
 }
 
 template <class OffT, class AT, class YT>
@@ -252,9 +259,9 @@ static int spmv_struct_typed(const StencilDesc& d, const kkamd_crs_t* A, double 
     num_int = interior * pencils;
 #define KK_STRUCT_LAUNCH(ND, STT)                                                                                          \
   do {                                                                                                                     \
-    if (use64) KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 64>), (unsigned)(pencils * cpp), 128, 0, st, ni, nj, \
+    if (use64) KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 64>), (unsigned)(pencils * cpp), 128, (size_t)g_struct_lds_pad_kb * 1024, st, ni, nj, \
                          (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap);                                                    \
-    else KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 128>), (unsigned)(pencils * cpp), 256, 0, st, ni, nj,      \
+    else KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 128>), (unsigned)(pencils * cpp), 256, (size_t)g_struct_lds_pad_kb * 1024, st, ni, nj,      \
                    (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap);                                                          \
   } while (0)
     if (d.ndim == 1) KK_STRUCT_LAUNCH(1, 1);

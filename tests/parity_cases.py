@@ -191,3 +191,12 @@ def check_spmv_struct(be, dims, stencil_type, mode="N", offset_dtype=np.int32, v
         ok, err = fspmv_ok(exp, got, max(tol, 1e-300))
         assert ok, "spmv_struct mismatch dims=%s stencil=%d mode=%s alpha=%g beta=%g: max err %g > tol %g" % (
             dims, stencil_type, mode, alpha, beta, err, tol)
+    if not trans:
+        # beta == 0 overwrites y: the incoming y (here all NaN) is never read (BLAS convention of the CRS kernels)
+        xd = be.from_numpy(x.reshape(-1, 1) if rank2 else x)
+        yd = be.from_numpy(np.full(y0.reshape(-1, 1).shape if rank2 else y0.shape, np.nan, dtype=vec_dtype))
+        kk.spmv_struct(mode, stencil_type, dims, 1.0, A, xd, 0.0, yd)
+        got = be.to_numpy(yd).astype(np.float64).reshape(-1)
+        exp = oracle.spmv_struct(mode, stencil_type, dims, Ao, 1.0, x.astype(np.float64), 0.0, np.zeros(nout))
+        ok, err = fspmv_ok(exp, got, max(oracle.spmv_max_error(A0, 1.0, 0.0, max_val=max_val) * eps_scale, 1e-300))
+        assert ok and np.isfinite(got).all(), "spmv_struct beta=0 must not read y (dims=%s stencil=%d)" % (dims, stencil_type)
