@@ -89,7 +89,7 @@ def c2_c3():
     ys = torch.zeros_like(y)
     mean, mn = gpu_time(lambda: kk.spmv_struct("N", 2, (n, n, n), 1.0, A, x, 0.0, ys), iters=100)
     kk.spmv(h, "N", 1.0, A, x, 0.0, y)
-    by_s = nnz * 8 + (nr + 1) * 4 + nr * 8 + 2 * nr * 8          # values + row_map + x + y read and written (beta*y is evaluated)
+    by_s = nnz * 8 + (nr + 1) * 4 + nr * 8 + nr * 8              # values + row_map + x + y written (beta = 0: y is not read)
     emit(config="C2-struct", device="1x MI355X", rows=nr, nnz=nnz, ms=mean, ms_min=mn, GFLOPs=2 * nnz / mean / 1e6, GBps=by_s / mean / 1e6,
          frac_of_8TBps=by_s / mean / 1e6 / 8000, crs_equivalent_GBps=spmv_bytes(nnz, nr, nr) / mean / 1e6,
          max_abs_diff_vs_crs_kernel=float((ys - y).abs().max().item()))
