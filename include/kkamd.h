@@ -105,15 +105,16 @@ int kkamd_spmv_mv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, doub
  * sparse/impl/KokkosSparse_spmv_struct_impl.hpp:640-705): y := alpha*op(A)*x + beta*y for a matrix that comes from a
  * 3-pt (1-D), 5-/9-pt (2-D, stencil_type 1 = FD / 2 = FE) or 7-/27-pt (3-D) stencil on a structure[0] x structure[1] x
  * structure[2] grid, rows numbered i fastest.  Interior rows never read entries(): their idx-th value multiplies
- * x(row + offset(idx)); exterior rows take the CRS row.  Like the reference it evaluates beta*y + alpha*sum for every
- * row (also when beta == 0) and modes 'T'/'H' ignore the structure.  structure is a HOST array of ndim extents. */
+ * x(row + offset(idx)); exterior rows take the CRS row.  y is not read when beta == 0 (BLAS convention; the reference's
+ * functor evaluates beta*y + alpha*sum also then) and modes 'T'/'H' ignore the structure.  structure is a HOST array of ndim extents. */
 int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndim, const int64_t* structure, double alpha,
                       const void* d_x, double beta, void* d_y, int vector_type, kkamd_stream_t stream);
 
 /* Expert knobs, the analogue of SPMVHandleImpl's public tuning members
  * (sparse/src/KokkosSparse_spmv_handle.hpp:243-252); per plan, or as defaults for plans created later.
  *   SpMV   "kernel" (0 auto, 1 no-analysis vector kernel), "lanes_per_row", "nnz_per_thread" (4 | 8 | 16, 0 = by size),
- *          "stream_variant", "xcd_remap", "nontemporal",
+ *          "stream_variant" (1 default; 6 = 16-bit window codes for the columns, built by the analysis when every tile's
+ *                            columns fit 16 windows of 4096, else the plan behaves like 1), "xcd_remap", "nontemporal",
  *          "transient_min_knnz"  handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 never),
  *          "explicit_transpose"  modes T/H through a transpose cached in the plan: 0 off (atomic scatter, default),
  *                                1 refresh the transposed values every call, 2 caller promises constant values,
@@ -123,6 +124,9 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_debug" (ablation bits). */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);
 int kkamd_set_default(const char* key, int value);
+/* What the analysis of a plan produced: "tile" (nnz per workgroup, 0 = no tiling), "tiles", "window_codes" (1 if the
+ * 16-bit column codes of stream_variant 6 are in use), "transpose_cached". */
+int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);
 
 /* ------------------------------------------------------------------------------------------------
  * SpGEMM.  Replaces Impl::SPGEMM_SYMBOLIC<...>::spgemm_symbolic and

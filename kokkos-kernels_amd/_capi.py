@@ -9,7 +9,7 @@ SPMV_DEFAULT, SPMV_FAST_SETUP, SPMV_NATIVE, SPMV_MERGE_PATH, SPMV_NATIVE_MERGE_P
 
 EXPORTS = [
     "kkamd_last_error", "kkamd_version", "kkamd_device_info", "kkamd_spmv_plan_create", "kkamd_spmv_plan_destroy",
-    "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_sort_and_merge", "kkamd_transpose", "kkamd_spmv_plan_set", "kkamd_set_default", "kkamd_spgemm_create",
+    "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_sort_and_merge", "kkamd_transpose", "kkamd_spmv_plan_set", "kkamd_spmv_plan_query", "kkamd_set_default", "kkamd_spgemm_create",
     "kkamd_spgemm_destroy", "kkamd_spgemm_symbolic", "kkamd_spgemm_numeric", "kkamd_spgemm_get", "kkamd_sort_crs",
     "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows", "kkamd_bench_read",
 ]
@@ -41,6 +41,7 @@ def bind(lib):
     lib.kkamd_spmv_struct.argtypes = [C.POINTER(CrsDesc), C.c_char, ci, ci, C.POINTER(i64), dbl, vp, dbl, vp, ci, vp]
     lib.kkamd_spmv_plan_set.argtypes = [vp, C.c_char_p, ci]
     lib.kkamd_set_default.argtypes = [C.c_char_p, ci]
+    lib.kkamd_spmv_plan_query.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     lib.kkamd_spgemm_create.argtypes = [C.POINTER(vp)]
     lib.kkamd_spgemm_destroy.argtypes = [vp]
     lib.kkamd_spgemm_symbolic.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, ci, C.POINTER(i64), vp]

@@ -68,6 +68,10 @@ struct kkamd_spmv_plan {
   int32_t* d_ucols = nullptr;    // distinct columns of every tile, ascending within a tile
   uint16_t* d_lidx = nullptr;    // [nnz] position of each nnz's column in its tile's list
   int64_t ucols_total = 0;
+  // window codes (stream_variant 6): per tile up to 16 column windows of 4096 and, per nnz, a 16-bit code
+  // (window << 12 | column - window base), stored in the order the kernel's work-items consume them
+  uint16_t* d_wcode = nullptr;   // [nblocks * tile]
+  int32_t* d_wbase = nullptr;    // [nblocks * 16] window bases, ascending
   // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
   void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr;
   kkamd_spmv_plan* t_plan = nullptr;
@@ -141,6 +145,8 @@ __global__ void spmv_plan_kernel(int64_t nrows, const OffT* __restrict__ row_map
 typedef double kk_f64x2 __attribute__((vector_size(16)));
 typedef float  kk_f32x2 __attribute__((vector_size(8)));
 typedef int    kk_i32x2 __attribute__((vector_size(8)));
+typedef unsigned kk_u32x2 __attribute__((vector_size(8)));
+typedef unsigned kk_u32x4 __attribute__((vector_size(16)));
 template <class T> struct vec2;
 template <> struct vec2<double> { using type = kk_f64x2; };
 template <> struct vec2<float>  { using type = kk_f32x2; };
@@ -168,6 +174,108 @@ __device__ __forceinline__ void load_tile(const AT* __restrict__ values, const i
       v0[k] = values[idx]; c0[k] = entries[idx]; v1[k] = AT(0); c1[k] = c0[k];
     } else {
       v0[k] = v1[k] = AT(0); c0[k] = c1[k] = -1;
+    }
+  }
+}
+
+// Window codes (stream_variant 6).  The column indices are 4 of the 12 bytes per nonzero the kernel streams.  On
+// matrices whose tiles touch few column neighbourhoods (stencils, banded and block-structured matrices) a tile's columns
+// fit into <= 16 windows of 4096 consecutive columns; the plan then keeps, per nonzero, a 16-bit code = window << 12 |
+// (column - window base) and per tile the 16 window bases: 10 instead of 12 bytes per nonzero.  Codes are stored in the
+// order work-item t consumes them (its 2*STEPS codes are contiguous: one or two 16-byte loads instead of STEPS 8-byte
+// ones), the bases sit in lanes 0-15 of every wave and are fetched with one lane permute per nonzero.
+constexpr int kWinBits = 12, kWinCount = 16;
+
+template <int NPT>
+__global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const int32_t* __restrict__ entries,
+                                                           uint16_t* __restrict__ wcode, int32_t* __restrict__ wbase,
+                                                           int* __restrict__ fail) {
+  constexpr int TILE = kBlock * NPT, STEPS = NPT / 2, SPAN = kBlock * 2;
+  __shared__ int s_base[kWinCount];
+  __shared__ int s_min;
+  const int t = threadIdx.x;
+  const int64_t b = blockIdx.x, s = b * TILE;
+  int c[NPT];
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t idx = s + (int64_t)k * SPAN + t * 2;
+    c[2 * k]     = idx < nnz ? entries[idx] : -1;
+    c[2 * k + 1] = idx + 1 < nnz ? entries[idx + 1] : -1;
+  }
+  // greedy cover of the tile's columns, left to right: the next window starts at the smallest column not covered yet
+  long long bound = 0;                                       // columns < bound are covered
+  for (int w = 0; w < kWinCount; ++w) {                      // workgroup-uniform trip count
+    if (t == 0) s_min = INT_MAX;
+    __syncthreads();
+    int m = INT_MAX;
+    KK_UNROLL
+    for (int k = 0; k < NPT; ++k) if (c[k] >= 0 && (long long)c[k] >= bound && c[k] < m) m = c[k];
+    if (m != INT_MAX) atomicMin(&s_min, m);
+    __syncthreads();
+    const int base = s_min;
+    if (t == 0) s_base[w] = (base == INT_MAX) ? (w ? s_base[w - 1] : 0) : base;
+    if (base != INT_MAX) bound = (long long)base + (1 << kWinBits);
+    __syncthreads();
+  }
+  bool uncovered = false;
+  KK_UNROLL
+  for (int k = 0; k < NPT; ++k) uncovered |= (c[k] >= 0 && (long long)c[k] >= bound);
+  if (uncovered) atomicAdd(fail, 1);
+  if (t < kWinCount) wbase[b * kWinCount + t] = s_base[t];
+  uint16_t* out = wcode + s + (int64_t)t * NPT;
+  KK_UNROLL
+  for (int k = 0; k < NPT; ++k) {
+    int w = 0;
+    for (int q = 1; q < kWinCount; ++q) if (s_base[q] <= c[k] && s_base[q] > s_base[q - 1]) w = q;
+    const int d = c[k] - s_base[w];
+    out[k] = (c[k] >= 0 && d >= 0 && d < (1 << kWinBits)) ? (uint16_t)((w << kWinBits) | d) : (uint16_t)0;
+  }
+}
+
+template <class AT, int STEPS, bool FULL>
+__device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, const uint16_t* __restrict__ wcode,
+                                              const int32_t* __restrict__ wbase, int64_t b, int64_t ts, int64_t te, int t,
+                                              AT (&v0)[STEPS], AT (&v1)[STEPS], int (&c0)[STEPS], int (&c1)[STEPS]) {
+  using AV = typename vec2<AT>::type;
+  constexpr int SPAN = kBlock * 2, NPT = 2 * STEPS;
+  const unsigned* cw = reinterpret_cast<const unsigned*>(wcode + ts + (int64_t)t * NPT);   // 4*STEPS bytes, aligned
+  unsigned w[STEPS];
+  if (STEPS % 4 == 0) {
+    KK_UNROLL
+    for (int k = 0; k < STEPS; k += 4) {
+      const kk_u32x4 q = *reinterpret_cast<const kk_u32x4*>(cw + k);
+      w[k] = q[0]; w[k + 1] = q[1]; w[k + 2] = q[2]; w[k + 3] = q[3];
+    }
+  } else {
+    KK_UNROLL
+    for (int k = 0; k < STEPS; k += 2) {
+      const kk_u32x2 q = *reinterpret_cast<const kk_u32x2*>(cw + k);
+      w[k] = q[0]; w[k + 1] = q[1];
+    }
+  }
+  const int basereg = wbase[b * kWinCount + (t & (kWinCount - 1))];
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t idx = ts + (int64_t)k * SPAN + t * 2;
+    if (FULL || idx + 1 < te) {
+      const AV vv = *reinterpret_cast<const AV*>(values + idx);
+      v0[k] = vv[0]; v1[k] = vv[1];
+    } else if (idx < te) {
+      v0[k] = values[idx]; v1[k] = AT(0);
+    } else {
+      v0[k] = v1[k] = AT(0);
+    }
+  }
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t idx = ts + (int64_t)k * SPAN + t * 2;
+    const unsigned lo = w[k] & 0xffffu, hi = w[k] >> 16;
+    const int b0 = __shfl(basereg, (int)(lo >> kWinBits), 64), b1 = __shfl(basereg, (int)(hi >> kWinBits), 64);
+    c0[k] = b0 + (int)(lo & ((1u << kWinBits) - 1));
+    c1[k] = b1 + (int)(hi & ((1u << kWinBits) - 1));
+    if (!FULL) {
+      if (idx >= te) c0[k] = c1[k] = -1;
+      else if (idx + 1 >= te) c1[k] = c0[k];
     }
   }
 }
@@ -342,14 +450,16 @@ template <class YT> __device__ __forceinline__ YT strided_lds_sum(const YT* prod
 // row_map[r], row_map[r+1] are requested together with the x gathers -- so a tile sees two memory
 // latencies (stream, then gather+bounds) instead of five (stream, gather, blk_row, row_map[ra], bounds).
 // After the barrier the row reduction touches only LDS and registers.
-template <class OffT, class AT, class YT, int NPT, bool NT, bool QP>
+template <class OffT, class AT, class YT, int NPT, bool NT, bool QP, bool WIN = false>
 __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const OffT* __restrict__ row_map,
                                                               const int32_t* __restrict__ entries,
                                                               const AT* __restrict__ values, const YT* __restrict__ x,
                                                               YT* __restrict__ y, YT alpha, YT beta,
                                                               const int32_t* __restrict__ blk_info,
                                                               YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
-                                                              int remap, int ablate) {
+                                                              int remap, int ablate, const uint16_t* __restrict__ wcode = nullptr,
+                                                              const int32_t* __restrict__ wbase = nullptr) {
+  // WIN: the columns come from the plan's 16-bit window codes (wcode, wbase) instead of entries
   // ablate (diagnosis knob, 0 in production; results in DESIGN.md 4.1): 4 = no y stores, 8 = no LDS reduction
   // loop, 16 = synthetic row bounds (no row_map loads), 32 = no barrier
   constexpr int TILE  = kBlock * NPT;
@@ -366,8 +476,13 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
 
   AT v0[STEPS], v1[STEPS];
   int c0[STEPS], c1[STEPS];
-  if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
-  else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
+  if (WIN) {
+    if (full) load_tile_win<AT, STEPS, true>(values, wcode, wbase, b, s, e, t, v0, v1, c0, c1);
+    else      load_tile_win<AT, STEPS, false>(values, wcode, wbase, b, s, e, t, v0, v1, c0, c1);
+  } else {
+    if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
+    else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
+  }
 
   const int64_t ra    = info0 & 0x7fffffff;
   const int64_t rb    = info1 & 0x7fffffff;
@@ -1046,6 +1161,11 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
     KK_LAUNCH((spmv_stream6_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
               (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
+  } else if (variant == 6 && p->d_wcode) {
+    KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, true, true>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
+              (const int32_t*)p->d_wbase);
   } else if (variant == 3) {
     KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, false>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
@@ -1415,6 +1535,8 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
   if (p->d_uoff) { KK_HIP(hipFree(p->d_uoff)); p->d_uoff = nullptr; }
   if (p->d_ucols) { KK_HIP(hipFree(p->d_ucols)); p->d_ucols = nullptr; }
   if (p->d_lidx) { KK_HIP(hipFree(p->d_lidx)); p->d_lidx = nullptr; }
+  if (p->d_wcode) { KK_HIP(hipFree(p->d_wcode)); p->d_wcode = nullptr; }
+  if (p->d_wbase) { KK_HIP(hipFree(p->d_wbase)); p->d_wbase = nullptr; }
   p->tile = 0; p->nblocks = 0;
   if (p->algorithm == KKAMD_SPMV_FAST_SETUP || p->tune.kernel == 1 || A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
   int npt = p->tune.nnz_per_thread;
@@ -1443,6 +1565,26 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
     if (npt == 8) { KK_LAUNCH((tlc_build_kernel<2048>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, (const int64_t*)p->d_uoff, p->d_ucols, p->d_lidx); }
     else          { KK_LAUNCH((tlc_build_kernel<1024>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, (const int64_t*)p->d_uoff, p->d_ucols, p->d_lidx); }
     KK_LAUNCH_CHECK();
+  }
+  if (p->tune.stream_variant == 6 && p->entries) {
+    // window codes: every tile must be coverable by 16 windows, otherwise the plan keeps reading entries
+    int* d_fail = nullptr;
+    int h_fail  = 0;
+    KK_HIP(hipMalloc((void**)&d_fail, sizeof(int)));
+    KK_HIP(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+    KK_HIP(hipMalloc((void**)&p->d_wcode, sizeof(uint16_t) * (size_t)p->nblocks * (size_t)p->tile));
+    KK_HIP(hipMalloc((void**)&p->d_wbase, sizeof(int32_t) * (size_t)p->nblocks * kWinCount));
+    if (npt == 16)     { KK_LAUNCH((win_build_kernel<16>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
+    else if (npt == 8) { KK_LAUNCH((win_build_kernel<8>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
+    else               { KK_LAUNCH((win_build_kernel<4>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
+    KK_LAUNCH_CHECK();
+    KK_HIP(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    KK_HIP(hipFree(d_fail));
+    if (h_fail) {
+      KK_HIP(hipFree(p->d_wcode)); p->d_wcode = nullptr;
+      KK_HIP(hipFree(p->d_wbase)); p->d_wbase = nullptr;
+    }
   }
   KK_HIP(hipStreamSynchronize(st));   // setup is synchronous, like the vendor analysis it replaces
   return KKAMD_OK;
@@ -1507,6 +1649,8 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_uoff) (void)hipFree(plan->d_uoff);
   if (plan->d_ucols) (void)hipFree(plan->d_ucols);
   if (plan->d_lidx) (void)hipFree(plan->d_lidx);
+  if (plan->d_wcode) (void)hipFree(plan->d_wcode);
+  if (plan->d_wbase) (void)hipFree(plan->d_wbase);
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
   if (plan->d_t_perm) (void)hipFree(plan->d_t_perm);
@@ -1522,13 +1666,25 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
   int rc = kk::set_tuning(plan->tune, key, value);
   if (rc) return rc;
   if (plan->tune.nnz_per_thread != old_npt || plan->tune.kernel != old_kernel ||
-      (plan->tune.stream_variant == 2) != (old_var == 2) || (plan->tune.stream_variant == 4) != (old_var == 4)) {
+      (plan->tune.stream_variant == 2) != (old_var == 2) || (plan->tune.stream_variant == 4) != (old_var == 4) ||
+      (plan->tune.stream_variant == 6) != (old_var == 6)) {
     // tiling changed: redo the analysis (needs the matrix again; rebuilt lazily from the stored row_map)
     kkamd_crs_t A{};
     A.num_rows = plan->num_rows; A.num_cols = plan->num_cols; A.nnz = plan->nnz; A.d_row_map = plan->row_map;
     A.offset_type = plan->offset_type; A.value_type = KKAMD_F64;
     return kk::build_analysis(plan, &A, nullptr);
   }
+  return KKAMD_OK;
+}
+
+int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value) {
+  if (!plan || !key || !value) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: null argument");
+  const std::string k(key);
+  if (k == "tile") *value = plan->tile;
+  else if (k == "tiles") *value = plan->nblocks;
+  else if (k == "window_codes") *value = plan->d_wcode ? 1 : 0;
+  else if (k == "transpose_cached") *value = plan->t_ready ? 1 : 0;
+  else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
   return KKAMD_OK;
 }
 

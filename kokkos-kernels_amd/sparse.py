@@ -129,6 +129,13 @@ class SPMVHandle:
         else:
             check(self.backend.lib, self.backend.lib.kkamd_spmv_plan_set(self._plan, key.encode(), int(value)))
 
+    def query(self, key):
+        """what the analysis produced (kkamd_spmv_plan_query); None before the first spmv call"""
+        if self._plan is None: return None
+        v = C.c_int64(0)
+        check(self.backend.lib, self.backend.lib.kkamd_spmv_plan_query(self._plan, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def _ensure(self, A):
         if self._plan is None:
             self.backend = A.backend

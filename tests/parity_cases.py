@@ -28,7 +28,7 @@ def fspmv_ok(expected, got, tol):
 
 
 def check_spmv(be, A0, mode="N", alpha=1.0, beta=0.0, algo=None, nans=False, seed=0, offset_dtype=np.int32,
-               max_val=1.0, knobs=None, value_dtype=None, vec_dtype=np.float64):
+               max_val=1.0, knobs=None, value_dtype=None, vec_dtype=np.float64, expect=None):
     """one check_spmv() of the reference test (Test_Sparse_spmv.hpp:168-216)"""
     rng = np.random.default_rng(seed)
     trans = mode in "TH"
@@ -47,6 +47,8 @@ def check_spmv(be, A0, mode="N", alpha=1.0, beta=0.0, algo=None, nans=False, see
             h.set(k_, v_)
         kk.spmv(h, mode, alpha, A, xd, beta, yd)
         kk.spmv(h, mode, alpha, A, xd, beta, yd) if beta == 0.0 else None   # handle reuse
+        for k_, v_ in (expect or {}).items():                               # what the analysis must have produced
+            assert h.query(k_) == v_, "plan query %s: %r, expected %r" % (k_, h.query(k_), v_)
     got = be.to_numpy(yd).astype(np.float64)
     Ao = A0 if value_dtype is None else oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, A0.values.astype(value_dtype))
     if vec_dtype == np.float64:
@@ -200,3 +202,30 @@ def check_spmv_struct(be, dims, stencil_type, mode="N", offset_dtype=np.int32, v
         exp = oracle.spmv_struct(mode, stencil_type, dims, Ao, 1.0, x.astype(np.float64), 0.0, np.zeros(nout))
         ok, err = fspmv_ok(exp, got, max(oracle.spmv_max_error(A0, 1.0, 0.0, max_val=max_val) * eps_scale, 1e-300))
         assert ok and np.isfinite(got).all(), "spmv_struct beta=0 must not read y (dims=%s stencil=%d)" % (dims, stencil_type)
+
+
+def window_code_cases():
+    """(name, matrix, window codes expected) for stream_variant 6: column sets that need 1, several, exactly 16 and more
+    than 16 windows of 4096 columns per tile, plus a ragged last tile."""
+    rng = np.random.default_rng(77)
+    out = []
+    # multi-diagonal: offsets spread over 7 windows, columns clipped to the matrix
+    n, nc = 5000, 400000
+    offs = np.array([0, 1, 2, 5000, 5001, 60000, 60007, 130000, 200000, 200001, 300000, 390000])
+    cols = (np.arange(n)[:, None] * 2 + offs[None, :])
+    keep = cols < nc
+    lens = keep.sum(1)
+    rm = np.zeros(n + 1, np.int64); rm[1:] = np.cumsum(lens)
+    out.append(("diagonals", oracle.Crs(n, nc, rm, cols[keep].astype(np.int32), rng.random(int(rm[-1]))), 1))
+    # exactly 16 column clusters per row (16 windows needed), then 17 (falls back to plain entries)
+    for k, ok in ((16, 1), (17, 0)):
+        n = 1500
+        cols = (np.arange(k)[None, :] * 20000 + rng.integers(0, 1000, (n, k))).astype(np.int32)
+        cols.sort(axis=1)
+        rm = np.arange(n + 1, dtype=np.int64) * k
+        out.append(("clusters%d" % k, oracle.Crs(n, 20000 * k, rm, cols.reshape(-1), rng.random(n * k)), ok))
+    # uniformly random columns over a wide range: no tile is coverable
+    out.append(("random-wide", oracle.random_crs(3000, 3000000, 9, variance=3, seed=5), 0))
+    # 27-pt stencil (9 x-lines per tile) with nnz not a multiple of any tile size
+    out.append(("27pt", oracle.laplace3d("FE", 40, 37, 21), 1))
+    return out

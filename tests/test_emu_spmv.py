@@ -38,7 +38,7 @@ def test_stream_kernel_tilings(be, npt):
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"nnz_per_thread": npt, "xcd_remap": 0, "nontemporal": 0})
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_stream_variants(be, variant):
     # every kept variant of the planned kernel (A/B knob "stream_variant"), incl. the tile-local column structure (4)
     mats = [oracle.laplace3d("FE", 12, 11, 10), oracle.random_crs(900, 880, 13, variance=9, seed=2), oracle.random_crs(2000, 2000, 25, variance=5, seed=3, bandwidth=40)]
@@ -46,6 +46,17 @@ def test_stream_variants(be, variant):
         for npt in (4, 8, 16):
             pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs={"nnz_per_thread": npt, "stream_variant": variant}, max_val=32.0)
             pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"nnz_per_thread": npt, "stream_variant": variant}, max_val=32.0)
+
+
+def test_window_codes(be):
+    # stream_variant 6: columns from 16-bit window codes where every tile fits 16 windows, plain entries otherwise
+    for name, A0, ok in pc.window_code_cases():
+        for npt in (4, 8, 16):
+            kn = {"nnz_per_thread": npt, "stream_variant": 6}
+            pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=32.0, expect={"window_codes": ok})
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"stream_variant": 6}, max_val=32.0, expect={"window_codes": ok})
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"stream_variant": 6}, max_val=32.0, offset_dtype=np.int64,
+                      value_dtype=np.float32, expect={"window_codes": ok})
 
 
 def _custom(lens, ncols, seed=0):

@@ -65,7 +65,7 @@ def test_vector_kernel_variants(be, lpr):
     pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_FAST_SETUP", knobs={"lanes_per_row": lpr})
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_stream_variants(be, variant):
     # every kept variant of the planned kernel (A/B knob "stream_variant"), incl. the tile-local column structure (4)
     mats = [oracle.laplace3d("FE", 60, 50, 40), oracle.random_crs(40000, 39000, 13, variance=9, seed=2), oracle.random_crs(30000, 30000, 25, variance=5, seed=3, bandwidth=40)]

@@ -18,9 +18,11 @@ x = torch.rand(A.numCols(), dtype=torch.float64, device="cuda"); y = torch.zeros
 ref = None
 for rep in range(2):
     for name, knobs in (("default (quad-dealt gather, 4096)", {}), ("late gather, 4096-nnz tiles", {"stream_variant": 5, "nnz_per_thread": 16}),
-                        ("late gather, 2048-nnz tiles", {"stream_variant": 5, "nnz_per_thread": 8}), ("late gather, 1024-nnz tiles", {"stream_variant": 5, "nnz_per_thread": 4})):
+                        ("late gather, 2048-nnz tiles", {"stream_variant": 5, "nnz_per_thread": 8}), ("late gather, 1024-nnz tiles", {"stream_variant": 5, "nnz_per_thread": 4}),
+                        ("window codes, 4096-nnz tiles", {"stream_variant": 6, "nnz_per_thread": 16}), ("window codes, 2048-nnz tiles", {"stream_variant": 6, "nnz_per_thread": 8}),
+                        ("default, 2048-nnz tiles", {"nnz_per_thread": 8})):
         h = kk.SPMVHandle("SPMV_DEFAULT")
         for k, v in knobs.items(): h.set(k, v)
         t = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y))
         if ref is None: ref = y.clone()
-        print("%-36s %.4f ms  maxdiff %.2g" % (name, t, (y - ref).abs().max().item()))
+        print("%-36s %.4f ms  maxdiff %.2g  window_codes=%s" % (name, t, (y - ref).abs().max().item(), h.query("window_codes")))
