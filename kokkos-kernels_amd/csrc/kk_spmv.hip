@@ -44,6 +44,8 @@ struct SpmvTuning {
                                 // values every call and run the N kernel on it; 2 = same, the caller promises constant values (no refresh)
   int explicit_transpose_min_knnz = 1000;   // ... from this many thousand nnz
   int transient_min_knnz = 10000;  // handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 = never)
+  int window_codes = 1;            // analysed handles with the default kernel: try the 16-bit window codes (stream_variant 6 forces the attempt)
+  int window_codes_min_knnz = 1000;  // ... from this many thousand nnz
 };
 static SpmvTuning g_spmv_default;
 
@@ -71,11 +73,13 @@ struct kkamd_spmv_plan {
   // window codes (stream_variant 6): per tile up to 16 column windows of 4096 and, per nnz, a 16-bit code
   // (window << 12 | column - window base), stored in the order the kernel's work-items consume them
   uint16_t* d_wcode = nullptr;   // [nblocks * tile]
-  int32_t* d_wbase = nullptr;    // [nblocks * 16] window bases, ascending
+  int32_t* d_wbase = nullptr;    // [nblocks * 64] window meta: bases, LDS slots, x chunk columns
+  bool win_stage = false;        // every tile's used column ranges fit its LDS x window
   // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
   void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr;
   kkamd_spmv_plan* t_plan = nullptr;
   bool t_ready = false, t_failed = false, t_values_valid = false;
+  bool win_failed = false;       // some tile of this matrix needs more than 16 windows: plain entries
 };
 
 namespace kk {
@@ -185,13 +189,24 @@ __device__ __forceinline__ void load_tile(const AT* __restrict__ values, const i
 // order work-item t consumes them (its 2*STEPS codes are contiguous: one or two 16-byte loads instead of STEPS 8-byte
 // ones), the bases sit in lanes 0-15 of every wave and are fetched with one lane permute per nonzero.
 constexpr int kWinBits = 12, kWinCount = 16;
+// Per tile the plan keeps 64 ints ("window meta", one coalesced load per wave): [0,16) window bases, [16,32) the LDS slot
+// of each window's first used column, [32,64) the first column of every 64-slot chunk of the staged x window (-1 = unused).
+// Staged x (stream_variant 6/1, every tile's used column ranges -- padded to 64 -- fit the tile's LDS): the x entries a
+// tile needs are contiguous ranges, so they are fetched with coalesced loads issued TOGETHER with the value loads and the
+// per-nonzero gather reads LDS: no dependent trip to memory, and ~10x fewer cache-line look-ups than the gather.
+constexpr int kWinMeta = 64, kWinChunks = 32;
 
 template <int NPT>
 __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const int32_t* __restrict__ entries,
-                                                           uint16_t* __restrict__ wcode, int32_t* __restrict__ wbase,
+                                                           uint16_t* __restrict__ wcode, int32_t* __restrict__ wmeta,
                                                            int* __restrict__ fail) {
+  // fail[0]: tiles that need more than 16 windows; fail[1]: tiles whose used column ranges exceed the LDS x window
   constexpr int TILE = kBlock * NPT, STEPS = NPT / 2, SPAN = kBlock * 2;
   __shared__ int s_base[kWinCount];
+  __shared__ int s_len[kWinCount];
+  __shared__ int s_off[kWinCount + 1];
+  __shared__ unsigned s_bits[128];                           // used columns of the window being formed
+  __shared__ int s_zero;
   __shared__ int s_min;
   const int t = threadIdx.x;
   const int64_t b = blockIdx.x, s = b * TILE;
@@ -202,44 +217,112 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
     c[2 * k]     = idx < nnz ? entries[idx] : -1;
     c[2 * k + 1] = idx + 1 < nnz ? entries[idx + 1] : -1;
   }
-  // greedy cover of the tile's columns, left to right: the next window starts at the smallest column not covered yet
-  long long bound = 0;                                       // columns < bound are covered
-  for (int w = 0; w < kWinCount; ++w) {                      // workgroup-uniform trip count
-    if (t == 0) s_min = INT_MAX;
-    __syncthreads();
-    int m = INT_MAX;
-    KK_UNROLL
-    for (int k = 0; k < NPT; ++k) if (c[k] >= 0 && (long long)c[k] >= bound && c[k] < m) m = c[k];
-    if (m != INT_MAX) atomicMin(&s_min, m);
-    __syncthreads();
-    const int base = s_min;
-    if (t == 0) s_base[w] = (base == INT_MAX) ? (w ? s_base[w - 1] : 0) : base;
-    if (base != INT_MAX) bound = (long long)base + (1 << kWinBits);
-    __syncthreads();
-  }
+  // Greedy cover of the tile's columns, left to right: the next window starts at the smallest column not covered yet.
+  // Pass 0 ends a window at the first run of 64 unused columns (64-aligned from its base), so that windows hug the
+  // contiguous column runs a tile really touches (27-pt: nine runs of ~80) and the staged x window stays small; if that
+  // needs more than 16 windows, pass 1 takes full 4096-column windows.
   bool uncovered = false;
-  KK_UNROLL
-  for (int k = 0; k < NPT; ++k) uncovered |= (c[k] >= 0 && (long long)c[k] >= bound);
+  for (int pass = 0; pass < 2; ++pass) {                       // workgroup-uniform control flow throughout
+    long long bound = 0;                                       // columns < bound are covered
+    for (int w = 0; w < kWinCount; ++w) {
+      if (t == 0) { s_min = INT_MAX; s_zero = 64; }
+      if (t < 128) s_bits[t] = 0u;
+      __syncthreads();
+      int m = INT_MAX;
+      KK_UNROLL
+      for (int k = 0; k < NPT; ++k) if (c[k] >= 0 && (long long)c[k] >= bound && c[k] < m) m = c[k];
+      if (m != INT_MAX) atomicMin(&s_min, m);
+      __syncthreads();
+      const int base = s_min;
+      if (base == INT_MAX) {                                   // everything is covered: the unused windows repeat the last base
+        if (t == 0) for (int q = w; q < kWinCount; ++q) s_base[q] = q ? s_base[q - 1] : 0;
+        __syncthreads();
+        break;
+      }
+      long long span = (1 << kWinBits);
+      if (pass == 0) {
+        KK_UNROLL
+        for (int k = 0; k < NPT; ++k) {
+          const long long d = (long long)c[k] - base;
+          if (c[k] >= 0 && d >= 0 && d < (1 << kWinBits)) atomicOr(&s_bits[d >> 5], 1u << (d & 31));
+        }
+        __syncthreads();
+        if (t < 64 && s_bits[2 * t] == 0u && s_bits[2 * t + 1] == 0u) atomicMin(&s_zero, t);
+        __syncthreads();
+        span = 64ll * s_zero;
+      }
+      if (t == 0) s_base[w] = base;
+      bound = (long long)base + span;
+      __syncthreads();
+    }
+    uncovered = false;
+    KK_UNROLL
+    for (int k = 0; k < NPT; ++k) uncovered |= (c[k] >= 0 && (long long)c[k] >= bound);
+    if (t == 0) s_min = 0;
+    __syncthreads();
+    if (uncovered) atomicOr(&s_min, 1);
+    __syncthreads();
+    const int any = s_min;
+    __syncthreads();
+    if (!any) break;
+  }
   if (uncovered) atomicAdd(fail, 1);
-  if (t < kWinCount) wbase[b * kWinCount + t] = s_base[t];
+  if (t < kWinCount) s_len[t] = 0;
+  __syncthreads();
   uint16_t* out = wcode + s + (int64_t)t * NPT;
   KK_UNROLL
   for (int k = 0; k < NPT; ++k) {
     int w = 0;
     for (int q = 1; q < kWinCount; ++q) if (s_base[q] <= c[k] && s_base[q] > s_base[q - 1]) w = q;
     const int d = c[k] - s_base[w];
-    out[k] = (c[k] >= 0 && d >= 0 && d < (1 << kWinBits)) ? (uint16_t)((w << kWinBits) | d) : (uint16_t)0;
+    const bool ok = (c[k] >= 0 && d >= 0 && d < (1 << kWinBits));
+    out[k] = ok ? (uint16_t)((w << kWinBits) | d) : (uint16_t)0;
+    if (ok) atomicMax(&s_len[w], d + 1);
+  }
+  __syncthreads();
+  // LDS slots of the used part of every window, padded to whole 64-slot chunks
+  if (t == 0) {
+    int off = 0;
+    for (int w = 0; w < kWinCount; ++w) { s_off[w] = off; off += (s_len[w] + 63) & ~63; }
+    s_off[kWinCount] = off;
+    constexpr int CAP = TILE < kWinChunks * 64 ? TILE : kWinChunks * 64;
+    if (off > CAP) atomicAdd(fail + 1, 1);
+  }
+  __syncthreads();
+  int32_t* meta = wmeta + b * kWinMeta;
+  if (t < kWinCount) { meta[t] = s_base[t]; meta[kWinCount + t] = s_off[t]; }
+  if (t < kWinChunks) {
+    const int slot = t * 64;
+    int col = -1;
+    for (int w = 0; w < kWinCount; ++w) if (slot >= s_off[w] && slot < s_off[w] + ((s_len[w] + 63) & ~63)) col = s_base[w] + (slot - s_off[w]);
+    meta[2 * kWinCount + t] = col;
   }
 }
 
 template <class AT, int STEPS, bool FULL>
-__device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, const uint16_t* __restrict__ wcode,
-                                              const int32_t* __restrict__ wbase, int64_t b, int64_t ts, int64_t te, int t,
-                                              AT (&v0)[STEPS], AT (&v1)[STEPS], int (&c0)[STEPS], int (&c1)[STEPS]) {
+__device__ __forceinline__ void load_tile_values(const AT* __restrict__ values, int64_t ts, int64_t te, int t, AT (&v0)[STEPS],
+                                                 AT (&v1)[STEPS]) {
   using AV = typename vec2<AT>::type;
-  constexpr int SPAN = kBlock * 2, NPT = 2 * STEPS;
+  constexpr int SPAN = kBlock * 2;
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int64_t idx = ts + (int64_t)k * SPAN + t * 2;
+    if (FULL || idx + 1 < te) {
+      const AV vv = *reinterpret_cast<const AV*>(values + idx);
+      v0[k] = vv[0]; v1[k] = vv[1];
+    } else if (idx < te) {
+      v0[k] = values[idx]; v1[k] = AT(0);
+    } else {
+      v0[k] = v1[k] = AT(0);
+    }
+  }
+}
+
+// the 2*STEPS codes of work-item t, two per 32-bit word (nonzero 2k of the item in the low half of word k)
+template <int STEPS>
+__device__ __forceinline__ void load_tile_codes(const uint16_t* __restrict__ wcode, int64_t ts, int t, unsigned (&w)[STEPS]) {
+  constexpr int NPT = 2 * STEPS;
   const unsigned* cw = reinterpret_cast<const unsigned*>(wcode + ts + (int64_t)t * NPT);   // 4*STEPS bytes, aligned
-  unsigned w[STEPS];
   if (STEPS % 4 == 0) {
     KK_UNROLL
     for (int k = 0; k < STEPS; k += 4) {
@@ -253,30 +336,75 @@ __device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, con
       w[k] = q[0]; w[k + 1] = q[1];
     }
   }
-  const int basereg = wbase[b * kWinCount + (t & (kWinCount - 1))];
-  KK_UNROLL
-  for (int k = 0; k < STEPS; ++k) {
-    const int64_t idx = ts + (int64_t)k * SPAN + t * 2;
-    if (FULL || idx + 1 < te) {
-      const AV vv = *reinterpret_cast<const AV*>(values + idx);
-      v0[k] = vv[0]; v1[k] = vv[1];
-    } else if (idx < te) {
-      v0[k] = values[idx]; v1[k] = AT(0);
-    } else {
-      v0[k] = v1[k] = AT(0);
-    }
-  }
+}
+
+template <class AT, int STEPS, bool FULL>
+__device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, const uint16_t* __restrict__ wcode,
+                                              const int32_t* __restrict__ wmeta, int64_t b, int64_t ts, int64_t te, int t,
+                                              AT (&v0)[STEPS], AT (&v1)[STEPS], int (&c0)[STEPS], int (&c1)[STEPS]) {
+  constexpr int SPAN = kBlock * 2;
+  unsigned w[STEPS];
+  load_tile_codes<STEPS>(wcode, ts, t, w);
+  const int meta = wmeta[b * kWinMeta + (t & (kWinMeta - 1))];
+  load_tile_values<AT, STEPS, FULL>(values, ts, te, t, v0, v1);
   KK_UNROLL
   for (int k = 0; k < STEPS; ++k) {
     const int64_t idx = ts + (int64_t)k * SPAN + t * 2;
     const unsigned lo = w[k] & 0xffffu, hi = w[k] >> 16;
-    const int b0 = __shfl(basereg, (int)(lo >> kWinBits), 64), b1 = __shfl(basereg, (int)(hi >> kWinBits), 64);
+    const int b0 = __shfl(meta, (int)(lo >> kWinBits), 64), b1 = __shfl(meta, (int)(hi >> kWinBits), 64);
     c0[k] = b0 + (int)(lo & ((1u << kWinBits) - 1));
     c1[k] = b1 + (int)(hi & ((1u << kWinBits) - 1));
     if (!FULL) {
       if (idx >= te) c0[k] = c1[k] = -1;
       else if (idx + 1 >= te) c1[k] = c0[k];
     }
+  }
+}
+
+// Staged-x tile: values, codes, meta and the x chunks are all requested before anything is waited for; the x chunks go to
+// LDS (aliasing the product array), every work-item then picks its x entries out of LDS and the products replace them.
+template <class AT, class YT, int STEPS, bool FULL>
+__device__ __forceinline__ void stage_products_win(const AT* __restrict__ values, const uint16_t* __restrict__ wcode,
+                                                   const int32_t* __restrict__ wmeta, const YT* __restrict__ x, int64_t ncols,
+                                                   YT* prod, int64_t b, int64_t ts, int64_t te, int t) {
+  constexpr int SPAN = kBlock * 2, NPT = 2 * STEPS, TILE = kBlock * NPT;
+  constexpr int CAPC = (TILE < kWinChunks * 64 ? TILE : kWinChunks * 64) / 64;     // chunks the LDS window can hold
+  constexpr int CPW  = (CAPC + kBlock / 64 - 1) / (kBlock / 64);                     // chunks per wave
+  AT v0[STEPS], v1[STEPS];
+  unsigned w[STEPS];
+  const int lane = t & 63, wave = t >> 6;
+  const int meta = wmeta[b * kWinMeta + lane];
+  load_tile_codes<STEPS>(wcode, ts, t, w);
+  load_tile_values<AT, STEPS, FULL>(values, ts, te, t, v0, v1);
+  YT xv[CPW];
+  KK_UNROLL
+  for (int i = 0; i < CPW; ++i) {
+    const int c   = wave + i * (kBlock / 64);
+    const int col = c < CAPC ? __shfl(meta, 2 * kWinCount + c, 64) : -1;            // wave-uniform
+    int64_t xi    = (int64_t)col + lane;
+    xi            = xi < ncols ? xi : ncols - 1;
+    xv[i]         = col >= 0 ? x[xi] : YT(0);
+  }
+  KK_UNROLL
+  for (int i = 0; i < CPW; ++i) {
+    const int c = wave + i * (kBlock / 64);
+    if (c < CAPC) prod[c * 64 + lane] = xv[i];
+  }
+  __syncthreads();
+  YT x0[STEPS], x1[STEPS];
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const unsigned lo = w[k] & 0xffffu, hi = w[k] >> 16;
+    const int s0 = __shfl(meta, kWinCount + (int)(lo >> kWinBits), 64) + (int)(lo & ((1u << kWinBits) - 1));
+    const int s1 = __shfl(meta, kWinCount + (int)(hi >> kWinBits), 64) + (int)(hi & ((1u << kWinBits) - 1));
+    x0[k] = prod[s0]; x1[k] = prod[s1];
+  }
+  __syncthreads();                       // every x entry is in registers: the products may overwrite the window
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    const int li = k * SPAN + t * 2;
+    prod[li]     = (YT)v0[k] * x0[k];
+    prod[li + 1] = (YT)v1[k] * x1[k];
   }
 }
 
@@ -450,7 +578,7 @@ template <class YT> __device__ __forceinline__ YT strided_lds_sum(const YT* prod
 // row_map[r], row_map[r+1] are requested together with the x gathers -- so a tile sees two memory
 // latencies (stream, then gather+bounds) instead of five (stream, gather, blk_row, row_map[ra], bounds).
 // After the barrier the row reduction touches only LDS and registers.
-template <class OffT, class AT, class YT, int NPT, bool NT, bool QP, bool WIN = false>
+template <class OffT, class AT, class YT, int NPT, bool NT, bool QP, int WIN = 0>
 __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const OffT* __restrict__ row_map,
                                                               const int32_t* __restrict__ entries,
                                                               const AT* __restrict__ values, const YT* __restrict__ x,
@@ -458,8 +586,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
                                                               const int32_t* __restrict__ blk_info,
                                                               YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
                                                               int remap, int ablate, const uint16_t* __restrict__ wcode = nullptr,
-                                                              const int32_t* __restrict__ wbase = nullptr) {
-  // WIN: the columns come from the plan's 16-bit window codes (wcode, wbase) instead of entries
+                                                              const int32_t* __restrict__ wmeta = nullptr, int64_t ncols = 0) {
+  // WIN 1: the columns come from the plan's 16-bit window codes (wcode, wmeta) instead of entries; WIN 2: x is staged
+  // in LDS from the tile's contiguous column ranges as well (stage_products_win)
   // ablate (diagnosis knob, 0 in production; results in DESIGN.md 4.1): 4 = no y stores, 8 = no LDS reduction
   // loop, 16 = synthetic row bounds (no row_map loads), 32 = no barrier
   constexpr int TILE  = kBlock * NPT;
@@ -476,9 +605,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
 
   AT v0[STEPS], v1[STEPS];
   int c0[STEPS], c1[STEPS];
-  if (WIN) {
-    if (full) load_tile_win<AT, STEPS, true>(values, wcode, wbase, b, s, e, t, v0, v1, c0, c1);
-    else      load_tile_win<AT, STEPS, false>(values, wcode, wbase, b, s, e, t, v0, v1, c0, c1);
+  if (WIN == 2) {
+    // nothing to load here: stage_products_win requests values, codes and x chunks together
+  } else if (WIN == 1) {
+    if (full) load_tile_win<AT, STEPS, true>(values, wcode, wmeta, b, s, e, t, v0, v1, c0, c1);
+    else      load_tile_win<AT, STEPS, false>(values, wcode, wmeta, b, s, e, t, v0, v1, c0, c1);
   } else {
     if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
     else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
@@ -500,8 +631,13 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
     else { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
   }
 
-  if (full) stage_products<AT, YT, STEPS, true, QP>(x, prod, t, v0, v1, c0, c1);
-  else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
+  if (WIN == 2) {
+    if (full) stage_products_win<AT, YT, STEPS, true>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
+    else      stage_products_win<AT, YT, STEPS, false>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
+  } else {
+    if (full) stage_products<AT, YT, STEPS, true, QP>(x, prod, t, v0, v1, c0, c1);
+    else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
+  }
   if (!(ablate & 32)) __syncthreads();
 
   for (int64_t base = 0; base < nv; base += ngrp) {
@@ -1161,11 +1297,18 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
     KK_LAUNCH((spmv_stream6_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
               (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
-  } else if (variant == 6 && p->d_wcode) {
-    KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, true, true>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
-              (const int32_t*)p->d_wbase);
+  } else if ((variant == 6 || variant == 1) && p->d_wcode) {
+    if (p->win_stage && p->tune.window_codes != 2) {
+      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, true, 2>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+                (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
+                (const int32_t*)p->d_wbase, A->num_cols);
+    } else {
+      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, true, 1>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+                (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
+                (const int32_t*)p->d_wbase, A->num_cols);
+    }
   } else if (variant == 3) {
     KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, false>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
@@ -1312,6 +1455,7 @@ static kkamd_spmv_plan* transient_plan(const kkamd_crs_t* A, const SpmvTuning& t
   p.num_rows = A->num_rows; p.num_cols = A->num_cols; p.nnz = A->nnz; p.row_map = A->d_row_map; p.entries = A->d_entries;
   p.offset_type = A->offset_type; p.algorithm = KKAMD_SPMV_FAST_SETUP; p.tune = tn;
   p.tune.stream_variant = 1;
+  p.tune.window_codes = 0;        // one-shot plans do not pay for the column codes
   int npt = (elem_size == 8 && A->nnz >= 200000000) ? 16 : 8;
   if (elem_size == 8 && (tn.nnz_per_thread == 4 || tn.nnz_per_thread == 8 || tn.nnz_per_thread == 16)) npt = tn.nnz_per_thread;
   p.tile    = kBlock * npt;
@@ -1513,6 +1657,8 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "wg_per_cu") t.wg_per_cu = value;
   else if (k == "ablate") t.ablate = value;
   else if (k == "mv_remap") t.mv_remap = value;
+  else if (k == "window_codes") t.window_codes = value;
+  else if (k == "window_codes_min_knnz") t.window_codes_min_knnz = value;
   else if (k == "transient_min_knnz") t.transient_min_knnz = value;
   else if (k == "explicit_transpose") t.explicit_transpose = value;
   else if (k == "explicit_transpose_min_knnz") t.explicit_transpose_min_knnz = value;
@@ -1529,7 +1675,7 @@ static int analyse(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
   return KKAMD_OK;
 }
 
-static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
+static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st, int force_npt = 0) {
   if (p->d_blk_row) { KK_HIP(hipStreamSynchronize(st)); KK_HIP(hipFree(p->d_blk_row)); p->d_blk_row = nullptr; }
   if (p->d_carry) { KK_HIP(hipFree(p->d_carry)); p->d_carry = nullptr; }
   if (p->d_uoff) { KK_HIP(hipFree(p->d_uoff)); p->d_uoff = nullptr; }
@@ -1542,7 +1688,19 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
   int npt = p->tune.nnz_per_thread;
   // auto: 4096-nnz tiles once there are plenty of them (measured best from ~2e8 nnz up), 2048-nnz tiles below that
   // (5-pt 1000^2: 19.2 vs 22.2 us)
-  if (npt != 4 && npt != 8 && npt != 16) npt = (p->tune.stream_variant == 4 || A->nnz < 200000000) ? 8 : 16;
+  const bool want_win = !p->win_failed && p->entries &&
+                        (p->tune.stream_variant == 6 || (p->tune.stream_variant == 1 && p->tune.window_codes &&
+                                                         A->nnz >= (int64_t)p->tune.window_codes_min_knnz * 1000));
+  const bool auto_npt = (npt != 4 && npt != 8 && npt != 16);
+  // With window codes: 4096-nnz tiles when the matrix is large and their x windows fit LDS (27-pt 300^3: 1.38 ms against
+  // 1.44 with 2048-nnz tiles), else 2048-nnz tiles (codes without staged x: 1.51 vs 1.58 ms; 7-pt 400^3 is only
+  // stageable at 2048) -- the 4096 attempt is redone at 2048 below when it does not stage.
+  if (force_npt) npt = force_npt;
+  else if (auto_npt) {
+    if (p->tune.stream_variant == 4) npt = 8;
+    else if (want_win) npt = (A->nnz >= 50000000) ? 16 : 8;
+    else npt = (A->nnz < 200000000) ? 8 : 16;
+  }
   if (p->tune.stream_variant == 4 && npt == 16) npt = 8;     // the tile-local structure uses 2048- or 1024-nnz tiles
   if (!(A->value_type == KKAMD_F64) && p->tune.nnz_per_thread != 16) npt = 8;   // fp32 values: 2048-nnz tiles unless asked
   p->tile    = (p->tune.stream_variant == 2 ? kWave : kBlock) * npt;
@@ -1566,24 +1724,30 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
     else          { KK_LAUNCH((tlc_build_kernel<1024>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, (const int64_t*)p->d_uoff, p->d_ucols, p->d_lidx); }
     KK_LAUNCH_CHECK();
   }
-  if (p->tune.stream_variant == 6 && p->entries) {
+  if (want_win) {
     // window codes: every tile must be coverable by 16 windows, otherwise the plan keeps reading entries
     int* d_fail = nullptr;
-    int h_fail  = 0;
-    KK_HIP(hipMalloc((void**)&d_fail, sizeof(int)));
-    KK_HIP(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+    int h_fails[2] = {0, 0};
+    KK_HIP(hipMalloc((void**)&d_fail, 2 * sizeof(int)));
+    KK_HIP(hipMemsetAsync(d_fail, 0, 2 * sizeof(int), st));
     KK_HIP(hipMalloc((void**)&p->d_wcode, sizeof(uint16_t) * (size_t)p->nblocks * (size_t)p->tile));
-    KK_HIP(hipMalloc((void**)&p->d_wbase, sizeof(int32_t) * (size_t)p->nblocks * kWinCount));
+    KK_HIP(hipMalloc((void**)&p->d_wbase, sizeof(int32_t) * (size_t)p->nblocks * kWinMeta));
     if (npt == 16)     { KK_LAUNCH((win_build_kernel<16>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
     else if (npt == 8) { KK_LAUNCH((win_build_kernel<8>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
     else               { KK_LAUNCH((win_build_kernel<4>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
     KK_LAUNCH_CHECK();
-    KK_HIP(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipMemcpyAsync(h_fails, d_fail, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
     KK_HIP(hipFree(d_fail));
+    const int h_fail = h_fails[0];
+    p->win_stage = (h_fails[0] == 0 && h_fails[1] == 0);
     if (h_fail) {
       KK_HIP(hipFree(p->d_wcode)); p->d_wcode = nullptr;
       KK_HIP(hipFree(p->d_wbase)); p->d_wbase = nullptr;
+      p->win_failed = true;
+      if (auto_npt && !force_npt) return build_analysis(p, A, st);   // the tile size was picked for the codes: redo
+    } else if (!p->win_stage && auto_npt && !force_npt && npt == 16) {
+      return build_analysis(p, A, st, 8);
     }
   }
   KK_HIP(hipStreamSynchronize(st));   // setup is synchronous, like the vendor analysis it replaces
@@ -1663,12 +1827,15 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
   if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_set: null plan");
   const int old_npt = plan->tune.nnz_per_thread, old_kernel = plan->tune.kernel, old_var = plan->tune.stream_variant;
+  const int old_win = plan->tune.window_codes;
   int rc = kk::set_tuning(plan->tune, key, value);
   if (rc) return rc;
   if (plan->tune.nnz_per_thread != old_npt || plan->tune.kernel != old_kernel ||
       (plan->tune.stream_variant == 2) != (old_var == 2) || (plan->tune.stream_variant == 4) != (old_var == 4) ||
-      (plan->tune.stream_variant == 6) != (old_var == 6)) {
+      (plan->tune.stream_variant == 6) != (old_var == 6) || (plan->tune.stream_variant == 1) != (old_var == 1) ||
+      plan->tune.window_codes != old_win) {
     // tiling changed: redo the analysis (needs the matrix again; rebuilt lazily from the stored row_map)
+    plan->win_failed = false;
     kkamd_crs_t A{};
     A.num_rows = plan->num_rows; A.num_cols = plan->num_cols; A.nnz = plan->nnz; A.d_row_map = plan->row_map;
     A.offset_type = plan->offset_type; A.value_type = KKAMD_F64;
@@ -1683,6 +1850,7 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   if (k == "tile") *value = plan->tile;
   else if (k == "tiles") *value = plan->nblocks;
   else if (k == "window_codes") *value = plan->d_wcode ? 1 : 0;
+  else if (k == "window_staged_x") *value = (plan->d_wcode && plan->win_stage && plan->tune.window_codes != 2) ? 1 : 0;
   else if (k == "transpose_cached") *value = plan->t_ready ? 1 : 0;
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
   return KKAMD_OK;

@@ -227,5 +227,5 @@ def window_code_cases():
     # uniformly random columns over a wide range: no tile is coverable
     out.append(("random-wide", oracle.random_crs(3000, 3000000, 9, variance=3, seed=5), 0))
     # 27-pt stencil (9 x-lines per tile) with nnz not a multiple of any tile size
-    out.append(("27pt", oracle.laplace3d("FE", 40, 37, 21), 1))
+    out.append(("27pt", oracle.laplace3d("FE", 24, 19, 13), 1))
     return out

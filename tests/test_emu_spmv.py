@@ -55,6 +55,20 @@ def test_window_codes(be):
             kn = {"nnz_per_thread": npt, "stream_variant": 6}
             pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=32.0, expect={"window_codes": ok})
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"stream_variant": 6}, max_val=32.0, expect={"window_codes": ok})
+        # the default kernel tries the codes by itself from window_codes_min_knnz on, and never with window_codes = 0
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0}, max_val=32.0, expect={"window_codes": ok, "tile": 2048})
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", max_val=32.0, expect={"window_codes": 0})
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "window_codes": 0}, max_val=32.0, expect={"window_codes": 0})
+        # window_codes 2: the codes without the staged x window
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"window_codes_min_knnz": 0, "window_codes": 2}, max_val=32.0,
+                      expect={"window_codes": ok, "window_staged_x": 0})
+    # contiguous column runs: the staged x window is used; a tile whose runs do not fit it keeps the gather
+    for A0, npt, staged in ((oracle.laplace3d("FE", 64, 40, 9), 8, 1), (oracle.laplace3d("FD", 70, 30, 12), 8, 1), (oracle.laplace3d("FE", 64, 40, 9), 4, 1),
+                            (oracle.laplace3d("FE", 64, 40, 9), 16, 1), (oracle.laplace2d("FD", 500, 37), 8, 1), (oracle.laplace3d("FE", 700, 5, 4), 16, 1),
+                            (pc.window_code_cases()[0][1], 8, 0)):
+        pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", nans=False, knobs={"stream_variant": 6, "nnz_per_thread": npt}, max_val=32.0,
+                      expect={"window_codes": 1, "window_staged_x": staged})
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"stream_variant": 6, "nnz_per_thread": npt}, max_val=32.0)
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"stream_variant": 6}, max_val=32.0, offset_dtype=np.int64,
                       value_dtype=np.float32, expect={"window_codes": ok})
 

@@ -75,6 +75,22 @@ def test_stream_variants(be, variant):
             pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"nnz_per_thread": npt, "stream_variant": variant}, max_val=32.0)
 
 
+def test_window_codes(be):
+    # 16-bit window codes for the columns: forced (stream_variant 6), picked by the default analysis, and the fall-back
+    for name, A0, ok in pc.window_code_cases():
+        for npt in (4, 8, 16):
+            pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs={"nnz_per_thread": npt, "stream_variant": 6}, max_val=32.0,
+                          expect={"window_codes": ok})
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"window_codes_min_knnz": 0}, max_val=32.0,
+                      offset_dtype=np.int64, value_dtype=np.float32, expect={"window_codes": ok})
+    A0 = oracle.laplace3d("FE", 60, 50, 40)            # 3.1e6 nnz: above the default threshold
+    pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, max_val=32.0, expect={"window_codes": 1, "tile": 2048})
+    pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_DEFAULT", knobs={"window_codes": 0}, max_val=32.0, expect={"window_codes": 0})
+    pc.check_spmv(be, A0, "T", 1.0, 1.0, "SPMV_DEFAULT", knobs={"explicit_transpose": 1}, max_val=32.0)
+    A0 = oracle.random_crs(200000, 3000000, 11, variance=4, seed=9)   # 2.2e6 nnz, no structure: plain entries
+    pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=1.0, expect={"window_codes": 0})
+
+
 def _custom(lens, ncols, seed=0):
     rng = np.random.default_rng(seed)
     lens = np.asarray(lens)
