@@ -219,6 +219,17 @@ def main():
                          "kernel": "kk::spmv_stream3_kernel (+ fix-up kernel), HIP events around the launch",
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        # What the plan really streams: with the analysis' 16-bit column codes the kernel reads 2 instead of 4 bytes of
+        # column information per nonzero (+256 B of window meta per tile); "achieved" stays on the CRS algorithmic bytes.
+        try:
+            h_ = handle if world == 1 else op.handle
+            if h_.query("window_codes"):
+                tile_ = h_.query("tile"); tiles_ = h_.query("tiles")
+                out["roofline"]["plan"] = {"column_codes": "16-bit window codes", "x_staged_in_lds": bool(h_.query("window_staged_x")),
+                                           "tile_nnz": tile_,
+                                           "streamed_bytes_per_launch": alg_bytes - nnz_local * 2 + tiles_ * 256}
+        except Exception:
+            pass
         # HBM traffic comes from the committed rocprofv3 PMC passes of this same command (it cannot be counted live)
         pmc = os.path.join(ROOT, "profiles", "round1", "bench_n1_pmc_hbm.json")
         if world == 1 and not args.n and not args.knob and os.path.exists(pmc):

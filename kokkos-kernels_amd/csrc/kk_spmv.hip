@@ -1618,7 +1618,7 @@ int check_crs(const kkamd_crs_t* A) {
 static int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   if (!p) return KKAMD_OK;
   if (p->num_rows != A->num_rows || p->num_cols != A->num_cols || p->nnz != A->nnz || p->row_map != A->d_row_map ||
-      p->offset_type != A->offset_type)
+      p->offset_type != A->offset_type || ((p->d_wcode || p->d_lidx) && p->entries != A->d_entries))
     return fail(KKAMD_ERR_STATE, "kkamd_spmv: plan was created for a different matrix (a handle is bound to one matrix)");
   return KKAMD_OK;
 }
