@@ -41,6 +41,22 @@ __host__ __device__ __forceinline__ int64_t xcd_remap(int64_t pid, int64_t nwg) 
   return x * q + (x < rem ? x : rem) + i;
 }
 
+// Grouped order: the launch is cut into blocks of 8*G consecutive logical tiles and XCD x takes G CONSECUTIVE tiles of
+// every block (physical workgroups b, b+8, ..., which are dispatched close in time).  Neighbouring tiles -- which share
+// x lines -- then meet in one L2, while all eight XCDs still sweep the same few-MB region of the matrix together (the DRAM
+// page locality the fully contiguous order gives up).  G a power of two; the incomplete last block keeps dispatch order.
+__host__ __device__ __forceinline__ int64_t xcd_group_order(int64_t pid, int64_t nwg, int G) {
+  const int sh = 3 + __builtin_ctz((unsigned)G);              // shifts only: G and the XCD count are powers of two
+  const int64_t blk = pid >> sh;
+  if (((blk + 1) << sh) > nwg) return pid;
+  const int within = (int)(pid & (((int64_t)1 << sh) - 1));
+  return (blk << sh) + (int64_t)(within & (kNumXcd - 1)) * G + (within >> 3);
+}
+// mode 0: dispatch order, 1: XCD-contiguous, >= 2: grouped with G = mode
+__host__ __device__ __forceinline__ int64_t xcd_order(int64_t pid, int64_t nwg, int mode) {
+  return mode == 0 ? pid : (mode == 1 ? xcd_remap(pid, nwg) : xcd_group_order(pid, nwg, mode));
+}
+
 // sum across the `width` lanes (power of two, <= 64) of an aligned lane group; result in every lane.
 template <class T> __device__ __forceinline__ T group_sum(T v, int width) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -55,6 +71,7 @@ int parse_mode(char mode, bool* trans);
 int spgemm_set_default(const char* key, int value);
 // kk_spmv_struct.hip: 1 = XCD-contiguous workgroup order in the interior kernel (knob "struct_remap")
 extern int g_struct_remap;
+extern int g_struct_group;        // kkamd_spmv_struct: grouped XCD order of the interior workgroups (0 = dispatch order)
 extern int g_struct_lds_pad_kb;  // measurement aid: extra dynamic LDS per interior workgroup (lowers occupancy)
 
 template <class T> struct scalar_tag;

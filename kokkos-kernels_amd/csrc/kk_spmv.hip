@@ -31,7 +31,8 @@ struct SpmvTuning {
   int kernel         = 0;  // 0 auto, 1 vector, 2 stream
   int lanes_per_row  = 0;  // vector kernel, 0 = auto
   int nnz_per_thread = 0;  // stream kernel: 4, 8 or 16 (0 = 16 for fp64, 8 otherwise)
-  int xcd_remap      = 0;  // measured: round-robin tile order (all XCDs sweep the same region) beats XCD-contiguous by ~3-8%
+  int xcd_remap      = 16; // tile order of the nnz-split kernel: 0 dispatch order (tile b on XCD b % 8), 1 XCD-contiguous (3-8 % slower than 0),
+                           // G >= 2 grouped (G consecutive tiles per XCD inside blocks of 8G tiles; 16: 1.37 -> 1.29 ms on C2, 7-pt 400^3 -7 %)
   int nontemporal    = 0;  // measured: no consistent gain from nt loads on the value/column streams
   int mv_kernel      = 0;  // reserved for rank-2 variants
   int stream_variant = 1;  // 1 lean kernel + quad-dealt gathers (default), 3 same with natural gather layout,
@@ -39,7 +40,7 @@ struct SpmvTuning {
   int wg_per_cu      = 0;  // unused (persistent variant measured slower and was removed)
   int ablate         = 0;  // bench-only: 1 no x gather, 2 no LDS/reduce, 3 both
   int lds_pad_kb     = 0;  // bench-only: extra dynamic LDS per workgroup (caps workgroups per CU)
-  int mv_remap       = 0;  // rank-2: 1 = XCD-contiguous workgroup order (higher L2 hit rate, yet measured 5-7 % slower: 7.92 vs 7.36 ms on C3)
+  int mv_remap       = 16; // rank-2: 0 dispatch order, 1 XCD-contiguous (no faster than 0), 4 / 8 / 16 / ... grouped (16: 5.60 -> 4.76 ms on C3)
   int explicit_transpose = 0;   // modes T/H with an analysed handle: 1 = cache A^T (structure + permutation) in the plan, refresh its
                                 // values every call and run the N kernel on it; 2 = same, the caller promises constant values (no refresh)
   int explicit_transpose_min_knnz = 1000;   // ... from this many thousand nnz
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   constexpr int STEPS = NPT / 2;
   __shared__ YT prod[TILE];
   const int t     = threadIdx.x;
-  const int64_t b = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t b = xcd_order(blockIdx.x, gridDim.x, remap);
   const int64_t s = b * TILE;
   const bool full = (s + TILE <= nnz);
   const int64_t e = full ? s + TILE : nnz;
@@ -1099,7 +1100,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
   const int lane64 = threadIdx.x & 63, w = threadIdx.x >> 6;
   AT* s_val  = s_val_all[w];
   int* s_col = s_col_all[w];
-  const int64_t wg   = (remap & 1) ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t wg   = xcd_order(blockIdx.x, gridDim.x, (remap & 1) ? 1 : (remap & ~3));   // 1 contiguous, 4 / 8 / 16 grouped
   const int64_t row0 = (wg * (kBlock / kWave) + w) * RW;
   if (row0 >= nrows) return;                                   // whole wave leaves together
   const int64_t rowN = (row0 + RW < nrows) ? row0 + RW : nrows;
@@ -1262,7 +1263,7 @@ static int launch_vector(const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT 
 
 template <class OffT, class AT, class YT>
 static int run_vector(const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, const SpmvTuning& tn, hipStream_t st) {
-  const int remap = tn.xcd_remap;
+  const int remap = tn.xcd_remap == 1;                      // the grouped orders (>= 2) belong to the nnz-split kernel
   switch (pick_lpr(A->num_rows, A->nnz, tn.lanes_per_row)) {
     case 1:  return launch_vector<OffT, AT, YT, 1>(A, x, y, alpha, beta, remap, st);
     case 2:  return launch_vector<OffT, AT, YT, 2>(A, x, y, alpha, beta, remap, st);
@@ -1283,7 +1284,7 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
   if (variant == 0) {
     KK_LAUNCH((spmv_stream_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate);
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap == 1, p->tune.ablate);
   } else if (variant == 2) {
     KK_LAUNCH((spmv_wave_kernel<OffT, AT, YT, NPT, NT>), (unsigned)ceil_div(p->nblocks, kBlock / kWave), kBlock, 0, st, A->nnz,
               p->nblocks, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
@@ -1296,7 +1297,7 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
   } else if (variant == 5) {
     KK_LAUNCH((spmv_stream6_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap);
+              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap == 1);
   } else if ((variant == 6 || variant == 1) && p->d_wcode) {
     if (p->win_stage && p->tune.window_codes != 2) {
       KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, true, 2>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
@@ -1534,7 +1535,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
   const YT alpha = (YT)alpha_d, beta = (YT)beta_d;
   const YT* X    = (const YT*)dX;
   YT* Y          = (YT*)dY;
-  const int remap = plan ? plan->tune.xcd_remap : g_spmv_default.xcd_remap;
+  const int remap = (plan ? plan->tune.xcd_remap : g_spmv_default.xcd_remap) == 1;
   if (trans) {
     int rc = launch_scale<YT>(Y, A->num_cols, ys0, nvec, ys1, beta, st);
     if (rc) return rc;
@@ -1776,6 +1777,7 @@ int kkamd_device_info(char* name, int name_len, int* is_gfx950, int* num_cus) {
 int kkamd_set_default(const char* key, int value) {
   if (key && std::strncmp(key, "spgemm_", 7) == 0) return kk::spgemm_set_default(key, value);
   if (key && std::strcmp(key, "struct_remap") == 0) { kk::g_struct_remap = value; return KKAMD_OK; }
+  if (key && std::strcmp(key, "struct_group") == 0) { kk::g_struct_group = value; return KKAMD_OK; }
   if (key && std::strcmp(key, "struct_lds_pad_kb") == 0) { kk::g_struct_lds_pad_kb = value; return KKAMD_OK; }
   return kk::set_tuning(kk::g_spmv_default, key, value);
 }

@@ -34,6 +34,7 @@ struct StencilDesc {
 };
 
 int g_struct_remap = 0;
+int g_struct_group = 0;
 int g_struct_lds_pad_kb = 0;
 
 static int make_stencil(int stencil_type, int ndim, const int64_t* st, StencilDesc* d) {
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
   const int t = threadIdx.x;
   // 32-bit index arithmetic on purpose: 64-bit divisions cost ~100 scalar instructions each at the start of every wave
   unsigned bid = blockIdx.x;
+  if (remap >> 8) bid = (unsigned)xcd_group_order(bid, gridDim.x, remap >> 8);
   if (remap & 1) {  // XCD-contiguous order (knob struct_remap): workgroup b runs on XCD b % 8, give each XCD one slab of the grid
     const unsigned q = gridDim.x / kNumXcd, rem = gridDim.x % kNumXcd, xc = bid % kNumXcd;
     bid = xc * q + (xc < rem ? xc : rem) + bid / kNumXcd;
@@ -260,9 +262,9 @@ static int spmv_struct_typed(const StencilDesc& d, const kkamd_crs_t* A, double 
 #define KK_STRUCT_LAUNCH(ND, STT)                                                                                          \
   do {                                                                                                                     \
     if (use64) KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 64>), (unsigned)(pencils * cpp), 128, (size_t)g_struct_lds_pad_kb * 1024, st, ni, nj, \
-                         (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap);                                                    \
+                         (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap | (g_struct_group << 8));                                                    \
     else KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 128>), (unsigned)(pencils * cpp), 256, (size_t)g_struct_lds_pad_kb * 1024, st, ni, nj,      \
-                   (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap);                                                          \
+                   (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap | (g_struct_group << 8));                                                          \
   } while (0)
     if (d.ndim == 1) KK_STRUCT_LAUNCH(1, 1);
     else if (d.ndim == 2 && d.S == 5) KK_STRUCT_LAUNCH(2, 1);

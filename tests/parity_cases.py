@@ -65,7 +65,7 @@ def check_spmv(be, A0, mode="N", alpha=1.0, beta=0.0, algo=None, nans=False, see
     assert ok, "spmv mismatch mode=%s alpha=%g beta=%g algo=%s: max err %g > tol %g" % (mode, alpha, beta, algo, err, tol)
 
 
-def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_order="F", algo=None, seed=0):
+def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_order="F", algo=None, seed=0, knobs=None):
     rng = np.random.default_rng(seed)
     trans = mode in "TH"
     nin, nout = (A0.nrows, A0.ncols) if trans else (A0.ncols, A0.nrows)
@@ -76,7 +76,10 @@ def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_or
     if algo is None:
         kk.spmv(mode, alpha, A, Xd, beta, Yd)
     else:
-        kk.spmv(kk.SPMVHandle(algo), mode, alpha, A, Xd, beta, Yd)
+        h = kk.SPMVHandle(algo)
+        for k_, v_ in (knobs or {}).items():
+            h.set(k_, v_)
+        kk.spmv(h, mode, alpha, A, Xd, beta, Yd)
     got = _to_host_2d(be, Yd)
     exp = oracle.spmv_mv_serial(mode, A0, alpha, X, beta, Y0.copy(order="K"))
     tol = oracle.spmv_max_error(A0, alpha, beta)

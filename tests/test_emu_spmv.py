@@ -73,6 +73,16 @@ def test_window_codes(be):
                       value_dtype=np.float32, expect={"window_codes": ok})
 
 
+def test_xcd_group_orders(be):
+    # grouped tile orders (xcd_remap / mv_remap = G): whole blocks of 8G tiles are permuted, the incomplete last block is not
+    for nrows in (64 * 15 + 5, 64 * 16, 64 * 17 + 1, 64 * 130):
+        A0 = oracle.random_crs(nrows, nrows + 7, 16, variance=0, seed=nrows)       # 1024-nnz tiles: nrows / 64 of them
+        for g in (2, 16, 32, 0):
+            pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs={"nnz_per_thread": 4, "xcd_remap": g}, expect={"tile": 1024})
+        for g in (4, 16, 0):
+            pc.check_spmv_mv(be, A0, 4, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_remap": g})
+
+
 def _custom(lens, ncols, seed=0):
     rng = np.random.default_rng(seed)
     lens = np.asarray(lens)
