@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
   }
 }
 
-template <class AT, int STEPS, bool FULL>
+template <class AT, int STEPS, bool FULL, bool NT = false>
 __device__ __forceinline__ void load_tile_values(const AT* __restrict__ values, int64_t ts, int64_t te, int t, AT (&v0)[STEPS],
                                                  AT (&v1)[STEPS]) {
   using AV = typename vec2<AT>::type;
@@ -309,7 +309,8 @@ __device__ __forceinline__ void load_tile_values(const AT* __restrict__ values, 
   for (int k = 0; k < STEPS; ++k) {
     const int64_t idx = ts + (int64_t)k * SPAN + t * 2;
     if (FULL || idx + 1 < te) {
-      const AV vv = *reinterpret_cast<const AV*>(values + idx);
+      const AV* vp = reinterpret_cast<const AV*>(values + idx);
+      const AV vv  = NT ? KK_NT_LOAD(vp) : *vp;
       v0[k] = vv[0]; v1[k] = vv[1];
     } else if (idx < te) {
       v0[k] = values[idx]; v1[k] = AT(0);
@@ -320,20 +321,22 @@ __device__ __forceinline__ void load_tile_values(const AT* __restrict__ values, 
 }
 
 // the 2*STEPS codes of work-item t, two per 32-bit word (nonzero 2k of the item in the low half of word k)
-template <int STEPS>
+template <int STEPS, bool NT = false>
 __device__ __forceinline__ void load_tile_codes(const uint16_t* __restrict__ wcode, int64_t ts, int t, unsigned (&w)[STEPS]) {
   constexpr int NPT = 2 * STEPS;
   const unsigned* cw = reinterpret_cast<const unsigned*>(wcode + ts + (int64_t)t * NPT);   // 4*STEPS bytes, aligned
   if (STEPS % 4 == 0) {
     KK_UNROLL
     for (int k = 0; k < STEPS; k += 4) {
-      const kk_u32x4 q = *reinterpret_cast<const kk_u32x4*>(cw + k);
+      const kk_u32x4* qp = reinterpret_cast<const kk_u32x4*>(cw + k);
+      const kk_u32x4 q   = NT ? KK_NT_LOAD(qp) : *qp;
       w[k] = q[0]; w[k + 1] = q[1]; w[k + 2] = q[2]; w[k + 3] = q[3];
     }
   } else {
     KK_UNROLL
     for (int k = 0; k < STEPS; k += 2) {
-      const kk_u32x2 q = *reinterpret_cast<const kk_u32x2*>(cw + k);
+      const kk_u32x2* qp = reinterpret_cast<const kk_u32x2*>(cw + k);
+      const kk_u32x2 q   = NT ? KK_NT_LOAD(qp) : *qp;
       w[k] = q[0]; w[k + 1] = q[1];
     }
   }
@@ -364,7 +367,7 @@ __device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, con
 
 // Staged-x tile: values, codes, meta and the x chunks are all requested before anything is waited for; the x chunks go to
 // LDS (aliasing the product array), every work-item then picks its x entries out of LDS and the products replace them.
-template <class AT, class YT, int STEPS, bool FULL>
+template <class AT, class YT, int STEPS, bool FULL, bool NT>
 __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values, const uint16_t* __restrict__ wcode,
                                                    const int32_t* __restrict__ wmeta, const YT* __restrict__ x, int64_t ncols,
                                                    YT* prod, int64_t b, int64_t ts, int64_t te, int t) {
@@ -375,8 +378,8 @@ __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values
   unsigned w[STEPS];
   const int lane = t & 63, wave = t >> 6;
   const int meta = wmeta[b * kWinMeta + lane];
-  load_tile_codes<STEPS>(wcode, ts, t, w);
-  load_tile_values<AT, STEPS, FULL>(values, ts, te, t, v0, v1);
+  load_tile_codes<STEPS, NT>(wcode, ts, t, w);
+  load_tile_values<AT, STEPS, FULL, NT>(values, ts, te, t, v0, v1);
   YT xv[CPW];
   KK_UNROLL
   for (int i = 0; i < CPW; ++i) {
@@ -633,8 +636,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   }
 
   if (WIN == 2) {
-    if (full) stage_products_win<AT, YT, STEPS, true>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
-    else      stage_products_win<AT, YT, STEPS, false>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
+    if (full) stage_products_win<AT, YT, STEPS, true, NT>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
+    else      stage_products_win<AT, YT, STEPS, false, NT>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
   } else {
     if (full) stage_products<AT, YT, STEPS, true, QP>(x, prod, t, v0, v1, c0, c1);
     else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
@@ -1300,7 +1303,7 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
               (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap == 1);
   } else if ((variant == 6 || variant == 1) && p->d_wcode) {
     if (p->win_stage && p->tune.window_codes != 2) {
-      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, true, 2>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true, 2>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
                 (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
                 (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
                 (const int32_t*)p->d_wbase, A->num_cols);
