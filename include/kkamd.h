@@ -113,13 +113,15 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
 /* Expert knobs, the analogue of SPMVHandleImpl's public tuning members
  * (sparse/src/KokkosSparse_spmv_handle.hpp:243-252); per plan, or as defaults for plans created later.
  *   SpMV   "kernel" (0 auto, 1 no-analysis vector kernel), "lanes_per_row", "nnz_per_thread" (4 | 8 | 16, 0 = by size),
+ *          "window_codes" (1: analysed handles try the 16-bit column codes + LDS-staged x from "window_codes_min_knnz" thousand
+ *                          nnz, 2: codes without staged x, 0: never),
  *          "stream_variant" (1 default; 6 = 16-bit window codes for the columns, built by the analysis when every tile's
- *                            columns fit 16 windows of 4096, else the plan behaves like 1), "xcd_remap", "nontemporal",
+ *                            columns fit 16 windows of 4096, else the plan behaves like 1), "xcd_remap" (tile order: 0 dispatch, 1 XCD-contiguous, G >= 2 grouped; default 16), "nontemporal",
  *          "transient_min_knnz"  handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 never),
  *          "explicit_transpose"  modes T/H through a transpose cached in the plan: 0 off (atomic scatter, default),
  *                                1 refresh the transposed values every call, 2 caller promises constant values,
  *          "explicit_transpose_min_knnz",
- *          "mv_kernel", "mv_remap" (rank-2 kernels); "struct_remap" (kkamd_spmv_struct, global only); "ablate", "lds_pad_kb" are measurement aids.
+ *          "mv_kernel", "mv_remap" (rank-2 kernels); "struct_remap", "struct_group", "struct_strip" (kkamd_spmv_struct workgroup orders, global only, all off); "ablate", "lds_pad_kb" are measurement aids.
  *   SpGEMM (kkamd_set_default only) "spgemm_win_bits" (columns per LDS bitmap pass), "spgemm_val_cap", "spgemm_val_shape",
  *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_debug" (ablation bits). */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);

@@ -71,6 +71,7 @@ int parse_mode(char mode, bool* trans);
 int spgemm_set_default(const char* key, int value);
 // kk_spmv_struct.hip: 1 = XCD-contiguous workgroup order in the interior kernel (knob "struct_remap")
 extern int g_struct_remap;
+extern int g_struct_strip;        // kkamd_spmv_struct: lines per XCD strip of the strip order (0 = off)
 extern int g_struct_group;        // kkamd_spmv_struct: grouped XCD order of the interior workgroups (0 = dispatch order)
 extern int g_struct_lds_pad_kb;  // measurement aid: extra dynamic LDS per interior workgroup (lowers occupancy)
 

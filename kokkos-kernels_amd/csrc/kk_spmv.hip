@@ -1781,6 +1781,7 @@ int kkamd_set_default(const char* key, int value) {
   if (key && std::strncmp(key, "spgemm_", 7) == 0) return kk::spgemm_set_default(key, value);
   if (key && std::strcmp(key, "struct_remap") == 0) { kk::g_struct_remap = value; return KKAMD_OK; }
   if (key && std::strcmp(key, "struct_group") == 0) { kk::g_struct_group = value; return KKAMD_OK; }
+  if (key && std::strcmp(key, "struct_strip") == 0) { kk::g_struct_strip = value; return KKAMD_OK; }
   if (key && std::strcmp(key, "struct_lds_pad_kb") == 0) { kk::g_struct_lds_pad_kb = value; return KKAMD_OK; }
   return kk::set_tuning(kk::g_spmv_default, key, value);
 }

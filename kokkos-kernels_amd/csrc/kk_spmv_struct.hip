@@ -35,6 +35,7 @@ struct StencilDesc {
 
 int g_struct_remap = 0;
 int g_struct_group = 0;
+int g_struct_strip = 0;
 int g_struct_lds_pad_kb = 0;
 
 static int make_stencil(int stencil_type, int ndim, const int64_t* st, StencilDesc* d) {
@@ -119,7 +120,7 @@ template <class OffT, class AT, class YT, int NDIM, int ST, int R>
 __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni, int64_t nj, int chunks_per_pencil,
                                                                       const OffT* __restrict__ rm, const AT* __restrict__ val,
                                                                       const YT* __restrict__ x, YT* __restrict__ y, YT alpha,
-                                                                      YT beta, int remap) {
+                                                                      YT beta, int remap, int nkm) {
   using St = Stencil<NDIM, ST>;
   constexpr int S = St::S, NL = St::NL, NT = 2 * R;
   constexpr int HS  = (S + 1) / 2;                             // first stencil half
@@ -134,10 +135,23 @@ __global__ __launch_bounds__(2 * R) void spmv_struct_interior_kernel(int64_t ni,
     const unsigned q = gridDim.x / kNumXcd, rem = gridDim.x % kNumXcd, xc = bid % kNumXcd;
     bid = xc * q + (xc < rem ? xc : rem) + bid / kNumXcd;
   }
-  const unsigned pencil = bid / (unsigned)chunks_per_pencil;
-  const int chunk       = (int)(bid - pencil * (unsigned)chunks_per_pencil);
+  unsigned pencil = bid / (unsigned)chunks_per_pencil;
+  int chunk       = (int)(bid - pencil * (unsigned)chunks_per_pencil);
   int64_t j = 0, k = 0;
-  if (NDIM == 2) j = (int64_t)pencil + 1;
+  const unsigned JL = (unsigned)(remap >> 16) & 0xffu;
+  if (NDIM >= 2 && JL) {
+    // Strip order (knob struct_strip): workgroup b runs on XCD b % 8; that XCD owns, inside every block of 8*JL grid lines,
+    // the JL consecutive lines of its strip and walks them plane after plane (chunk fastest, then line, then k).  The x
+    // lines of planes k and k+1 it just used are still in ITS L2 when it gets to plane k+1, so x crosses the fabric about
+    // once instead of once per XCD, while the eight XCDs together still sweep one 8*JL-line region of one plane at a time.
+    const unsigned xc = bid & (kNumXcd - 1), seq = bid >> 3, cpp = (unsigned)chunks_per_pencil;
+    const unsigned q1 = seq / cpp, q2 = q1 / JL, jb = q2 / (unsigned)nkm;
+    chunk = (int)(seq - q1 * cpp);
+    const unsigned jq = (jb * kNumXcd + xc) * JL + (q1 - q2 * JL), kq = q2 - jb * (unsigned)nkm;
+    if (jq >= (unsigned)(nj - 2)) return;                      // the last block of lines is padded: the whole workgroup leaves
+    j = (int64_t)jq + 1;
+    k = (NDIM == 3) ? (int64_t)kq + 1 : 0;
+  } else if (NDIM == 2) j = (int64_t)pencil + 1;
   else if (NDIM == 3) { const unsigned njm = (unsigned)(nj - 2), kq = pencil / njm; k = (int64_t)kq + 1; j = (int64_t)(pencil - kq * njm) + 1; }
   const int64_t i0   = 1 + (int64_t)chunk * R;                 // first interior i of this chunk
   const int nr       = (int)((ni - 1 - i0 < R) ? ni - 1 - i0 : R);
@@ -259,12 +273,18 @@ static int spmv_struct_typed(const StencilDesc& d, const kkamd_crs_t* A, double 
     const int64_t cpp = use64 ? c64 : c128;
     if (pencils * cpp > INT32_MAX) return fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: grid too large");
     num_int = interior * pencils;
+    // strip order (see the kernel): the lines are padded to whole blocks of 8 * strip
+    const int strip    = (d.ndim >= 2 && nj - 2 >= 8 * g_struct_strip) ? (g_struct_strip & 0xff) : 0;
+    const int64_t nkm  = d.ndim == 3 ? nk - 2 : 1;
+    const int64_t nwg  = strip ? ceil_div(nj - 2, (int64_t)kNumXcd * strip) * kNumXcd * strip * nkm * cpp : pencils * cpp;
+    if (nwg > INT32_MAX) return fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_struct: grid too large");
+    const int flags    = g_struct_remap | (g_struct_group << 8) | (strip << 16);
 #define KK_STRUCT_LAUNCH(ND, STT)                                                                                          \
   do {                                                                                                                     \
-    if (use64) KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 64>), (unsigned)(pencils * cpp), 128, (size_t)g_struct_lds_pad_kb * 1024, st, ni, nj, \
-                         (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap | (g_struct_group << 8));                                                    \
-    else KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 128>), (unsigned)(pencils * cpp), 256, (size_t)g_struct_lds_pad_kb * 1024, st, ni, nj,      \
-                   (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, g_struct_remap | (g_struct_group << 8));                                                          \
+    if (use64) KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 64>), (unsigned)nwg, 128, (size_t)g_struct_lds_pad_kb * 1024, st, ni, nj, \
+                         (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, flags, (int)nkm);                                   \
+    else KK_LAUNCH((spmv_struct_interior_kernel<OffT, AT, YT, ND, STT, 128>), (unsigned)nwg, 256, (size_t)g_struct_lds_pad_kb * 1024, st, ni, nj,      \
+                   (int)cpp, rm, val, x, y, (YT)alpha, (YT)beta, flags, (int)nkm);                                         \
   } while (0)
     if (d.ndim == 1) KK_STRUCT_LAUNCH(1, 1);
     else if (d.ndim == 2 && d.S == 5) KK_STRUCT_LAUNCH(2, 1);

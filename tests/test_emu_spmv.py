@@ -59,6 +59,8 @@ def test_window_codes(be):
         pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0}, max_val=32.0, expect={"window_codes": ok, "tile": 2048})
         pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", max_val=32.0, expect={"window_codes": 0})
         pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "window_codes": 0}, max_val=32.0, expect={"window_codes": 0})
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"stream_variant": 6}, max_val=32.0, offset_dtype=np.int64,
+                      value_dtype=np.float32, expect={"window_codes": ok})
         # window_codes 2: the codes without the staged x window
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"window_codes_min_knnz": 0, "window_codes": 2}, max_val=32.0,
                       expect={"window_codes": ok, "window_staged_x": 0})
@@ -69,8 +71,8 @@ def test_window_codes(be):
         pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", nans=False, knobs={"stream_variant": 6, "nnz_per_thread": npt}, max_val=32.0,
                       expect={"window_codes": 1, "window_staged_x": staged})
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"stream_variant": 6, "nnz_per_thread": npt}, max_val=32.0)
-        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"stream_variant": 6}, max_val=32.0, offset_dtype=np.int64,
-                      value_dtype=np.float32, expect={"window_codes": ok})
+        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"stream_variant": 6, "nnz_per_thread": npt}, max_val=32.0, offset_dtype=np.int64,
+                      value_dtype=np.float32, expect={"window_codes": 1})
 
 
 def test_xcd_group_orders(be):
@@ -181,6 +183,20 @@ def test_mv_long_rows_chunked_staging(be):
                          [(d, 2) for d in pc.STRUCT_CASES_2D + pc.STRUCT_CASES_3D[2:]])
 def test_spmv_struct_reference_cases(be, dims, st):
     pc.check_spmv_struct(be, dims, st)
+
+
+def test_spmv_struct_strip_order(be):
+    # strip order of the interior workgroups (knob struct_strip = lines per XCD strip): padded last block of lines, 2-D and 3-D
+    def setk(v): pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(b"struct_strip", v))
+    try:
+        for strip in (1, 2, 8, 0):
+            setk(strip)
+            pc.check_spmv_struct(be, (12, 21, 5), 2)
+            pc.check_spmv_struct(be, (12, 21, 5), 1, offset_dtype=np.int64)
+            pc.check_spmv_struct(be, (40, 19), 2)
+            pc.check_spmv_struct(be, (140, 5, 4), 2)                   # fewer lines than one block: the order is not applied
+    finally:
+        setk(0)
 
 
 def test_spmv_struct_variants(be):

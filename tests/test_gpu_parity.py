@@ -203,6 +203,20 @@ def test_spmv_struct_reference_cases(be, dims, st):
     pc.check_spmv_struct(be, dims, st)
 
 
+def test_spmv_struct_strip_order(be):
+    # strip order of the interior workgroups (knob struct_strip = lines per XCD strip): padded last block of lines, 2-D and 3-D
+    def setk(v): pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(b"struct_strip", v))
+    try:
+        for strip in (1, 2, 8, 0):
+            setk(strip)
+            pc.check_spmv_struct(be, (70, 37, 21), 2)
+            pc.check_spmv_struct(be, (70, 37, 21), 1, offset_dtype=np.int64)
+            pc.check_spmv_struct(be, (300, 90), 2)
+            pc.check_spmv_struct(be, (140, 5, 4), 2)                   # fewer lines than one block: the order is not applied
+    finally:
+        setk(0)
+
+
 def test_spmv_struct_variants(be):
     pc.check_spmv_struct(be, (300, 40, 7), 2)                      # three 128-row chunks per grid line
     pc.check_spmv_struct(be, (515, 33), 1, offset_dtype=np.int64)
