@@ -25,7 +25,7 @@ def hubby(rng, n, ncols, base, nhubs, hublen, sort=True):
         ent[rm[i]:rm[i + 1]] = np.sort(c) if sort else c
     return oracle.Crs(n, ncols, rm, ent, 1 + 49 * rng.random(rm[-1]))
 while time.time() < t_end:
-    rng = np.random.default_rng(seed0 + case); kind = case % 7; case += 1
+    rng = np.random.default_rng(seed0 + case); kind = case % 8; case += 1
     odt = np.int64 if rng.random() < 0.5 else np.int32
     vdt = np.float32 if rng.random() < 0.3 else np.float64
     try:
@@ -61,6 +61,31 @@ while time.time() < t_end:
             B = hubby(rng, n, k, int(rng.integers(2, 12)), int(rng.integers(0, 4)), int(rng.integers(300, 3000)))
             A = hubby(rng, int(rng.integers(2, 12)), n, 3, int(rng.integers(1, 4)), int(rng.integers(600, min(n, 6500))))
             pc.check_spgemm(be, A, B, offset_dtype=odt, value_dtype=vdt)
+        elif kind == 7:    # SpMV through an analysed handle with the 16-bit window codes forced on: structured, clustered, banded, random
+            sub = int(rng.integers(0, 4))
+            if sub == 0:       # several diagonals at random offsets
+                n = int(rng.integers(500, 30000)); nc = int(rng.integers(n, 40 * n)); step = max(1, nc // n)
+                offs = np.unique(rng.integers(0, nc - step * n + 1, size=int(rng.integers(2, 30))))
+                cols = np.arange(n)[:, None] * step + offs[None, :]
+                rm = np.arange(n + 1, dtype=np.int64) * len(offs)
+                M = oracle.Crs(n, nc, rm, cols.reshape(-1).astype(np.int32), 1 + rng.random(n * len(offs)))
+            elif sub == 1:     # k column clusters per row
+                n = int(rng.integers(300, 8000)); k = int(rng.integers(1, 22)); width = int(rng.integers(1, 5000)); gap = int(rng.integers(width, 30000))
+                cols = np.sort((np.arange(k)[None, :] * gap + rng.integers(0, width, (n, k))).astype(np.int32), axis=1)
+                M = oracle.Crs(n, gap * k + 1, np.arange(n + 1, dtype=np.int64) * k, cols.reshape(-1), 1 + rng.random(n * k))
+            elif sub == 2:     # stencils
+                nd = int(rng.integers(2, 4)); dims = tuple(int(rng.integers(3, 400 if nd == 2 else 60)) for _ in range(nd))
+                st = "FE" if rng.random() < 0.5 else "FD"
+                M = oracle.laplace2d(st, *dims) if nd == 2 else oracle.laplace3d(st, *dims)
+            else:              # banded random with duplicates / unsorted rows
+                n = int(rng.integers(200, 20000))
+                M = oracle.random_crs(n, n + int(rng.integers(0, 50)), int(rng.integers(1, 40)), variance=int(rng.integers(0, 10)), seed=int(rng.integers(1, 1 << 30)),
+                                      bandwidth=int(rng.integers(5, 3000)))
+            knobs = {"window_codes_min_knnz": 0, "window_codes": int(rng.integers(1, 3)), "nnz_per_thread": int(rng.choice([0, 4, 8, 16])),
+                     "xcd_remap": int(rng.choice([0, 1, 2, 16]))}
+            for beta in (0.0, float(rng.integers(-2, 3))):
+                pc.check_spmv(be, M, "N", float(rng.integers(-3, 4)), beta, algo="SPMV_DEFAULT", offset_dtype=odt, max_val=50.0, seed=case, knobs=knobs,
+                              nans=(beta == 0.0), value_dtype=(vdt if vdt == np.float32 and rng.random() < 0.5 else None))
         else:              # spmv_struct, random grids
             nd = int(rng.integers(1, 4)); dims = tuple(int(rng.integers(3, 300 if nd == 1 else (150 if nd == 2 else 40))) for _ in range(nd))
             pc.check_spmv_struct(be, dims, 1 if nd == 1 else int(rng.integers(1, 3)), offset_dtype=odt, seed=case)
