@@ -634,6 +634,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
     if (ablate & 16) { rs = s + (int64_t)grp * 27; re = rs + 27; }
     else { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
   }
+  // beta != 0: the old y of the first pass' rows is requested now, with everything else, instead of right before the store
+  YT yold = YT(0);
+  if (beta != YT(0) && valid && lane == 0 && r >= 0) yold = y[r];
 
   if (WIN == 2) {
     if (full) stage_products_win<AT, YT, STEPS, true, NT>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
       else if (!complete) carry_tail[b] = sum;
       else if (!(ablate & 4)) {
         sum *= alpha;
-        const YT out = (beta == YT(0)) ? sum : beta * y[r] + sum;
+        const YT out = (beta == YT(0)) ? sum : beta * (base == 0 ? yold : y[r]) + sum;
         y[r] = out;
       }
     }
