@@ -1306,7 +1306,7 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
               (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap == 1);
   } else if ((variant == 6 || variant == 1) && p->d_wcode) {
     if (p->win_stage && p->tune.window_codes != 2) {
-      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true, 2>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
+      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true, 2>), (unsigned)p->nblocks, kBlock, (size_t)p->tune.lds_pad_kb * 1024, st, A->nnz,
                 (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
                 (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
                 (const int32_t*)p->d_wbase, A->num_cols);
