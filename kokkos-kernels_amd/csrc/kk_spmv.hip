@@ -1737,8 +1737,18 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
     int h_fails[2] = {0, 0};
     KK_HIP(hipMalloc((void**)&d_fail, 2 * sizeof(int)));
     KK_HIP(hipMemsetAsync(d_fail, 0, 2 * sizeof(int), st));
-    KK_HIP(hipMalloc((void**)&p->d_wcode, sizeof(uint16_t) * (size_t)p->nblocks * (size_t)p->tile));
-    KK_HIP(hipMalloc((void**)&p->d_wbase, sizeof(int32_t) * (size_t)p->nblocks * kWinMeta));
+    // the codes are an optimisation: if HBM cannot hold them (2 bytes per nonzero) the plan simply keeps reading entries
+    if (hipMalloc((void**)&p->d_wcode, sizeof(uint16_t) * (size_t)p->nblocks * (size_t)p->tile) != hipSuccess ||
+        hipMalloc((void**)&p->d_wbase, sizeof(int32_t) * (size_t)p->nblocks * kWinMeta) != hipSuccess) {
+      (void)hipGetLastError();
+      if (p->d_wcode) { (void)hipFree(p->d_wcode); p->d_wcode = nullptr; }
+      p->d_wbase = nullptr;
+      (void)hipFree(d_fail);
+      p->win_failed = true;
+      if (auto_npt && !force_npt) return build_analysis(p, A, st);
+      KK_HIP(hipStreamSynchronize(st));
+      return KKAMD_OK;
+    }
     if (npt == 16)     { KK_LAUNCH((win_build_kernel<16>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
     else if (npt == 8) { KK_LAUNCH((win_build_kernel<8>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
     else               { KK_LAUNCH((win_build_kernel<4>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
