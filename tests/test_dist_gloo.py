@@ -22,6 +22,8 @@ def _worker(rank, world, port, ragged, exchange, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     be = emu_backend.backend()
+    # the slab plans (whole slab, interior and boundary views) take the 16-bit column codes even at this size
+    kk._capi.check(be.lib, be.lib.kkamd_set_default(b"window_codes_min_knnz", 0))
     nx, ny, nz = 9, 8, 7
     A0 = oracle.laplace3d("FE", nx, ny, nz)
     n = A0.nrows
