@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   // WIN 1: the columns come from the plan's 16-bit window codes (wcode, wmeta) instead of entries; WIN 2: x is staged
   // in LDS from the tile's contiguous column ranges as well (stage_products_win)
   // ablate (diagnosis knob, 0 in production; results in DESIGN.md 4.1): 4 = no y stores, 8 = no LDS reduction
-  // loop, 16 = synthetic row bounds (no row_map loads), 32 = no barrier
+  // loop, 16 = synthetic row bounds (no row_map loads), 32 = no barrier, 64 / 128 = y-store experiments (see the store)
   constexpr int TILE  = kBlock * NPT;
   constexpr int STEPS = NPT / 2;
   __shared__ YT prod[TILE];
@@ -661,10 +661,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
     if (valid && lane == 0) {
       if (is_head) carry_head[b] = sum;
       else if (!complete) carry_tail[b] = sum;
-      else if (!(ablate & 4)) {
+      else if (!(ablate & 4) && !((ablate & 64) && (b & 7))) {       // 64: only one tile in eight stores its rows
         sum *= alpha;
         const YT out = (beta == YT(0)) ? sum : beta * (base == 0 ? yold : y[r]) + sum;
-        y[r] = out;
+        y[(ablate & 128) ? (r & 255) : r] = out;                         // 128: every store lands in the same 2 KB
       }
     }
   }
