@@ -115,6 +115,8 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *   SpMV   "kernel" (0 auto, 1 no-analysis vector kernel), "lanes_per_row", "nnz_per_thread" (4 | 8 | 16, 0 = by size),
  *          "window_codes" (1: analysed handles try the 16-bit column codes + LDS-staged x from "window_codes_min_knnz" thousand
  *                          nnz, 2: codes without staged x, 0: never),
+ *          "pattern_codes" (staged-x plans: row-pattern records instead of per-nonzero codes; 0 off (default), 1 when >= 90 % of the
+ *                           tiles decompose, 2 whenever one does),
  *          "stream_variant" (1 default; 6 = 16-bit window codes for the columns, built by the analysis when every tile's
  *                            columns fit 16 windows of 4096, else the plan behaves like 1), "xcd_remap" (tile order: 0 dispatch, 1 XCD-contiguous, G >= 2 grouped; default 16), "nontemporal",
  *          "transient_min_knnz"  handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 never),
@@ -126,7 +128,7 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_debug" (ablation bits). */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);
 int kkamd_set_default(const char* key, int value);
-/* What the analysis of a plan produced: "tile" (nnz per workgroup, 0 = no tiling), "tiles", "window_codes" (1 if the
+/* What the analysis of a plan produced: "tile" (nnz per workgroup, 0 = no tiling), "tiles", "pattern_tiles" (tiles decoded from row-pattern records), "window_staged_x", "window_codes" (1 if the
  * 16-bit column codes of stream_variant 6 are in use), "transpose_cached". */
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);
 

@@ -47,6 +47,9 @@ struct SpmvTuning {
   int transient_min_knnz = 10000;  // handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 = never)
   int window_codes = 1;            // analysed handles with the default kernel: try the 16-bit window codes (stream_variant 6 forces the attempt)
   int window_codes_min_knnz = 1000;  // ... from this many thousand nnz
+  int pattern_codes = 0;           // staged-x plans: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one,
+                                   // 2 = whenever any tile has one, 0 = never (default: the decode costs more than the 2 B/nnz it saves on
+                                   // 27-pt 300^3, 1.289 -> 1.348 ms; it wins on 7-pt 400^3, 1.019 -> 0.970 ms)
 };
 static SpmvTuning g_spmv_default;
 
@@ -76,6 +79,9 @@ struct kkamd_spmv_plan {
   uint16_t* d_wcode = nullptr;   // [nblocks * tile]
   int32_t* d_wbase = nullptr;    // [nblocks * 64] window meta: bases, LDS slots, x chunk columns
   bool win_stage = false;        // every tile's used column ranges fit its LDS x window
+  int32_t* d_pmeta = nullptr;    // [nblocks * kPatW] row-pattern records (see pat_build_kernel); nseg = 0: the tile keeps its codes
+  int64_t pat_tiles = 0;         // tiles with a record
+  bool use_pat = false;
   // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
   void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr;
   kkamd_spmv_plan* t_plan = nullptr;
@@ -300,6 +306,104 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
   }
 }
 
+// Row-pattern codes (on top of the staged x window).  On locally Toeplitz matrices -- stencils: column = row + a constant
+// per diagonal -- the LDS slot of entry k of a row is the slot of entry k of the row before, plus one.  A tile then
+// decomposes into a few SEGMENTS of consecutive rows of equal length L that share one slot table T[0..L): nonzero i of the
+// tile belongs to segment g (its start sb_g <= i), j = i - (start of the segment's first row), row = j / L, k = j % L and
+// its x entry sits in LDS slot T_g[k] + row.  Per tile that is kPatW ints instead of 2 bytes per nonzero.  Tiles that do not
+// decompose into <= kPatSeg segments of rows with 1..kPatLen entries keep their 16-bit codes (nseg = 0).
+// Tile record: [0] nseg, [1..kPatSeg-1] starts of segments 1.. (INT_MAX when unused; segment 0 starts at 0), [8 + 4g ..] {start, -first row start, L,
+// ceil(2^32 / L)}, [8 + 4 kPatSeg + 32 g + k] T_g[k].
+constexpr int kPatSeg = 8, kPatLen = 32, kPatRec = 8, kPatTab = kPatRec + 4 * kPatSeg, kPatW = kPatTab + kPatSeg * kPatLen;
+
+template <class OffT, int NPT>
+__global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const OffT* __restrict__ row_map,
+                                                           const int32_t* __restrict__ blk_info,
+                                                           const uint16_t* __restrict__ wcode, const int32_t* __restrict__ wmeta,
+                                                           int32_t* __restrict__ pmeta, int* __restrict__ count) {
+  constexpr int TILE = kBlock * NPT, STEPS = NPT / 2, SPAN = kBlock * 2;
+  __shared__ unsigned short s_slot[TILE];
+  __shared__ unsigned char s_head[TILE + 2];
+  __shared__ int s_segq[kPatSeg];
+  __shared__ int s_nseg, s_bad, s_chunks;
+  const int t = threadIdx.x;
+  const int64_t b = blockIdx.x, s = b * TILE;
+  int32_t* out = pmeta + b * kPatW;
+  if (t == 0) { s_nseg = 0; s_bad = (s + TILE <= nnz) ? 0 : 1; s_chunks = 0; }    // the ragged last tile keeps its codes
+  __syncthreads();
+  // LDS slot of every nonzero, in tile order (the codes are stored in work-item order)
+  const int ldsoff = wmeta[b * kWinMeta + kWinCount + (t & (kWinCount - 1))];
+  KK_UNROLL
+  for (int k = 0; k < STEPS; ++k) {
+    KK_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      const unsigned code = wcode[s + (int64_t)t * NPT + 2 * k + j];
+      const int off = __shfl(ldsoff, (int)(code >> kWinBits), 64);
+      s_slot[k * SPAN + 2 * t + j] = (unsigned short)(off + (int)(code & ((1u << kWinBits) - 1)));
+    }
+  }
+  if (t < kWinChunks && wmeta[b * kWinMeta + 2 * kWinCount + t] >= 0) atomicAdd(&s_chunks, 1);
+  const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
+  const int64_t ra = info0 & 0x7fffffff, rb = info1 & 0x7fffffff;
+  const int has_head = (info0 >> 31) & 1;
+  const int64_t nv = (rb - ra) + has_head;                   // rows with at least their start or their end in this tile
+  __syncthreads();
+  // the tail of the product array holds this record at run time: the x window must leave it free (float products: 4 B slots)
+  if (t == 0 && s_chunks * 64 > TILE - kPatW) s_bad = 1;
+  for (int64_t q = t; q < nv; q += kBlock) {
+    const int64_t r  = ra + q - has_head;
+    const int64_t rs = (int64_t)row_map[r] - s, re = (int64_t)row_map[r + 1] - s, L = re - rs;
+    bool head = true;
+    if (L < 1 || L > kPatLen) atomicOr(&s_bad, 1);
+    else if (q > 0) {
+      const int64_t ps = (int64_t)row_map[r - 1] - s;
+      if (rs - ps == L) {
+        head = false;
+        for (int k = 0; k < (int)L; ++k) {
+          const int64_t i0 = ps + k, i1 = rs + k;
+          if (i0 >= 0 && i1 < TILE && (int)s_slot[i1] != (int)s_slot[i0] + 1) head = true;
+        }
+      }
+    }
+    s_head[q] = head ? 1 : 0;
+    if (head) { const int idx = atomicAdd(&s_nseg, 1); if (idx < kPatSeg) s_segq[idx] = (int)q; }
+  }
+  __syncthreads();
+  const int nseg = s_nseg;
+  if (s_bad || nseg > kPatSeg || nseg < 1) { if (t == 0) out[0] = 0; return; }      // workgroup-uniform
+  if (t == 0) {                                               // segment heads in row order
+    for (int a = 1; a < nseg; ++a) { const int v = s_segq[a]; int c = a - 1; while (c >= 0 && s_segq[c] > v) { s_segq[c + 1] = s_segq[c]; --c; } s_segq[c + 1] = v; }
+  }
+  __syncthreads();
+  if (t < kPatSeg) {
+    int sb = INT_MAX, rs32 = 0, L32 = 1; unsigned M = 0;
+    if (t < nseg) {
+      const int64_t r  = ra + s_segq[t] - has_head;
+      const int64_t rs = (int64_t)row_map[r] - s, L = (int64_t)row_map[r + 1] - s - rs;
+      sb = rs > 0 ? (int)rs : 0; rs32 = (int)rs; L32 = (int)L;
+      M  = (unsigned)(0x100000000ull / (unsigned long long)L) + 1u;       // floor(j / L) = (j * M) >> 32 for j < 2^16 (L == 1: row = j)
+    }
+    if (t >= 1) out[t] = sb;                                  // starts of segments 1..7 (segment 0 starts at 0)
+    out[kPatRec + 4 * t + 0] = sb; out[kPatRec + 4 * t + 1] = -rs32; out[kPatRec + 4 * t + 2] = L32; out[kPatRec + 4 * t + 3] = (int)M;
+  }
+  if (t == 0) { out[0] = nseg; atomicAdd(count, 1); }
+  if (t < kPatSeg * kPatLen) {
+    const int g = t / kPatLen, k = t % kPatLen;
+    int val = 0;
+    if (g < nseg) {
+      const int q = s_segq[g];
+      const int64_t r  = ra + q - has_head;
+      const int64_t rs = (int64_t)row_map[r] - s, re = (int64_t)row_map[r + 1] - s;
+      if (k < re - rs) {
+        const int64_t i = rs + k;
+        if (i >= 0 && i < TILE) val = (int)s_slot[i];
+        else if (i < 0 && q + 1 < nv && !s_head[q + 1] && re + k < TILE) val = (int)s_slot[re + k] - 1;   // from the next row of the segment
+      }
+    }
+    out[kPatTab + t] = val;
+  }
+}
+
 template <class AT, int STEPS, bool FULL, bool NT = false>
 __device__ __forceinline__ void load_tile_values(const AT* __restrict__ values, int64_t ts, int64_t te, int t, AT (&v0)[STEPS],
                                                  AT (&v1)[STEPS]) {
@@ -367,10 +471,11 @@ __device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, con
 
 // Staged-x tile: values, codes, meta and the x chunks are all requested before anything is waited for; the x chunks go to
 // LDS (aliasing the product array), every work-item then picks its x entries out of LDS and the products replace them.
-template <class AT, class YT, int STEPS, bool FULL, bool NT>
+template <class AT, class YT, int STEPS, bool FULL, bool NT, bool PAT = false>
 __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values, const uint16_t* __restrict__ wcode,
                                                    const int32_t* __restrict__ wmeta, const YT* __restrict__ x, int64_t ncols,
-                                                   YT* prod, int64_t b, int64_t ts, int64_t te, int t) {
+                                                   YT* prod, int64_t b, int64_t ts, int64_t te, int t,
+                                                   const int32_t* __restrict__ pmeta = nullptr) {
   constexpr int SPAN = kBlock * 2, NPT = 2 * STEPS, TILE = kBlock * NPT;
   constexpr int CAPC = (TILE < kWinChunks * 64 ? TILE : kWinChunks * 64) / 64;     // chunks the LDS window can hold
   constexpr int CPW  = (CAPC + kBlock / 64 - 1) / (kBlock / 64);                     // chunks per wave
@@ -378,30 +483,57 @@ __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values
   unsigned w[STEPS];
   const int lane = t & 63, wave = t >> 6;
   const int meta = wmeta[b * kWinMeta + lane];
-  load_tile_codes<STEPS, NT>(wcode, ts, t, w);
+  // PAT: a tile with a row-pattern record (nseg > 0) needs no per-nonzero codes at all
+  const int32_t* pm = PAT ? pmeta + b * kPatW : nullptr;
+  const int nseg    = PAT ? pm[0] : 0;                         // workgroup-uniform
+  int prec0 = 0, prec1 = 0;                                    // kPatW <= 2 * kBlock
+  if (PAT) { prec0 = pm[t]; if (t + kBlock < kPatW) prec1 = pm[t + kBlock]; }
   load_tile_values<AT, STEPS, FULL, NT>(values, ts, te, t, v0, v1);
   YT xv[CPW];
+  bool used[CPW];                                              // unused chunks are not written: the pattern record may sit there
   KK_UNROLL
   for (int i = 0; i < CPW; ++i) {
     const int c   = wave + i * (kBlock / 64);
     const int col = c < CAPC ? __shfl(meta, 2 * kWinCount + c, 64) : -1;            // wave-uniform
     int64_t xi    = (int64_t)col + lane;
     xi            = xi < ncols ? xi : ncols - 1;
-    xv[i]         = col >= 0 ? x[xi] : YT(0);
+    used[i]       = col >= 0;
+    xv[i]         = used[i] ? x[xi] : YT(0);
   }
+  if (!PAT || nseg == 0) load_tile_codes<STEPS, NT>(wcode, ts, t, w);
   KK_UNROLL
   for (int i = 0; i < CPW; ++i) {
     const int c = wave + i * (kBlock / 64);
-    if (c < CAPC) prod[c * 64 + lane] = xv[i];
+    if (used[i]) prod[c * 64 + lane] = xv[i];
   }
+  int* sseg = reinterpret_cast<int*>(prod + TILE) - kPatW;     // the record sits behind the x window (the analysis leaves room)
+  if (PAT && nseg > 0) { sseg[t] = prec0; if (t + kBlock < kPatW) sseg[t + kBlock] = prec1; }
   __syncthreads();
   YT x0[STEPS], x1[STEPS];
-  KK_UNROLL
-  for (int k = 0; k < STEPS; ++k) {
-    const unsigned lo = w[k] & 0xffffu, hi = w[k] >> 16;
-    const int s0 = __shfl(meta, kWinCount + (int)(lo >> kWinBits), 64) + (int)(lo & ((1u << kWinBits) - 1));
-    const int s1 = __shfl(meta, kWinCount + (int)(hi >> kWinBits), 64) + (int)(hi & ((1u << kWinBits) - 1));
-    x0[k] = prod[s0]; x1[k] = prod[s1];
+  if (PAT && nseg > 0) {
+    const int sb1 = pm[1], sb2 = pm[2], sb3 = pm[3], sb4 = pm[4], sb5 = pm[5], sb6 = pm[6], sb7 = pm[7];
+    KK_UNROLL
+    for (int k = 0; k < STEPS; ++k) {
+      KK_UNROLL
+      for (int h = 0; h < 2; ++h) {
+        const int li = k * SPAN + t * 2 + h;
+        const int g  = (li >= sb1) + (li >= sb2) + (li >= sb3) + (li >= sb4) + (li >= sb5) + (li >= sb6) + (li >= sb7);
+        const int* rec   = sseg + kPatRec + 4 * g;
+        const unsigned j = (unsigned)(li + rec[1]);
+        const unsigned L = (unsigned)rec[2];
+        const unsigned row = (L == 1u) ? j : (unsigned)(((unsigned long long)j * (unsigned)rec[3]) >> 32);
+        const int slot = sseg[kPatTab + g * kPatLen + (int)(j - row * L)] + (int)row;
+        if (h == 0) x0[k] = prod[slot]; else x1[k] = prod[slot];
+      }
+    }
+  } else {
+    KK_UNROLL
+    for (int k = 0; k < STEPS; ++k) {
+      const unsigned lo = w[k] & 0xffffu, hi = w[k] >> 16;
+      const int s0 = __shfl(meta, kWinCount + (int)(lo >> kWinBits), 64) + (int)(lo & ((1u << kWinBits) - 1));
+      const int s1 = __shfl(meta, kWinCount + (int)(hi >> kWinBits), 64) + (int)(hi & ((1u << kWinBits) - 1));
+      x0[k] = prod[s0]; x1[k] = prod[s1];
+    }
   }
   __syncthreads();                       // every x entry is in registers: the products may overwrite the window
   KK_UNROLL
@@ -590,9 +722,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
                                                               const int32_t* __restrict__ blk_info,
                                                               YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
                                                               int remap, int ablate, const uint16_t* __restrict__ wcode = nullptr,
-                                                              const int32_t* __restrict__ wmeta = nullptr, int64_t ncols = 0) {
+                                                              const int32_t* __restrict__ wmeta = nullptr, int64_t ncols = 0,
+                                                              const int32_t* __restrict__ pmeta = nullptr) {
   // WIN 1: the columns come from the plan's 16-bit window codes (wcode, wmeta) instead of entries; WIN 2: x is staged
-  // in LDS from the tile's contiguous column ranges as well (stage_products_win)
+  // in LDS from the tile's contiguous column ranges as well (stage_products_win); WIN 3: as 2, and tiles with a
+  // row-pattern record (pmeta) read no per-nonzero codes at all
   // ablate (diagnosis knob, 0 in production; results in DESIGN.md 4.1): 4 = no y stores, 8 = no LDS reduction
   // loop, 16 = synthetic row bounds (no row_map loads), 32 = no barrier, 64 / 128 = y-store experiments (see the store)
   constexpr int TILE  = kBlock * NPT;
@@ -609,7 +743,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
 
   AT v0[STEPS], v1[STEPS];
   int c0[STEPS], c1[STEPS];
-  if (WIN == 2) {
+  if (WIN >= 2) {
     // nothing to load here: stage_products_win requests values, codes and x chunks together
   } else if (WIN == 1) {
     if (full) load_tile_win<AT, STEPS, true>(values, wcode, wmeta, b, s, e, t, v0, v1, c0, c1);
@@ -638,9 +772,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   YT yold = YT(0);
   if (beta != YT(0) && valid && lane == 0 && r >= 0) yold = y[r];
 
-  if (WIN == 2) {
-    if (full) stage_products_win<AT, YT, STEPS, true, NT>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
-    else      stage_products_win<AT, YT, STEPS, false, NT>(values, wcode, wmeta, x, ncols, prod, b, s, e, t);
+  if (WIN >= 2) {
+    if (full) stage_products_win<AT, YT, STEPS, true, NT, WIN == 3>(values, wcode, wmeta, x, ncols, prod, b, s, e, t, pmeta);
+    else      stage_products_win<AT, YT, STEPS, false, NT, WIN == 3>(values, wcode, wmeta, x, ncols, prod, b, s, e, t, pmeta);
   } else {
     if (full) stage_products<AT, YT, STEPS, true, QP>(x, prod, t, v0, v1, c0, c1);
     else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
@@ -1305,7 +1439,12 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
               (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
               (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap == 1);
   } else if ((variant == 6 || variant == 1) && p->d_wcode) {
-    if (p->win_stage && p->tune.window_codes != 2) {
+    if (p->win_stage && p->tune.window_codes != 2 && p->use_pat && (NPT == 16 || NPT == 8)) {
+      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, (NPT == 4 ? 8 : NPT), NT, true, 3>), (unsigned)p->nblocks, kBlock, (size_t)p->tune.lds_pad_kb * 1024, st, A->nnz,
+                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
+                (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
+                (const int32_t*)p->d_wbase, A->num_cols, (const int32_t*)p->d_pmeta);
+    } else if (p->win_stage && p->tune.window_codes != 2) {
       KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true, 2>), (unsigned)p->nblocks, kBlock, (size_t)p->tune.lds_pad_kb * 1024, st, A->nnz,
                 (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
                 (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
@@ -1666,6 +1805,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "mv_remap") t.mv_remap = value;
   else if (k == "window_codes") t.window_codes = value;
   else if (k == "window_codes_min_knnz") t.window_codes_min_knnz = value;
+  else if (k == "pattern_codes") t.pattern_codes = value;
   else if (k == "transient_min_knnz") t.transient_min_knnz = value;
   else if (k == "explicit_transpose") t.explicit_transpose = value;
   else if (k == "explicit_transpose_min_knnz") t.explicit_transpose_min_knnz = value;
@@ -1690,6 +1830,8 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
   if (p->d_lidx) { KK_HIP(hipFree(p->d_lidx)); p->d_lidx = nullptr; }
   if (p->d_wcode) { KK_HIP(hipFree(p->d_wcode)); p->d_wcode = nullptr; }
   if (p->d_wbase) { KK_HIP(hipFree(p->d_wbase)); p->d_wbase = nullptr; }
+  if (p->d_pmeta) { KK_HIP(hipFree(p->d_pmeta)); p->d_pmeta = nullptr; }
+  p->pat_tiles = 0; p->use_pat = false;
   p->tile = 0; p->nblocks = 0;
   if (p->algorithm == KKAMD_SPMV_FAST_SETUP || p->tune.kernel == 1 || A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
   int npt = p->tune.nnz_per_thread;
@@ -1765,6 +1907,28 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
       if (auto_npt && !force_npt) return build_analysis(p, A, st);   // the tile size was picked for the codes: redo
     } else if (!p->win_stage && auto_npt && !force_npt && npt == 16) {
       return build_analysis(p, A, st, 8);
+    } else if (p->win_stage && p->tune.pattern_codes && (npt == 16 || npt == 8) &&
+               hipMalloc((void**)&p->d_pmeta, sizeof(int32_t) * (size_t)p->nblocks * kPatW) == hipSuccess) {
+      // row-pattern records: which tiles decompose into a few segments of equal rows with a common slot table
+      int* d_cnt = nullptr; int h_cnt = 0;
+      KK_HIP(hipMalloc((void**)&d_cnt, sizeof(int)));
+      KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
+      const bool o64 = A->offset_type == KKAMD_I64;
+#define KK_PAT_BUILD(OT, N)                                                                                                  \
+  KK_LAUNCH((pat_build_kernel<OT, N>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const OT*)A->d_row_map,                 \
+            (const int32_t*)p->d_blk_row, (const uint16_t*)p->d_wcode, (const int32_t*)p->d_wbase, p->d_pmeta, d_cnt)
+      if (npt == 16) { if (o64) { KK_PAT_BUILD(int64_t, 16); } else { KK_PAT_BUILD(int32_t, 16); } }
+      else           { if (o64) { KK_PAT_BUILD(int64_t, 8); } else { KK_PAT_BUILD(int32_t, 8); } }
+#undef KK_PAT_BUILD
+      KK_LAUNCH_CHECK();
+      KK_HIP(hipMemcpyAsync(&h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+      KK_HIP(hipStreamSynchronize(st));
+      KK_HIP(hipFree(d_cnt));
+      p->pat_tiles = h_cnt;
+      p->use_pat   = p->tune.pattern_codes >= 2 ? h_cnt > 0 : (double)h_cnt >= 0.9 * (double)p->nblocks;
+      if (!p->use_pat) { KK_HIP(hipFree(p->d_pmeta)); p->d_pmeta = nullptr; }
+    } else {
+      (void)hipGetLastError();
     }
   }
   KK_HIP(hipStreamSynchronize(st));   // setup is synchronous, like the vendor analysis it replaces
@@ -1834,6 +1998,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_lidx) (void)hipFree(plan->d_lidx);
   if (plan->d_wcode) (void)hipFree(plan->d_wcode);
   if (plan->d_wbase) (void)hipFree(plan->d_wbase);
+  if (plan->d_pmeta) (void)hipFree(plan->d_pmeta);
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
   if (plan->d_t_perm) (void)hipFree(plan->d_t_perm);
@@ -1846,13 +2011,13 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
   if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_set: null plan");
   const int old_npt = plan->tune.nnz_per_thread, old_kernel = plan->tune.kernel, old_var = plan->tune.stream_variant;
-  const int old_win = plan->tune.window_codes;
+  const int old_win = plan->tune.window_codes, old_pat = plan->tune.pattern_codes;
   int rc = kk::set_tuning(plan->tune, key, value);
   if (rc) return rc;
   if (plan->tune.nnz_per_thread != old_npt || plan->tune.kernel != old_kernel ||
       (plan->tune.stream_variant == 2) != (old_var == 2) || (plan->tune.stream_variant == 4) != (old_var == 4) ||
       (plan->tune.stream_variant == 6) != (old_var == 6) || (plan->tune.stream_variant == 1) != (old_var == 1) ||
-      plan->tune.window_codes != old_win) {
+      plan->tune.window_codes != old_win || plan->tune.pattern_codes != old_pat) {
     // tiling changed: redo the analysis (needs the matrix again; rebuilt lazily from the stored row_map)
     plan->win_failed = false;
     kkamd_crs_t A{};
@@ -1870,6 +2035,7 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "tiles") *value = plan->nblocks;
   else if (k == "window_codes") *value = plan->d_wcode ? 1 : 0;
   else if (k == "window_staged_x") *value = (plan->d_wcode && plan->win_stage && plan->tune.window_codes != 2) ? 1 : 0;
+  else if (k == "pattern_tiles") *value = plan->use_pat ? plan->pat_tiles : 0;
   else if (k == "transpose_cached") *value = plan->t_ready ? 1 : 0;
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
   return KKAMD_OK;

@@ -63,6 +63,7 @@ def check_spmv(be, A0, mode="N", alpha=1.0, beta=0.0, algo=None, nans=False, see
         tol *= max(1.0, longest_col / max(longest_row, 1))
     ok, err = fspmv_ok(exp, got, max(tol, 1e-300))
     assert ok, "spmv mismatch mode=%s alpha=%g beta=%g algo=%s: max err %g > tol %g" % (mode, alpha, beta, algo, err, tol)
+    return h if algo is not None else None
 
 
 def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_order="F", algo=None, seed=0, knobs=None):
@@ -231,4 +232,23 @@ def window_code_cases():
     out.append(("random-wide", oracle.random_crs(3000, 3000000, 9, variance=3, seed=5), 0))
     # 27-pt stencil (9 x-lines per tile) with nnz not a multiple of any tile size
     out.append(("27pt", oracle.laplace3d("FE", 24, 19, 13), 1))
+    return out
+
+
+def pattern_code_cases():
+    """(name, matrix, nnz_per_thread, row-pattern records expected) for the staged SpMV kernel's row-pattern codes."""
+    out = []
+    out.append(("27pt", oracle.laplace3d("FE", 210, 9, 5), 16, True))
+    out.append(("27pt-2048", oracle.laplace3d("FE", 120, 11, 5), 8, True))
+    out.append(("7pt", oracle.laplace3d("FD", 400, 8, 5), 8, True))
+    out.append(("5pt", oracle.laplace2d("FD", 500, 37), 8, True))
+    out.append(("3pt", oracle.laplace1d(12000), 16, True))
+    # a stencil with a handful of rows carrying one extra explicit zero: more segments in the tiles they fall into
+    A0 = oracle.laplace2d("FE", 200, 60)
+    rm = A0.row_map.copy(); ent = A0.entries; val = A0.values
+    for r in (1234, 1235, 5000, 9000, 9001, 9002, 9003, 9004, 9005, 9006, 9007):       # eight in a row: that tile keeps its codes
+        ent = np.insert(ent, rm[r + 1], ent[rm[r + 1] - 1]); val = np.insert(val, rm[r + 1], 0.0); rm[r + 1:] += 1
+    out.append(("9pt-perturbed", oracle.Crs(A0.nrows, A0.ncols, rm, ent.astype(np.int32), val), 16, True))
+    # banded random columns: staged x, but no two rows share a pattern
+    out.append(("banded-random", oracle.random_crs(6000, 6000, 9, variance=0, seed=4, bandwidth=300, sorted_rows=True), 16, False))
     return out

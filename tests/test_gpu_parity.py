@@ -91,6 +91,20 @@ def test_window_codes(be):
     pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=1.0, expect={"window_codes": 0})
 
 
+def test_pattern_codes(be):
+    # row-pattern records instead of per-nonzero codes (staged-x kernel): forced on for every tile that has one
+    for name, A0, npt, expect_pat in pc.pattern_code_cases():
+        kn = {"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": 2}
+        for odt, vdt, beta in ((np.int32, None, 0.5), (np.int64, None, 0.0), (np.int32, np.float32, 0.0)):
+            h = pc.check_spmv(be, A0, "N", 1.5, beta, "SPMV_DEFAULT", knobs=kn, max_val=32.0, nans=(beta == 0.0), offset_dtype=odt, value_dtype=vdt,
+                              expect={"window_staged_x": 1})
+            assert (h.query("pattern_tiles") > 0) == expect_pat, (name, h.query("pattern_tiles"), h.query("tiles"))
+        # auto (90 % of the tiles) and off (the default) give the same y
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": 1}, max_val=32.0)
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "nnz_per_thread": npt}, max_val=32.0,
+                      expect={"pattern_tiles": 0})
+
+
 def test_xcd_group_orders(be):
     # grouped tile orders (xcd_remap / mv_remap = G): whole blocks of 8G tiles are permuted, the incomplete last block is not
     for nrows in (64 * 255 + 5, 64 * 256, 64 * 257 + 1, 64 * 1030):
