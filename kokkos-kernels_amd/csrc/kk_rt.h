@@ -16,6 +16,7 @@
 #define KK_UNROLL4
 #define KK_WAVE_SYNC() kk_emu::sync_wave()
 #define KK_QUAD_PERM(v, ctrl) kk_emu::quad_perm((v), (ctrl))
+#define KK_UMUL24(a, b) ((unsigned)(a) * (unsigned)(b))
 #else
 #include <hip/hip_runtime.h>
 #define KK_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -30,4 +31,6 @@
 #define KK_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // DPP quad permute of a 32-bit value: lane (4q+j) receives the value of lane 4q + ((ctrl >> 2j) & 3)
 #define KK_QUAD_PERM(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xf, 0xf, true)
+// full-rate 24-bit multiply (v_mul_u32_u24); the 32-bit v_mul_lo_u32 is quarter rate
+#define KK_UMUL24(a, b) __umul24((a), (b))
 #endif

@@ -47,9 +47,9 @@ struct SpmvTuning {
   int transient_min_knnz = 10000;  // handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 = never)
   int window_codes = 1;            // analysed handles with the default kernel: try the 16-bit window codes (stream_variant 6 forces the attempt)
   int window_codes_min_knnz = 1000;  // ... from this many thousand nnz
-  int pattern_codes = 0;           // staged-x plans: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one,
-                                   // 2 = whenever any tile has one, 0 = never (default: the decode costs more than the 2 B/nnz it saves on
-                                   // 27-pt 300^3, 1.289 -> 1.348 ms; it wins on 7-pt 400^3, 1.019 -> 0.970 ms)
+  int pattern_codes = 1;           // staged-x plans: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one
+                                   // (27-pt 300^3 1.349 -> 1.267 ms, 7-pt 400^3 1.025 -> 0.940 ms), 2 = whenever any tile has one, 0 = never
+  int pattern_codes_min_knnz = 10000;  // ... from this many thousand nnz (5-pt 1000^2, 5e6 nnz: 17.5 -> 18.3 us with the records)
 };
 static SpmvTuning g_spmv_default;
 
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
 // its x entry sits in LDS slot T_g[k] + row.  Per tile that is kPatW ints instead of 2 bytes per nonzero.  Tiles that do not
 // decompose into <= kPatSeg segments of rows with 1..kPatLen entries keep their 16-bit codes (nseg = 0).
 // Tile record: [0] nseg, [1..kPatSeg-1] starts of segments 1.. (INT_MAX when unused; segment 0 starts at 0), [8 + 4g ..] {start, -first row start, L,
-// ceil(2^32 / L)}, [8 + 4 kPatSeg + 32 g + k] T_g[k].
+// float 1 / L}, [8 + 4 kPatSeg + 32 g + k] T_g[k].
 constexpr int kPatSeg = 8, kPatLen = 32, kPatRec = 8, kPatTab = kPatRec + 4 * kPatSeg, kPatW = kPatTab + kPatSeg * kPatLen;
 
 template <class OffT, int NPT>
@@ -376,15 +376,15 @@ __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const Of
   }
   __syncthreads();
   if (t < kPatSeg) {
-    int sb = INT_MAX, rs32 = 0, L32 = 1; unsigned M = 0;
+    int sb = INT_MAX, rs32 = 0, L32 = 1; float M = 1.0f;
     if (t < nseg) {
       const int64_t r  = ra + s_segq[t] - has_head;
       const int64_t rs = (int64_t)row_map[r] - s, L = (int64_t)row_map[r + 1] - s - rs;
       sb = rs > 0 ? (int)rs : 0; rs32 = (int)rs; L32 = (int)L;
-      M  = (unsigned)(0x100000000ull / (unsigned long long)L) + 1u;       // floor(j / L) = (j * M) >> 32 for j < 2^16 (L == 1: row = j)
+      M  = 1.0f / (float)L;                                    // floor(j / L) = (int)((j + 0.5f) * M), exact for j < 2^16, L <= 32
     }
     if (t >= 1) out[t] = sb;                                  // starts of segments 1..7 (segment 0 starts at 0)
-    out[kPatRec + 4 * t + 0] = sb; out[kPatRec + 4 * t + 1] = -rs32; out[kPatRec + 4 * t + 2] = L32; out[kPatRec + 4 * t + 3] = (int)M;
+    out[kPatRec + 4 * t + 0] = sb; out[kPatRec + 4 * t + 1] = -rs32; out[kPatRec + 4 * t + 2] = L32; out[kPatRec + 4 * t + 3] = __float_as_int(M);
   }
   if (t == 0) { out[0] = nseg; atomicAdd(count, 1); }
   if (t < kPatSeg * kPatLen) {
@@ -511,19 +511,39 @@ __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values
   __syncthreads();
   YT x0[STEPS], x1[STEPS];
   if (PAT && nseg > 0) {
-    const int sb1 = pm[1], sb2 = pm[2], sb3 = pm[3], sb4 = pm[4], sb5 = pm[5], sb6 = pm[6], sb7 = pm[7];
-    KK_UNROLL
-    for (int k = 0; k < STEPS; ++k) {
+    // nonzero li -> (segment g, row, k): row = floor((li - first row start) / L) by a float reciprocal (exact: (j + 0.5) / L
+    // stays 1/64 away from every integer), k by a full-rate 24-bit multiply; slot = T_g[k] + row.  One-segment tiles (no grid
+    // line boundary inside) need no search and keep the segment's constants in scalar registers.
+    if (nseg == 1) {
+      const int jadd = pm[kPatRec + 1];
+      const unsigned L = (unsigned)pm[kPatRec + 2];
+      const float rcp  = __int_as_float(pm[kPatRec + 3]);
       KK_UNROLL
-      for (int h = 0; h < 2; ++h) {
-        const int li = k * SPAN + t * 2 + h;
-        const int g  = (li >= sb1) + (li >= sb2) + (li >= sb3) + (li >= sb4) + (li >= sb5) + (li >= sb6) + (li >= sb7);
-        const int* rec   = sseg + kPatRec + 4 * g;
-        const unsigned j = (unsigned)(li + rec[1]);
-        const unsigned L = (unsigned)rec[2];
-        const unsigned row = (L == 1u) ? j : (unsigned)(((unsigned long long)j * (unsigned)rec[3]) >> 32);
-        const int slot = sseg[kPatTab + g * kPatLen + (int)(j - row * L)] + (int)row;
-        if (h == 0) x0[k] = prod[slot]; else x1[k] = prod[slot];
+      for (int k = 0; k < STEPS; ++k) {
+        KK_UNROLL
+        for (int h = 0; h < 2; ++h) {
+          const unsigned j   = (unsigned)(k * SPAN + t * 2 + h + jadd);
+          const unsigned row = (unsigned)(((float)j + 0.5f) * rcp);
+          const int slot     = sseg[kPatTab + (int)(j - KK_UMUL24(row, L))] + (int)row;
+          if (h == 0) x0[k] = prod[slot]; else x1[k] = prod[slot];
+        }
+      }
+    } else {
+      const int sb1 = pm[1], sb2 = pm[2], sb3 = pm[3], sb4 = pm[4], sb5 = pm[5], sb6 = pm[6], sb7 = pm[7];
+      KK_UNROLL
+      for (int k = 0; k < STEPS; ++k) {
+        KK_UNROLL
+        for (int h = 0; h < 2; ++h) {
+          const int li = k * SPAN + t * 2 + h;
+          int g = (li >= sb1) + (li >= sb2) + (li >= sb3);
+          if (nseg > 4) g += (li >= sb4) + (li >= sb5) + (li >= sb6) + (li >= sb7);      // workgroup-uniform
+          const int* rec     = sseg + kPatRec + 4 * g;
+          const unsigned j   = (unsigned)(li + rec[1]);
+          const unsigned L   = (unsigned)rec[2];
+          const unsigned row = (unsigned)(((float)j + 0.5f) * __int_as_float(rec[3]));
+          const int slot     = sseg[kPatTab + g * kPatLen + (int)(j - KK_UMUL24(row, L))] + (int)row;
+          if (h == 0) x0[k] = prod[slot]; else x1[k] = prod[slot];
+        }
       }
     }
   } else {
@@ -1806,6 +1826,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "window_codes") t.window_codes = value;
   else if (k == "window_codes_min_knnz") t.window_codes_min_knnz = value;
   else if (k == "pattern_codes") t.pattern_codes = value;
+  else if (k == "pattern_codes_min_knnz") t.pattern_codes_min_knnz = value;
   else if (k == "transient_min_knnz") t.transient_min_knnz = value;
   else if (k == "explicit_transpose") t.explicit_transpose = value;
   else if (k == "explicit_transpose_min_knnz") t.explicit_transpose_min_knnz = value;
@@ -1908,6 +1929,7 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
     } else if (!p->win_stage && auto_npt && !force_npt && npt == 16) {
       return build_analysis(p, A, st, 8);
     } else if (p->win_stage && p->tune.pattern_codes && (npt == 16 || npt == 8) &&
+               (p->tune.pattern_codes >= 2 || A->nnz >= (int64_t)p->tune.pattern_codes_min_knnz * 1000) &&
                hipMalloc((void**)&p->d_pmeta, sizeof(int32_t) * (size_t)p->nblocks * kPatW) == hipSuccess) {
       // row-pattern records: which tiles decompose into a few segments of equal rows with a common slot table
       int* d_cnt = nullptr; int h_cnt = 0;

@@ -104,7 +104,7 @@ class CrsMatrix:
                 None if self.values is None else be.to_numpy(self.values))
 
 
-_PRE_KNOBS = {"kernel": 0, "nnz_per_thread": 0, "stream_variant": 1, "window_codes": 1, "window_codes_min_knnz": 1000, "pattern_codes": 0}   # knob -> library default
+_PRE_KNOBS = {"kernel": 0, "nnz_per_thread": 0, "stream_variant": 1, "window_codes": 1, "window_codes_min_knnz": 1000, "pattern_codes": 1, "pattern_codes_min_knnz": 10000}   # knob -> library default
 _ALGOS = {"SPMV_DEFAULT": 0, "SPMV_FAST_SETUP": 1, "SPMV_NATIVE": 2, "SPMV_MERGE_PATH": 3, "SPMV_NATIVE_MERGE_PATH": 4}
 
 

@@ -99,10 +99,12 @@ def test_pattern_codes(be):
             h = pc.check_spmv(be, A0, "N", 1.5, beta, "SPMV_DEFAULT", knobs=kn, max_val=32.0, nans=(beta == 0.0), offset_dtype=odt, value_dtype=vdt,
                               expect={"window_staged_x": 1})
             assert (h.query("pattern_tiles") > 0) == expect_pat, (name, h.query("pattern_tiles"), h.query("tiles"))
-        # auto (90 % of the tiles) and off (the default) give the same y
-        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": 1}, max_val=32.0)
+        # auto (90 % of the tiles, from pattern_codes_min_knnz on) and off give the same y
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes_min_knnz": 0}, max_val=32.0)
         pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "nnz_per_thread": npt}, max_val=32.0,
-                      expect={"pattern_tiles": 0})
+                      expect={"pattern_tiles": 0})                 # below the default size threshold
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": 0,
+                                                                       "pattern_codes_min_knnz": 0}, max_val=32.0, expect={"pattern_tiles": 0})
 
 
 def test_xcd_group_orders(be):

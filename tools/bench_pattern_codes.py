@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Row-pattern records against per-nonzero 16-bit codes in the staged SpMV kernel (knob pattern_codes 0 = default / 1)."""
+"""Row-pattern records against per-nonzero 16-bit codes in the staged SpMV kernel (knob pattern_codes 0 / 1 = default from 1e7 nnz)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, kk_loader
@@ -17,7 +17,7 @@ def case(name, A):
     ref = None
     for rep in range(2):
         for pat in (0, 1):
-            h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("pattern_codes", pat)
+            h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("pattern_codes", pat); h.set("pattern_codes_min_knnz", 0)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             kk.spmv(h, "N", 1.0, A, x, 0.0, y); torch.cuda.synchronize(); first = (time.perf_counter() - t0) * 1e3
             t = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y))
