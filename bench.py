@@ -219,15 +219,19 @@ def main():
                          "kernel": "kk::spmv_stream3_kernel (+ fix-up kernel), HIP events around the launch",
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        # What the plan really streams: with the analysis' 16-bit column codes the kernel reads 2 instead of 4 bytes of
-        # column information per nonzero (+256 B of window meta per tile); "achieved" stays on the CRS algorithmic bytes.
+        # What the plan really streams: the analysis replaces the 4-byte column indices by 16-bit codes or, on locally
+        # Toeplitz tiles, by one small record per tile; "achieved" stays on the CRS algorithmic bytes.
         try:
             h_ = handle if world == 1 else op.handle
             if h_.query("window_codes"):
                 tile_ = h_.query("tile"); tiles_ = h_.query("tiles")
-                out["roofline"]["plan"] = {"column_codes": "16-bit window codes", "x_staged_in_lds": bool(h_.query("window_staged_x")),
-                                           "tile_nnz": tile_,
-                                           "streamed_bytes_per_launch": alg_bytes - nnz_local * 2 + tiles_ * 256}
+                pat_ = h_.query("pattern_tiles")
+                # tiles decoded from a row-pattern record read no per-nonzero column information at all (1184 B per tile instead)
+                streamed_ = alg_bytes - nnz_local * 4 + tiles_ * 256 + (tiles_ - pat_) * tile_ * 2 + pat_ * 1184
+                out["roofline"]["plan"] = {"column_codes": ("row-pattern records on %d of %d tiles, 16-bit window codes on the rest" % (pat_, tiles_))
+                                                           if pat_ else "16-bit window codes",
+                                           "x_staged_in_lds": bool(h_.query("window_staged_x")), "tile_nnz": tile_,
+                                           "streamed_bytes_per_launch": streamed_}
         except Exception:
             pass
         # HBM traffic comes from the committed rocprofv3 PMC passes of this same command (it cannot be counted live)
