@@ -75,6 +75,7 @@ while time.time() < t_end:
                 M = oracle.Crs(n, gap * k + 1, np.arange(n + 1, dtype=np.int64) * k, cols.reshape(-1), 1 + rng.random(n * k))
             elif sub == 2:     # stencils
                 nd = int(rng.integers(2, 4)); dims = tuple(int(rng.integers(3, 400 if nd == 2 else 60)) for _ in range(nd))
+                if rng.random() < 0.5: dims = (int(rng.integers(150, 700)),) + tuple(int(rng.integers(3, 12)) for _ in range(nd - 1))   # long grid lines
                 st = "FE" if rng.random() < 0.5 else "FD"
                 M = oracle.laplace2d(st, *dims) if nd == 2 else oracle.laplace3d(st, *dims)
             else:              # banded random with duplicates / unsorted rows
@@ -82,7 +83,7 @@ while time.time() < t_end:
                 M = oracle.random_crs(n, n + int(rng.integers(0, 50)), int(rng.integers(1, 40)), variance=int(rng.integers(0, 10)), seed=int(rng.integers(1, 1 << 30)),
                                       bandwidth=int(rng.integers(5, 3000)))
             knobs = {"window_codes_min_knnz": 0, "window_codes": int(rng.integers(1, 3)), "nnz_per_thread": int(rng.choice([0, 4, 8, 16])),
-                     "xcd_remap": int(rng.choice([0, 1, 2, 16]))}
+                     "xcd_remap": int(rng.choice([0, 1, 2, 16])), "pattern_codes": int(rng.choice([0, 1, 2, 2])), "pattern_codes_min_knnz": 0}
             for beta in (0.0, float(rng.integers(-2, 3))):
                 pc.check_spmv(be, M, "N", float(rng.integers(-3, 4)), beta, algo="SPMV_DEFAULT", offset_dtype=odt, max_val=50.0, seed=case, knobs=knobs,
                               nans=(beta == 0.0), value_dtype=(vdt if vdt == np.float32 and rng.random() < 0.5 else None))
