@@ -249,6 +249,16 @@ def pattern_code_cases():
     for r in (1234, 1235, 5000, 9000, 9001, 9002, 9003, 9004, 9005, 9006, 9007):       # eight in a row: that tile keeps its codes
         ent = np.insert(ent, rm[r + 1], ent[rm[r + 1] - 1]); val = np.insert(val, rm[r + 1], 0.0); rm[r + 1:] += 1
     out.append(("9pt-perturbed", oracle.Crs(A0.nrows, A0.ncols, rm, ent.astype(np.int32), val), 16, True))
+    # Toeplitz band of 40 diagonals (rows longer than a record's table) and a stencil with empty rows: the codes stay
+    n = 3000; offs = np.arange(-20, 20)
+    cols = np.arange(n)[:, None] + offs[None, :]; keep = (cols >= 0) & (cols < n)
+    rm = np.zeros(n + 1, np.int64); rm[1:] = np.cumsum(keep.sum(1))
+    out.append(("band40", oracle.Crs(n, n, rm, cols[keep].astype(np.int32), np.random.default_rng(1).random(int(rm[-1]))), 16, False))
+    A0 = oracle.laplace2d("FD", 400, 30)
+    lens = np.diff(A0.row_map).copy(); keep = np.ones(A0.nnz, bool)
+    for r in range(100, A0.nrows, 3000): keep[A0.row_map[r]:A0.row_map[r + 1]] = False; lens[r] = 0
+    rm = np.zeros(A0.nrows + 1, np.int64); rm[1:] = np.cumsum(lens)
+    out.append(("5pt-empty-rows", oracle.Crs(A0.nrows, A0.ncols, rm, A0.entries[keep], A0.values[keep]), 16, True))
     # banded random columns: staged x, but no two rows share a pattern
     out.append(("banded-random", oracle.random_crs(6000, 6000, 9, variance=0, seed=4, bandwidth=300, sorted_rows=True), 16, False))
     return out
