@@ -25,90 +25,9 @@
 #include <cstring>
 #include <climits>
 
-namespace kk {
-
-struct SpmvTuning {
-  int kernel         = 0;  // 0 auto, 1 vector, 2 stream
-  int lanes_per_row  = 0;  // vector kernel, 0 = auto
-  int nnz_per_thread = 0;  // stream kernel: 4, 8 or 16 (0 = 16 for fp64, 8 otherwise)
-  int xcd_remap      = 16; // tile order of the nnz-split kernel: 0 dispatch order (tile b on XCD b % 8), 1 XCD-contiguous (3-8 % slower than 0),
-                           // G >= 2 grouped (G consecutive tiles per XCD inside blocks of 8G tiles; 16: 1.37 -> 1.29 ms on C2, 7-pt 400^3 -7 %)
-  int nontemporal    = 0;  // measured: no consistent gain from nt loads on the value/column streams
-  int mv_kernel      = 0;  // reserved for rank-2 variants
-  int stream_variant = 1;  // 1 lean kernel + quad-dealt gathers (default), 3 same with natural gather layout,
-                           // 0 first-generation, 2 wave-private tiles, 4 tile-local column structure (kept for A/B)
-  int wg_per_cu      = 0;  // unused (persistent variant measured slower and was removed)
-  int ablate         = 0;  // bench-only: 1 no x gather, 2 no LDS/reduce, 3 both
-  int lds_pad_kb     = 0;  // bench-only: extra dynamic LDS per workgroup (caps workgroups per CU)
-  int mv_remap       = 16; // rank-2: 0 dispatch order, 1 XCD-contiguous (no faster than 0), 4 / 8 / 16 / ... grouped (16: 5.60 -> 4.76 ms on C3)
-  int explicit_transpose = 0;   // modes T/H with an analysed handle: 1 = cache A^T (structure + permutation) in the plan, refresh its
-                                // values every call and run the N kernel on it; 2 = same, the caller promises constant values (no refresh)
-  int explicit_transpose_min_knnz = 1000;   // ... from this many thousand nnz
-  int transient_min_knnz = 10000;  // handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 = never)
-  int window_codes = 1;            // analysed handles with the default kernel: try the 16-bit window codes (stream_variant 6 forces the attempt)
-  int window_codes_min_knnz = 1000;  // ... from this many thousand nnz
-  int pattern_codes = 1;           // staged-x plans: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one
-                                   // (27-pt 300^3 1.349 -> 1.267 ms, 7-pt 400^3 1.025 -> 0.940 ms), 2 = whenever any tile has one, 0 = never
-  int pattern_codes_min_knnz = 10000;  // ... from this many thousand nnz (5-pt 1000^2, 5e6 nnz: 17.5 -> 18.3 us with the records)
-};
-static SpmvTuning g_spmv_default;
-
-}  // namespace kk
-
-struct kkamd_spmv_plan {
-  int64_t num_rows = 0, num_cols = 0, nnz = 0;
-  const void* row_map = nullptr;
-  int offset_type = 0, algorithm = 0;
-  kk::SpmvTuning tune;
-  int tile = 0;             // nnz per workgroup of the analysed tiling (0 = no stream analysis)
-  int64_t nblocks = 0;
-  int num_cus = 256;
-  int32_t* d_blk_row = nullptr;  // [nblocks+1] first row starting at or after b*tile
-  void* d_carry = nullptr;       // [2*nblocks] 8-byte slots: head partials, then tail partials
-  void* d_xpack = nullptr;       // rank-2: row-major packed copy of a column-major X (grown on demand)
-  size_t xpack_bytes = 0;
-  const void* entries = nullptr; // the matrix's column array (identity check + tile-local analysis)
-  // tile-local column structure ("TLC", stream_variant 4): per tile the sorted list of DISTINCT columns and, per
-  // nnz, a 16-bit index into that list.  Built once per matrix; values are still read from the caller's array.
-  int64_t* d_uoff = nullptr;     // [nblocks+1] offsets into d_ucols
-  int32_t* d_ucols = nullptr;    // distinct columns of every tile, ascending within a tile
-  uint16_t* d_lidx = nullptr;    // [nnz] position of each nnz's column in its tile's list
-  int64_t ucols_total = 0;
-  // window codes (stream_variant 6): per tile up to 16 column windows of 4096 and, per nnz, a 16-bit code
-  // (window << 12 | column - window base), stored in the order the kernel's work-items consume them
-  uint16_t* d_wcode = nullptr;   // [nblocks * tile]
-  int32_t* d_wbase = nullptr;    // [nblocks * 64] window meta: bases, LDS slots, x chunk columns
-  bool win_stage = false;        // every tile's used column ranges fit its LDS x window
-  int32_t* d_pmeta = nullptr;    // [nblocks * kPatW] row-pattern records (see pat_build_kernel); nseg = 0: the tile keeps its codes
-  int64_t pat_tiles = 0;         // tiles with a record
-  bool use_pat = false;
-  // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
-  void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr;
-  kkamd_spmv_plan* t_plan = nullptr;
-  bool t_ready = false, t_failed = false, t_values_valid = false;
-  bool win_failed = false;       // some tile of this matrix needs more than 16 windows: plain entries
-};
+#include "kk_spmv_plan.h"
 
 namespace kk {
-
-// ------------------------------------------------------------------------------------------------
-template <class YT> __global__ void scale_kernel(YT* __restrict__ y, int64_t n, int64_t s0, int64_t ncol, int64_t s1, YT beta) {
-  // y(i,j) at i*s0 + j*s1; beta == 0 writes exact zeros (KokkosBlas::scal semantics)
-  const int64_t total = n * ncol;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = g / ncol, j = g % ncol;
-    YT* p = y + i * s0 + j * s1;
-    *p = (beta == YT(0)) ? YT(0) : beta * (*p);
-  }
-}
-
-template <class YT> static int launch_scale(YT* y, int64_t n, int64_t s0, int64_t ncol, int64_t s1, YT beta, hipStream_t st) {
-  if (n * ncol == 0 || beta == YT(1)) return KKAMD_OK;
-  const int64_t nb = ceil_div(n * ncol, kBlock);
-  KK_LAUNCH((scale_kernel<YT>), (unsigned)(nb < 8192 ? nb : 8192), kBlock, 0, st, y, n, s0, ncol, s1, beta);
-  KK_LAUNCH_CHECK();
-  return KKAMD_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 // vector kernel: LPR lanes cooperate on a row (K1 analogue).
@@ -151,16 +70,6 @@ __global__ void spmv_plan_kernel(int64_t nrows, const OffT* __restrict__ row_map
   const bool head = (int64_t)row_map[lo] > target;
   blk_row[b] = (int32_t)lo | (head ? (int32_t)0x80000000 : 0);
 }
-
-// native 2-element vectors (accepted by __builtin_nontemporal_load; same syntax under clang and gcc)
-typedef double kk_f64x2 __attribute__((vector_size(16)));
-typedef float  kk_f32x2 __attribute__((vector_size(8)));
-typedef int    kk_i32x2 __attribute__((vector_size(8)));
-typedef unsigned kk_u32x2 __attribute__((vector_size(8)));
-typedef unsigned kk_u32x4 __attribute__((vector_size(16)));
-template <class T> struct vec2;
-template <> struct vec2<double> { using type = kk_f64x2; };
-template <> struct vec2<float>  { using type = kk_f32x2; };
 
 // Streaming loads of one tile into registers and staging of the val*x products in LDS.  FULL (the whole
 // tile lies inside [0, nnz): every tile but the last) is a workgroup-uniform property; its code path has
@@ -206,8 +115,9 @@ constexpr int kWinMeta = 64, kWinChunks = 32;
 template <int NPT>
 __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const int32_t* __restrict__ entries,
                                                            uint16_t* __restrict__ wcode, int32_t* __restrict__ wmeta,
-                                                           int* __restrict__ fail) {
-  // fail[0]: tiles that need more than 16 windows; fail[1]: tiles whose used column ranges exceed the LDS x window
+                                                           int32_t* __restrict__ tinfo, int* __restrict__ counts, int allow_stage) {
+  // Per tile (tinfo[b]): kTilePlain when the tile needs more than 16 windows (it keeps reading entries), kTileCodes when
+  // its used column ranges exceed the LDS x window, kTileStaged otherwise.  counts[mode] = tiles of that mode.
   constexpr int TILE = kBlock * NPT, STEPS = NPT / 2, SPAN = kBlock * 2;
   __shared__ int s_base[kWinCount];
   __shared__ int s_len[kWinCount];
@@ -273,7 +183,15 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
     __syncthreads();
     if (!any) break;
   }
-  if (uncovered) atomicAdd(fail, 1);
+  if (t == 0) s_min = 0;
+  __syncthreads();
+  if (uncovered) atomicOr(&s_min, 1);
+  __syncthreads();
+  const bool plain = s_min != 0;                               // workgroup-uniform
+  if (plain) {
+    if (t == 0) { tinfo[b] = kTilePlain; atomicAdd(counts + kTilePlain, 1); }
+    return;
+  }
   if (t < kWinCount) s_len[t] = 0;
   __syncthreads();
   uint16_t* out = wcode + s + (int64_t)t * NPT;
@@ -293,7 +211,8 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
     for (int w = 0; w < kWinCount; ++w) { s_off[w] = off; off += (s_len[w] + 63) & ~63; }
     s_off[kWinCount] = off;
     constexpr int CAP = TILE < kWinChunks * 64 ? TILE : kWinChunks * 64;
-    if (off > CAP) atomicAdd(fail + 1, 1);
+    const int mode = (off > CAP || !allow_stage) ? kTileCodes : kTileStaged;
+    tinfo[b] = mode; atomicAdd(counts + mode, 1);
   }
   __syncthreads();
   int32_t* meta = wmeta + b * kWinMeta;
@@ -312,15 +231,17 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
 // tile belongs to segment g (its start sb_g <= i), j = i - (start of the segment's first row), row = j / L, k = j % L and
 // its x entry sits in LDS slot T_g[k] + row.  Per tile that is kPatW ints instead of 2 bytes per nonzero.  Tiles that do not
 // decompose into <= kPatSeg segments of rows with 1..kPatLen entries keep their 16-bit codes (nseg = 0).
-// Tile record: [0] nseg, [1..kPatSeg-1] starts of segments 1.. (INT_MAX when unused; segment 0 starts at 0), [8 + 4g ..] {start, -first row start, L,
-// float 1 / L}, [8 + 4 kPatSeg + 32 g + k] T_g[k].
-constexpr int kPatSeg = 8, kPatLen = 32, kPatRec = 8, kPatTab = kPatRec + 4 * kPatSeg, kPatW = kPatTab + kPatSeg * kPatLen;
+// Tile record (ints): [0] nseg, [1..kPatSeg-1] starts of segments 1.. (INT_MAX when unused; segment 0 starts at 0), [8 + 4g ..] {start,
+// -first row start, L, float 1 / L}, then the slot tables as signed 16-bit values (-1 <= slot < 4096): T_g[k] = short[32 g + k] behind
+// int kPatTab.  672 bytes per tile.
+constexpr int kPatSeg = 8, kPatLen = 32, kPatRec = 8, kPatTab = kPatRec + 4 * kPatSeg, kPatW = kPatTab + kPatSeg * kPatLen / 2;
 
 template <class OffT, int NPT>
 __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const OffT* __restrict__ row_map,
                                                            const int32_t* __restrict__ blk_info,
                                                            const uint16_t* __restrict__ wcode, const int32_t* __restrict__ wmeta,
-                                                           int32_t* __restrict__ pmeta, int* __restrict__ count) {
+                                                           int32_t* __restrict__ tinfo, int32_t* __restrict__ pmeta,
+                                                           int* __restrict__ count) {
   constexpr int TILE = kBlock * NPT, STEPS = NPT / 2, SPAN = kBlock * 2;
   __shared__ unsigned short s_slot[TILE];
   __shared__ unsigned char s_head[TILE + 2];
@@ -329,6 +250,7 @@ __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const Of
   const int t = threadIdx.x;
   const int64_t b = blockIdx.x, s = b * TILE;
   int32_t* out = pmeta + b * kPatW;
+  if ((tinfo[b] & 3) != kTileStaged) return;                   // workgroup-uniform: only staged-x tiles can carry a record
   if (t == 0) { s_nseg = 0; s_bad = (s + TILE <= nnz) ? 0 : 1; s_chunks = 0; }    // the ragged last tile keeps its codes
   __syncthreads();
   // LDS slot of every nonzero, in tile order (the codes are stored in work-item order)
@@ -370,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const Of
   }
   __syncthreads();
   const int nseg = s_nseg;
-  if (s_bad || nseg > kPatSeg || nseg < 1) { if (t == 0) out[0] = 0; return; }      // workgroup-uniform
+  if (s_bad || nseg > kPatSeg || nseg < 1) return;            // workgroup-uniform: the tile keeps its codes
   if (t == 0) {                                               // segment heads in row order
     for (int a = 1; a < nseg; ++a) { const int v = s_segq[a]; int c = a - 1; while (c >= 0 && s_segq[c] > v) { s_segq[c + 1] = s_segq[c]; --c; } s_segq[c + 1] = v; }
   }
@@ -386,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const Of
     if (t >= 1) out[t] = sb;                                  // starts of segments 1..7 (segment 0 starts at 0)
     out[kPatRec + 4 * t + 0] = sb; out[kPatRec + 4 * t + 1] = -rs32; out[kPatRec + 4 * t + 2] = L32; out[kPatRec + 4 * t + 3] = __float_as_int(M);
   }
-  if (t == 0) { out[0] = nseg; atomicAdd(count, 1); }
+  if (t == 0) { out[0] = nseg; tinfo[b] = kTilePattern; atomicAdd(count, 1); }
   if (t < kPatSeg * kPatLen) {
     const int g = t / kPatLen, k = t % kPatLen;
     int val = 0;
@@ -400,8 +322,32 @@ __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const Of
         else if (i < 0 && q + 1 < nv && !s_head[q + 1] && re + k < TILE) val = (int)s_slot[re + k] - 1;   // from the next row of the segment
       }
     }
-    out[kPatTab + t] = val;
+    reinterpret_cast<short*>(out + kPatTab)[t] = (short)val;     // may be -1: the slot before a row that starts in an earlier tile
   }
+}
+
+// Which tiles keep per-nonzero codes (modes 1, 2, and 3 when the records are not used) -> flags for the scan; demotes unused records.
+__global__ void code_flag_kernel(int64_t nblocks, int32_t* __restrict__ tinfo, int32_t* __restrict__ flag, int use_pat) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nblocks) return;
+  if (b == nblocks) { flag[b] = 0; return; }
+  int mode = tinfo[b] & 3;
+  if (mode == kTilePattern && !use_pat) { mode = kTileStaged; tinfo[b] = mode; }
+  flag[b] = (mode == kTileCodes || mode == kTileStaged) ? 1 : 0;
+}
+// Moves the codes of the flagged tiles to their compact position (idx = exclusive scan of the flags) and completes tinfo.
+template <int TILE>
+__global__ __launch_bounds__(kBlock) void code_compact_kernel(const uint16_t* __restrict__ full, uint16_t* __restrict__ compact,
+                                                              int32_t* __restrict__ tinfo, const int32_t* __restrict__ idx) {
+  const int64_t b = blockIdx.x;
+  const int mode = tinfo[b] & 3;
+  if (mode == kTilePattern) { if (threadIdx.x == 0) tinfo[b] = mode | (int32_t)((unsigned)b << 2); return; }   // records stay in place
+  if (mode != kTileCodes && mode != kTileStaged) return;
+  const int64_t d = idx[b];
+  const kk_u32x4* src = reinterpret_cast<const kk_u32x4*>(full + b * TILE);
+  kk_u32x4* dst       = reinterpret_cast<kk_u32x4*>(compact + d * TILE);
+  for (int i = threadIdx.x; i < TILE / 8; i += kBlock) dst[i] = src[i];
+  if (threadIdx.x == 0) tinfo[b] = mode | (int32_t)((unsigned)d << 2);
 }
 
 template <class AT, int STEPS, bool FULL, bool NT = false>
@@ -426,9 +372,10 @@ __device__ __forceinline__ void load_tile_values(const AT* __restrict__ values, 
 
 // the 2*STEPS codes of work-item t, two per 32-bit word (nonzero 2k of the item in the low half of word k)
 template <int STEPS, bool NT = false>
-__device__ __forceinline__ void load_tile_codes(const uint16_t* __restrict__ wcode, int64_t ts, int t, unsigned (&w)[STEPS]) {
+__device__ __forceinline__ void load_tile_codes(const uint16_t* __restrict__ wtile, int t, unsigned (&w)[STEPS]) {
+  // wtile: the tile's codes (the plan stores codes only for the tiles that use them)
   constexpr int NPT = 2 * STEPS;
-  const unsigned* cw = reinterpret_cast<const unsigned*>(wcode + ts + (int64_t)t * NPT);   // 4*STEPS bytes, aligned
+  const unsigned* cw = reinterpret_cast<const unsigned*>(wtile + t * NPT);   // 4*STEPS bytes, aligned
   if (STEPS % 4 == 0) {
     KK_UNROLL
     for (int k = 0; k < STEPS; k += 4) {
@@ -447,12 +394,12 @@ __device__ __forceinline__ void load_tile_codes(const uint16_t* __restrict__ wco
 }
 
 template <class AT, int STEPS, bool FULL>
-__device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, const uint16_t* __restrict__ wcode,
+__device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, const uint16_t* __restrict__ wtile,
                                               const int32_t* __restrict__ wmeta, int64_t b, int64_t ts, int64_t te, int t,
                                               AT (&v0)[STEPS], AT (&v1)[STEPS], int (&c0)[STEPS], int (&c1)[STEPS]) {
   constexpr int SPAN = kBlock * 2;
   unsigned w[STEPS];
-  load_tile_codes<STEPS>(wcode, ts, t, w);
+  load_tile_codes<STEPS>(wtile, t, w);
   const int meta = wmeta[b * kWinMeta + (t & (kWinMeta - 1))];
   load_tile_values<AT, STEPS, FULL>(values, ts, te, t, v0, v1);
   KK_UNROLL
@@ -471,11 +418,12 @@ __device__ __forceinline__ void load_tile_win(const AT* __restrict__ values, con
 
 // Staged-x tile: values, codes, meta and the x chunks are all requested before anything is waited for; the x chunks go to
 // LDS (aliasing the product array), every work-item then picks its x entries out of LDS and the products replace them.
-template <class AT, class YT, int STEPS, bool FULL, bool NT, bool PAT = false>
-__device__ __forceinline__ void stage_products_win(const AT* __restrict__ values, const uint16_t* __restrict__ wcode,
+template <class AT, class YT, int STEPS, bool FULL, bool NT, bool PAT>
+__device__ __forceinline__ void stage_products_win(const AT* __restrict__ values, const uint16_t* __restrict__ wtile,
                                                    const int32_t* __restrict__ wmeta, const YT* __restrict__ x, int64_t ncols,
                                                    YT* prod, int64_t b, int64_t ts, int64_t te, int t,
-                                                   const int32_t* __restrict__ pmeta = nullptr) {
+                                                   const int32_t* __restrict__ pmeta) {
+  // PAT (workgroup-uniform template choice made by the caller from the tile's mode): the tile has a row-pattern record
   constexpr int SPAN = kBlock * 2, NPT = 2 * STEPS, TILE = kBlock * NPT;
   constexpr int CAPC = (TILE < kWinChunks * 64 ? TILE : kWinChunks * 64) / 64;     // chunks the LDS window can hold
   constexpr int CPW  = (CAPC + kBlock / 64 - 1) / (kBlock / 64);                     // chunks per wave
@@ -483,11 +431,11 @@ __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values
   unsigned w[STEPS];
   const int lane = t & 63, wave = t >> 6;
   const int meta = wmeta[b * kWinMeta + lane];
-  // PAT: a tile with a row-pattern record (nseg > 0) needs no per-nonzero codes at all
+  // PAT: a tile with a row-pattern record needs no per-nonzero codes at all
   const int32_t* pm = PAT ? pmeta + b * kPatW : nullptr;
-  const int nseg    = PAT ? pm[0] : 0;                         // workgroup-uniform
-  int prec0 = 0, prec1 = 0;                                    // kPatW <= 2 * kBlock
-  if (PAT) { prec0 = pm[t]; if (t + kBlock < kPatW) prec1 = pm[t + kBlock]; }
+  const int nseg    = PAT ? pm[0] : 0;                         // workgroup-uniform, >= 1
+  int prec0 = 0;                                               // kPatW <= kBlock
+  if (PAT && t < kPatW) prec0 = pm[t];
   load_tile_values<AT, STEPS, FULL, NT>(values, ts, te, t, v0, v1);
   YT xv[CPW];
   bool used[CPW];                                              // unused chunks are not written: the pattern record may sit there
@@ -500,17 +448,18 @@ __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values
     used[i]       = col >= 0;
     xv[i]         = used[i] ? x[xi] : YT(0);
   }
-  if (!PAT || nseg == 0) load_tile_codes<STEPS, NT>(wcode, ts, t, w);
+  if (!PAT) load_tile_codes<STEPS, NT>(wtile, t, w);
   KK_UNROLL
   for (int i = 0; i < CPW; ++i) {
     const int c = wave + i * (kBlock / 64);
     if (used[i]) prod[c * 64 + lane] = xv[i];
   }
   int* sseg = reinterpret_cast<int*>(prod + TILE) - kPatW;     // the record sits behind the x window (the analysis leaves room)
-  if (PAT && nseg > 0) { sseg[t] = prec0; if (t + kBlock < kPatW) sseg[t + kBlock] = prec1; }
+  const short* stab = reinterpret_cast<const short*>(sseg + kPatTab);   // 16-bit (signed) slot tables
+  if (PAT && t < kPatW) sseg[t] = prec0;
   __syncthreads();
   YT x0[STEPS], x1[STEPS];
-  if (PAT && nseg > 0) {
+  if (PAT) {
     // nonzero li -> (segment g, row, k): row = floor((li - first row start) / L) by a float reciprocal (exact: (j + 0.5) / L
     // stays 1/64 away from every integer), k by a full-rate 24-bit multiply; slot = T_g[k] + row.  One-segment tiles (no grid
     // line boundary inside) need no search and keep the segment's constants in scalar registers.
@@ -524,7 +473,7 @@ __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values
         for (int h = 0; h < 2; ++h) {
           const unsigned j   = (unsigned)(k * SPAN + t * 2 + h + jadd);
           const unsigned row = (unsigned)(((float)j + 0.5f) * rcp);
-          const int slot     = sseg[kPatTab + (int)(j - KK_UMUL24(row, L))] + (int)row;
+          const int slot     = (int)stab[(int)(j - KK_UMUL24(row, L))] + (int)row;
           if (h == 0) x0[k] = prod[slot]; else x1[k] = prod[slot];
         }
       }
@@ -541,7 +490,7 @@ __device__ __forceinline__ void stage_products_win(const AT* __restrict__ values
           const unsigned j   = (unsigned)(li + rec[1]);
           const unsigned L   = (unsigned)rec[2];
           const unsigned row = (unsigned)(((float)j + 0.5f) * __int_as_float(rec[3]));
-          const int slot     = sseg[kPatTab + g * kPatLen + (int)(j - KK_UMUL24(row, L))] + (int)row;
+          const int slot     = (int)stab[g * kPatLen + (int)(j - KK_UMUL24(row, L))] + (int)row;
           if (h == 0) x0[k] = prod[slot]; else x1[k] = prod[slot];
         }
       }
@@ -632,87 +581,6 @@ __device__ __forceinline__ void stage_products(const YT* __restrict__ x, YT* pro
   }
 }
 
-// stream kernel: workgroup b owns nnz [b*TILE, (b+1)*TILE).
-template <class OffT, class AT, class YT, int NPT, bool NT>
-__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(int64_t nnz, const OffT* __restrict__ row_map,
-                                                             const int32_t* __restrict__ entries,
-                                                             const AT* __restrict__ values, const YT* __restrict__ x,
-                                                             YT* __restrict__ y, YT alpha, YT beta,
-                                                             const int32_t* __restrict__ blk_row,
-                                                             YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
-                                                             int remap, int ablate) {
-  // ablate (bench-only diagnosis, 0 in production): bit 0 = no x gather, bit 1 = no LDS staging / row reduction
-  constexpr int TILE  = kBlock * NPT;
-  constexpr int STEPS = NPT / 2;      // two consecutive nnz per lane per step: 16 B of fp64 values + 8 B of columns
-  __shared__ YT prod[TILE];
-
-  const int t     = threadIdx.x;
-  const int64_t b = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-  const int64_t s = b * TILE;
-  const int64_t e = (s + TILE < nnz) ? s + TILE : nnz;
-
-  // 1. issue every streaming load of the tile up front (all independent, all aligned)
-  AT v0[STEPS], v1[STEPS];
-  int c0[STEPS], c1[STEPS];
-  const bool full = (s + TILE <= nnz);
-  if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
-  else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
-  // 2. gather x (L2 / Infinity-Cache resident window), multiply, stage in LDS
-  if (ablate) {
-    YT acc = YT(0);
-    KK_UNROLL
-    for (int k = 0; k < STEPS; ++k) {
-      const YT x0 = (ablate & 1) ? (YT)(c0[k] & 3) : x[c0[k] < 0 ? 0 : c0[k]];
-      const YT x1 = (ablate & 1) ? (YT)(c1[k] & 3) : x[c1[k] < 0 ? 0 : c1[k]];
-      if (ablate & 2) { acc += (YT)v0[k] * x0 + (YT)v1[k] * x1; }
-      else { prod[k * kBlock * 2 + t * 2] = (YT)v0[k] * x0; prod[k * kBlock * 2 + t * 2 + 1] = (YT)v1[k] * x1; }
-    }
-    if (ablate & 2) { if (acc == (YT)1.2345e30) y[0] = acc; return; }
-  } else {
-    if (full) stage_products<AT, YT, STEPS, true, false>(x, prod, t, v0, v1, c0, c1);
-    else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
-  }
-  __syncthreads();
-
-  // 3. per-row reduction out of LDS.  "Virtual rows" of this tile: an optional head (the row that
-  //    started in an earlier tile) followed by the rows that start here; only the last may be cut.
-  const int64_t ra         = blk_row[b] & 0x7fffffff;
-  const int64_t rb         = blk_row[b + 1] & 0x7fffffff;
-  const int64_t first_start = (int64_t)row_map[ra];
-  const bool has_head      = first_start > s;
-  const int64_t nv         = (rb - ra) + (has_head ? 1 : 0);
-  int G = 1;
-  while (G < kWave && nv * (G * 2) <= kBlock) G *= 2;
-  const int lane = t & (G - 1), grp = t / G, ngrp = kBlock / G;
-  for (int64_t base = 0; base < nv; base += ngrp) {
-    const int64_t j  = base + grp;
-    const bool valid = j < nv;
-    YT sum           = YT(0);
-    int64_t r        = -1;
-    bool is_head = false, complete = false;
-    if (valid) {
-      const int64_t jj = has_head ? j - 1 : j;
-      int64_t seg_s, seg_e;
-      if (jj < 0) {
-        is_head = true; seg_s = s; seg_e = first_start < e ? first_start : e;
-      } else {
-        r                = ra + jj;
-        seg_s            = (int64_t)row_map[r];
-        const int64_t re = (int64_t)row_map[r + 1];
-        complete         = re <= e;
-        seg_e            = complete ? re : e;
-      }
-      for (int i = (int)(seg_s - s) + lane; i < (int)(seg_e - s); i += G) sum += prod[i];
-    }
-    sum = group_sum(sum, G);
-    if (valid && lane == 0) {
-      if (is_head) carry_head[b] = sum;
-      else if (!complete) carry_tail[b] = sum;
-      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
-    }
-  }
-}
-
 // sum of prod[i0+lane], prod[i0+lane+G], ... below i1: four independent partial sums so that four LDS reads are
 // in flight per lane (a plain loop waits out one LDS round trip per element: ~1.3 us per 4096-nnz tile)
 template <class YT> __device__ __forceinline__ YT strided_lds_sum(const YT* prod, int i0, int i1, int lane, int G) {
@@ -727,28 +595,43 @@ template <class YT> __device__ __forceinline__ YT strided_lds_sum(const YT* prod
   return (s0 + s1) + (s2 + s3);
 }
 
-// Latency-lean stream kernel (the default).  Same tiling and carry protocol as spmv_stream_kernel; what
-// changes is the DEPENDENCY CHAIN each tile goes through, which is what bounds a kernel that needs ~100 KB
-// in flight per CU: the tile descriptor (first row + "starts inside a row" flag, one 8-byte scalar load) is
-// requested first, the streaming loads do not depend on it, and the per-lane row bounds
-// row_map[r], row_map[r+1] are requested together with the x gathers -- so a tile sees two memory
-// latencies (stream, then gather+bounds) instead of five (stream, gather, blk_row, row_map[ra], bounds).
-// After the barrier the row reduction touches only LDS and registers.
-template <class OffT, class AT, class YT, int NPT, bool NT, bool QP, int WIN = 0>
+// Measurement build (-DKK_ABLATE, tools/ only): parts of the kernel can be switched off through an extra kernel argument.
+// In the product build the argument does not exist and every KK_ABL(bit) folds to false.
+#ifdef KK_ABLATE
+#define KK_ABL_PARAM , int ablate
+#define KK_ABL_ARG(p) , (p)->tune.ablate
+#define KK_ABL(bit) ((ablate & (bit)) != 0)
+#define KK_LDS_PAD(p) ((size_t)(p)->tune.lds_pad_kb * 1024)
+#else
+#define KK_ABL_PARAM
+#define KK_ABL_ARG(p)
+#define KK_ABL(bit) false
+#define KK_LDS_PAD(p) ((size_t)0)
+#endif
+
+// The planned kernel (nnz-split tiles).  What bounds a kernel that needs ~100 KB in flight per CU is the DEPENDENCY CHAIN
+// each tile goes through: the tile descriptors (first row + "starts inside a row" flag, tile mode: two scalar loads) are
+// requested first, the streaming loads do not depend on them, and the per-lane row bounds row_map[r], row_map[r+1] are
+// requested together with the x gathers -- so a tile sees two memory latencies (stream, then gather + bounds).  After the
+// barrier the row reduction touches only LDS and registers.
+// CAP is what the plan can hold: 0 = no column analysis (every tile reads entries), 1 = window codes / LDS-staged x,
+// 2 = row-pattern records too.  The MODE is per tile (tinfo[b], workgroup-uniform): kTilePlain reads entries and gathers x
+// with quad-dealt loads, kTileCodes takes its columns from the plan's 16-bit window codes, kTileStaged also stages the
+// tile's x ranges in LDS (stage_products_win), kTilePattern decodes a row-pattern record and reads no per-nonzero code.
+// One tile the codes cannot cover costs that tile its codes, not the matrix.
+template <class OffT, class AT, class YT, int NPT, bool NT, int CAP>
 __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const OffT* __restrict__ row_map,
                                                               const int32_t* __restrict__ entries,
                                                               const AT* __restrict__ values, const YT* __restrict__ x,
                                                               YT* __restrict__ y, YT alpha, YT beta,
                                                               const int32_t* __restrict__ blk_info,
                                                               YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
-                                                              int remap, int ablate, const uint16_t* __restrict__ wcode = nullptr,
-                                                              const int32_t* __restrict__ wmeta = nullptr, int64_t ncols = 0,
-                                                              const int32_t* __restrict__ pmeta = nullptr) {
-  // WIN 1: the columns come from the plan's 16-bit window codes (wcode, wmeta) instead of entries; WIN 2: x is staged
-  // in LDS from the tile's contiguous column ranges as well (stage_products_win); WIN 3: as 2, and tiles with a
-  // row-pattern record (pmeta) read no per-nonzero codes at all
-  // ablate (diagnosis knob, 0 in production; results in DESIGN.md 4.1): 4 = no y stores, 8 = no LDS reduction
-  // loop, 16 = synthetic row bounds (no row_map loads), 32 = no barrier, 64 / 128 = y-store experiments (see the store)
+                                                              int remap, const int32_t* __restrict__ tinfo,
+                                                              const uint16_t* __restrict__ wcode,
+                                                              const int32_t* __restrict__ wmeta, int64_t ncols,
+                                                              const int32_t* __restrict__ pmeta KK_ABL_PARAM) {
+  // KK_ABL bits (measurement build): 4 = no y stores, 8 = no LDS reduction loop, 16 = synthetic row bounds (no row_map
+  // loads), 32 = no barrier, 64 / 128 = y-store experiments (see the store)
   constexpr int TILE  = kBlock * NPT;
   constexpr int STEPS = NPT / 2;
   __shared__ YT prod[TILE];
@@ -760,14 +643,22 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
 
   // tile descriptor: bit 31 = the tile starts inside a row (a "head" segment exists)
   const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
+  int mode = kTilePlain;
+  const uint16_t* wtile = nullptr;
+  if (CAP >= 1) {
+    const int32_t ti = tinfo[b];
+    mode  = ti & 3;
+    if (CAP < 2 && mode == kTilePattern) mode = kTileStaged;
+    wtile = wcode + (int64_t)((unsigned)ti >> 2) * TILE;       // meaningful for modes 1 and 2 only
+  }
 
   AT v0[STEPS], v1[STEPS];
   int c0[STEPS], c1[STEPS];
-  if (WIN >= 2) {
+  if (CAP >= 1 && mode >= kTileStaged) {
     // nothing to load here: stage_products_win requests values, codes and x chunks together
-  } else if (WIN == 1) {
-    if (full) load_tile_win<AT, STEPS, true>(values, wcode, wmeta, b, s, e, t, v0, v1, c0, c1);
-    else      load_tile_win<AT, STEPS, false>(values, wcode, wmeta, b, s, e, t, v0, v1, c0, c1);
+  } else if (CAP >= 1 && mode == kTileCodes) {
+    if (full) load_tile_win<AT, STEPS, true>(values, wtile, wmeta, b, s, e, t, v0, v1, c0, c1);
+    else      load_tile_win<AT, STEPS, false>(values, wtile, wmeta, b, s, e, t, v0, v1, c0, c1);
   } else {
     if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
     else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
@@ -785,21 +676,23 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   int64_t r  = ra + grp - has_head;
   int64_t rs = 0, re = 0;
   if (valid) {
-    if (ablate & 16) { rs = s + (int64_t)grp * 27; re = rs + 27; }
+    if (KK_ABL(16)) { rs = s + (int64_t)grp * 27; re = rs + 27; }
     else { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
   }
   // beta != 0: the old y of the first pass' rows is requested now, with everything else, instead of right before the store
   YT yold = YT(0);
   if (beta != YT(0) && valid && lane == 0 && r >= 0) yold = y[r];
 
-  if (WIN >= 2) {
-    if (full) stage_products_win<AT, YT, STEPS, true, NT, WIN == 3>(values, wcode, wmeta, x, ncols, prod, b, s, e, t, pmeta);
-    else      stage_products_win<AT, YT, STEPS, false, NT, WIN == 3>(values, wcode, wmeta, x, ncols, prod, b, s, e, t, pmeta);
+  if (CAP >= 2 && mode == kTilePattern) {                       // records exist for full tiles only
+    stage_products_win<AT, YT, STEPS, true, NT, true>(values, wtile, wmeta, x, ncols, prod, b, s, e, t, pmeta);
+  } else if (CAP >= 1 && mode == kTileStaged) {
+    if (full) stage_products_win<AT, YT, STEPS, true, NT, false>(values, wtile, wmeta, x, ncols, prod, b, s, e, t, nullptr);
+    else      stage_products_win<AT, YT, STEPS, false, NT, false>(values, wtile, wmeta, x, ncols, prod, b, s, e, t, nullptr);
   } else {
-    if (full) stage_products<AT, YT, STEPS, true, QP>(x, prod, t, v0, v1, c0, c1);
+    if (full) stage_products<AT, YT, STEPS, true, true>(x, prod, t, v0, v1, c0, c1);
     else      stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
   }
-  if (!(ablate & 32)) __syncthreads();
+  if (!KK_ABL(32)) __syncthreads();
 
   for (int64_t base = 0; base < nv; base += ngrp) {
     if (base > 0) {
@@ -810,337 +703,16 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
     const bool is_head  = r < ra;
     const bool complete = !is_head && re <= e;
     const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
-    YT sum = valid ? ((ablate & 8) ? prod[i0 < TILE ? i0 : 0] : strided_lds_sum<YT>(prod, i0, i1, lane, G)) : YT(0);
+    YT sum = valid ? (KK_ABL(8) ? prod[i0 < TILE ? i0 : 0] : strided_lds_sum<YT>(prod, i0, i1, lane, G)) : YT(0);
     sum = group_sum(sum, G);
     if (valid && lane == 0) {
       if (is_head) carry_head[b] = sum;
       else if (!complete) carry_tail[b] = sum;
-      else if (!(ablate & 4) && !((ablate & 64) && (b & 7))) {       // 64: only one tile in eight stores its rows
+      else if (!KK_ABL(4) && !(KK_ABL(64) && (b & 7))) {          // 64: only one tile in eight stores its rows
         sum *= alpha;
         const YT out = (beta == YT(0)) ? sum : beta * (base == 0 ? yold : y[r]) + sum;
-        y[(ablate & 128) ? (r & 255) : r] = out;                         // 128: every store lands in the same 2 KB
+        y[KK_ABL(128) ? (r & 255) : r] = out;                      // 128: every store lands in the same 2 KB
       }
-    }
-  }
-}
-
-// Late-gather variant (stream_variant 5): the tile's (value, column) pairs are staged in LDS as they are, and x is
-// gathered in the ROW phase -- the lanes that sum a row read its entries back from LDS and fetch x there.  With one
-// lane per row, the lanes of a quad then gather the k-th entries of four CONSECUTIVE rows; on stencil-like matrices
-// those are adjacent columns, i.e. one cache line and one L1 tag look-up per quad instead of the ~2 the quad-dealt
-// layout of the default kernel needs (the tag look-up rate is what bounds the default kernel: 5.8e8 look-ups per
-// launch on the 27-pt 300^3 matrix, ~1 per clock per CU).
-template <class AT, class YT>
-__device__ __forceinline__ YT strided_lds_dot(const AT* s_val, const int* s_col, const YT* __restrict__ x, int i0, int i1, int lane, int G) {
-  YT s0 = YT(0), s1 = YT(0), s2 = YT(0), s3 = YT(0);
-  int i = i0 + lane;
-  const int G2 = 2 * G, G3 = 3 * G, G4 = 4 * G;
-  for (; i + G3 < i1; i += G4) {
-    const int ca = s_col[i], cb = s_col[i + G], cc = s_col[i + G2], cd = s_col[i + G3];
-    const YT xa = x[ca], xb = x[cb], xc = x[cc], xd = x[cd];
-    s0 += (YT)s_val[i] * xa; s1 += (YT)s_val[i + G] * xb; s2 += (YT)s_val[i + G2] * xc; s3 += (YT)s_val[i + G3] * xd;
-  }
-  for (; i < i1; i += G) s0 += (YT)s_val[i] * x[s_col[i]];
-  return (s0 + s1) + (s2 + s3);
-}
-template <class OffT, class AT, class YT, int NPT, bool NT>
-__global__ __launch_bounds__(kBlock) void spmv_stream6_kernel(int64_t nnz, const OffT* __restrict__ row_map,
-                                                              const int32_t* __restrict__ entries,
-                                                              const AT* __restrict__ values, const YT* __restrict__ x,
-                                                              YT* __restrict__ y, YT alpha, YT beta,
-                                                              const int32_t* __restrict__ blk_info,
-                                                              YT* __restrict__ carry_head, YT* __restrict__ carry_tail, int remap) {
-  constexpr int TILE  = kBlock * NPT;
-  constexpr int STEPS = NPT / 2;
-  constexpr int SPAN  = kBlock * 2;
-  __shared__ AT s_val[TILE];
-  __shared__ int s_col[TILE];
-  const int t     = threadIdx.x;
-  const int64_t b = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-  const int64_t s = b * TILE;
-  const bool full = (s + TILE <= nnz);
-  const int64_t e = full ? s + TILE : nnz;
-  const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
-  AT v0[STEPS], v1[STEPS];
-  int c0[STEPS], c1[STEPS];
-  if (full) load_tile<AT, STEPS, NT, true>(values, entries, s, e, t, v0, v1, c0, c1);
-  else      load_tile<AT, STEPS, NT, false>(values, entries, s, e, t, v0, v1, c0, c1);
-  const int64_t ra    = info0 & 0x7fffffff;
-  const int64_t rb    = info1 & 0x7fffffff;
-  const int has_head  = (info0 >> 31) & 1;
-  const int64_t nv    = (rb - ra) + has_head;
-  int G = 1;
-  while (G < kWave && nv * (G * 2) <= kBlock) G *= 2;
-  const int lane = t & (G - 1), grp = t / G, ngrp = kBlock / G;
-  bool valid = grp < nv;
-  int64_t r  = ra + grp - has_head;
-  int64_t rs = 0, re = 0;
-  if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
-  KK_UNROLL
-  for (int k = 0; k < STEPS; ++k) {
-    const int li = k * SPAN + t * 2;
-    s_val[li] = v0[k]; s_val[li + 1] = v1[k];
-    s_col[li] = c0[k] < 0 ? 0 : c0[k]; s_col[li + 1] = c1[k] < 0 ? 0 : c1[k];     // padding entries carry value 0
-  }
-  __syncthreads();
-  for (int64_t base = 0; base < nv; base += ngrp) {
-    if (base > 0) {
-      valid = (base + grp) < nv;
-      r     = ra + base + grp - has_head;
-      if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
-    }
-    const bool is_head  = r < ra;
-    const bool complete = !is_head && re <= e;
-    const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
-    YT sum = valid ? strided_lds_dot<AT, YT>(s_val, s_col, x, i0, i1, lane, G) : YT(0);
-    sum = group_sum(sum, G);
-    if (valid && lane == 0) {
-      if (is_head) carry_head[b] = sum;
-      else if (!complete) carry_tail[b] = sum;
-      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
-    }
-  }
-}
-
-// Wave-private variant: every 64-lane wave owns its own tile of 64*NPT nnz and its own slice of LDS, so the
-// kernel contains no workgroup barrier at all -- a wave's load -> gather -> LDS -> reduce chain never waits
-// for its three siblings, and a CU interleaves 32 independent chains instead of 8.  Same descriptor / carry
-// protocol with tile = 64*NPT.
-template <class OffT, class AT, class YT, int NPT, bool NT>
-__global__ __launch_bounds__(kBlock) void spmv_wave_kernel(int64_t nnz, int64_t ntiles, const OffT* __restrict__ row_map,
-                                                           const int32_t* __restrict__ entries,
-                                                           const AT* __restrict__ values, const YT* __restrict__ x,
-                                                           YT* __restrict__ y, YT alpha, YT beta,
-                                                           const int32_t* __restrict__ blk_info,
-                                                           YT* __restrict__ carry_head, YT* __restrict__ carry_tail) {
-  constexpr int WT    = kWave * NPT;
-  constexpr int STEPS = NPT / 2;
-  constexpr int SPAN  = kWave * 2;
-  using AV = typename vec2<AT>::type;
-  __shared__ YT prod_all[kBlock / kWave][WT];
-  const int lane64 = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t b  = (int64_t)blockIdx.x * (kBlock / kWave) + w;
-  YT* prod         = prod_all[w];
-  const bool active = b < ntiles;          // wave-uniform
-  const int64_t s   = b * WT;
-  const bool full   = active && (s + WT <= nnz);
-  const int64_t e   = full ? s + WT : nnz;
-
-  AT v0[STEPS], v1[STEPS];
-  int c0[STEPS], c1[STEPS];
-  int32_t info0 = 0, info1 = 0;
-  if (active) { info0 = blk_info[b]; info1 = blk_info[b + 1]; }
-  KK_UNROLL
-  for (int k = 0; k < STEPS; ++k) {
-    const int64_t idx = s + (int64_t)k * SPAN + lane64 * 2;
-    if (full) {
-      const AV* vp       = reinterpret_cast<const AV*>(values + idx);
-      const kk_i32x2* cp = reinterpret_cast<const kk_i32x2*>(entries + idx);
-      const AV vv        = NT ? KK_NT_LOAD(vp) : *vp;
-      const kk_i32x2 cc  = NT ? KK_NT_LOAD(cp) : *cp;
-      v0[k] = vv[0]; v1[k] = vv[1]; c0[k] = cc[0]; c1[k] = cc[1];
-    } else {
-      v0[k] = (active && idx < e) ? values[idx] : AT(0);         c0[k] = (active && idx < e) ? entries[idx] : 0;
-      v1[k] = (active && idx + 1 < e) ? values[idx + 1] : AT(0); c1[k] = (active && idx + 1 < e) ? entries[idx + 1] : 0;
-    }
-  }
-  const int64_t ra   = info0 & 0x7fffffff;
-  const int64_t rb   = info1 & 0x7fffffff;
-  const int has_head = (info0 >> 31) & 1;
-  const int64_t nv   = active ? (rb - ra) + has_head : 0;
-  int G = 1;
-  while (G < kWave && nv * (G * 2) <= kWave) G *= 2;
-  const int lane = lane64 & (G - 1), grp = lane64 / G, ngrp = kWave / G;
-  bool valid = grp < nv;
-  int64_t r  = ra + grp - has_head;
-  int64_t rs = 0, re = 0;
-  if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
-
-  YT x0[STEPS], x1[STEPS];
-  KK_UNROLL
-  for (int k = 0; k < STEPS; ++k) { x0[k] = x[c0[k]]; x1[k] = x[c1[k]]; }     // masked lanes read x[0] times 0
-  KK_UNROLL
-  for (int k = 0; k < STEPS; ++k) {
-    const int li = k * SPAN + lane64 * 2;
-    prod[li]     = (YT)v0[k] * x0[k];
-    prod[li + 1] = (YT)v1[k] * x1[k];
-  }
-  KK_WAVE_SYNC();   // the wave's own LDS writes precede its reads (LDS is in-order per wave); no s_barrier
-
-  for (int64_t base = 0; base < nv; base += ngrp) {
-    if (base > 0) {
-      valid = (base + grp) < nv;
-      r     = ra + base + grp - has_head;
-      if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
-    }
-    const bool is_head  = r < ra;
-    const bool complete = !is_head && re <= e;
-    const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
-    YT sum = valid ? strided_lds_sum<YT>(prod, i0, i1, lane, G) : YT(0);
-    sum = group_sum(sum, G);
-    if (valid && lane == 0) {
-      if (is_head) carry_head[b] = sum;
-      else if (!complete) carry_tail[b] = sum;
-      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
-    }
-  }
-}
-
-// ---- tile-local column structure (TLC) ----------------------------------------------------------------
-// Sorted distinct columns of tile b in LDS (uniq[0..nd)); returns nd.  keys/uniq: T ints each.
-template <int T>
-__device__ __forceinline__ int tile_sort_unique(const int32_t* __restrict__ entries, int64_t s, int64_t e, int* keys, int* uniq,
-                                                int* s_wave) {
-  const int t = threadIdx.x;
-  constexpr int PER = T / kBlock;
-  for (int i = t; i < T; i += kBlock) keys[i] = (s + i < e) ? entries[s + i] : INT_MAX;
-  __syncthreads();
-  for (int k = 2; k <= T; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < T; i += kBlock) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const int a = keys[i], b = keys[ixj];
-          if ((a > b) == ((i & k) == 0)) { keys[i] = b; keys[ixj] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  // each thread owns PER consecutive sorted keys; a key is kept when it differs from its predecessor
-  int cnt = 0;
-  for (int q = 0; q < PER; ++q) {
-    const int i = t * PER + q;
-    const int kv = keys[i];
-    if (kv != INT_MAX && (i == 0 || keys[i - 1] != kv)) ++cnt;
-  }
-  int total;
-  int pos = block_exclusive_scan<int>(cnt, &total, s_wave);
-  for (int q = 0; q < PER; ++q) {
-    const int i = t * PER + q;
-    const int kv = keys[i];
-    if (kv != INT_MAX && (i == 0 || keys[i - 1] != kv)) uniq[pos++] = kv;
-  }
-  __syncthreads();
-  return total;
-}
-
-template <int T>
-__global__ __launch_bounds__(kBlock) void tlc_count_kernel(int64_t nnz, const int32_t* __restrict__ entries, int64_t* __restrict__ uoff) {
-  __shared__ int keys[T];
-  __shared__ int uniq[T];
-  __shared__ int s_wave[kBlock / 64];
-  const int64_t b = blockIdx.x, s = b * T, e = (s + T < nnz) ? s + T : nnz;
-  const int nd = tile_sort_unique<T>(entries, s, e, keys, uniq, s_wave);
-  if (threadIdx.x == 0) { uoff[b] = nd; if (b == (int64_t)gridDim.x - 1) uoff[b + 1] = 0; }
-}
-
-template <int T>
-__global__ __launch_bounds__(kBlock) void tlc_build_kernel(int64_t nnz, const int32_t* __restrict__ entries,
-                                                           const int64_t* __restrict__ uoff, int32_t* __restrict__ ucols,
-                                                           uint16_t* __restrict__ lidx) {
-  __shared__ int keys[T];
-  __shared__ int uniq[T];
-  __shared__ int s_wave[kBlock / 64];
-  const int64_t b = blockIdx.x, s = b * T, e = (s + T < nnz) ? s + T : nnz;
-  const int nd = tile_sort_unique<T>(entries, s, e, keys, uniq, s_wave);
-  const int64_t u0 = uoff[b];
-  for (int j = threadIdx.x; j < nd; j += kBlock) ucols[u0 + j] = uniq[j];
-  for (int64_t i = s + threadIdx.x; i < e; i += kBlock) {
-    const int c = entries[i];
-    int lo = 0, hi = nd;                       // lower bound in uniq (c is present)
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (uniq[mid] < c) lo = mid + 1; else hi = mid; }
-    lidx[i] = (uint16_t)lo;
-  }
-}
-
-// Stream kernel over the tile-local column structure: the tile's distinct x entries are fetched ONCE, through
-// an ascending (hence well-coalesced) index list, into an LDS window; the per-nnz gather then reads LDS with a
-// 16-bit local index.  Per nnz this moves 8 B (value) + 2 B (local index) + 4 B per DISTINCT column instead of
-// 8 + 4, and cuts the texture-path lookups ~2-3x on matrices whose neighbouring rows share columns.  A tile with
-// more than XCAP distinct columns (no reuse to exploit) falls back to direct gathers through `entries`.
-template <class OffT, class AT, class YT, int NPT, int XCAP>
-__global__ __launch_bounds__(kBlock) void spmv_stream5_kernel(int64_t nnz, const OffT* __restrict__ row_map,
-                                                              const int32_t* __restrict__ entries,
-                                                              const AT* __restrict__ values, const YT* __restrict__ x,
-                                                              YT* __restrict__ y, YT alpha, YT beta,
-                                                              const int32_t* __restrict__ blk_info,
-                                                              const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucols,
-                                                              const uint16_t* __restrict__ lidx,
-                                                              YT* __restrict__ carry_head, YT* __restrict__ carry_tail) {
-  constexpr int TILE  = kBlock * NPT;
-  constexpr int STEPS = NPT / 2;
-  constexpr int SPAN  = kBlock * 2;
-  using AV = typename vec2<AT>::type;
-  __shared__ YT prod[TILE];
-  __shared__ YT xw[XCAP];
-  const int t     = threadIdx.x;
-  const int64_t b = blockIdx.x;
-  const int64_t s = b * TILE;
-  const bool full = (s + TILE <= nnz);
-  const int64_t e = full ? s + TILE : nnz;
-  const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
-  const int64_t u0 = uoff[b];
-  const int nd     = (int)(uoff[b + 1] - u0);
-  const bool windowed = full && nd <= XCAP;                // workgroup-uniform
-
-  AT v0[STEPS], v1[STEPS];
-  int c0[STEPS], c1[STEPS];                                // local indices (windowed) or global columns (fallback)
-  if (windowed) {
-    KK_UNROLL
-    for (int k = 0; k < STEPS; ++k) {
-      const int64_t idx = s + (int64_t)k * SPAN + t * 2;
-      const AV vv = *reinterpret_cast<const AV*>(values + idx);
-      const unsigned pr = *reinterpret_cast<const unsigned*>(lidx + idx);     // two 16-bit local indices
-      v0[k] = vv[0]; v1[k] = vv[1]; c0[k] = (int)(pr & 0xffffu); c1[k] = (int)(pr >> 16);
-    }
-    for (int j = t; j < nd; j += kBlock) xw[j] = x[ucols[u0 + j]];
-  } else if (full) {
-    load_tile<AT, STEPS, false, true>(values, entries, s, e, t, v0, v1, c0, c1);
-  } else {
-    load_tile<AT, STEPS, false, false>(values, entries, s, e, t, v0, v1, c0, c1);
-  }
-  const int64_t ra   = info0 & 0x7fffffff;
-  const int64_t rb   = info1 & 0x7fffffff;
-  const int has_head = (info0 >> 31) & 1;
-  const int64_t nv   = (rb - ra) + has_head;
-  int G = 1;
-  while (G < kWave && nv * (G * 2) <= kBlock) G *= 2;
-  const int lane = t & (G - 1), grp = t / G, ngrp = kBlock / G;
-  bool valid = grp < nv;
-  int64_t r  = ra + grp - has_head;
-  int64_t rs = 0, re = 0;
-  if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
-
-  if (windowed) {
-    __syncthreads();                                       // x window complete
-    KK_UNROLL
-    for (int k = 0; k < STEPS; ++k) {
-      const int li = k * SPAN + t * 2;
-      prod[li]     = (YT)v0[k] * xw[c0[k]];
-      prod[li + 1] = (YT)v1[k] * xw[c1[k]];
-    }
-  } else if (full) {
-    stage_products<AT, YT, STEPS, true, true>(x, prod, t, v0, v1, c0, c1);
-  } else {
-    stage_products<AT, YT, STEPS, false, false>(x, prod, t, v0, v1, c0, c1);
-  }
-  __syncthreads();
-
-  for (int64_t base = 0; base < nv; base += ngrp) {
-    if (base > 0) {
-      valid = (base + grp) < nv;
-      r     = ra + base + grp - has_head;
-      if (valid) { rs = (int64_t)row_map[r]; re = (int64_t)row_map[r + 1]; }
-    }
-    const bool is_head  = r < ra;
-    const bool complete = !is_head && re <= e;
-    const int i0 = (int)((rs > s ? rs : s) - s), i1 = (int)((re < e ? re : e) - s);
-    YT sum = valid ? strided_lds_sum<YT>(prod, i0, i1, lane, G) : YT(0);
-    sum = group_sum(sum, G);
-    if (valid && lane == 0) {
-      if (is_head) carry_head[b] = sum;
-      else if (!complete) carry_tail[b] = sum;
-      else { sum *= alpha; y[r] = (beta == YT(0)) ? sum : beta * y[r] + sum; }
     }
   }
 }
@@ -1181,228 +753,6 @@ __global__ __launch_bounds__(kBlock) void spmv_transpose_kernel(int64_t nrows, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// rank-2, no transpose.  A workgroup takes RPB = 256/SW consecutive rows; SW lanes (one per right-hand
-// side of the current strip) form a row group.  The rows' nnz range is contiguous in CSR, so the
-// workgroup streams it through LDS in CH-sized chunks with coalesced loads (A is read once per strip),
-// and each group walks its own row's part of the chunk: LDS broadcast of (val, col), then one
-// X(col, strip) access per lane -- a contiguous 8*SW bytes when X is row-major.
-template <class OffT, class AT, class YT, int SW>
-__global__ __launch_bounds__(kBlock) void spmv_mv_kernel(int64_t nrows, const OffT* __restrict__ row_map,
-                                                         const int32_t* __restrict__ entries,
-                                                         const AT* __restrict__ values, const YT* __restrict__ X,
-                                                         int64_t xs0, int64_t xs1, YT* __restrict__ Y, int64_t ys0,
-                                                         int64_t ys1, int64_t nvec, YT alpha, YT beta, int remap) {
-  constexpr int RPB = kBlock / SW;
-  constexpr int CH  = 2048;
-  __shared__ AT s_val[CH];
-  __shared__ int s_col[CH];
-  const int t        = threadIdx.x;
-  const int64_t wg   = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-  const int64_t row0 = wg * RPB;
-  const int64_t rowN = (row0 + RPB < nrows) ? row0 + RPB : nrows;
-  const int64_t row  = row0 + t / SW;
-  const int k        = t % SW;
-  const int64_t lo   = (int64_t)row_map[row0];
-  const int64_t hi   = (int64_t)row_map[rowN];
-  int64_t rs = 0, re = 0;
-  if (row < nrows) { rs = (int64_t)row_map[row]; re = (int64_t)row_map[row + 1]; }
-  for (int64_t kk = 0; kk < nvec; kk += SW) {
-    const bool col_ok = (kk + k) < nvec;
-    YT acc            = YT(0);
-    for (int64_t c = lo; c < hi; c += CH) {
-      const int64_t ce = (c + CH < hi) ? c + CH : hi;
-      __syncthreads();
-      for (int64_t i = c + t; i < ce; i += kBlock) { s_val[i - c] = values[i]; s_col[i - c] = entries[i]; }
-      __syncthreads();
-      if (col_ok) {
-        const int64_t a = rs > c ? rs : c, z = re < ce ? re : ce;
-        const YT* xp    = X + (kk + k) * xs1;
-        for (int64_t i = a; i < z; ++i) acc += (YT)s_val[i - c] * xp[(int64_t)s_col[i - c] * xs0];
-      }
-    }
-    if (col_ok && row < nrows) {
-      acc *= alpha;
-      YT* yp = Y + row * ys0 + (kk + k) * ys1;
-      *yp    = (beta == YT(0)) ? acc : beta * (*yp) + acc;
-    }
-  }
-}
-
-// rank-2, no transpose, row-major X (the fast path).  One 64-lane WAVE owns RW = 64/LPRW consecutive rows;
-// LPRW lanes form a row group and each lane carries TWO right-hand sides, so one X access is a 16-byte load and a
-// wave-level load instruction moves 64 x 16 B = 1 KB (the generic kernel above moves 512 B per instruction with
-// 4 rows in flight and is bound by the texture path at ~13 % of the HBM roofline).  The wave's contiguous CSR
-// range is staged through its private LDS slice with 16-byte loads (4-aligned windows), no workgroup barrier.
-typedef int kk_i32x4 __attribute__((vector_size(16)));
-template <class OffT, class AT, class YT, int LPRW, int RPL, int CHW>
-__global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ row_map,
-                                                          const int32_t* __restrict__ entries,
-                                                          const AT* __restrict__ values, const YT* __restrict__ X,
-                                                          int64_t xs0, YT* __restrict__ Y, int64_t ys0, int64_t ys1,
-                                                          int64_t nvec, YT alpha, YT beta, int y_vec_ok, int remap) {
-  // XCD-contiguous workgroup order (remap): the 128-byte X rows a row block touches are shared with the blocks
-  // that handle rows i+-1, j+-1 (and k+-1); keeping neighbouring blocks on ONE XCD keeps those X rows in its
-  // 4 MiB L2.  With the dispatcher's round-robin order every XCD fetched every X row: rocprof showed 10.7
-  // memory fetches per X row (45 GB per launch on the 300^3 x 16 case against 12 GB of compulsory reads).
-  // LPRW lanes per row, RPL (2 or 4) right-hand sides per lane: strip width SW = LPRW*RPL, RW rows per wave.
-  // RPL = 4 halves the per-nnz LDS-read / address arithmetic per FMA; a quad of lanes then covers one 128 B X row.
-  constexpr int RW  = kWave / LPRW;
-  constexpr int SW  = RPL * LPRW;
-  constexpr int NV2 = RPL / 2;           // 16-byte pieces per lane
-  // CHW = nnz staged per wave per pass (256 / 512 / 1024, picked from the average row length): a window smaller than the
-  // RW rows of the wave makes every wave run several passes with part of its lanes idle -- with 256 on the 27-pt matrix
-  // (16 rows x 27 = 432 nnz) the kernel issued twice the X load instructions it needed and the texture addresser was busy
-  // 95 % of the time (rocprof TA_BUSY).
-  using AV = typename vec2<AT>::type;
-  using XV = typename vec2<YT>::type;
-  __shared__ AT s_val_all[kBlock / kWave][CHW];
-  __shared__ int s_col_all[kBlock / kWave][CHW];
-  const int lane64 = threadIdx.x & 63, w = threadIdx.x >> 6;
-  AT* s_val  = s_val_all[w];
-  int* s_col = s_col_all[w];
-  const int64_t wg   = xcd_order(blockIdx.x, gridDim.x, (remap & 1) ? 1 : (remap & ~3));   // 1 contiguous, 4 / 8 / 16 grouped
-  const int64_t row0 = (wg * (kBlock / kWave) + w) * RW;
-  if (row0 >= nrows) return;                                   // whole wave leaves together
-  const int64_t rowN = (row0 + RW < nrows) ? row0 + RW : nrows;
-  const int grp = lane64 / LPRW, l = lane64 % LPRW;
-  const int64_t row = row0 + grp;
-  const int64_t lo  = (int64_t)row_map[row0] & ~(int64_t)3;    // 4-aligned staging windows
-  const int64_t hi  = (int64_t)row_map[rowN];
-  int64_t rs = 0, re = 0;
-  if (row < rowN) { rs = (int64_t)row_map[row]; re = (int64_t)row_map[row + 1]; }
-  for (int64_t kk = 0; kk < nvec; kk += SW) {
-    // piece q of lane l covers right-hand sides kk + q*2*LPRW + 2l and +1: the LPRW lanes of a row then read ONE contiguous
-    // 16*LPRW-byte run per load instruction (one 64 B sector of the X row for LPRW = 4) instead of 16 B out of every
-    // 32 B, which made each of the two instructions pull both sectors of the 128 B line through the L1
-    const int64_t cA = kk + 2 * l;
-    constexpr int64_t PQ = 2 * LPRW;                 // column distance between a lane's pieces
-    const bool all_ok = kk + SW <= nvec;
-    YT acc[RPL];
-    KK_UNROLL
-    for (int q = 0; q < RPL; ++q) acc[q] = YT(0);
-    for (int64_t c = lo; c < hi; c += CHW) {
-      KK_WAVE_SYNC();
-      if (c + CHW <= nnz) {   // whole window inside the arrays (wave-uniform): three unguarded 16-byte loads per lane and 256 nnz
-        KK_UNROLL
-        for (int sub = 0; sub < CHW; sub += 256) {
-          const kk_i32x4 cc = *reinterpret_cast<const kk_i32x4*>(entries + c + sub + lane64 * 4);
-          const AV va = *reinterpret_cast<const AV*>(values + c + sub + lane64 * 2);
-          const AV vb = *reinterpret_cast<const AV*>(values + c + sub + 128 + lane64 * 2);
-          const int cm = (remap & 2) ? 255 : -1;       // bench-only ablation: every X access hits 256 rows that stay in L1
-          s_col[sub + lane64 * 4] = cc[0] & cm; s_col[sub + lane64 * 4 + 1] = cc[1] & cm; s_col[sub + lane64 * 4 + 2] = cc[2] & cm; s_col[sub + lane64 * 4 + 3] = cc[3] & cm;
-          s_val[sub + lane64 * 2] = va[0]; s_val[sub + lane64 * 2 + 1] = va[1];
-          s_val[sub + 128 + lane64 * 2] = vb[0]; s_val[sub + 128 + lane64 * 2 + 1] = vb[1];
-        }
-      } else {
-        for (int q = 0; q < CHW / 64; ++q) {
-          const int64_t i = c + lane64 * (CHW / 64) + q;
-          s_col[lane64 * (CHW / 64) + q] = (i < nnz) ? entries[i] : 0;
-          s_val[lane64 * (CHW / 64) + q] = (i < nnz) ? values[i] : AT(0);
-        }
-      }
-      KK_WAVE_SYNC();
-      const int64_t ce = c + CHW;
-      const int a = (int)((rs > c ? rs : c) - c), z = (int)((re < ce ? re : ce) - c);
-      if (all_ok) {
-        // batches of U entries: all U*NV2 16-byte X loads are issued before the first FMA consumes one
-        // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> fma per entry: one load in flight per wave)
-        // batches of 8, then 4, 2, 1 entries: inside a batch all X loads are issued before the first FMA consumes one
-        // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> fma per entry: one load in flight per wave)
-#define KK_MV_BATCH(UU)                                                                                                  \
-        {                                                                                                                \
-          YT v[UU]; XV xv[UU][NV2];                                                                                      \
-          KK_UNROLL                                                                                                      \
-          for (int u = 0; u < UU; ++u) {                                                                                 \
-            v[u] = (YT)s_val[i + u];                                                                                     \
-            const YT* xp = X + (int64_t)s_col[i + u] * xs0 + cA;                                                         \
-            KK_UNROLL                                                                                                    \
-            for (int q = 0; q < NV2; ++q) xv[u][q] = *reinterpret_cast<const XV*>(xp + q * PQ);                          \
-          }                                                                                                              \
-          KK_UNROLL                                                                                                      \
-          for (int u = 0; u < UU; ++u) {                                                                                 \
-            KK_UNROLL                                                                                                    \
-            for (int q = 0; q < NV2; ++q) { acc[2 * q] += v[u] * xv[u][q][0]; acc[2 * q + 1] += v[u] * xv[u][q][1]; }    \
-          }                                                                                                              \
-          i += UU;                                                                                                       \
-        }
-        int i = a;
-        while (i + 8 <= z) KK_MV_BATCH(8)
-        if (i + 4 <= z) KK_MV_BATCH(4)
-        if (i + 2 <= z) KK_MV_BATCH(2)
-        if (i < z) KK_MV_BATCH(1)
-#undef KK_MV_BATCH
-      } else {
-        for (int i = a; i < z; ++i) {
-          const YT v = (YT)s_val[i];
-          const YT* xp = X + (int64_t)s_col[i] * xs0 + cA;
-          for (int q = 0; q < RPL; ++q) { const int64_t cq = (q >> 1) * PQ + (q & 1); if (cA + cq < nvec) acc[q] += v * xp[cq]; }
-        }
-      }
-    }
-    if (row < rowN) {
-      YT* yp = Y + row * ys0 + cA * ys1;
-      if (all_ok && y_vec_ok) {
-        KK_UNROLL
-        for (int q = 0; q < NV2; ++q) {
-          XV out;
-          XV* yq = reinterpret_cast<XV*>(yp + q * PQ);
-          if (beta == YT(0)) { out[0] = alpha * acc[2 * q]; out[1] = alpha * acc[2 * q + 1]; }
-          else { const XV old = *yq; out[0] = beta * old[0] + alpha * acc[2 * q]; out[1] = beta * old[1] + alpha * acc[2 * q + 1]; }
-          *yq = out;
-        }
-      } else {
-        for (int q = 0; q < RPL; ++q) {
-          const int64_t cq = (q >> 1) * PQ + (q & 1);
-          if (cA + cq < nvec) { const YT r = alpha * acc[q]; yp[cq * ys1] = (beta == YT(0)) ? r : beta * yp[cq * ys1] + r; }
-        }
-      }
-    }
-  }
-}
-
-// X(ncols x nvec, column-major or any strides) -> row-major, leading dimension ldp (even): the packing step that
-// lets a LayoutLeft multivector use the 16-byte-per-lane row-major kernel.  32x32 LDS tile transpose.
-template <class YT>
-__global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n, int64_t nvec, const YT* __restrict__ X, int64_t xs0,
-                                                           int64_t xs1, YT* __restrict__ Xp, int64_t ldp) {
-  __shared__ YT tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-  const int64_t i0 = (int64_t)blockIdx.x * 32;
-  for (int64_t j0 = 0; j0 < nvec; j0 += 32) {
-    __syncthreads();
-    for (int q = ty; q < 32; q += 8) {                             // read: consecutive lanes walk i (stride xs0)
-      const int64_t i = i0 + tx, j = j0 + q;
-      tile[q][tx] = (i < n && j < nvec) ? X[i * xs0 + j * xs1] : YT(0);
-    }
-    __syncthreads();
-    for (int q = ty; q < 32; q += 8) {                             // write: consecutive lanes walk j (contiguous)
-      const int64_t i = i0 + q, j = j0 + tx;
-      if (i < n && j < ldp) Xp[i * ldp + j] = tile[tx][q];
-    }
-  }
-}
-
-// rank-2 transpose: Y(col, k) += alpha * val * X(row, k) after Y := beta*Y (K6 analogue).
-template <class OffT, class AT, class YT>
-__global__ __launch_bounds__(kBlock) void spmv_mv_transpose_kernel(int64_t nrows, const OffT* __restrict__ row_map,
-                                                                   const int32_t* __restrict__ entries,
-                                                                   const AT* __restrict__ values,
-                                                                   const YT* __restrict__ X, int64_t xs0, int64_t xs1,
-                                                                   YT* __restrict__ Y, int64_t ys0, int64_t ys1,
-                                                                   int64_t nvec, YT alpha) {
-  constexpr int SW  = 16;
-  constexpr int RPB = kBlock / SW;
-  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / SW;
-  const int k0      = threadIdx.x % SW;
-  if (row >= nrows) return;
-  const OffT s = row_map[row], e = row_map[row + 1];
-  for (int64_t k = k0; k < nvec; k += SW) {
-    const YT xv = alpha * X[row * xs0 + k * xs1];
-    for (OffT j = s; j < e; ++j) atomicAdd(&Y[(int64_t)entries[j] * ys0 + k * ys1], (YT)values[j] * xv);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // host-side dispatch
 static int pick_lpr(int64_t nrows, int64_t nnz, int forced) {
   if (forced > 0) { int l = 1; while (l < forced && l < 64) l *= 2; return l; }
@@ -1435,55 +785,22 @@ static int run_vector(const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT bet
   }
 }
 
-template <class OffT, class AT, class YT, int NPT, bool NT>
+template <class OffT, class AT, class YT, int NPT>
 static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta,
                          hipStream_t st) {
   YT* ch = reinterpret_cast<YT*>(p->d_carry);
   YT* ct = reinterpret_cast<YT*>(reinterpret_cast<char*>(p->d_carry) + 8 * p->nblocks);
-  const int variant = p->tune.stream_variant;
-  if (variant == 0) {
-    KK_LAUNCH((spmv_stream_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap == 1, p->tune.ablate);
-  } else if (variant == 2) {
-    KK_LAUNCH((spmv_wave_kernel<OffT, AT, YT, NPT, NT>), (unsigned)ceil_div(p->nblocks, kBlock / kWave), kBlock, 0, st, A->nnz,
-              p->nblocks, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct);
-  } else if (variant == 4 && p->d_lidx && (NPT == 8 || NPT == 4)) {
-    KK_LAUNCH((spmv_stream5_kernel<OffT, AT, YT, NPT, (NPT == 8 ? 1024 : 768)>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, (const int64_t*)p->d_uoff, (const int32_t*)p->d_ucols, (const uint16_t*)p->d_lidx,
-              ch, ct);
-  } else if (variant == 5) {
-    KK_LAUNCH((spmv_stream6_kernel<OffT, AT, YT, NPT, NT>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap == 1);
-  } else if ((variant == 6 || variant == 1) && p->d_wcode) {
-    if (p->win_stage && p->tune.window_codes != 2 && p->use_pat && (NPT == 16 || NPT == 8)) {
-      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, (NPT == 4 ? 8 : NPT), NT, true, 3>), (unsigned)p->nblocks, kBlock, (size_t)p->tune.lds_pad_kb * 1024, st, A->nnz,
-                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-                (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
-                (const int32_t*)p->d_wbase, A->num_cols, (const int32_t*)p->d_pmeta);
-    } else if (p->win_stage && p->tune.window_codes != 2) {
-      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true, 2>), (unsigned)p->nblocks, kBlock, (size_t)p->tune.lds_pad_kb * 1024, st, A->nnz,
-                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-                (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
-                (const int32_t*)p->d_wbase, A->num_cols);
-    } else {
-      KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, true, 1>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
-                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-                (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate, (const uint16_t*)p->d_wcode,
-                (const int32_t*)p->d_wbase, A->num_cols);
-    }
-  } else if (variant == 3) {
-    KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, false>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate);
-  } else {
-    KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, NT, true>), (unsigned)p->nblocks, kBlock, (size_t)p->tune.lds_pad_kb * 1024, st, A->nnz,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,
-              (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, p->tune.ablate);
-  }
+  // what the plan holds decides the instantiation; the mode of every tile is read from tinfo at run time
+  const int cap = !p->d_tinfo ? 0 : (p->d_pmeta ? 2 : 1);
+#define KK_STREAM3(CAPV)                                                                                                  \
+  KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, CAPV>), (unsigned)p->nblocks, kBlock, KK_LDS_PAD(p), st, A->nnz, \
+            (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,          \
+            (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, (const int32_t*)p->d_tinfo,                         \
+            (const uint16_t*)p->d_wcode, (const int32_t*)p->d_wbase, A->num_cols, (const int32_t*)p->d_pmeta KK_ABL_ARG(p))
+  if (cap == 2)      { KK_STREAM3(2); }
+  else if (cap == 1) { KK_STREAM3(1); }
+  else               { KK_STREAM3(0); }
+#undef KK_STREAM3
   KK_LAUNCH_CHECK();
   KK_LAUNCH((spmv_stream_fixup_kernel<OffT, YT>), (unsigned)ceil_div(p->nblocks, kBlock), kBlock, 0, st, p->nblocks,
             A->nnz, (int64_t)p->tile, (const OffT*)A->d_row_map, (const int32_t*)p->d_blk_row, (const YT*)ch,
@@ -1492,27 +809,16 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
   return KKAMD_OK;
 }
 
-template <class OffT, class AT, class YT> struct StreamDispatch {
-  // sweep variants (tile size, non-temporal loads) exist for the fp64 headline type; others use 8 / NT
-  static int run(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, hipStream_t st) {
-    const int npt = p->tile / (p->tune.stream_variant == 2 ? kWave : kBlock);
-    if (npt == 16) return launch_stream<OffT, AT, YT, 16, false>(p, A, x, y, alpha, beta, st);
-    return launch_stream<OffT, AT, YT, 8, true>(p, A, x, y, alpha, beta, st);
-  }
-};
-template <class OffT> struct StreamDispatch<OffT, double, double> {
-  static int run(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const double* x, double* y, double alpha, double beta,
-                 hipStream_t st) {
-    const int npt = p->tile / (p->tune.stream_variant == 2 ? kWave : kBlock);
-    const bool nt = p->tune.nontemporal != 0;
-    if (npt == 4)  return nt ? launch_stream<OffT, double, double, 4, true>(p, A, x, y, alpha, beta, st)
-                             : launch_stream<OffT, double, double, 4, false>(p, A, x, y, alpha, beta, st);
-    if (npt == 16) return nt ? launch_stream<OffT, double, double, 16, true>(p, A, x, y, alpha, beta, st)
-                             : launch_stream<OffT, double, double, 16, false>(p, A, x, y, alpha, beta, st);
-    return nt ? launch_stream<OffT, double, double, 8, true>(p, A, x, y, alpha, beta, st)
-              : launch_stream<OffT, double, double, 8, false>(p, A, x, y, alpha, beta, st);
-  }
-};
+// tile sizes the kernels are instantiated for: 2048 and 4096 nnz, plus 1024 for fp64 values
+template <class OffT, class AT, class YT>
+static int run_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, hipStream_t st) {
+  const int npt = p->tile / kBlock;
+  if (npt * kBlock != p->tile) return fail(KKAMD_ERR_STATE, "kkamd_spmv: plan tile %d is not a multiple of the workgroup size", p->tile);
+  if (npt == 16) return launch_stream<OffT, AT, YT, 16>(p, A, x, y, alpha, beta, st);
+  if (npt == 8)  return launch_stream<OffT, AT, YT, 8>(p, A, x, y, alpha, beta, st);
+  if (npt == 4 && sizeof(AT) == 8) return launch_stream<OffT, AT, YT, (sizeof(AT) == 8 ? 4 : 8)>(p, A, x, y, alpha, beta, st);
+  return fail(KKAMD_ERR_STATE, "kkamd_spmv: no kernel for %d nonzeros per work-item with %d-byte values", npt, (int)sizeof(AT));
+}
 
 template <class OffT, class AT, class YT>
 static int run_transpose(const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, hipStream_t st) {
@@ -1608,9 +914,18 @@ struct TransientPlan {
   hipStream_t last_stream = nullptr;
   bool used = false;
 };
+static TransientPlan& transient_ref() { static thread_local TransientPlan tp; return tp; }
+int release_transient() {
+  TransientPlan& tp = transient_ref();
+  if (tp.used) (void)hipStreamSynchronize(tp.last_stream);
+  if (tp.plan.d_blk_row) (void)hipFree(tp.plan.d_blk_row);
+  if (tp.plan.d_carry) (void)hipFree(tp.plan.d_carry);
+  tp.plan.d_blk_row = nullptr; tp.plan.d_carry = nullptr; tp.cap_blk = tp.cap_carry = 0; tp.used = false;
+  return KKAMD_OK;
+}
 template <class OffT>
 static kkamd_spmv_plan* transient_plan(const kkamd_crs_t* A, const SpmvTuning& tn, int elem_size, hipStream_t st) {
-  static thread_local TransientPlan tp;
+  TransientPlan& tp = transient_ref();
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   kkamd_spmv_plan& p = tp.plan;
@@ -1619,8 +934,7 @@ static kkamd_spmv_plan* transient_plan(const kkamd_crs_t* A, const SpmvTuning& t
     if (tp.device != dev) { p.d_blk_row = nullptr; p.d_carry = nullptr; tp.cap_blk = tp.cap_carry = 0; }   // other device's buffers are abandoned
   }
   p.num_rows = A->num_rows; p.num_cols = A->num_cols; p.nnz = A->nnz; p.row_map = A->d_row_map; p.entries = A->d_entries;
-  p.offset_type = A->offset_type; p.algorithm = KKAMD_SPMV_FAST_SETUP; p.tune = tn;
-  p.tune.stream_variant = 1;
+  p.offset_type = A->offset_type; p.value_type = A->value_type; p.algorithm = KKAMD_SPMV_FAST_SETUP; p.tune = tn;
   p.tune.window_codes = 0;        // one-shot plans do not pay for the column codes
   int npt = (elem_size == 8 && A->nnz >= 200000000) ? 16 : 8;
   if (elem_size == 8 && (tn.nnz_per_thread == 4 || tn.nnz_per_thread == 8 || tn.nnz_per_thread == 16)) npt = tn.nnz_per_thread;
@@ -1671,97 +985,16 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
     }
     return run_transpose<OffT, AT, YT>(A, x, y, alpha, beta, st);
   }
-  if (stream_usable(plan, A, (int)sizeof(AT))) return StreamDispatch<OffT, AT, YT>::run(plan, A, x, y, alpha, beta, st);
+  if (stream_usable(plan, A, (int)sizeof(AT))) return run_stream<OffT, AT, YT>(plan, A, x, y, alpha, beta, st);
   // No analysed plan (handle-less overloads, SPMV_FAST_SETUP): a large matrix is still worth the nnz-split kernel --
   // its "analysis" is one tiny kernel (a binary search per 4096-nnz tile) into a per-thread scratch that is reused
   // from call to call, so nothing is allocated or kept per matrix and the call stays asynchronous.
   const SpmvTuning& tn = plan ? plan->tune : g_spmv_default;
   if (tn.kernel != 1 && tn.transient_min_knnz > 0 && A->nnz >= (int64_t)tn.transient_min_knnz * 1000 && A->num_rows > 0) {
     kkamd_spmv_plan* tp = transient_plan<OffT>(A, tn, (int)sizeof(AT), st);
-    if (tp && stream_usable(tp, A, (int)sizeof(AT))) return StreamDispatch<OffT, AT, YT>::run(tp, A, x, y, alpha, beta, st);
+    if (tp && stream_usable(tp, A, (int)sizeof(AT))) return run_stream<OffT, AT, YT>(tp, A, x, y, alpha, beta, st);
   }
   return run_vector<OffT, AT, YT>(A, x, y, alpha, beta, tn, st);
-}
-
-template <class OffT, class AT, class YT, int SW>
-static int launch_mv(const kkamd_crs_t* A, const YT* X, int64_t xs0, int64_t xs1, YT* Y, int64_t ys0, int64_t ys1,
-                     int64_t nvec, YT alpha, YT beta, int remap, hipStream_t st) {
-  KK_LAUNCH((spmv_mv_kernel<OffT, AT, YT, SW>), (unsigned)ceil_div(A->num_rows, kBlock / SW), kBlock, 0, st,
-            A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1,
-            Y, ys0, ys1, nvec, alpha, beta, remap);
-  KK_LAUNCH_CHECK();
-  return KKAMD_OK;
-}
-
-template <class OffT, class AT, class YT>
-static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dX,
-                         int64_t xs0, int64_t xs1, double beta_d, void* dY, int64_t ys0, int64_t ys1, int64_t nvec,
-                         hipStream_t st) {
-  const YT alpha = (YT)alpha_d, beta = (YT)beta_d;
-  const YT* X    = (const YT*)dX;
-  YT* Y          = (YT*)dY;
-  const int remap = (plan ? plan->tune.xcd_remap : g_spmv_default.xcd_remap) == 1;
-  if (trans) {
-    int rc = launch_scale<YT>(Y, A->num_cols, ys0, nvec, ys1, beta, st);
-    if (rc) return rc;
-    KK_LAUNCH((spmv_mv_transpose_kernel<OffT, AT, YT>), (unsigned)ceil_div(A->num_rows, kBlock / 16), kBlock, 0, st,
-              A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1,
-              Y, ys0, ys1, nvec, alpha);
-    KK_LAUNCH_CHECK();
-    return KKAMD_OK;
-  }
-  const int mvk = plan ? plan->tune.mv_kernel : g_spmv_default.mv_kernel;      // 0 auto, 1 force generic, 2 force packed/row-major
-  const bool a_aligned = ((uintptr_t)A->d_values % 16 == 0) && ((uintptr_t)A->d_entries % 16 == 0);
-  if (mvk != 1 && a_aligned) {
-    const YT* Xr = nullptr; int64_t ldx = 0;
-    if (xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0)) { Xr = X; ldx = xs0; }
-    else if (plan && nvec >= 2) {
-      // pack X into a row-major workspace owned by the plan (the reference's rank-2 sub-handle tpl_rank2 plays this role)
-      const int64_t ldp = (nvec + 1) & ~(int64_t)1;
-      const size_t need = (size_t)A->num_cols * (size_t)ldp * sizeof(YT);
-      if (plan->xpack_bytes < need) {
-        if (plan->d_xpack) { KK_HIP(hipStreamSynchronize(st)); KK_HIP(hipFree(plan->d_xpack)); plan->d_xpack = nullptr; plan->xpack_bytes = 0; }
-        KK_HIP(hipMalloc(&plan->d_xpack, need));
-        plan->xpack_bytes = need;
-      }
-      KK_LAUNCH((pack_rows_kernel<YT>), (unsigned)ceil_div(A->num_cols, 32), kBlock, 0, st, A->num_cols, nvec, X, xs0, xs1,
-                (YT*)plan->d_xpack, ldp);
-      KK_LAUNCH_CHECK();
-      Xr = (const YT*)plan->d_xpack; ldx = ldp;
-    }
-    if (Xr) {
-      const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
-      const int mv_remap = plan ? plan->tune.mv_remap : g_spmv_default.mv_remap;
-#define KK_MV2C(L, R, C)                                                                                                 \
-      do {                                                                                                               \
-        KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R, C>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
-                  0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, \
-                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap);                                                        \
-        KK_LAUNCH_CHECK();                                                                                               \
-        return KKAMD_OK;                                                                                                 \
-      } while (0)
-      // staging window: the nnz of the wave's kWave/L rows (+15 % and the 4-alignment slack), rounded up to 256 / 512 / 1024
-#define KK_MV2(L, R)                                                                                                     \
-      do {                                                                                                               \
-        const int64_t need = (int64_t)(1.15 * (double)(kWave / L) * (double)A->nnz / (double)A->num_rows) + 4;            \
-        if (need <= 256) KK_MV2C(L, R, 256);                                                                              \
-        if (need <= 512) KK_MV2C(L, R, 512);                                                                              \
-        KK_MV2C(L, R, 1024);                                                                                              \
-      } while (0)
-      if (mvk == 3) { if (nvec >= 12) KK_MV2(8, 2); }                      // A/B: 8 lanes x 2 RHS
-      if (mvk == 4) { if (nvec >= 12) KK_MV2(2, 4); }                      // A/B: 2 lanes x 4 RHS (strips of 8)
-      if (nvec >= 12) KK_MV2(4, 4);
-      if (nvec >= 6) KK_MV2(2, 4);
-      if (nvec >= 3) KK_MV2(2, 2);
-      KK_MV2(1, 2);
-#undef KK_MV2C
-#undef KK_MV2
-    }
-  }
-  if (nvec >= 12) return launch_mv<OffT, AT, YT, 16>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
-  if (nvec >= 6)  return launch_mv<OffT, AT, YT, 8>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
-  if (nvec >= 3)  return launch_mv<OffT, AT, YT, 4>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
-  return launch_mv<OffT, AT, YT, 2>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
 }
 
 int check_crs(const kkamd_crs_t* A) {
@@ -1781,11 +1014,20 @@ int check_crs(const kkamd_crs_t* A) {
   return KKAMD_OK;
 }
 
-static int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
+int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   if (!p) return KKAMD_OK;
   if (p->num_rows != A->num_rows || p->num_cols != A->num_cols || p->nnz != A->nnz || p->row_map != A->d_row_map ||
-      p->offset_type != A->offset_type || ((p->d_wcode || p->d_lidx) && p->entries != A->d_entries))
+      p->offset_type != A->offset_type || p->value_type != A->value_type || ((p->d_tinfo || p->mv) && p->entries != A->d_entries))
     return fail(KKAMD_ERR_STATE, "kkamd_spmv: plan was created for a different matrix (a handle is bound to one matrix)");
+  return KKAMD_OK;
+}
+
+// TPL_SpMV_Data::set_exec_space (sparse/src/KokkosSparse_spmv_handle.hpp:95-104): a handle's scratch (carry slots, packed
+// X / Y) is ordered by the stream it was last used on; when the caller switches streams, the old one is fenced first.
+int bind_stream(kkamd_spmv_plan* p, hipStream_t st) {
+  if (!p) return KKAMD_OK;
+  if (p->used && p->last_stream != st) KK_HIP(hipStreamSynchronize(p->last_stream));
+  p->last_stream = st; p->used = true;
   return KKAMD_OK;
 }
 
@@ -1797,40 +1039,31 @@ int parse_mode(char mode, bool* trans) {
   }
 }
 
-#define KK_DISPATCH_TYPES(FN, ...)                                                                        \
-  do {                                                                                                    \
-    const bool o64 = A->offset_type == KKAMD_I64;                                                         \
-    if (A->value_type == KKAMD_F64 && vector_type == KKAMD_F64)                                           \
-      return o64 ? FN<int64_t, double, double>(__VA_ARGS__) : FN<int32_t, double, double>(__VA_ARGS__);   \
-    if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F32)                                           \
-      return o64 ? FN<int64_t, float, float>(__VA_ARGS__) : FN<int32_t, float, float>(__VA_ARGS__);       \
-    if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F64)                                           \
-      return o64 ? FN<int64_t, float, double>(__VA_ARGS__) : FN<int32_t, float, double>(__VA_ARGS__);     \
-    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv: unsupported (value,vector) type pair (%d,%d)",        \
-                A->value_type, vector_type);                                                              \
-  } while (0)
-
 static int set_tuning(SpmvTuning& t, const char* key, int value) {
   if (!key) return fail(KKAMD_ERR_INVALID_ARG, "null key");
   const std::string k(key);
-  if (k == "kernel") t.kernel = value;
-  else if (k == "lanes_per_row") t.lanes_per_row = value;
-  else if (k == "nnz_per_thread") t.nnz_per_thread = value;
-  else if (k == "xcd_remap") t.xcd_remap = value;
-  else if (k == "nontemporal") t.nontemporal = value;
-  else if (k == "mv_kernel") t.mv_kernel = value;
-  else if (k == "stream_variant") t.stream_variant = value;
-  else if (k == "wg_per_cu") t.wg_per_cu = value;
+  auto bad = [&](const char* what) { return fail(KKAMD_ERR_INVALID_ARG, "tuning key '%s': %d is not %s", key, value, what); };
+  if (k == "kernel") { if (value < 0 || value > 2) return bad("0, 1 or 2"); t.kernel = value; }
+  else if (k == "lanes_per_row") { if (value < 0 || value > 64) return bad("in 0..64"); t.lanes_per_row = value; }
+  else if (k == "nnz_per_thread") { if (value != 0 && value != 4 && value != 8 && value != 16) return bad("0, 4, 8 or 16"); t.nnz_per_thread = value; }
+  else if (k == "xcd_remap") { if (!valid_order_knob(value)) return bad("0, 1 or a power of two"); t.xcd_remap = value; }
+  else if (k == "mv_kernel") { if (value < 0 || value > 3) return bad("in 0..3"); t.mv_kernel = value; }
+  else if (k == "stream_variant") { if (value != 1 && value != 6) return bad("1 or 6"); t.stream_variant = value; }
+  else if (k == "mv_remap") { if (!valid_order_knob(value)) return bad("0, 1 or a power of two"); t.mv_remap = value; }
+  else if (k == "mv_order") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv_order = value; }
+  else if (k == "mv_inner") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv_inner = value; }
+  else if (k == "window_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.window_codes = value; }
+  else if (k == "window_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.window_codes_min_knnz = value; }
+  else if (k == "window_codes_min_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.window_codes_min_pct = value; }
+  else if (k == "pattern_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.pattern_codes = value; }
+  else if (k == "pattern_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.pattern_codes_min_knnz = value; }
+  else if (k == "transient_min_knnz") { if (value < 0) return bad("non-negative"); t.transient_min_knnz = value; }
+  else if (k == "explicit_transpose") { if (value < 0 || value > 2) return bad("in 0..2"); t.explicit_transpose = value; }
+  else if (k == "explicit_transpose_min_knnz") { if (value < 0) return bad("non-negative"); t.explicit_transpose_min_knnz = value; }
+#ifdef KK_ABLATE
   else if (k == "ablate") t.ablate = value;
-  else if (k == "mv_remap") t.mv_remap = value;
-  else if (k == "window_codes") t.window_codes = value;
-  else if (k == "window_codes_min_knnz") t.window_codes_min_knnz = value;
-  else if (k == "pattern_codes") t.pattern_codes = value;
-  else if (k == "pattern_codes_min_knnz") t.pattern_codes_min_knnz = value;
-  else if (k == "transient_min_knnz") t.transient_min_knnz = value;
-  else if (k == "explicit_transpose") t.explicit_transpose = value;
-  else if (k == "explicit_transpose_min_knnz") t.explicit_transpose_min_knnz = value;
   else if (k == "lds_pad_kb") t.lds_pad_kb = value;
+#endif
   else return fail(KKAMD_ERR_INVALID_ARG, "unknown tuning key '%s'", key);
   return KKAMD_OK;
 }
@@ -1843,119 +1076,141 @@ static int analyse(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
   return KKAMD_OK;
 }
 
+static void free_analysis(kkamd_spmv_plan* p) {
+  void** bufs[] = {(void**)&p->d_blk_row, &p->d_carry, (void**)&p->d_tinfo, (void**)&p->d_wcode, (void**)&p->d_wbase, (void**)&p->d_pmeta};
+  for (void** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
+  p->pat_tiles = p->code_tiles = p->staged_tiles = p->plain_tiles = 0;
+  p->tile = 0; p->nblocks = 0; p->plan_bytes = 0;
+}
+
+// Column analysis of the tiling (window codes, staged x, row-pattern records), tile by tile.  Returns KKAMD_OK with
+// p->d_tinfo == nullptr when the codes are not used (not worth it, or no memory for them); *redo_npt != 0 asks the caller to
+// repeat the whole analysis with that many nonzeros per work-item (the tile size was picked for the codes).
+static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st, int npt, bool may_retile, int* redo_npt) {
+  *redo_npt = 0;
+  const size_t nb = (size_t)p->nblocks;
+  DevBuf full, counts, flag, tinfo_b, wbase_b;                  // freed on every early return
+  auto give_up = [&]() {
+    (void)hipGetLastError();
+    if (p->d_pmeta) { (void)hipFree(p->d_pmeta); p->d_pmeta = nullptr; }
+    if (p->d_wcode) { (void)hipFree(p->d_wcode); p->d_wcode = nullptr; }
+    p->d_tinfo = nullptr; p->d_wbase = nullptr;
+    p->pat_tiles = p->code_tiles = p->staged_tiles = 0; p->plain_tiles = p->nblocks;
+    p->win_failed = true;
+    return KKAMD_OK;
+  };
+  // the codes are an optimisation: if HBM cannot hold them (2 bytes per nonzero while they are built) the plan keeps reading entries
+  if (full.alloc(sizeof(uint16_t) * nb * (size_t)p->tile) != hipSuccess || counts.alloc(8 * sizeof(int)) != hipSuccess ||
+      flag.alloc(sizeof(int32_t) * (nb + 1)) != hipSuccess || tinfo_b.alloc(sizeof(int32_t) * nb) != hipSuccess ||
+      wbase_b.alloc(sizeof(int32_t) * nb * kWinMeta) != hipSuccess)
+    return give_up();
+  int32_t* tinfo = tinfo_b.as<int32_t>();
+  int32_t* wbase = wbase_b.as<int32_t>();
+  uint16_t* d_full = full.as<uint16_t>();                      // raw pointers for the launches (the buffers stay owned above)
+  int* d_counts    = counts.as<int>();
+  int32_t* d_flag  = flag.as<int32_t>();
+  KK_HIP(hipMemsetAsync(counts.p, 0, 8 * sizeof(int), st));
+  const int allow_stage = p->tune.window_codes != 2;
+  const int32_t* ent = (const int32_t*)p->entries;
+  if (npt == 16)     { KK_LAUNCH((win_build_kernel<16>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, d_counts, allow_stage); }
+  else if (npt == 8) { KK_LAUNCH((win_build_kernel<8>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, d_counts, allow_stage); }
+  else               { KK_LAUNCH((win_build_kernel<4>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, d_counts, allow_stage); }
+  if (hipGetLastError() != hipSuccess) return give_up();
+  int h[8] = {0};
+  KK_HIP(hipMemcpyAsync(h, counts.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  const int64_t n_plain = h[kTilePlain], n_codes = h[kTileCodes], n_staged = h[kTileStaged];
+  // worth it?  Tiles that cannot use the codes keep reading entries, so this is a question of how many can.
+  if ((double)(n_codes + n_staged) * 100.0 < (double)p->tune.window_codes_min_pct * (double)nb || n_codes + n_staged == 0) return give_up();
+  // 4096-nnz tiles were picked in the hope that their x windows stage: when fewer than 90 % do, 2048-nnz tiles serve better
+  if (may_retile && npt == 16 && allow_stage && (double)n_staged < 0.9 * (double)nb) { give_up(); p->win_failed = false; *redo_npt = 8; return KKAMD_OK; }
+  // row-pattern records for the staged tiles
+  int64_t n_pat = 0;
+  bool use_pat = false;
+  if (n_staged > 0 && p->tune.pattern_codes && (npt == 16 || npt == 8) &&
+      (p->tune.pattern_codes >= 2 || A->nnz >= (int64_t)p->tune.pattern_codes_min_knnz * 1000) &&
+      hipMalloc((void**)&p->d_pmeta, sizeof(int32_t) * nb * kPatW) == hipSuccess) {
+    const bool o64 = A->offset_type == KKAMD_I64;
+    int* d_cnt = d_counts + 4;
+#define KK_PAT_BUILD(OT, N)                                                                                                  \
+  KK_LAUNCH((pat_build_kernel<OT, N>), (unsigned)nb, kBlock, 0, st, A->nnz, (const OT*)A->d_row_map,                        \
+            (const int32_t*)p->d_blk_row, d_full, (const int32_t*)wbase, tinfo, p->d_pmeta, d_cnt)
+    if (npt == 16) { if (o64) { KK_PAT_BUILD(int64_t, 16); } else { KK_PAT_BUILD(int32_t, 16); } }
+    else           { if (o64) { KK_PAT_BUILD(int64_t, 8); } else { KK_PAT_BUILD(int32_t, 8); } }
+#undef KK_PAT_BUILD
+    if (hipGetLastError() != hipSuccess) return give_up();
+    int h_cnt = 0;
+    KK_HIP(hipMemcpyAsync(&h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    n_pat   = h_cnt;
+    use_pat = p->tune.pattern_codes >= 2 ? n_pat > 0 : (double)n_pat >= 0.9 * (double)nb;
+    if (!use_pat) { KK_HIP(hipFree(p->d_pmeta)); p->d_pmeta = nullptr; n_pat = 0; }
+  } else {
+    (void)hipGetLastError();
+  }
+  // keep codes only for the tiles that read them: flags -> scan -> compact copy
+  KK_LAUNCH(code_flag_kernel, (unsigned)ceil_div((int64_t)nb + 1, kBlock), kBlock, 0, st, (int64_t)nb, tinfo, d_flag, use_pat ? 1 : 0);
+  if (hipGetLastError() != hipSuccess) return give_up();
+  int rc = exclusive_scan_inplace<int32_t>(d_flag, (int64_t)nb + 1, st);
+  if (rc) { give_up(); return rc; }
+  int32_t h_keep = 0;
+  KK_HIP(hipMemcpyAsync(&h_keep, d_flag + nb, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  if (hipMalloc((void**)&p->d_wcode, sizeof(uint16_t) * (size_t)(h_keep > 0 ? h_keep : 1) * (size_t)p->tile) != hipSuccess) return give_up();
+  if (npt == 16)     { KK_LAUNCH((code_compact_kernel<kBlock * 16>), (unsigned)nb, kBlock, 0, st, d_full, p->d_wcode, tinfo, d_flag); }
+  else if (npt == 8) { KK_LAUNCH((code_compact_kernel<kBlock * 8>), (unsigned)nb, kBlock, 0, st, d_full, p->d_wcode, tinfo, d_flag); }
+  else               { KK_LAUNCH((code_compact_kernel<kBlock * 4>), (unsigned)nb, kBlock, 0, st, d_full, p->d_wcode, tinfo, d_flag); }
+  if (hipGetLastError() != hipSuccess) return give_up();
+  KK_HIP(hipStreamSynchronize(st));
+  p->d_tinfo = (int32_t*)tinfo_b.release(); p->d_wbase = (int32_t*)wbase_b.release();
+  p->plain_tiles = n_plain; p->pat_tiles = n_pat; p->code_tiles = h_keep; p->staged_tiles = n_staged;
+  p->plan_bytes += sizeof(int32_t) * nb * (1 + kWinMeta) + sizeof(uint16_t) * (size_t)h_keep * (size_t)p->tile +
+                   (p->d_pmeta ? sizeof(int32_t) * nb * kPatW : 0);
+  return KKAMD_OK;
+}
+
 static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st, int force_npt = 0) {
-  if (p->d_blk_row) { KK_HIP(hipStreamSynchronize(st)); KK_HIP(hipFree(p->d_blk_row)); p->d_blk_row = nullptr; }
-  if (p->d_carry) { KK_HIP(hipFree(p->d_carry)); p->d_carry = nullptr; }
-  if (p->d_uoff) { KK_HIP(hipFree(p->d_uoff)); p->d_uoff = nullptr; }
-  if (p->d_ucols) { KK_HIP(hipFree(p->d_ucols)); p->d_ucols = nullptr; }
-  if (p->d_lidx) { KK_HIP(hipFree(p->d_lidx)); p->d_lidx = nullptr; }
-  if (p->d_wcode) { KK_HIP(hipFree(p->d_wcode)); p->d_wcode = nullptr; }
-  if (p->d_wbase) { KK_HIP(hipFree(p->d_wbase)); p->d_wbase = nullptr; }
-  if (p->d_pmeta) { KK_HIP(hipFree(p->d_pmeta)); p->d_pmeta = nullptr; }
-  p->pat_tiles = 0; p->use_pat = false;
-  p->tile = 0; p->nblocks = 0;
+  if (p->d_blk_row) KK_HIP(hipStreamSynchronize(st));
+  free_analysis(p);
   if (p->algorithm == KKAMD_SPMV_FAST_SETUP || p->tune.kernel == 1 || A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
   int npt = p->tune.nnz_per_thread;
-  // auto: 4096-nnz tiles once there are plenty of them (measured best from ~2e8 nnz up), 2048-nnz tiles below that
-  // (5-pt 1000^2: 19.2 vs 22.2 us)
-  const bool want_win = !p->win_failed && p->entries &&
-                        (p->tune.stream_variant == 6 || (p->tune.stream_variant == 1 && p->tune.window_codes &&
-                                                         A->nnz >= (int64_t)p->tune.window_codes_min_knnz * 1000));
+  const bool f64v = A->value_type == KKAMD_F64;
+  const bool want_win = !p->win_failed && p->entries && p->tune.window_codes &&
+                        (p->tune.stream_variant == 6 || A->nnz >= (int64_t)p->tune.window_codes_min_knnz * 1000);
   const bool auto_npt = (npt != 4 && npt != 8 && npt != 16);
-  // With window codes: 4096-nnz tiles when the matrix is large and their x windows fit LDS (27-pt 300^3: 1.38 ms against
-  // 1.44 with 2048-nnz tiles), else 2048-nnz tiles (codes without staged x: 1.51 vs 1.58 ms; 7-pt 400^3 is only
-  // stageable at 2048) -- the 4096 attempt is redone at 2048 below when it does not stage.
+  // auto: 4096-nnz tiles once there are plenty of them (measured best from ~2e8 nnz up), 2048-nnz tiles below that
+  // (5-pt 1000^2: 19.2 vs 22.2 us).  With window codes: 4096-nnz tiles when the matrix is large and their x windows fit
+  // LDS (27-pt 300^3: 1.38 ms against 1.44 with 2048-nnz tiles), else 2048-nnz tiles (7-pt 400^3 is only stageable at
+  // 2048) -- build_codes asks for the 4096 attempt to be redone at 2048 when too few tiles stage.
   if (force_npt) npt = force_npt;
   else if (auto_npt) {
-    if (p->tune.stream_variant == 4) npt = 8;
+    if (!f64v) npt = 8;                                        // fp32 values: 2048-nnz tiles unless asked
     else if (want_win) npt = (A->nnz >= 50000000) ? 16 : 8;
     else npt = (A->nnz < 200000000) ? 8 : 16;
   }
-  if (p->tune.stream_variant == 4 && npt == 16) npt = 8;     // the tile-local structure uses 2048- or 1024-nnz tiles
-  if (!(A->value_type == KKAMD_F64) && p->tune.nnz_per_thread != 16) npt = 8;   // fp32 values: 2048-nnz tiles unless asked
-  p->tile    = (p->tune.stream_variant == 2 ? kWave : kBlock) * npt;
+  if (npt == 4 && !f64v) npt = 8;                              // 1024-nnz tiles are instantiated for fp64 values only
+  p->tile    = kBlock * npt;
   p->nblocks = ceil_div(A->nnz, p->tile);
-  KK_HIP(hipMalloc((void**)&p->d_blk_row, sizeof(int32_t) * (size_t)(p->nblocks + 1)));
-  KK_HIP(hipMalloc(&p->d_carry, (size_t)16 * (size_t)p->nblocks));
+  if (hipMalloc((void**)&p->d_blk_row, sizeof(int32_t) * (size_t)(p->nblocks + 1)) != hipSuccess ||
+      hipMalloc(&p->d_carry, (size_t)16 * (size_t)p->nblocks) != hipSuccess) {
+    free_analysis(p);
+    return fail(KKAMD_ERR_ALLOC, "kkamd_spmv_plan: out of device memory for the tile descriptors");
+  }
+  p->plan_bytes = (sizeof(int32_t) + 16) * (size_t)p->nblocks + 4;
   int rc = A->offset_type == KKAMD_I64 ? analyse<int64_t>(p, A, st) : analyse<int32_t>(p, A, st);
   if (rc) return rc;
-  if (p->tune.stream_variant == 4 && p->entries && (npt == 8 || npt == 4) && ((uintptr_t)p->entries % 8 == 0)) {
-    // tile-local column structure: count distinct columns per tile, scan, then emit lists + 16-bit local indices
-    KK_HIP(hipMalloc((void**)&p->d_uoff, sizeof(int64_t) * (size_t)(p->nblocks + 1)));
-    if (npt == 8) { KK_LAUNCH((tlc_count_kernel<2048>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_uoff); }
-    else          { KK_LAUNCH((tlc_count_kernel<1024>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_uoff); }
-    KK_LAUNCH_CHECK();
-    if ((rc = exclusive_scan_inplace<int64_t>(p->d_uoff, p->nblocks + 1, st))) return rc;
-    KK_HIP(hipMemcpyAsync(&p->ucols_total, p->d_uoff + p->nblocks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    KK_HIP(hipStreamSynchronize(st));
-    KK_HIP(hipMalloc((void**)&p->d_ucols, sizeof(int32_t) * (size_t)(p->ucols_total > 0 ? p->ucols_total : 1)));
-    KK_HIP(hipMalloc((void**)&p->d_lidx, sizeof(uint16_t) * (size_t)(A->nnz + 8)));
-    if (npt == 8) { KK_LAUNCH((tlc_build_kernel<2048>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, (const int64_t*)p->d_uoff, p->d_ucols, p->d_lidx); }
-    else          { KK_LAUNCH((tlc_build_kernel<1024>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, (const int64_t*)p->d_uoff, p->d_ucols, p->d_lidx); }
-    KK_LAUNCH_CHECK();
-  }
-  if (want_win) {
-    // window codes: every tile must be coverable by 16 windows, otherwise the plan keeps reading entries
-    int* d_fail = nullptr;
-    int h_fails[2] = {0, 0};
-    KK_HIP(hipMalloc((void**)&d_fail, 2 * sizeof(int)));
-    KK_HIP(hipMemsetAsync(d_fail, 0, 2 * sizeof(int), st));
-    // the codes are an optimisation: if HBM cannot hold them (2 bytes per nonzero) the plan simply keeps reading entries
-    if (hipMalloc((void**)&p->d_wcode, sizeof(uint16_t) * (size_t)p->nblocks * (size_t)p->tile) != hipSuccess ||
-        hipMalloc((void**)&p->d_wbase, sizeof(int32_t) * (size_t)p->nblocks * kWinMeta) != hipSuccess) {
-      (void)hipGetLastError();
-      if (p->d_wcode) { (void)hipFree(p->d_wcode); p->d_wcode = nullptr; }
-      p->d_wbase = nullptr;
-      (void)hipFree(d_fail);
-      p->win_failed = true;
-      if (auto_npt && !force_npt) return build_analysis(p, A, st);
-      KK_HIP(hipStreamSynchronize(st));
-      return KKAMD_OK;
-    }
-    if (npt == 16)     { KK_LAUNCH((win_build_kernel<16>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
-    else if (npt == 8) { KK_LAUNCH((win_build_kernel<8>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
-    else               { KK_LAUNCH((win_build_kernel<4>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const int32_t*)p->entries, p->d_wcode, p->d_wbase, d_fail); }
-    KK_LAUNCH_CHECK();
-    KK_HIP(hipMemcpyAsync(h_fails, d_fail, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    KK_HIP(hipStreamSynchronize(st));
-    KK_HIP(hipFree(d_fail));
-    const int h_fail = h_fails[0];
-    p->win_stage = (h_fails[0] == 0 && h_fails[1] == 0);
-    if (h_fail) {
-      KK_HIP(hipFree(p->d_wcode)); p->d_wcode = nullptr;
-      KK_HIP(hipFree(p->d_wbase)); p->d_wbase = nullptr;
-      p->win_failed = true;
-      if (auto_npt && !force_npt) return build_analysis(p, A, st);   // the tile size was picked for the codes: redo
-    } else if (!p->win_stage && auto_npt && !force_npt && npt == 16) {
-      return build_analysis(p, A, st, 8);
-    } else if (p->win_stage && p->tune.pattern_codes && (npt == 16 || npt == 8) &&
-               (p->tune.pattern_codes >= 2 || A->nnz >= (int64_t)p->tune.pattern_codes_min_knnz * 1000) &&
-               hipMalloc((void**)&p->d_pmeta, sizeof(int32_t) * (size_t)p->nblocks * kPatW) == hipSuccess) {
-      // row-pattern records: which tiles decompose into a few segments of equal rows with a common slot table
-      int* d_cnt = nullptr; int h_cnt = 0;
-      KK_HIP(hipMalloc((void**)&d_cnt, sizeof(int)));
-      KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
-      const bool o64 = A->offset_type == KKAMD_I64;
-#define KK_PAT_BUILD(OT, N)                                                                                                  \
-  KK_LAUNCH((pat_build_kernel<OT, N>), (unsigned)p->nblocks, kBlock, 0, st, A->nnz, (const OT*)A->d_row_map,                 \
-            (const int32_t*)p->d_blk_row, (const uint16_t*)p->d_wcode, (const int32_t*)p->d_wbase, p->d_pmeta, d_cnt)
-      if (npt == 16) { if (o64) { KK_PAT_BUILD(int64_t, 16); } else { KK_PAT_BUILD(int32_t, 16); } }
-      else           { if (o64) { KK_PAT_BUILD(int64_t, 8); } else { KK_PAT_BUILD(int32_t, 8); } }
-#undef KK_PAT_BUILD
-      KK_LAUNCH_CHECK();
-      KK_HIP(hipMemcpyAsync(&h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
-      KK_HIP(hipStreamSynchronize(st));
-      KK_HIP(hipFree(d_cnt));
-      p->pat_tiles = h_cnt;
-      p->use_pat   = p->tune.pattern_codes >= 2 ? h_cnt > 0 : (double)h_cnt >= 0.9 * (double)p->nblocks;
-      if (!p->use_pat) { KK_HIP(hipFree(p->d_pmeta)); p->d_pmeta = nullptr; }
-    } else {
-      (void)hipGetLastError();
-    }
+  if (want_win && ((uintptr_t)p->entries % 8 == 0)) {
+    int redo = 0;
+    if ((rc = build_codes(p, A, st, npt, auto_npt && !force_npt, &redo))) return rc;
+    if (redo) return build_analysis(p, A, st, redo);
+    if (!p->d_tinfo && auto_npt && !force_npt && f64v && npt != ((A->nnz < 200000000) ? 8 : 16))
+      return build_analysis(p, A, st);                         // no codes after all (win_failed is set): the plain kernel's tile size
   }
   KK_HIP(hipStreamSynchronize(st));   // setup is synchronous, like the vendor analysis it replaces
   return KKAMD_OK;
 }
+
+SpmvTuning g_spmv_default;
 
 }  // namespace kk
 
@@ -1978,10 +1233,21 @@ int kkamd_device_info(char* name, int name_len, int* is_gfx950, int* num_cus) {
 
 int kkamd_set_default(const char* key, int value) {
   if (key && std::strncmp(key, "spgemm_", 7) == 0) return kk::spgemm_set_default(key, value);
-  if (key && std::strcmp(key, "struct_remap") == 0) { kk::g_struct_remap = value; return KKAMD_OK; }
-  if (key && std::strcmp(key, "struct_group") == 0) { kk::g_struct_group = value; return KKAMD_OK; }
-  if (key && std::strcmp(key, "struct_strip") == 0) { kk::g_struct_strip = value; return KKAMD_OK; }
+  if (key && std::strcmp(key, "struct_remap") == 0) {
+    if (value != 0 && value != 1) return kk::fail(KKAMD_ERR_INVALID_ARG, "struct_remap: %d is not 0 or 1", value);
+    kk::g_struct_remap = value; return KKAMD_OK;
+  }
+  if (key && std::strcmp(key, "struct_group") == 0) {
+    if (!kk::valid_order_knob(value) || value == 1) return kk::fail(KKAMD_ERR_INVALID_ARG, "struct_group: %d is not 0 or a power of two >= 2", value);
+    kk::g_struct_group = value; return KKAMD_OK;
+  }
+  if (key && std::strcmp(key, "struct_strip") == 0) {
+    if (value < 0) return kk::fail(KKAMD_ERR_INVALID_ARG, "struct_strip: %d is negative", value);
+    kk::g_struct_strip = value; return KKAMD_OK;
+  }
+#ifdef KK_ABLATE
   if (key && std::strcmp(key, "struct_lds_pad_kb") == 0) { kk::g_struct_lds_pad_kb = value; return KKAMD_OK; }
+#endif
   return kk::set_tuning(kk::g_spmv_default, key, value);
 }
 
@@ -1996,7 +1262,7 @@ int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int a
   if (!p) return kk::fail(KKAMD_ERR_ALLOC, "kkamd_spmv_plan_create: out of host memory");
   p->num_rows = A->num_rows; p->num_cols = A->num_cols; p->nnz = A->nnz; p->row_map = A->d_row_map;
   p->entries = A->d_entries;
-  p->offset_type = A->offset_type; p->algorithm = algorithm; p->tune = kk::g_spmv_default;
+  p->offset_type = A->offset_type; p->value_type = A->value_type; p->algorithm = algorithm; p->tune = kk::g_spmv_default;
   {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -2012,15 +1278,10 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (!plan) return KKAMD_OK;
   // hipFree synchronises the device, so kernels still using the buffers have finished
   // (the reference's rocSPARSE sub-handle relies on the same property, spmv_handle.hpp:148-152)
-  if (plan->d_blk_row) (void)hipFree(plan->d_blk_row);
-  if (plan->d_carry) (void)hipFree(plan->d_carry);
+  kk::free_analysis(plan);
   if (plan->d_xpack) (void)hipFree(plan->d_xpack);
-  if (plan->d_uoff) (void)hipFree(plan->d_uoff);
-  if (plan->d_ucols) (void)hipFree(plan->d_ucols);
-  if (plan->d_lidx) (void)hipFree(plan->d_lidx);
-  if (plan->d_wcode) (void)hipFree(plan->d_wcode);
-  if (plan->d_wbase) (void)hipFree(plan->d_wbase);
-  if (plan->d_pmeta) (void)hipFree(plan->d_pmeta);
+  if (plan->d_ypack) (void)hipFree(plan->d_ypack);
+  if (plan->mv) kk::mv_plan_destroy(plan->mv);
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
   if (plan->d_t_perm) (void)hipFree(plan->d_t_perm);
@@ -2032,21 +1293,23 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
 
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
   if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_set: null plan");
-  const int old_npt = plan->tune.nnz_per_thread, old_kernel = plan->tune.kernel, old_var = plan->tune.stream_variant;
-  const int old_win = plan->tune.window_codes, old_pat = plan->tune.pattern_codes;
+  const kk::SpmvTuning old = plan->tune;
   int rc = kk::set_tuning(plan->tune, key, value);
   if (rc) return rc;
-  if (plan->tune.nnz_per_thread != old_npt || plan->tune.kernel != old_kernel ||
-      (plan->tune.stream_variant == 2) != (old_var == 2) || (plan->tune.stream_variant == 4) != (old_var == 4) ||
-      (plan->tune.stream_variant == 6) != (old_var == 6) || (plan->tune.stream_variant == 1) != (old_var == 1) ||
-      plan->tune.window_codes != old_win || plan->tune.pattern_codes != old_pat) {
-    // tiling changed: redo the analysis (needs the matrix again; rebuilt lazily from the stored row_map)
+  const kk::SpmvTuning& t = plan->tune;
+  if (t.nnz_per_thread != old.nnz_per_thread || t.kernel != old.kernel || t.stream_variant != old.stream_variant ||
+      t.window_codes != old.window_codes || t.window_codes_min_knnz != old.window_codes_min_knnz ||
+      t.window_codes_min_pct != old.window_codes_min_pct || t.pattern_codes != old.pattern_codes ||
+      t.pattern_codes_min_knnz != old.pattern_codes_min_knnz) {
+    // the tiling or its column analysis changed: redo the analysis from the matrix the plan is bound to
     plan->win_failed = false;
     kkamd_crs_t A{};
     A.num_rows = plan->num_rows; A.num_cols = plan->num_cols; A.nnz = plan->nnz; A.d_row_map = plan->row_map;
-    A.offset_type = plan->offset_type; A.value_type = KKAMD_F64;
-    return kk::build_analysis(plan, &A, nullptr);
+    A.d_entries = plan->entries; A.offset_type = plan->offset_type; A.value_type = plan->value_type;
+    if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
+    return kk::build_analysis(plan, &A, plan->last_stream);
   }
+  if (t.mv_order != old.mv_order && plan->mv) { kk::mv_plan_destroy(plan->mv); plan->mv = nullptr; plan->mv_failed = false; }
   return KKAMD_OK;
 }
 
@@ -2055,13 +1318,24 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   const std::string k(key);
   if (k == "tile") *value = plan->tile;
   else if (k == "tiles") *value = plan->nblocks;
-  else if (k == "window_codes") *value = plan->d_wcode ? 1 : 0;
-  else if (k == "window_staged_x") *value = (plan->d_wcode && plan->win_stage && plan->tune.window_codes != 2) ? 1 : 0;
-  else if (k == "pattern_tiles") *value = plan->use_pat ? plan->pat_tiles : 0;
+  else if (k == "window_codes") *value = plan->d_tinfo ? 1 : 0;
+  else if (k == "window_staged_x") *value = (plan->d_tinfo && plan->staged_tiles > 0) ? 1 : 0;
+  else if (k == "plain_tiles") *value = plan->d_tinfo ? plan->plain_tiles : plan->nblocks;
+  else if (k == "code_tiles") *value = plan->code_tiles;
+  else if (k == "staged_tiles") *value = plan->d_tinfo ? plan->staged_tiles : 0;
+  else if (k == "pattern_tiles") *value = plan->d_pmeta ? plan->pat_tiles : 0;
+  else if (k == "plan_bytes") *value = (int64_t)plan->plan_bytes;
   else if (k == "transpose_cached") *value = plan->t_ready ? 1 : 0;
+  else if (k == "mv_tiles") *value = kk::mv_plan_query(plan->mv, 0);
+  else if (k == "mv_pattern_tiles") *value = kk::mv_plan_query(plan->mv, 1);
+  else if (k == "mv_order") *value = kk::mv_plan_query(plan->mv, 2);
+  else if (k == "mv_plan_bytes") *value = kk::mv_plan_query(plan->mv, 3);
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
   return KKAMD_OK;
 }
+
+/* frees the calling host thread's scratch of the handle-less route (tile descriptors + carries, grown on demand) */
+int kkamd_release_scratch(void) { return kk::release_transient(); }
 
 int kkamd_spmv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double alpha, const void* d_x, double beta,
                void* d_y, int vector_type, kkamd_stream_t stream) {
@@ -2082,33 +1356,8 @@ int kkamd_spmv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double 
     return kk::launch_scale<float>((float*)d_y, ylen, 1, 1, 1, (float)beta, st);
   }
   if (xlen > 0 && !d_x) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv: null x");
+  if ((rc = kk::bind_stream(plan, st))) return rc;
   KK_DISPATCH_TYPES(kk::spmv_typed, plan, A, trans, alpha, d_x, beta, d_y, st);
-}
-
-int kkamd_spmv_mv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double alpha, const void* d_X,
-                  int64_t x_stride0, int64_t x_stride1, double beta, void* d_Y, int64_t y_stride0, int64_t y_stride1,
-                  int64_t nvec, int vector_type, kkamd_stream_t stream) {
-  int rc = kk::check_crs(A);
-  if (rc) return rc;
-  bool trans = false;
-  if ((rc = kk::parse_mode(mode, &trans))) return rc;
-  if ((rc = kk::check_plan(plan, A))) return rc;
-  if (nvec < 0) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: negative number of vectors");
-  if (vector_type != KKAMD_F32 && vector_type != KKAMD_F64)
-    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv_mv: unsupported vector_type %d", vector_type);
-  hipStream_t st     = kk::to_hip(stream);
-  const int64_t ylen = trans ? A->num_cols : A->num_rows;
-  if (nvec == 0 || ylen == 0) return KKAMD_OK;
-  if (!d_Y) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: null Y");
-  if (alpha == 0.0 || A->num_rows == 0 || A->num_cols == 0 || A->nnz == 0) {
-    if (vector_type == KKAMD_F64) return kk::launch_scale<double>((double*)d_Y, ylen, y_stride0, nvec, y_stride1, beta, st);
-    return kk::launch_scale<float>((float*)d_Y, ylen, y_stride0, nvec, y_stride1, (float)beta, st);
-  }
-  if (!d_X) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: null X");
-  // one contiguous column: the rank-1 path (sparse/src/KokkosSparse_spmv.hpp:203-217)
-  if (nvec == 1 && x_stride0 == 1 && y_stride0 == 1) return kkamd_spmv(plan, A, mode, alpha, d_X, beta, d_Y, vector_type, stream);
-  KK_DISPATCH_TYPES(kk::spmv_mv_typed, plan, A, trans, alpha, d_X, x_stride0, x_stride1, beta, d_Y, y_stride0,
-                    y_stride1, nvec, st);
 }
 
 }  // extern "C"

@@ -1,0 +1,775 @@
+// kk_spmv_mv.hip -- rank-2 CSR SpMV (SpMV_MV, Y := alpha*op(A)*X + beta*Y) for gfx950.
+//
+// Reference: sparse/impl/KokkosSparse_spmv_impl.hpp:634-1004 (SPMV_MV_LayoutLeft_Functor: a team of rows, strip-mined 8
+// right-hand sides at a time on a GPU, X gathered per entry through the texture path), :547-632 (transpose, atomics).
+// Here (bound: HBM; the contraction is 2 flop per 12-20 bytes moved):
+//   spmv_mv3_kernel -- analysed handles: the plan cuts the matrix into row blocks whose X rows are a few contiguous runs,
+//       stages those runs in LDS once per tile with coalesced 16-byte loads and walks the tile's rows out of LDS; per
+//       nonzero the plan keeps a 16-bit LDS slot instead of the 32-bit column.  Tile order follows the grid strides the
+//       analysis finds, so that every XCD's L2 sees each X row once.
+//   spmv_mv2_kernel -- no analysis: wave-private row blocks, X rows gathered with 16-byte loads.
+//   spmv_mv_kernel  -- generic fallback (any strides, odd widths); spmv_mv_transpose_kernel -- modes T/H (atomics).
+#include "kk_spmv_plan.h"
+#include "kk_scan.h"
+#include <new>
+#include <cstring>
+#include <climits>
+#include <vector>
+
+namespace kk {
+
+// ------------------------------------------------------------------------------------------------
+// rank-2, no transpose.  A workgroup takes RPB = 256/SW consecutive rows; SW lanes (one per right-hand
+// side of the current strip) form a row group.  The rows' nnz range is contiguous in CSR, so the
+// workgroup streams it through LDS in CH-sized chunks with coalesced loads (A is read once per strip),
+// and each group walks its own row's part of the chunk: LDS broadcast of (val, col), then one
+// X(col, strip) access per lane -- a contiguous 8*SW bytes when X is row-major.
+template <class OffT, class AT, class YT, int SW>
+__global__ __launch_bounds__(kBlock) void spmv_mv_kernel(int64_t nrows, const OffT* __restrict__ row_map,
+                                                         const int32_t* __restrict__ entries,
+                                                         const AT* __restrict__ values, const YT* __restrict__ X,
+                                                         int64_t xs0, int64_t xs1, YT* __restrict__ Y, int64_t ys0,
+                                                         int64_t ys1, int64_t nvec, YT alpha, YT beta, int remap) {
+  constexpr int RPB = kBlock / SW;
+  constexpr int CH  = 2048;
+  __shared__ AT s_val[CH];
+  __shared__ int s_col[CH];
+  const int t        = threadIdx.x;
+  const int64_t wg   = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t row0 = wg * RPB;
+  const int64_t rowN = (row0 + RPB < nrows) ? row0 + RPB : nrows;
+  const int64_t row  = row0 + t / SW;
+  const int k        = t % SW;
+  const int64_t lo   = (int64_t)row_map[row0];
+  const int64_t hi   = (int64_t)row_map[rowN];
+  int64_t rs = 0, re = 0;
+  if (row < nrows) { rs = (int64_t)row_map[row]; re = (int64_t)row_map[row + 1]; }
+  for (int64_t kk = 0; kk < nvec; kk += SW) {
+    const bool col_ok = (kk + k) < nvec;
+    YT acc            = YT(0);
+    for (int64_t c = lo; c < hi; c += CH) {
+      const int64_t ce = (c + CH < hi) ? c + CH : hi;
+      __syncthreads();
+      for (int64_t i = c + t; i < ce; i += kBlock) { s_val[i - c] = values[i]; s_col[i - c] = entries[i]; }
+      __syncthreads();
+      if (col_ok) {
+        const int64_t a = rs > c ? rs : c, z = re < ce ? re : ce;
+        const YT* xp    = X + (kk + k) * xs1;
+        for (int64_t i = a; i < z; ++i) acc += (YT)s_val[i - c] * xp[(int64_t)s_col[i - c] * xs0];
+      }
+    }
+    if (col_ok && row < nrows) {
+      acc *= alpha;
+      YT* yp = Y + row * ys0 + (kk + k) * ys1;
+      *yp    = (beta == YT(0)) ? acc : beta * (*yp) + acc;
+    }
+  }
+}
+
+// rank-2, no transpose, row-major X (the fast path).  One 64-lane WAVE owns RW = 64/LPRW consecutive rows;
+// LPRW lanes form a row group and each lane carries TWO right-hand sides, so one X access is a 16-byte load and a
+// wave-level load instruction moves 64 x 16 B = 1 KB (the generic kernel above moves 512 B per instruction with
+// 4 rows in flight and is bound by the texture path at ~13 % of the HBM roofline).  The wave's contiguous CSR
+// range is staged through its private LDS slice with 16-byte loads (4-aligned windows), no workgroup barrier.
+typedef int kk_i32x4 __attribute__((vector_size(16)));
+template <class OffT, class AT, class YT, int LPRW, int RPL, int CHW>
+__global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ row_map,
+                                                          const int32_t* __restrict__ entries,
+                                                          const AT* __restrict__ values, const YT* __restrict__ X,
+                                                          int64_t xs0, YT* __restrict__ Y, int64_t ys0, int64_t ys1,
+                                                          int64_t nvec, YT alpha, YT beta, int y_vec_ok, int remap) {
+  // XCD-contiguous workgroup order (remap): the 128-byte X rows a row block touches are shared with the blocks
+  // that handle rows i+-1, j+-1 (and k+-1); keeping neighbouring blocks on ONE XCD keeps those X rows in its
+  // 4 MiB L2.  With the dispatcher's round-robin order every XCD fetched every X row: rocprof showed 10.7
+  // memory fetches per X row (45 GB per launch on the 300^3 x 16 case against 12 GB of compulsory reads).
+  // LPRW lanes per row, RPL (2 or 4) right-hand sides per lane: strip width SW = LPRW*RPL, RW rows per wave.
+  // RPL = 4 halves the per-nnz LDS-read / address arithmetic per FMA; a quad of lanes then covers one 128 B X row.
+  constexpr int RW  = kWave / LPRW;
+  constexpr int SW  = RPL * LPRW;
+  constexpr int NV2 = RPL / 2;           // 16-byte pieces per lane
+  // CHW = nnz staged per wave per pass (256 / 512 / 1024, picked from the average row length): a window smaller than the
+  // RW rows of the wave makes every wave run several passes with part of its lanes idle -- with 256 on the 27-pt matrix
+  // (16 rows x 27 = 432 nnz) the kernel issued twice the X load instructions it needed and the texture addresser was busy
+  // 95 % of the time (rocprof TA_BUSY).
+  using AV = typename vec2<AT>::type;
+  using XV = typename vec2<YT>::type;
+  __shared__ AT s_val_all[kBlock / kWave][CHW];
+  __shared__ int s_col_all[kBlock / kWave][CHW];
+  const int lane64 = threadIdx.x & 63, w = threadIdx.x >> 6;
+  AT* s_val  = s_val_all[w];
+  int* s_col = s_col_all[w];
+  const int64_t wg   = xcd_order(blockIdx.x, gridDim.x, remap);   // 0 dispatch order, 1 contiguous, 4 / 8 / 16 grouped
+  const int64_t row0 = (wg * (kBlock / kWave) + w) * RW;
+  if (row0 >= nrows) return;                                   // whole wave leaves together
+  const int64_t rowN = (row0 + RW < nrows) ? row0 + RW : nrows;
+  const int grp = lane64 / LPRW, l = lane64 % LPRW;
+  const int64_t row = row0 + grp;
+  const int64_t lo  = (int64_t)row_map[row0] & ~(int64_t)3;    // 4-aligned staging windows
+  const int64_t hi  = (int64_t)row_map[rowN];
+  int64_t rs = 0, re = 0;
+  if (row < rowN) { rs = (int64_t)row_map[row]; re = (int64_t)row_map[row + 1]; }
+  for (int64_t kk = 0; kk < nvec; kk += SW) {
+    // piece q of lane l covers right-hand sides kk + q*2*LPRW + 2l and +1: the LPRW lanes of a row then read ONE contiguous
+    // 16*LPRW-byte run per load instruction (one 64 B sector of the X row for LPRW = 4) instead of 16 B out of every
+    // 32 B, which made each of the two instructions pull both sectors of the 128 B line through the L1
+    const int64_t cA = kk + 2 * l;
+    constexpr int64_t PQ = 2 * LPRW;                 // column distance between a lane's pieces
+    const bool all_ok = kk + SW <= nvec;
+    YT acc[RPL];
+    KK_UNROLL
+    for (int q = 0; q < RPL; ++q) acc[q] = YT(0);
+    for (int64_t c = lo; c < hi; c += CHW) {
+      KK_WAVE_SYNC();
+      if (c + CHW <= nnz) {   // whole window inside the arrays (wave-uniform): three unguarded 16-byte loads per lane and 256 nnz
+        KK_UNROLL
+        for (int sub = 0; sub < CHW; sub += 256) {
+          const kk_i32x4 cc = *reinterpret_cast<const kk_i32x4*>(entries + c + sub + lane64 * 4);
+          const AV va = *reinterpret_cast<const AV*>(values + c + sub + lane64 * 2);
+          const AV vb = *reinterpret_cast<const AV*>(values + c + sub + 128 + lane64 * 2);
+          s_col[sub + lane64 * 4] = cc[0]; s_col[sub + lane64 * 4 + 1] = cc[1]; s_col[sub + lane64 * 4 + 2] = cc[2]; s_col[sub + lane64 * 4 + 3] = cc[3];
+          s_val[sub + lane64 * 2] = va[0]; s_val[sub + lane64 * 2 + 1] = va[1];
+          s_val[sub + 128 + lane64 * 2] = vb[0]; s_val[sub + 128 + lane64 * 2 + 1] = vb[1];
+        }
+      } else {
+        for (int q = 0; q < CHW / 64; ++q) {
+          const int64_t i = c + lane64 * (CHW / 64) + q;
+          s_col[lane64 * (CHW / 64) + q] = (i < nnz) ? entries[i] : 0;
+          s_val[lane64 * (CHW / 64) + q] = (i < nnz) ? values[i] : AT(0);
+        }
+      }
+      KK_WAVE_SYNC();
+      const int64_t ce = c + CHW;
+      const int a = (int)((rs > c ? rs : c) - c), z = (int)((re < ce ? re : ce) - c);
+      if (all_ok) {
+        // batches of U entries: all U*NV2 16-byte X loads are issued before the first FMA consumes one
+        // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> fma per entry: one load in flight per wave)
+        // batches of 8, then 4, 2, 1 entries: inside a batch all X loads are issued before the first FMA consumes one
+        // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> fma per entry: one load in flight per wave)
+#define KK_MV_BATCH(UU)                                                                                                  \
+        {                                                                                                                \
+          YT v[UU]; XV xv[UU][NV2];                                                                                      \
+          KK_UNROLL                                                                                                      \
+          for (int u = 0; u < UU; ++u) {                                                                                 \
+            v[u] = (YT)s_val[i + u];                                                                                     \
+            const YT* xp = X + (int64_t)s_col[i + u] * xs0 + cA;                                                         \
+            KK_UNROLL                                                                                                    \
+            for (int q = 0; q < NV2; ++q) xv[u][q] = *reinterpret_cast<const XV*>(xp + q * PQ);                          \
+          }                                                                                                              \
+          KK_UNROLL                                                                                                      \
+          for (int u = 0; u < UU; ++u) {                                                                                 \
+            KK_UNROLL                                                                                                    \
+            for (int q = 0; q < NV2; ++q) { acc[2 * q] += v[u] * xv[u][q][0]; acc[2 * q + 1] += v[u] * xv[u][q][1]; }    \
+          }                                                                                                              \
+          i += UU;                                                                                                       \
+        }
+        int i = a;
+        while (i + 8 <= z) KK_MV_BATCH(8)
+        if (i + 4 <= z) KK_MV_BATCH(4)
+        if (i + 2 <= z) KK_MV_BATCH(2)
+        if (i < z) KK_MV_BATCH(1)
+#undef KK_MV_BATCH
+      } else {
+        for (int i = a; i < z; ++i) {
+          const YT v = (YT)s_val[i];
+          const YT* xp = X + (int64_t)s_col[i] * xs0 + cA;
+          for (int q = 0; q < RPL; ++q) { const int64_t cq = (q >> 1) * PQ + (q & 1); if (cA + cq < nvec) acc[q] += v * xp[cq]; }
+        }
+      }
+    }
+    if (row < rowN) {
+      YT* yp = Y + row * ys0 + cA * ys1;
+      if (all_ok && y_vec_ok) {
+        KK_UNROLL
+        for (int q = 0; q < NV2; ++q) {
+          XV out;
+          XV* yq = reinterpret_cast<XV*>(yp + q * PQ);
+          if (beta == YT(0)) { out[0] = alpha * acc[2 * q]; out[1] = alpha * acc[2 * q + 1]; }
+          else { const XV old = *yq; out[0] = beta * old[0] + alpha * acc[2 * q]; out[1] = beta * old[1] + alpha * acc[2 * q + 1]; }
+          *yq = out;
+        }
+      } else {
+        for (int q = 0; q < RPL; ++q) {
+          const int64_t cq = (q >> 1) * PQ + (q & 1);
+          if (cA + cq < nvec) { const YT r = alpha * acc[q]; yp[cq * ys1] = (beta == YT(0)) ? r : beta * yp[cq * ys1] + r; }
+        }
+      }
+    }
+  }
+}
+
+// X(ncols x nvec, column-major or any strides) -> row-major, leading dimension ldp (even): the packing step that
+// lets a LayoutLeft multivector use the 16-byte-per-lane row-major kernel.  32x32 LDS tile transpose.
+template <class YT>
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(int64_t n, int64_t nvec, const YT* __restrict__ X, int64_t xs0,
+                                                           int64_t xs1, YT* __restrict__ Xp, int64_t ldp) {
+  __shared__ YT tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  const int64_t i0 = (int64_t)blockIdx.x * 32;
+  for (int64_t j0 = 0; j0 < nvec; j0 += 32) {
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {                             // read: consecutive lanes walk i (stride xs0)
+      const int64_t i = i0 + tx, j = j0 + q;
+      tile[q][tx] = (i < n && j < nvec) ? X[i * xs0 + j * xs1] : YT(0);
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {                             // write: consecutive lanes walk j (contiguous)
+      const int64_t i = i0 + q, j = j0 + tx;
+      if (i < n && j < ldp) Xp[i * ldp + j] = tile[tx][q];
+    }
+  }
+}
+
+// rank-2 transpose: Y(col, k) += alpha * val * X(row, k) after Y := beta*Y (K6 analogue).
+template <class OffT, class AT, class YT>
+__global__ __launch_bounds__(kBlock) void spmv_mv_transpose_kernel(int64_t nrows, const OffT* __restrict__ row_map,
+                                                                   const int32_t* __restrict__ entries,
+                                                                   const AT* __restrict__ values,
+                                                                   const YT* __restrict__ X, int64_t xs0, int64_t xs1,
+                                                                   YT* __restrict__ Y, int64_t ys0, int64_t ys1,
+                                                                   int64_t nvec, YT alpha) {
+  constexpr int SW  = 16;
+  constexpr int RPB = kBlock / SW;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / SW;
+  const int k0      = threadIdx.x % SW;
+  if (row >= nrows) return;
+  const OffT s = row_map[row], e = row_map[row + 1];
+  for (int64_t k = k0; k < nvec; k += SW) {
+    const YT xv = alpha * X[row * xs0 + k * xs1];
+    for (OffT j = s; j < e; ++j) atomicAdd(&Y[(int64_t)entries[j] * ys0 + k * ys1], (YT)values[j] * xv);
+  }
+}
+
+
+// ================================================================================================================
+// LDS-staged rank-2 kernel (analysed handles).
+//
+// A tile is RB consecutive rows (RB = 32 for 16 right-hand sides, 64 for 8).  On matrices whose rows touch a few contiguous
+// column runs (stencils, banded and block-structured matrices) the X rows a tile needs are a few contiguous RUNS of X
+// rows; the analysis (mv_build_kernel, once per handle) finds them -- greedily, left to right, a run ends at the first four
+// consecutive unused columns, at most 16 runs -- and keeps, per tile, the first column of every 4-row CHUNK of the staged
+// window and, per nonzero, a 16-bit SLOT (the X row's position in that window) instead of the 32-bit column.  The kernel
+// then fetches the window with coalesced 16-byte loads -- every X row crosses L2 -> LDS once per tile instead of once per
+// nonzero through the texture path (27-pt: 34 x 9 rows instead of 32 x 27 gathers) -- and walks the rows out of LDS.
+// Tiles that do not stage (too many runs, window or row block too large) are handled by the same kernel through `entries`
+// and gathers from X, tile by tile.
+constexpr int kMvRuns     = 16;                    // contiguous X-row runs per tile
+constexpr int kMvChunk    = 4;                     // X rows per chunk of the staged window
+constexpr int kMvXBytes   = 44 * 1024;             // LDS a tile's X window may take
+constexpr int kMvNnzCap   = 2048;                  // nonzeros of a staged tile (A sits in LDS as 12-byte records)
+constexpr int kMvHdr      = 40;                    // tile meta (ints): [0] mode, [1] chunks, [2] runs, [3] nnz, [4..20) first column of every run,
+                                                   // [20..36) rows of every run (multiple of kMvChunk), [40..) first column of every chunk
+constexpr int kMvGather = 0, kMvStaged = 1;
+
+}  // namespace kk
+
+struct kkamd_mv_plan {
+  int rb = 0, nv = 0;                // rows per tile, right-hand sides per strip the tiling was made for
+  int meta_stride = 0;               // ints per tile in d_meta
+  int64_t ntiles = 0, staged_tiles = 0;
+  int32_t* d_meta = nullptr;         // [ntiles * meta_stride]
+  uint16_t* d_slot = nullptr;        // [nnz] LDS slot of every nonzero's X row (staged tiles)
+  int32_t* d_order = nullptr;        // [ntiles] workgroup -> tile (strip order), or null
+  int order_used = 0;                // 0 dispatch, 1 XCD-contiguous, 2 strips
+  int64_t period = 0;                // rows between tiles that share X rows across the far stride (0 = none found)
+  int max_slots = 0, max_nnz = 0;    // over the staged tiles: sizes the dynamic LDS
+  size_t bytes = 0;
+};
+
+namespace kk {
+
+void mv_plan_destroy(kkamd_mv_plan* mv) {
+  if (!mv) return;
+  if (mv->d_meta) (void)hipFree(mv->d_meta);
+  if (mv->d_slot) (void)hipFree(mv->d_slot);
+  if (mv->d_order) (void)hipFree(mv->d_order);
+  delete mv;
+}
+int64_t mv_plan_query(const kkamd_mv_plan* mv, int what) {
+  if (!mv) return 0;
+  switch (what) {
+    case 0: return mv->ntiles;
+    case 1: return mv->staged_tiles;
+    case 2: return mv->order_used;
+    case 3: return (int64_t)mv->bytes;
+    case 4: return mv->period;
+    default: return 0;
+  }
+}
+
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv_build_kernel(int64_t nrows, int64_t ncols, const OffT* __restrict__ row_map,
+                                                          const int32_t* __restrict__ entries, int rb, int max_slots, int meta_stride,
+                                                          int rowbytes, int lds_budget, int32_t* __restrict__ meta, uint16_t* __restrict__ slot,
+                                                          int* __restrict__ stats) {
+  // stats: [0] staged tiles, [1] max slots, [2] max nnz over the staged tiles
+  constexpr int PER = kMvNnzCap / kBlock;
+  __shared__ int s_base[kMvRuns], s_len[kMvRuns], s_off[kMvRuns + 1];
+  __shared__ unsigned s_bits[128];                             // used columns among the 4096 after the run's base
+  __shared__ int s_min, s_zero, s_flag;
+  const int t = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int64_t row0 = b * rb, rowN = (row0 + rb < nrows) ? row0 + rb : nrows;
+  const int64_t a0 = (int64_t)row_map[row0], a1 = (int64_t)row_map[rowN];
+  const int64_t n = a1 - a0;
+  int32_t* m = meta + b * meta_stride;
+  if (n > kMvNnzCap || n == 0) {                               // workgroup-uniform
+    if (t == 0) { m[0] = kMvGather; m[1] = 0; m[2] = 0; m[3] = (int32_t)(n > INT_MAX ? INT_MAX : n); }
+    return;
+  }
+  int c[PER];
+  KK_UNROLL
+  for (int k = 0; k < PER; ++k) { const int64_t i = (int64_t)k * kBlock + t; c[k] = i < n ? entries[a0 + i] : -1; }
+  long long bound = 0;                                         // columns < bound are covered
+  int nruns = 0;
+  for (int w = 0; w < kMvRuns; ++w) {                          // workgroup-uniform control flow throughout
+    if (t == 0) { s_min = INT_MAX; s_zero = 1024; }
+    if (t < 128) s_bits[t] = 0u;
+    __syncthreads();
+    int mn = INT_MAX;
+    KK_UNROLL
+    for (int k = 0; k < PER; ++k) if (c[k] >= 0 && (long long)c[k] >= bound && c[k] < mn) mn = c[k];
+    if (mn != INT_MAX) atomicMin(&s_min, mn);
+    __syncthreads();
+    const int base = s_min;
+    if (base == INT_MAX) break;
+    KK_UNROLL
+    for (int k = 0; k < PER; ++k) {
+      const long long d = (long long)c[k] - base;
+      if (c[k] >= 0 && d >= 0 && d < 4096) atomicOr(&s_bits[d >> 5], 1u << (d & 31));
+    }
+    __syncthreads();
+    // the run ends at the first kMvChunk-aligned group of kMvChunk unused columns (nibble j = columns [4j, 4j + 4))
+    for (int j = t; j < 1024; j += kBlock) if (((s_bits[j >> 3] >> ((j & 7) * 4)) & 0xfu) == 0u) atomicMin(&s_zero, j);
+    __syncthreads();
+    const int len = kMvChunk * s_zero;
+    if (t == 0) { s_base[w] = base; s_len[w] = len; }
+    bound = (long long)base + len;
+    nruns = w + 1;
+    __syncthreads();
+  }
+  bool uncovered = false;
+  KK_UNROLL
+  for (int k = 0; k < PER; ++k) uncovered |= (c[k] >= 0 && (long long)c[k] >= bound);
+  if (t == 0) {
+    s_flag = 0;
+    int off = 0;
+    for (int w = 0; w < nruns; ++w) { s_off[w] = off; off += s_len[w]; }
+    s_off[nruns] = off;
+  }
+  __syncthreads();
+  if (uncovered) atomicOr(&s_flag, 1);
+  __syncthreads();
+  const int total = s_off[nruns];
+  if (s_flag || total > max_slots || total * rowbytes + 12 * (int)n > lds_budget) {      // workgroup-uniform
+    if (t == 0) { m[0] = kMvGather; m[1] = 0; m[2] = 0; m[3] = (int32_t)n; }
+    return;
+  }
+  KK_UNROLL
+  for (int k = 0; k < PER; ++k) {
+    if (c[k] < 0) continue;
+    int w = 0;
+    for (int q = 1; q < nruns; ++q) if (s_base[q] <= c[k]) w = q;       // run bases ascend
+    slot[a0 + (int64_t)k * kBlock + t] = (uint16_t)(s_off[w] + (c[k] - s_base[w]));
+  }
+  const int nchunks = total / kMvChunk;
+  if (t == 0) {
+    m[0] = kMvStaged; m[1] = nchunks; m[2] = nruns; m[3] = (int32_t)n;
+    atomicAdd(stats, 1); atomicMax(stats + 1, total); atomicMax(stats + 2, (int)n);
+  }
+  if (t < kMvRuns) { m[4 + t] = t < nruns ? s_base[t] : 0; m[20 + t] = t < nruns ? s_len[t] : 0; }
+  for (int ch = t; ch < nchunks; ch += kBlock) {
+    const int s0 = ch * kMvChunk;
+    int w = 0;
+    for (int q = 1; q < nruns; ++q) if (s_off[q] <= s0) w = q;
+    m[kMvHdr + ch] = s_base[w] + (s0 - s_off[w]);
+  }
+}
+
+// Rank-2 kernel over the plan's row-block tiles.  256 work-items = RB rows x 2 halves of every row's entries (even / odd
+// positions) x NV/4 lanes of four right-hand sides each (two 16-byte pieces of the X row); the halves are summed with one
+// lane exchange at the end.
+//   1. everything the tile needs is requested up front: its A entries (values + slots, coalesced), the row bounds, and the
+//      X window in 16-byte pieces (piece g -> chunk g / PPC, whose first column comes from the tile's chunk table);
+//   2. A goes to LDS as (value, byte offset of the X row in the window), the window as it is; one barrier;
+//   3. every lane walks its half row in batches of four entries: four LDS reads of A (broadcast within the row's lanes),
+//      eight 16-byte LDS reads of X, sixteen FMAs;
+//   4. Y leaves as 16 bytes per lane, 128 contiguous bytes per row.
+// Tiles in gather mode (kMvGather) take the same route with the column in place of the offset and X read from memory.
+template <class OffT, class AT, int NV>
+__global__ __launch_bounds__(kBlock) void spmv_mv3_kernel(int64_t nrows, int64_t ncols, const OffT* __restrict__ row_map,
+                                                          const int32_t* __restrict__ entries, const AT* __restrict__ values,
+                                                          const uint16_t* __restrict__ slot, const int32_t* __restrict__ meta,
+                                                          int meta_stride, const int32_t* __restrict__ order, int order_mode,
+                                                          const double* __restrict__ X, int64_t xs0, double* __restrict__ Y,
+                                                          int64_t ys0, int64_t ys1, int64_t nvec, double alpha, double beta,
+                                                          int y_vec_ok, int xbytes, int cap_rec) {
+  constexpr int ROWB = NV * 8;                  // bytes of one staged X row
+  constexpr int LQ   = NV / 4;                  // lanes (of four right-hand sides) per half row
+  constexpr int LPR  = 2 * LQ;                  // lanes per row
+  constexpr int RB   = kBlock / LPR;            // rows per tile
+  constexpr int PPR  = ROWB / 16;               // 16-byte pieces per X row
+  constexpr int PPC  = kMvChunk * PPR;          // ... per chunk
+  using XV = kk_f64x2;
+  KK_DYN_SMEM(char, smem);                      // [X window: xbytes][A values: 8 * cap_rec][A offsets: 4 * cap_rec]
+  char* xwin    = smem;
+  double* a_val = reinterpret_cast<double*>(smem + xbytes);
+  int* a_off    = reinterpret_cast<int*>(smem + xbytes + 8 * (size_t)cap_rec);
+  const int t = threadIdx.x;
+  const int64_t b = order ? (int64_t)order[blockIdx.x] : xcd_order(blockIdx.x, gridDim.x, order_mode);
+  const int32_t* m = meta + b * meta_stride;
+  const int mode = m[0], nchunks = m[1];        // workgroup-uniform
+  const int64_t row0 = b * RB, rowN = (row0 + RB < nrows) ? row0 + RB : nrows;
+  const int64_t a0 = (int64_t)row_map[row0], a1 = (int64_t)row_map[rowN];
+  const int r = t / LPR, h = (t / LQ) & 1, l = t % LQ;
+  const int64_t row = row0 + r;
+  int64_t rs = 0, re = 0;
+  if (row < rowN) { rs = (int64_t)row_map[row] - a0; re = (int64_t)row_map[row + 1] - a0; }
+  const int64_t n = a1 - a0;
+  for (int64_t kk = 0; kk < nvec; kk += NV) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t c = 0; c < n; c += cap_rec) {                 // one pass for staged tiles; gather tiles may be longer
+      const int64_t ce = (c + cap_rec < n) ? c + cap_rec : n;
+      if (c > 0 || kk > 0) __syncthreads();                    // the previous pass is done with the LDS
+      // 1. requests: A entries ...
+      constexpr int AMAX = kMvNnzCap / kBlock;
+      AT av[AMAX]; int ao[AMAX];
+      if (mode == kMvStaged) {
+        KK_UNROLL
+        for (int k = 0; k < AMAX; ++k) {                       // unguarded (clamped) loads stay in flight together
+          if (c + (int64_t)k * kBlock >= ce) break;            // workgroup-uniform
+          int64_t i = c + (int64_t)k * kBlock + t;
+          i = i < ce ? i : ce - 1;
+          av[k] = values[a0 + i]; ao[k] = (int)slot[a0 + i] * ROWB;
+        }
+        // ... and the X window, 16 bytes per request
+        const int npieces = nchunks * PPC;
+        constexpr int XMAX = (kMvXBytes / 16 + kBlock - 1) / kBlock;
+        XV xv[XMAX];
+        KK_UNROLL
+        for (int k = 0; k < XMAX; ++k) {
+          if (k * kBlock >= npieces) break;                    // workgroup-uniform
+          int g = k * kBlock + t;
+          g = g < npieces ? g : npieces - 1;
+          const int ch = g / PPC, p = g % PPC;
+          int64_t col = (int64_t)m[kMvHdr + ch] + p / PPR;
+          col = col < ncols ? col : ncols - 1;                 // the padding of the last run may reach past the matrix
+          xv[k] = *reinterpret_cast<const XV*>(X + col * xs0 + kk + (p % PPR) * 2);
+        }
+        // 2. into LDS
+        KK_UNROLL
+        for (int k = 0; k < XMAX; ++k) { const int g = k * kBlock + t; if (g < npieces) *reinterpret_cast<XV*>(xwin + (size_t)g * 16) = xv[k]; }
+        KK_UNROLL
+        for (int k = 0; k < AMAX; ++k) { const int i = k * kBlock + t; if (c + i < ce) { a_val[i] = (double)av[k]; a_off[i] = ao[k]; } }
+      } else {
+        for (int64_t i = c + t; i < ce; i += kBlock) { a_val[i - c] = (double)values[a0 + i]; a_off[i - c] = entries[a0 + i]; }
+      }
+      __syncthreads();
+      // 3. my half of my row's entries inside this pass: positions rs + h, rs + h + 2, ...
+      const int64_t lo = rs > c ? rs : c, hi = re < ce ? re : ce;
+      int i = (int)(lo - c) + (int)((h - (lo - rs)) & 1);
+      const int e = (int)(hi - c);
+      if (mode == kMvStaged) {
+        // piece P of lane (l, h) sits in half h of the X row, piece Q in the other half: the 16 lanes ds_read_b128 serves per
+        // cycle (four rows x four lanes, two of each half) then cover all 64 banks once
+        const char* xl = xwin + l * 16 + h * (ROWB / 2);
+        const char* xq = xwin + l * 16 + (1 - h) * (ROWB / 2);
+        for (; i + 6 < e; i += 8) {
+          const double v0 = a_val[i], v1 = a_val[i + 2], v2 = a_val[i + 4], v3 = a_val[i + 6];
+          const int o0 = a_off[i], o1 = a_off[i + 2], o2 = a_off[i + 4], o3 = a_off[i + 6];
+          const XV p0 = *reinterpret_cast<const XV*>(xl + o0), q0 = *reinterpret_cast<const XV*>(xq + o0);
+          const XV p1 = *reinterpret_cast<const XV*>(xl + o1), q1 = *reinterpret_cast<const XV*>(xq + o1);
+          const XV p2 = *reinterpret_cast<const XV*>(xl + o2), q2 = *reinterpret_cast<const XV*>(xq + o2);
+          const XV p3 = *reinterpret_cast<const XV*>(xl + o3), q3 = *reinterpret_cast<const XV*>(xq + o3);
+          acc[0] += v0 * p0[0]; acc[1] += v0 * p0[1]; acc[2] += v0 * q0[0]; acc[3] += v0 * q0[1];
+          acc[0] += v1 * p1[0]; acc[1] += v1 * p1[1]; acc[2] += v1 * q1[0]; acc[3] += v1 * q1[1];
+          acc[0] += v2 * p2[0]; acc[1] += v2 * p2[1]; acc[2] += v2 * q2[0]; acc[3] += v2 * q2[1];
+          acc[0] += v3 * p3[0]; acc[1] += v3 * p3[1]; acc[2] += v3 * q3[0]; acc[3] += v3 * q3[1];
+        }
+        for (; i < e; i += 2) {
+          const double v0 = a_val[i];
+          const int o0 = a_off[i];
+          const XV p0 = *reinterpret_cast<const XV*>(xl + o0), q0 = *reinterpret_cast<const XV*>(xq + o0);
+          acc[0] += v0 * p0[0]; acc[1] += v0 * p0[1]; acc[2] += v0 * q0[0]; acc[3] += v0 * q0[1];
+        }
+      } else {
+        const double* xg = X + kk + l * 2 + h * (NV / 2);
+        constexpr int QD = NV / 2;
+        const int qd = h ? -QD : QD;                           // the lane's other piece, in doubles
+        for (; i + 2 < e; i += 4) {
+          const double v0 = a_val[i], v1 = a_val[i + 2];
+          const double* x0 = xg + (int64_t)a_off[i] * xs0;
+          const double* x1 = xg + (int64_t)a_off[i + 2] * xs0;
+          const XV p0 = *reinterpret_cast<const XV*>(x0), q0 = *reinterpret_cast<const XV*>(x0 + qd);
+          const XV p1 = *reinterpret_cast<const XV*>(x1), q1 = *reinterpret_cast<const XV*>(x1 + qd);
+          acc[0] += v0 * p0[0]; acc[1] += v0 * p0[1]; acc[2] += v0 * q0[0]; acc[3] += v0 * q0[1];
+          acc[0] += v1 * p1[0]; acc[1] += v1 * p1[1]; acc[2] += v1 * q1[0]; acc[3] += v1 * q1[1];
+        }
+        for (; i < e; i += 2) {
+          const double v0 = a_val[i];
+          const double* x0 = xg + (int64_t)a_off[i] * xs0;
+          const XV p0 = *reinterpret_cast<const XV*>(x0), q0 = *reinterpret_cast<const XV*>(x0 + qd);
+          acc[0] += v0 * p0[0]; acc[1] += v0 * p0[1]; acc[2] += v0 * q0[0]; acc[3] += v0 * q0[1];
+        }
+      }
+    }
+    // the two halves of a row meet: the partner (LQ lanes away) holds this lane's piece P as its piece Q
+    const double f0 = acc[0] + __shfl_xor(acc[2], LQ, 64), f1 = acc[1] + __shfl_xor(acc[3], LQ, 64);
+    // 4. lane (l, h) writes right-hand sides kk + 2l + (NV/2) h, + 1: 16 bytes per lane, the row's 8 NV bytes contiguous
+    if (row < rowN) {
+      const int64_t cq = kk + 2 * l + (NV / 2) * h;
+      const double s0 = alpha * f0, s1 = alpha * f1;
+      double* yp = Y + row * ys0 + cq * ys1;
+      if (y_vec_ok) {
+        XV out;
+        if (beta == 0.0) { out[0] = s0; out[1] = s1; }
+        else { const XV old = *reinterpret_cast<const XV*>(yp); out[0] = beta * old[0] + s0; out[1] = beta * old[1] + s1; }
+        *reinterpret_cast<XV*>(yp) = out;
+      } else {
+        yp[0]   = (beta == 0.0) ? s0 : beta * yp[0] + s0;
+        yp[ys1] = (beta == 0.0) ? s1 : beta * yp[ys1] + s1;
+      }
+    }
+  }
+}
+
+// ---- host side of the LDS-staged kernel ------------------------------------------------------------------------
+constexpr int kMvLdsBytes = 60 * 1024;     // X window + A records of one tile (the analysis accepts a tile only if it fits)
+
+// Far stride of the matrix, from the run tables of a few tiles: a run's centre minus the tile's centre is the offset d of
+// a "diagonal band" (27-pt: 0, +-S1, +-S2, +-S2 +-S1); the far cluster (offsets above half the largest) has S2 as its median.
+static int64_t mv_detect_period(const kkamd_mv_plan* mv, int64_t nrows, hipStream_t st) {
+  if (mv->ntiles < 64) return 0;
+  int64_t votes[16]; int nv = 0;
+  for (int s = 1; s <= 15; ++s) {
+    const int64_t tile = mv->ntiles * s / 16;
+    int32_t hdr[kMvHdr];
+    if (hipMemcpyAsync(hdr, mv->d_meta + tile * mv->meta_stride, sizeof hdr, hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
+    if (hipStreamSynchronize(st) != hipSuccess) return 0;
+    if (hdr[0] != kMvStaged) continue;
+    const double centre = (double)tile * mv->rb + 0.5 * mv->rb;
+    double off[kMvRuns]; int no = 0; double mx = 0;
+    for (int w = 0; w < hdr[2] && w < kMvRuns; ++w) {
+      const double d = (double)hdr[4 + w] + 0.5 * (double)hdr[20 + w] - centre;
+      if (d > 0) { off[no++] = d; if (d > mx) mx = d; }
+    }
+    double far[kMvRuns]; int nf = 0;
+    for (int i = 0; i < no; ++i) if (off[i] > 0.5 * mx) far[nf++] = off[i];
+    if (!nf) continue;
+    for (int i = 1; i < nf; ++i) { const double v = far[i]; int j = i - 1; while (j >= 0 && far[j] > v) { far[j + 1] = far[j]; --j; } far[j + 1] = v; }
+    votes[nv++] = (int64_t)(far[nf / 2] + 0.5);
+  }
+  if (nv < 3) return 0;
+  // the most frequent vote (run lengths are padded, so centres wobble by a row or two: votes within 2 rows agree)
+  int64_t best = 0; int best_n = 0;
+  for (int i = 0; i < nv; ++i) { int c = 0; for (int j = 0; j < nv; ++j) if (votes[j] >= votes[i] - 2 && votes[j] <= votes[i] + 2) ++c; if (c > best_n) { best_n = c; best = votes[i]; } }
+  return (best_n * 2 > nv && best > 0 && best < nrows) ? best : 0;
+}
+
+// Strip order.  Tiles P rows apart share X rows (the far stride); a sweep in row order brings them P rows * row bytes apart
+// in time -- 11.5 MB of X on the 27-pt 300^3 matrix, against a 4 MB L2 -- so every L2 fetches every X row once per far
+// neighbour and once per XCD.  Here every XCD instead owns STRIPS of W consecutive rows of every period and walks a strip
+// period after period: the three periods' worth of X rows a strip needs (3 W rows) stay in its L2, and an X row crosses the
+// fabric about once.  order[8 i + x] = i-th tile of XCD x (workgroup b runs on XCD b % 8).
+static int mv_build_strip_order(kkamd_mv_plan* mv, int64_t period, int rowbytes, hipStream_t st) {
+  const int64_t nt = mv->ntiles, rb = mv->rb;
+  const double l2_rows = 2.5e6 / (3.0 * (double)rowbytes);                 // rows of X per period a strip may keep in a 4 MB L2
+  int64_t nstrips = (int64_t)((double)period / l2_rows) + 1;
+  nstrips = (nstrips + kNumXcd - 1) / kNumXcd * kNumXcd;
+  const int64_t width = (period + nstrips - 1) / nstrips;                 // rows per strip
+  if (width < 4 * rb) return KKAMD_ERR_UNSUPPORTED;                       // strips of a few tiles: nothing to gain
+  std::vector<std::vector<int32_t>> lists((size_t)nstrips);
+  for (int64_t t = 0; t < nt; ++t) lists[(size_t)(((t * rb) % period) / width)].push_back((int32_t)t);   // natural order = (period, position) ascending
+  std::vector<std::vector<int32_t>> xcd(kNumXcd);
+  for (int64_t s = 0; s < nstrips; ++s) { auto& dst = xcd[(size_t)(s % kNumXcd)]; dst.insert(dst.end(), lists[(size_t)s].begin(), lists[(size_t)s].end()); }
+  std::vector<int32_t> order; order.reserve((size_t)nt);
+  size_t longest = 0;
+  for (auto& v : xcd) if (v.size() > longest) longest = v.size();
+  for (size_t i = 0; i < longest; ++i) for (int x = 0; x < kNumXcd; ++x) if (i < xcd[(size_t)x].size()) order.push_back(xcd[(size_t)x][i]);
+  KK_HIP(hipMalloc((void**)&mv->d_order, sizeof(int32_t) * (size_t)nt));
+  KK_HIP(hipMemcpyAsync(mv->d_order, order.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+  KK_HIP(hipStreamSynchronize(st));
+  mv->bytes += sizeof(int32_t) * (size_t)nt;
+  return KKAMD_OK;
+}
+
+template <class OffT>
+static int mv_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, int nv, hipStream_t st) {
+  if (plan->mv) { mv_plan_destroy(plan->mv); plan->mv = nullptr; }
+  kkamd_mv_plan* mv = new (std::nothrow) kkamd_mv_plan();
+  if (!mv) return fail(KKAMD_ERR_ALLOC, "kkamd_spmv_mv: out of host memory");
+  mv->nv = nv; mv->rb = 2 * kBlock / nv;                       // kBlock / (2 halves * nv / 4 lanes)
+  mv->ntiles = ceil_div(A->num_rows, mv->rb);
+  const int rowbytes  = nv * 8;
+  const int max_slots = kMvXBytes / rowbytes;
+  mv->meta_stride = (kMvHdr + max_slots / kMvChunk + 31) / 32 * 32;
+  DevBuf stats;
+  auto give_up = [&]() { (void)hipGetLastError(); mv_plan_destroy(mv); plan->mv_failed = true; return KKAMD_OK; };
+  if (hipMalloc((void**)&mv->d_meta, sizeof(int32_t) * (size_t)mv->ntiles * (size_t)mv->meta_stride) != hipSuccess ||
+      hipMalloc((void**)&mv->d_slot, sizeof(uint16_t) * (size_t)(A->nnz + 8)) != hipSuccess || stats.alloc(4 * sizeof(int)) != hipSuccess)
+    return give_up();                                          // an optimisation: without the memory the wave-private kernel serves
+  mv->bytes = sizeof(int32_t) * (size_t)mv->ntiles * (size_t)mv->meta_stride + sizeof(uint16_t) * (size_t)(A->nnz + 8);
+  int* d_stats = stats.as<int>();
+  KK_HIP(hipMemsetAsync(d_stats, 0, 4 * sizeof(int), st));
+  KK_LAUNCH((mv_build_kernel<OffT>), (unsigned)mv->ntiles, kBlock, 0, st, A->num_rows, A->num_cols, (const OffT*)A->d_row_map,
+            (const int32_t*)A->d_entries, mv->rb, max_slots, mv->meta_stride, rowbytes, kMvLdsBytes, mv->d_meta, mv->d_slot, d_stats);
+  if (hipGetLastError() != hipSuccess) return give_up();
+  int h[4] = {0, 0, 0, 0};
+  KK_HIP(hipMemcpyAsync(h, stats.p, sizeof h, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  mv->staged_tiles = h[0]; mv->max_slots = h[1]; mv->max_nnz = h[2];
+  if ((double)mv->staged_tiles < 0.5 * (double)mv->ntiles) return give_up();     // mostly gathers anyway: the wave-private kernel is the better gather kernel
+  mv->order_used = plan->tune.mv_order ? 1 : 0;
+  if (plan->tune.mv_order == 2) {
+    mv->period = mv_detect_period(mv, A->num_rows, st);
+    // worth it when a period's worth of X rows overflows an L2 (4 MB per XCD)
+    if (mv->period > 0 && (double)mv->period * rowbytes * 3.0 > 3.0e6 && mv_build_strip_order(mv, mv->period, rowbytes, st) == KKAMD_OK) mv->order_used = 2;
+    (void)hipGetLastError();
+  }
+  plan->mv = mv;
+  return KKAMD_OK;
+}
+
+template <class OffT, class AT, int NV>
+static int launch_mv3(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0,
+                      int64_t ys1, int64_t nvec, double alpha, double beta, hipStream_t st) {
+  const kkamd_mv_plan* mv = plan->mv;
+  const int xbytes  = mv->max_slots * NV * 8;
+  int cap_rec       = (mv->max_nnz + 63) / 64 * 64;
+  if (cap_rec < 256) cap_rec = 256;
+  const size_t lds  = (size_t)xbytes + 12 * (size_t)cap_rec;
+  const int yv      = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
+  KK_LAUNCH((spmv_mv3_kernel<OffT, AT, NV>), (unsigned)mv->ntiles, kBlock, lds, st, A->num_rows, A->num_cols, (const OffT*)A->d_row_map,
+            (const int32_t*)A->d_entries, (const AT*)A->d_values, (const uint16_t*)mv->d_slot, (const int32_t*)mv->d_meta,
+            mv->meta_stride, (const int32_t*)(mv->order_used == 2 ? mv->d_order : nullptr), mv->order_used == 1 ? 1 : 0, X, ldx, Y, ys0,
+            ys1, nvec, alpha, beta, yv, xbytes, cap_rec);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+template <class OffT, class AT, class YT, int SW>
+static int launch_mv(const kkamd_crs_t* A, const YT* X, int64_t xs0, int64_t xs1, YT* Y, int64_t ys0, int64_t ys1,
+                     int64_t nvec, YT alpha, YT beta, int remap, hipStream_t st) {
+  KK_LAUNCH((spmv_mv_kernel<OffT, AT, YT, SW>), (unsigned)ceil_div(A->num_rows, kBlock / SW), kBlock, 0, st,
+            A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1,
+            Y, ys0, ys1, nvec, alpha, beta, remap);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+template <class OffT, class AT, class YT>
+static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dX,
+                         int64_t xs0, int64_t xs1, double beta_d, void* dY, int64_t ys0, int64_t ys1, int64_t nvec,
+                         hipStream_t st) {
+  const YT alpha = (YT)alpha_d, beta = (YT)beta_d;
+  const YT* X    = (const YT*)dX;
+  YT* Y          = (YT*)dY;
+  const int remap = (plan ? plan->tune.xcd_remap : g_spmv_default.xcd_remap) == 1;
+  if (trans) {
+    int rc = launch_scale<YT>(Y, A->num_cols, ys0, nvec, ys1, beta, st);
+    if (rc) return rc;
+    KK_LAUNCH((spmv_mv_transpose_kernel<OffT, AT, YT>), (unsigned)ceil_div(A->num_rows, kBlock / 16), kBlock, 0, st,
+              A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1,
+              Y, ys0, ys1, nvec, alpha);
+    KK_LAUNCH_CHECK();
+    return KKAMD_OK;
+  }
+  const int mvk = plan ? plan->tune.mv_kernel : g_spmv_default.mv_kernel;      // 0 auto, 1 generic, 2 wave-private row-major, 3 LDS-staged X tiles
+  const bool a_aligned = ((uintptr_t)A->d_values % 16 == 0) && ((uintptr_t)A->d_entries % 16 == 0);
+  if (mvk != 1 && a_aligned) {
+    const YT* Xr = nullptr; int64_t ldx = 0;
+    if (xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0)) { Xr = X; ldx = xs0; }
+    else if (plan && nvec >= 2) {
+      // pack X into a row-major workspace owned by the plan (the reference's rank-2 sub-handle tpl_rank2 plays this role)
+      const int64_t ldp = (nvec + 1) & ~(int64_t)1;
+      const size_t need = (size_t)A->num_cols * (size_t)ldp * sizeof(YT);
+      if (plan->xpack_bytes < need) {
+        if (plan->d_xpack) { KK_HIP(hipStreamSynchronize(st)); KK_HIP(hipFree(plan->d_xpack)); plan->d_xpack = nullptr; plan->xpack_bytes = 0; }
+        KK_HIP(hipMalloc(&plan->d_xpack, need));
+        plan->xpack_bytes = need;
+      }
+      KK_LAUNCH((pack_rows_kernel<YT>), (unsigned)ceil_div(A->num_cols, 32), kBlock, 0, st, A->num_cols, nvec, X, xs0, xs1,
+                (YT*)plan->d_xpack, ldp);
+      KK_LAUNCH_CHECK();
+      Xr = (const YT*)plan->d_xpack; ldx = ldp;
+    }
+    // LDS-staged X tiles: analysed handles, fp64 vectors, 8 or 16 right-hand sides per strip; the analysis happens on the
+    // first such call (like the vendor's rank-2 sub-handle) and is kept for the handle's life
+    if constexpr (sizeof(YT) == 8) {
+      if (Xr && plan && plan->tile != 0 && mvk != 2 && nvec >= 8 && nvec % 8 == 0 && !plan->mv_failed && plan->entries == A->d_entries &&
+          (mvk == 3 || A->nnz >= 1000000)) {
+        const int nv = (nvec % 16 == 0) ? 16 : 8;
+        if (!plan->mv || plan->mv->nv != nv) {
+          int rc = mv_plan_build<OffT>(plan, A, nv, st);
+          if (rc) return rc;
+        }
+        if (plan->mv) {
+          if (nv == 16) return launch_mv3<OffT, AT, 16>(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
+          return launch_mv3<OffT, AT, 8>(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
+        }
+      }
+    }
+    if (Xr) {
+      const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
+      const int mv_remap = plan ? plan->tune.mv_remap : g_spmv_default.mv_remap;
+#define KK_MV2C(L, R, C)                                                                                                 \
+      do {                                                                                                               \
+        KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R, C>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
+                  0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, \
+                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap);                                                        \
+        KK_LAUNCH_CHECK();                                                                                               \
+        return KKAMD_OK;                                                                                                 \
+      } while (0)
+      // staging window: the nnz of the wave's kWave/L rows (+15 % and the 4-alignment slack), rounded up to 256 / 512 / 1024
+#define KK_MV2(L, R)                                                                                                     \
+      do {                                                                                                               \
+        const int64_t need = (int64_t)(1.15 * (double)(kWave / L) * (double)A->nnz / (double)A->num_rows) + 4;            \
+        if (need <= 256) KK_MV2C(L, R, 256);                                                                              \
+        if (need <= 512) KK_MV2C(L, R, 512);                                                                              \
+        KK_MV2C(L, R, 1024);                                                                                              \
+      } while (0)
+      if (nvec >= 12) KK_MV2(4, 4);
+      if (nvec >= 6) KK_MV2(2, 4);
+      if (nvec >= 3) KK_MV2(2, 2);
+      KK_MV2(1, 2);
+#undef KK_MV2C
+#undef KK_MV2
+    }
+  }
+  if (nvec >= 12) return launch_mv<OffT, AT, YT, 16>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
+  if (nvec >= 6)  return launch_mv<OffT, AT, YT, 8>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
+  if (nvec >= 3)  return launch_mv<OffT, AT, YT, 4>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
+  return launch_mv<OffT, AT, YT, 2>(A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, remap, st);
+}
+
+}  // namespace kk
+
+extern "C" {
+
+int kkamd_spmv_mv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double alpha, const void* d_X,
+                  int64_t x_stride0, int64_t x_stride1, double beta, void* d_Y, int64_t y_stride0, int64_t y_stride1,
+                  int64_t nvec, int vector_type, kkamd_stream_t stream) {
+  int rc = kk::check_crs(A);
+  if (rc) return rc;
+  bool trans = false;
+  if ((rc = kk::parse_mode(mode, &trans))) return rc;
+  if ((rc = kk::check_plan(plan, A))) return rc;
+  if (nvec < 0) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: negative number of vectors");
+  if (vector_type != KKAMD_F32 && vector_type != KKAMD_F64)
+    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv_mv: unsupported vector_type %d", vector_type);
+  hipStream_t st     = kk::to_hip(stream);
+  const int64_t ylen = trans ? A->num_cols : A->num_rows;
+  if (nvec == 0 || ylen == 0) return KKAMD_OK;
+  if (!d_Y) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: null Y");
+  if (alpha == 0.0 || A->num_rows == 0 || A->num_cols == 0 || A->nnz == 0) {
+    if (vector_type == KKAMD_F64) return kk::launch_scale<double>((double*)d_Y, ylen, y_stride0, nvec, y_stride1, beta, st);
+    return kk::launch_scale<float>((float*)d_Y, ylen, y_stride0, nvec, y_stride1, (float)beta, st);
+  }
+  if (!d_X) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: null X");
+  if ((rc = kk::bind_stream(plan, st))) return rc;
+  // one contiguous column: the rank-1 path (sparse/src/KokkosSparse_spmv.hpp:203-217)
+  if (nvec == 1 && x_stride0 == 1 && y_stride0 == 1) return kkamd_spmv(plan, A, mode, alpha, d_X, beta, d_Y, vector_type, stream);
+  KK_DISPATCH_TYPES(kk::spmv_mv_typed, plan, A, trans, alpha, d_X, x_stride0, x_stride1, beta, d_Y, y_stride0,
+                    y_stride1, nvec, st);
+}
+
+}  // extern "C"

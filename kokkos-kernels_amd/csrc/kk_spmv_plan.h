@@ -1,0 +1,154 @@
+// kk_spmv_plan.h -- the SpMV plan (the analogue of SPMVHandleImpl::tpl_rank1 / tpl_rank2,
+// sparse/src/KokkosSparse_spmv_handle.hpp:241-242) and its tuning knobs, shared by the rank-1 (kk_spmv.hip),
+// rank-2 (kk_spmv_mv.hip) and multi-GPU (kk_dist.hip) translation units.
+#pragma once
+#include "kk_common.h"
+
+namespace kk {
+
+struct SpmvTuning {
+  int kernel         = 0;  // 0 auto, 1 vector (no analysis), 2 stream
+  int lanes_per_row  = 0;  // vector kernel, 0 = auto
+  int nnz_per_thread = 0;  // stream kernel: 4 (fp64 only), 8 or 16; 0 = by size
+  int xcd_remap      = 16; // tile order of the nnz-split kernel: 0 dispatch order (tile b on XCD b % 8), 1 XCD-contiguous (3-8 % slower than 0),
+                           // G = 2^k >= 2 grouped (G consecutive tiles per XCD inside blocks of 8G tiles; 16: 1.37 -> 1.29 ms on C2, 7-pt 400^3 -7 %)
+  int nontemporal    = 0;  // measured: no consistent gain from nt loads on the value/column streams
+  int mv_kernel      = 0;  // rank-2: 0 auto, 1 generic strided kernel, 2 wave-private row-major kernel, 3 LDS-staged X tiles (needs an analysed handle)
+  int stream_variant = 1;  // 1 default; 6 = attempt the window codes whatever the matrix size (tests)
+  int mv_remap       = 16; // rank-2 wave-private kernel: 0 dispatch order, 1 XCD-contiguous, 2^k grouped (16: 5.60 -> 4.76 ms on C3)
+  int mv_order       = 2;  // rank-2 LDS-staged kernel, tile order: 0 dispatch, 1 XCD-contiguous, 2 strips from the detected grid strides (falls back to 1)
+  int mv_inner       = 0;  // rank-2 LDS-staged kernel, contraction: 0 auto, 1 VALU, 2 MFMA (v_mfma_f64_4x4x4 on row-pattern tiles)
+  int explicit_transpose = 0;   // modes T/H with an analysed handle: 1 = cache A^T (structure + permutation) in the plan, refresh its
+                                // values every call and run the N kernel on it; 2 = same, the caller promises constant values (no refresh)
+  int explicit_transpose_min_knnz = 1000;   // ... from this many thousand nnz
+  int transient_min_knnz = 10000;  // handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 = never)
+  int window_codes = 1;            // analysed handles: 16-bit window codes + LDS-staged x, tile by tile (2 = codes without staged x, 0 = never)
+  int window_codes_min_knnz = 1000;  // ... from this many thousand nnz
+  int window_codes_min_pct = 25;   // ... when at least this share of the tiles can use them (the others read entries, per tile)
+  int pattern_codes = 1;           // staged-x tiles: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one
+                                   // (27-pt 300^3 1.349 -> 1.267 ms, 7-pt 400^3 1.025 -> 0.940 ms), 2 = whenever any tile has one, 0 = never
+  int pattern_codes_min_knnz = 10000;  // ... from this many thousand nnz (5-pt 1000^2, 5e6 nnz: 17.5 -> 18.3 us with the records)
+#ifdef KK_ABLATE                   // measurement build only (tools/, libkkamd_ablate.so): never part of libkkamd.so
+  int ablate         = 0;          // switches parts of the kernels off (see the kernels)
+  int lds_pad_kb     = 0;          // extra dynamic LDS per workgroup (caps workgroups per CU)
+#endif
+};
+extern SpmvTuning g_spmv_default;
+
+// 0, 1 or a power of two >= 2: the tile orders of xcd_order() (kk_common.h) are only bijective for those
+inline bool valid_order_knob(int v) { return v == 0 || v == 1 || (v >= 2 && v <= (1 << 20) && (v & (v - 1)) == 0); }
+
+// a device buffer that frees itself (host-side temporaries of the analysis; error paths return early)
+struct DevBuf {
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { reset(); }
+  hipError_t alloc(size_t bytes) { reset(); return hipMalloc(&p, bytes ? bytes : 1); }
+  void reset() { if (p) { (void)hipFree(p); p = nullptr; } }
+  void* release() { void* q = p; p = nullptr; return q; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace kk
+
+// Tile modes of the planned rank-1 kernel (low two bits of tinfo[b]; the upper bits index the tile's codes / record):
+//   0 plain (entries + gather), 1 window codes + gather, 2 window codes + LDS-staged x, 3 row-pattern record + staged x
+constexpr int kTilePlain = 0, kTileCodes = 1, kTileStaged = 2, kTilePattern = 3;
+
+struct kkamd_mv_plan;   // kk_spmv_mv.hip
+
+struct kkamd_spmv_plan {
+  int64_t num_rows = 0, num_cols = 0, nnz = 0;
+  const void* row_map = nullptr;
+  int offset_type = 0, value_type = 1, algorithm = 0;
+  kk::SpmvTuning tune;
+  int tile = 0;             // nnz per workgroup of the analysed tiling (0 = no stream analysis)
+  int64_t nblocks = 0;
+  int num_cus = 256;
+  int32_t* d_blk_row = nullptr;  // [nblocks+1] first row starting at or after b*tile
+  void* d_carry = nullptr;       // [2*nblocks] 8-byte slots: head partials, then tail partials
+  void* d_xpack = nullptr;       // rank-2: row-major packed copy of a column-major X (grown on demand)
+  size_t xpack_bytes = 0;
+  void* d_ypack = nullptr;       // rank-2 LDS-staged kernel: row-major Y scratch for a column-major Y
+  size_t ypack_bytes = 0;
+  const void* entries = nullptr; // the matrix's column array (identity check + analysis)
+  // Window codes: per tile up to 16 column windows of 4096 and, per nonzero, a 16-bit code (window << 12 | column - window
+  // base), stored in the order the kernel's work-items consume them -- only for the tiles that use them (tinfo)
+  int32_t* d_tinfo = nullptr;    // [nblocks] mode | index << 2 (index: tile's position in d_wcode resp. d_pmeta)
+  uint16_t* d_wcode = nullptr;   // [code_tiles * tile]
+  int32_t* d_wbase = nullptr;    // [nblocks * 64] window meta: bases, LDS slots, x chunk columns
+  int32_t* d_pmeta = nullptr;    // [pat_tiles * kPatW] row-pattern records (see pat_build_kernel)
+  int64_t code_tiles = 0;        // tiles that read per-nonzero codes (modes 1, 2)
+  int64_t staged_tiles = 0;      // tiles whose x window is staged in LDS (modes 2, 3)
+  int64_t pat_tiles = 0;         // tiles decoded from a row-pattern record (mode 3)
+  int64_t plain_tiles = 0;       // tiles that read entries (mode 0)
+  size_t plan_bytes = 0;         // HBM the analysis keeps
+  // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
+  void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr;
+  kkamd_spmv_plan* t_plan = nullptr;
+  bool t_ready = false, t_failed = false, t_values_valid = false;
+  bool win_failed = false;       // the codes are not worth it on this matrix (or HBM cannot hold them): plain entries
+  // rank-2 analysis (LDS-staged X tiles), built by the first rank-2 call that can use it
+  kkamd_mv_plan* mv = nullptr;
+  bool mv_failed = false;
+  // stream the plan's scratch (carry, packs) was last used on: a change of stream fences the old one first
+  // (TPL_SpMV_Data::set_exec_space, sparse/src/KokkosSparse_spmv_handle.hpp:95-104)
+  hipStream_t last_stream = nullptr;
+  bool used = false;
+};
+
+namespace kk {
+// the plan's scratch (carry, packs) is stream-ordered: when the stream changes, the old one is fenced first
+int  bind_stream(kkamd_spmv_plan* p, hipStream_t st);
+int  check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A);
+void mv_plan_destroy(kkamd_mv_plan* mv);
+int64_t mv_plan_query(const kkamd_mv_plan* mv, int what);   // 0 tiles, 1 pattern tiles, 2 order in use, 3 bytes
+int  release_transient();
+
+// native 2-element vectors (accepted by __builtin_nontemporal_load; same syntax under clang and gcc)
+typedef double kk_f64x2 __attribute__((vector_size(16)));
+typedef float  kk_f32x2 __attribute__((vector_size(8)));
+typedef int    kk_i32x2 __attribute__((vector_size(8)));
+typedef unsigned kk_u32x2 __attribute__((vector_size(8)));
+typedef unsigned kk_u32x4 __attribute__((vector_size(16)));
+template <class T> struct vec2;
+template <> struct vec2<double> { using type = kk_f64x2; };
+template <> struct vec2<float>  { using type = kk_f32x2; };
+
+
+// ------------------------------------------------------------------------------------------------
+template <class YT> __global__ void scale_kernel(YT* __restrict__ y, int64_t n, int64_t s0, int64_t ncol, int64_t s1, YT beta) {
+  // y(i,j) at i*s0 + j*s1; beta == 0 writes exact zeros (KokkosBlas::scal semantics)
+  const int64_t total = n * ncol;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = g / ncol, j = g % ncol;
+    YT* p = y + i * s0 + j * s1;
+    *p = (beta == YT(0)) ? YT(0) : beta * (*p);
+  }
+}
+
+template <class YT> static int launch_scale(YT* y, int64_t n, int64_t s0, int64_t ncol, int64_t s1, YT beta, hipStream_t st) {
+  if (n * ncol == 0 || beta == YT(1)) return KKAMD_OK;
+  const int64_t nb = ceil_div(n * ncol, kBlock);
+  KK_LAUNCH((scale_kernel<YT>), (unsigned)(nb < 8192 ? nb : 8192), kBlock, 0, st, y, n, s0, ncol, s1, beta);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+}  // namespace kk
+
+#define KK_DISPATCH_TYPES(FN, ...)                                                                        \
+  do {                                                                                                    \
+    const bool o64 = A->offset_type == KKAMD_I64;                                                         \
+    if (A->value_type == KKAMD_F64 && vector_type == KKAMD_F64)                                           \
+      return o64 ? FN<int64_t, double, double>(__VA_ARGS__) : FN<int32_t, double, double>(__VA_ARGS__);   \
+    if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F32)                                           \
+      return o64 ? FN<int64_t, float, float>(__VA_ARGS__) : FN<int32_t, float, float>(__VA_ARGS__);       \
+    if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F64)                                           \
+      return o64 ? FN<int64_t, float, double>(__VA_ARGS__) : FN<int32_t, float, double>(__VA_ARGS__);     \
+    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv: unsupported (value,vector) type pair (%d,%d)",        \
+                A->value_type, vector_type);                                                              \
+  } while (0)
+

@@ -66,14 +66,18 @@ def check_spmv(be, A0, mode="N", alpha=1.0, beta=0.0, algo=None, nans=False, see
     return h if algo is not None else None
 
 
-def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_order="F", algo=None, seed=0, knobs=None):
+def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_order="F", algo=None, seed=0, knobs=None, expect=None,
+                  max_val=1.0, nans=False):
     rng = np.random.default_rng(seed)
     trans = mode in "TH"
     nin, nout = (A0.nrows, A0.ncols) if trans else (A0.ncols, A0.nrows)
     X = np.asarray(rng.random((nin, nvec)), order=x_order)
     Y0 = np.asarray(rng.random((nout, nvec)), order=y_order)
+    if nans:
+        Y0[::7, :] = np.nan
     A = dev(be, A0)
     Xd, Yd = _to_dev_2d(be, X), _to_dev_2d(be, Y0)
+    h = None
     if algo is None:
         kk.spmv(mode, alpha, A, Xd, beta, Yd)
     else:
@@ -81,11 +85,17 @@ def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_or
         for k_, v_ in (knobs or {}).items():
             h.set(k_, v_)
         kk.spmv(h, mode, alpha, A, Xd, beta, Yd)
+        if beta == 0.0:
+            kk.spmv(h, mode, alpha, A, Xd, beta, Yd)                            # handle reuse
+        for k_, v_ in (expect or {}).items():
+            assert h.query(k_) == v_, "plan query %s: %r, expected %r" % (k_, h.query(k_), v_)
     got = _to_host_2d(be, Yd)
     exp = oracle.spmv_mv_serial(mode, A0, alpha, X, beta, Y0.copy(order="K"))
-    tol = oracle.spmv_max_error(A0, alpha, beta)
-    err = np.abs(exp - got).max() if got.size else 0.0
+    tol = oracle.spmv_max_error(A0, alpha, beta, max_val=max_val)
+    assert not (np.isnan(exp) ^ np.isnan(got)).any(), "spmv_mv NaN mismatch nvec=%d" % nvec
+    err = np.nanmax(np.abs(exp - got)) if got.size else 0.0
     assert err <= max(tol, 1e-300), "spmv_mv mismatch nvec=%d mode=%s orders=%s%s: %g > %g" % (nvec, mode, x_order, y_order, err, tol)
+    return h
 
 
 def _to_dev_2d(be, M):
@@ -261,4 +271,44 @@ def pattern_code_cases():
     out.append(("5pt-empty-rows", oracle.Crs(A0.nrows, A0.ncols, rm, A0.entries[keep], A0.values[keep]), 16, True))
     # banded random columns: staged x, but no two rows share a pattern
     out.append(("banded-random", oracle.random_crs(6000, 6000, 9, variance=0, seed=4, bandwidth=300, sorted_rows=True), 16, False))
+    return out
+
+
+def mixed_tile_cases():
+    """(name, matrix) where only SOME tiles of the planned kernel can use the column codes: a stencil with a few rows that
+    couple to columns all over the matrix (the rest of the tiles keep codes / staged x / records), and the reverse."""
+    rng = np.random.default_rng(21)
+    out = []
+    A0 = oracle.laplace3d("FE", 40, 30, 12)
+    rm = A0.row_map.copy(); ent = A0.entries.copy(); val = A0.values.copy()
+    wide = 400000                                            # x is longer than the stencil's grid: the coupling rows reach all over it
+    for r in (777, 5000, 5001, 11000):                       # four rows get 40 extra far-apart columns each
+        extra = (A0.ncols + np.sort(rng.choice(wide - A0.ncols, size=40, replace=False))).astype(np.int32)
+        ent = np.insert(ent, rm[r + 1], extra); val = np.insert(val, rm[r + 1], rng.random(40)); rm[r + 1:] += 40
+    out.append(("stencil+dense-rows", oracle.Crs(A0.nrows, wide, rm, ent, val)))
+    # first half random wide (no tile coverable), second half a banded block (every tile coverable)
+    n = 6000
+    top = oracle.random_crs(n // 2, 2000000, 12, variance=0, seed=3)
+    band = oracle.random_crs(n // 2, n // 2, 12, variance=0, seed=4, bandwidth=200, sorted_rows=True)       # columns inside [0, 3000)
+    rm = np.concatenate([top.row_map, band.row_map[1:] + top.row_map[-1]])
+    out.append(("random-then-banded", oracle.Crs(n, 2000000, rm, np.concatenate([top.entries, band.entries]), np.concatenate([top.values, band.values]))))
+    return out
+
+
+def mv3_cases():
+    """(name, matrix, staged tiles expected) for the LDS-staged rank-2 kernel"""
+    out = [("27pt", oracle.laplace3d("FE", 37, 11, 9), True), ("7pt", oracle.laplace3d("FD", 50, 12, 7), True),
+           ("9pt", oracle.laplace2d("FE", 130, 41), True),
+           ("banded-random", oracle.random_crs(3000, 3000, 9, variance=4, seed=4, bandwidth=60, sorted_rows=True), True),
+           ("random-wide", oracle.random_crs(2000, 50000, 9, variance=3, seed=5), False)]
+    name, A0 = mixed_tile_cases()[0]
+    out.append((name, A0, True))
+    # rows longer than a staged tile may hold, between stencil rows
+    A0 = oracle.laplace2d("FD", 90, 40)
+    rm = A0.row_map.copy(); ent = A0.entries.copy(); val = A0.values.copy()
+    rng = np.random.default_rng(8)
+    for r in (500, 2000):
+        extra = np.sort(rng.choice(A0.ncols, size=2500, replace=False)).astype(np.int32)
+        ent = np.insert(ent, rm[r + 1], extra); val = np.insert(val, rm[r + 1], rng.random(2500)); rm[r + 1:] += 2500
+    out.append(("5pt+long-rows", oracle.Crs(A0.nrows, A0.ncols, rm, ent, val), True))
     return out
