@@ -30,17 +30,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a plain copy reaches
+PMC_FILE = os.path.join(ROOT, "profiles", "round2", "bench_n1_pmc_hbm.json")
 
 
-def cpu_baseline(sample_n=160, min_seconds=6.0):
-    """Reference host path (port) on a bounded sample: 27-pt FE Laplacian sample_n^3, all host cores."""
+def kernel_source_sha():
+    """sha256 over the kernel sources (csrc/*.hip, *.h): stamps every committed counter file, so that bench.py can tell
+    whether the traffic figure it quotes was measured on the code it is running (.git does not travel to the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kokkos-kernels_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+
+def cpu_baseline(sample_n=300, min_seconds=6.0):
+    """Reference host path (port) on the workload's own matrix (27-pt FE Laplacian 300^3; a 160^3 sample only if the host
+    cannot hold it), all usable host cores, about ten seconds of SpMVs."""
     # thread placement Kokkos recommends for its OpenMP backend; must be set before the OpenMP runtime starts
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "threads")
     import numpy as np
     import oracle
     oracle.set_omp_threads(oracle.usable_cpus())     # the cgroup CPU quota, not the visible core count (see usable_cpus)
-    A = oracle.laplace3d("FE", sample_n, sample_n, sample_n)
+    try:
+        A = oracle.laplace3d("FE", sample_n, sample_n, sample_n)
+        note = "the full workload matrix"
+    except MemoryError:
+        sample_n = 160
+        A = oracle.laplace3d("FE", sample_n, sample_n, sample_n)
+        note = "FALLBACK sample (the host could not hold 300^3)"
     ft = oracle.first_touch          # pages spread over NUMA nodes the way a Kokkos::View's would be
     rm32 = ft(A.row_map.astype(np.int32)); ent = ft(A.entries); val = ft(A.values)
     rng = np.random.default_rng(17312837)
@@ -57,8 +78,8 @@ def cpu_baseline(sample_n=160, min_seconds=6.0):
     gflops = 2.0 * A.nnz * it / el / 1e9
     gbps = (A.nnz * 12 + (A.nrows + 1) * 4 + A.ncols * 8 + A.nrows * 8) * it / el / 1e9
     return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": oracle.omp_threads(), "kind": "port",
-            "sample": "27-pt FE Laplacian %d^3 (%d rows, %d nnz), fp64, OpenMP dynamic schedule (nnz > 1e7), %d iterations, %.1f algorithmic GB/s"
-                      % (sample_n, A.nrows, A.nnz, it, gbps)}
+            "sample": "%s: 27-pt FE Laplacian %d^3 (%d rows, %d nnz), fp64, OpenMP dynamic schedule (nnz > 1e7), %d iterations, %.1f algorithmic GB/s"
+                      % (note, sample_n, A.nrows, A.nnz, it, gbps)}
 
 
 def main():
@@ -220,31 +241,41 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         # What the plan really streams: the analysis replaces the 4-byte column indices by 16-bit codes or, on locally
-        # Toeplitz tiles, by one small record per tile; "achieved" stays on the CRS algorithmic bytes.
+        # Toeplitz tiles, by one small record per tile; "achieved" / "frac" stay on the CRS algorithmic bytes.
         try:
             h_ = handle if world == 1 else op.handle
             if h_.query("window_codes"):
                 tile_ = h_.query("tile"); tiles_ = h_.query("tiles")
-                pat_ = h_.query("pattern_tiles")
-                # tiles decoded from a row-pattern record read no per-nonzero column information at all (1184 B per tile instead)
-                streamed_ = alg_bytes - nnz_local * 4 + tiles_ * 256 + (tiles_ - pat_) * tile_ * 2 + pat_ * 1184
-                out["roofline"]["plan"] = {"column_codes": ("row-pattern records on %d of %d tiles, 16-bit window codes on the rest" % (pat_, tiles_))
-                                                           if pat_ else "16-bit window codes",
+                pat_, code_, plain_ = h_.query("pattern_tiles"), h_.query("code_tiles"), h_.query("plain_tiles")
+                # per tile: 4 B mode word; 256 B window meta unless plain; 2 B per nonzero of code tiles; 672 B record of pattern
+                # tiles; plain tiles read their 4-byte columns
+                streamed_ = (alg_bytes - nnz_local * 4 + tiles_ * 4 + (tiles_ - plain_) * 256 + code_ * tile_ * 2 + pat_ * 672
+                             + plain_ * tile_ * 4)
+                out["roofline"]["plan"] = {"tiles": tiles_, "pattern_record_tiles": pat_, "code_tiles": code_, "plain_tiles": plain_,
                                            "x_staged_in_lds": bool(h_.query("window_staged_x")), "tile_nnz": tile_,
-                                           "streamed_bytes_per_launch": streamed_}
+                                           "plan_bytes": h_.query("plan_bytes"), "streamed_bytes_per_launch": streamed_}
         except Exception:
             pass
-        # HBM traffic comes from the committed rocprofv3 PMC passes of this same command (it cannot be counted live)
-        pmc = os.path.join(ROOT, "profiles", "round1", "bench_n1_pmc_hbm.json")
-        if world == 1 and not args.n and not args.knob and os.path.exists(pmc):
+        # Memory-side traffic comes from rocprofv3 PMC passes of this same command (it cannot be counted live); the file is
+        # stamped with the hash of the kernel sources it was measured on and is IGNORED when that differs from the sources here.
+        out["roofline"]["kernel_source_sha"] = kernel_source_sha()
+        if world == 1 and not args.n and not args.knob and os.path.exists(PMC_FILE):
             try:
-                d = json.load(open(pmc)); rd = wr = None
-                for k, v in d.items():
-                    if "spmv_stream3_kernel" in k and "FETCH_SIZE" in k: rd = v["mean_KB"] * 1024 * 2   # gfx950 x2 correction
-                    if "spmv_stream3_kernel" in k and "WRITE_SIZE" in k: wr = v["mean_KB"] * 1024
-                if rd and wr:
-                    out["roofline"]["traffic"] = int(rd + wr)
-                    out["roofline"]["traffic_source"] = "profiles/round1/bench_n1_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+                d = json.load(open(PMC_FILE))
+                if d.get("kernel_source_sha") != out["roofline"]["kernel_source_sha"]:
+                    out["roofline"]["traffic_source"] = ("%s is stale (measured on kernel sources %s): traffic not quoted"
+                                                         % (os.path.relpath(PMC_FILE, ROOT), d.get("kernel_source_sha")))
+                else:
+                    rd = wr = None
+                    for k, v in d.get("counters", {}).items():
+                        if "spmv_stream3_kernel" in k and "FETCH_SIZE" in k: rd = v["mean_KB"] * 1024 * 2   # gfx950 x2 correction
+                        if "spmv_stream3_kernel" in k and "WRITE_SIZE" in k: wr = v["mean_KB"] * 1024
+                    if rd and wr:
+                        out["roofline"]["traffic"] = int(rd + wr)
+                        # what actually crossed the memory side per second, against the same peak
+                        out["roofline"]["moved_frac"] = round((rd + wr) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                        out["roofline"]["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                                             "FETCH_SIZE x2 per MI355X_MICROARCH.md)" % os.path.relpath(PMC_FILE, ROOT))
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -68,6 +68,11 @@ typedef struct {
 
 const char* kkamd_last_error(void);
 int kkamd_version(void);
+/* Profiling ranges (roctx, shown by rocprofv3 --marker-trace): what Kokkos::Profiling::pushRegion / popRegion map to on the
+ * host side of the boundary.  The library's own entry points open ranges labelled like the reference's
+ * ("KokkosSparse::spmv[TPL_KKAMD,double]", sparse/tpls/KokkosSparse_spmv_tpl_spec_decl.hpp:411-414). */
+int kkamd_trace_push(const char* label);
+int kkamd_trace_pop(void);
 /* name of the device the library is running on and whether it is gfx950; used by tests. */
 int kkamd_device_info(char* name, int name_len, int* is_gfx950, int* num_cus);
 
@@ -84,7 +89,14 @@ int kkamd_device_info(char* name, int name_len, int* is_gfx950, int* num_cus);
 typedef struct kkamd_spmv_plan kkamd_spmv_plan_t;
 
 int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int algorithm, kkamd_stream_t stream);
+/* same, with this plan's expert knobs (see kkamd_spmv_plan_set) applied BEFORE the analysis they shape; the library-wide
+ * defaults are not touched. */
+int kkamd_spmv_plan_create_knobs(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int algorithm, const char* const* keys,
+                                 const int* values, int nknobs, kkamd_stream_t stream);
 int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan);
+/* Frees the calling host thread's scratch of the handle-less route (tile descriptors + carry slots, grown on demand and
+ * otherwise kept for the thread's life). */
+int kkamd_release_scratch(void);
 
 /* y := alpha*op(A)*x + beta*y.  mode 'N','C' (== 'N' for real scalars), 'T','H' (== 'T').
  * vector_type is the scalar type of x and y (and of alpha/beta, the reference's coefficient_type);

@@ -14,13 +14,18 @@ from ._capi import KkamdError  # noqa: F401
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 LIB_PATH = _os.path.join(_HERE, "libkkamd.so")
+# tools/ only: KKAMD_LIBRARY=libkkamd_ablate.so selects the measurement build (csrc: `make ablate`, -DKK_ABLATE), whose extra
+# knobs switch parts of the kernels off.  Tests, bench.py and the drop-in headers always use libkkamd.so.
+if _os.environ.get("KKAMD_LIBRARY"):
+    LIB_PATH = _os.path.join(_HERE, _os.path.basename(_os.environ["KKAMD_LIBRARY"]))
 _lib = None
 
 
-def build(verbose=False):
-    """Compile csrc/*.hip for gfx950 into libkkamd.so (hipcc cross-compiles without a GPU)."""
+def build(verbose=False, ablate=False):
+    """Compile csrc/*.hip for gfx950 into libkkamd.so (hipcc cross-compiles without a GPU); ablate=True also builds the
+    measurement library libkkamd_ablate.so."""
     import subprocess
-    cmd = ["make", "-C", _os.path.join(_HERE, "csrc"), "-j4"] + ([] if verbose else ["-s"])
+    cmd = ["make", "-C", _os.path.join(_HERE, "csrc"), "-j8"] + (["all", "ablate"] if ablate else []) + ([] if verbose else ["-s"])
     subprocess.check_call(cmd)
     return LIB_PATH
 

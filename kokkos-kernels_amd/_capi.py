@@ -8,7 +8,7 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_ALLOC, ERR_STATE = range(6)
 SPMV_DEFAULT, SPMV_FAST_SETUP, SPMV_NATIVE, SPMV_MERGE_PATH, SPMV_NATIVE_MERGE_PATH = range(5)
 
 EXPORTS = [
-    "kkamd_last_error", "kkamd_version", "kkamd_device_info", "kkamd_spmv_plan_create", "kkamd_spmv_plan_destroy",
+    "kkamd_last_error", "kkamd_version", "kkamd_device_info", "kkamd_trace_push", "kkamd_trace_pop", "kkamd_spmv_plan_create", "kkamd_spmv_plan_create_knobs", "kkamd_release_scratch", "kkamd_spmv_plan_destroy",
     "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_sort_and_merge", "kkamd_transpose", "kkamd_spmv_plan_set", "kkamd_spmv_plan_query", "kkamd_set_default", "kkamd_spgemm_create",
     "kkamd_spgemm_destroy", "kkamd_spgemm_symbolic", "kkamd_spgemm_numeric", "kkamd_spgemm_get", "kkamd_sort_crs",
     "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows", "kkamd_bench_read",
@@ -34,7 +34,11 @@ def bind(lib):
     lib.kkamd_last_error.restype = C.c_char_p
     lib.kkamd_version.restype = ci
     lib.kkamd_device_info.argtypes = [C.c_char_p, ci, C.POINTER(ci), C.POINTER(ci)]
+    lib.kkamd_trace_push.argtypes = [C.c_char_p]
+    lib.kkamd_trace_pop.argtypes = []
     lib.kkamd_spmv_plan_create.argtypes = [C.POINTER(vp), C.POINTER(CrsDesc), ci, vp]
+    lib.kkamd_spmv_plan_create_knobs.argtypes = [C.POINTER(vp), C.POINTER(CrsDesc), ci, C.POINTER(C.c_char_p), C.POINTER(ci), ci, vp]
+    lib.kkamd_release_scratch.argtypes = []
     lib.kkamd_spmv_plan_destroy.argtypes = [vp]
     lib.kkamd_spmv.argtypes = [vp, C.POINTER(CrsDesc), C.c_char, dbl, vp, dbl, vp, ci, vp]
     lib.kkamd_spmv_mv.argtypes = [vp, C.POINTER(CrsDesc), C.c_char, dbl, vp, i64, i64, dbl, vp, i64, i64, i64, ci, vp]

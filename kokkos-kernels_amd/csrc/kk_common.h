@@ -63,6 +63,21 @@ template <class T> __device__ __forceinline__ T group_sum(T v, int width) {
   return v;
 }
 
+// Profiling ranges with the reference's label strings (Kokkos::Profiling::pushRegion at sparse/src/KokkosSparse_spmv.hpp:261-266,
+// sparse/tpls/KokkosSparse_spmv_tpl_spec_decl.hpp:411-414, ...spgemm_symbolic_tpl_spec_decl.hpp:343-344): emitted as roctx
+// ranges, so rocprofv3 --marker-trace shows "KokkosSparse::spmv[TPL_KKAMD,double]" around the kernels.  libroctx64 is
+// looked up at run time; without it the ranges cost one predictable branch.
+void trace_push(const char* label);
+void trace_pop();
+struct TraceRange {
+  explicit TraceRange(const char* label) { trace_push(label); }
+  ~TraceRange() { trace_pop(); }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
+// KokkosKernelsHandle::set_verbose / KOKKOSKERNELS_VERBOSE: what was chosen (kernels, bins, tile modes) and phase times, on stdout
+extern int g_verbose;
+
 // argument checks shared by the SpMV entry points (kk_spmv.hip)
 int check_crs(const kkamd_crs_t* A);
 int parse_mode(char mode, bool* trans);

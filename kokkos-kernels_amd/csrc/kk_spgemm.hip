@@ -40,6 +40,18 @@
 #include <string>
 #include <type_traits>
 
+// Measurement build (-DKK_ABLATE, tools/ only): ablation bits reach the dense-row kernels through an extra argument; in the
+// product build the argument does not exist and every KK_DBG(bit) folds to false.
+#ifdef KK_ABLATE
+#define KK_DBG_PARAM , int debug
+#define KK_DBG_ARG , g_spgemm.debug
+#define KK_DBG(bit) ((debug & (bit)) != 0)
+#else
+#define KK_DBG_PARAM
+#define KK_DBG_ARG
+#define KK_DBG(bit) false
+#endif
+
 #ifdef KK_EMU
 #define KK_ATOMIC_FADD(p, v) atomicAdd((p), (v))
 #define KK_LOAD_L2(p) (*(p))
@@ -69,7 +81,9 @@ struct SpgemmTuning {
   int win_bits       = 1 << 20;   // columns per LDS bitmap window (128 KB); rows wider than this take several passes
   int val_cap        = kValCap;   // C entries per value window
   int force_unsorted = 0;         // test hook: treat B as unsorted (dense rows accumulate in HBM)
-  int debug          = 0;         // bench-only ablation bits for the dense-row kernels
+#ifdef KK_ABLATE
+  int debug          = 0;         // measurement build only: ablation bits for the dense-row kernels
+#endif
   int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
 };
@@ -471,7 +485,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
                                                                         const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
                                                                         OffT* __restrict__ counts, const OffT* __restrict__ rmC,
                                                                         int32_t* __restrict__ entC, int64_t k, int win_bits,
-                                                                        int sg_log2, int debug) {
+                                                                        int sg_log2 KK_DBG_PARAM) {
   KK_DYN_SMEM(kk_u64, bm);
   __shared__ int s_min, s_max;
   __shared__ int s_wave[kDenseBlock / 64];
@@ -487,22 +501,22 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
     if (t == 0) { s_min = INT_MAX; s_max = -1; }
     __syncthreads();
     int cmin = INT_MAX, cmax = -1;
-    if (!(debug & 2)) flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int cb) {
+    if (!KK_DBG(2)) flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int cb) {
       const int64_t c64 = (int64_t)cb - c0;
       if (c64 >= 0 && c64 < nbits) {
         const int c = (int)c64;
-        if (!(debug & 256)) atomicOr(&bm[c >> 6], 1ull << (c & 63));
+        if (!KK_DBG(256)) atomicOr(&bm[c >> 6], 1ull << (c & 63));
         cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
       }
     });
     if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
     __syncthreads();
-    if (s_max >= 0 && !(debug & 4)) {
+    if (s_max >= 0 && !KK_DBG(4)) {
       const int w_lo = s_min >> 6, w_hi = s_max >> 6, nw = w_hi - w_lo + 1;
       // sparse bitmaps (fewer than 4 columns per touched word on average; always when only counting): every
       // work-item takes one contiguous run of words -- one workgroup scan per window instead of one per 1024 words.
       // Dense bitmaps keep the interleaved walk, whose stores to entries(C) coalesce.
-      const bool chunked = !EMIT || (debug & 128) || (int64_t)rmC[row + 1] - (int64_t)rmC[row] < 4 * (int64_t)nw;
+      const bool chunked = !EMIT || KK_DBG(128) || (int64_t)rmC[row + 1] - (int64_t)rmC[row] < 4 * (int64_t)nw;
       if (chunked) {
         const int per = (nw + kDenseBlock - 1) / kDenseBlock;
         const int a = w_lo + t * per, z = (a + per <= w_hi + 1) ? a + per : w_hi + 1;
@@ -510,7 +524,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
         for (int wd = a; wd < z; ++wd) cnt += __popcll(bm[wd]);
         int tot;
         const int excl = block_exclusive_scan_n<int, kDenseBlock>(cnt, &tot, s_wave);
-        if (EMIT && !(debug & 1)) {
+        if (EMIT && !KK_DBG(1)) {
           int64_t pos = (int64_t)rmC[row] + total + excl;
           for (int wd = a; wd < z; ++wd) {
             kk_u64 v = bm[wd];
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
           kk_u64 v     = (wd <= w_hi) ? bm[wd] : 0ull;
           int tot;
           const int excl = block_exclusive_scan_n<int, kDenseBlock>(__popcll(v), &tot, s_wave);
-          if (EMIT && !(debug & 1)) {
+          if (EMIT && !KK_DBG(1)) {
             int64_t pos = (int64_t)rmC[row] + total + excl;
             while (v) {
               const int bit = __ffsll(v) - 1;
@@ -718,7 +732,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
                                                                       const VT* __restrict__ valA, const OffT* __restrict__ rmB,
                                                                       const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                       const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
-                                                                      VT* __restrict__ valC, int cap, int debug) {
+                                                                      VT* __restrict__ valC, int cap KK_DBG_PARAM) {
   __shared__ int hk[H];
   __shared__ VT hv[H];
   __shared__ long long s_cur[kValLa];
@@ -756,7 +770,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
     KK_UNROLL
     for (int u = 0; u < UL; ++u) {
       const int idx = u * 64 + lane;
-      const bool ok = idx < rem && !(debug & 1024);
+      const bool ok = idx < rem && !KK_DBG(1024);
       c[u] = ok ? entB[p + idx] : INT_MAX;
       v[u] = ok ? valB[p + idx] : VT(0);
     }
@@ -766,7 +780,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
     KK_UNROLL
     for (int u = 0; u < UL; ++u) {
       const bool in = c[u] <= whi;
-      if (in && !(debug & 512)) accumulate(c[u], av * v[u]);
+      if (in && !KK_DBG(512)) accumulate(c[u], av * v[u]);
       nin += __popcll(__ballot(in));
     }
     return nin;
@@ -796,7 +810,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
     const int whi    = s_whi;
     const bool last = done + n >= cnt;
     // long B rows: one wave per A entry, EL entries in flight per wave
-    if (!(debug & 32)) for (int64_t a = wave; a < la_c; a += EL * NW) {
+    if (!KK_DBG(32)) for (int64_t a = wave; a < la_c; a += EL * NW) {
       bool ok[EL];
       int64_t p[EL];
       int rem[EL];
@@ -829,7 +843,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
       if (have) { p = s_cur[a]; rem = s_rem[a]; av = s_av[a]; }
     };
     fetch();
-    if (debug & 64) have = false;
+    if (KK_DBG(64)) have = false;
     while (true) {
       int c[US];
       VT v[US];
@@ -1054,7 +1068,7 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
   KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,
-            rmC, entC, k, (int)win, sg, g_spgemm.debug);
+            rmC, entC, k, (int)win, sg KK_DBG_ARG);
   return KKAMD_OK;
 }
 
@@ -1185,7 +1199,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   do {                                                                                                                \
     if (cap > HH / 2) cap = HH / 2;                                                                                   \
     KK_LAUNCH((spgemm_dense_vals_kernel<OffT, VT, HH, NTT>), (unsigned)n_lds, NTT, 0, st, dperm, rmA, entA, valA, rmB, \
-              entB, valB, rmC, (const int32_t*)entC, valC, cap, g_spgemm.debug);                                      \
+              entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);                                      \
   } while (0)
       switch (g_spgemm.val_shape) {
         case 1: KK_VALS(8192, 1024); break;
@@ -1242,7 +1256,9 @@ int spgemm_set_default(const char* key, int value) {
     if (value < 64 || value > 4096) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_cap must be in [64, 4096]");
     g_spgemm.val_cap = value;
   } else if (k == "spgemm_force_unsorted") g_spgemm.force_unsorted = value != 0;
+#ifdef KK_ABLATE
   else if (k == "spgemm_debug") g_spgemm.debug = value;
+#endif
   else if (k == "spgemm_val_shape") g_spgemm.val_shape = value;
   else if (k == "spgemm_val_la") g_spgemm.val_la = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "kkamd_set_default: unknown key '%s'", k.c_str());

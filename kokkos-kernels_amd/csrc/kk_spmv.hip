@@ -1051,6 +1051,8 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "stream_variant") { if (value != 1 && value != 6) return bad("1 or 6"); t.stream_variant = value; }
   else if (k == "mv_remap") { if (!valid_order_knob(value)) return bad("0, 1 or a power of two"); t.mv_remap = value; }
   else if (k == "mv_order") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv_order = value; }
+  else if (k == "mv_strip_min_kb") { if (value < 0) return bad("non-negative"); t.mv_strip_min_kb = value; }
+  else if (k == "mv_strip_l2_kb") { if (value < 1) return bad("positive"); t.mv_strip_l2_kb = value; }
   else if (k == "mv_inner") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv_inner = value; }
   else if (k == "window_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.window_codes = value; }
   else if (k == "window_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.window_codes_min_knnz = value; }
@@ -1211,6 +1213,33 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
 }
 
 SpmvTuning g_spmv_default;
+int g_verbose = 0;
+
+#ifdef KK_EMU
+void trace_push(const char*) {}
+void trace_pop() {}
+#else
+}  // namespace kk
+#include <dlfcn.h>
+namespace kk {
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)()             = nullptr;
+  Roctx() {
+    void* h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop  = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void trace_push(const char* label) { Roctx& r = roctx(); if (r.push) (void)r.push(label); }
+void trace_pop() { Roctx& r = roctx(); if (r.pop) (void)r.pop(); }
+#endif
 
 }  // namespace kk
 
@@ -1231,7 +1260,11 @@ int kkamd_device_info(char* name, int name_len, int* is_gfx950, int* num_cus) {
   return KKAMD_OK;
 }
 
+int kkamd_trace_push(const char* label) { if (!label) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_trace_push: null label"); kk::trace_push(label); return KKAMD_OK; }
+int kkamd_trace_pop(void) { kk::trace_pop(); return KKAMD_OK; }
+
 int kkamd_set_default(const char* key, int value) {
+  if (key && std::strcmp(key, "verbose") == 0) { kk::g_verbose = value != 0; return KKAMD_OK; }
   if (key && std::strncmp(key, "spgemm_", 7) == 0) return kk::spgemm_set_default(key, value);
   if (key && std::strcmp(key, "struct_remap") == 0) {
     if (value != 0 && value != 1) return kk::fail(KKAMD_ERR_INVALID_ARG, "struct_remap: %d is not 0 or 1", value);
@@ -1252,6 +1285,11 @@ int kkamd_set_default(const char* key, int value) {
 }
 
 int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int algorithm, kkamd_stream_t stream) {
+  return kkamd_spmv_plan_create_knobs(plan, A, algorithm, nullptr, nullptr, 0, stream);
+}
+
+int kkamd_spmv_plan_create_knobs(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int algorithm, const char* const* keys,
+                                 const int* values, int nknobs, kkamd_stream_t stream) {
   if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_create: null output pointer");
   *plan = nullptr;
   int rc = kk::check_crs(A);
@@ -1263,6 +1301,10 @@ int kkamd_spmv_plan_create(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A, int a
   p->num_rows = A->num_rows; p->num_cols = A->num_cols; p->nnz = A->nnz; p->row_map = A->d_row_map;
   p->entries = A->d_entries;
   p->offset_type = A->offset_type; p->value_type = A->value_type; p->algorithm = algorithm; p->tune = kk::g_spmv_default;
+  for (int i = 0; i < nknobs; ++i) {                           // this plan's knobs, applied before the analysis they shape
+    if (!keys || !values) { delete p; return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_create_knobs: null knob arrays"); }
+    if ((rc = kk::set_tuning(p->tune, keys[i], values[i]))) { delete p; return rc; }
+  }
   {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1309,7 +1351,7 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
     return kk::build_analysis(plan, &A, plan->last_stream);
   }
-  if (t.mv_order != old.mv_order && plan->mv) { kk::mv_plan_destroy(plan->mv); plan->mv = nullptr; plan->mv_failed = false; }
+  if ((t.mv_order != old.mv_order || t.mv_strip_min_kb != old.mv_strip_min_kb || t.mv_strip_l2_kb != old.mv_strip_l2_kb) && plan->mv) { kk::mv_plan_destroy(plan->mv); plan->mv = nullptr; plan->mv_failed = false; }
   return KKAMD_OK;
 }
 
@@ -1327,7 +1369,7 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "plan_bytes") *value = (int64_t)plan->plan_bytes;
   else if (k == "transpose_cached") *value = plan->t_ready ? 1 : 0;
   else if (k == "mv_tiles") *value = kk::mv_plan_query(plan->mv, 0);
-  else if (k == "mv_pattern_tiles") *value = kk::mv_plan_query(plan->mv, 1);
+  else if (k == "mv_staged_tiles") *value = kk::mv_plan_query(plan->mv, 1);
   else if (k == "mv_order") *value = kk::mv_plan_query(plan->mv, 2);
   else if (k == "mv_plan_bytes") *value = kk::mv_plan_query(plan->mv, 3);
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
@@ -1357,6 +1399,7 @@ int kkamd_spmv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double 
   }
   if (xlen > 0 && !d_x) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv: null x");
   if ((rc = kk::bind_stream(plan, st))) return rc;
+  kk::TraceRange range(A->value_type == KKAMD_F64 ? "KokkosSparse::spmv[TPL_KKAMD,double]" : "KokkosSparse::spmv[TPL_KKAMD,float]");
   KK_DISPATCH_TYPES(kk::spmv_typed, plan, A, trans, alpha, d_x, beta, d_y, st);
 }
 

@@ -570,9 +570,9 @@ static int64_t mv_detect_period(const kkamd_mv_plan* mv, int64_t nrows, hipStrea
 // neighbour and once per XCD.  Here every XCD instead owns STRIPS of W consecutive rows of every period and walks a strip
 // period after period: the three periods' worth of X rows a strip needs (3 W rows) stay in its L2, and an X row crosses the
 // fabric about once.  order[8 i + x] = i-th tile of XCD x (workgroup b runs on XCD b % 8).
-static int mv_build_strip_order(kkamd_mv_plan* mv, int64_t period, int rowbytes, hipStream_t st) {
+static int mv_build_strip_order(kkamd_mv_plan* mv, int64_t period, int rowbytes, int l2_kb, hipStream_t st) {
   const int64_t nt = mv->ntiles, rb = mv->rb;
-  const double l2_rows = 2.5e6 / (3.0 * (double)rowbytes);                 // rows of X per period a strip may keep in a 4 MB L2
+  const double l2_rows = 1e3 * (double)l2_kb / (3.0 * (double)rowbytes);   // rows of X per period a strip may keep in a 4 MB L2
   int64_t nstrips = (int64_t)((double)period / l2_rows) + 1;
   nstrips = (nstrips + kNumXcd - 1) / kNumXcd * kNumXcd;
   const int64_t width = (period + nstrips - 1) / nstrips;                 // rows per strip
@@ -622,7 +622,8 @@ static int mv_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, int nv, hi
   if (plan->tune.mv_order == 2) {
     mv->period = mv_detect_period(mv, A->num_rows, st);
     // worth it when a period's worth of X rows overflows an L2 (4 MB per XCD)
-    if (mv->period > 0 && (double)mv->period * rowbytes * 3.0 > 3.0e6 && mv_build_strip_order(mv, mv->period, rowbytes, st) == KKAMD_OK) mv->order_used = 2;
+    if (mv->period > 0 && (double)mv->period * rowbytes * 3.0 > 1e3 * (double)plan->tune.mv_strip_min_kb &&
+        mv_build_strip_order(mv, mv->period, rowbytes, plan->tune.mv_strip_l2_kb, st) == KKAMD_OK) mv->order_used = 2;
     (void)hipGetLastError();
   }
   plan->mv = mv;
@@ -766,6 +767,7 @@ int kkamd_spmv_mv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, doub
   }
   if (!d_X) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: null X");
   if ((rc = kk::bind_stream(plan, st))) return rc;
+  kk::TraceRange range(A->value_type == KKAMD_F64 ? "KokkosSparse::spmv[TPL_KKAMD,double]" : "KokkosSparse::spmv[TPL_KKAMD,float]");
   // one contiguous column: the rank-1 path (sparse/src/KokkosSparse_spmv.hpp:203-217)
   if (nvec == 1 && x_stride0 == 1 && y_stride0 == 1) return kkamd_spmv(plan, A, mode, alpha, d_X, beta, d_Y, vector_type, stream);
   KK_DISPATCH_TYPES(kk::spmv_mv_typed, plan, A, trans, alpha, d_X, x_stride0, x_stride1, beta, d_Y, y_stride0,

@@ -17,6 +17,8 @@ struct SpmvTuning {
   int stream_variant = 1;  // 1 default; 6 = attempt the window codes whatever the matrix size (tests)
   int mv_remap       = 16; // rank-2 wave-private kernel: 0 dispatch order, 1 XCD-contiguous, 2^k grouped (16: 5.60 -> 4.76 ms on C3)
   int mv_order       = 2;  // rank-2 LDS-staged kernel, tile order: 0 dispatch, 1 XCD-contiguous, 2 strips from the detected grid strides (falls back to 1)
+  int mv_strip_min_kb = 3000;  // ... strips engage when three periods' worth of X rows exceed this (an XCD's L2 holds 4 MB)
+  int mv_strip_l2_kb  = 2500;  // ... and are sized so that three periods' worth of a strip's X rows stay below this
   int mv_inner       = 0;  // rank-2 LDS-staged kernel, contraction: 0 auto, 1 VALU, 2 MFMA (v_mfma_f64_4x4x4 on row-pattern tiles)
   int explicit_transpose = 0;   // modes T/H with an analysed handle: 1 = cache A^T (structure + permutation) in the plan, refresh its
                                 // values every call and run the N kernel on it; 2 = same, the caller promises constant values (no refresh)

@@ -67,7 +67,12 @@ void spmv(const ExecutionSpace& space, Handle* handle, const char mode[], const 
   kkamd_stream_t stream = reinterpret_cast<kkamd_stream_t>(space.hip_stream());
   // lazily create the per-matrix plan (the reference's tpl_rank1/2); SPMV_FAST_SETUP never analyses
   if (!h->plan && h->get_algorithm() != SPMV_FAST_SETUP && A.nnz() > 0 && mode[0] != Transpose[0] && mode[0] != ConjugateTranspose[0])
-    Impl::kkamd_check(kkamd_spmv_plan_create(&h->plan, &desc, (int)h->get_algorithm(), stream));
+  {
+    std::vector<const char*> keys; std::vector<int> vals;
+    for (auto& kv : h->pending_) { keys.push_back(kv.first.c_str()); vals.push_back(kv.second); }
+    if (h->vector_length > 0) { keys.push_back("lanes_per_row"); vals.push_back(h->vector_length); }
+    Impl::kkamd_check(kkamd_spmv_plan_create_knobs(&h->plan, &desc, (int)h->get_algorithm(), keys.data(), vals.data(), (int)keys.size(), stream));
+  }
   constexpr int vt = Impl::kkamd_scalar<typename YVector::non_const_value_type>::value;
   Kokkos::Profiling::pushRegion("KokkosSparse::spmv[KKAMD]");
   if constexpr (XVector::rank() == 1) {

@@ -45,10 +45,17 @@ struct SPMVHandleImpl {
   SPMVAlgorithm get_algorithm() const { return algo; }
   const SPMVAlgorithm algo = SPMV_DEFAULT;
   kkamd_spmv_plan_t* plan  = nullptr;     // the reference's tpl_rank1 / tpl_rank2
-  // expert knobs the reference exposes as public members (:243-252); mapped onto plan knobs where meaningful
-  int team_size = -1, vector_length = -1;
-  int64_t rows_per_thread     = -1;
-  bool force_static_schedule  = false, force_dynamic_schedule = false;
+  // Expert knobs.  Of the reference's public members (:243-252) only vector_length has a meaning here: lanes per row of the
+  // no-analysis row kernel (knob "lanes_per_row"; -1 = automatic from nnz / row, like the reference).  team_size,
+  // rows_per_thread and force_static/dynamic_schedule describe Kokkos TeamPolicy / RangePolicy launches that do not exist
+  // in this implementation, so they are NOT declared: code that sets them fails to compile instead of being ignored.
+  int vector_length = -1;
+  // any plan knob of include/kkamd.h by name (applied when the plan is created, or to the live plan)
+  void set_knob(const char* key, int value) {
+    if (plan) KokkosSparse::Impl::kkamd_check(kkamd_spmv_plan_set(plan, key, value));
+    else pending_.emplace_back(key, value);
+  }
+  std::vector<std::pair<std::string, int>> pending_;
 };
 }  // namespace Impl
 

@@ -8,6 +8,7 @@
 // LayoutLeft / LayoutRight, managed (reference counted) and Unmanaged memory, const conversion.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include "../../include/kkamd.h"
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -75,8 +76,9 @@ inline void finalize() {}
 inline void fence(const std::string& = std::string()) { (void)hipDeviceSynchronize(); }
 
 namespace Profiling {
-inline void pushRegion(const std::string&) {}
-inline void popRegion() {}
+// roctx ranges through the library (rocprofv3 --marker-trace shows them like a Kokkos Tools connector would)
+inline void pushRegion(const std::string& label) { (void)kkamd_trace_push(label.c_str()); }
+inline void popRegion() { (void)kkamd_trace_pop(); }
 }  // namespace Profiling
 
 namespace Impl {

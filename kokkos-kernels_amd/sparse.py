@@ -104,7 +104,6 @@ class CrsMatrix:
                 None if self.values is None else be.to_numpy(self.values))
 
 
-_PRE_KNOBS = {"kernel": 0, "nnz_per_thread": 0, "stream_variant": 1, "window_codes": 1, "window_codes_min_knnz": 1000, "pattern_codes": 1, "pattern_codes_min_knnz": 10000}   # knob -> library default
 _ALGOS = {"SPMV_DEFAULT": 0, "SPMV_FAST_SETUP": 1, "SPMV_NATIVE": 2, "SPMV_MERGE_PATH": 3, "SPMV_NATIVE_MERGE_PATH": 4}
 
 
@@ -140,21 +139,13 @@ class SPMVHandle:
         if self._plan is None:
             self.backend = A.backend
             lib = A.backend.lib
-            for k in _PRE_KNOBS:   # analysis-shaping knobs must precede the analysis
-                if k in self._pending:
-                    check(lib, lib.kkamd_set_default(k.encode(), int(self._pending[k])))
             p = C.c_void_p()
             d = A.desc()
-            try:
-                check(lib, lib.kkamd_spmv_plan_create(C.byref(p), C.byref(d), _ALGOS[self.algo], A.backend.stream()))
-            finally:
-                for k in _PRE_KNOBS:
-                    if k in self._pending:
-                        lib.kkamd_set_default(k.encode(), _PRE_KNOBS[k])
+            n = len(self._pending)                 # the handle's knobs go in with the creation: they shape the analysis
+            keys = (C.c_char_p * max(n, 1))(*[k.encode() for k in self._pending])
+            vals = (C.c_int * max(n, 1))(*[int(v) for v in self._pending.values()])
+            check(lib, lib.kkamd_spmv_plan_create_knobs(C.byref(p), C.byref(d), _ALGOS[self.algo], keys, vals, n, A.backend.stream()))
             self._plan = p
-            for k, v in self._pending.items():
-                if k not in _PRE_KNOBS:
-                    check(lib, lib.kkamd_spmv_plan_set(p, k.encode(), int(v)))
         return self._plan
 
     def __del__(self):

@@ -132,10 +132,14 @@ def test_mv3_lds_staged(be):
                                           (16, "F", "F", 2.0, 0.0), (16, "F", "C", 1.0, -1.0)):
             h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", knobs={"mv_kernel": 3}, max_val=32.0,
                                  nans=(beta == 0.0))
-            assert (h.query("mv_pattern_tiles") > 0) == staged, (name, nvec, h.query("mv_pattern_tiles"), h.query("mv_tiles"))
+            assert (h.query("mv_staged_tiles") > 0) == staged, (name, nvec, h.query("mv_staged_tiles"), h.query("mv_tiles"))
     A0 = oracle.laplace3d("FE", 37, 11, 9)
     for order in (0, 1, 2):
         pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 3, "mv_order": order}, max_val=32.0, nans=True)
+    # strip order (every XCD walks strips of the grid plane after plane): thresholds lowered so that a small grid engages it
+    A0 = oracle.laplace3d("FE", 130, 10, 6)
+    h = pc.check_spmv_mv(be, A0, 16, "N", 1.5, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
+                         knobs={"mv_kernel": 3, "mv_order": 2, "mv_strip_min_kb": 100, "mv_strip_l2_kb": 64}, expect={"mv_order": 2})
     # below the size threshold the automatic choice stays with the wave-private kernel; odd widths never take the staged kernel
     pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, expect={"mv_tiles": 0})
     pc.check_spmv_mv(be, A0, 12, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 3}, max_val=32.0, expect={"mv_tiles": 0})

@@ -1,0 +1,165 @@
+"""Parity at the sizes that are BENCHMARKED (BASELINE.json configs 2-4 and the unstructured matrices of the plan table):
+the default-knob paths -- exactly what bench.py / tools/run_configs.py time -- compared directly with the CPU oracle on the
+same inputs, with the reference's own comparators (sparse/unit_test/Test_Sparse_spmv.hpp:67-104,181;
+sparse/unit_test/Test_Sparse_Utils.hpp:39-127).  The matrices are generated on the device (generator parity with the
+oracle / the reference's generator is pinned at smaller sizes in test_gpu_parity.py and test_oracle.py) and copied to the
+host for the oracle, so both sides see the same arrays.  KK_SKIP_HEAVY=1 skips this file (iteration runs only)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import parity_cases as pc
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("KK_SKIP_HEAVY") == "1", reason="KK_SKIP_HEAVY=1")]
+
+EPS = float(np.finfo(np.float64).eps)
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    assert torch.cuda.is_available(), "GPU parity tests need the MI355X"
+    oracle.set_omp_threads(oracle.usable_cpus())
+    return pc.kk.torch_backend()
+
+
+@pytest.fixture(scope="module")
+def c2(be):
+    """27-pt FE Laplacian 300^3 on the device + its host copy for the oracle"""
+    n = 300
+    A = pc.kk.laplace_matrix("FE", n, n, n)
+    assert A.nnz() == 724_150_792 and A.numRows() == 27_000_000
+    rm, ent, val = A.to_host()
+    return A, oracle.Crs(A.numRows(), A.numCols(), rm.astype(np.int64), ent, val), rm
+
+
+def _fspmv(exp, got, tol, what):
+    nanmis = np.isnan(exp) ^ np.isnan(got)
+    assert not nanmis.any(), "%s: NaN mismatch in %d places" % (what, int(nanmis.sum()))
+    err = float(np.nanmax(np.abs(exp - got)))
+    assert err <= tol, "%s: max |expected - y| = %g > %g" % (what, err, tol)
+    return err
+
+
+def test_c2_default_plan_against_oracle(be, c2):
+    """BASELINE config 2, the path bench.py times: SPMVHandle(SPMV_DEFAULT), default knobs -> row-pattern records on >= 90 % of
+    the tiles; y compared with the Kokkos::Serial restatement (fSPMV bound), beta = 0 over a NaN-seeded y and beta = 1."""
+    import torch
+    A, A0, rm = c2
+    rng = np.random.default_rng(17312837)
+    x = rng.integers(-20, 20, size=A0.ncols).astype(np.float64)          # the perf driver's x (KokkosSparse_kk_spmv.cpp:95-99)
+    y0 = rng.integers(-20, 20, size=A0.nrows).astype(np.float64)
+    xd = torch.from_numpy(x).cuda()
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT")
+    for beta, seed_nan in ((0.0, True), (1.0, False)):
+        yh = y0.copy()
+        if seed_nan:
+            yh[::19] = np.nan
+        yd = torch.from_numpy(yh).cuda()
+        pc.kk.spmv(h, "N", 1.0, A, xd, beta, yd)
+        assert h.query("tile") == 4096 and h.query("window_staged_x") == 1
+        assert h.query("pattern_tiles") >= 0.9 * h.query("tiles"), (h.query("pattern_tiles"), h.query("tiles"))
+        exp = oracle.spmv_serial("N", A0, 1.0, x, beta, np.where(np.isnan(yh), 0.0, yh) if beta == 0.0 else yh.copy())
+        tol = 10 * EPS * (abs(beta) * 20.0 + 27 * 32.0 * 20.0)           # 10 eps (beta max_y + alpha max_nnz_row max_val max_x)
+        _fspmv(exp, yd.cpu().numpy(), tol, "C2 default plan beta=%g" % beta)
+    # the plan keeps less than a quarter of a byte per nonzero (tile descriptors, window meta, pattern records)
+    assert h.query("plan_bytes") <= 0.25 * A0.nnz, h.query("plan_bytes")
+    # handle-less route (no codes, plain nnz-split kernel) on the same inputs
+    yd = torch.full((A0.nrows,), float("nan"), dtype=torch.float64, device="cuda")
+    pc.kk.spmv("N", 1.0, A, xd, 0.0, yd)
+    _fspmv(oracle.spmv_serial("N", A0, 1.0, x, 0.0, np.zeros(A0.nrows)), yd.cpu().numpy(), 10 * EPS * 27 * 32.0 * 20.0, "C2 handle-less")
+
+
+@pytest.mark.parametrize("layout", ["right", "left"])
+def test_c3_all_columns_against_oracle(be, c2, layout):
+    """BASELINE config 3 (C2 x 16 right-hand sides), default knobs, LayoutRight and LayoutLeft: all 16 columns against the
+    OpenMP port of the host SpMV_MV functor (sparse/impl/KokkosSparse_spmv_impl.hpp:745-792)."""
+    import torch
+    A, A0, rm = c2
+    nv = 16
+    rng = np.random.default_rng(5)
+    X = rng.integers(-20, 20, size=(A0.ncols, nv)).astype(np.float64)
+    Y0 = np.full((A0.nrows, nv), np.nan)
+    if layout == "left":
+        Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda().t()
+        Yd = torch.from_numpy(np.ascontiguousarray(Y0.T)).cuda().t()
+    else:
+        Xd = torch.from_numpy(X).cuda(); Yd = torch.from_numpy(Y0).cuda()
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT")
+    pc.kk.spmv(h, "N", 1.0, A, Xd, 0.0, Yd)
+    assert h.query("mv_tiles") > 0 and h.query("mv_staged_tiles") >= 0.9 * h.query("mv_tiles")     # the LDS-staged kernel ran
+    exp = np.zeros((A0.nrows, nv))
+    oracle.spmv_mv_omp(rm.astype(np.int32), A0.entries, A0.values, 1.0, X, 0.0, exp)
+    tol = 10 * EPS * 27 * 32.0 * 20.0
+    _fspmv(exp, Yd.cpu().numpy(), tol, "C3 %s" % layout)
+    # beta = -1 on the row-major pair
+    if layout == "right":
+        Y1 = rng.integers(-20, 20, size=(A0.nrows, nv)).astype(np.float64)
+        Yd = torch.from_numpy(Y1).cuda()
+        pc.kk.spmv(h, "N", 2.0, A, Xd, -1.0, Yd)
+        exp = Y1.copy()
+        oracle.spmv_mv_omp(rm.astype(np.int32), A0.entries, A0.values, 2.0, X, -1.0, exp)
+        _fspmv(exp, Yd.cpu().numpy(), 10 * EPS * (20.0 + 2 * 27 * 32.0 * 20.0), "C3 right beta=-1")
+
+
+def _avail_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2**30
+    except Exception:
+        return 0.0
+
+
+def test_spgemm_rmat_against_oracle(be):
+    """BASELINE config 4 family: C = A*A on R-MAT (scale 18 when the host has the memory for the oracle's copy of C, else 17),
+    row_map and entries IDENTICAL to SPGEMM_DEBUG + sort, values to 1e-7 relative (Test_Sparse_Utils.hpp:86-119)."""
+    scale = 18 if _avail_gb() >= 90 else 17
+    R = oracle.rmat(scale, 16)
+    A = pc.dev(be, R, offset_dtype=np.int64)
+    Cd = pc.kk.spgemm(A, False, A, False)
+    rm, ent, val = Cd.to_host()
+    G = oracle.spgemm(R, R)
+    assert Cd.nnz() == G.nnz, (scale, Cd.nnz(), G.nnz)
+    assert np.array_equal(rm.astype(np.int64), G.row_map), "row_map differs"
+    assert np.array_equal(ent, G.entries), "entries differ"
+    worst = 0.0
+    for s in range(0, G.nnz, 1 << 26):                                     # chunked: no 10-GB temporaries
+        a = val[s:s + (1 << 26)]; b = G.values[s:s + (1 << 26)]
+        den = np.abs(a) + np.abs(b)
+        worst = max(worst, float((np.abs(a - b) / np.where(den > 0, den, 1.0)).max()))
+    assert worst <= 1e-7, "values differ: max rel %g" % worst
+    print("spgemm R-MAT scale %d: nnz(C) %d identical structure, max rel value error %.2e" % (scale, G.nnz, worst))
+
+
+def _check_unstructured(be, A0, name, expect_codes=None):
+    import torch
+    rng = np.random.default_rng(3)
+    x = rng.integers(-20, 20, size=A0.ncols).astype(np.float64)
+    A = pc.dev(be, A0)
+    xd = torch.from_numpy(x).cuda()
+    lens = np.diff(A0.row_map); longest = int(lens.max())
+    max_val = float(np.abs(A0.values).max())
+    exp = oracle.spmv_serial("N", A0, 1.0, x, 0.0, np.zeros(A0.nrows))
+    tol = 10 * EPS * longest * max_val * 20.0
+    for handle in (pc.kk.SPMVHandle("SPMV_DEFAULT"), None):
+        yd = torch.full((A0.nrows,), float("nan"), dtype=torch.float64, device="cuda")
+        args = ("N", 1.0, A, xd, 0.0, yd)
+        pc.kk.spmv(handle, *args) if handle is not None else pc.kk.spmv(*args)
+        _fspmv(exp, yd.cpu().numpy(), tol, "%s (%s)" % (name, "handle" if handle is not None else "handle-less"))
+        if handle is not None and expect_codes is not None:
+            assert bool(handle.query("window_codes")) == expect_codes, (name, handle.query("plain_tiles"), handle.query("tiles"))
+
+
+def test_unstructured_rmat_1e8(be):
+    """>= 1e8 nonzeros without structure: R-MAT scale 22, edge factor 32 (hub rows of 1e5 entries, no tile coverable)"""
+    R = oracle.rmat(22, 32)
+    assert R.nnz >= 100_000_000, R.nnz
+    _check_unstructured(be, R, "R-MAT s22 ef32", expect_codes=False)
+
+
+def test_unstructured_banded_1e8(be):
+    """1e7 rows x 12 random columns inside a band of +-20000: tiles are coverable by windows but share no row pattern"""
+    A0 = oracle.random_crs(10_000_000, 10_000_000, 12, variance=0, seed=11, bandwidth=20000, sorted_rows=True)
+    _check_unstructured(be, A0, "banded random 1e7 x 12", expect_codes=True)

@@ -107,6 +107,68 @@ def test_pattern_codes(be):
                                                                        "pattern_codes_min_knnz": 0}, max_val=32.0, expect={"pattern_tiles": 0})
 
 
+def test_mixed_tiles(be):
+    # the column analysis is per tile: tiles the windows cannot cover read entries, the others keep codes / staged x / records
+    for name, A0 in pc.mixed_tile_cases():
+        for npt in (4, 8, 16):
+            for pat in (0, 2):
+                kn = {"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": pat, "window_codes_min_pct": 10}
+                h = pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=32.0, expect={"window_codes": 1})
+                assert 0 < h.query("plain_tiles") < h.query("tiles"), (name, npt, h.query("plain_tiles"), h.query("tiles"))
+                pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs=kn, max_val=32.0, nans=True, offset_dtype=np.int64, value_dtype=np.float32)
+
+
+def test_knob_validation(be):
+    A0 = oracle.random_crs(3000, 3000, 9, seed=1)
+    A = pc.dev(be, A0)
+    x, y = be.from_numpy(np.ones(3000)), be.from_numpy(np.zeros(3000))
+    for key, val in (("xcd_remap", 3), ("xcd_remap", 6), ("mv_remap", 12), ("nnz_per_thread", 5), ("stream_variant", 2), ("ablate", 1),
+                     ("lds_pad_kb", 8), ("nontemporal", 1), ("kernel", 7)):
+        h = pc.kk.SPMVHandle("SPMV_DEFAULT"); h.set(key, val)
+        with pytest.raises(pc.kk.KkamdError):
+            pc.kk.spmv(h, "N", 1.0, A, x, 0.0, y)
+    with pytest.raises(pc.kk.KkamdError):
+        from kokkos_kernels_amd._capi import check
+        check(be.lib, be.lib.kkamd_set_default(b"spgemm_debug", 1))     # measurement-build knob: not in libkkamd.so
+
+
+def test_handle_stream_change(be):
+    # a handle used on a second stream: the plan's scratch (carries) is fenced on the old stream first
+    # (TPL_SpMV_Data::set_exec_space, sparse/src/KokkosSparse_spmv_handle.hpp:95-104)
+    import torch
+    A0 = oracle.laplace3d("FE", 50, 40, 30)
+    A = pc.dev(be, A0)
+    rng = np.random.default_rng(2)
+    xs = [rng.random(A0.ncols) for _ in range(4)]
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for i, x in enumerate(xs):
+        with torch.cuda.stream(streams[i % 2]):
+            xd = torch.from_numpy(x).cuda(); yd = torch.full((A0.nrows,), float("nan"), dtype=torch.float64, device="cuda")
+            pc.kk.spmv(h, "N", 1.0, A, xd, 0.0, yd)
+            outs.append((xd, yd))
+    torch.cuda.synchronize()
+    tol = oracle.spmv_max_error(A0, 1.0, 0.0, max_val=32.0)
+    for x, (xd, yd) in zip(xs, outs):
+        assert np.abs(yd.cpu().numpy() - oracle.spmv_serial("N", A0, 1.0, x, 0.0, np.zeros(A0.nrows))).max() <= tol
+
+
+def test_mv3_lds_staged(be):
+    # rank-2 kernel over LDS-staged X tiles: staged and gather tiles, 8 / 16 / 24 / 32 right-hand sides, both layouts, every tile order
+    for name, A0, staged in pc.mv3_cases():
+        for nvec, xo, yo, alpha, beta in ((16, "C", "C", 1.5, 0.5), (8, "C", "C", 1.0, 0.0), (32, "C", "C", -1.0, 0.0), (24, "C", "F", 1.0, 1.0),
+                                          (16, "F", "F", 2.0, 0.0), (16, "F", "C", 1.0, -1.0)):
+            h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", knobs={"mv_kernel": 3}, max_val=32.0,
+                                 nans=(beta == 0.0))
+            assert (h.query("mv_staged_tiles") > 0) == staged, (name, nvec, h.query("mv_staged_tiles"), h.query("mv_tiles"))
+    # a grid large enough for the strip order to engage (far stride 160 * 120 rows * 128 B * 3 > 3 MB)
+    A0 = oracle.laplace3d("FE", 160, 120, 12)
+    for order in (0, 1, 2):
+        h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_order": order}, max_val=32.0, nans=True)
+        assert h.query("mv_tiles") > 0 and h.query("mv_order") == order, (order, h.query("mv_order"))
+
+
 def test_xcd_group_orders(be):
     # grouped tile orders (xcd_remap / mv_remap = G): whole blocks of 8G tiles are permuted, the incomplete last block is not
     for nrows in (64 * 255 + 5, 64 * 256, 64 * 257 + 1, 64 * 1030):

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+import os; os.environ.setdefault("KKAMD_LIBRARY", "libkkamd_ablate.so")   # the -DKK_ABLATE measurement build (csrc: make ablate)
 """C2 SpMV through the analysed handle (window codes + staged x) with parts of the kernel switched off (knob ablate:
 4 no y stores, 64 one tile in eight stores, 128 all stores into one 2 KB window, 8 no LDS row reduction, 16 synthetic row bounds instead of row_map loads).  Results are wrong by design."""
 import os, sys

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+import os; os.environ.setdefault("KKAMD_LIBRARY", "libkkamd_ablate.so")   # the -DKK_ABLATE measurement build (csrc: make ablate)
 """C2 SpMV (window codes + staged x) against workgroups per CU: extra dynamic LDS (knob lds_pad_kb) lowers the occupancy."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

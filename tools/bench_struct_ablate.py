@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("KKAMD_LIBRARY", "libkkamd_ablate.so")   # the -DKK_ABLATE measurement build (csrc: make ablate)
 """spmv_struct interior kernel on C2 with parts switched off (struct_remap bits: 2 no y store, 4 no old-y load, 8 no x loads, 16 no stencil loop)."""
 import sys; sys.path.insert(0, sys.argv[1])
 import torch, kk_loader

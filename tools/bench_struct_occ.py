@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("KKAMD_LIBRARY", "libkkamd_ablate.so")   # the -DKK_ABLATE measurement build (csrc: make ablate)
 """spmv_struct interior kernel on C2 against workgroups per CU (extra dynamic LDS lowers the occupancy)."""
 import sys; sys.path.insert(0, sys.argv[1])
 import torch, kk_loader
