@@ -14,9 +14,12 @@
 #define KK_DEVICE_ONLY(...)
 #define KK_UNROLL
 #define KK_UNROLL4
+#define KK_NOUNROLL
 #define KK_WAVE_SYNC() kk_emu::sync_wave()
 #define KK_QUAD_PERM(v, ctrl) kk_emu::quad_perm((v), (ctrl))
 #define KK_UMUL24(a, b) ((unsigned)(a) * (unsigned)(b))
+#define KK_GLDS16(gsrc, lds_wave_base, lane) std::memcpy((char*)(lds_wave_base) + 16 * (lane), (const void*)(gsrc), 16)
+#define KK_GLDS_WAIT()
 #else
 #include <hip/hip_runtime.h>
 #define KK_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -28,9 +31,17 @@
 #define KK_DEVICE_ONLY(...) __VA_ARGS__
 #define KK_UNROLL _Pragma("unroll")
 #define KK_UNROLL4 _Pragma("unroll 4")
+#define KK_NOUNROLL _Pragma("nounroll")
 #define KK_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // DPP quad permute of a 32-bit value: lane (4q+j) receives the value of lane 4q + ((ctrl >> 2j) & 3)
 #define KK_QUAD_PERM(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xf, 0xf, true)
 // full-rate 24-bit multiply (v_mul_u32_u24); the 32-bit v_mul_lo_u32 is quarter rate
 #define KK_UMUL24(a, b) __umul24((a), (b))
+// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4, gfx950): every lane names its own source; the destination
+// is the wave-uniform LDS address `lds_wave_base` plus 16 * lane.  hipcc does not track the copy: KK_GLDS_WAIT (s_waitcnt 0)
+// must precede the barrier that publishes the data.
+#define KK_GLDS16(gsrc, lds_wave_base, lane)                                                                       \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                          \
+                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+#define KK_GLDS_WAIT() __builtin_amdgcn_s_waitcnt(0)
 #endif

@@ -81,6 +81,7 @@ struct SpgemmTuning {
   int win_bits       = 1 << 20;   // columns per LDS bitmap window (128 KB); rows wider than this take several passes
   int val_cap        = kValCap;   // C entries per value window
   int force_unsorted = 0;         // test hook: treat B as unsorted (dense rows accumulate in HBM)
+  int emit_chunked   = 0;         // 1 = every dense row walks its bitmap in contiguous runs (the sparse-bitmap path) when emitting entries(C)
 #ifdef KK_ABLATE
   int debug          = 0;         // measurement build only: ablation bits for the dense-row kernels
 #endif
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
                                                                         const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
                                                                         OffT* __restrict__ counts, const OffT* __restrict__ rmC,
                                                                         int32_t* __restrict__ entC, int64_t k, int win_bits,
-                                                                        int sg_log2 KK_DBG_PARAM) {
+                                                                        int sg_log2, int force_chunked KK_DBG_PARAM) {
   KK_DYN_SMEM(kk_u64, bm);
   __shared__ int s_min, s_max;
   __shared__ int s_wave[kDenseBlock / 64];
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
       // sparse bitmaps (fewer than 4 columns per touched word on average; always when only counting): every
       // work-item takes one contiguous run of words -- one workgroup scan per window instead of one per 1024 words.
       // Dense bitmaps keep the interleaved walk, whose stores to entries(C) coalesce.
-      const bool chunked = !EMIT || KK_DBG(128) || (int64_t)rmC[row + 1] - (int64_t)rmC[row] < 4 * (int64_t)nw;
+      const bool chunked = !EMIT || force_chunked || (int64_t)rmC[row + 1] - (int64_t)rmC[row] < 4 * (int64_t)nw;
       if (chunked) {
         const int per = (nw + kDenseBlock - 1) / kDenseBlock;
         const int a = w_lo + t * per, z = (a + per <= w_hi + 1) ? a + per : w_hi + 1;
@@ -1068,7 +1069,7 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
   KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,
-            rmC, entC, k, (int)win, sg KK_DBG_ARG);
+            rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked KK_DBG_ARG);
   return KKAMD_OK;
 }
 
@@ -1256,6 +1257,7 @@ int spgemm_set_default(const char* key, int value) {
     if (value < 64 || value > 4096) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_cap must be in [64, 4096]");
     g_spgemm.val_cap = value;
   } else if (k == "spgemm_force_unsorted") g_spgemm.force_unsorted = value != 0;
+  else if (k == "spgemm_emit_chunked") g_spgemm.emit_chunked = value != 0;
 #ifdef KK_ABLATE
   else if (k == "spgemm_debug") g_spgemm.debug = value;
 #endif

@@ -335,6 +335,16 @@ __global__ void code_flag_kernel(int64_t nblocks, int32_t* __restrict__ tinfo, i
   if (mode == kTilePattern && !use_pat) { mode = kTileStaged; tinfo[b] = mode; }
   flag[b] = (mode == kTileCodes || mode == kTileStaged) ? 1 : 0;
 }
+// Tile lists per mode: flag, scan, scatter.
+__global__ void mode_flag_kernel(int64_t nblocks, const int32_t* __restrict__ tinfo, int32_t* __restrict__ flag, int mode) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nblocks) return;
+  flag[b] = (b < nblocks && (tinfo[b] & 3) == mode) ? 1 : 0;
+}
+__global__ void mode_scatter_kernel(int64_t nblocks, const int32_t* __restrict__ tinfo, const int32_t* __restrict__ idx, int32_t* __restrict__ list, int mode) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nblocks && (tinfo[b] & 3) == mode) list[idx[b]] = (int32_t)b;
+}
 // Moves the codes of the flagged tiles to their compact position (idx = exclusive scan of the flags) and completes tinfo.
 template <int TILE>
 __global__ __launch_bounds__(kBlock) void code_compact_kernel(const uint16_t* __restrict__ full, uint16_t* __restrict__ compact,
@@ -595,38 +605,26 @@ template <class YT> __device__ __forceinline__ YT strided_lds_sum(const YT* prod
   return (s0 + s1) + (s2 + s3);
 }
 
-// Measurement build (-DKK_ABLATE, tools/ only): parts of the kernel can be switched off through an extra kernel argument.
-// In the product build the argument does not exist and every KK_ABL(bit) folds to false.
-#ifdef KK_ABLATE
-#define KK_ABL_PARAM , int ablate
-#define KK_ABL_ARG(p) , (p)->tune.ablate
-#define KK_ABL(bit) ((ablate & (bit)) != 0)
-#define KK_LDS_PAD(p) ((size_t)(p)->tune.lds_pad_kb * 1024)
-#else
-#define KK_ABL_PARAM
-#define KK_ABL_ARG(p)
-#define KK_ABL(bit) false
-#define KK_LDS_PAD(p) ((size_t)0)
-#endif
-
 // The planned kernel (nnz-split tiles).  What bounds a kernel that needs ~100 KB in flight per CU is the DEPENDENCY CHAIN
-// each tile goes through: the tile descriptors (first row + "starts inside a row" flag, tile mode: two scalar loads) are
-// requested first, the streaming loads do not depend on them, and the per-lane row bounds row_map[r], row_map[r+1] are
-// requested together with the x gathers -- so a tile sees two memory latencies (stream, then gather + bounds).  After the
-// barrier the row reduction touches only LDS and registers.
-// CAP is what the plan can hold: 0 = no column analysis (every tile reads entries), 1 = window codes / LDS-staged x,
-// 2 = row-pattern records too.  The MODE is per tile (tinfo[b], workgroup-uniform): kTilePlain reads entries and gathers x
-// with quad-dealt loads, kTileCodes takes its columns from the plan's 16-bit window codes, kTileStaged also stages the
-// tile's x ranges in LDS (stage_products_win), kTilePattern decodes a row-pattern record and reads no per-nonzero code.
-// One tile the codes cannot cover costs that tile its codes, not the matrix.
-template <class OffT, class AT, class YT, int NPT, bool NT, int CAP>
+// each tile goes through: the tile descriptor (first row + "starts inside a row" flag: one scalar load) is requested first,
+// the streaming loads do not depend on it, and the per-lane row bounds row_map[r], row_map[r+1] are requested together
+// with the x gathers -- so a tile sees two memory latencies (stream, then gather + bounds).  After the barrier the row
+// reduction touches only LDS and registers.
+// The column analysis is PER TILE (tinfo[b]): kTilePlain reads entries and gathers x with quad-dealt loads, kTileCodes takes
+// its columns from the plan's 16-bit window codes, kTileStaged also stages the tile's x ranges in LDS (stage_products_win),
+// kTilePattern decodes a row-pattern record and reads no per-nonzero code at all.  One tile the codes cannot cover costs
+// that tile its codes, not the matrix.  Each mode is its own instantiation (MODE) launched over the plan's LIST of the
+// tiles of that mode (null = every tile): one kernel with all four paths needs 135-152 registers per work-item where the
+// pattern path alone needs 88, i.e. three instead of five workgroups per CU for the tiles that matter.
+template <class OffT, class AT, class YT, int NPT, int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const OffT* __restrict__ row_map,
                                                               const int32_t* __restrict__ entries,
                                                               const AT* __restrict__ values, const YT* __restrict__ x,
                                                               YT* __restrict__ y, YT alpha, YT beta,
                                                               const int32_t* __restrict__ blk_info,
                                                               YT* __restrict__ carry_head, YT* __restrict__ carry_tail,
-                                                              int remap, const int32_t* __restrict__ tinfo,
+                                                              int remap, const int32_t* __restrict__ list,
+                                                              const int32_t* __restrict__ tinfo,
                                                               const uint16_t* __restrict__ wcode,
                                                               const int32_t* __restrict__ wmeta, int64_t ncols,
                                                               const int32_t* __restrict__ pmeta KK_ABL_PARAM) {
@@ -635,28 +633,24 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   constexpr int TILE  = kBlock * NPT;
   constexpr int STEPS = NPT / 2;
   __shared__ YT prod[TILE];
-  const int t     = threadIdx.x;
-  const int64_t b = xcd_order(blockIdx.x, gridDim.x, remap);
+  constexpr bool NT = false;
+  const int t       = threadIdx.x;
+  const int64_t pos = xcd_order(blockIdx.x, gridDim.x, remap);
+  const int64_t b   = list ? (int64_t)list[pos] : pos;         // the plan's list of the tiles of this mode (ascending), or every tile
   const int64_t s = b * TILE;
   const bool full = (s + TILE <= nnz);
   const int64_t e = full ? s + TILE : nnz;
 
   // tile descriptor: bit 31 = the tile starts inside a row (a "head" segment exists)
   const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
-  int mode = kTilePlain;
   const uint16_t* wtile = nullptr;
-  if (CAP >= 1) {
-    const int32_t ti = tinfo[b];
-    mode  = ti & 3;
-    if (CAP < 2 && mode == kTilePattern) mode = kTileStaged;
-    wtile = wcode + (int64_t)((unsigned)ti >> 2) * TILE;       // meaningful for modes 1 and 2 only
-  }
+  if (MODE == kTileCodes || MODE == kTileStaged) wtile = wcode + (int64_t)((unsigned)tinfo[b] >> 2) * TILE;   // the tile's codes
 
   AT v0[STEPS], v1[STEPS];
   int c0[STEPS], c1[STEPS];
-  if (CAP >= 1 && mode >= kTileStaged) {
+  if (MODE >= kTileStaged) {
     // nothing to load here: stage_products_win requests values, codes and x chunks together
-  } else if (CAP >= 1 && mode == kTileCodes) {
+  } else if (MODE == kTileCodes) {
     if (full) load_tile_win<AT, STEPS, true>(values, wtile, wmeta, b, s, e, t, v0, v1, c0, c1);
     else      load_tile_win<AT, STEPS, false>(values, wtile, wmeta, b, s, e, t, v0, v1, c0, c1);
   } else {
@@ -683,9 +677,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream3_kernel(int64_t nnz, const
   YT yold = YT(0);
   if (beta != YT(0) && valid && lane == 0 && r >= 0) yold = y[r];
 
-  if (CAP >= 2 && mode == kTilePattern) {                       // records exist for full tiles only
+  if (MODE == kTilePattern) {                                   // records exist for full tiles only (the ragged last tile keeps its codes)
     stage_products_win<AT, YT, STEPS, true, NT, true>(values, wtile, wmeta, x, ncols, prod, b, s, e, t, pmeta);
-  } else if (CAP >= 1 && mode == kTileStaged) {
+  } else if (MODE == kTileStaged) {
     if (full) stage_products_win<AT, YT, STEPS, true, NT, false>(values, wtile, wmeta, x, ncols, prod, b, s, e, t, nullptr);
     else      stage_products_win<AT, YT, STEPS, false, NT, false>(values, wtile, wmeta, x, ncols, prod, b, s, e, t, nullptr);
   } else {
@@ -790,16 +784,20 @@ static int launch_stream(const kkamd_spmv_plan* p, const kkamd_crs_t* A, const Y
                          hipStream_t st) {
   YT* ch = reinterpret_cast<YT*>(p->d_carry);
   YT* ct = reinterpret_cast<YT*>(reinterpret_cast<char*>(p->d_carry) + 8 * p->nblocks);
-  // what the plan holds decides the instantiation; the mode of every tile is read from tinfo at run time
-  const int cap = !p->d_tinfo ? 0 : (p->d_pmeta ? 2 : 1);
-#define KK_STREAM3(CAPV)                                                                                                  \
-  KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, false, CAPV>), (unsigned)p->nblocks, kBlock, KK_LDS_PAD(p), st, A->nnz, \
+  // one launch per tile mode the plan holds, each over the list of its tiles (no column analysis: every tile is plain)
+#define KK_STREAM3(MODE, NTILES, LIST)                                                                                    \
+  KK_LAUNCH((spmv_stream3_kernel<OffT, AT, YT, NPT, MODE>), (unsigned)(NTILES), kBlock, KK_LDS_PAD(p), st, A->nnz,        \
             (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta,          \
-            (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, (const int32_t*)p->d_tinfo,                         \
+            (const int32_t*)p->d_blk_row, ch, ct, p->tune.xcd_remap, (const int32_t*)(LIST), (const int32_t*)p->d_tinfo, \
             (const uint16_t*)p->d_wcode, (const int32_t*)p->d_wbase, A->num_cols, (const int32_t*)p->d_pmeta KK_ABL_ARG(p))
-  if (cap == 2)      { KK_STREAM3(2); }
-  else if (cap == 1) { KK_STREAM3(1); }
-  else               { KK_STREAM3(0); }
+  if (!p->d_tinfo) {
+    KK_STREAM3(kTilePlain, p->nblocks, nullptr);
+  } else {
+    if (NPT != 4 && p->n_mode[kTilePattern] > 0) KK_STREAM3((NPT == 4 ? kTileStaged : kTilePattern), p->n_mode[kTilePattern], p->d_list[kTilePattern]);
+    if (p->n_mode[kTileStaged] > 0) KK_STREAM3(kTileStaged, p->n_mode[kTileStaged], p->d_list[kTileStaged]);
+    if (p->n_mode[kTileCodes] > 0)  KK_STREAM3(kTileCodes, p->n_mode[kTileCodes], p->d_list[kTileCodes]);
+    if (p->n_mode[kTilePlain] > 0)  KK_STREAM3(kTilePlain, p->n_mode[kTilePlain], p->d_list[kTilePlain]);
+  }
 #undef KK_STREAM3
   KK_LAUNCH_CHECK();
   KK_LAUNCH((spmv_stream_fixup_kernel<OffT, YT>), (unsigned)ceil_div(p->nblocks, kBlock), kBlock, 0, st, p->nblocks,
@@ -1081,6 +1079,7 @@ static int analyse(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
 static void free_analysis(kkamd_spmv_plan* p) {
   void** bufs[] = {(void**)&p->d_blk_row, &p->d_carry, (void**)&p->d_tinfo, (void**)&p->d_wcode, (void**)&p->d_wbase, (void**)&p->d_pmeta};
   for (void** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
+  for (int m = 0; m < 4; ++m) { if (p->d_list[m]) { (void)hipFree(p->d_list[m]); p->d_list[m] = nullptr; } p->n_mode[m] = 0; }
   p->pat_tiles = p->code_tiles = p->staged_tiles = p->plain_tiles = 0;
   p->tile = 0; p->nblocks = 0; p->plan_bytes = 0;
 }
@@ -1096,6 +1095,7 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
     (void)hipGetLastError();
     if (p->d_pmeta) { (void)hipFree(p->d_pmeta); p->d_pmeta = nullptr; }
     if (p->d_wcode) { (void)hipFree(p->d_wcode); p->d_wcode = nullptr; }
+    for (int m = 0; m < 4; ++m) { if (p->d_list[m]) { (void)hipFree(p->d_list[m]); p->d_list[m] = nullptr; } p->n_mode[m] = 0; }
     p->d_tinfo = nullptr; p->d_wbase = nullptr;
     p->pat_tiles = p->code_tiles = p->staged_tiles = 0; p->plain_tiles = p->nblocks;
     p->win_failed = true;
@@ -1163,8 +1163,27 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
   else if (npt == 8) { KK_LAUNCH((code_compact_kernel<kBlock * 8>), (unsigned)nb, kBlock, 0, st, d_full, p->d_wcode, tinfo, d_flag); }
   else               { KK_LAUNCH((code_compact_kernel<kBlock * 4>), (unsigned)nb, kBlock, 0, st, d_full, p->d_wcode, tinfo, d_flag); }
   if (hipGetLastError() != hipSuccess) return give_up();
+  // the launch lists: the tiles of every mode, ascending (none needed when one mode has every tile)
+  size_t list_bytes = 0;
+  for (int m = 0; m < 4; ++m) {
+    KK_LAUNCH(mode_flag_kernel, (unsigned)ceil_div((int64_t)nb + 1, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, d_flag, m);
+    if (hipGetLastError() != hipSuccess) return give_up();
+    if ((rc = exclusive_scan_inplace<int32_t>(d_flag, (int64_t)nb + 1, st))) { give_up(); return rc; }
+    int32_t cnt = 0;
+    KK_HIP(hipMemcpyAsync(&cnt, d_flag + nb, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    p->n_mode[m] = cnt;
+    if (cnt > 0 && (size_t)cnt < nb) {
+      if (hipMalloc((void**)&p->d_list[m], sizeof(int32_t) * (size_t)cnt) != hipSuccess) return give_up();
+      list_bytes += sizeof(int32_t) * (size_t)cnt;
+      int32_t* d_list_m = p->d_list[m];
+      KK_LAUNCH(mode_scatter_kernel, (unsigned)ceil_div((int64_t)nb, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, (const int32_t*)d_flag, d_list_m, m);
+      if (hipGetLastError() != hipSuccess) return give_up();
+    }
+  }
   KK_HIP(hipStreamSynchronize(st));
   p->d_tinfo = (int32_t*)tinfo_b.release(); p->d_wbase = (int32_t*)wbase_b.release();
+  p->plan_bytes += list_bytes;
   p->plain_tiles = n_plain; p->pat_tiles = n_pat; p->code_tiles = h_keep; p->staged_tiles = n_staged;
   p->plan_bytes += sizeof(int32_t) * nb * (1 + kWinMeta) + sizeof(uint16_t) * (size_t)h_keep * (size_t)p->tile +
                    (p->d_pmeta ? sizeof(int32_t) * nb * kPatW : 0);

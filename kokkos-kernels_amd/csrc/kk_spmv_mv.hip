@@ -396,13 +396,14 @@ __global__ __launch_bounds__(kBlock) void mv_build_kernel(int64_t nrows, int64_t
 //   4. Y leaves as 16 bytes per lane, 128 contiguous bytes per row.
 // Tiles in gather mode (kMvGather) take the same route with the column in place of the offset and X read from memory.
 template <class OffT, class AT, int NV>
-__global__ __launch_bounds__(kBlock) void spmv_mv3_kernel(int64_t nrows, int64_t ncols, const OffT* __restrict__ row_map,
+__global__ __launch_bounds__(kBlock, 3) void spmv_mv3_kernel(int64_t nrows, int64_t ncols, const OffT* __restrict__ row_map,
                                                           const int32_t* __restrict__ entries, const AT* __restrict__ values,
                                                           const uint16_t* __restrict__ slot, const int32_t* __restrict__ meta,
                                                           int meta_stride, const int32_t* __restrict__ order, int order_mode,
                                                           const double* __restrict__ X, int64_t xs0, double* __restrict__ Y,
                                                           int64_t ys0, int64_t ys1, int64_t nvec, double alpha, double beta,
-                                                          int y_vec_ok, int xbytes, int cap_rec) {
+                                                          int y_vec_ok, int xbytes, int cap_rec KK_ABL_PARAM) {
+  // KK_ABL bits (measurement build): 1 = no X staging, 2 = no contraction loop, 4 = no A staging, 8 = no Y store
   constexpr int ROWB = NV * 8;                  // bytes of one staged X row
   constexpr int LQ   = NV / 4;                  // lanes (of four right-hand sides) per half row
   constexpr int LPR  = 2 * LQ;                  // lanes per row
@@ -436,30 +437,30 @@ __global__ __launch_bounds__(kBlock) void spmv_mv3_kernel(int64_t nrows, int64_t
       if (mode == kMvStaged) {
         KK_UNROLL
         for (int k = 0; k < AMAX; ++k) {                       // unguarded (clamped) loads stay in flight together
-          if (c + (int64_t)k * kBlock >= ce) break;            // workgroup-uniform
+          if (c + (int64_t)k * kBlock >= ce || KK_ABL(4)) break;            // workgroup-uniform
           int64_t i = c + (int64_t)k * kBlock + t;
           i = i < ce ? i : ce - 1;
           av[k] = values[a0 + i]; ao[k] = (int)slot[a0 + i] * ROWB;
         }
-        // ... and the X window, 16 bytes per request
+        // ... and the X window, 16 bytes per request, straight into LDS (global_load_lds: no register round trip; piece g
+        // lands at byte 16 g, i.e. wave-uniform base + 16 * lane)
         const int npieces = nchunks * PPC;
         constexpr int XMAX = (kMvXBytes / 16 + kBlock - 1) / kBlock;
-        XV xv[XMAX];
         KK_UNROLL
         for (int k = 0; k < XMAX; ++k) {
           if (k * kBlock >= npieces) break;                    // workgroup-uniform
-          int g = k * kBlock + t;
-          g = g < npieces ? g : npieces - 1;
-          const int ch = g / PPC, p = g % PPC;
-          int64_t col = (int64_t)m[kMvHdr + ch] + p / PPR;
-          col = col < ncols ? col : ncols - 1;                 // the padding of the last run may reach past the matrix
-          xv[k] = *reinterpret_cast<const XV*>(X + col * xs0 + kk + (p % PPR) * 2);
+          const int g = k * kBlock + t;
+          if (g < npieces && !KK_ABL(1)) {
+            const int ch = g / PPC, p = g % PPC;
+            int64_t col = (int64_t)m[kMvHdr + ch] + p / PPR;
+            col = col < ncols ? col : ncols - 1;               // the padding of the last run may reach past the matrix
+            KK_GLDS16(X + col * xs0 + kk + (p % PPR) * 2, xwin + (size_t)(k * kBlock + (t & ~63)) * 16, t & 63);
+          }
         }
-        // 2. into LDS
-        KK_UNROLL
-        for (int k = 0; k < XMAX; ++k) { const int g = k * kBlock + t; if (g < npieces) *reinterpret_cast<XV*>(xwin + (size_t)g * 16) = xv[k]; }
+        // 2. A into LDS
         KK_UNROLL
         for (int k = 0; k < AMAX; ++k) { const int i = k * kBlock + t; if (c + i < ce) { a_val[i] = (double)av[k]; a_off[i] = ao[k]; } }
+        KK_GLDS_WAIT();                                        // this wave's pieces have landed (the barrier covers the other waves')
       } else {
         for (int64_t i = c + t; i < ce; i += kBlock) { a_val[i - c] = (double)values[a0 + i]; a_off[i - c] = entries[a0 + i]; }
       }
@@ -467,12 +468,13 @@ __global__ __launch_bounds__(kBlock) void spmv_mv3_kernel(int64_t nrows, int64_t
       // 3. my half of my row's entries inside this pass: positions rs + h, rs + h + 2, ...
       const int64_t lo = rs > c ? rs : c, hi = re < ce ? re : ce;
       int i = (int)(lo - c) + (int)((h - (lo - rs)) & 1);
-      const int e = (int)(hi - c);
+      const int e = KK_ABL(2) ? i : (int)(hi - c);
       if (mode == kMvStaged) {
         // piece P of lane (l, h) sits in half h of the X row, piece Q in the other half: the 16 lanes ds_read_b128 serves per
         // cycle (four rows x four lanes, two of each half) then cover all 64 banks once
         const char* xl = xwin + l * 16 + h * (ROWB / 2);
         const char* xq = xwin + l * 16 + (1 - h) * (ROWB / 2);
+        KK_NOUNROLL
         for (; i + 6 < e; i += 8) {
           const double v0 = a_val[i], v1 = a_val[i + 2], v2 = a_val[i + 4], v3 = a_val[i + 6];
           const int o0 = a_off[i], o1 = a_off[i + 2], o2 = a_off[i + 4], o3 = a_off[i + 6];
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv3_kernel(int64_t nrows, int64_t
           acc[0] += v2 * p2[0]; acc[1] += v2 * p2[1]; acc[2] += v2 * q2[0]; acc[3] += v2 * q2[1];
           acc[0] += v3 * p3[0]; acc[1] += v3 * p3[1]; acc[2] += v3 * q3[0]; acc[3] += v3 * q3[1];
         }
+        KK_NOUNROLL
         for (; i < e; i += 2) {
           const double v0 = a_val[i];
           const int o0 = a_off[i];
@@ -495,6 +498,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv3_kernel(int64_t nrows, int64_t
         const double* xg = X + kk + l * 2 + h * (NV / 2);
         constexpr int QD = NV / 2;
         const int qd = h ? -QD : QD;                           // the lane's other piece, in doubles
+        KK_NOUNROLL
         for (; i + 2 < e; i += 4) {
           const double v0 = a_val[i], v1 = a_val[i + 2];
           const double* x0 = xg + (int64_t)a_off[i] * xs0;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv3_kernel(int64_t nrows, int64_t
     // the two halves of a row meet: the partner (LQ lanes away) holds this lane's piece P as its piece Q
     const double f0 = acc[0] + __shfl_xor(acc[2], LQ, 64), f1 = acc[1] + __shfl_xor(acc[3], LQ, 64);
     // 4. lane (l, h) writes right-hand sides kk + 2l + (NV/2) h, + 1: 16 bytes per lane, the row's 8 NV bytes contiguous
-    if (row < rowN) {
+    if (row < rowN && !KK_ABL(8)) {
       const int64_t cq = kk + 2 * l + (NV / 2) * h;
       const double s0 = alpha * f0, s1 = alpha * f1;
       double* yp = Y + row * ys0 + cq * ys1;
@@ -642,7 +646,7 @@ static int launch_mv3(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   KK_LAUNCH((spmv_mv3_kernel<OffT, AT, NV>), (unsigned)mv->ntiles, kBlock, lds, st, A->num_rows, A->num_cols, (const OffT*)A->d_row_map,
             (const int32_t*)A->d_entries, (const AT*)A->d_values, (const uint16_t*)mv->d_slot, (const int32_t*)mv->d_meta,
             mv->meta_stride, (const int32_t*)(mv->order_used == 2 ? mv->d_order : nullptr), mv->order_used == 1 ? 1 : 0, X, ldx, Y, ys0,
-            ys1, nvec, alpha, beta, yv, xbytes, cap_rec);
+            ys1, nvec, alpha, beta, yv, xbytes, cap_rec KK_ABL_ARG(plan));
   KK_LAUNCH_CHECK();
   return KKAMD_OK;
 }

@@ -4,6 +4,20 @@
 #pragma once
 #include "kk_common.h"
 
+// Measurement build (-DKK_ABLATE, tools/ only): parts of the kernel can be switched off through an extra kernel argument.
+// In the product build the argument does not exist and every KK_ABL(bit) folds to false.
+#ifdef KK_ABLATE
+#define KK_ABL_PARAM , int ablate
+#define KK_ABL_ARG(p) , (p)->tune.ablate
+#define KK_ABL(bit) ((ablate & (bit)) != 0)
+#define KK_LDS_PAD(p) ((size_t)(p)->tune.lds_pad_kb * 1024)
+#else
+#define KK_ABL_PARAM
+#define KK_ABL_ARG(p)
+#define KK_ABL(bit) false
+#define KK_LDS_PAD(p) ((size_t)0)
+#endif
+
 namespace kk {
 
 struct SpmvTuning {
@@ -81,7 +95,9 @@ struct kkamd_spmv_plan {
   int32_t* d_tinfo = nullptr;    // [nblocks] mode | index << 2 (index: tile's position in d_wcode resp. d_pmeta)
   uint16_t* d_wcode = nullptr;   // [code_tiles * tile]
   int32_t* d_wbase = nullptr;    // [nblocks * 64] window meta: bases, LDS slots, x chunk columns
-  int32_t* d_pmeta = nullptr;    // [pat_tiles * kPatW] row-pattern records (see pat_build_kernel)
+  int32_t* d_pmeta = nullptr;    // [nblocks * kPatW] row-pattern records (see pat_build_kernel), allocated when records are in use
+  int32_t* d_list[4] = {nullptr, nullptr, nullptr, nullptr};   // per tile mode: ascending list of its tiles (null: none, or every tile)
+  int64_t n_mode[4]  = {0, 0, 0, 0};                           // tiles per mode (the launch sizes)
   int64_t code_tiles = 0;        // tiles that read per-nonzero codes (modes 1, 2)
   int64_t staged_tiles = 0;      // tiles whose x window is staged in LDS (modes 2, 3)
   int64_t pat_tiles = 0;         // tiles decoded from a row-pattern record (mode 3)

@@ -160,13 +160,13 @@ def test_spgemm_dense_row_windows(be):
         pc.check_spgemm(be, A0, B0, offset_dtype=np.int64, value_dtype=np.float32)
         _set(be, "spgemm_force_unsorted", 1)
         pc.check_spgemm(be, A0, B0)
-        _set(be, "spgemm_force_unsorted", 0); _set(be, "spgemm_debug", 128)      # contiguous-run bitmap walk for every row
+        _set(be, "spgemm_force_unsorted", 0); _set(be, "spgemm_emit_chunked", 1)      # contiguous-run bitmap walk for every row
         pc.check_spgemm(be, A0, B0)
         _set(be, "spgemm_win_bits", 4096)
         pc.check_spgemm(be, A1, B1)
     finally:
         _set(be, "spgemm_win_bits", 1 << 20); _set(be, "spgemm_val_cap", 2048); _set(be, "spgemm_force_unsorted", 0)
-        _set(be, "spgemm_debug", 0)
+        _set(be, "spgemm_emit_chunked", 0)
     ent, val = B0.entries.copy(), B0.values.copy()          # unsorted B: detected by the symbolic phase, dense rows fall back
     for i in range(B0.nrows):
         lo, hi = B0.row_map[i], B0.row_map[i + 1]
