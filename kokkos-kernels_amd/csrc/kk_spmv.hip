@@ -1342,6 +1342,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   kk::free_analysis(plan);
   if (plan->d_xpack) (void)hipFree(plan->d_xpack);
   if (plan->d_ypack) (void)hipFree(plan->d_ypack);
+  if (plan->d_mv2_order) (void)hipFree(plan->d_mv2_order);
   if (plan->mv) kk::mv_plan_destroy(plan->mv);
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
@@ -1370,6 +1371,10 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
     return kk::build_analysis(plan, &A, plan->last_stream);
   }
+  if (t.mv_order != old.mv_order || t.mv_strip_min_kb != old.mv_strip_min_kb || t.mv_strip_l2_kb != old.mv_strip_l2_kb) {
+    if (plan->d_mv2_order) { if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream)); KK_HIP(hipFree(plan->d_mv2_order)); plan->d_mv2_order = nullptr; }
+    plan->mv2_tried = false;
+  }
   if ((t.mv_order != old.mv_order || t.mv_strip_min_kb != old.mv_strip_min_kb || t.mv_strip_l2_kb != old.mv_strip_l2_kb) && plan->mv) { kk::mv_plan_destroy(plan->mv); plan->mv = nullptr; plan->mv_failed = false; }
   return KKAMD_OK;
 }
@@ -1389,7 +1394,8 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "transpose_cached") *value = plan->t_ready ? 1 : 0;
   else if (k == "mv_tiles") *value = kk::mv_plan_query(plan->mv, 0);
   else if (k == "mv_staged_tiles") *value = kk::mv_plan_query(plan->mv, 1);
-  else if (k == "mv_order") *value = kk::mv_plan_query(plan->mv, 2);
+  else if (k == "mv_order") *value = plan->mv ? kk::mv_plan_query(plan->mv, 2) : (plan->d_mv2_order ? 2 : 0);
+  else if (k == "mv_period") *value = plan->mv_period;
   else if (k == "mv_plan_bytes") *value = kk::mv_plan_query(plan->mv, 3);
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
   return KKAMD_OK;

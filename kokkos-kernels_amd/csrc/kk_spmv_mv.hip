@@ -77,7 +77,8 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
                                                           const int32_t* __restrict__ entries,
                                                           const AT* __restrict__ values, const YT* __restrict__ X,
                                                           int64_t xs0, YT* __restrict__ Y, int64_t ys0, int64_t ys1,
-                                                          int64_t nvec, YT alpha, YT beta, int y_vec_ok, int remap) {
+                                                          int64_t nvec, YT alpha, YT beta, int y_vec_ok, int remap,
+                                                          const int32_t* __restrict__ order) {
   // XCD-contiguous workgroup order (remap): the 128-byte X rows a row block touches are shared with the blocks
   // that handle rows i+-1, j+-1 (and k+-1); keeping neighbouring blocks on ONE XCD keeps those X rows in its
   // 4 MiB L2.  With the dispatcher's round-robin order every XCD fetched every X row: rocprof showed 10.7
@@ -98,7 +99,9 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
   const int lane64 = threadIdx.x & 63, w = threadIdx.x >> 6;
   AT* s_val  = s_val_all[w];
   int* s_col = s_col_all[w];
-  const int64_t wg   = xcd_order(blockIdx.x, gridDim.x, remap);   // 0 dispatch order, 1 contiguous, 4 / 8 / 16 grouped
+  // row block of this workgroup: the plan's strip order (see mv_build_strip_order) when it has one, else 0 dispatch order,
+  // 1 XCD-contiguous, 4 / 8 / 16 grouped
+  const int64_t wg   = order ? (int64_t)order[blockIdx.x] : xcd_order(blockIdx.x, gridDim.x, remap);
   const int64_t row0 = (wg * (kBlock / kWave) + w) * RW;
   if (row0 >= nrows) return;                                   // whole wave leaves together
   const int64_t rowN = (row0 + RW < nrows) ? row0 + RW : nrows;
@@ -574,8 +577,7 @@ static int64_t mv_detect_period(const kkamd_mv_plan* mv, int64_t nrows, hipStrea
 // neighbour and once per XCD.  Here every XCD instead owns STRIPS of W consecutive rows of every period and walks a strip
 // period after period: the three periods' worth of X rows a strip needs (3 W rows) stay in its L2, and an X row crosses the
 // fabric about once.  order[8 i + x] = i-th tile of XCD x (workgroup b runs on XCD b % 8).
-static int mv_build_strip_order(kkamd_mv_plan* mv, int64_t period, int rowbytes, int l2_kb, hipStream_t st) {
-  const int64_t nt = mv->ntiles, rb = mv->rb;
+static int build_strip_order(int64_t nt, int64_t rb, int64_t period, int rowbytes, int l2_kb, int32_t** d_order, hipStream_t st) {
   const double l2_rows = 1e3 * (double)l2_kb / (3.0 * (double)rowbytes);   // rows of X per period a strip may keep in a 4 MB L2
   int64_t nstrips = (int64_t)((double)period / l2_rows) + 1;
   nstrips = (nstrips + kNumXcd - 1) / kNumXcd * kNumXcd;
@@ -589,11 +591,44 @@ static int mv_build_strip_order(kkamd_mv_plan* mv, int64_t period, int rowbytes,
   size_t longest = 0;
   for (auto& v : xcd) if (v.size() > longest) longest = v.size();
   for (size_t i = 0; i < longest; ++i) for (int x = 0; x < kNumXcd; ++x) if (i < xcd[(size_t)x].size()) order.push_back(xcd[(size_t)x][i]);
-  KK_HIP(hipMalloc((void**)&mv->d_order, sizeof(int32_t) * (size_t)nt));
-  KK_HIP(hipMemcpyAsync(mv->d_order, order.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+  KK_HIP(hipMalloc((void**)d_order, sizeof(int32_t) * (size_t)nt));
+  KK_HIP(hipMemcpyAsync(*d_order, order.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
   KK_HIP(hipStreamSynchronize(st));
-  mv->bytes += sizeof(int32_t) * (size_t)nt;
   return KKAMD_OK;
+}
+static int mv_build_strip_order(kkamd_mv_plan* mv, int64_t period, int rowbytes, int l2_kb, hipStream_t st) {
+  int rc = build_strip_order(mv->ntiles, mv->rb, period, rowbytes, l2_kb, &mv->d_order, st);
+  if (rc == KKAMD_OK) mv->bytes += sizeof(int32_t) * (size_t)mv->ntiles;
+  return rc;
+}
+
+// Far stride of the matrix from the columns of a few rows (no tile analysis needed): the offsets col - row of a row cluster
+// around 0, +-S1, +-S2, +-S2 +-S1; the far cluster (above half the largest) has S2 as its median.  0 = none found.
+template <class OffT>
+static int64_t detect_period_rows(const kkamd_crs_t* A, hipStream_t st) {
+  if (A->num_rows < 4096 || A->num_rows != A->num_cols) return 0;
+  int64_t votes[16]; int nv = 0;
+  for (int s = 1; s <= 15; ++s) {
+    const int64_t r = A->num_rows * s / 16;
+    OffT rm[2];
+    if (hipMemcpyAsync(rm, (const OffT*)A->d_row_map + r, sizeof rm, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
+    const int64_t len = (int64_t)(rm[1] - rm[0]);
+    if (len < 2 || len > 256) continue;
+    int32_t cols[256];
+    if (hipMemcpyAsync(cols, (const int32_t*)A->d_entries + (int64_t)rm[0], sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return 0;
+    int64_t mx = 0;
+    for (int64_t i = 0; i < len; ++i) if (cols[i] - r > mx) mx = cols[i] - r;
+    int64_t far[256]; int nf = 0;
+    for (int64_t i = 0; i < len; ++i) if (2 * (cols[i] - r) > mx) far[nf++] = cols[i] - r;
+    if (!nf) continue;
+    for (int i = 1; i < nf; ++i) { const int64_t v = far[i]; int j = i - 1; while (j >= 0 && far[j] > v) { far[j + 1] = far[j]; --j; } far[j + 1] = v; }
+    votes[nv++] = far[nf / 2];
+  }
+  if (nv < 3) return 0;
+  int64_t best = 0; int best_n = 0;
+  for (int i = 0; i < nv; ++i) { int c = 0; for (int j = 0; j < nv; ++j) if (votes[j] == votes[i]) ++c; if (c > best_n) { best_n = c; best = votes[i]; } }
+  return (best_n * 2 > nv && best > 0 && best < A->num_rows) ? best : 0;
 }
 
 template <class OffT>
@@ -661,6 +696,28 @@ static int launch_mv(const kkamd_crs_t* A, const YT* X, int64_t xs0, int64_t xs1
   return KKAMD_OK;
 }
 
+// the wave-private kernel's row blocks in strip order (mv_order = 2, analysed handles, matrices with a far stride): built on
+// the first rank-2 call for the kernel's block size and kept with the plan
+template <class OffT>
+static const int32_t* mv2_order_t(kkamd_spmv_plan* plan, const kkamd_crs_t* A, int rows_per_wg, int rowbytes, hipStream_t st) {
+  if (!plan || plan->tile == 0 || plan->tune.mv_order != 2 || plan->entries != A->d_entries) return nullptr;
+  if (plan->d_mv2_order && plan->mv2_rb == rows_per_wg) return plan->d_mv2_order;
+  if (plan->mv2_tried && plan->mv2_rb == rows_per_wg) return nullptr;
+  if (plan->d_mv2_order) { (void)hipStreamSynchronize(st); (void)hipFree(plan->d_mv2_order); plan->d_mv2_order = nullptr; }
+  plan->mv2_tried = true; plan->mv2_rb = rows_per_wg;
+  if (!plan->mv_period_known) { plan->mv_period = detect_period_rows<OffT>(A, st); plan->mv_period_known = true; }
+  const int64_t period = plan->mv_period;
+  if (period <= 0 || (double)period * rowbytes * 3.0 <= 1e3 * (double)plan->tune.mv_strip_min_kb) return nullptr;
+  if (build_strip_order(ceil_div(A->num_rows, rows_per_wg), rows_per_wg, period, rowbytes, plan->tune.mv_strip_l2_kb, &plan->d_mv2_order, st) != KKAMD_OK) {
+    (void)hipGetLastError();
+    plan->d_mv2_order = nullptr;
+  }
+  return plan->d_mv2_order;
+}
+static const int32_t* mv2_order(kkamd_spmv_plan* plan, const kkamd_crs_t* A, int rows_per_wg, int rowbytes, hipStream_t st) {
+  return A->offset_type == KKAMD_I64 ? mv2_order_t<int64_t>(plan, A, rows_per_wg, rowbytes, st) : mv2_order_t<int32_t>(plan, A, rows_per_wg, rowbytes, st);
+}
+
 template <class OffT, class AT, class YT>
 static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dX,
                          int64_t xs0, int64_t xs1, double beta_d, void* dY, int64_t ys0, int64_t ys1, int64_t nvec,
@@ -697,11 +754,10 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
       KK_LAUNCH_CHECK();
       Xr = (const YT*)plan->d_xpack; ldx = ldp;
     }
-    // LDS-staged X tiles: analysed handles, fp64 vectors, 8 or 16 right-hand sides per strip; the analysis happens on the
-    // first such call (like the vendor's rank-2 sub-handle) and is kept for the handle's life
+    // LDS-staged X tiles (knob mv_kernel = 3; measured slower than the wave-private kernel on C3): analysed
+    // handles, fp64 vectors, 8 or 16 right-hand sides per strip; the analysis happens on the first such call
     if constexpr (sizeof(YT) == 8) {
-      if (Xr && plan && plan->tile != 0 && mvk != 2 && nvec >= 8 && nvec % 8 == 0 && !plan->mv_failed && plan->entries == A->d_entries &&
-          (mvk == 3 || A->nnz >= 1000000)) {
+      if (Xr && plan && plan->tile != 0 && mvk == 3 && nvec >= 8 && nvec % 8 == 0 && !plan->mv_failed && plan->entries == A->d_entries) {
         const int nv = (nvec % 16 == 0) ? 16 : 8;
         if (!plan->mv || plan->mv->nv != nv) {
           int rc = mv_plan_build<OffT>(plan, A, nv, st);
@@ -720,7 +776,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
       do {                                                                                                               \
         KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R, C>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
                   0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, \
-                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap);                                                        \
+                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap, mv2_order(plan, A, (kBlock / kWave) * (kWave / L), (int)(nvec < 16 ? nvec : 16) * (int)sizeof(YT), st)); \
         KK_LAUNCH_CHECK();                                                                                               \
         return KKAMD_OK;                                                                                                 \
       } while (0)

@@ -111,6 +111,11 @@ struct kkamd_spmv_plan {
   // rank-2 analysis (LDS-staged X tiles), built by the first rank-2 call that can use it
   kkamd_mv_plan* mv = nullptr;
   bool mv_failed = false;
+  // rank-2 wave-private kernel: its row blocks in strip order (see mv_build_strip_order)
+  int32_t* d_mv2_order = nullptr;
+  int mv2_rb = 0;
+  bool mv2_tried = false, mv_period_known = false;
+  int64_t mv_period = 0;
   // stream the plan's scratch (carry, packs) was last used on: a change of stream fences the old one first
   // (TPL_SpMV_Data::set_exec_space, sparse/src/KokkosSparse_spmv_handle.hpp:95-104)
   hipStream_t last_stream = nullptr;

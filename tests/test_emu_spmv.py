@@ -140,7 +140,9 @@ def test_mv3_lds_staged(be):
     A0 = oracle.laplace3d("FE", 130, 10, 6)
     h = pc.check_spmv_mv(be, A0, 16, "N", 1.5, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
                          knobs={"mv_kernel": 3, "mv_order": 2, "mv_strip_min_kb": 100, "mv_strip_l2_kb": 64}, expect={"mv_order": 2})
-    # below the size threshold the automatic choice stays with the wave-private kernel; odd widths never take the staged kernel
+    # the staged kernel runs on request only (knob mv_kernel = 3); widths that are not multiples of 8 never take it
+    h = pc.check_spmv_mv(be, oracle.laplace3d("FE", 300, 10, 5), 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
+                         knobs={"mv_strip_min_kb": 100, "mv_strip_l2_kb": 160}, expect={"mv_tiles": 0, "mv_order": 2, "mv_period": 3000})
     pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, expect={"mv_tiles": 0})
     pc.check_spmv_mv(be, A0, 12, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 3}, max_val=32.0, expect={"mv_tiles": 0})
 

@@ -165,8 +165,15 @@ def test_mv3_lds_staged(be):
     # a grid large enough for the strip order to engage (far stride 160 * 120 rows * 128 B * 3 > 3 MB)
     A0 = oracle.laplace3d("FE", 160, 120, 12)
     for order in (0, 1, 2):
-        h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_order": order}, max_val=32.0, nans=True)
+        h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 3, "mv_order": order}, max_val=32.0, nans=True)
         assert h.query("mv_tiles") > 0 and h.query("mv_order") == order, (order, h.query("mv_order"))
+    # the default (wave-private gather kernel) takes its row blocks in strip order on the same grid, for every width
+    for nvec, xo, yo in ((16, "C", "C"), (8, "C", "C"), (4, "C", "C"), (16, "F", "F"), (3, "C", "C")):
+        h = pc.check_spmv_mv(be, A0, nvec, "N", 1.5, 0.0, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=True)
+        assert h.query("mv_tiles") == 0 and h.query("mv_period") == 160 * 120, (nvec, h.query("mv_period"))
+        assert h.query("mv_order") == (2 if nvec >= 8 else h.query("mv_order")), (nvec, h.query("mv_order"))
+    for order in (0, 1):
+        pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_order": order}, max_val=32.0, expect={"mv_order": 0})
 
 
 def test_xcd_group_orders(be):

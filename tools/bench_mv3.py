@@ -26,7 +26,11 @@ for nv in ((16,) if quick else (16, 8, 32)):
     X = torch.rand(A.numCols(), nv, dtype=torch.float64, device="cuda")
     Y = torch.zeros(rows, nv, dtype=torch.float64, device="cuda")
     alg = nnz * 12 + (rows + 1) * 4 + 2 * rows * nv * 8
-    cases = [("mv2 wave-private gather", {"mv_kernel": 2})] + [("mv3 LDS-staged, order %d" % o, {"mv_kernel": 3, "mv_order": o}) for o in (0, 1, 2)]
+    cases = [("mv2 wave-private gather, grouped order 16", {"mv_kernel": 2, "mv_order": 0}),
+             ("mv2 wave-private gather, strip order", {"mv_kernel": 2, "mv_order": 2})]
+    if not quick:
+        cases += [("mv2 strip order, L2 budget %d KB" % kb, {"mv_kernel": 2, "mv_order": 2, "mv_strip_l2_kb": kb}) for kb in (1000, 1600, 3500)]
+        cases += [("mv3 LDS-staged, order %d" % o, {"mv_kernel": 3, "mv_order": o}) for o in (1, 2)]
     for rep in range(2):
         for name, knobs in cases:
             h = kk.SPMVHandle("SPMV_DEFAULT")
@@ -38,7 +42,7 @@ for nv in ((16,) if quick else (16, 8, 32)):
                               "mv_plan_bytes": h.query("mv_plan_bytes")}), flush=True)
     if nv == 16:
         Xl = torch.rand(nv, A.numCols(), dtype=torch.float64, device="cuda").t(); Yl = torch.zeros(nv, rows, dtype=torch.float64, device="cuda").t()
-        for name, knobs in (cases[0], cases[-1]):
+        for name, knobs in (cases[0], cases[1]):
             h = kk.SPMVHandle("SPMV_DEFAULT")
             for k, v in knobs.items(): h.set(k, v)
             ms = timeit(lambda: kk.spmv(h, "N", 1.0, A, Xl, 0.0, Yl), it=5)
