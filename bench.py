@@ -170,10 +170,12 @@ def main():
     else:
         from kokkos_kernels_amd.dist import DistSpmv
         offsets = [r * rows_per_rank for r in range(world + 1)]
+        lib_ = (be or kk.torch_backend()).lib
+        for kv in args.knob:                       # the slab plans are created inside the library: knobs go in as defaults
+            k, v = kv.split("="); kk._capi.check(lib_, lib_.kkamd_set_default(k.encode(), int(v)))
         op = DistSpmv(A, offsets, rank, algo=args.algo, exchange=args.exchange, overlap=not args.no_overlap,
                       to_backend=tb if emu else None)
-        for kv in args.knob:
-            k, v = kv.split("="); op.handle.set(k, int(v))
+        xl = op.x_local(); xl.copy_(x_shard); x_shard = xl      # x lives in the operator's window: no per-step copy
         def step(ev0, ev1):
             op.apply(alpha, x_shard, beta, y_shard, events=(ev0, ev1))
 
@@ -202,10 +204,43 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     nnz_global = int(nnz_total.item()); ms_step, kern_ms = tmax.tolist()
 
+    # ---- N > 1: what each exchange costs (outside the timed region above): halo and all-gather steps, and the exchange alone ----
+    xchg = None
+    if world > 1:
+        def timed(fn, n=max(3, min(args.steps, 20))):
+            fn(); barrier()
+            t_ = time.perf_counter()
+            for _ in range(n): fn()
+            barrier()
+            return (time.perf_counter() - t_) * 1e3 / n
+        xchg = {}
+        ops = {op.exchange_mode: op}
+        other = "allgather" if op.exchange_mode == "halo" else "halo"
+        try:
+            ops[other] = DistSpmv(A, offsets, rank, algo=args.algo, exchange=other, overlap=not args.no_overlap, to_backend=tb if emu else None)
+        except Exception as e:                     # e.g. not enough memory for a second operator: report what there is
+            xchg["note"] = "no %s operator: %s" % (other, str(e)[:80])
+        for name, o in ops.items():
+            xs_ = o.x_local()
+            if o is not op: xs_.copy_(x_shard)
+            t_step = timed(lambda: o.apply(alpha, xs_, beta, y_shard))
+            t_x = timed(lambda: o.apply(alpha, xs_, beta, y_shard, what=1))
+            t_l = timed(lambda: o.apply(alpha, xs_, beta, y_shard, what=2))
+            tt = torch.tensor([t_step, t_x, t_l], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            xchg[name] = {"step_ms": round(tt[0].item(), 5), "exchange_only_ms": round(tt[1].item(), 5), "local_spmv_only_ms": round(tt[2].item(), 5),
+                          "bytes_received_per_gpu": o.exchange_bytes, "aggregate_GFLOPs": round(2.0 * nnz_global / (tt[0].item() * 1e-3) / 1e9, 1)}
+        ops.clear()
+
     # ---- sanity inside the bench: A*1 over the slab must be the row-sum vector (0 interior, 1 boundary) ----
-    ones = torch.ones(nrows_global, dtype=torch.float64, device=dev)
     chk = torch.empty(rows_per_rank, dtype=torch.float64, device=dev)
-    kk.spmv(handle if world == 1 else op.handle, "N", 1.0, A, tb(ones), 0.0, tb(chk))
+    if world == 1:
+        ones = torch.ones(nrows_global, dtype=torch.float64, device=dev)
+        kk.spmv(handle, "N", 1.0, A, tb(ones), 0.0, tb(chk))
+    else:
+        x_keep = x_shard.clone(); x_shard.fill_(1.0)
+        op.apply(1.0, x_shard, 0.0, chk)               # through the exchange: every rank's halo must arrive as ones
+        x_shard.copy_(x_keep)
     lens = A.graph.row_map[1:] - A.graph.row_map[:-1]
     if emu:
         lens = torch.from_numpy(np.asarray(lens))
@@ -230,8 +265,9 @@ def main():
             "config": {"workload": workload, "rows": nrows_global, "nnz": nnz_global, "rows_per_gpu": rows_per_rank,
                        "alpha": alpha, "beta": beta, "offsets": "int32", "ordinals": "int32", "algorithm": args.algo,
                        "partition": ("1-D row slabs; x exchange = %s over RCCL/xGMI, %d bytes received per GPU per SpMV%s"
-                                     % (op._plan[0], op.exchange_bytes,
-                                        "; interior rows overlap the exchange" if op._split else "")) if world > 1 else "single GPU",
+                                     % (op.exchange_mode, op.exchange_bytes,
+                                        "; %d interior rows overlap the exchange" % op.interior_rows if op.query("parts") > 1 else ""))
+                                    if world > 1 else "single GPU",
                        "knobs": args.knob},
             "achieved_hbm_GBps_per_gpu": round(achieved, 1),
             "spmv_kernel_ms": round(kern_ms, 5),
@@ -243,8 +279,8 @@ def main():
         # What the plan really streams: the analysis replaces the 4-byte column indices by 16-bit codes or, on locally
         # Toeplitz tiles, by one small record per tile; "achieved" / "frac" stay on the CRS algorithmic bytes.
         try:
-            h_ = handle if world == 1 else op.handle
-            if h_.query("window_codes"):
+            h_ = handle if world == 1 else None
+            if h_ is not None and h_.query("window_codes"):
                 tile_ = h_.query("tile"); tiles_ = h_.query("tiles")
                 pat_, code_, plain_ = h_.query("pattern_tiles"), h_.query("code_tiles"), h_.query("plain_tiles")
                 # per tile: 4 B mode word; 256 B window meta unless plain; 2 B per nonzero of code tiles; 672 B record of pattern
@@ -278,6 +314,8 @@ def main():
                                                              "FETCH_SIZE x2 per MI355X_MICROARCH.md)" % os.path.relpath(PMC_FILE, ROOT))
             except Exception:
                 pass
+        if xchg is not None:
+            out["exchange"] = xchg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

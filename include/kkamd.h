@@ -145,6 +145,45 @@ int kkamd_set_default(const char* key, int value);
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-GPU SpMV: the CrsMatrix is 1-D row-partitioned over the GPUs of one node, one process per GPU.  Rank r owns the row slab
+ * [row_offsets[r], row_offsets[r+1]) of A (LOCAL row_map, GLOBAL column indices), the matching slab of y and shard of x; one
+ * exchange of x entries per SpMV (RCCL over xGMI), no other communication.  The reference has no counterpart (upstream this is
+ * Tpetra's job); the local SpMV is kkamd_spmv.
+ *   exchange  0 auto (halo when it moves less than half of the all-gather), 1 halo (only the x ranges the slab's columns
+ *             touch, point to point), 2 all-gather (every shard to every rank);
+ *   overlap   1: rows that reference only the rank's own x entries are computed while the halo is in flight.
+ * Transport: by default RCCL, bound at run time from the librccl.so.1 already in the process; rank 0 obtains the 128-byte id
+ * with kkamd_dist_unique_id and the host's launcher (MPI, torch.distributed, a file) hands it to every rank.  A host that
+ * communicates otherwise passes its own kkamd_transport_t (both functions are stream-ordered; sizes in bytes).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct kkamd_dist_spmv kkamd_dist_spmv_t;
+typedef struct {
+  void* ctx;
+  /* every rank contributes bytes_per_rank bytes; d_recv receives world * bytes_per_rank bytes in rank order */
+  int (*all_gather)(void* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank, kkamd_stream_t stream);
+  /* one batch of point-to-point transfers: nsend sends and nrecv receives, matched by peer */
+  int (*exchange)(void* ctx, int nsend, const void* const* d_send, const int64_t* send_bytes, const int* send_peer, int nrecv,
+                  void* const* d_recv, const int64_t* recv_bytes, const int* recv_peer, kkamd_stream_t stream);
+} kkamd_transport_t;
+
+int kkamd_dist_unique_id(void* id128);
+int kkamd_dist_spmv_create(kkamd_dist_spmv_t** op, const kkamd_crs_t* A_local, const int64_t* row_offsets /* host, world + 1 */,
+                           int world, int rank, const void* id128 /* NULL with a transport or world == 1 */,
+                           const kkamd_transport_t* transport /* NULL = RCCL */, int algorithm, int exchange, int overlap,
+                           int vector_type, kkamd_stream_t stream);
+int kkamd_dist_spmv_destroy(kkamd_dist_spmv_t* op);
+/* x lives in a full-length buffer owned by the operator: *d_x_local is the rank's own window of it (a caller that keeps its x
+ * shard there never copies it), *d_x_full the whole buffer.  Either pointer argument may be NULL. */
+int kkamd_dist_spmv_x_local(kkamd_dist_spmv_t* op, void** d_x_local, void** d_x_full);
+/* y_shard := alpha * A_local * exchanged(x) + beta * y_shard.  d_x_shard may be the pointer of kkamd_dist_spmv_x_local (no copy)
+ * or any device buffer of the shard's length (copied in).  what: 0 the whole step, 1 the exchange only, 2 the local SpMV only
+ * (measurement aids: 1 and 2 split a step into its two costs). */
+int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_shard, double beta, void* d_y_shard, int what,
+                          kkamd_stream_t stream);
+/* "exchange" (0 local, 1 halo, 2 all-gather), "exchange_bytes" (received per SpMV), "interior_rows", "parts", "sends", "recvs" */
+int kkamd_dist_spmv_query(const kkamd_dist_spmv_t* op, const char* key, int64_t* value);
+
+/* ------------------------------------------------------------------------------------------------
  * SpGEMM.  Replaces Impl::SPGEMM_SYMBOLIC<...>::spgemm_symbolic and
  * Impl::SPGEMM_NUMERIC<...>::spgemm_numeric (sparse/impl/KokkosSparse_spgemm_symbolic_spec.hpp:72-126,
  * ..._numeric_spec.hpp:91-145; vendor precedent sparse/tpls/KokkosSparse_spgemm_symbolic_tpl_spec_decl.hpp:367-,

@@ -12,7 +12,18 @@ EXPORTS = [
     "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_sort_and_merge", "kkamd_transpose", "kkamd_spmv_plan_set", "kkamd_spmv_plan_query", "kkamd_set_default", "kkamd_spgemm_create",
     "kkamd_spgemm_destroy", "kkamd_spgemm_symbolic", "kkamd_spgemm_numeric", "kkamd_spgemm_get", "kkamd_sort_crs",
     "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows", "kkamd_bench_read",
+    "kkamd_dist_unique_id", "kkamd_dist_spmv_create", "kkamd_dist_spmv_destroy", "kkamd_dist_spmv_x_local", "kkamd_dist_spmv_apply",
+    "kkamd_dist_spmv_query",
 ]
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_int,
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_void_p)
+
+
+class Transport(C.Structure):
+    """kkamd_transport_t: how the multi-GPU SpMV moves x entries when it is not the built-in RCCL"""
+    _fields_ = [("ctx", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("exchange", EXCHANGE_FN)]
 
 
 class CrsDesc(C.Structure):
@@ -58,6 +69,12 @@ def bind(lib):
     lib.kkamd_gen_laplace.argtypes = [ci, ci, i64, i64, i64, vp, vp, vp, ci, ci, C.POINTER(i64), vp]
     lib.kkamd_gen_laplace_rows.argtypes = [ci, ci, i64, i64, i64, i64, i64, vp, vp, vp, ci, ci, C.POINTER(i64), vp]
     lib.kkamd_bench_read.argtypes = [vp, i64, ci, ci, ci, vp, vp]
+    lib.kkamd_dist_unique_id.argtypes = [vp]
+    lib.kkamd_dist_spmv_create.argtypes = [C.POINTER(vp), C.POINTER(CrsDesc), C.POINTER(i64), ci, ci, vp, C.POINTER(Transport), ci, ci, ci, ci, vp]
+    lib.kkamd_dist_spmv_destroy.argtypes = [vp]
+    lib.kkamd_dist_spmv_x_local.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.kkamd_dist_spmv_apply.argtypes = [vp, dbl, vp, dbl, vp, ci, vp]
+    lib.kkamd_dist_spmv_query.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("kkamd_last_error",):

@@ -137,11 +137,9 @@ static void dist_free(kkamd_dist_spmv* op) {
   if (!op) return;
   for (auto& p : op->parts) { if (p.plan) kkamd_spmv_plan_destroy(p.plan); if (p.d_rm) (void)hipFree(p.d_rm); }
   if (op->d_x_full) (void)hipFree(op->d_x_full);
-#ifndef KK_EMU
   if (op->ev_ready) (void)hipEventDestroy(op->ev_ready);
   if (op->ev_done) (void)hipEventDestroy(op->ev_done);
   if (op->comm_stream) (void)hipStreamDestroy(op->comm_stream);
-#endif
   if (op->own_comm && op->rccl_ctx.comm && rccl().ok) (void)rccl().CommDestroy(op->rccl_ctx.comm);
   delete op;
 }
@@ -318,13 +316,11 @@ int kkamd_dist_spmv_create(kkamd_dist_spmv_t** out, const kkamd_crs_t* A_local, 
   if (hipMalloc(&op->d_x_full, xbytes) != hipSuccess) return bail(kk::fail(KKAMD_ERR_ALLOC, "kkamd_dist_spmv_create: out of device memory for x (%zu bytes)", xbytes));
   // zero once: entries outside the slab's column range are never read, but must not be garbage NaNs for beta = 0 sanity checks
   if (hipMemsetAsync(op->d_x_full, 0, xbytes, st) != hipSuccess) return bail(kk::fail(KKAMD_ERR_HIP, "hipMemsetAsync failed"));
-#ifndef KK_EMU
   if (world > 1) {
     if (hipStreamCreateWithFlags(&op->comm_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&op->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&op->ev_done, hipEventDisableTiming) != hipSuccess)
       return bail(kk::fail(KKAMD_ERR_HIP, "kkamd_dist_spmv_create: could not create the communication stream"));
   }
-#endif
   rc = A_local->offset_type == KKAMD_I64 ? kk::dist_setup<int64_t>(op, exchange, overlap, st) : kk::dist_setup<int32_t>(op, exchange, overlap, st);
   if (rc) return bail(rc);
   *out = op;
@@ -366,41 +362,27 @@ int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_s
     if (d_x_shard && d_x_shard != x_local && mrows > 0)          // a solver that keeps its x in x_local skips this copy
       KK_HIP(hipMemcpyAsync(x_local, d_x_shard, (size_t)op->elem * (size_t)mrows, hipMemcpyDeviceToDevice, st));
     if (op->mode != 0) {
-#ifndef KK_EMU
       hipStream_t cs = op->comm_stream;
       KK_HIP(hipEventRecord(op->ev_ready, st));                  // x_local is in place, and earlier SpMVs are done with the halo
       KK_HIP(hipStreamWaitEvent(cs, op->ev_ready, 0));
-#else
-      hipStream_t cs = st;
-#endif
       kkamd_stream_t kcs = reinterpret_cast<kkamd_stream_t>(cs);
       if (op->mode == 2 && op->equal) rc = op->tr.all_gather(op->tr.ctx, x_local, op->d_x_full, (int64_t)op->elem * mrows, kcs);
       else rc = op->tr.exchange(op->tr.ctx, (int)op->send_peer.size(), op->send_ptr.data(), op->send_bytes.data(), op->send_peer.data(),
                                 (int)op->recv_peer.size(), op->recv_ptr.data(), op->recv_bytes.data(), op->recv_peer.data(), kcs);
       if (rc) return rc;
-#ifndef KK_EMU
       KK_HIP(hipEventRecord(op->ev_done, cs));
-#endif
     }
   }
   const bool split = op->parts.size() > 1;
   for (size_t i = 0; i < op->parts.size(); ++i) {
     // the interior (part 0 of a split slab) needs no halo entry and runs while the exchange is in flight
-    if (what != 2 && op->mode != 0 && (i == (split ? 1u : 0u))) {
-#ifndef KK_EMU
-      KK_HIP(hipStreamWaitEvent(st, op->ev_done, 0));
-#endif
-    }
+    if (what != 2 && op->mode != 0 && (i == (split ? 1u : 0u))) KK_HIP(hipStreamWaitEvent(st, op->ev_done, 0));
     if (what == 1) continue;
     auto& p = op->parts[i];
     if (p.A.num_rows == 0) continue;
     if ((rc = kkamd_spmv(p.plan, &p.A, 'N', alpha, op->d_x_full, beta, (char*)d_y_shard + (int64_t)op->elem * p.row0, vt, stream))) return rc;
   }
-  if (what != 2 && op->mode != 0 && split && op->parts.size() == 1) {
-#ifndef KK_EMU
-    KK_HIP(hipStreamWaitEvent(st, op->ev_done, 0));
-#endif
-  }
+  if (what == 1 && op->mode != 0) KK_HIP(hipStreamWaitEvent(st, op->ev_done, 0));     // exchange only: the caller's stream still waits for it
   return KKAMD_OK;
 }
 

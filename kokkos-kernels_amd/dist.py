@@ -1,28 +1,24 @@
-"""1-D row-partitioned SpMV across the GPUs of one node: rank r owns the contiguous row slab
-[offsets[r], offsets[r+1]) of A (local row_map, GLOBAL column indices), the matching slab of y and the
-matching shard of x.  One exchange step per SpMV: an all-gather of the x shards (RCCL over xGMI when the
-process group is "nccl"), then the local planned SpMV.  The reference has no distributed layer at all
-(SURVEY F2); this is the multi-GPU row of the scope table.
+"""1-D row-partitioned SpMV across the GPUs of one node -- a thin caller of the C ABI (kkamd_dist_spmv_*, include/kkamd.h,
+csrc/kk_dist.hip).  Rank r owns the contiguous row slab [offsets[r], offsets[r+1]) of A (local row_map, GLOBAL column
+indices), the matching slab of y and shard of x; the library exchanges the x entries a slab references (halo: grouped
+ncclSend / ncclRecv of the column range each slab touches; all-gather: every shard to every rank), overlaps the interior
+rows with the exchange, and runs the planned local SpMV.  What happens here:
 
-Exchange step.  "allgather": every rank receives every shard (what BASELINE.json's north star names).
-"halo" (default when it moves less than half of that): a rank only needs the x entries its slab's column
-indices reference -- for the column RANGE [cmin, cmax] of the slab it receives, from each peer, the piece of that
-range the peer owns (point-to-point RCCL send/recv, one batch per SpMV).  For a 1-D slab of a 3-D stencil that is
-one grid plane from each neighbour (2 x 600^2 x 8 B = 5.8 MB per rank at 600^3) instead of 1.5 GB; for a matrix
-whose slab touches every column it degenerates to the all-gather.  This is row N1 of SURVEY 8(f) (an importer
-built from the column set of each slab).
+  * GPU (torch backend, process group "nccl"): the library's built-in RCCL transport; rank 0 obtains the 128-byte RCCL id from
+    the library and torch.distributed broadcasts it -- the only thing torch.distributed does on the data path's behalf;
+  * CPU tests (emulator backend, process group "gloo"): the same library code with a kkamd_transport_t whose two callbacks run
+    the gloo collectives -- so the world-2 tests exercise the C implementation's exchange lists, overlap split and sequencing.
 
-Overlap (halo mode): rows whose columns all lie in the rank's own x range form the INTERIOR -- the longest contiguous
-run of such rows; the rows before and after it (one grid plane each for a stencil slab) are the boundary.  Interior,
-head and tail are zero-copy row-range views of the slab (rebased row_map, offset entries/values) with their own SpMV
-plans.  Per SpMV: start the point-to-point exchange, run the interior SpMV while the halo is in flight, wait, run the
-two boundary SpMVs.
+SpGEMM shards by rows of A with B replicated: no data-path communication (spgemm_row_slab)."""
+import ctypes as C
 
-One process per GPU (torch.distributed); no other data-path collective.
-"""
 import numpy as np
 
-from .sparse import SPMVHandle, spmv
+from . import _capi
+from ._capi import check
+from .sparse import _ALGOS, _scalar_type
+
+_EXCHANGE = {"auto": 0, "halo": 1, "allgather": 2}
 
 
 def slab_offsets(nrows, world, align=1):
@@ -57,200 +53,128 @@ def spgemm_row_slab(A_slab, B):
     return spgemm(A_slab, False, B, False)
 
 
+class _GlooTransport:
+    """TEST transport: kkamd_transport_t over a torch.distributed CPU process group (gloo).  "Device" pointers are host
+    pointers under the emulator backend."""
+
+    def __init__(self, group, world):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.world = torch, dist, group, world
+
+        def view(ptr, nbytes):
+            return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes),)))
+
+        def all_gather(ctx, d_send, d_recv, nbytes, stream):
+            try:
+                outs = [torch.empty(int(nbytes), dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(outs, view(d_send, nbytes).clone(), group=group)
+                view(d_recv, nbytes * world).copy_(torch.cat(outs))
+                return 0
+            except Exception as e:             # never raise through the C frame
+                print("gloo transport all_gather failed:", e, flush=True)
+                return 3
+
+        def exchange(ctx, nsend, d_send, send_bytes, send_peer, nrecv, d_recv, recv_bytes, recv_peer, stream):
+            try:
+                ops = [dist.P2POp(dist.isend, view(d_send[i], send_bytes[i]).clone(), int(send_peer[i]), group=group) for i in range(nsend)]
+                bufs = [torch.empty(int(recv_bytes[i]), dtype=torch.uint8) for i in range(nrecv)]
+                ops += [dist.P2POp(dist.irecv, bufs[i], int(recv_peer[i]), group=group) for i in range(nrecv)]
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                for i in range(nrecv):
+                    view(d_recv[i], recv_bytes[i]).copy_(bufs[i])
+                return 0
+            except Exception as e:
+                print("gloo transport exchange failed:", e, flush=True)
+                return 3
+
+        self._ag, self._ex = _capi.ALL_GATHER_FN(all_gather), _capi.EXCHANGE_FN(exchange)     # keep the callbacks alive
+        self.struct = _capi.Transport(None, self._ag, self._ex)
+
+
+class _DeviceView:
+    """a library-owned device buffer as something torch.as_tensor understands"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
 class DistSpmv:
     def __init__(self, A_local, offsets, rank, group=None, algo="SPMV_DEFAULT", to_backend=None, exchange="auto",
-                 overlap=True):
+                 overlap=True, dtype=np.float64):
         """A_local: CrsMatrix slab (numRows = offsets[rank+1]-offsets[rank], numCols = global).
         to_backend: converts a torch tensor to what the backend's ptr() accepts (identity for HBM tensors;
         tests on CPU/gloo pass `lambda t: t.numpy()` for the emulator backend)."""
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
-        self.A, self.offsets, self.rank, self.group = A_local, list(offsets), rank, group
+        self.A, self.offsets, self.rank, self.group = A_local, [int(o) for o in offsets], int(rank), group
         self.world = len(offsets) - 1
         assert A_local.numRows() == offsets[rank + 1] - offsets[rank]
         assert A_local.numCols() == offsets[-1], "column indices must be global"
-        self.handle = SPMVHandle(algo)
+        self.be = A_local.backend
+        self.lib = self.be.lib
         self.to_backend = to_backend or (lambda t: t)
-        sizes = np.diff(self.offsets)
-        self.equal = bool((sizes == sizes[0]).all())
-        self.max_shard = int(sizes.max())
-        self.x_full = None
-        self._pad = None
-        self.exchange = exchange          # "auto" | "halo" | "allgather"
-        self._plan = None                 # (mode, send list, recv list)
-        self.exchange_bytes = None        # bytes this rank receives per SpMV
-        self.algo = algo
-        self.overlap = overlap            # halo mode: interior rows computed while the halo is in flight
-        self._split = None                # [(handle, sub-matrix, row_begin, row_end)]: interior first, then boundary parts
-
-    def _entries_minmax(self):
-        ent = self.A.graph.entries
-        if self.A.nnz() == 0:
-            return 0, -1
-        if hasattr(ent, "min") and not isinstance(ent, np.ndarray):
-            return int(ent.min().item()), int(ent.max().item())
-        return int(ent.min()), int(ent.max())
-
-    def _setup_exchange(self, like):
-        """decide halo vs all-gather and build the per-peer segment lists (once per operator)"""
-        torch, dist = self.torch, self.dist
-        n, me, offs = self.offsets[-1], self.rank, self.offsets
-        item = like.element_size()
-        full_bytes = (n - (offs[me + 1] - offs[me])) * item
-        if self.world == 1:
-            self._plan = ("local", [], []); self.exchange_bytes = 0
-            return
-        cmin, cmax = self._entries_minmax()
-        mine = torch.tensor([cmin, cmax], dtype=torch.int64, device=like.device)
-        allr = torch.empty(2 * self.world, dtype=torch.int64, device=like.device)
-        dist.all_gather_into_tensor(allr, mine, group=self.group)
-        allr = allr.cpu().tolist()
-        recv, send = [], []
-        for p in range(self.world):
-            if p == me:
-                continue
-            lo, hi = max(cmin, offs[p]), min(cmax + 1, offs[p + 1])          # what I need from p
-            if hi > lo:
-                recv.append((p, lo, hi))
-            plo, phi = allr[2 * p], allr[2 * p + 1]
-            lo, hi = max(plo, offs[me]), min(phi + 1, offs[me + 1])          # what p needs from me
-            if hi > lo:
-                send.append((p, lo - offs[me], hi - offs[me]))
-        halo_bytes = sum(hi - lo for _, lo, hi in recv) * item
-        # every rank must take the same decision: all-reduce the largest halo fraction
-        frac = torch.tensor([halo_bytes / max(full_bytes, 1)], dtype=torch.float64, device=like.device)
-        dist.all_reduce(frac, op=dist.ReduceOp.MAX, group=self.group)
-        use_halo = self.exchange == "halo" or (self.exchange == "auto" and frac.item() < 0.5)
-        if use_halo:
-            self._plan = ("halo", send, recv); self.exchange_bytes = halo_bytes
-            if self.overlap:
-                self._setup_overlap()
-        else:
-            self._plan = ("allgather", [], []); self.exchange_bytes = full_bytes
-
-    def _setup_overlap(self):
-        """interior = longest contiguous run of rows that reference only this rank's own x entries"""
-        from .sparse import CrsMatrix
-        A, me0, me1 = self.A, self.offsets[self.rank], self.offsets[self.rank + 1]
-        m = A.numRows()
-        rm, ent = A.graph.row_map, A.graph.entries
-        is_np = isinstance(ent, np.ndarray)
-        if m == 0 or A.nnz() == 0:
-            return
-        outside = (ent < me0) | (ent >= me1)
-        if is_np:
-            cs = np.concatenate([[0], np.cumsum(outside, dtype=np.int64)])
-            per_row = cs[np.asarray(rm[1:], dtype=np.int64)] - cs[np.asarray(rm[:-1], dtype=np.int64)]
-            bad = np.nonzero(per_row)[0]
-        else:
-            torch = self.torch
-            cs = torch.zeros(ent.numel() + 1, dtype=torch.int32, device=ent.device)
-            torch.cumsum(outside, 0, dtype=torch.int32, out=cs[1:])
-            rml = rm.long()
-            per_row = cs[rml[1:]] - cs[rml[:-1]]
-            bad = torch.nonzero(per_row).flatten().cpu().numpy()
-            del cs, outside, per_row
-        if bad.size == 0:
-            return                                   # nothing depends on the halo
-        edges = np.concatenate([[-1], bad, [m]])
-        gaps = np.diff(edges) - 1
-        g = int(np.argmax(gaps))
-        r_lo, r_hi = int(edges[g]) + 1, int(edges[g + 1])
-        # the planned kernel wants 16-byte aligned entries / values: start the interior and the tail on rows whose
-        # first entry sits at a multiple of 4 (a misaligned view still works, through the slower no-analysis kernel)
-        def offset_of(r):
-            return int(rm[r]) if is_np else int(rm[r].item())
-        for _ in range(64):
-            if r_lo < r_hi and offset_of(r_lo) % 4:
-                r_lo += 1
-        for _ in range(64):
-            if r_hi > r_lo and offset_of(r_hi) % 4:
-                r_hi -= 1
-        if r_hi - r_lo < m // 2:
-            return                                   # not worth splitting
-        parts = []
-        for a, b in ((r_lo, r_hi), (0, r_lo), (r_hi, m)):
-            if b <= a:
-                continue
-            if is_np:
-                p0, p1 = int(rm[a]), int(rm[b])
-                sub_rm = (rm[a:b + 1] - rm[a]).astype(rm.dtype)
+        self.dtype = np.dtype(dtype)
+        self._transport = None
+        id_buf = None
+        tr_ptr = None
+        if self.world > 1:
+            if self.be.name == "torch":
+                # the library's RCCL transport: its id comes from rank 0 through the process group
+                ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    raw = (C.c_char * 128)()
+                    check(self.lib, self.lib.kkamd_dist_unique_id(raw))
+                    ident = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).cuda()
+                dist.broadcast(ident, src=0, group=group)
+                id_buf = (C.c_char * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
             else:
-                p0, p1 = int(rm[a].item()), int(rm[b].item())
-                sub_rm = (rm[a:b + 1] - rm[a]).contiguous()
-            sub = CrsMatrix(b - a, A.numCols(), sub_rm, ent[p0:p1], A.values[p0:p1], backend=A.backend)
-            parts.append((SPMVHandle(self.algo), sub, a, b))
-        self._split = parts
+                self._transport = _GlooTransport(group, self.world)
+                tr_ptr = C.byref(self._transport.struct)
+        offs = (C.c_int64 * (self.world + 1))(*self.offsets)
+        d = A_local.desc()
+        op = C.c_void_p()
+        vt = _capi.F64 if self.dtype == np.dtype(np.float64) else _capi.F32
+        check(self.lib, self.lib.kkamd_dist_spmv_create(C.byref(op), C.byref(d), offs, self.world, self.rank, id_buf, tr_ptr,
+                                                        _ALGOS[algo], _EXCHANGE[exchange], 1 if overlap else 0, vt, self.be.stream()))
+        self._op = op
+        self.exchange_mode = ("local", "halo", "allgather")[self.query("exchange")]
+        self.exchange_bytes = self.query("exchange_bytes")
+        self.interior_rows = self.query("interior_rows")
 
-    def _buffers(self, like):
-        if self.x_full is None:
-            n = self.offsets[-1]
-            # zero-filled once: entries outside the slab's column range are never read, but must not be garbage NaNs
-            self.x_full = self.torch.zeros(n, dtype=like.dtype, device=like.device)
-            if not self.equal:
-                self._pad = self.torch.empty(self.world * self.max_shard, dtype=like.dtype, device=like.device)
-        return self.x_full
+    def query(self, key):
+        v = C.c_int64(0)
+        check(self.lib, self.lib.kkamd_dist_spmv_query(self._op, key.encode(), C.byref(v)))
+        return int(v.value)
 
-    def gather_x(self, x_shard):
-        """make the x entries this rank's slab references available in the full-length buffer"""
-        x_full = self._buffers(x_shard)
-        if self._plan is None:
-            self._setup_exchange(x_shard)
-        mode, send, recv = self._plan
-        me0, me1 = self.offsets[self.rank], self.offsets[self.rank + 1]
-        if mode == "local":
-            x_full.copy_(x_shard)
-        elif mode == "halo":
-            x_full[me0:me1].copy_(x_shard)
-            dist = self.dist
-            ops = [dist.P2POp(dist.isend, x_shard[lo:hi], p, group=self.group) for p, lo, hi in send]
-            ops += [dist.P2POp(dist.irecv, x_full[lo:hi], p, group=self.group) for p, lo, hi in recv]
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-        elif self.equal:
-            self.dist.all_gather_into_tensor(x_full, x_shard, group=self.group)
-        else:
-            mine = self.torch.zeros(self.max_shard, dtype=x_shard.dtype, device=x_shard.device)
-            mine[: x_shard.numel()] = x_shard
-            self.dist.all_gather_into_tensor(self._pad, mine, group=self.group)
-            for r in range(self.world):
-                n = self.offsets[r + 1] - self.offsets[r]
-                x_full[self.offsets[r]: self.offsets[r + 1]] = self._pad[r * self.max_shard: r * self.max_shard + n]
-        return x_full
+    def x_local(self):
+        """the rank's own window of the operator's full-length x buffer: an x kept here is never copied by apply()"""
+        p = C.c_void_p()
+        check(self.lib, self.lib.kkamd_dist_spmv_x_local(self._op, C.byref(p), None))
+        n = self.offsets[self.rank + 1] - self.offsets[self.rank]
+        if self.be.name == "torch":
+            return self.torch.as_tensor(_DeviceView(p.value, n, "<f8" if self.dtype.itemsize == 8 else "<f4"), device="cuda")
+        ct = C.c_double if self.dtype.itemsize == 8 else C.c_float
+        return self.torch.from_numpy(np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)))
 
-    def apply(self, alpha, x_shard, beta, y_shard, events=None):
-        """y_shard := alpha * A_local * exchanged(x) + beta * y_shard.  events = (start, end): recorded around the
-        compute part (local SpMV kernels) when given."""
-        if self._plan is None:
-            self._buffers(x_shard)
-            self._setup_exchange(x_shard)
-        if self._plan[0] == "halo" and self._split:
-            x_full = self._buffers(x_shard)
-            _, send, recv = self._plan
-            me0, me1 = self.offsets[self.rank], self.offsets[self.rank + 1]
-            x_full[me0:me1].copy_(x_shard)
-            dist = self.dist
-            ops = [dist.P2POp(dist.isend, x_shard[lo:hi], p, group=self.group) for p, lo, hi in send]
-            ops += [dist.P2POp(dist.irecv, x_full[lo:hi], p, group=self.group) for p, lo, hi in recv]
-            reqs = dist.batch_isend_irecv(ops) if ops else []
-            xb = self.to_backend(x_full)
-            if events:
-                events[0].record()
-            h, sub, a, b = self._split[0]                        # interior: needs no halo entry
-            spmv(h, "N", alpha, sub, xb, beta, self.to_backend(y_shard[a:b]))
-            for req in reqs:
-                req.wait()
-            for h, sub, a, b in self._split[1:]:
-                spmv(h, "N", alpha, sub, xb, beta, self.to_backend(y_shard[a:b]))
-            if events:
-                events[1].record()
-            return y_shard
-        x_full = self.gather_x(x_shard)
+    def apply(self, alpha, x_shard, beta, y_shard, events=None, what=0):
+        """y_shard := alpha * A_local * exchanged(x) + beta * y_shard.  events = (start, end) are recorded around the step when
+        given; what = 1 runs the exchange only, 2 the local SpMV only (measurement)."""
         if events:
             events[0].record()
-        spmv(self.handle, "N", alpha, self.A, self.to_backend(x_full), beta, self.to_backend(y_shard))
+        check(self.lib, self.lib.kkamd_dist_spmv_apply(self._op, float(alpha), self.be.ptr(self.to_backend(x_shard)), float(beta),
+                                                       self.be.ptr(self.to_backend(y_shard)), int(what), self.be.stream()))
         if events:
             events[1].record()
         return y_shard
+
+    def __del__(self):
+        try:
+            if self._op:
+                self.lib.kkamd_dist_spmv_destroy(self._op)
+        except Exception:
+            pass
+        self._op = None

@@ -1,6 +1,7 @@
-"""world_size-2 test of the multi-GPU path (kokkos-kernels_amd/dist.py) on CPU: torch.distributed with the
-gloo backend does the all-gather of the x shards; the local SpMV runs the real kernel sources under the SIMT
-emulator (tests/emu).  Checks the 1-D row partition (local row_map, global columns), equal and ragged slabs."""
+"""world_size-2 test of the multi-GPU path on CPU: the C implementation (csrc/kk_dist.hip, built under the SIMT emulator of
+tests/emu) with a kkamd_transport_t whose two callbacks run gloo collectives (dist._GlooTransport) in place of RCCL; the
+local SpMV runs the real kernel sources.  Checks the 1-D row partition (local row_map, global columns), equal and ragged
+slabs, the halo lists, the interior / boundary split and the zero-copy x window."""
 import os
 import sys
 
@@ -44,11 +45,16 @@ def _worker(rank, world, port, ragged, exchange, ret):
     op = DistSpmv(A, offs, rank, to_backend=lambda t: t.numpy(), exchange=exchange)
     xs = torch.from_numpy(x[r0:r1].copy()); ys = torch.from_numpy(y0[r0:r1].copy())
     op.apply(2.0, xs, 0.5, ys)
-    op.apply(1.0, xs, 0.0, ys.clone())        # second call reuses the plan and gather buffers
+    op.apply(1.0, xs, 0.0, ys.clone())        # second call reuses the plans and the x buffer
     exp = oracle.spmv_serial("N", A0, 2.0, x, 0.5, y0.copy())[r0:r1]
     err = float(np.abs(ys.numpy() - exp).max())
-    tol = oracle.spmv_max_error(A0, 2.0, 0.5, max_val=32.0)
-    ret[rank] = (ok_gen, err, tol, op._plan[0], op.exchange_bytes, [(a, b) for _, _, a, b in (op._split or [])])
+    # x kept in the operator's own window (no copy), NaN-seeded y overwritten with beta = 0
+    xl = op.x_local(); xl.copy_(torch.from_numpy(3.0 * x[r0:r1]))
+    y2 = torch.full((r1 - r0,), float("nan"), dtype=torch.float64)
+    op.apply(1.0, xl, 0.0, y2)
+    err = max(err, float(np.abs(y2.numpy() - oracle.spmv_serial("N", A0, 3.0, x, 0.0, np.zeros(n))[r0:r1]).max()))
+    tol = oracle.spmv_max_error(A0, 3.0, 0.5, max_val=32.0)
+    ret[rank] = (ok_gen, err, tol, op.exchange_mode, op.exchange_bytes, op.interior_rows, op.query("parts"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,7 +70,7 @@ def test_row_partitioned_spmv_world2(ragged, exchange):
         mp.spawn(_worker, args=(world, port, ragged, exchange, ret), nprocs=world, join=True)
         assert len(ret) == world
         for r in range(world):
-            ok_gen, err, tol, mode, nbytes, split = ret[r]
+            ok_gen, err, tol, mode, nbytes, interior, parts = ret[r]
             assert ok_gen, "slab generator mismatch on rank %d" % r
             assert err <= tol, "rank %d: %g > %g" % (r, err, tol)
             if exchange == "auto" and not ragged:
@@ -72,9 +78,8 @@ def test_row_partitioned_spmv_world2(ragged, exchange):
                 assert mode == "halo" and nbytes == 72 * 8, (mode, nbytes)
                 # interior = every plane that does not touch the neighbour's plane, computed while the halo is in flight
                 planes = 4 if r == 0 else 3
-                lo, hi = (0, (planes - 1) * 72) if r == 0 else (72, planes * 72)
                 # (boundaries may move a few rows inward so the views start on 16-byte aligned entries)
-                assert split and 0 <= split[0][0] - lo <= 8 and 0 <= hi - split[0][1] <= 8, split
+                assert parts == 2 and (planes - 1) * 72 - 16 <= interior <= (planes - 1) * 72, (parts, interior)
             if exchange == "allgather":
                 assert mode == "allgather"
 
