@@ -63,6 +63,19 @@ template <class T> __device__ __forceinline__ T group_sum(T v, int width) {
   return v;
 }
 
+// a device buffer that frees itself (host-side temporaries of the analysis; error paths return early)
+struct DevBuf {
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { reset(); }
+  hipError_t alloc(size_t bytes) { reset(); return hipMalloc(&p, bytes ? bytes : 1); }
+  void reset() { if (p) { (void)hipFree(p); p = nullptr; } }
+  void* release() { void* q = p; p = nullptr; return q; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 // Profiling ranges with the reference's label strings (Kokkos::Profiling::pushRegion at sparse/src/KokkosSparse_spmv.hpp:261-266,
 // sparse/tpls/KokkosSparse_spmv_tpl_spec_decl.hpp:411-414, ...spgemm_symbolic_tpl_spec_decl.hpp:343-344): emitted as roctx
 // ranges, so rocprofv3 --marker-trace shows "KokkosSparse::spmv[TPL_KKAMD,double]" around the kernels.  libroctx64 is

@@ -40,6 +40,8 @@
 #include <string>
 #include <type_traits>
 
+#define KK_VERBOSE(...) do { printf(__VA_ARGS__); fflush(stdout); } while (0)
+
 // Measurement build (-DKK_ABLATE, tools/ only): ablation bits reach the dense-row kernels through an extra argument; in the
 // product build the argument does not exist and every KK_DBG(bit) folds to false.
 #ifdef KK_ABLATE
@@ -92,6 +94,8 @@ static SpgemmTuning g_spgemm;
 
 struct BinLimits { int64_t lim[kNumBins - 1]; };   // size <= lim[b] -> bin b  (lim[0] = 0)
 static const BinLimits kSymLimits = {{0, (kSymWaveTable * 2) / 3, kSymBlkS / 2, kSymBlkL / 2}};
+static const BinLimits kSymLimitsC = {{0, (1024 * 2) / 3, 4096 / 2, 16384 / 2}};     // compressed symbolic (keys + masks: smaller tables)
+static const BinLimits kAllDense = {{0, 0, 0, 0}};                                   // every non-empty row in the last bin
 static const BinLimits kNumLimits = {{0, kWaveTable / 2, kNumBlkS / 2, (kNumBlkL * 2) / 3}};
 // B sorted: everything above the small block table goes to the column + windowed value kernels (no 8192-slot bitonic sort)
 static const BinLimits kNumLimitsSorted = {{0, kWaveTable / 2, kWaveTable / 2, kWaveTable / 2}};
@@ -112,7 +116,8 @@ template <class OffT>
 __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const OffT* __restrict__ rmA,
                                                               const int32_t* __restrict__ entA,
                                                               const OffT* __restrict__ rmB, int64_t* __restrict__ flops,
-                                                              unsigned long long* __restrict__ stats /*[0]=total,[1]=max*/) {
+                                                              unsigned long long* __restrict__ stats /*[0]=total,[1]=max*/,
+                                                              const OffT* __restrict__ endB = nullptr) {
   __shared__ unsigned long long s_sum, s_max;
   if (threadIdx.x == 0) { s_sum = 0; s_max = 0; }
   __syncthreads();
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
     if (row < m)
       for (int64_t a = (int64_t)rmA[row] + lane; a < (int64_t)rmA[row + 1]; a += 8) {
         const int32_t c = entA[a];
-        f += (long long)rmB[c + 1] - (long long)rmB[c];
+        f += (long long)(endB ? endB[c] : rmB[c + 1]) - (long long)rmB[c];
       }
     f = group_sum(f, 8);
     if (row < m && lane == 0) { flops[row] = f; sum += f; mx = f > mx ? f : mx; }
@@ -312,14 +317,15 @@ struct NoVals {};
 template <int NT, class OffT, class VT, class F>
 __device__ __forceinline__ void flat_products_impl(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                    const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
-                                                   const VT* __restrict__ valB, FlatScratch<NT>& sc, F f) {
+                                                   const VT* __restrict__ valB, FlatScratch<NT>& sc, F f,
+                                                   const OffT* __restrict__ endB = nullptr) {
   constexpr bool kVals = !std::is_same<VT, NoVals>::value;
   const int t = threadIdx.x;
   const int64_t a_beg = (int64_t)rmA[row], a_end = (int64_t)rmA[row + 1];
   for (int64_t chunk = a_beg; chunk < a_end; chunk += NT) {
     const int n = (int)(a_end - chunk < NT ? a_end - chunk : NT);
     long long len = 0, b0 = 0;
-    if (t < n) { const int32_t c = entA[chunk + t]; b0 = (long long)rmB[c]; len = (long long)rmB[c + 1] - b0; }
+    if (t < n) { const int32_t c = entA[chunk + t]; b0 = (long long)rmB[c]; len = (long long)(endB ? endB[c] : rmB[c + 1]) - b0; }
     long long tot;
     const long long excl = block_exclusive_scan_n<long long, NT>(len, &tot, sc.wave);
     if (t < n) { sc.pre[t] = excl; sc.b0[t] = b0; }
@@ -361,8 +367,8 @@ __device__ __forceinline__ void flat_products_impl(int64_t row, const OffT* __re
 template <int NT, class OffT, class F>
 __device__ __forceinline__ void flat_products(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                               const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
-                                              FlatScratch<NT>& sc, F f) {
-  flat_products_impl<NT, OffT, NoVals>(row, rmA, entA, rmB, entB, (const NoVals*)nullptr, sc, f);
+                                              FlatScratch<NT>& sc, F f, const OffT* __restrict__ endB = nullptr) {
+  flat_products_impl<NT, OffT, NoVals>(row, rmA, entA, rmB, entB, (const NoVals*)nullptr, sc, f, endB);
 }
 // f(a, column, value of B)
 template <int NT, class OffT, class VT, class F>
@@ -380,7 +386,8 @@ struct WaveFlatScratch { int pre[65]; long long b0[64]; };
 template <class OffT, class VT, class F>
 __device__ __forceinline__ void wave_flat_products(bool active, int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                    const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
-                                                   const VT* __restrict__ valB, int lane, WaveFlatScratch& sc, F f) {
+                                                   const VT* __restrict__ valB, int lane, WaveFlatScratch& sc, F f,
+                                                   const OffT* __restrict__ endB = nullptr) {
   constexpr bool kVals = !std::is_same<VT, NoVals>::value;
   int64_t a_beg = 0, a_end = 0;
   if (active) { a_beg = (int64_t)rmA[row]; a_end = (int64_t)rmA[row + 1]; }
@@ -388,7 +395,7 @@ __device__ __forceinline__ void wave_flat_products(bool active, int64_t row, con
     const int n = (int)(a_end - chunk < 64 ? a_end - chunk : 64);
     long long b0 = 0;
     int len = 0;
-    if (lane < n) { const int32_t c = entA[chunk + lane]; b0 = (long long)rmB[c]; len = (int)((long long)rmB[c + 1] - b0); }
+    if (lane < n) { const int32_t c = entA[chunk + lane]; b0 = (long long)rmB[c]; len = (int)((long long)(endB ? endB[c] : rmB[c + 1]) - b0); }
     int inc = len;
     for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(inc, (unsigned)o, 64); if (lane >= o) inc += nb; }
     const int tot = __shfl(inc, 63, 64);
@@ -419,10 +426,110 @@ __device__ __forceinline__ void wave_flat_products(bool active, int64_t row, con
       for (int u = 0; u < kProdUnroll; ++u)
         if (col[u] >= 0) {
           if constexpr (kVals) f(chunk + seg[u], col[u], bv[u]);
-          else f(chunk + seg[u], (int64_t)0, col[u]);
+          else f(chunk + seg[u], (int64_t)(sc.b0[seg[u]] + (base + u * 64 + lane - sc.pre[seg[u]])), col[u]);
         }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B compression for the symbolic phase (K9 analogue: sparse/impl/KokkosSparse_spgemm_impl_compression.hpp:400-636; layout note
+// SURVEY A5).  Columns are grouped into SETS of 32 consecutive columns: set index = column >> 5, mask bit = column & 31.  Row
+// i's (set, mask) pairs are written from the ORIGINAL start row_map(B)[i]; end[i] marks where they stop.  On matrices whose
+// rows hold runs of neighbouring columns (stencils: three neighbours in x per grid line) the symbolic phase then inserts a
+// third as many keys; on matrices without such runs (R-MAT) compression buys nothing and is dropped: it is kept only when
+// it removes at least 15 % of the symbolic work (sparse/impl/KokkosSparse_spgemm_impl_def.hpp:81-127, cut-off 0.85).
+// Needs column-sorted rows of B (a set is a run); the masks are OR-ed with atomics into a zeroed array, so lanes may split a
+// row anywhere.  8 lanes per row, each a contiguous piece.
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_compress_kernel(int64_t n, const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                                 int32_t* __restrict__ setB, unsigned* __restrict__ maskB,
+                                                                 OffT* __restrict__ endB) {
+  const int lane = threadIdx.x & 7;
+  for (int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 8; row < n; row += (int64_t)gridDim.x * (kBlock / 8)) {   // uniform per 8-lane group
+    const int64_t b = (int64_t)rmB[row], e = (int64_t)rmB[row + 1], len = e - b;
+    const int64_t per = (len + 7) / 8;
+    const int64_t j0 = b + lane * per, j1 = (j0 + per < e) ? j0 + per : e;
+    int starts = 0;
+    for (int64_t j = j0; j < j1; ++j) starts += (j == b || (entB[j] >> 5) != (entB[j - 1] >> 5)) ? 1 : 0;
+    int incl = starts;                                          // inclusive scan over the row's 8 lanes
+    for (int o = 1; o < 8; o <<= 1) { const int v = __shfl_up(incl, (unsigned)o, 8); if (lane >= o) incl += v; }
+    const int total = __shfl(incl, 7, 8);
+    int64_t pos = b + (incl - starts) - 1;                      // position of the set the piece's first entry belongs to (if it continues one)
+    for (int64_t j = j0; j < j1; ++j) {
+      const int c = entB[j];
+      if (j == b || (c >> 5) != (entB[j - 1] >> 5)) { ++pos; setB[pos] = c >> 5; }
+      atomicOr(&maskB[pos], 1u << (c & 31));
+    }
+    if (lane == 0) endB[row] = (OffT)(b + total);
+  }
+}
+
+// keys = set indices, masks OR-ed per key; the row's nnz is the number of mask bits
+__device__ __forceinline__ void hash_insert_or(int* keys, unsigned* masks, int mask, int key, unsigned bits) {
+  int h = (int)(((unsigned)key * (unsigned)kHashMul) & (unsigned)mask);
+  while (true) {
+    const int k = keys[h];
+    if (k == key) { atomicOr(&masks[h], bits); return; }
+    if (k == -1) {
+      const int old = atomicCAS(&keys[h], -1, key);
+      if (old == -1 || old == key) { atomicOr(&masks[h], bits); return; }
+    }
+    h = (h + 1) & mask;
+  }
+}
+constexpr int kSymWaveTableC = 1024;       // compressed symbolic: keys + masks, 8 KB per wave
+constexpr int kSymBlkSC = 4096, kSymBlkLC = 16384;
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_symc_wave_kernel(int64_t nbin, const int32_t* __restrict__ perm,
+                                                                  const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                  const OffT* __restrict__ rmB, const OffT* __restrict__ endB,
+                                                                  const int32_t* __restrict__ setB, const unsigned* __restrict__ maskB,
+                                                                  OffT* __restrict__ counts) {
+  constexpr int H = kSymWaveTableC;
+  __shared__ int tab[kBlock / 64][H];
+  __shared__ unsigned msk[kBlock / 64][H];
+  __shared__ WaveFlatScratch s_wf[kBlock / 64];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
+  for (int i = lane; i < H; i += 64) { tab[w][i] = -1; msk[w][i] = 0u; }
+  __syncthreads();
+  const bool active = idx < nbin;
+  const int64_t row = active ? (int64_t)perm[idx] : 0;
+  int* mytab = tab[w]; unsigned* mymsk = msk[w];
+  wave_flat_products<OffT, NoVals>(active, row, rmA, entA, rmB, setB, (const NoVals*)nullptr, lane, s_wf[w],
+                                   [&](int64_t, int64_t j, int c) { hash_insert_or(mytab, mymsk, H - 1, c, maskB[j]); }, endB);
+  KK_WAVE_SYNC();
+  int cnt = 0;
+  for (int i = lane; i < H; i += 64) cnt += __popc(mymsk[i]);
+  cnt = group_sum(cnt, 64);
+  if (active && lane == 0) counts[row] = (OffT)cnt;
+}
+template <class OffT, int H, int NT>
+__global__ __launch_bounds__(NT) void spgemm_symc_block_kernel(int64_t nbin, const int32_t* __restrict__ perm,
+                                                                   const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                   const OffT* __restrict__ rmB, const OffT* __restrict__ endB,
+                                                                   const int32_t* __restrict__ setB, const unsigned* __restrict__ maskB,
+                                                                   OffT* __restrict__ counts) {
+  KK_DYN_SMEM(int, dyn);                     // [H keys][H masks]
+  int* tab = dyn; unsigned* msk = reinterpret_cast<unsigned*>(dyn + H);
+  __shared__ int s_count;
+  __shared__ FlatScratch<NT> s_flat;
+  const int t = threadIdx.x;
+  const int64_t row = perm[blockIdx.x];
+  for (int i = t; i < H; i += NT) { tab[i] = -1; msk[i] = 0u; }
+  if (t == 0) s_count = 0;
+  __syncthreads();
+  flat_products<NT, OffT>(row, rmA, entA, rmB, setB, s_flat,
+                          [&](int64_t, int64_t j, int c) { hash_insert_or(tab, msk, H - 1, c, maskB[j]); }, endB);
+  __syncthreads();
+  int cnt = 0;
+  for (int i = t; i < H; i += NT) cnt += __popc(msk[i]);
+  cnt = group_sum(cnt, 64);
+  if ((t & 63) == 0 && cnt) atomicAdd(&s_count, cnt);
+  __syncthreads();
+  if (t == 0) counts[row] = (OffT)s_count;
+  (void)nbin;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,7 +593,9 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
                                                                         const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
                                                                         OffT* __restrict__ counts, const OffT* __restrict__ rmC,
                                                                         int32_t* __restrict__ entC, int64_t k, int win_bits,
-                                                                        int sg_log2, int force_chunked KK_DBG_PARAM) {
+                                                                        int sg_log2, int force_chunked, const OffT* __restrict__ endB,
+                                                                        const unsigned* __restrict__ maskB KK_DBG_PARAM) {
+  // endB / maskB (symbolic count only): B is compressed -- entB holds set indices, a product ORs its 32-column mask into the bitmap
   KK_DYN_SMEM(kk_u64, bm);
   __shared__ int s_min, s_max;
   __shared__ int s_wave[kDenseBlock / 64];
@@ -502,7 +611,16 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
     if (t == 0) { s_min = INT_MAX; s_max = -1; }
     __syncthreads();
     int cmin = INT_MAX, cmax = -1;
-    if (!KK_DBG(2)) flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int cb) {
+    if (maskB) {
+      flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t j, int sb) {
+        const int64_t c64 = (int64_t)sb * 32 - c0;               // windows are multiples of 64 columns: a set never straddles one
+        if (c64 >= 0 && c64 < nbits) {
+          const int c = (int)c64;
+          atomicOr(&bm[c >> 6], (kk_u64)maskB[j] << (c & 63));
+          cmin = c < cmin ? c : cmin; cmax = (c + 31 < nbits ? c + 31 : nbits - 1) > cmax ? (c + 31 < nbits ? c + 31 : nbits - 1) : cmax;
+        }
+      }, endB);
+    } else if (!KK_DBG(2)) flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int cb) {
       const int64_t c64 = (int64_t)cb - c0;
       if (c64 >= 0 && c64 < nbits) {
         const int c = (int)c64;
@@ -1026,6 +1144,13 @@ struct kkamd_spgemm_handle {
   bool dense_lds = false;          // decided when the numeric bins are made
   int64_t n_dense_lds = 0;         // leading rows of the dense bin taken by the LDS value kernel,
   int64_t n_dense_hub_lds = 0;     // then rows for the LDS hub kernel; the rest accumulate in HBM
+  // options (kkamd_spgemm_set; the reference's SPGEMMHandle / KokkosKernelsHandle setters)
+  int algorithm = 0;               // 0 hash accumulators in LDS (SPGEMM_KK and its aliases), 1 dense accumulator numeric (SPGEMM_KK_DENSE)
+  int compression = 1;             // symbolic phase: 0 never compress B, 1 compress and keep it if it pays (default), 2 always keep it
+  double compression_cutoff = 0.85;  // kept when compressed work <= cutoff * original work (impl_compression.hpp:718)
+  int verbose = 0;
+  bool compressed = false;         // what the last symbolic call did
+  int64_t compressed_mults = 0;
 };
 
 namespace kk {
@@ -1060,7 +1185,8 @@ static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLi
 // one workgroup per dense row; dynamic LDS = the bitmap window
 template <class OffT, bool EMIT>
 static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA, const int32_t* entA, const OffT* rmB,
-                             const int32_t* entB, OffT* counts, const OffT* rmC, int32_t* entC, int64_t k, int sg, hipStream_t st) {
+                             const int32_t* entB, OffT* counts, const OffT* rmC, int32_t* entC, int64_t k, int sg, hipStream_t st,
+                             const OffT* endB = nullptr, const unsigned* maskB = nullptr) {
   int64_t win = g_spgemm.win_bits;
   if (win > k) win = ceil_div(k, 64) * 64;
   const size_t smem = (size_t)(win / 8);
@@ -1069,7 +1195,7 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
   KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,
-            rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked KK_DBG_ARG);
+            rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked, endB, maskB KK_DBG_ARG);
   return KKAMD_OK;
 }
 
@@ -1090,37 +1216,92 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   unsigned long long h_stats[2] = {0, 0};
   KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
-  KK_HIP(hipFree(d_stats));
   h->mults = (int64_t)h_stats[0]; h->max_row_flops = (int64_t)h_stats[1];
   h->sg_log2 = pick_sg_log2(nnzB, n);
-
-  BinOffsets off;
-  int rc = make_bins(m, h->d_sizes, k, kSymLimits, h->d_perm, &off, st);   // a C row cannot exceed k columns
-  if (rc) return rc;
-  const int sg = h->sg_log2;
-  auto nb = [&](int b) { return off.off[b + 1] - off.off[b]; };
-  if (nb(1)) KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
-                       (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, sg);
-  if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
-                       (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
-  if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
-                       (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
-  if (nb(4)) {
-    if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, entB, rmC, (const OffT*)nullptr,
-                                             (int32_t*)nullptr, k, sg, st))) return rc;
-  }
-  // sortedness of B decides how the numeric phase handles dense rows
+  int rc;
+  // sortedness of B decides how the numeric phase handles dense rows, and whether B can be compressed
   {
-    int* d_flag = nullptr; int h_flag = 0;
-    KK_HIP(hipMalloc((void**)&d_flag, sizeof(int)));
+    DevBuf flag; int h_flag = 0;
+    KK_HIP(flag.alloc(sizeof(int)));
+    int* d_flag = flag.as<int>();
     KK_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
     const int64_t nbk = ceil_div(n * 8, kBlock);
     KK_LAUNCH((rows_sorted_kernel<OffT>), (unsigned)(nbk < 8192 ? nbk : 8192), kBlock, 0, st, n, rmB, entB, d_flag);
     KK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
-    KK_HIP(hipFree(d_flag));
     h->b_sorted = h_flag == 0;
   }
+  // B compression (a18): 32-column sets with bit masks; kept when it removes >= 15 % of the symbolic insertions
+  DevBuf setB_b, maskB_b, endB_b;
+  h->compressed = false; h->compressed_mults = h->mults;
+  if (h->compression && h->b_sorted && nnzB > 0 && h->mults > 0 &&
+      setB_b.alloc(sizeof(int32_t) * (size_t)nnzB) == hipSuccess && maskB_b.alloc(sizeof(unsigned) * (size_t)nnzB) == hipSuccess &&
+      endB_b.alloc(sizeof(OffT) * (size_t)n) == hipSuccess) {
+    int32_t* d_set = setB_b.as<int32_t>(); unsigned* d_mask = maskB_b.as<unsigned>(); OffT* d_end = endB_b.as<OffT>();
+    KK_HIP(hipMemsetAsync(d_mask, 0, sizeof(unsigned) * (size_t)nnzB, st));
+    const int64_t nbk = ceil_div(n * 8, kBlock);
+    KK_LAUNCH((spgemm_compress_kernel<OffT>), (unsigned)(nbk < 65536 ? nbk : 65536), kBlock, 0, st, n, rmB, entB, d_set, d_mask, d_end);
+    KK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), st));
+    DevBuf cflops;                                              // compressed insertions per row, into a scratch copy first
+    if (cflops.alloc(sizeof(int64_t) * (size_t)m) == hipSuccess) {
+      int64_t* d_cf = cflops.as<int64_t>();
+      const int64_t nbf = ceil_div(m * 8, kBlock);
+      KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbf < 4096 ? nbf : 4096), kBlock, 0, st, m, rmA, entA, rmB, d_cf, d_stats, (const OffT*)d_end);
+      KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
+      KK_HIP(hipStreamSynchronize(st));
+      h->compressed_mults = (int64_t)h_stats[0];
+      if (h->compression == 2 || (double)h->compressed_mults <= h->compression_cutoff * (double)h->mults) {
+        KK_HIP(hipMemcpyAsync(h->d_sizes, d_cf, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToDevice, st));    // bin by the compressed work
+        h->compressed = true;
+      }
+    }
+  } else {
+    (void)hipGetLastError();
+  }
+  KK_HIP(hipFree(d_stats)); d_stats = nullptr;
+  if (h->verbose)
+    KK_VERBOSE("\tkkamd spgemm symbolic: m %lld n %lld k %lld, multiplications %lld (max per row %lld), B %s, compression %s (%.3f of the work)\n",
+           (long long)m, (long long)n, (long long)k, (long long)h->mults, (long long)h->max_row_flops, h->b_sorted ? "sorted" : "unsorted",
+           h->compressed ? "kept" : (h->compression ? "dropped" : "off"), h->mults ? (double)h->compressed_mults / (double)h->mults : 1.0);
+
+  BinOffsets off;
+  const int sg = h->sg_log2;
+  auto nb = [&](int b) { return off.off[b + 1] - off.off[b]; };
+  if (h->compressed) {
+    const int32_t* setB = setB_b.as<int32_t>(); const unsigned* maskB = maskB_b.as<unsigned>(); const OffT* endB = endB_b.as<OffT>();
+    if ((rc = make_bins(m, h->d_sizes, (k + 31) / 32, kSymLimitsC, h->d_perm, &off, st))) return rc;     // a C row has at most k / 32 sets
+    if (nb(1)) KK_LAUNCH((spgemm_symc_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
+                         (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, endB, setB, maskB, rmC);
+    if (nb(2)) KK_LAUNCH((spgemm_symc_block_kernel<OffT, kSymBlkSC, kBlock>), (unsigned)nb(2), kBlock, (size_t)kSymBlkSC * 8, st, nb(2),
+                         (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, endB, setB, maskB, rmC);
+    if (nb(3)) {
+#ifndef KK_EMU
+      KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_symc_block_kernel<OffT, kSymBlkLC, kDenseBlock>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kSymBlkLC * 8));
+#endif
+      KK_LAUNCH((spgemm_symc_block_kernel<OffT, kSymBlkLC, kDenseBlock>), (unsigned)nb(3), kDenseBlock, (size_t)kSymBlkLC * 8, st, nb(3),
+                (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, endB, setB, maskB, rmC);
+    }
+    if (nb(4)) {
+      if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, setB, rmC, (const OffT*)nullptr,
+                                               (int32_t*)nullptr, k, sg, st, endB, maskB))) return rc;
+    }
+  } else {
+    if ((rc = make_bins(m, h->d_sizes, k, kSymLimits, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
+    if (nb(1)) KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
+                         (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, sg);
+    if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
+                         (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
+    if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
+                         (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
+    if (nb(4)) {
+      if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, entB, rmC, (const OffT*)nullptr,
+                                               (int32_t*)nullptr, k, sg, st))) return rc;
+    }
+  }
+  if (h->verbose)
+    KK_VERBOSE("\tkkamd spgemm symbolic bins (rows): empty %lld, wave %lld, block-small %lld, block-large %lld, bitmap %lld\n",
+           (long long)nb(0), (long long)nb(1), (long long)nb(2), (long long)nb(3), (long long)nb(4));
   hipError_t e = hipGetLastError();
   rc = (e == hipSuccess) ? exclusive_scan_inplace<OffT>(rmC, m + 1, st) : fail(KKAMD_ERR_HIP, "spgemm symbolic launch failed: %s", hipGetErrorString(e));
   OffT total = 0;
@@ -1144,8 +1325,11 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   if (!h->numeric_bins_ready) {
     const int64_t nbk = ceil_div(m, kBlock);
     KK_LAUNCH((spgemm_rowsize_kernel<OffT>), (unsigned)(nbk < 65536 ? nbk : 65536), kBlock, 0, st, m, rmC, h->d_sizes);
-    h->dense_lds = h->b_sorted && !g_spgemm.force_unsorted;
-    if ((rc = make_bins(m, h->d_sizes, INT64_MAX, h->dense_lds ? kNumLimitsSorted : kNumLimits, h->d_perm, &h->num_off, st))) return rc;
+    // SPGEMM_KK_DENSE (a21, sparse/impl/KokkosSparse_spgemm_impl_speed.hpp:28-150): every row accumulates into a k-wide dense
+    // accumulator (here: in HBM, one per concurrently processed row) instead of an LDS hash table
+    const bool dense_alg = h->algorithm == 1;
+    h->dense_lds = h->b_sorted && !g_spgemm.force_unsorted && !dense_alg;
+    if ((rc = make_bins(m, h->d_sizes, INT64_MAX, dense_alg ? kAllDense : (h->dense_lds ? kNumLimitsSorted : kNumLimits), h->d_perm, &h->num_off, st))) return rc;
     h->n_dense_lds = 0; h->n_dense_hub_lds = 0;
     const int64_t nd = h->num_off.off[5] - h->num_off.off[4];
     if (nd > 0) {
@@ -1175,6 +1359,11 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   const BinOffsets& off = h->num_off;
   const int sg = h->sg_log2;
   auto nb = [&](int b) { return off.off[b + 1] - off.off[b]; };
+  if (h->verbose)
+    KK_VERBOSE("\tkkamd spgemm numeric (%s): rows per kernel -- wave hash %lld, block hash small %lld, block hash large %lld, dense rows %lld "
+           "(LDS value windows %lld, LDS hub windows %lld, HBM accumulator %lld)\n", h->algorithm == 1 ? "SPGEMM_KK_DENSE" : "SPGEMM_KK",
+           (long long)nb(1), (long long)nb(2), (long long)nb(3), (long long)nb(4), (long long)h->n_dense_lds, (long long)h->n_dense_hub_lds,
+           (long long)(nb(4) - h->n_dense_lds - h->n_dense_hub_lds));
   if (nb(1)) KK_LAUNCH((spgemm_num_wave_kernel<OffT, VT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
                        (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
   if (nb(2)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkS>), (unsigned)nb(2), kBlock, 0, st, nb(2),
@@ -1294,6 +1483,7 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
   if (offset_type != KKAMD_I32 && offset_type != KKAMD_I64) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: unknown offset_type %d", offset_type);
   if (!d_row_mapC) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: null row_map C");
   hipStream_t st = kk::to_hip(stream);
+  kk::TraceRange range("KokkosSparse::spgemm_symbolic[TPL_KKAMD]");
   const size_t osz = offset_type == KKAMD_I64 ? 8 : 4;
   // idempotent: a second symbolic on the same handle returns the stored answer
   // (sparse/impl/KokkosSparse_spgemm_symbolic_spec.hpp:99)
@@ -1302,7 +1492,7 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
     return KKAMD_OK;
   }
   h->m = m; h->n = n; h->k = k; h->offset_type = offset_type; h->rmA = d_row_mapA; h->rmB = d_row_mapB;
-  h->numeric_called = false; h->numeric_bins_ready = false;
+  h->symbolic_called = false; h->numeric_called = false; h->numeric_bins_ready = false;
   h->c_nnz = 0; h->mults = 0; h->max_row_flops = 0; h->max_row_nnz = 0;
   // empty product: zero row_map (:100-107; the rocSPARSE wrapper memsets too)
   int64_t nnzA = 0, nnzB = 0;
@@ -1367,6 +1557,7 @@ int kkamd_spgemm_numeric(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_t
   if (!d_valuesA || !d_valuesB || !d_entriesC || !d_valuesC || !d_row_mapC || !d_entriesA || !d_entriesB)
     return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_numeric: null pointer");
   hipStream_t st = kk::to_hip(stream);
+  kk::TraceRange range(value_type == KKAMD_F64 ? "KokkosSparse::spgemm_numeric[TPL_KKAMD,double]" : "KokkosSparse::spgemm_numeric[TPL_KKAMD,float]");
   (void)n;
   if (offset_type == KKAMD_I64) {
     return value_type == KKAMD_F64
@@ -1378,6 +1569,46 @@ int kkamd_spgemm_numeric(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_t
              : kk::numeric_typed<int32_t, float>(h, m, k, d_row_mapA, d_entriesA, d_valuesA, d_row_mapB, d_entriesB, d_valuesB, d_row_mapC, d_entriesC, d_valuesC, st);
 }
 
+int kkamd_spgemm_set(kkamd_spgemm_handle_t* h, const char* key, double value) {
+  if (!h || !key) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: null argument");
+  const std::string k(key);
+  if (k == "algorithm") {
+    // SPGEMMAlgorithm (sparse/src/KokkosSparse_spgemm_handle.hpp:44-93): 0 KK, 1 KK_DENSE, 2 KK_MEMORY, 3 KK_LP, 4 DEFAULT, 5 DEBUG,
+    // 6 SERIAL, 7 KK_SPEED, 8 KK_MEMSPEED
+    const int a = (int)value;
+    if (a == 5 || a == 6)
+      return kk::fail(KKAMD_ERR_UNSUPPORTED, "SPGEMM_DEBUG / SPGEMM_SERIAL are the reference's host-sequential algorithms: no device implementation here "
+                                             "(the caller diverts to the native path)");
+    if (a < 0 || a > 8) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: unknown SPGEMMAlgorithm %d", a);
+    const int alg = (a == 1) ? 1 : 0;                             // KK_MEMORY / KK_SPEED / KK_MEMSPEED / KK_LP are variants of the hash algorithm
+    if (alg != h->algorithm) h->numeric_bins_ready = false;
+    h->algorithm = alg;
+  } else if (k == "accumulator") {                               // SPGEMMAccumulator: 0 default, 1 dense, 2 sparse
+    const int a = (int)value;
+    if (a < 0 || a > 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: unknown SPGEMMAccumulator %d", a);
+    if ((a == 1) != (h->algorithm == 1)) h->numeric_bins_ready = false;
+    h->algorithm = a == 1 ? 1 : 0;
+  } else if (k == "compression") {
+    if (value != 0 && value != 1 && value != 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: compression is 0 (off), 1 (keep if it pays) or 2 (always)");
+    h->compression = (int)value;
+  } else if (k == "compression_cut_off") {
+    if (!(value > 0.0 && value <= 1.0)) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: compression cut-off must be in (0, 1]");
+    h->compression_cutoff = value;
+  } else if (k == "verbose") {
+    h->verbose = value != 0;
+  } else if (k == "sort_option") {
+    // the numeric kernels emit every row column-sorted (the reference's post-numeric sort is built in): nothing to switch
+    if ((int)value == 0) return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spgemm_set: unsorted output (sort_option 0) is not available: rows of C always leave sorted");
+  } else if (k == "team_work_size" || k == "shmem_size" || k == "suggested_team_size" || k == "suggested_vector_size" || k == "dynamic_scheduling" ||
+             k == "min_hash_size_scale" || k == "first_level_hash_cut_off" || k == "mkl_sort_option" || k == "multi_color_scale") {
+    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spgemm_set: '%s' tunes Kokkos team launches / two-level hash tables of the reference's kernels and has no "
+                                           "counterpart here (LDS tables are sized from the row bins)", key);
+  } else {
+    return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: unknown key '%s'", key);
+  }
+  return KKAMD_OK;
+}
+
 int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
   if (!h || !value) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: null pointer");
   switch (what) {
@@ -1387,6 +1618,9 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 3: *value = h->max_row_nnz; break;
     case 4: *value = h->symbolic_called; break;
     case 5: *value = h->numeric_called; break;
+    case 6: *value = h->compressed ? 1 : 0; break;
+    case 7: *value = h->compressed_mults; break;
+    case 8: *value = h->algorithm; break;
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
   return KKAMD_OK;

@@ -54,19 +54,6 @@ extern SpmvTuning g_spmv_default;
 // 0, 1 or a power of two >= 2: the tile orders of xcd_order() (kk_common.h) are only bijective for those
 inline bool valid_order_knob(int v) { return v == 0 || v == 1 || (v >= 2 && v <= (1 << 20) && (v & (v - 1)) == 0); }
 
-// a device buffer that frees itself (host-side temporaries of the analysis; error paths return early)
-struct DevBuf {
-  void* p = nullptr;
-  DevBuf() = default;
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { reset(); }
-  hipError_t alloc(size_t bytes) { reset(); return hipMalloc(&p, bytes ? bytes : 1); }
-  void reset() { if (p) { (void)hipFree(p); p = nullptr; } }
-  void* release() { void* q = p; p = nullptr; return q; }
-  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
 }  // namespace kk
 
 // Tile modes of the planned rank-1 kernel (low two bits of tinfo[b]; the upper bits index the tile's codes / record):

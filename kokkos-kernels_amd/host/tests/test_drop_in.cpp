@@ -184,6 +184,30 @@ void test_spgemm() {
   threw = false;
   try { KokkosSparse::spgemm_numeric(kh2, A, false, B, false, C); } catch (const std::invalid_argument&) { threw = true; }
   EXPECT(threw);
+  // handle options act or throw (sparse/src/KokkosSparse_spgemm_handle.hpp:427-501, KokkosKernels_Handle.hpp:380-465)
+  KH kh3; kh3.create_spgemm_handle(KokkosSparse::SPGEMM_KK_DENSE);          // dense-accumulator numeric
+  kh3.get_spgemm_handle()->set_compression(false);
+  M C3;
+  KokkosSparse::spgemm_symbolic(kh3, A, false, B, false, C3);
+  EXPECT(!kh3.get_spgemm_handle()->is_compressed());
+  KokkosSparse::spgemm_numeric(kh3, A, false, B, false, C3);
+  compare(C3);
+  kh3.get_spgemm_handle()->set_accumulator_type(KokkosSparse::SPGEMM_ACC_SPARSE);
+  kh3.get_spgemm_handle()->set_compression(true); kh3.get_spgemm_handle()->set_compression_cut_off(1.0);
+  KokkosSparse::spgemm_numeric(kh3, A, false, B, false, C3);
+  compare(C3);
+  auto throws = [&](auto&& fn) { bool t = false; try { fn(); } catch (const std::runtime_error&) { t = true; } return t; };
+  EXPECT(throws([&] { kh3.set_shmem_size(16128); }));
+  EXPECT(throws([&] { kh3.set_team_work_size(16); }));
+  EXPECT(throws([&] { kh3.set_suggested_team_size(64); }));
+  EXPECT(throws([&] { kh3.set_suggested_vector_size(8); }));
+  EXPECT(throws([&] { kh3.set_dynamic_scheduling(true); }));
+  EXPECT(throws([&] { kh3.get_spgemm_handle()->set_min_hash_size_scale(2); }));
+  EXPECT(throws([&] { kh3.get_spgemm_handle()->set_first_level_hash_cut_off(0.5); }));
+  EXPECT(throws([&] { kh3.get_spgemm_handle()->set_sort_option(0); }));
+  EXPECT(throws([&] { KH k4; k4.create_spgemm_handle(KokkosSparse::SPGEMM_DEBUG); }));
+  EXPECT(throws([&] { KH k4; k4.create_spgemm_handle(KokkosSparse::SPGEMM_SERIAL); }));
+  kh3.get_spgemm_handle()->set_sort_option(1);
 }
 
 // 5-pt stencil on an ni x nj grid: interior rows hold -1 -1 4 -1 -1 in ascending column order, boundary rows the

@@ -240,6 +240,11 @@ class _SpgemmHandle:
         check(self.backend.lib, self.backend.lib.kkamd_spgemm_get(self.h, what, C.byref(v)))
         return int(v.value)
 
+    def set(self, key, value):
+        """SPGEMMHandle / KokkosKernelsHandle option setters (kkamd_spgemm_set): "algorithm", "accumulator", "compression",
+        "compression_cut_off", "verbose", "sort_option"; the reference's team / shared-memory knobs raise KkamdError(UNSUPPORTED)"""
+        check(self.backend.lib, self.backend.lib.kkamd_spgemm_set(self.h, key.encode(), float(value)))
+
     def get_c_nnz(self): return self.get(0)
     def is_symbolic_called(self): return bool(self.get(4))
     def is_numeric_called(self): return bool(self.get(5))
@@ -256,6 +261,10 @@ class _SpgemmHandle:
             pass
 
 
+_SPGEMM_ALGOS = {"SPGEMM_KK": 0, "SPGEMM_KK_DENSE": 1, "SPGEMM_KK_MEMORY": 2, "SPGEMM_KK_LP": 3, "SPGEMM_DEFAULT": 4, "SPGEMM_DEBUG": 5,
+                 "SPGEMM_SERIAL": 6, "SPGEMM_KK_SPEED": 7, "SPGEMM_KK_MEMSPEED": 8}
+
+
 class KokkosKernelsHandle:
     """The slice of KokkosKernels::Experimental::KokkosKernelsHandle the SpGEMM path uses
     (sparse/src/KokkosKernels_Handle.hpp:385-482): create_spgemm_handle / get_spgemm_handle /
@@ -266,9 +275,14 @@ class KokkosKernelsHandle:
         self._spgemm = None
 
     def create_spgemm_handle(self, algo="SPGEMM_KK"):
+        """algo: a KokkosSparse::SPGEMMAlgorithm name (sparse/src/KokkosSparse_spgemm_handle.hpp:44-93).  SPGEMM_DEBUG / SPGEMM_SERIAL
+        are host-sequential in the reference and raise here (no CPU path); SPGEMM_KK_DENSE selects the dense-accumulator numeric."""
         self.backend = self.backend or torch_backend()
+        if algo not in _SPGEMM_ALGOS:
+            raise RuntimeError("Invalid SPGEMMAlgorithm name")
         self._spgemm = _SpgemmHandle(self.backend)
         self._spgemm.algo = algo
+        self._spgemm.set("algorithm", _SPGEMM_ALGOS[algo])
 
     def get_spgemm_handle(self): return self._spgemm
 

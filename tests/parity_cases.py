@@ -114,15 +114,20 @@ def _to_host_2d(be, M):
     return M.detach().cpu().numpy()
 
 
-def check_spgemm(be, A0, B0, offset_dtype=np.int32, reuse=True, value_dtype=np.float64):
+def check_spgemm(be, A0, B0, offset_dtype=np.int32, reuse=True, value_dtype=np.float64, algo="SPGEMM_KK", options=None, expect_compressed=None):
     A, B = dev(be, A0, offset_dtype, value_dtype), dev(be, B0, offset_dtype, value_dtype)
     kh = kk.KokkosKernelsHandle(be)
-    kh.create_spgemm_handle()
+    kh.create_spgemm_handle(algo)
+    for k_, v_ in (options or {}).items():
+        kh.get_spgemm_handle().set(k_, v_)
     Cm = kk.spgemm_symbolic(kh, A, False, B, False)
     Cgold = oracle.spgemm(A0, B0)
     rmC = be.to_numpy(Cm.graph.row_map).astype(np.int64)
     assert kh.get_spgemm_handle().get_c_nnz() == Cgold.nnz
     assert np.array_equal(rmC, Cgold.row_map), "symbolic row_map differs"
+    if expect_compressed is not None:
+        assert bool(kh.get_spgemm_handle().get(6)) == expect_compressed, "compression decision: %d (work %d of %d)" % (
+            kh.get_spgemm_handle().get(6), kh.get_spgemm_handle().get(7), kh.get_spgemm_handle().get(1))
     kk.spgemm_numeric(kh, A, False, B, False, Cm)
     rm, ent, val = Cm.to_host()
     got = oracle.Crs(A0.nrows, B0.ncols, rm.astype(np.int64), ent, val.astype(np.float64))

@@ -216,3 +216,77 @@ def test_spgemm_handle_contract(be):
     assert ok, msg
     with pytest.raises(RuntimeError, match="numCols"):
         pc.kk.spgemm(A, False, A, False)
+
+
+def test_spgemm_compression(be):
+    """a18: B compressed into 32-column sets + masks for the symbolic phase (impl_compression.hpp): forced on every row bin
+    (wave, block-small, block-large, bitmap), kept by the 0.85 rule on stencils and dropped on matrices without column runs"""
+    L = oracle.laplace3d("FE", 9, 8, 7)
+    pc.check_spgemm(be, L, L, expect_compressed=True)                                   # runs of three neighbours: pays
+    pc.check_spgemm(be, L, L, options={"compression": 0}, expect_compressed=False)
+    R = pc.randomized(oracle.random_crs(400, 30000, 9, variance=4, seed=2, sorted_rows=True))
+    Rt = pc.randomized(oracle.random_crs(30000, 40000, 7, variance=3, seed=3, sorted_rows=True))
+    pc.check_spgemm(be, R, Rt, expect_compressed=False)                                 # scattered columns: dropped
+    pc.check_spgemm(be, R, Rt, options={"compression": 2}, expect_compressed=True)      # ... unless forced
+    pc.check_spgemm(be, L, L, options={"compression_cut_off": 0.1}, expect_compressed=False)
+    # every symbolic bin with compressed input: long rows of A against a banded B, hub rows (bitmap kernel, several windows)
+    band = pc.randomized(oracle.random_crs(6000, 6000, 40, variance=10, seed=5, bandwidth=150, sorted_rows=True))
+    lens = [3, 40, 200, 900, 2500, 0, 60]
+    rm = np.concatenate([[0], np.cumsum(lens)])
+    rng = np.random.default_rng(9)
+    ent = np.concatenate([np.sort(rng.choice(6000, size=l, replace=False)) for l in lens]).astype(np.int32)
+    A0 = oracle.Crs(len(lens), 6000, rm, ent, 1 + 49 * rng.random(int(rm[-1])))
+    for odt in (np.int32, np.int64):
+        pc.check_spgemm(be, A0, band, offset_dtype=odt, options={"compression": 2}, expect_compressed=True)
+    try:
+        _set(be, "spgemm_win_bits", 4096)
+        pc.check_spgemm(be, A0, band, options={"compression": 2}, expect_compressed=True)
+    finally:
+        _set(be, "spgemm_win_bits", 1 << 20)
+    # unsorted B cannot be compressed (a set is a run of a sorted row)
+    U = pc.randomized(oracle.random_crs(300, 300, 8, variance=3, seed=8))
+    pc.check_spgemm(be, U, U, options={"compression": 2}, expect_compressed=False)
+
+
+def test_spgemm_dense_accumulator_algorithm(be):
+    """a21: SPGEMM_KK_DENSE / SPGEMM_ACC_DENSE -- every row through a k-wide dense accumulator (impl_speed.hpp:28-150)"""
+    for A0, B0 in ((pc.randomized(oracle.laplace3d("FE", 7, 6, 5)),) * 2,
+                   (pc.randomized(oracle.random_crs(120, 900, 11, variance=6, seed=4, sorted_rows=True)),
+                    pc.randomized(oracle.random_crs(900, 700, 9, variance=5, seed=6, sorted_rows=True))),
+                   (pc.hub_matrix(30, 2000, 6, {3: 700}, seed=2), pc.randomized(oracle.random_crs(2000, 1500, 10, variance=4, seed=7, sorted_rows=True)))):
+        got = pc.check_spgemm(be, A0, B0, algo="SPGEMM_KK_DENSE")
+        pc.check_spgemm(be, A0, B0, options={"accumulator": 1}, offset_dtype=np.int64, value_dtype=np.float32)
+    kh = pc.kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK_DENSE")
+    assert kh.get_spgemm_handle().get(8) == 1
+    for alias in ("SPGEMM_KK_MEMORY", "SPGEMM_KK_SPEED", "SPGEMM_KK_MEMSPEED", "SPGEMM_KK_LP", "SPGEMM_DEFAULT"):
+        kh.create_spgemm_handle(alias)
+        assert kh.get_spgemm_handle().get(8) == 0
+
+
+def test_spgemm_options_act_or_raise(be, capfd):
+    """handle options either act or raise -- none is silently swallowed"""
+    kh = pc.kk.KokkosKernelsHandle(be)
+    for algo in ("SPGEMM_DEBUG", "SPGEMM_SERIAL"):
+        with pytest.raises(pc.kk.KkamdError) as e:
+            kh.create_spgemm_handle(algo)
+        assert e.value.status == pc.kk._capi.ERR_UNSUPPORTED
+    with pytest.raises(RuntimeError):
+        kh.create_spgemm_handle("SPGEMM_CUSPARSE")
+    kh.create_spgemm_handle()
+    sh = kh.get_spgemm_handle()
+    for key in ("team_work_size", "shmem_size", "suggested_team_size", "suggested_vector_size", "dynamic_scheduling", "min_hash_size_scale",
+                "first_level_hash_cut_off"):
+        with pytest.raises(pc.kk.KkamdError) as e:
+            sh.set(key, 16)
+        assert e.value.status == pc.kk._capi.ERR_UNSUPPORTED
+    with pytest.raises(pc.kk.KkamdError):
+        sh.set("no_such_option", 1)
+    with pytest.raises(pc.kk.KkamdError):
+        sh.set("sort_option", 0)
+    sh.set("sort_option", 1); sh.set("verbose", 1)
+    L = pc.randomized(oracle.laplace3d("FE", 6, 5, 4))
+    A = pc.dev(be, L)
+    Cm = pc.kk.spgemm_symbolic(kh, A, False, A, False)
+    pc.kk.spgemm_numeric(kh, A, False, A, False, Cm)
+    out = capfd.readouterr().out
+    assert "kkamd spgemm symbolic" in out and "compression kept" in out and "kkamd spgemm numeric (SPGEMM_KK)" in out, out
