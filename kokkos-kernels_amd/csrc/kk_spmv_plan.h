@@ -34,8 +34,9 @@ struct SpmvTuning {
   int mv_strip_min_kb = 3000;  // ... strips engage when three periods' worth of X rows exceed this (an XCD's L2 holds 4 MB)
   int mv_strip_l2_kb  = 2500;  // ... and are sized so that three periods' worth of a strip's X rows stay below this
   int mv_inner       = 0;  // rank-2 LDS-staged kernel, contraction: 0 auto, 1 VALU, 2 MFMA (v_mfma_f64_4x4x4 on row-pattern tiles)
-  int explicit_transpose = 0;   // modes T/H with an analysed handle: 1 = cache A^T (structure + permutation) in the plan, refresh its
-                                // values every call and run the N kernel on it; 2 = same, the caller promises constant values (no refresh)
+  int explicit_transpose = 1;   // modes T/H with an analysed handle: 1 = cache A^T in the plan (when it fits an eighth of free HBM), move the
+                                // values that changed since the last call into it and run the N kernel on it; 2 = same, the caller promises
+                                // constant values (no comparison); 0 = the reference's atomic scatter
   int explicit_transpose_min_knnz = 1000;   // ... from this many thousand nnz
   int transient_min_knnz = 10000;  // handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 = never)
   int window_codes = 1;            // analysed handles: 16-bit window codes + LDS-staged x, tile by tile (2 = codes without staged x, 0 = never)
@@ -91,7 +92,7 @@ struct kkamd_spmv_plan {
   int64_t plain_tiles = 0;       // tiles that read entries (mode 0)
   size_t plan_bytes = 0;         // HBM the analysis keeps
   // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
-  void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr;
+  void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr; void* d_t_shadow = nullptr;
   kkamd_spmv_plan* t_plan = nullptr;
   bool t_ready = false, t_failed = false, t_values_valid = false;
   bool win_failed = false;       // the codes are not worth it on this matrix (or HBM cannot hold them): plain entries

@@ -332,7 +332,8 @@ def test_transposed_modes_through_cached_explicit_transpose(be):
             pc.kk.spmv(h, "T", 1.0, A, be.from_numpy(x), 0.0, y)
             exp = oracle.spmv_sequential("T", oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, be.to_numpy(A.values).copy()), 1.0, x, 0.0, np.zeros(A0.ncols))
             assert np.allclose(be.to_numpy(y), exp, rtol=1e-13, atol=1e-13)
-            A.values[:] = rng.random(A0.nnz) + rep                          # in place: same device array, new numbers
+            if rep == 0: A.values[:] = rng.random(A0.nnz) + rep             # in place: same device array, new numbers
+            else: A.values[::3] = rng.random(len(A.values[::3])) - rep      # ... and only some of them
         # the atomic kernel stays reachable
         pc.check_spmv(be, oracle.laplace3d("FE", 9, 8, 7), "T", 1.0, 0.0, algo="SPMV_DEFAULT", knobs={"explicit_transpose": 0}, max_val=32.0)
     finally:
