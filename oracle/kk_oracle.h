@@ -91,6 +91,9 @@ int kko_spmv_omp(int64_t nrows, const int64_t* row_map, const int32_t* entries, 
                  const double* x, double beta, double* y);
 int kko_spmv_omp_i32(int64_t nrows, const int32_t* row_map, const int32_t* entries, const double* values, double alpha,
                      const double* x, double beta, double* y);
+int64_t kko_spgemm_kkmem_omp(int phase, int32_t m, int32_t n, int32_t k, const int64_t* row_mapA, const int32_t* entriesA,
+                             const double* valuesA, const int64_t* row_mapB, const int32_t* entriesB, const double* valuesB,
+                             int64_t* row_mapC, int32_t* entriesC, double* valuesC);
 int kko_spmv_mv_omp_i32(int64_t nrows, int64_t nvec, const int32_t* row_map, const int32_t* entries,
                         const double* values, double alpha, const double* X, int64_t xs0, int64_t xs1, double beta,
                         double* Y, int64_t ys0, int64_t ys1);

@@ -31,6 +31,7 @@ def lib():
         _LIB.kko_laplace2d_nnz.restype = C.c_int64
         _LIB.kko_laplace3d_nnz.restype = C.c_int64
         _LIB.kko_hash_value_1_50.restype = C.c_double
+        _LIB.kko_spgemm_kkmem_omp.restype = C.c_int64
     return _LIB
 
 
@@ -330,6 +331,30 @@ def spmv_omp(A_row_map, entries, values, alpha, x, beta, y):
     fn(_i64(len(A_row_map) - 1), _p(A_row_map), _p(entries), _p(values), C.c_double(alpha), _p(x),
        C.c_double(beta), _p(y))
     return y
+
+
+def spgemm_kkmem_omp(A, B, sort=True, timings=None):
+    """SPGEMM_KK on the host: OpenMP port of the KKMEM hash-accumulator kernels (impl_kkmem.hpp:196-272) -- the CPU baseline
+    beside the GPU SpGEMM.  timings (dict) receives symbolic / numeric / sort seconds."""
+    import time
+    L = lib()
+    rmC = np.zeros(A.nrows + 1, dtype=np.int64)
+    args = (C.c_int32(A.nrows), C.c_int32(A.ncols), C.c_int32(B.ncols), _p(A.row_map), _p(A.entries), _p(A.values), _p(B.row_map), _p(B.entries), _p(B.values))
+    t0 = time.perf_counter()
+    nnz = L.kko_spgemm_kkmem_omp(C.c_int(0), *args, _p(rmC), None, None)
+    t1 = time.perf_counter()
+    assert nnz >= 0
+    entC = np.zeros(nnz, dtype=np.int32); valC = np.zeros(nnz, dtype=np.float64)
+    t2 = time.perf_counter()
+    rc = L.kko_spgemm_kkmem_omp(C.c_int(1), *args, _p(rmC), _p(entC), _p(valC))
+    t3 = time.perf_counter()
+    assert rc == nnz
+    Cm = Crs(A.nrows, B.ncols, rmC, entC, valC)
+    if sort:
+        sort_crs(Cm)
+    if timings is not None:
+        timings.update(symbolic_s=t1 - t0, numeric_s=t3 - t2, sort_s=time.perf_counter() - t3)
+    return Cm
 
 
 def spmv_mv_omp(row_map_i32, entries, values, alpha, X, beta, Y):

@@ -93,3 +93,88 @@ int kko_spmv_mv_omp_i32(int64_t nrows, int64_t nvec, const int32_t* row_map, con
   }
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * SPGEMM_KK on the host (Kokkos::OpenMP): the KKMEM kernels with a per-thread linear-probing hash accumulator,
+ * sparse/impl/KokkosSparse_spgemm_impl_kkmem.hpp:196-272 (MultiCoreTag4: hash = (column * HASHSCALAR) & (size - 1),
+ * HASHSCALAR = 107 (:17); first-touch order kept in used_indices, table reset through that list), selected on the host
+ * when k is large (:1259-1300; k < 250001 would take the dense accumulator of impl_speed.hpp instead), and the symbolic
+ * counterpart without values (impl_symbolic.hpp:527-700, uncompressed).  Rows are handed out dynamically
+ * (Kokkos::Schedule<Kokkos::Dynamic> team policy, :1440-1467) in chunks of team_work_size = 16
+ * (KokkosKernels_Handle.hpp:323).  The library sorts C afterwards (numeric_spec.hpp:138-140): callers apply kko_sort_crs.
+ * phase 0: symbolic -- fills row_mapC (m + 1, exclusive scan done here) and returns nnz(C);
+ * phase 1: numeric  -- fills entriesC / valuesC in first-touch order.                                                  */
+#include <stdlib.h>
+#include <string.h>
+static int64_t kko_next_pow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
+
+int64_t kko_spgemm_kkmem_omp(int phase, int32_t m, int32_t n, int32_t k, const int64_t* row_mapA, const int32_t* entriesA,
+                             const double* valuesA, const int64_t* row_mapB, const int32_t* entriesB, const double* valuesB,
+                             int64_t* row_mapC, int32_t* entriesC, double* valuesC) {
+  (void)n;
+  /* table size: power of two >= 2 * the largest row it must hold (numeric: max nnz of a C row; symbolic: max row flops, <= k) */
+  int64_t max_need = 1;
+  if (phase == 0) {
+#pragma omp parallel for schedule(static) reduction(max : max_need)
+    for (int32_t i = 0; i < m; ++i) {
+      int64_t f = 0;
+      for (int64_t a = row_mapA[i]; a < row_mapA[i + 1]; ++a) { const int32_t r = entriesA[a]; f += row_mapB[r + 1] - row_mapB[r]; }
+      if (f > max_need) max_need = f;
+    }
+    if (max_need > k) max_need = k;
+  } else {
+#pragma omp parallel for schedule(static) reduction(max : max_need)
+    for (int32_t i = 0; i < m; ++i) { const int64_t l = row_mapC[i + 1] - row_mapC[i]; if (l > max_need) max_need = l; }
+  }
+  const int64_t hsize = kko_next_pow2(2 * max_need), hmask = hsize - 1;
+  int fail = 0;
+#pragma omp parallel
+  {
+    int32_t* hash_ids   = (int32_t*)malloc(sizeof(int32_t) * (size_t)hsize);
+    double* hash_values = phase ? (double*)malloc(sizeof(double) * (size_t)hsize) : NULL;
+    int32_t* used       = (int32_t*)malloc(sizeof(int32_t) * (size_t)hsize);
+    if (!hash_ids || !used || (phase && !hash_values)) {
+#pragma omp atomic write
+      fail = 1;
+    } else {
+      for (int64_t i = 0; i < hsize; ++i) hash_ids[i] = -1;
+#pragma omp for schedule(dynamic, 16)
+      for (int32_t row = 0; row < m; ++row) {
+        int32_t used_count = 0;
+        for (int64_t a = row_mapA[row]; a < row_mapA[row + 1]; ++a) {
+          const int32_t rowB = entriesA[a];
+          const double valA  = phase ? valuesA[a] : 0.0;
+          for (int64_t j = row_mapB[rowB]; j < row_mapB[rowB + 1]; ++j) {
+            const int32_t c = entriesB[j];
+            int64_t hash    = ((int64_t)c * 107) & hmask;
+            while (1) {
+              if (hash_ids[hash] == -1) {
+                used[used_count++] = (int32_t)hash; hash_ids[hash] = c;
+                if (phase) hash_values[hash] = valuesB[j] * valA;
+                break;
+              } else if (hash_ids[hash] == c) {
+                if (phase) hash_values[hash] += valuesB[j] * valA;
+                break;
+              }
+              hash = (hash + 1) & hmask;
+            }
+          }
+        }
+        if (phase) {
+          int64_t pos = row_mapC[row];
+          for (int32_t i = 0; i < used_count; ++i) { entriesC[pos] = hash_ids[used[i]]; valuesC[pos++] = hash_values[used[i]]; hash_ids[used[i]] = -1; }
+        } else {
+          row_mapC[row + 1] = used_count;
+          for (int32_t i = 0; i < used_count; ++i) hash_ids[used[i]] = -1;
+        }
+      }
+    }
+    free(hash_ids); free(hash_values); free(used);
+  }
+  if (fail) return -1;
+  if (phase == 0) {
+    row_mapC[0] = 0;
+    for (int32_t i = 0; i < m; ++i) row_mapC[i + 1] += row_mapC[i];      /* kk_exclusive_parallel_prefix_sum */
+  }
+  return row_mapC[m];
+}

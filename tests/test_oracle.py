@@ -223,3 +223,16 @@ def test_omp_baseline_matches_serial():
     oracle.spmv_mv_omp(A.row_map.astype(np.int32), A.entries, A.values, 1.0, X, 0.0, Y)
     Yr = oracle.spmv_mv_serial("N", A, 1.0, X, 0.0, np.zeros((A.nrows, 16)))
     assert np.abs(Y - Yr).max() <= tol
+
+
+def test_spgemm_kkmem_omp_matches_debug():
+    """the OpenMP KKMEM port (CPU baseline of the SpGEMM measurements) against SPGEMM_DEBUG + sort: same structure, values to rounding"""
+    for A0, B0 in ((oracle.rmat(9, 8), oracle.rmat(9, 8)),
+                   (oracle.random_crs(300, 2000, 12, variance=8, seed=1), oracle.random_crs(2000, 700, 9, variance=7, seed=2)),
+                   (oracle.laplace3d("FE", 9, 8, 7),) * 2):
+        t = {}
+        G = oracle.spgemm(A0, B0)
+        K = oracle.spgemm_kkmem_omp(A0, B0, timings=t)
+        ok, msg = oracle.is_same_matrix(K, G, 1e-12)
+        assert ok, msg
+        assert set(t) == {"symbolic_s", "numeric_s", "sort_s"}

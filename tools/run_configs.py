@@ -85,6 +85,15 @@ def c2_c3():
     mean, mn = gpu_time(lambda: kk.spmv("N", 1.0, A, x, 0.0, y), iters=30)
     emit(config="C2", device="1x MI355X", variant="handle-less (SPMV_FAST_SETUP, vector kernel)", ms=mean, GFLOPs=2 * nnz / mean / 1e6,
          GBps=spmv_bytes(nnz, nr, nr) / mean / 1e6)
+    # modes T / H: cached transpose (default: compare-and-move refresh; 2: constant values promised) against the atomic scatter (0)
+    for et, label in ((1, "cached transpose, values compared every call (default)"), (2, "cached transpose, constant values promised"), (0, "atomic scatter (the reference's algorithm)")):
+        ht = kk.SPMVHandle("SPMV_DEFAULT"); ht.set("explicit_transpose", et)
+        t0 = time.perf_counter(); kk.spmv(ht, "T", 1.0, A, x, 0.0, y); torch.cuda.synchronize(); first = time.perf_counter() - t0
+        mean, mn = gpu_time(lambda: kk.spmv(ht, "T", 1.0, A, x, 0.0, y), iters=10, warm=2)
+        emit(config="C2-transpose", device="1x MI355X", variant=label, ms=mean, ms_min=mn, first_call_s=first, GFLOPs=2 * nnz / mean / 1e6,
+             frac_of_8TBps=spmv_bytes(nnz, nr, nr) / mean / 1e6 / 8000, transpose_cached=ht.query("transpose_cached"))
+        del ht
+        torch.cuda.empty_cache()
     # N2: the structured path on the same matrix (what the reference's Laplacian perf driver times first)
     ys = torch.zeros_like(y)
     mean, mn = gpu_time(lambda: kk.spmv_struct("N", 2, (n, n, n), 1.0, A, x, 0.0, ys), iters=100)
@@ -163,28 +172,37 @@ def c4(scales=(14, 16, 18, 20)):
             emit(config="C4", device="CPU SPGEMM_SERIAL restatement (+ sort), 1 core", case="R-MAT scale %d" % scale, mults=mults, total_ms=tc * 1e3,
                  GFLOPs=2 * mults / tc / 1e9, gpu_result_identical_structure_and_values_1e7=ok, msg=msg)
             kh.destroy_spgemm_handle(); del Cm
+        if scale <= 18:
+            # SPGEMM_KK on the host cores: OpenMP port of the KKMEM hash kernels (what SPGEMM_KK runs on Kokkos::OpenMP for this k)
+            oracle.set_omp_threads(oracle.usable_cpus())
+            tk = {}
+            oracle.spgemm_kkmem_omp(R, R, timings=tk)
+            emit(config="C4", device="CPU SPGEMM_KK (KKMEM hash accumulators, OpenMP port), %d threads" % oracle.omp_threads(), case="R-MAT scale %d" % scale,
+                 mults=mults, symbolic_ms=tk["symbolic_s"] * 1e3, numeric_ms=tk["numeric_s"] * 1e3, sort_ms=tk["sort_s"] * 1e3,
+                 GFLOPs_numeric=2 * mults / tk["numeric_s"] / 1e9)
         del M
         torch.cuda.empty_cache()
 
 
-def c4_laplace(n=100):
+def c4_laplace(n=100, compression=1, algo="SPGEMM_KK"):
     """structured SpGEMM (the reference perf test's usual input): 27-pt Laplacian squared"""
     M = kk.laplace_matrix("FE", n, n, n)
     best = None
     for rep in range(3):
-        kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle()
+        kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle(algo); kh.get_spgemm_handle().set("compression", compression)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         Cm = kk.spgemm_symbolic(kh, M, False, M, False)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         kk.spgemm_numeric(kh, M, False, M, False, Cm)
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        mults = kh.get_spgemm_handle().get(1); nnzC = Cm.nnz()
+        mults = kh.get_spgemm_handle().get(1); nnzC = Cm.nnz(); comp = (kh.get_spgemm_handle().get(6), kh.get_spgemm_handle().get(7))
         cur = (t2 - t0, t1 - t0, t2 - t1)
         best = cur if best is None or cur[0] < best[0] else best
         kh.destroy_spgemm_handle(); del Cm
     nr, nnz = M.numRows(), M.nnz()
     b_num = nnz * 12 + (nr + 1) * 4 + mults * 12 + nnzC * 12 + (nr + 1) * 4
-    emit(config="C4-structured", device="1x MI355X", case="27-pt %d^3 Laplacian, C = A*A" % n, rows=nr, nnzA=nnz, nnzC=nnzC, mults=mults,
+    emit(config="C4-structured", device="1x MI355X", case="27-pt %d^3 Laplacian, C = A*A" % n, algorithm=algo, compression_option=compression,
+         b_compressed=bool(comp[0]), symbolic_insertions=comp[1], rows=nr, nnzA=nnz, nnzC=nnzC, mults=mults,
          symbolic_ms=best[1] * 1e3, numeric_ms=best[2] * 1e3, GFLOPs_numeric=2 * mults / best[2] / 1e9,
          gather_model_GBps_numeric=b_num / best[2] / 1e9)
 
@@ -251,6 +269,7 @@ if __name__ == "__main__":
     if "c1" in what: c1()
     if "c2" in what: c2_c3()
     if "c4" in what: c4(tuple(int(v) for v in os.environ.get("KK_C4_SCALES", "14,16,18,20").split(",")))
-    if "c4lap" in what: c4_laplace()
+    if "c4lap" in what:
+        c4_laplace(compression=0); c4_laplace(compression=1); c4_laplace(algo="SPGEMM_KK_DENSE")
     if "c4s22" in what: c4_symbolic_only(22)
     if "c4slab" in what: c4_slab(int(os.environ.get("KK_C4_SLAB_SCALE", "22")))
