@@ -33,15 +33,15 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is
 PMC_FILE = os.path.join(ROOT, "profiles", "round2", "bench_n1_pmc_hbm.json")
 
 
-def kernel_source_sha():
-    """sha256 over the kernel sources (csrc/*.hip, *.h): stamps every committed counter file, so that bench.py can tell
-    whether the traffic figure it quotes was measured on the code it is running (.git does not travel to the GPU box)."""
-    import glob
+def kernel_source_sha(unit="kk_spmv.hip"):
+    """sha256 over one kernel translation unit and the headers every unit shares: stamps every committed counter file, so that
+    bench.py can tell whether the traffic figure it quotes was measured on the code it is running (.git does not travel to
+    the GPU box).  The rank-1 SpMV the bench times lives in kk_spmv.hip."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "kokkos-kernels_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
-        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    for f in (unit, "kk_spmv_plan.h", "kk_common.h", "kk_rt.h", "kk_scan.h"):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

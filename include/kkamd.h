@@ -143,6 +143,11 @@ int kkamd_set_default(const char* key, int value);
 /* What the analysis of a plan produced: "tile" (nnz per workgroup, 0 = no tiling), "tiles", "pattern_tiles" (tiles decoded from row-pattern records), "window_staged_x", "window_codes" (1 if the
  * 16-bit column codes of stream_variant 6 are in use), "transpose_cached". */
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);
+/* Copies a per-tile array of the analysis to a HOST buffer of `count` int32: "tile_first_row" (tiles + 1 entries: the first row that
+ * starts at or after nonzero b * tile, bit 31 set when the tile starts inside a row -- the nnz-split counterpart of the
+ * reference's merge-path diagonal search, sparse/impl/KokkosSparse_merge_matrix.hpp:196-227) or "tile_mode" (tiles entries,
+ * low two bits 0 plain / 1 codes / 2 codes + staged x / 3 row-pattern record). */
+int kkamd_spmv_plan_export(const kkamd_spmv_plan_t* plan, const char* what, void* h_out, int64_t count);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU SpMV: the CrsMatrix is 1-D row-partitioned over the GPUs of one node, one process per GPU.  Rank r owns the row slab

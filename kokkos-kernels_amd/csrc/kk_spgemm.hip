@@ -465,15 +465,17 @@ __global__ __launch_bounds__(kBlock) void spgemm_compress_kernel(int64_t n, cons
   }
 }
 
-// keys = set indices, masks OR-ed per key; the row's nnz is the number of mask bits
-__device__ __forceinline__ void hash_insert_or(int* keys, unsigned* masks, int mask, int key, unsigned bits) {
+// keys = set indices, masks OR-ed per key; returns how many mask bits this call added (the row's nnz is their sum: no pass
+// over the table afterwards).  A plain read filters the common case of bits that are already there.
+__device__ __forceinline__ int hash_insert_or(int* keys, unsigned* masks, int mask, int key, unsigned bits) {
   int h = (int)(((unsigned)key * (unsigned)kHashMul) & (unsigned)mask);
   while (true) {
     const int k = keys[h];
-    if (k == key) { atomicOr(&masks[h], bits); return; }
-    if (k == -1) {
-      const int old = atomicCAS(&keys[h], -1, key);
-      if (old == -1 || old == key) { atomicOr(&masks[h], bits); return; }
+    bool mine = (k == key);
+    if (k == -1) { const int old = atomicCAS(&keys[h], -1, key); mine = (old == -1 || old == key); }
+    if (mine) {
+      if ((masks[h] & bits) == bits) return 0;
+      return __popc(bits & ~atomicOr(&masks[h], bits));
     }
     h = (h + 1) & mask;
   }
@@ -497,11 +499,9 @@ __global__ __launch_bounds__(kBlock) void spgemm_symc_wave_kernel(int64_t nbin, 
   const bool active = idx < nbin;
   const int64_t row = active ? (int64_t)perm[idx] : 0;
   int* mytab = tab[w]; unsigned* mymsk = msk[w];
-  wave_flat_products<OffT, NoVals>(active, row, rmA, entA, rmB, setB, (const NoVals*)nullptr, lane, s_wf[w],
-                                   [&](int64_t, int64_t j, int c) { hash_insert_or(mytab, mymsk, H - 1, c, maskB[j]); }, endB);
-  KK_WAVE_SYNC();
   int cnt = 0;
-  for (int i = lane; i < H; i += 64) cnt += __popc(mymsk[i]);
+  wave_flat_products<OffT, NoVals>(active, row, rmA, entA, rmB, setB, (const NoVals*)nullptr, lane, s_wf[w],
+                                   [&](int64_t, int64_t j, int c) { cnt += hash_insert_or(mytab, mymsk, H - 1, c, maskB[j]); }, endB);
   cnt = group_sum(cnt, 64);
   if (active && lane == 0) counts[row] = (OffT)cnt;
 }
@@ -520,11 +520,9 @@ __global__ __launch_bounds__(NT) void spgemm_symc_block_kernel(int64_t nbin, con
   for (int i = t; i < H; i += NT) { tab[i] = -1; msk[i] = 0u; }
   if (t == 0) s_count = 0;
   __syncthreads();
-  flat_products<NT, OffT>(row, rmA, entA, rmB, setB, s_flat,
-                          [&](int64_t, int64_t j, int c) { hash_insert_or(tab, msk, H - 1, c, maskB[j]); }, endB);
-  __syncthreads();
   int cnt = 0;
-  for (int i = t; i < H; i += NT) cnt += __popc(msk[i]);
+  flat_products<NT, OffT>(row, rmA, entA, rmB, setB, s_flat,
+                          [&](int64_t, int64_t j, int c) { cnt += hash_insert_or(tab, msk, H - 1, c, maskB[j]); }, endB);
   cnt = group_sum(cnt, 64);
   if ((t & 63) == 0 && cnt) atomicAdd(&s_count, cnt);
   __syncthreads();

@@ -1427,6 +1427,19 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   return KKAMD_OK;
 }
 
+/* copies a per-tile array of the plan to the host (tests pin the tile -> row search against the reference's merge-path vectors) */
+int kkamd_spmv_plan_export(const kkamd_spmv_plan_t* plan, const char* what, void* h_out, int64_t count) {
+  if (!plan || !what || !h_out) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_export: null argument");
+  const std::string k(what);
+  const void* src = nullptr; int64_t have = 0; size_t esz = 4;
+  if (k == "tile_first_row") { src = plan->d_blk_row; have = plan->d_blk_row ? plan->nblocks + 1 : 0; }     // bit 31: the tile starts inside a row
+  else if (k == "tile_mode") { src = plan->d_tinfo; have = plan->d_tinfo ? plan->nblocks : 0; }             // low two bits: kTilePlain .. kTilePattern
+  else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_export: unknown array '%s'", what);
+  if (count > have) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_export: '%s' has %lld entries, %lld asked for", what, (long long)have, (long long)count);
+  if (count > 0) KK_HIP(hipMemcpy(h_out, src, esz * (size_t)count, hipMemcpyDeviceToHost));
+  return KKAMD_OK;
+}
+
 /* frees the calling host thread's scratch of the handle-less route (tile descriptors + carries, grown on demand) */
 int kkamd_release_scratch(void) { return kk::release_transient(); }
 

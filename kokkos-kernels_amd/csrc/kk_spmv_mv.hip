@@ -607,9 +607,10 @@ static int mv_build_strip_order(kkamd_mv_plan* mv, int64_t period, int rowbytes,
 template <class OffT>
 static int64_t detect_period_rows(const kkamd_crs_t* A, hipStream_t st) {
   if (A->num_rows < 4096 || A->num_rows != A->num_cols) return 0;
-  int64_t votes[16]; int nv = 0;
-  for (int s = 1; s <= 15; ++s) {
-    const int64_t r = A->num_rows * s / 16;
+  // rows at scattered positions (a regular sample lands on one grid face: 27e6 * s / 16 is a multiple of 300), majority vote
+  int64_t votes[32]; int nv = 0;
+  for (int s = 1; s <= 32; ++s) {
+    const int64_t r = (int64_t)((((unsigned long long)s * 0x9E3779B97F4A7C15ull) >> 11) % (unsigned long long)A->num_rows);
     OffT rm[2];
     if (hipMemcpyAsync(rm, (const OffT*)A->d_row_map + r, sizeof rm, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0;
     const int64_t len = (int64_t)(rm[1] - rm[0]);

@@ -135,6 +135,12 @@ class SPMVHandle:
         check(self.backend.lib, self.backend.lib.kkamd_spmv_plan_query(self._plan, key.encode(), C.byref(v)))
         return int(v.value)
 
+    def export(self, what, count):
+        """a per-tile array of the analysis ("tile_first_row", "tile_mode") as a host int32 array"""
+        out = np.zeros(int(count), dtype=np.int32)
+        check(self.backend.lib, self.backend.lib.kkamd_spmv_plan_export(self._plan, what.encode(), out.ctypes.data_as(C.c_void_p), int(count)))
+        return out
+
     def _ensure(self, A):
         if self._plan is None:
             self.backend = A.backend

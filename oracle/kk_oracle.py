@@ -285,6 +285,39 @@ def random_crs(nrows, ncols, nnz_per_row, variance=0, seed=0, bandwidth=None, so
     return A
 
 
+# --------------------------------------------------------------------------- merge matrix (merge-path SpMV, K4)
+def merge_matrix_diagonal(a, b, d):
+    """Entries of the merge matrix M[i, j] = (a[i] > b[j]) along diagonal d, from the +a end towards the +b end
+    (MergeMatrixDiagonal::operator() and diag_to_a_b, sparse/impl/KokkosSparse_merge_matrix.hpp:140-196)."""
+    na, nb = len(a), len(b)
+    if d <= na and d <= nb: size = d
+    elif d > na and d > nb: size = na + nb - d
+    else: size = min(na, nb)
+    out = []
+    for di in range(size):
+        ai = (d - 1) - di if d < na else na - 1 - di
+        bi = di if d < na else d + di - na
+        out.append(1 if ai >= na else (0 if bi >= nb else int(a[ai] > b[bi])))
+    return out
+
+
+def diagonal_search(a, b, d):
+    """(ai, bi): the first position on diagonal d whose merge-matrix entry is not 1 (diagonal_search + MergeMatrixDiagonal::position,
+    sparse/impl/KokkosSparse_merge_matrix.hpp:118-135,196-227): a lower bound over the diagonal with predicate "equals 1"."""
+    na = len(a)
+    if d == 0:
+        return 0, 0
+    entries = merge_matrix_diagonal(a, b, d)
+    lo, hi = 0, len(entries)                # lower_bound_thread with Equal<bool>: first idx with entries[idx] != 1
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if entries[mid] == 1: lo = mid + 1
+        else: hi = mid
+    ai = (d - 1) - lo if d < na else na - 1 - lo
+    bi = lo if d < na else d + lo - na
+    return ai + 1, bi
+
+
 # --------------------------------------------------------------------------- CPU baselines
 def first_touch(a):
     """copy of `a` whose pages were first touched by the OpenMP team (NUMA spread, like a Kokkos::View)"""

@@ -366,3 +366,28 @@ def test_degenerate_dimensions(be):
         pc.check_spmv(be, A0, "N", 1.0, 0.0, None, nans=True)
         pc.check_spmv(be, A0, "N", 1.0, 2.0, "SPMV_DEFAULT")
         pc.check_spmv(be, A0, "T", 1.0, 0.0, None, nans=True)
+
+
+def test_tile_descriptors_against_merge_path(be):
+    """The plan's tile -> row search (spmv_plan_kernel) against the closed form pinned by the merge-matrix vectors
+    (tests/test_oracle.py::test_merge_path_split_equals_nnz_split_descriptors): tile b starts at nonzero p = b * tile; its
+    descriptor is the first row starting at or after p, with bit 31 set when p falls inside a row -- i.e. (rows that end at or
+    before p) + (1 if p is inside a row), which is what the reference's diagonal_search yields on the diagonal through p."""
+    for lens in ([5000, 1, 0, 4100, 2048, 2048, 3], [0, 0, 5, 0, 0, 0, 7, 0, 2047, 1, 0, 0] * 40, [27] * 700, [0] * 30 + [1024] * 9 + [0] * 5):
+        A0 = _custom(lens, 5000, seed=len(lens))
+        h = pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"nnz_per_thread": 4})
+        tile, tiles = h.query("tile"), h.query("tiles")
+        assert tile == 1024 and tiles == -(-A0.nnz // tile)
+        got = h.export("tile_first_row", tiles + 1).astype(np.int64)
+        rm = A0.row_map
+        for b in range(tiles + 1):
+            if b == tiles:
+                assert got[b] == A0.nrows
+                continue
+            p = b * tile
+            first = int(np.searchsorted(rm, p, side="left"))            # first row whose start is >= p
+            inside = rm[first] > p                                       # p cuts a row: that row started earlier
+            ended = int(np.searchsorted(rm[1:], p, side="right"))       # merge path: rows consumed on the diagonal through p
+            while ended < A0.nrows and rm[ended + 1] == rm[ended] and rm[ended] == p: ended += 1   # empty rows at p belong to neither side
+            assert (got[b] & 0x7fffffff) == first and bool(got[b] >> 31 & 1) == bool(inside), (b, got[b], first, inside)
+            assert first == ended + (1 if inside else 0) or rm[first] == p, (b, first, ended, inside)

@@ -236,3 +236,47 @@ def test_spgemm_kkmem_omp_matches_debug():
         ok, msg = oracle.is_same_matrix(K, G, 1e-12)
         assert ok, msg
         assert set(t) == {"symbolic_s", "numeric_s", "sort_s"}
+
+
+# ---- merge matrix: the reference's hand-computed diagonals (sparse/unit_test/Test_Sparse_MergeMatrix.hpp:136-575) ----------------
+MERGE_CASES = [
+    ([0, 0, 0, 0], [0, 1, 2, 3], None, 0),                                                  # all zero
+    ([1, 2, 3, 4], [0, 0, 0, 0], None, 1),                                                  # all one
+    ([1, 2, 3, 4], [0, 1, 2, 3], [[], [1], [1, 0], [1, 1, 0], [1, 1, 0, 0], [1, 1, 0], [1, 0], [1]], None),          # case 1 (:161-181)
+    ([1, 2, 9], [0, 2, 2, 8, 8, 8], [[], [1], [1, 0], [1, 0, 0], [1, 0, 0], [1, 0, 0], [1, 0, 0], [1, 0], [1]], None),   # case 2 (:184-203)
+    ([-1, 9, 9], [0, 2, 7], [[], [0], [1, 0], [1, 1, 0], [1, 1], [1]], None),                 # case 3 (:206-223)
+    ([1, 6, 6], [-3, -1, 7], [[], [1], [1, 1], [1, 1, 0], [1, 0], [0]], None),                # case 4 (:226-245)
+    ([-3, -2, 2], [-2, 0, 1], [[], [0], [0, 0], [1, 0, 0], [1, 0], [1]], None),               # case 5 (expectations at :339-344)
+]
+
+
+@pytest.mark.parametrize("a,b,diags,const", MERGE_CASES)
+def test_merge_matrix_known_diagonals(a, b, diags, const):
+    n = len(a) + len(b) - 1
+    for d in range(n if diags is None else len(diags)):
+        got = oracle.merge_matrix_diagonal(a, b, d)
+        if diags is None:
+            assert got == [const] * len(got)
+        else:
+            assert got == diags[d], (d, got, diags[d])
+        # diagonal_search = the first entry that is not 1, as a position (ai, bi) with ai + bi = d
+        ai, bi = oracle.diagonal_search(a, b, d)
+        ones = 0
+        while ones < len(got) and got[ones] == 1: ones += 1
+        assert ai + bi == d and (d == 0 or bi == (ones if d < len(a) else d + ones - len(a)))
+
+
+def test_merge_path_split_equals_nnz_split_descriptors():
+    """The reference's merge-path SpMV cuts (rows + nnz) with diagonal_search over a = row ends, b = iota(nnz)
+    (sparse/impl/KokkosSparse_spmv_impl_merge.hpp:100-160); the nnz-split tiles here cut nnz alone.  On the diagonal that passes
+    through a tile boundary p (all rows that end at or before p, p nonzeros) the search must land exactly on it -- which pins the
+    closed forms the tile descriptors are checked against (test_emu_spmv.py::test_tile_descriptors_against_merge_path)."""
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([rng.integers(0, 9, 60), [0, 0, 40, 0, 1]])
+    rm = np.concatenate([[0], np.cumsum(lens)])
+    ends, nnz = list(rm[1:]), int(rm[-1])
+    for tile in (7, 16, 64):
+        for p in range(0, nnz + 1, tile):
+            f = int(np.searchsorted(rm[1:], p, side="right"))           # rows that end at or before p
+            ai, bi = oracle.diagonal_search(ends, list(range(nnz)), f + p)
+            assert (ai, bi) == (f, p), (tile, p, ai, bi, f)

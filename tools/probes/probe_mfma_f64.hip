@@ -22,6 +22,39 @@ __global__ void probe16(double* out) {      // v_mfma_f64_16x16x4f64: one double
     for (int r = 0; r < 4; ++r) out[(bl * 64 + lane) * 4 + r] = d[r];
   }
 }
+// Issue rates: every wave runs `iters` rounds of 8 independent accumulators, so the pipe (not the dependency) is what is timed.
+__global__ void rate_mfma4(double* out, int iters) {
+  double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4, c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < iters; ++i)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c[u], 0, 0, 0);
+  double s = 0; for (int u = 0; u < 8; ++u) s += c[u];
+  if (s == 1.2345e300) out[0] = s;
+}
+__global__ void rate_mfma16(double* out, int iters) {
+  double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+  d4 c[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int i = 0; i < iters; ++i)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[u], 0, 0, 0);
+  double s = 0; for (int u = 0; u < 4; ++u) s += c[u][0] + c[u][1] + c[u][2] + c[u][3];
+  if (s == 1.2345e300) out[0] = s;
+}
+__global__ void rate_fma(double* out, int iters) {
+  double a = 1.0 + threadIdx.x * 1e-9, b = threadIdx.x * 1e-7, c[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+  for (int i = 0; i < iters; ++i)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = __builtin_fma(a, c[u], b);
+  double s = 0; for (int u = 0; u < 8; ++u) s += c[u];
+  if (s == 1.2345e300) out[0] = s;
+}
+template <class K> static double time_ms(K k, double* d, int iters) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  k<<<256 * 8, 256>>>(d, iters); hipDeviceSynchronize();
+  hipEventRecord(e0); k<<<256 * 8, 256>>>(d, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1); return ms;
+}
+
 int main() {
   double *d4o, *d16o;
   hipMalloc(&d4o, 64 * 64 * 8); hipMalloc(&d16o, 64 * 64 * 4 * 8);
@@ -41,5 +74,13 @@ int main() {
     for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) if (h16[(bl * 64 + l) * 4 + r] != 0.0) printf(" D(%d,%d)<-A%d", l, r, (int)h16[(bl * 64 + l) * 4 + r] - 1);
     printf("\n");
   }
+  // rates: 256 CUs x 8 workgroups x 4 waves
+  const int iters = 20000; const double waves = 256.0 * 8 * 4;
+  double ms = time_ms(rate_mfma4, d4o, iters);
+  printf("== rate v_mfma_f64_4x4x4f64 : %.3f ms -> %.1f TFLOP/s (512 flop per wave-instruction)\n", ms, waves * iters * 8 * 512.0 / ms / 1e9);
+  ms = time_ms(rate_mfma16, d4o, iters);
+  printf("== rate v_mfma_f64_16x16x4f64: %.3f ms -> %.1f TFLOP/s (2048 flop per wave-instruction)\n", ms, waves * iters * 4 * 2048.0 / ms / 1e9);
+  ms = time_ms(rate_fma, d4o, iters);
+  printf("== rate v_fma_f64 (VALU)     : %.3f ms -> %.1f TFLOP/s (128 flop per wave-instruction)\n", ms, waves * iters * 8 * 128.0 / ms / 1e9);
   return 0;
 }
