@@ -222,7 +222,7 @@ int kkamd_spgemm_numeric(kkamd_spgemm_handle_t* handle, int64_t m, int64_t n, in
  *                          LDS hash-accumulator numeric; SPGEMM_KK_DENSE runs the dense-accumulator numeric (impl_speed.hpp:28-150);
  *                          SPGEMM_DEBUG / SPGEMM_SERIAL (host-sequential) return KKAMD_ERR_UNSUPPORTED: the caller diverts to native
  *   "accumulator"          SPGEMMAccumulator: 1 = dense (same as SPGEMM_KK_DENSE), 0 / 2 = hash
- *   "compression"          B compression for the symbolic phase (impl_compression.hpp): 0 off, 1 keep when it pays (default), 2 always
+ *   "compression"          B compression for the symbolic phase (impl_compression.hpp): 0 off (default), 1 keep when it pays, 2 always
  *   "compression_cut_off"  keep the compressed B when it leaves at most this share of the symbolic work (default 0.85)
  *   "verbose"              1: chosen algorithm, row bins, kernels and compression decision on stdout (KOKKOSKERNELS_VERBOSE)
  *   "sort_option"          rows of C always leave column-sorted; asking for unsorted output (0) returns KKAMD_ERR_UNSUPPORTED

@@ -1144,7 +1144,8 @@ struct kkamd_spgemm_handle {
   int64_t n_dense_hub_lds = 0;     // then rows for the LDS hub kernel; the rest accumulate in HBM
   // options (kkamd_spgemm_set; the reference's SPGEMMHandle / KokkosKernelsHandle setters)
   int algorithm = 0;               // 0 hash accumulators in LDS (SPGEMM_KK and its aliases), 1 dense accumulator numeric (SPGEMM_KK_DENSE)
-  int compression = 1;             // symbolic phase: 0 never compress B, 1 compress and keep it if it pays (default), 2 always keep it
+  int compression = 0;             // symbolic phase: 0 never compress B (default: measured 3.19 -> 3.75 ms on 27-pt 100^3 A*A although it removes
+                                   // 64 % of the insertions -- the phase is not insertion-bound here), 1 compress and keep it if it pays, 2 always keep it
   double compression_cutoff = 0.85;  // kept when compressed work <= cutoff * original work (impl_compression.hpp:718)
   int verbose = 0;
   bool compressed = false;         // what the last symbolic call did

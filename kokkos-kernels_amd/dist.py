@@ -103,7 +103,7 @@ class _DeviceView:
 
 class DistSpmv:
     def __init__(self, A_local, offsets, rank, group=None, algo="SPMV_DEFAULT", to_backend=None, exchange="auto",
-                 overlap=True, dtype=np.float64):
+                 overlap=True, dtype=np.float64, transport=None):
         """A_local: CrsMatrix slab (numRows = offsets[rank+1]-offsets[rank], numCols = global).
         to_backend: converts a torch tensor to what the backend's ptr() accepts (identity for HBM tensors;
         tests on CPU/gloo pass `lambda t: t.numpy()` for the emulator backend)."""
@@ -121,7 +121,10 @@ class DistSpmv:
         self._transport = None
         id_buf = None
         tr_ptr = None
-        if self.world > 1:
+        if self.world > 1 and transport is not None:
+            self._transport = transport            # a caller-supplied kkamd_transport_t holder (object with a .struct)
+            tr_ptr = C.byref(transport.struct)
+        elif self.world > 1:
             if self.be.name == "torch":
                 # the library's RCCL transport: its id comes from rank 0 through the process group
                 ident = torch.zeros(128, dtype=torch.uint8, device="cuda")

@@ -186,14 +186,14 @@ void test_spgemm() {
   EXPECT(threw);
   // handle options act or throw (sparse/src/KokkosSparse_spgemm_handle.hpp:427-501, KokkosKernels_Handle.hpp:380-465)
   KH kh3; kh3.create_spgemm_handle(KokkosSparse::SPGEMM_KK_DENSE);          // dense-accumulator numeric
-  kh3.get_spgemm_handle()->set_compression(false);
+  kh3.get_spgemm_handle()->set_compression(true); kh3.get_spgemm_handle()->set_compression_cut_off(1.0);
   M C3;
   KokkosSparse::spgemm_symbolic(kh3, A, false, B, false, C3);
-  EXPECT(!kh3.get_spgemm_handle()->is_compressed());
+  EXPECT(kh3.get_spgemm_handle()->is_compressed());          // B is sorted here, the cut-off of 1.0 keeps whatever compression gives
   KokkosSparse::spgemm_numeric(kh3, A, false, B, false, C3);
   compare(C3);
   kh3.get_spgemm_handle()->set_accumulator_type(KokkosSparse::SPGEMM_ACC_SPARSE);
-  kh3.get_spgemm_handle()->set_compression(true); kh3.get_spgemm_handle()->set_compression_cut_off(1.0);
+  kh3.get_spgemm_handle()->set_compression(false);
   KokkosSparse::spgemm_numeric(kh3, A, false, B, false, C3);
   compare(C3);
   auto throws = [&](auto&& fn) { bool t = false; try { fn(); } catch (const std::runtime_error&) { t = true; } return t; };

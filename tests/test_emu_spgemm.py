@@ -222,13 +222,14 @@ def test_spgemm_compression(be):
     """a18: B compressed into 32-column sets + masks for the symbolic phase (impl_compression.hpp): forced on every row bin
     (wave, block-small, block-large, bitmap), kept by the 0.85 rule on stencils and dropped on matrices without column runs"""
     L = oracle.laplace3d("FE", 9, 8, 7)
-    pc.check_spgemm(be, L, L, expect_compressed=True)                                   # runs of three neighbours: pays
+    pc.check_spgemm(be, L, L, expect_compressed=False)                                  # off unless asked for
+    pc.check_spgemm(be, L, L, options={"compression": 1}, expect_compressed=True)       # runs of three neighbours: pays
     pc.check_spgemm(be, L, L, options={"compression": 0}, expect_compressed=False)
     R = pc.randomized(oracle.random_crs(400, 30000, 9, variance=4, seed=2, sorted_rows=True))
     Rt = pc.randomized(oracle.random_crs(30000, 40000, 7, variance=3, seed=3, sorted_rows=True))
-    pc.check_spgemm(be, R, Rt, expect_compressed=False)                                 # scattered columns: dropped
+    pc.check_spgemm(be, R, Rt, options={"compression": 1}, expect_compressed=False)     # scattered columns: dropped
     pc.check_spgemm(be, R, Rt, options={"compression": 2}, expect_compressed=True)      # ... unless forced
-    pc.check_spgemm(be, L, L, options={"compression_cut_off": 0.1}, expect_compressed=False)
+    pc.check_spgemm(be, L, L, options={"compression": 1, "compression_cut_off": 0.1}, expect_compressed=False)
     # every symbolic bin with compressed input: long rows of A against a banded B, hub rows (bitmap kernel, several windows)
     band = pc.randomized(oracle.random_crs(6000, 6000, 40, variance=10, seed=5, bandwidth=150, sorted_rows=True))
     lens = [3, 40, 200, 900, 2500, 0, 60]
@@ -283,7 +284,7 @@ def test_spgemm_options_act_or_raise(be, capfd):
         sh.set("no_such_option", 1)
     with pytest.raises(pc.kk.KkamdError):
         sh.set("sort_option", 0)
-    sh.set("sort_option", 1); sh.set("verbose", 1)
+    sh.set("sort_option", 1); sh.set("verbose", 1); sh.set("compression", 1)
     L = pc.randomized(oracle.laplace3d("FE", 6, 5, 4))
     A = pc.dev(be, L)
     Cm = pc.kk.spgemm_symbolic(kh, A, False, A, False)

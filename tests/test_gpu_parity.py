@@ -345,31 +345,75 @@ def test_row_range_views_with_unaligned_offsets(be):
     assert tried_odd
 
 
-def test_dist_overlap_split_on_device_tensors(be):
-    """dist.py's interior / boundary split with torch tensors in HBM (the gloo test covers it with numpy arrays):
-    rank 1 of 3 of a 20x20x30 grid, no process group needed for the split itself."""
+def test_dist_operator_on_device_with_loopback_transport(be):
+    """The C implementation of the row-partitioned SpMV (kkamd_dist_spmv_*) on the GPU, one process playing rank 1 of 3 of a
+    20 x 20 x 30 grid: a loop-back kkamd_transport_t answers the collectives from the test's own copy of the global x, so the
+    halo lists, the interior / boundary split, the communication stream + events and the zero-copy x window all run on real
+    device pointers (the world-2 gloo test covers the protocol between processes; RCCL itself needs a second GPU)."""
+    import ctypes as C
     import torch
-    from kokkos_kernels_amd.dist import DistSpmv
+    from kokkos_kernels_amd import _capi
+    from kokkos_kernels_amd.dist import DistSpmv, _DeviceView
     nx, ny, nz, world, rank = 20, 20, 30, 3, 1
-    rows = nx * ny * (nz // world)
+    rows = nx * ny * (nz // world); n = nx * ny * nz; plane = nx * ny
     offsets = [r * rows for r in range(world + 1)]
     A = pc.kk.laplace_matrix("FE", nx, ny, nz, rows=(rank * rows, rows))
-    op = DistSpmv(A, offsets, rank)
-    op._setup_overlap()
-    (ia, ib), (ha, hb), (ta, tb) = [(a, b) for _, _, a, b in op._split]
-    assert 0 <= ia - nx * ny <= 8 and 0 <= (rows - nx * ny) - ib <= 8 and (ha, hb) == (0, ia) and (ta, tb) == (ib, rows)
-    assert int(A.graph.row_map[ia].item()) % 4 == 0 and int(A.graph.row_map[ib].item()) % 4 == 0
     g = torch.Generator(device="cuda"); g.manual_seed(5)
-    x = torch.rand(nx * ny * nz, dtype=torch.float64, device="cuda", generator=g)
-    y_ref = torch.zeros(rows, dtype=torch.float64, device="cuda"); y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    ranges = [(max(0, offsets[p] - plane), min(n, offsets[p + 1] + plane) - 1) for p in range(world)]     # column range of every slab
+
+    def view(ptr, nbytes):
+        return torch.as_tensor(_DeviceView(ptr, nbytes, "|u1"), device="cuda")
+
+    class Loopback:
+        def __init__(self):
+            self.calls, self.base, self.log = 0, None, []
+
+            def all_gather(ctx, d_send, d_recv, nbytes, stream):
+                torch.cuda.synchronize()
+                mine = view(d_send, nbytes).clone(); out = view(d_recv, nbytes * world)
+                for p in range(world):
+                    if p == rank: out[p * nbytes:(p + 1) * nbytes] = mine
+                    elif self.calls == 0: out[p * nbytes:(p + 1) * nbytes] = torch.tensor(ranges[p], dtype=torch.int64, device="cuda").view(torch.uint8)
+                    else: out[p * nbytes:(p + 1) * nbytes] = torch.tensor([0.01, 0.0], dtype=torch.float64, device="cuda").view(torch.uint8)
+                self.calls += 1
+                torch.cuda.synchronize()
+                return 0
+
+            def exchange(ctx, nsend, d_send, send_bytes, send_peer, nrecv, d_recv, recv_bytes, recv_peer, stream):
+                torch.cuda.synchronize()
+                for i in range(nrecv):                       # serve every receive from the global x (what the peer would have sent)
+                    lo = (int(d_recv[i]) - self.base) // 8; cnt = int(recv_bytes[i]) // 8
+                    view(d_recv[i], recv_bytes[i]).copy_(x[lo:lo + cnt].view(torch.uint8))
+                    self.log.append(("recv", int(recv_peer[i]), lo, cnt))
+                for i in range(nsend):
+                    self.log.append(("send", int(send_peer[i]), (int(d_send[i]) - self.base) // 8, int(send_bytes[i]) // 8))
+                torch.cuda.synchronize()
+                return 0
+            self._ag, self._ex = _capi.ALL_GATHER_FN(all_gather), _capi.EXCHANGE_FN(exchange)
+            self.struct = _capi.Transport(None, self._ag, self._ex)
+
+    tr = Loopback()
+    op = DistSpmv(A, offsets, rank, transport=tr)
+    assert op.exchange_mode == "halo" and op.exchange_bytes == 2 * plane * 8 and op.query("parts") == 3
+    assert rows - 2 * plane - 16 <= op.interior_rows <= rows - 2 * plane
+    p_full = C.c_void_p(); pc.kk._capi.check(be.lib, be.lib.kkamd_dist_spmv_x_local(op._op, None, C.byref(p_full)))
+    tr.base = p_full.value
+    y_ref = torch.zeros(rows, dtype=torch.float64, device="cuda")
     pc.kk.spmv(pc.kk.SPMVHandle("SPMV_DEFAULT"), "N", 1.0, A, x, 0.0, y_ref)
-    for h, sub, a, b in op._split:
-        pc.kk.spmv(h, "N", 1.0, sub, x, 0.0, y[a:b])
-    assert (y - y_ref).abs().max().item() <= 10 * np.finfo(np.float64).eps * 27 * 26
-    # interior rows must not reference anything outside the rank's own x range
-    _, sub, a, b = op._split[0]
-    assert int(sub.graph.entries.min().item()) >= offsets[rank] and int(sub.graph.entries.max().item()) < offsets[rank + 1]
-    assert sub.graph.entries.data_ptr() % 16 == 0 and sub.values.data_ptr() % 16 == 0
+    tol = 10 * np.finfo(np.float64).eps * 27 * 32
+    xl = op.x_local(); xl.copy_(x[offsets[rank]:offsets[rank + 1]])          # x kept in the operator's window: no copy in apply()
+    for rep in range(2):
+        y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+        op.apply(1.0, xl, 0.0, y)
+        assert (y - y_ref).abs().max().item() <= tol
+    y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+    op.apply(1.0, x[offsets[rank]:offsets[rank + 1]].clone(), 0.0, y)           # a foreign x shard is copied in
+    assert (y - y_ref).abs().max().item() <= tol
+    # one plane from each neighbour, one plane to each neighbour
+    assert sorted(set(tr.log)) == sorted([("recv", 0, offsets[1] - plane, plane), ("recv", 2, offsets[2], plane),
+                                          ("send", 0, offsets[1], plane), ("send", 2, offsets[2] - plane, plane)]), tr.log[:8]
+    del op
 
 
 def test_transposed_modes_through_cached_explicit_transpose(be):
