@@ -123,25 +123,41 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
                       const void* d_x, double beta, void* d_y, int vector_type, kkamd_stream_t stream);
 
 /* Expert knobs, the analogue of SPMVHandleImpl's public tuning members
- * (sparse/src/KokkosSparse_spmv_handle.hpp:243-252); per plan, or as defaults for plans created later.
- *   SpMV   "kernel" (0 auto, 1 no-analysis vector kernel), "lanes_per_row", "nnz_per_thread" (4 | 8 | 16, 0 = by size),
- *          "window_codes" (1: analysed handles try the 16-bit column codes + LDS-staged x from "window_codes_min_knnz" thousand
- *                          nnz, 2: codes without staged x, 0: never),
- *          "pattern_codes" (staged-x plans: row-pattern records instead of per-nonzero codes; 0 off (default), 1 when >= 90 % of the
- *                           tiles decompose, 2 whenever one does),
- *          "stream_variant" (1 default; 6 = 16-bit window codes for the columns, built by the analysis when every tile's
- *                            columns fit 16 windows of 4096, else the plan behaves like 1), "xcd_remap" (tile order: 0 dispatch, 1 XCD-contiguous, G >= 2 grouped; default 16), "nontemporal",
- *          "transient_min_knnz"  handle-less / FAST_SETUP calls analyse on the fly from this many thousand nnz (0 never),
- *          "explicit_transpose"  modes T/H through a transpose cached in the plan: 0 off (atomic scatter, default),
- *                                1 refresh the transposed values every call, 2 caller promises constant values,
- *          "explicit_transpose_min_knnz",
- *          "mv_kernel", "mv_remap" (rank-2 kernels); "struct_remap", "struct_group", "struct_strip" (kkamd_spmv_struct workgroup orders, global only, all off); "ablate", "lds_pad_kb" are measurement aids.
+ * (sparse/src/KokkosSparse_spmv_handle.hpp:243-252); per plan (kkamd_spmv_plan_set / kkamd_spmv_plan_create_knobs), or as
+ * defaults for plans created later (kkamd_set_default).  Values outside the listed ranges return KKAMD_ERR_INVALID_ARG.
+ *   SpMV, rank 1
+ *     "kernel"          0 auto, 1 no-analysis vector kernel, 2 nnz-split kernel
+ *     "lanes_per_row"   vector kernel, 0 = from nnz / row (the reference's vector_length)
+ *     "nnz_per_thread"  nnz-split kernel: 4 (fp64 values only) | 8 | 16 nonzeros per work-item = 1024 / 2048 / 4096 per tile, 0 = by size
+ *     "xcd_remap"       tile order: 0 dispatch, 1 XCD-contiguous, 2^k grouped (default 16)
+ *     "window_codes"    per-tile column analysis of an analysed handle: 1 (default) 16-bit window codes + LDS-staged x where a tile's
+ *                       columns allow it, 2 codes without staged x, 0 never; from "window_codes_min_knnz" thousand nonzeros and when
+ *                       at least "window_codes_min_pct" percent of the tiles can use them (the others read entries, tile by tile);
+ *                       "stream_variant" 6 attempts the analysis whatever the size (tests), 1 is the default
+ *     "pattern_codes"   staged-x tiles: row-pattern records instead of per-nonzero codes; 1 (default) when >= 90 % of the tiles
+ *                       decompose, 2 whenever one does, 0 never; from "pattern_codes_min_knnz" thousand nonzeros
+ *     "transient_min_knnz"  handle-less / FAST_SETUP calls analyse on the fly from this many thousand nonzeros (0 never)
+ *     "explicit_transpose"  modes T/H with an analysed handle: 1 (default) through a transpose cached in the plan when it fits an
+ *                       eighth of free HBM, values that changed since the last call are moved into it; 2 the caller promises constant
+ *                       values (no comparison either); 0 the reference's atomic scatter.  From "explicit_transpose_min_knnz"
+ *   SpMV, rank 2
+ *     "mv_kernel"       0 auto (wave-private gather kernel), 1 generic strided kernel, 2 wave-private kernel, 3 LDS-staged X tiles
+ *     "mv_order"        row-block order: 2 (default) strips from the far stride found in the matrix (falls back to "mv_remap"),
+ *                       1 XCD-contiguous (LDS-staged kernel), 0 "mv_remap": 0 dispatch, 1 XCD-contiguous, 2^k grouped (default 16)
+ *     "mv_strip_min_kb" / "mv_strip_l2_kb"  when strips engage / how much of an XCD's L2 a strip's X rows may take
+ *     "mv_glds"         LDS-staged kernel: X window through global_load_lds (1) or registers (0)
+ *   kkamd_spmv_struct (global only): "struct_remap", "struct_group", "struct_strip" workgroup orders, all off
+ *   "verbose" (global): 1 = the library reports what it chose on stdout
  *   SpGEMM (kkamd_set_default only) "spgemm_win_bits" (columns per LDS bitmap pass), "spgemm_val_cap", "spgemm_val_shape",
- *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_debug" (ablation bits). */
+ *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_emit_chunked" (test hooks for alternative code paths).
+ * Knobs that switch parts of kernels OFF ("ablate", "lds_pad_kb", "struct_lds_pad_kb", "spgemm_debug") exist only in the
+ * measurement build libkkamd_ablate.so (csrc: make ablate, -DKK_ABLATE); libkkamd.so answers KKAMD_ERR_INVALID_ARG. */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);
 int kkamd_set_default(const char* key, int value);
-/* What the analysis of a plan produced: "tile" (nnz per workgroup, 0 = no tiling), "tiles", "pattern_tiles" (tiles decoded from row-pattern records), "window_staged_x", "window_codes" (1 if the
- * 16-bit column codes of stream_variant 6 are in use), "transpose_cached". */
+/* What the analysis of a plan produced: "tile" (nnz per workgroup, 0 = no tiling), "tiles", per-mode tile counts "plain_tiles" /
+ * "code_tiles" / "staged_tiles" / "pattern_tiles", "window_codes" (1 if any tile uses the column analysis), "window_staged_x",
+ * "plan_bytes" (HBM the analysis keeps), "transpose_cached", rank 2: "mv_tiles", "mv_staged_tiles", "mv_order" (order in use),
+ * "mv_period" (far stride found), "mv_plan_bytes". */
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);
 /* Copies a per-tile array of the analysis to a HOST buffer of `count` int32: "tile_first_row" (tiles + 1 entries: the first row that
  * starts at or after nonzero b * tile, bit 31 set when the tile starts inside a row -- the nnz-split counterpart of the

@@ -1076,7 +1076,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "mv_order") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv_order = value; }
   else if (k == "mv_strip_min_kb") { if (value < 0) return bad("non-negative"); t.mv_strip_min_kb = value; }
   else if (k == "mv_strip_l2_kb") { if (value < 1) return bad("positive"); t.mv_strip_l2_kb = value; }
-  else if (k == "mv_inner") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv_inner = value; }
+  else if (k == "mv_glds") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv_glds = value; }
   else if (k == "window_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.window_codes = value; }
   else if (k == "window_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.window_codes_min_knnz = value; }
   else if (k == "window_codes_min_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.window_codes_min_pct = value; }

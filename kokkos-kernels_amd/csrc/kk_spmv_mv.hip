@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void mv_build_kernel(int64_t nrows, int64_t
 //      eight 16-byte LDS reads of X, sixteen FMAs;
 //   4. Y leaves as 16 bytes per lane, 128 contiguous bytes per row.
 // Tiles in gather mode (kMvGather) take the same route with the column in place of the offset and X read from memory.
-template <class OffT, class AT, int NV>
+template <class OffT, class AT, int NV, bool GLDS>
 __global__ __launch_bounds__(kBlock, 3) void spmv_mv3_kernel(int64_t nrows, int64_t ncols, const OffT* __restrict__ row_map,
                                                           const int32_t* __restrict__ entries, const AT* __restrict__ values,
                                                           const uint16_t* __restrict__ slot, const int32_t* __restrict__ meta,
@@ -434,21 +434,13 @@ __global__ __launch_bounds__(kBlock, 3) void spmv_mv3_kernel(int64_t nrows, int6
     for (int64_t c = 0; c < n; c += cap_rec) {                 // one pass for staged tiles; gather tiles may be longer
       const int64_t ce = (c + cap_rec < n) ? c + cap_rec : n;
       if (c > 0 || kk > 0) __syncthreads();                    // the previous pass is done with the LDS
-      // 1. requests: A entries ...
-      constexpr int AMAX = kMvNnzCap / kBlock;
-      AT av[AMAX]; int ao[AMAX];
+      // 1. requests: the X window first, 16 bytes per request, straight into LDS (global_load_lds: no register round trip;
+      //    piece g lands at byte 16 g, i.e. wave-uniform base + 16 * lane) ...
+      constexpr int AMAX = kMvNnzCap / kBlock, AR = 4;           // A entries per work-item, in rounds of AR
       if (mode == kMvStaged) {
-        KK_UNROLL
-        for (int k = 0; k < AMAX; ++k) {                       // unguarded (clamped) loads stay in flight together
-          if (c + (int64_t)k * kBlock >= ce || KK_ABL(4)) break;            // workgroup-uniform
-          int64_t i = c + (int64_t)k * kBlock + t;
-          i = i < ce ? i : ce - 1;
-          av[k] = values[a0 + i]; ao[k] = (int)slot[a0 + i] * ROWB;
-        }
-        // ... and the X window, 16 bytes per request, straight into LDS (global_load_lds: no register round trip; piece g
-        // lands at byte 16 g, i.e. wave-uniform base + 16 * lane)
         const int npieces = nchunks * PPC;
         constexpr int XMAX = (kMvXBytes / 16 + kBlock - 1) / kBlock;
+        XV xv[GLDS ? 1 : XMAX];                                // GLDS = false (knob mv_glds 0): through registers, for comparison
         KK_UNROLL
         for (int k = 0; k < XMAX; ++k) {
           if (k * kBlock >= npieces) break;                    // workgroup-uniform
@@ -457,12 +449,27 @@ __global__ __launch_bounds__(kBlock, 3) void spmv_mv3_kernel(int64_t nrows, int6
             const int ch = g / PPC, p = g % PPC;
             int64_t col = (int64_t)m[kMvHdr + ch] + p / PPR;
             col = col < ncols ? col : ncols - 1;               // the padding of the last run may reach past the matrix
-            KK_GLDS16(X + col * xs0 + kk + (p % PPR) * 2, xwin + (size_t)(k * kBlock + (t & ~63)) * 16, t & 63);
+            if (GLDS) KK_GLDS16(X + col * xs0 + kk + (p % PPR) * 2, xwin + (size_t)(k * kBlock + (t & ~63)) * 16, t & 63);
+            else xv[GLDS ? 0 : k] = *reinterpret_cast<const XV*>(X + col * xs0 + kk + (p % PPR) * 2);
           }
         }
-        // 2. A into LDS
-        KK_UNROLL
-        for (int k = 0; k < AMAX; ++k) { const int i = k * kBlock + t; if (c + i < ce) { a_val[i] = (double)av[k]; a_off[i] = ao[k]; } }
+        // ... then the tile's A entries (values + slots, coalesced), AR per work-item in flight, into LDS as (value, byte offset)
+        for (int k0 = 0; k0 < AMAX; k0 += AR) {
+          if (c + (int64_t)k0 * kBlock >= ce || KK_ABL(4)) break;             // workgroup-uniform
+          AT av[AR]; int ao[AR];
+          KK_UNROLL
+          for (int k = 0; k < AR; ++k) {                       // unguarded (clamped) loads stay in flight together
+            int64_t i = c + (int64_t)(k0 + k) * kBlock + t;
+            i = i < ce ? i : ce - 1;
+            av[k] = values[a0 + i]; ao[k] = (int)slot[a0 + i] * ROWB;
+          }
+          KK_UNROLL
+          for (int k = 0; k < AR; ++k) { const int i = (k0 + k) * kBlock + t; if (c + i < ce) { a_val[i] = (double)av[k]; a_off[i] = ao[k]; } }
+        }
+        if (!GLDS) {
+          KK_UNROLL
+          for (int k = 0; k < XMAX; ++k) { const int g = k * kBlock + t; if (g < npieces && !KK_ABL(1)) *reinterpret_cast<XV*>(xwin + (size_t)g * 16) = xv[GLDS ? 0 : k]; }
+        }
         KK_GLDS_WAIT();                                        // this wave's pieces have landed (the barrier covers the other waves')
       } else {
         for (int64_t i = c + t; i < ce; i += kBlock) { a_val[i - c] = (double)values[a0 + i]; a_off[i - c] = entries[a0 + i]; }
@@ -679,10 +686,13 @@ static int launch_mv3(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   if (cap_rec < 256) cap_rec = 256;
   const size_t lds  = (size_t)xbytes + 12 * (size_t)cap_rec;
   const int yv      = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
-  KK_LAUNCH((spmv_mv3_kernel<OffT, AT, NV>), (unsigned)mv->ntiles, kBlock, lds, st, A->num_rows, A->num_cols, (const OffT*)A->d_row_map,
-            (const int32_t*)A->d_entries, (const AT*)A->d_values, (const uint16_t*)mv->d_slot, (const int32_t*)mv->d_meta,
-            mv->meta_stride, (const int32_t*)(mv->order_used == 2 ? mv->d_order : nullptr), mv->order_used == 1 ? 1 : 0, X, ldx, Y, ys0,
-            ys1, nvec, alpha, beta, yv, xbytes, cap_rec KK_ABL_ARG(plan));
+#define KK_MV3(G)                                                                                                            \
+  KK_LAUNCH((spmv_mv3_kernel<OffT, AT, NV, G>), (unsigned)mv->ntiles, kBlock, lds, st, A->num_rows, A->num_cols, (const OffT*)A->d_row_map, \
+            (const int32_t*)A->d_entries, (const AT*)A->d_values, (const uint16_t*)mv->d_slot, (const int32_t*)mv->d_meta,           \
+            mv->meta_stride, (const int32_t*)(mv->order_used == 2 ? mv->d_order : nullptr), mv->order_used == 1 ? 1 : 0, X, ldx, Y, ys0, \
+            ys1, nvec, alpha, beta, yv, xbytes, cap_rec KK_ABL_ARG(plan))
+  if (plan->tune.mv_glds) { KK_MV3(true); } else { KK_MV3(false); }
+#undef KK_MV3
   KK_LAUNCH_CHECK();
   return KKAMD_OK;
 }

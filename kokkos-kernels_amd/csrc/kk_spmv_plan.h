@@ -33,7 +33,7 @@ struct SpmvTuning {
   int mv_order       = 2;  // rank-2 LDS-staged kernel, tile order: 0 dispatch, 1 XCD-contiguous, 2 strips from the detected grid strides (falls back to 1)
   int mv_strip_min_kb = 3000;  // ... strips engage when three periods' worth of X rows exceed this (an XCD's L2 holds 4 MB)
   int mv_strip_l2_kb  = 2500;  // ... and are sized so that three periods' worth of a strip's X rows stay below this
-  int mv_inner       = 0;  // rank-2 LDS-staged kernel, contraction: 0 auto, 1 VALU, 2 MFMA (v_mfma_f64_4x4x4 on row-pattern tiles)
+  int mv_glds        = 1;  // rank-2 LDS-staged kernel: X window through global_load_lds (1) or through registers (0)
   int explicit_transpose = 1;   // modes T/H with an analysed handle: 1 = cache A^T in the plan (when it fits an eighth of free HBM), move the
                                 // values that changed since the last call into it and run the N kernel on it; 2 = same, the caller promises
                                 // constant values (no comparison); 0 = the reference's atomic scatter

@@ -21,7 +21,7 @@ def timeit(fn, it=6):
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 A = kk.laplace_matrix("FE", n, n, n)
 X = torch.rand(A.numCols(), 16, dtype=torch.float64, device="cuda"); Y = torch.zeros(A.numRows(), 16, dtype=torch.float64, device="cuda")
-for order in (2, 1):
+for glds in (1, 0):
     for ab in (0, 1, 2, 4, 8, 3, 5, 7, 15):
-        h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("mv_kernel", 3); h.set("mv_order", order); h.set("ablate", ab)
-        print("order %d ablate %2d: %.3f ms" % (order, ab, timeit(lambda: kk.spmv(h, "N", 1.0, A, X, 0.0, Y))), flush=True)
+        h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("mv_kernel", 3); h.set("mv_order", 2); h.set("ablate", ab); h.set("mv_glds", glds)
+        print("glds %d ablate %2d: %.3f ms" % (glds, ab, timeit(lambda: kk.spmv(h, "N", 1.0, A, X, 0.0, Y))), flush=True)

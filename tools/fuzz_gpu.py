@@ -13,7 +13,7 @@ be = kk.torch_backend()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 t_end = time.time() + budget
-n_ok = 0; case = 0
+n_ok = 0; case = 0; per_kind = [0] * 8
 def hubby(rng, n, ncols, base, nhubs, hublen, sort=True):
     lens = rng.integers(0, 2 * base + 1, size=n)
     for h in rng.choice(n, size=min(nhubs, n), replace=False):
@@ -36,7 +36,8 @@ while time.time() < t_end:
             pc.check_spgemm(be, A, B, offset_dtype=odt, value_dtype=vdt)
         elif kind == 1:    # SpGEMM, R-MAT square
             s = int(rng.integers(8, 14)); R = oracle.rmat(s, int(rng.integers(4, 24)), seed=int(rng.integers(1, 1 << 30)))
-            pc.check_spgemm(be, R, R, offset_dtype=odt, value_dtype=vdt)
+            pc.check_spgemm(be, R, R, offset_dtype=odt, value_dtype=vdt, algo=("SPGEMM_KK_DENSE" if s <= 10 and rng.random() < 0.3 else "SPGEMM_KK"),
+                            options={"compression": int(rng.integers(0, 3))})
         elif kind == 2:    # SpGEMM, unsorted inputs with duplicates (B unsorted -> HBM accumulators for dense rows)
             A = pc.randomized(oracle.random_crs(int(rng.integers(20, 200)), 150, int(rng.integers(2, 40)), seed=int(rng.integers(1, 1 << 30))))
             B = hubby(rng, 150, int(rng.integers(2000, 30000)), int(rng.integers(2, 20)), 3, 6000, sort=False)
@@ -83,15 +84,21 @@ while time.time() < t_end:
                 M = oracle.random_crs(n, n + int(rng.integers(0, 50)), int(rng.integers(1, 40)), variance=int(rng.integers(0, 10)), seed=int(rng.integers(1, 1 << 30)),
                                       bandwidth=int(rng.integers(5, 3000)))
             knobs = {"window_codes_min_knnz": 0, "window_codes": int(rng.integers(1, 3)), "nnz_per_thread": int(rng.choice([0, 4, 8, 16])),
-                     "xcd_remap": int(rng.choice([0, 1, 2, 16])), "pattern_codes": int(rng.choice([0, 1, 2, 2])), "pattern_codes_min_knnz": 0}
+                     "xcd_remap": int(rng.choice([0, 1, 2, 16])), "pattern_codes": int(rng.choice([0, 1, 2, 2])), "pattern_codes_min_knnz": 0,
+                     "window_codes_min_pct": int(rng.choice([0, 10, 25, 60]))}
+            if rng.random() < 0.5:     # rank 2 on the same matrix: LDS-staged tiles and the wave-private kernel, every tile order
+                pc.check_spmv_mv(be, M, int(rng.choice([8, 16, 24, 5])), "N", float(rng.integers(-3, 4)), float(rng.integers(-1, 2)), "C", str(rng.choice(["C", "F"])),
+                                 algo="SPMV_DEFAULT", seed=case, max_val=50.0,
+                                 knobs={"mv_kernel": int(rng.choice([2, 3])), "mv_order": int(rng.integers(0, 3)), "mv_strip_min_kb": 50, "mv_strip_l2_kb": int(rng.choice([64, 512]))})
             for beta in (0.0, float(rng.integers(-2, 3))):
                 pc.check_spmv(be, M, "N", float(rng.integers(-3, 4)), beta, algo="SPMV_DEFAULT", offset_dtype=odt, max_val=50.0, seed=case, knobs=knobs,
                               nans=(beta == 0.0), value_dtype=(vdt if vdt == np.float32 and rng.random() < 0.5 else None))
         else:              # spmv_struct, random grids
             nd = int(rng.integers(1, 4)); dims = tuple(int(rng.integers(3, 300 if nd == 1 else (150 if nd == 2 else 40))) for _ in range(nd))
             pc.check_spmv_struct(be, dims, 1 if nd == 1 else int(rng.integers(1, 3)), offset_dtype=odt, seed=case)
-        n_ok += 1
+        n_ok += 1; per_kind[kind] += 1
     except Exception as ex:
         print("FAILED case %d (seed %d, kind %d): %r" % (case - 1, seed0 + case - 1, kind, ex), flush=True)
         raise
-print("fuzz: %d cases passed in %.0f s (seeds %d..%d)" % (n_ok, budget, seed0, seed0 + case - 1))
+print("fuzz: %d cases passed in %.0f s (seeds %d..%d); per kind (spgemm skewed, spgemm rmat + options, spgemm unsorted, spmv irregular, sort/merge/transpose, "
+      "spmv_struct, spgemm long rows, spmv plan modes + rank 2): %s" % (n_ok, budget, seed0, seed0 + case - 1, per_kind))
