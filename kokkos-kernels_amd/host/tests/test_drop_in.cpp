@@ -12,6 +12,7 @@
 #include <limits>
 #include <random>
 #include "KokkosSparse_spmv.hpp"
+#include "KokkosSparse_dist_spmv.hpp"
 #include "KokkosSparse_spgemm.hpp"
 #include "KokkosSparse_IOUtils.hpp"
 #include "KokkosSparse_SortCrs.hpp"
@@ -393,8 +394,37 @@ void test_sort_merge_transpose() {
   }
 }
 
+// the multi-GPU operator with one rank (no communication): same y as the plain call, x kept in the operator's window
+void test_dist_single_rank() {
+  using M  = KokkosSparse::CrsMatrix<double, int, device, void, int>;
+  using V1 = Kokkos::View<double*, device>;
+  std::vector<int> rm, ent; std::vector<double> val;
+  const int n = 5000;
+  M A = make_random<double, int>(n, n, 9, rm, ent, val, 21);
+  V1 x("x", n), y("y", n), y2("y2", n);
+  std::vector<double> hx(n); std::mt19937 g(4); for (auto& v : hx) v = (g() % 1000) / 500.0 - 1.0;
+  Kokkos::deep_copy(x, Kokkos::View<double*, Kokkos::HostSpace>(hx.data(), n));
+  Kokkos::HIP space;
+  KokkosSparse::Experimental::DistributedSpMV<M> op(space, A, {0, (int64_t)n}, 0, nullptr);
+  EXPECT(op.query("exchange") == 0 && op.query("parts") == 1);
+  op.apply(space, 2.0, x, 0.0, y); space.fence();
+  KokkosSparse::spmv("N", 2.0, A, x, 0.0, y2); Kokkos::fence();
+  auto h1 = Kokkos::create_mirror_view(y); Kokkos::deep_copy(h1, y);
+  auto h2 = Kokkos::create_mirror_view(y2); Kokkos::deep_copy(h2, y2);
+  bool ok = true;
+  for (int i = 0; i < n; ++i) ok = ok && std::fabs(h1(i) - h2(i)) <= 1e-12;
+  EXPECT(ok);
+  V1 xl(op.x_local(), n);                                  // unmanaged view of the operator's own x window
+  Kokkos::deep_copy(xl, x);
+  op.apply(space, 2.0, xl, 0.0, y); space.fence();
+  Kokkos::deep_copy(h1, y);
+  for (int i = 0; i < n; ++i) ok = ok && std::fabs(h1(i) - h2(i)) <= 1e-12;
+  EXPECT(ok);
+}
+
 int main() {
   Kokkos::initialize();
+  test_dist_single_rank();
   test_sort_merge_transpose();
   test_ioutils();
   test_spmv_struct();

@@ -20,6 +20,7 @@ def timeit(fn, it=10):
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 quick = len(sys.argv) > 2
+sq = quick and sys.argv[2] == "sq"          # counter passes: the default kernel and the LDS-staged kernel once each
 A = kk.laplace_matrix("FE", n, n, n)
 nnz, rows = A.nnz(), A.numRows()
 for nv in ((16,) if quick else (16, 8, 32)):
@@ -31,6 +32,8 @@ for nv in ((16,) if quick else (16, 8, 32)):
     if not quick:
         cases += [("mv2 strip order, L2 budget %d KB" % kb, {"mv_kernel": 2, "mv_order": 2, "mv_strip_l2_kb": kb}) for kb in (1000, 1600, 3500)]
         cases += [("mv3 LDS-staged, order %d" % o, {"mv_kernel": 3, "mv_order": o}) for o in (1, 2)]
+    if sq:
+        cases = [cases[1], ("mv3 LDS-staged, order 2", {"mv_kernel": 3, "mv_order": 2})]
     for rep in range(2):
         for name, knobs in cases:
             h = kk.SPMVHandle("SPMV_DEFAULT")
@@ -40,7 +43,7 @@ for nv in ((16,) if quick else (16, 8, 32)):
                               "frac_8TBps": round(alg / ms / 1e6 / 8000, 3), "GFLOPs": round(2.0 * nnz * nv / ms / 1e6, 1),
                               "mv_tiles": h.query("mv_tiles"), "mv_staged": h.query("mv_staged_tiles"), "order_used": h.query("mv_order"),
                               "mv_plan_bytes": h.query("mv_plan_bytes")}), flush=True)
-    if nv == 16:
+    if nv == 16 and not sq:
         Xl = torch.rand(nv, A.numCols(), dtype=torch.float64, device="cuda").t(); Yl = torch.zeros(nv, rows, dtype=torch.float64, device="cuda").t()
         for name, knobs in (cases[0], cases[1]):
             h = kk.SPMVHandle("SPMV_DEFAULT")
