@@ -161,6 +161,13 @@ __global__ __launch_bounds__(kBlock) void rows_sorted_kernel(int64_t n, const Of
   if (bad) *unsorted = 1;
 }
 
+// sum of the per-row counts (before the scan) in 64 bits: a 32-bit row_map must not wrap silently
+template <class OffT> __global__ void sum_counts_kernel(int64_t m, const OffT* __restrict__ counts, unsigned long long* out) {
+  unsigned long long s = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) s += (unsigned long long)counts[r];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
 // row size of C from its row_map (numeric binning)
 template <class OffT>
 __global__ void spgemm_rowsize_kernel(int64_t m, const OffT* __restrict__ rmC, int64_t* __restrict__ sizes) {
@@ -1302,6 +1309,18 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     KK_VERBOSE("\tkkamd spgemm symbolic bins (rows): empty %lld, wave %lld, block-small %lld, block-large %lld, bitmap %lld\n",
            (long long)nb(0), (long long)nb(1), (long long)nb(2), (long long)nb(3), (long long)nb(4));
   hipError_t e = hipGetLastError();
+  if (e == hipSuccess && sizeof(OffT) == 4) {                   // 32-bit offsets: nnz(C) must fit before the in-place scan wraps
+    DevBuf tot_b; unsigned long long h_tot = 0;
+    KK_HIP(tot_b.alloc(sizeof(unsigned long long)));
+    unsigned long long* d_tot = tot_b.as<unsigned long long>();
+    KK_HIP(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), st));
+    const int64_t nbk = ceil_div(m, kBlock);
+    KK_LAUNCH((sum_counts_kernel<OffT>), (unsigned)(nbk < 4096 ? nbk : 4096), kBlock, 0, st, m, (const OffT*)rmC, d_tot);
+    KK_HIP(hipMemcpyAsync(&h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    if (h_tot > (unsigned long long)INT32_MAX)
+      return fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: nnz(C) = %llu overflows 32-bit offsets; use 64-bit offsets", h_tot);
+  }
   rc = (e == hipSuccess) ? exclusive_scan_inplace<OffT>(rmC, m + 1, st) : fail(KKAMD_ERR_HIP, "spgemm symbolic launch failed: %s", hipGetErrorString(e));
   OffT total = 0;
   if (rc == KKAMD_OK) {

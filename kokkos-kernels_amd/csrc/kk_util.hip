@@ -254,29 +254,32 @@ template <class OffT> __global__ void max_row_len_kernel(int64_t nrows, const Of
 
 template <class OffT, class VT, bool HAS_VAL>
 static int sort_vt(int64_t nrows, const OffT* rm, int32_t* d_entries, VT* d_values, hipStream_t st) {
-  int* d_max = nullptr;
-  KK_HIP(hipMalloc((void**)&d_max, sizeof(int)));
+  DevBuf max_b;                                                // temporaries free themselves on every early return
+  KK_HIP(max_b.alloc(sizeof(int)));
+  int* d_max = max_b.as<int>();
   KK_HIP(hipMemsetAsync(d_max, 0, sizeof(int), st));
   const int64_t nb = ceil_div(nrows, kBlock);
   KK_LAUNCH((max_row_len_kernel<OffT>), (unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st, nrows, rm, d_max);
   int h_max = 0;
   KK_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
-  KK_HIP(hipFree(d_max));
+  max_b.reset();
   KK_LAUNCH((sort_rows_kernel<OffT, VT, HAS_VAL>), (unsigned)(nrows < 65536 ? nrows : 65536), kBlock, 0, st, nrows, rm, d_entries, d_values);
   KK_LAUNCH_CHECK();
   if (h_max <= kSortCap) return KKAMD_OK;
   // long rows
-  int32_t* d_list = nullptr; unsigned long long* d_cnt = nullptr; unsigned long long h_cnt = 0;
+  DevBuf list_b, cnt_b;
+  unsigned long long h_cnt = 0;
   OffT h_nnz = 0;
-  KK_HIP(hipMalloc((void**)&d_list, sizeof(int32_t) * (size_t)nrows));
-  KK_HIP(hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
+  KK_HIP(list_b.alloc(sizeof(int32_t) * (size_t)nrows));
+  KK_HIP(cnt_b.alloc(sizeof(unsigned long long)));
+  int32_t* d_list = list_b.as<int32_t>(); unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
   KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
   KK_LAUNCH((long_rows_kernel<OffT>), (unsigned)nb, kBlock, 0, st, nrows, rm, d_list, d_cnt);
   KK_HIP(hipMemcpyAsync(&h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
   KK_HIP(hipMemcpyAsync(&h_nnz, rm + nrows, sizeof(OffT), hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
-  KK_HIP(hipFree(d_cnt));
+  cnt_b.reset();
   const unsigned L = (unsigned)h_cnt;
   int rc = KKAMD_OK;
   int32_t* t_e = nullptr; VT* t_v = nullptr;
@@ -304,7 +307,7 @@ static int sort_vt(int64_t nrows, const OffT* rm, int32_t* d_entries, VT* d_valu
   }
   if (t_e) (void)hipFree(t_e);
   if (t_v) (void)hipFree(t_v);
-  (void)hipFree(d_list);
+  list_b.reset();
   return rc;
 }
 
