@@ -1070,13 +1070,14 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "lanes_per_row") { if (value < 0 || value > 64) return bad("in 0..64"); t.lanes_per_row = value; }
   else if (k == "nnz_per_thread") { if (value != 0 && value != 4 && value != 8 && value != 16) return bad("0, 4, 8 or 16"); t.nnz_per_thread = value; }
   else if (k == "xcd_remap") { if (!valid_order_knob(value)) return bad("0, 1 or a power of two"); t.xcd_remap = value; }
-  else if (k == "mv_kernel") { if (value < 0 || value > 3) return bad("in 0..3"); t.mv_kernel = value; }
+  else if (k == "mv_kernel") { if (value < 0 || value > 4) return bad("in 0..4"); t.mv_kernel = value; }
   else if (k == "stream_variant") { if (value != 1 && value != 6) return bad("1 or 6"); t.stream_variant = value; }
   else if (k == "mv_remap") { if (!valid_order_knob(value)) return bad("0, 1 or a power of two"); t.mv_remap = value; }
   else if (k == "mv_order") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv_order = value; }
   else if (k == "mv_strip_min_kb") { if (value < 0) return bad("non-negative"); t.mv_strip_min_kb = value; }
   else if (k == "mv_strip_l2_kb") { if (value < 1) return bad("positive"); t.mv_strip_l2_kb = value; }
   else if (k == "mv_glds") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv_glds = value; }
+  else if (k == "mv4_wg_per_cu") { if (value < 1 || value > 64) return bad("in 1..64"); t.mv4_wg_per_cu = value; }
   else if (k == "window_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.window_codes = value; }
   else if (k == "window_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.window_codes_min_knnz = value; }
   else if (k == "window_codes_min_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.window_codes_min_pct = value; }
@@ -1369,6 +1370,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_ypack) (void)hipFree(plan->d_ypack);
   if (plan->d_mv2_order) (void)hipFree(plan->d_mv2_order);
   if (plan->mv) kk::mv_plan_destroy(plan->mv);
+  if (plan->mv4) kk::mv4_plan_destroy(plan->mv4);
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
   if (plan->d_t_perm) (void)hipFree(plan->d_t_perm);
@@ -1402,6 +1404,10 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
     plan->mv2_tried = false;
   }
   if ((t.mv_order != old.mv_order || t.mv_strip_min_kb != old.mv_strip_min_kb || t.mv_strip_l2_kb != old.mv_strip_l2_kb) && plan->mv) { kk::mv_plan_destroy(plan->mv); plan->mv = nullptr; plan->mv_failed = false; }
+  if (t.mv4_wg_per_cu != old.mv4_wg_per_cu && plan->mv4) {
+    if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
+    kk::mv4_plan_destroy(plan->mv4); plan->mv4 = nullptr; plan->mv4_tried = false;
+  }
   return KKAMD_OK;
 }
 
@@ -1422,7 +1428,11 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "mv_staged_tiles") *value = kk::mv_plan_query(plan->mv, 1);
   else if (k == "mv_order") *value = plan->mv ? kk::mv_plan_query(plan->mv, 2) : (plan->d_mv2_order ? 2 : 0);
   else if (k == "mv_period") *value = plan->mv_period;
-  else if (k == "mv_plan_bytes") *value = kk::mv_plan_query(plan->mv, 3);
+  else if (k == "mv_plan_bytes") *value = kk::mv_plan_query(plan->mv, 3) + kk::mv4_plan_query(plan->mv4, 3);
+  else if (k == "mv4_workgroups") *value = kk::mv4_plan_query(plan->mv4, 0);
+  else if (k == "mv4_other_rows") *value = kk::mv4_plan_query(plan->mv4, 1);
+  else if (k == "mv4_stencil") *value = kk::mv4_plan_query(plan->mv4, 2);
+  else if (k == "mv4_near_stride") *value = kk::mv4_plan_query(plan->mv4, 4);
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
   return KKAMD_OK;
 }

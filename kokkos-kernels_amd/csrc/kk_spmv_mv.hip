@@ -729,6 +729,370 @@ static const int32_t* mv2_order(kkamd_spmv_plan* plan, const kkamd_crs_t* A, int
   return A->offset_type == KKAMD_I64 ? mv2_order_t<int64_t>(plan, A, rows_per_wg, rowbytes, st) : mv2_order_t<int32_t>(plan, A, rows_per_wg, rowbytes, st);
 }
 
+// ================================================================================================================
+// Plane-marching rank-2 kernel (knob mv_kernel 4; analysed handles, 16 fp64 right-hand sides, row-major X).
+//
+// What the two kernels above cannot do is keep X inside the CU across MANY rows: the gather kernel re-reads every X row
+// through the texture path once per nonzero, the LDS-staged tiles re-fetch their window once per 32 rows.  On a matrix whose
+// rows are a radius-1 stencil on an nx x ny x nz lattice -- found, not assumed: the strides S2 (= nx ny) and S1 (= nx) come
+// out of the columns of a few rows, one interior row gives the offset list, and a device pass checks EVERY row against it --
+// a workgroup takes a patch of RI x RJ lattice points and MARCHES along the far stride: the X rows of three consecutive
+// planes of the patch (plus a one-point halo) sit in an LDS ring of four slabs and an X row crosses L2 -> LDS about 1.6
+// times per product instead of once per tile that touches it.  Rows that conform read no column information at all (8 B per
+// nonzero, the values, plus one word per row: where the values start, or -1); the others -- lattice boundaries, anything
+// irregular: 2 % of C3 -- are listed by the analysis and done by a small gather kernel afterwards.
+//   One plane of the patch = two steps of 64 rows (8 lanes per row, two right-hand sides per lane).  One workgroup fits a CU
+// (133-162 KB of LDS), so HBM latency cannot be hidden by other workgroups; the loop is software-pipelined a whole plane deep
+// instead, TWO planes deep: while plane k is computed out of LDS, the values of planes k + 1 and k + 2, the X slabs of planes
+// k + 2 and k + 3 and the row words of plane k + 3 are in flight to two register sets (about 108 KB per CU), and the older
+// set is written to the other half of the value buffer and to the free ring slot just before the plane's single barrier.  (Measured alternatives, profiles/round2: global_load_lds
+// for all three streams -- LDS-DMA sustains about 12 B/clk/CU with 16-byte pieces and a quarter of that with 4-byte ones --
+// 5.9 ms; values one step ahead with a wait per step 4.35 ms.)
+constexpr int kMv4Threads = 512, kMv4RI = 32, kMv4RJ = 4, kMv4MaxL = 28;
+__host__ __device__ constexpr int mv4_pitch(int ne, int vbytes) {   // entries per row of the value ring: the 4 rows of a read group on 4 different 16-B slots
+  return ((ne * vbytes) % 128 == 0) ? ne + 2 * (8 / vbytes) : ne;
+}
+
+struct Mv4Tab { int n; int e[kMv4MaxL]; };   // analysis: n offsets col - row; kernel: n packed entries (dk + 1) | (dj (RI + 2) + di) << 2
+
+}  // namespace kk
+
+struct kkamd_mv4_plan {
+  int nx = 0, ny = 0, nz = 0, kc = 0;
+  int64_t S1 = 0, S2 = 0, npi = 0, npj = 0, nchunk = 0, n_nc = 0;
+  kk::Mv4Tab tab{};                  // packed entries, padded to the kernel's entry count with (centre, value 0)
+  void* d_arow = nullptr;            // [rows] offset type of the matrix: where the row's values start when it conforms to the stencil, else -1
+  int32_t* d_nc = nullptr;           // [n_nc] the rows that do not
+  size_t bytes = 0;
+};
+
+namespace kk {
+
+void mv4_plan_destroy(kkamd_mv4_plan* p) {
+  if (!p) return;
+  if (p->d_arow) (void)hipFree(p->d_arow);
+  if (p->d_nc) (void)hipFree(p->d_nc);
+  delete p;
+}
+int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what) {
+  if (!p) return 0;
+  switch (what) {
+    case 0: return p->npi * p->npj * p->nchunk;   // workgroups
+    case 1: return p->n_nc;                       // rows outside the stencil
+    case 2: return p->tab.n;
+    case 3: return (int64_t)p->bytes;
+    case 4: return p->S1;
+    default: return 0;
+  }
+}
+
+// arow[r] = row_map[r] when row r has exactly the reference row's entries, shifted (col[q] = r + off[q]), and sits strictly
+// inside the lattice, else -1; *count = rows that do not
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv4_verify_kernel(int64_t nrows, const OffT* __restrict__ row_map, const int32_t* __restrict__ entries,
+                                                            Mv4Tab offs, int nx, int ny, int nz, OffT* __restrict__ arow,
+                                                            unsigned long long* __restrict__ count) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int64_t b = (int64_t)row_map[r], len = (int64_t)row_map[r + 1] - b;
+  const int i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((int64_t)nx * ny));
+  bool ok = len == offs.n && i >= 1 && i <= nx - 2 && j >= 1 && j <= ny - 2 && k >= 1 && k <= nz - 2;
+  for (int q = 0; ok && q < offs.n; ++q) ok = (int64_t)entries[b + q] == r + offs.e[q];
+  arow[r] = ok ? (OffT)b : (OffT)-1;
+  if (!ok) atomicAdd(count, 1ull);
+}
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv4_list_kernel(int64_t nrows, const OffT* __restrict__ arow, int32_t* __restrict__ list,
+                                                          unsigned long long* __restrict__ cursor) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nrows && arow[r] < 0) list[atomicAdd(cursor, 1ull)] = (int32_t)r;
+}
+
+// rows outside the stencil pattern: 16 lanes per row (one right-hand side each); an entry's X row is one contiguous 128 B
+template <class OffT, class AT>
+__global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
+                                                          const int32_t* __restrict__ entries, const AT* __restrict__ values,
+                                                          const double* __restrict__ X, int64_t xs0, double* __restrict__ Y, int64_t ys0,
+                                                          int64_t ys1, double alpha, double beta) {
+  const int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
+  const int j = threadIdx.x & 15;
+  if (idx >= n_list) return;
+  const int64_t r = list[idx];
+  double acc = 0.0;
+  for (int64_t a = (int64_t)row_map[r]; a < (int64_t)row_map[r + 1]; ++a) acc += (double)values[a] * X[(int64_t)entries[a] * xs0 + j];
+  double* yp = Y + r * ys0 + j * ys1;
+  *yp = (beta == 0.0) ? alpha * acc : beta * (*yp) + alpha * acc;
+}
+
+template <class OffT, class AT, int NE, bool BETA0>
+__global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const AT* __restrict__ values, Mv4Tab tab,
+                                                                  const double* __restrict__ X, int64_t xs0, double* __restrict__ Y,
+                                                                  int64_t ys0, int64_t ys1, double alpha, double beta, int y_vec_ok, int nx,
+                                                                  int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc) {
+  constexpr int RI = kMv4RI, RJ = kMv4RJ, W = RI + 2, SLABR = (RJ + 2) * W, SLABB = SLABR * 128, NT = kMv4Threads;
+  constexpr int ROWS = NT / 8;                         // rows per step: two lines of the patch; two steps per plane
+  constexpr int NP = SLABR * 8, NXP = (NP + NT - 1) / NT;   // 16-byte pieces per slab, per thread
+  constexpr int LP = mv4_pitch(NE, (int)sizeof(AT));   // entries per row of the value buffer
+  constexpr int AV = (NE + 7) / 8;                     // values a lane carries for a row: entries c, c + 8, ...
+  using XV = kk_f64x2;
+  using AV2 = typename vec2<AT>::type;
+  KK_DYN_SMEM(char, smem);                             // [X ring: 4 slabs][values: 2 buffers x 2 steps x ROWS x LP]
+  char* ring = smem;
+  AT* abuf   = reinterpret_cast<AT*>(smem + 4 * (size_t)SLABB);
+  const int t = threadIdx.x, rs = t >> 3, line = rs / RI, ii = rs % RI, c = t & 7;
+  const int64_t b = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring patches of one k-chunk meet in one XCD's L2
+  const int64_t npatch = npi * npj;
+  const int64_t ch = b / npatch, p = b % npatch;
+  const int i0 = (int)(p % npi) * RI, j0 = (int)(p / npi) * RJ;
+  const int kbeg = (int)ch * kc, kend = (kbeg + kc < nz) ? kbeg + kc : nz;
+  const int njj = (j0 + RJ <= ny) ? RJ : ny - j0;
+  auto row_of = [&](int k, int u) -> int64_t {         // this lane's lattice row in step u of plane k, or -1
+    const int jj = 2 * u + line;
+    if (k >= kend || jj >= njj || i0 + ii >= nx) return -1;
+    return (int64_t)k * S2 + (int64_t)(j0 + jj) * S1 + i0 + ii;
+  };
+  // Every load of the loop is UNCONDITIONAL (indices clamped to something legal, the result discarded by a select): the
+  // compiler counts the vector-memory operations between a load and its use to place s_waitcnt vmcnt(N), and a load it may
+  // have branched around counts as zero -- one conditional load younger than the awaited one turns the wait into vmcnt(0).
+  // ... and nothing touches a loaded register before its real use (a select or a sign extension right after the load is a use:
+  // the wait would sit there): row words and values stay raw, validity is applied where they are consumed.
+  auto load_word = [&](int k, int u) -> OffT {         // raw: where the row's values start, or -1 (not a stencil row)
+    const int64_t r = row_of(k, u);
+    return arow[r >= 0 ? r : 0];
+  };
+  auto conforms = [&](int k, int u, OffT w) { return row_of(k, u) >= 0 && w >= 0; };
+  auto slab_ok = [&](int kp) { return kp >= 0 && kp < nz && kp <= kend; };   // workgroup-uniform; stencil rows reference no other plane
+  auto load_slab = [&](int kp, XV (&rx)[NXP]) {        // plane kp of the patch (with its halo): this thread's pieces
+    kp = kp < 0 ? 0 : (kp > nz - 1 ? nz - 1 : kp);
+    KK_UNROLL
+    for (int it = 0; it < NXP; ++it) {
+      int g = it * NT + t;
+      g = g < NP ? g : NP - 1;
+      const int xr = g >> 3, part = g & 7;
+      int jq = j0 - 1 + xr / W, iq = i0 - 1 + xr % W;
+      jq = jq < 0 ? 0 : (jq > ny - 1 ? ny - 1 : jq);    // halo points outside the lattice are never read: any legal address will do
+      iq = iq < 0 ? 0 : (iq > nx - 1 ? nx - 1 : iq);
+      const int64_t col = (int64_t)kp * S2 + (int64_t)jq * S1 + iq;
+      rx[it] = *reinterpret_cast<const XV*>(X + col * xs0 + part * 2);
+    }
+  };
+  auto store_slab = [&](int kp, const XV (&rx)[NXP]) {
+    if (!slab_ok(kp)) return;
+    char* dst = ring + (size_t)(kp & 3) * SLABB;
+    KK_UNROLL
+    for (int it = 0; it < NXP; ++it) {
+      const int g = it * NT + t;
+      if (g < NP) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = rx[it];
+    }
+  };
+  auto load_values = [&](int k, const OffT (&w)[2], AT (&ra)[2][AV]) {      // raw; rows that do not conform load the head of the array
+    KK_UNROLL
+    for (int u = 0; u < 2; ++u) {
+      const int64_t base = conforms(k, u, w[u]) ? (int64_t)w[u] : 0;
+      KK_UNROLL
+      for (int m = 0; m < AV; ++m) { const int q = c + 8 * m; ra[u][m] = values[base + (q < tab.n ? q : tab.n - 1)]; }
+    }
+  };
+  auto store_values = [&](int buf, int k, const OffT (&w)[2], const AT (&ra)[2][AV]) {      // pad entries (q >= n) carry 0
+    KK_UNROLL
+    for (int u = 0; u < 2; ++u) {
+      AT* dst = abuf + ((size_t)(buf * 2 + u) * ROWS + rs) * LP;
+      KK_UNROLL
+      for (int m = 0; m < AV; ++m) { const int q = c + 8 * m; if (q < NE) dst[q] = q < tab.n ? ra[u][m] : AT(0); }
+    }
+    (void)k; (void)w;                                  // rows that do not conform are never read
+  };
+  auto y_ptr = [&](int k, int u) -> double* { return Y + row_of(k, u) * ys0 + (2 * c) * ys1; };
+  auto load_yold = [&](int k, const OffT (&w)[2], XV (&yo)[2]) {
+    KK_UNROLL
+    for (int u = 0; u < 2; ++u) {
+      if (conforms(k, u, w[u])) {
+        const double* yp = y_ptr(k, u);
+        if (y_vec_ok) yo[u] = *reinterpret_cast<const XV*>(yp); else { yo[u][0] = yp[0]; yo[u][1] = yp[ys1]; }
+      }
+    }
+  };
+
+  // prologue: the row words of the first three planes, the values of the first, three planes of X; then the first set in flight
+  OffT w_cur[2], w_nxt[2], w_nn[2], w_new[2];
+  AT ra[2][2][AV];                                     // two sets in flight: set P is loaded in planes of parity P ...
+  XV rx[2][NXP];                                       // ... and written to LDS at the end of the next plane
+  KK_UNROLL
+  for (int u = 0; u < 2; ++u) { w_cur[u] = load_word(kbeg, u); w_nxt[u] = load_word(kbeg + 1, u); w_nn[u] = load_word(kbeg + 2, u); }
+  load_values(kbeg, w_cur, ra[0]);
+  for (int kp = kbeg - 1; kp <= kbeg + 1; ++kp) { load_slab(kp, rx[0]); store_slab(kp, rx[0]); }
+  store_values(0, kbeg, w_cur, ra[0]);
+  load_slab(kbeg + 2, rx[1]);
+  load_values(kbeg + 1, w_nxt, ra[1]);
+  __syncthreads();
+  for (int kk = kbeg; kk < kend; kk += 2) {
+    KK_UNROLL
+    for (int P = 0; P < 2; ++P) {                      // plane kk + P computes out of value buffer P
+      const int k = kk + P;
+      if (k >= kend) break;
+      // issued now, awaited at the end of the NEXT plane: the row words of plane k + 3 (first: they are moved, i.e. awaited, at
+      // the end of this plane, and operations retire in order), X of plane k + 3, the values of plane k + 2
+      KK_UNROLL
+      for (int u = 0; u < 2; ++u) w_new[u] = load_word(k + 3, u);
+      load_slab(k + 3, rx[P]);
+      load_values(k + 2, w_nn, ra[P]);
+      XV yold[2] = {{0.0, 0.0}, {0.0, 0.0}}, out[2] = {{0.0, 0.0}, {0.0, 0.0}};
+      if constexpr (!BETA0) load_yold(k, w_cur, yold);
+      KK_UNROLL
+      for (int u = 0; u < 2; ++u) {
+        if (conforms(k, u, w_cur[u])) {
+          const int jj = 2 * u + line;
+          const AT* av = abuf + ((size_t)(P * 2 + u) * ROWS + rs) * LP;
+          const char* own = ring + (((jj + 1) * W + ii + 1) << 7) + c * 16;   // this row's own X row in slot 0, this lane's piece
+          double acc0 = 0.0, acc1 = 0.0;
+          KK_UNROLL
+          for (int q = 0; q < NE; q += 2) {
+            const AV2 v = *reinterpret_cast<const AV2*>(av + q);             // two values per read (the row's 8 lanes: one address)
+            KK_UNROLL
+            for (int h = 0; h < 2; ++h) {
+              const int e = tab.e[q + h];                                    // uniform: scalar registers
+              const int sb = ((k + (e & 3) - 1) & 3) * SLABB + (e >> 2) * 128;
+              const XV x = *reinterpret_cast<const XV*>(own + sb);
+              acc0 = __builtin_fma((double)v[h], x[0], acc0); acc1 = __builtin_fma((double)v[h], x[1], acc1);
+            }
+          }
+          out[u][0] = alpha * acc0; out[u][1] = alpha * acc1;
+        }
+      }
+      // what the PREVIOUS plane issued: the values of plane k + 1 into the other buffer (last read in plane k - 1), X of plane
+      // k + 2 into the slot that held plane k - 2 -- both behind a barrier.  This plane's stores to Y come after the wait.
+      store_values(1 - P, k + 1, w_nxt, ra[1 - P]);
+      store_slab(k + 2, rx[1 - P]);
+      KK_UNROLL
+      for (int u = 0; u < 2; ++u) {
+        if (conforms(k, u, w_cur[u])) {
+          double* yp = y_ptr(k, u);
+          if constexpr (!BETA0) { out[u][0] += beta * yold[u][0]; out[u][1] += beta * yold[u][1]; }
+          if (y_vec_ok) *reinterpret_cast<XV*>(yp) = out[u]; else { yp[0] = out[u][0]; yp[ys1] = out[u][1]; }
+        }
+      }
+      __syncthreads();
+      KK_UNROLL
+      for (int u = 0; u < 2; ++u) { w_cur[u] = w_nxt[u]; w_nxt[u] = w_nn[u]; w_nn[u] = w_new[u]; }
+    }
+  }
+}
+
+// floor((d + s / 2) / s): the lattice step an offset d makes along a stride s
+static inline int64_t mv4_round_div(int64_t d, int64_t s) {
+  const int64_t v = d + s / 2;
+  return v >= 0 ? v / s : -((-v + s - 1) / s);
+}
+
+template <class OffT>
+static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st) {
+  plan->mv4_tried = true;
+  if (A->num_rows != A->num_cols || A->num_rows < 4096) return KKAMD_OK;
+  if (!plan->mv_period_known) { plan->mv_period = detect_period_rows<OffT>(A, st); plan->mv_period_known = true; }
+  const int64_t S2 = plan->mv_period;
+  if (S2 <= 0 || A->num_rows % S2) return KKAMD_OK;
+  // the near stride and the offset list: the longest of a few scattered rows whose offsets all decompose as
+  // dk S2 + dj S1 + di with |dk|, |dj|, |di| <= 1 (a shorter one is a boundary row)
+  int64_t S1 = 0; Mv4Tab offs{};
+  for (int s = 1; s <= 32; ++s) {
+    const int64_t r = (int64_t)((((unsigned long long)s * 0x9E3779B97F4A7C15ull) >> 11) % (unsigned long long)A->num_rows);
+    OffT rm[2];
+    if (hipMemcpyAsync(rm, (const OffT*)A->d_row_map + r, sizeof rm, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return KKAMD_OK;
+    const int len = (int)(rm[1] - rm[0]);
+    if (rm[1] - rm[0] < 3 || rm[1] - rm[0] > kMv4MaxL || len <= offs.n) continue;
+    int32_t cols[kMv4MaxL];
+    if (hipMemcpyAsync(cols, (const int32_t*)A->d_entries + (int64_t)rm[0], sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return KKAMD_OK;
+    int64_t near[kMv4MaxL]; int nn = 0;                // offsets between the unit neighbours and the far cluster: S1 - 1, S1, S1 + 1
+    for (int q = 0; q < len; ++q) { const int64_t d = cols[q] - r; if (d > 1 && 2 * d < S2) near[nn++] = d; }
+    if (!nn) continue;
+    for (int a = 1; a < nn; ++a) { const int64_t v = near[a]; int e = a - 1; while (e >= 0 && near[e] > v) { near[e + 1] = near[e]; --e; } near[e + 1] = v; }
+    const int64_t cand = near[nn / 2];
+    if (cand < 3 || S2 % cand) continue;
+    bool okr = true;
+    for (int q = 0; q < len && okr; ++q) {
+      const int64_t d = cols[q] - r, dk = mv4_round_div(d, S2), rem = d - dk * S2, dj = mv4_round_div(rem, cand), di = rem - dj * cand;
+      okr = dk >= -1 && dk <= 1 && dj >= -1 && dj <= 1 && di >= -1 && di <= 1;
+    }
+    if (!okr) continue;
+    S1 = cand; offs.n = len;
+    for (int q = 0; q < len; ++q) offs.e[q] = (int)(cols[q] - r);
+  }
+  if (!S1) return KKAMD_OK;
+  const int64_t nx = S1, ny = S2 / S1, nz = A->num_rows / S2;
+  if (nx < 8 || ny < 3 || nz < 3 || nx > (1 << 24) || ny > (1 << 24) || nz > (1 << 24)) return KKAMD_OK;
+  kkamd_mv4_plan* m = new (std::nothrow) kkamd_mv4_plan();
+  if (!m) return KKAMD_OK;
+  auto drop = [&]() { (void)hipGetLastError(); mv4_plan_destroy(m); return KKAMD_OK; };   // an optimisation: the gather kernel serves
+  m->nx = (int)nx; m->ny = (int)ny; m->nz = (int)nz; m->S1 = S1; m->S2 = S2;
+  DevBuf cnt;
+  if (hipMalloc(&m->d_arow, sizeof(OffT) * (size_t)A->num_rows) != hipSuccess || cnt.alloc(2 * sizeof(unsigned long long)) != hipSuccess) return drop();
+  unsigned long long* d_cnt = cnt.as<unsigned long long>();
+  OffT* d_arow = (OffT*)m->d_arow;
+  if (hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st) != hipSuccess) return drop();
+  KK_LAUNCH((mv4_verify_kernel<OffT>), (unsigned)ceil_div(A->num_rows, kBlock), kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map,
+            (const int32_t*)A->d_entries, offs, m->nx, m->ny, m->nz, d_arow, d_cnt);
+  unsigned long long h_bad = 0;
+  if (hipMemcpyAsync(&h_bad, d_cnt, sizeof h_bad, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return drop();
+  m->n_nc = (int64_t)h_bad;
+  if ((double)m->n_nc > 0.5 * (double)A->num_rows) return drop();               // mostly irregular: not this kernel's matrix
+  if (hipMalloc((void**)&m->d_nc, sizeof(int32_t) * (size_t)(m->n_nc > 0 ? m->n_nc : 1)) != hipSuccess) return drop();
+  int32_t* d_nc = m->d_nc;
+  KK_LAUNCH((mv4_list_kernel<OffT>), (unsigned)ceil_div(A->num_rows, kBlock), kBlock, 0, st, A->num_rows, (const OffT*)d_arow, d_nc, d_cnt + 1);
+  if (hipStreamSynchronize(st) != hipSuccess) return drop();
+  // per entry: plane selector and position relative to the row's own X row inside a slab; the pad entries read the centre
+  m->tab.n = offs.n;
+  for (int q = 0; q < kMv4MaxL; ++q) {
+    if (q >= offs.n) { m->tab.e[q] = 1; continue; }
+    const int64_t d = offs.e[q], dk = mv4_round_div(d, S2), rem = d - dk * S2, dj = mv4_round_div(rem, S1), di = rem - dj * S1;
+    m->tab.e[q] = (int)((dk + 1) | ((dj * (kMv4RI + 2) + di) * 4));
+  }
+  m->npi = ceil_div(nx, (int64_t)kMv4RI); m->npj = ceil_div(ny, (int64_t)kMv4RJ);
+  // k-chunks: enough workgroups to fill the chip several times over (one workgroup per CU at a time), few halo planes
+  int64_t nchunk = ceil_div((int64_t)plan->num_cus * plan->tune.mv4_wg_per_cu, m->npi * m->npj);
+  if (nchunk > nz / 4) nchunk = nz / 4;
+  if (nchunk < 1) nchunk = 1;
+  m->kc = (int)ceil_div(nz, nchunk); m->nchunk = ceil_div(nz, (int64_t)m->kc);
+  m->bytes = sizeof(OffT) * (size_t)A->num_rows + sizeof(int32_t) * (size_t)(m->n_nc > 0 ? m->n_nc : 1);
+  plan->mv4 = m;
+  return KKAMD_OK;
+}
+
+template <class OffT, class AT>
+static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0, int64_t ys1,
+                      double alpha, double beta, hipStream_t st) {
+  const kkamd_mv4_plan* m = plan->mv4;
+  const size_t slabs = 4 * (size_t)((kMv4RJ + 2) * (kMv4RI + 2) * 128), rows = kMv4Threads / 8;
+  const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
+#ifndef KK_EMU
+#define KK_MV4_ATTR(NE, B0) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, B0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+#else
+#define KK_MV4_ATTR(NE, B0) (void)0
+#endif
+#define KK_MV4B(NE, B0)                                                                                                         \
+  do {                                                                                                                          \
+    const size_t lds = slabs + 4 * rows * mv4_pitch(NE, (int)sizeof(AT)) * sizeof(AT);                                           \
+    KK_MV4_ATTR(NE, B0);                                                                                                        \
+    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, B0>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,                \
+              (const OffT*)m->d_arow, (const AT*)A->d_values, m->tab, X, ldx, Y, ys0, ys1, alpha, beta, yv, m->nx, m->ny, m->nz,  \
+              m->S1, m->S2, m->npi, m->npj, m->kc);                                                                              \
+  } while (0)
+#define KK_MV4(NE) do { if (beta == 0.0) KK_MV4B(NE, true); else KK_MV4B(NE, false); } while (0)
+  const int n = m->tab.n;
+  if (n <= 8) KK_MV4(8); else if (n <= 16) KK_MV4(16); else if (n <= 20) KK_MV4(20); else if (n <= 24) KK_MV4(24);
+  else KK_MV4(28);
+#undef KK_MV4B
+#undef KK_MV4
+#undef KK_MV4_ATTR
+  KK_LAUNCH_CHECK();
+  if (m->n_nc > 0) {
+    KK_LAUNCH((mv4_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, ldx, Y, ys0, ys1, alpha, beta);
+    KK_LAUNCH_CHECK();
+  }
+  return KKAMD_OK;
+}
+
 template <class OffT, class AT, class YT>
 static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dX,
                          int64_t xs0, int64_t xs1, double beta_d, void* dY, int64_t ys0, int64_t ys1, int64_t nvec,
@@ -746,7 +1110,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
     KK_LAUNCH_CHECK();
     return KKAMD_OK;
   }
-  const int mvk = plan ? plan->tune.mv_kernel : g_spmv_default.mv_kernel;      // 0 auto, 1 generic, 2 wave-private row-major, 3 LDS-staged X tiles
+  const int mvk = plan ? plan->tune.mv_kernel : g_spmv_default.mv_kernel;      // 0 auto, 1 generic, 2 wave-private row-major, 3 LDS-staged X tiles, 4 plane marching
   const bool a_aligned = ((uintptr_t)A->d_values % 16 == 0) && ((uintptr_t)A->d_entries % 16 == 0);
   if (mvk != 1 && a_aligned) {
     const YT* Xr = nullptr; int64_t ldx = 0;
@@ -778,6 +1142,17 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
           if (nv == 16) return launch_mv3<OffT, AT, 16>(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
           return launch_mv3<OffT, AT, 8>(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
         }
+      }
+    }
+    // plane-marching kernel (knob mv_kernel = 4): analysed handles, 16 fp64 right-hand sides, matrices that verify as a
+    // radius-1 lattice stencil; the analysis happens on the first such call
+    if constexpr (sizeof(YT) == 8) {
+      if (Xr && plan && plan->tile != 0 && mvk == 4 && nvec == 16 && plan->entries == A->d_entries) {
+        if (!plan->mv4 && !plan->mv4_tried) {
+          int rc = mv4_plan_build<OffT>(plan, A, st);
+          if (rc) return rc;
+        }
+        if (plan->mv4) return launch_mv4<OffT, AT>(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, (double)alpha, (double)beta, st);
       }
     }
     if (Xr) {

@@ -34,6 +34,7 @@ struct SpmvTuning {
   int mv_strip_min_kb = 3000;  // ... strips engage when three periods' worth of X rows exceed this (an XCD's L2 holds 4 MB)
   int mv_strip_l2_kb  = 2500;  // ... and are sized so that three periods' worth of a strip's X rows stay below this
   int mv_glds        = 1;  // rank-2 LDS-staged kernel: X window through global_load_lds (1) or through registers (0)
+  int mv4_wg_per_cu  = 8;  // rank-2 plane-marching kernel: workgroups per CU the k-chunking aims for (one is resident at a time)
   int explicit_transpose = 1;   // modes T/H with an analysed handle: 1 = cache A^T in the plan (when it fits an eighth of free HBM), move the
                                 // values that changed since the last call into it and run the N kernel on it; 2 = same, the caller promises
                                 // constant values (no comparison); 0 = the reference's atomic scatter
@@ -62,6 +63,7 @@ inline bool valid_order_knob(int v) { return v == 0 || v == 1 || (v >= 2 && v <=
 constexpr int kTilePlain = 0, kTileCodes = 1, kTileStaged = 2, kTilePattern = 3;
 
 struct kkamd_mv_plan;   // kk_spmv_mv.hip
+struct kkamd_mv4_plan;  // kk_spmv_mv.hip
 
 struct kkamd_spmv_plan {
   int64_t num_rows = 0, num_cols = 0, nnz = 0;
@@ -99,6 +101,9 @@ struct kkamd_spmv_plan {
   // rank-2 analysis (LDS-staged X tiles), built by the first rank-2 call that can use it
   kkamd_mv_plan* mv = nullptr;
   bool mv_failed = false;
+  // rank-2 analysis of the plane-marching kernel (lattice strides, per-row conformity), built by the first call that asks for it
+  kkamd_mv4_plan* mv4 = nullptr;
+  bool mv4_tried = false;
   // rank-2 wave-private kernel: its row blocks in strip order (see mv_build_strip_order)
   int32_t* d_mv2_order = nullptr;
   int mv2_rb = 0;
@@ -116,6 +121,8 @@ int  bind_stream(kkamd_spmv_plan* p, hipStream_t st);
 int  check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A);
 void mv_plan_destroy(kkamd_mv_plan* mv);
 int64_t mv_plan_query(const kkamd_mv_plan* mv, int what);   // 0 tiles, 1 pattern tiles, 2 order in use, 3 bytes
+void mv4_plan_destroy(kkamd_mv4_plan* p);
+int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what);  // 0 workgroups, 1 rows outside the stencil, 2 stencil entries, 3 bytes, 4 near stride
 int  release_transient();
 
 // native 2-element vectors (accepted by __builtin_nontemporal_load; same syntax under clang and gcc)

@@ -10,6 +10,7 @@ if has pytest; then timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gp
 if has pytestfast; then KK_SKIP_HEAVY=1 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu_fast.log 2>&1; echo "pytest(fast) rc=$?"; tail -4 $OUT/pytest_gpu_fast.log; fi
 if has bench;  then timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -3 $OUT/bench.err; cat $OUT/bench.json; fi
 if has mv3;    then timeout 900 python tools/bench_mv3.py 300 ${MV3_ARGS:-} > $OUT/bench_mv3.jsonl 2> $OUT/bench_mv3.err; echo "mv3 rc=$?"; tail -3 $OUT/bench_mv3.err; cat $OUT/bench_mv3.jsonl; fi
+if has mv4;    then timeout 900 python tools/bench_mv4.py 300 ${MV4_ARGS:-} > $OUT/bench_mv4.jsonl 2> $OUT/bench_mv4.err; echo "mv4 rc=$?"; tail -3 $OUT/bench_mv4.err; cat $OUT/bench_mv4.jsonl; fi
 if has extra;  then timeout ${EXTRA_TIMEOUT:-900} bash -c "$EXTRA_CMD" > $OUT/extra.log 2>&1; echo "extra rc=$?"; tail -${EXTRA_TAIL:-40} $OUT/extra.log; fi
 prof() {   # prof <tag> <command...>: kernel stats + FETCH_SIZE and WRITE_SIZE in separate passes
   local tag=$1; shift
@@ -22,6 +23,7 @@ prof() {   # prof <tag> <command...>: kernel stats + FETCH_SIZE and WRITE_SIZE i
 }
 if has profbench; then prof bench python $R/bench.py --steps 30 --no-cpu-baseline; fi
 if has profmv;    then prof mv python $R/tools/bench_mv3.py 300 quick; fi
+if has profmv4;   then prof mv4 python $R/tools/bench_mv4.py 300 quick; fi
 if has sq; then
   cd /tmp
   for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
