@@ -762,6 +762,7 @@ struct kkamd_mv4_plan {
   int64_t S1 = 0, S2 = 0, npi = 0, npj = 0, nchunk = 0, n_nc = 0;
   kk::Mv4Tab tab{};                  // packed entries, padded to the kernel's entry count with (centre, value 0)
   void* d_arow = nullptr;            // [rows] offset type of the matrix: where the row's values start when it conforms to the stencil, else -1
+  uint32_t* d_amask = nullptr;       // [rows] which entries of the stencil the row holds (all of them away from the lattice boundary)
   int32_t* d_nc = nullptr;           // [n_nc] the rows that do not
   size_t bytes = 0;
 };
@@ -771,6 +772,7 @@ namespace kk {
 void mv4_plan_destroy(kkamd_mv4_plan* p) {
   if (!p) return;
   if (p->d_arow) (void)hipFree(p->d_arow);
+  if (p->d_amask) (void)hipFree(p->d_amask);
   if (p->d_nc) (void)hipFree(p->d_nc);
   delete p;
 }
@@ -786,19 +788,34 @@ int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what) {
   }
 }
 
-// arow[r] = row_map[r] when row r has exactly the reference row's entries, shifted (col[q] = r + off[q]), and sits strictly
-// inside the lattice, else -1; *count = rows that do not
+// A row CONFORMS when its entries are, in order, a subset of the reference row's (col[q'] = r + off[q]), every entry it holds
+// points inside the lattice and every entry it lacks points outside: interior rows hold them all, rows on a lattice boundary
+// of a truncated stencil hold the rest, anything else (wrap-around couplings, extra or missing interior entries) does not
+// conform.  arow[r] = row_map[r] and amask[r] = the entries held, or -1 and 0; *count = rows that do not conform.
 template <class OffT>
 __global__ __launch_bounds__(kBlock) void mv4_verify_kernel(int64_t nrows, const OffT* __restrict__ row_map, const int32_t* __restrict__ entries,
-                                                            Mv4Tab offs, int nx, int ny, int nz, OffT* __restrict__ arow,
-                                                            unsigned long long* __restrict__ count) {
+                                                            Mv4Tab offs, Mv4Tab steps, int nx, int ny, int nz, OffT* __restrict__ arow,
+                                                            uint32_t* __restrict__ amask, unsigned long long* __restrict__ count) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   const int64_t b = (int64_t)row_map[r], len = (int64_t)row_map[r + 1] - b;
   const int i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((int64_t)nx * ny));
-  bool ok = len == offs.n && i >= 1 && i <= nx - 2 && j >= 1 && j <= ny - 2 && k >= 1 && k <= nz - 2;
-  for (int q = 0; ok && q < offs.n; ++q) ok = (int64_t)entries[b + q] == r + offs.e[q];
-  arow[r] = ok ? (OffT)b : (OffT)-1;
+  auto inside = [&](int q) {                           // steps.e[q] = (dk + 1) | (dj + 1) << 2 | (di + 1) << 4
+    const int s = steps.e[q], kk = k + (s & 3) - 1, jj = j + ((s >> 2) & 3) - 1, ii = i + ((s >> 4) & 3) - 1;
+    return kk >= 0 && kk < nz && jj >= 0 && jj < ny && ii >= 0 && ii < nx;
+  };
+  bool ok = len >= 1 && len <= offs.n;
+  uint32_t mask = 0;
+  int q = 0;
+  for (int64_t a = 0; ok && a < len; ++a) {
+    const int64_t d = (int64_t)entries[b + a] - r;
+    while (q < offs.n && offs.e[q] != d) ++q;          // in order: the packed position of an entry is the count of held entries before it
+    ok = q < offs.n && inside(q);
+    if (ok) mask |= 1u << q++;
+  }
+  for (int z = 0; ok && z < offs.n; ++z) ok = ((mask >> z) & 1u) || !inside(z);
+  arow[r]  = ok ? (OffT)b : (OffT)-1;
+  amask[r] = ok ? mask : 0u;
   if (!ok) atomicAdd(count, 1ull);
 }
 template <class OffT>
@@ -808,24 +825,38 @@ __global__ __launch_bounds__(kBlock) void mv4_list_kernel(int64_t nrows, const O
   if (r < nrows && arow[r] < 0) list[atomicAdd(cursor, 1ull)] = (int32_t)r;
 }
 
-// rows outside the stencil pattern: 16 lanes per row (one right-hand side each); an entry's X row is one contiguous 128 B
+// rows outside the stencil pattern: 16 lanes per row (one right-hand side each).  The lanes fetch 16 entries of the row at a
+// time (one each), then every lane walks all 16: the X reads of a chunk are independent loads (one contiguous 128 B each)
 template <class OffT, class AT>
 __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
                                                           const int32_t* __restrict__ entries, const AT* __restrict__ values,
                                                           const double* __restrict__ X, int64_t xs0, double* __restrict__ Y, int64_t ys0,
                                                           int64_t ys1, double alpha, double beta) {
-  const int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
+  int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
   const int j = threadIdx.x & 15;
-  if (idx >= n_list) return;
+  const bool live = idx < n_list;                      // no early return: the shuffles below want whole groups
+  if (!live) idx = n_list - 1;
   const int64_t r = list[idx];
+  const int64_t b = (int64_t)row_map[r], e = (int64_t)row_map[r + 1];
   double acc = 0.0;
-  for (int64_t a = (int64_t)row_map[r]; a < (int64_t)row_map[r + 1]; ++a) acc += (double)values[a] * X[(int64_t)entries[a] * xs0 + j];
+  for (int64_t a = b; a < e; a += 16) {
+    const bool in = a + j < e;
+    const int32_t my_col = in ? entries[a + j] : 0;
+    const double my_val  = in ? (double)values[a + j] : 0.0;
+    KK_UNROLL
+    for (int q = 0; q < 16; ++q) {
+      const int32_t col = __shfl(my_col, q, 16);
+      const double v    = __shfl(my_val, q, 16);
+      acc += v * X[(int64_t)col * xs0 + j];
+    }
+  }
+  if (!live) return;
   double* yp = Y + r * ys0 + j * ys1;
   *yp = (beta == 0.0) ? alpha * acc : beta * (*yp) + alpha * acc;
 }
 
 template <class OffT, class AT, int NE, bool BETA0>
-__global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const AT* __restrict__ values, Mv4Tab tab,
+__global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask, const AT* __restrict__ values, Mv4Tab tab,
                                                                   const double* __restrict__ X, int64_t xs0, double* __restrict__ Y,
                                                                   int64_t ys0, int64_t ys1, double alpha, double beta, int y_vec_ok, int nx,
                                                                   int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc) {
@@ -834,6 +865,7 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
   constexpr int NP = SLABR * 8, NXP = (NP + NT - 1) / NT;   // 16-byte pieces per slab, per thread
   constexpr int LP = mv4_pitch(NE, (int)sizeof(AT));   // entries per row of the value buffer
   constexpr int AV = (NE + 7) / 8;                     // values a lane carries for a row: entries c, c + 8, ...
+  constexpr int NLO = NE <= 8 ? 3 : (NE <= 16 ? 9 : NE - 3);   // this instantiation serves stencils of NLO..NE entries
   using XV = kk_f64x2;
   using AV2 = typename vec2<AT>::type;
   KK_DYN_SMEM(char, smem);                             // [X ring: 4 slabs][values: 2 buffers x 2 steps x ROWS x LP]
@@ -846,63 +878,101 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
   const int i0 = (int)(p % npi) * RI, j0 = (int)(p / npi) * RJ;
   const int kbeg = (int)ch * kc, kend = (kbeg + kc < nz) ? kbeg + kc : nz;
   const int njj = (j0 + RJ <= ny) ? RJ : ny - j0;
-  auto row_of = [&](int k, int u) -> int64_t {         // this lane's lattice row in step u of plane k, or -1
-    const int jj = 2 * u + line;
-    if (k >= kend || jj >= njj || i0 + ii >= nx) return -1;
-    return (int64_t)k * S2 + (int64_t)(j0 + jj) * S1 + i0 + ii;
-  };
-  // Every load of the loop is UNCONDITIONAL (indices clamped to something legal, the result discarded by a select): the
-  // compiler counts the vector-memory operations between a load and its use to place s_waitcnt vmcnt(N), and a load it may
+  // Addresses are a per-lane base (plane 0 of the lattice; computed once) plus a per-plane scalar offset: the 64-bit products
+  // stay on the scalar unit, a load costs the vector unit one 64-bit add.  Lanes without a row, halo points outside the
+  // lattice and planes past the end use a clamped, legal address: every load of the loop is UNCONDITIONAL, because the
+  // compiler counts the vector-memory operations between a load and its use to place s_waitcnt vmcnt(N) and a load it may
   // have branched around counts as zero -- one conditional load younger than the awaited one turns the wait into vmcnt(0).
-  // ... and nothing touches a loaded register before its real use (a select or a sign extension right after the load is a use:
-  // the wait would sit there): row words and values stay raw, validity is applied where they are consumed.
-  auto load_word = [&](int k, int u) -> OffT {         // raw: where the row's values start, or -1 (not a stencil row)
-    const int64_t r = row_of(k, u);
-    return arow[r >= 0 ? r : 0];
+  // And nothing touches a loaded register before its real use (a select or a sign extension right after the load is a use:
+  // the wait would sit there): row words, masks and values stay raw, validity is applied where they are consumed.
+  bool lane_ok[2];
+  const OffT* wbase[2]; const uint32_t* mbase[2]; double* ybase[2];
+  KK_UNROLL
+  for (int u = 0; u < 2; ++u) {
+    const int jj = 2 * u + line;
+    lane_ok[u] = jj < njj && i0 + ii < nx;
+    const int64_t r0 = lane_ok[u] ? (int64_t)(j0 + jj) * S1 + i0 + ii : 0;
+    wbase[u] = arow + r0; mbase[u] = amask + r0;
+    ybase[u] = Y + r0 * ys0 + (2 * c) * ys1;
+  }
+  const double* xbase[NXP];
+  bool x_in[NXP];                                      // the piece is a lattice point of the plane (else the halo holds 0)
+  KK_UNROLL
+  for (int it = 0; it < NXP; ++it) {
+    int g = it * NT + t;
+    g = g < NP ? g : NP - 1;
+    const int xr = g >> 3, part = g & 7;
+    const int jr = j0 - 1 + xr / W, ir = i0 - 1 + xr % W;
+    x_in[it] = jr >= 0 && jr < ny && ir >= 0 && ir < nx;
+    const int jq = jr < 0 ? 0 : (jr > ny - 1 ? ny - 1 : jr), iq = ir < 0 ? 0 : (ir > nx - 1 ? nx - 1 : ir);
+    xbase[it] = X + ((int64_t)jq * S1 + iq) * xs0 + part * 2;
+  }
+  auto plane_clamped = [&](int kp) -> int64_t { return kp < 0 ? 0 : (kp > nz - 1 ? nz - 1 : kp); };   // scalar
+  auto conforms = [&](int k, int u, OffT w) { return lane_ok[u] && k < kend && w >= 0; };
+  auto load_words = [&](int kp, OffT (&w)[2], uint32_t (&mk)[2]) {          // raw: where the rows' values start (or -1), which entries they hold
+    const int64_t off = plane_clamped(kp) * S2;
+    KK_UNROLL
+    for (int u = 0; u < 2; ++u) { w[u] = wbase[u][off]; mk[u] = mbase[u][off]; }
   };
-  auto conforms = [&](int k, int u, OffT w) { return row_of(k, u) >= 0 && w >= 0; };
-  auto slab_ok = [&](int kp) { return kp >= 0 && kp < nz && kp <= kend; };   // workgroup-uniform; stencil rows reference no other plane
   auto load_slab = [&](int kp, XV (&rx)[NXP]) {        // plane kp of the patch (with its halo): this thread's pieces
-    kp = kp < 0 ? 0 : (kp > nz - 1 ? nz - 1 : kp);
+    const int64_t off = plane_clamped(kp) * S2 * xs0;
+    KK_UNROLL
+    for (int it = 0; it < NXP; ++it) rx[it] = *reinterpret_cast<const XV*>(xbase[it] + off);
+  };
+  // halo points outside the lattice hold 0 (boundary rows meet them with the value 0: no 0 * Inf): zeros go in when the slot
+  // is free, the loaded pieces -- lattice points only, a predicated store, no select on a loaded register -- at the end
+  auto zero_halo = [&](int kp) {
+    if (kp > kend) return;
+    char* dst = ring + (size_t)(kp & 3) * SLABB;
+    const bool plane_in = kp >= 0 && kp < nz;
+    const XV zero = {0.0, 0.0};
     KK_UNROLL
     for (int it = 0; it < NXP; ++it) {
-      int g = it * NT + t;
-      g = g < NP ? g : NP - 1;
-      const int xr = g >> 3, part = g & 7;
-      int jq = j0 - 1 + xr / W, iq = i0 - 1 + xr % W;
-      jq = jq < 0 ? 0 : (jq > ny - 1 ? ny - 1 : jq);    // halo points outside the lattice are never read: any legal address will do
-      iq = iq < 0 ? 0 : (iq > nx - 1 ? nx - 1 : iq);
-      const int64_t col = (int64_t)kp * S2 + (int64_t)jq * S1 + iq;
-      rx[it] = *reinterpret_cast<const XV*>(X + col * xs0 + part * 2);
+      const int g = it * NT + t;
+      if (g < NP && !(plane_in && x_in[it])) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = zero;
     }
   };
   auto store_slab = [&](int kp, const XV (&rx)[NXP]) {
-    if (!slab_ok(kp)) return;
+    if (kp > kend || kp < 0 || kp >= nz) return;       // workgroup-uniform; no row of this chunk references a plane past kend
     char* dst = ring + (size_t)(kp & 3) * SLABB;
     KK_UNROLL
     for (int it = 0; it < NXP; ++it) {
       const int g = it * NT + t;
-      if (g < NP) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = rx[it];
+      if (g < NP && x_in[it]) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = rx[it];
     }
   };
-  auto load_values = [&](int k, const OffT (&w)[2], AT (&ra)[2][AV]) {      // raw; rows that do not conform load the head of the array
+  const uint32_t full = tab.n >= 32 ? 0xffffffffu : ((1u << tab.n) - 1u);
+  int qoff[AV];                                        // entry c + 8 m of a full row, clamped into the row
+  KK_UNROLL
+  for (int m = 0; m < AV; ++m) qoff[m] = (c + 8 * m < tab.n) ? c + 8 * m : tab.n - 1;
+  auto load_values = [&](int k, const OffT (&w)[2], const uint32_t (&mk)[2], AT (&ra)[2][AV]) {   // raw; rows that do not conform load the head of the array
     KK_UNROLL
     for (int u = 0; u < 2; ++u) {
-      const int64_t base = conforms(k, u, w[u]) ? (int64_t)w[u] : 0;
-      KK_UNROLL
-      for (int m = 0; m < AV; ++m) { const int q = c + 8 * m; ra[u][m] = values[base + (q < tab.n ? q : tab.n - 1)]; }
+      const bool cf = conforms(k, u, w[u]);
+      const AT* vb = values + (cf ? (int64_t)w[u] : 0);
+      const bool part = cf && mk[u] != full;           // a boundary row: stencil entry q sits at the packed position = entries held before it
+      if (!__any(part)) {
+        KK_UNROLL
+        for (int m = 0; m < AV; ++m) ra[u][m] = vb[qoff[m]];
+      } else {
+        const uint32_t mask = cf ? mk[u] : 1u;
+        KK_UNROLL
+        for (int m = 0; m < AV; ++m) {
+          const int q = c + 8 * m;
+          ra[u][m] = vb[((mask >> q) & 1u) ? __popc(mask & ((1u << q) - 1u)) : 0];
+        }
+      }
     }
   };
-  auto store_values = [&](int buf, int k, const OffT (&w)[2], const AT (&ra)[2][AV]) {      // pad entries (q >= n) carry 0
+  auto store_values = [&](int buf, const uint32_t (&mk)[2], const AT (&ra)[2][AV]) {      // entries the row lacks, and pad entries, carry 0
     KK_UNROLL
     for (int u = 0; u < 2; ++u) {
       AT* dst = abuf + ((size_t)(buf * 2 + u) * ROWS + rs) * LP;
       KK_UNROLL
-      for (int m = 0; m < AV; ++m) { const int q = c + 8 * m; if (q < NE) dst[q] = q < tab.n ? ra[u][m] : AT(0); }
+      for (int m = 0; m < AV; ++m) { const int q = c + 8 * m; if (q < NE) dst[q] = ((mk[u] >> q) & 1u) ? ra[u][m] : AT(0); }
     }
-    (void)k; (void)w;                                  // rows that do not conform are never read
   };
-  auto y_ptr = [&](int k, int u) -> double* { return Y + row_of(k, u) * ys0 + (2 * c) * ys1; };
+  auto y_ptr = [&](int k, int u) -> double* { return ybase[u] + (int64_t)k * S2 * ys0; };
   auto load_yold = [&](int k, const OffT (&w)[2], XV (&yo)[2]) {
     KK_UNROLL
     for (int u = 0; u < 2; ++u) {
@@ -913,29 +983,36 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     }
   };
 
-  // prologue: the row words of the first three planes, the values of the first, three planes of X; then the first set in flight
-  OffT w_cur[2], w_nxt[2], w_nn[2], w_new[2];
+  // Row words (and entry masks) of plane p are loaded at the top of plane p - 3 into the stage of that plane's parity, read
+  // from there for the value addresses at the top of plane p - 2, moved to `nxt` at the end of plane p - 2 (nothing moves a
+  // register in the plane that loads it: the move would be a wait inside the youngest batch), to `cur` a plane later.
+  OffT w_cur[2], w_nxt[2], w_stage[2][2];
+  uint32_t m_cur[2], m_nxt[2], m_stage[2][2];
   AT ra[2][2][AV];                                     // two sets in flight: set P is loaded in planes of parity P ...
   XV rx[2][NXP];                                       // ... and written to LDS at the end of the next plane
-  KK_UNROLL
-  for (int u = 0; u < 2; ++u) { w_cur[u] = load_word(kbeg, u); w_nxt[u] = load_word(kbeg + 1, u); w_nn[u] = load_word(kbeg + 2, u); }
-  load_values(kbeg, w_cur, ra[0]);
-  for (int kp = kbeg - 1; kp <= kbeg + 1; ++kp) { load_slab(kp, rx[0]); store_slab(kp, rx[0]); }
-  store_values(0, kbeg, w_cur, ra[0]);
+  // prologue: the row words of the first three planes, the values of the first, three planes of X; then the first set in flight
+  load_words(kbeg, w_cur, m_cur); load_words(kbeg + 1, w_nxt, m_nxt); load_words(kbeg + 2, w_stage[1], m_stage[1]);
+  load_values(kbeg, w_cur, m_cur, ra[0]);
+  {
+    XV rt[NXP];                                        // three slabs requested before the first is awaited
+    load_slab(kbeg - 1, rx[0]); load_slab(kbeg, rx[1]); load_slab(kbeg + 1, rt);
+    zero_halo(kbeg - 1); zero_halo(kbeg); zero_halo(kbeg + 1); zero_halo(kbeg + 2);
+    store_slab(kbeg - 1, rx[0]); store_slab(kbeg, rx[1]); store_slab(kbeg + 1, rt);
+  }
+  store_values(0, m_cur, ra[0]);
   load_slab(kbeg + 2, rx[1]);
-  load_values(kbeg + 1, w_nxt, ra[1]);
+  load_values(kbeg + 1, w_nxt, m_nxt, ra[1]);
   __syncthreads();
   for (int kk = kbeg; kk < kend; kk += 2) {
     KK_UNROLL
     for (int P = 0; P < 2; ++P) {                      // plane kk + P computes out of value buffer P
       const int k = kk + P;
       if (k >= kend) break;
-      // issued now, awaited at the end of the NEXT plane: the row words of plane k + 3 (first: they are moved, i.e. awaited, at
-      // the end of this plane, and operations retire in order), X of plane k + 3, the values of plane k + 2
-      KK_UNROLL
-      for (int u = 0; u < 2; ++u) w_new[u] = load_word(k + 3, u);
+      // issued now, awaited at the end of the NEXT plane: the row words of plane k + 3, X of plane k + 3, the values of plane
+      // k + 2 (addressed by the words the previous plane loaded)
+      load_words(k + 3, w_stage[P], m_stage[P]);
       load_slab(k + 3, rx[P]);
-      load_values(k + 2, w_nn, ra[P]);
+      load_values(k + 2, w_stage[1 - P], m_stage[1 - P], ra[P]);
       XV yold[2] = {{0.0, 0.0}, {0.0, 0.0}}, out[2] = {{0.0, 0.0}, {0.0, 0.0}};
       if constexpr (!BETA0) load_yold(k, w_cur, yold);
       KK_UNROLL
@@ -950,6 +1027,7 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
             const AV2 v = *reinterpret_cast<const AV2*>(av + q);             // two values per read (the row's 8 lanes: one address)
             KK_UNROLL
             for (int h = 0; h < 2; ++h) {
+              if (q + h >= NLO && q + h >= tab.n) continue;                  // pad entries take no part (0 * Inf would be NaN); uniform
               const int e = tab.e[q + h];                                    // uniform: scalar registers
               const int sb = ((k + (e & 3) - 1) & 3) * SLABB + (e >> 2) * 128;
               const XV x = *reinterpret_cast<const XV*>(own + sb);
@@ -960,8 +1038,9 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
         }
       }
       // what the PREVIOUS plane issued: the values of plane k + 1 into the other buffer (last read in plane k - 1), X of plane
-      // k + 2 into the slot that held plane k - 2 -- both behind a barrier.  This plane's stores to Y come after the wait.
-      store_values(1 - P, k + 1, w_nxt, ra[1 - P]);
+      // k + 2 into the slot that held plane k - 2 -- both behind a barrier.  This plane's stores to Y come after the wait:
+      // vector-memory operations retire in order, and a wait placed after a store would wait for the store as well.
+      store_values(1 - P, m_nxt, ra[1 - P]);
       store_slab(k + 2, rx[1 - P]);
       KK_UNROLL
       for (int u = 0; u < 2; ++u) {
@@ -972,8 +1051,9 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
         }
       }
       __syncthreads();
+      zero_halo(k + 3);                                // its slot held plane k - 1, read for the last time before the barrier
       KK_UNROLL
-      for (int u = 0; u < 2; ++u) { w_cur[u] = w_nxt[u]; w_nxt[u] = w_nn[u]; w_nn[u] = w_new[u]; }
+      for (int u = 0; u < 2; ++u) { w_cur[u] = w_nxt[u]; w_nxt[u] = w_stage[1 - P][u]; m_nxt[u] = m_stage[1 - P][u]; }
     }
   }
 }
@@ -1026,12 +1106,20 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
   auto drop = [&]() { (void)hipGetLastError(); mv4_plan_destroy(m); return KKAMD_OK; };   // an optimisation: the gather kernel serves
   m->nx = (int)nx; m->ny = (int)ny; m->nz = (int)nz; m->S1 = S1; m->S2 = S2;
   DevBuf cnt;
-  if (hipMalloc(&m->d_arow, sizeof(OffT) * (size_t)A->num_rows) != hipSuccess || cnt.alloc(2 * sizeof(unsigned long long)) != hipSuccess) return drop();
+  if (hipMalloc(&m->d_arow, sizeof(OffT) * (size_t)A->num_rows) != hipSuccess || hipMalloc((void**)&m->d_amask, sizeof(uint32_t) * (size_t)A->num_rows) != hipSuccess ||
+      cnt.alloc(2 * sizeof(unsigned long long)) != hipSuccess) return drop();
   unsigned long long* d_cnt = cnt.as<unsigned long long>();
   OffT* d_arow = (OffT*)m->d_arow;
   if (hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st) != hipSuccess) return drop();
+  Mv4Tab steps{};                                      // the lattice step of every stencil entry, for the in/out-of-lattice tests
+  steps.n = offs.n;
+  for (int q = 0; q < offs.n; ++q) {
+    const int64_t d = offs.e[q], dk = mv4_round_div(d, S2), rem = d - dk * S2, dj = mv4_round_div(rem, S1), di = rem - dj * S1;
+    steps.e[q] = (int)((dk + 1) | ((dj + 1) << 2) | ((di + 1) << 4));
+  }
+  uint32_t* d_amask = m->d_amask;
   KK_LAUNCH((mv4_verify_kernel<OffT>), (unsigned)ceil_div(A->num_rows, kBlock), kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map,
-            (const int32_t*)A->d_entries, offs, m->nx, m->ny, m->nz, d_arow, d_cnt);
+            (const int32_t*)A->d_entries, offs, steps, m->nx, m->ny, m->nz, d_arow, d_amask, d_cnt);
   unsigned long long h_bad = 0;
   if (hipMemcpyAsync(&h_bad, d_cnt, sizeof h_bad, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return drop();
   m->n_nc = (int64_t)h_bad;
@@ -1053,7 +1141,7 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
   if (nchunk > nz / 4) nchunk = nz / 4;
   if (nchunk < 1) nchunk = 1;
   m->kc = (int)ceil_div(nz, nchunk); m->nchunk = ceil_div(nz, (int64_t)m->kc);
-  m->bytes = sizeof(OffT) * (size_t)A->num_rows + sizeof(int32_t) * (size_t)(m->n_nc > 0 ? m->n_nc : 1);
+  m->bytes = (sizeof(OffT) + sizeof(uint32_t)) * (size_t)A->num_rows + sizeof(int32_t) * (size_t)(m->n_nc > 0 ? m->n_nc : 1);
   plan->mv4 = m;
   return KKAMD_OK;
 }
@@ -1074,7 +1162,7 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
     const size_t lds = slabs + 4 * rows * mv4_pitch(NE, (int)sizeof(AT)) * sizeof(AT);                                           \
     KK_MV4_ATTR(NE, B0);                                                                                                        \
     KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, B0>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,                \
-              (const OffT*)m->d_arow, (const AT*)A->d_values, m->tab, X, ldx, Y, ys0, ys1, alpha, beta, yv, m->nx, m->ny, m->nz,  \
+              (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values, m->tab, X, ldx, Y, ys0, ys1, alpha, beta, yv, m->nx, m->ny, m->nz,  \
               m->S1, m->S2, m->npi, m->npj, m->kc);                                                                              \
   } while (0)
 #define KK_MV4(NE) do { if (beta == 0.0) KK_MV4B(NE, true); else KK_MV4B(NE, false); } while (0)
@@ -1144,15 +1232,21 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
         }
       }
     }
-    // plane-marching kernel (knob mv_kernel = 4): analysed handles, 16 fp64 right-hand sides, matrices that verify as a
-    // radius-1 lattice stencil; the analysis happens on the first such call
+    // plane-marching kernel (mv_kernel 0 = auto, or 4): analysed handles, fp64 vectors, right-hand sides in blocks of 16,
+    // matrices that verify as a radius-1 lattice stencil; the analysis happens on the first such call
     if constexpr (sizeof(YT) == 8) {
-      if (Xr && plan && plan->tile != 0 && mvk == 4 && nvec == 16 && plan->entries == A->d_entries) {
+      if (Xr && plan && plan->tile != 0 && (mvk == 0 || mvk == 4) && nvec >= 16 && nvec % 16 == 0 && plan->entries == A->d_entries) {
         if (!plan->mv4 && !plan->mv4_tried) {
           int rc = mv4_plan_build<OffT>(plan, A, st);
           if (rc) return rc;
         }
-        if (plan->mv4) return launch_mv4<OffT, AT>(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, (double)alpha, (double)beta, st);
+        if (plan->mv4) {
+          for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
+            int rc = launch_mv4<OffT, AT>(plan, A, (const double*)Xr + c0, ldx, (double*)Y + c0 * ys1, ys0, ys1, (double)alpha, (double)beta, st);
+            if (rc) return rc;
+          }
+          return KKAMD_OK;
+        }
       }
     }
     if (Xr) {

@@ -67,15 +67,20 @@ def check_spmv(be, A0, mode="N", alpha=1.0, beta=0.0, algo=None, nans=False, see
 
 
 def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_order="F", algo=None, seed=0, knobs=None, expect=None,
-                  max_val=1.0, nans=False):
+                  max_val=1.0, nans=False, offset_dtype=np.int32, value_dtype=None, x_special=None):
+    """x_special: {row: value} written into every column of X after the random fill (Inf / NaN propagation)"""
     rng = np.random.default_rng(seed)
     trans = mode in "TH"
     nin, nout = (A0.nrows, A0.ncols) if trans else (A0.ncols, A0.nrows)
     X = np.asarray(rng.random((nin, nvec)), order=x_order)
+    for r_, v_ in (x_special or {}).items():
+        X[r_, :] = v_
     Y0 = np.asarray(rng.random((nout, nvec)), order=y_order)
     if nans:
         Y0[::7, :] = np.nan
-    A = dev(be, A0)
+    if value_dtype is not None:
+        A0 = oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, A0.values.astype(value_dtype).astype(np.float64))
+    A = dev(be, A0, offset_dtype, value_dtype)
     Xd, Yd = _to_dev_2d(be, X), _to_dev_2d(be, Y0)
     h = None
     if algo is None:
@@ -93,6 +98,9 @@ def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_or
     exp = oracle.spmv_mv_serial(mode, A0, alpha, X, beta, Y0.copy(order="K"))
     tol = oracle.spmv_max_error(A0, alpha, beta, max_val=max_val)
     assert not (np.isnan(exp) ^ np.isnan(got)).any(), "spmv_mv NaN mismatch nvec=%d" % nvec
+    inf = np.isinf(exp)
+    assert np.array_equal(inf, np.isinf(got)) and np.array_equal(exp[inf], got[inf]), "spmv_mv Inf mismatch nvec=%d" % nvec
+    exp = np.where(inf, 0.0, exp); got = np.where(inf, 0.0, got)
     err = np.nanmax(np.abs(exp - got)) if got.size else 0.0
     assert err <= max(tol, 1e-300), "spmv_mv mismatch nvec=%d mode=%s orders=%s%s: %g > %g" % (nvec, mode, x_order, y_order, err, tol)
     return h
@@ -297,6 +305,45 @@ def mixed_tile_cases():
     band = oracle.random_crs(n // 2, n // 2, 12, variance=0, seed=4, bandwidth=200, sorted_rows=True)       # columns inside [0, 3000)
     rm = np.concatenate([top.row_map, band.row_map[1:] + top.row_map[-1]])
     out.append(("random-then-banded", oracle.Crs(n, 2000000, rm, np.concatenate([top.entries, band.entries]), np.concatenate([top.values, band.values]))))
+    return out
+
+
+def mv4_cases():
+    """(name, matrix, rows the plane-marching rank-2 kernel must leave to the gather kernel: None = any, 0 = none) -- lattice
+    stencils whose patches, lines and k-chunks are ragged (nx % 32, ny % 4 != 0), boundary rows of a truncated stencil, rows
+    that break the pattern"""
+    out = [("27pt 40x14x14", oracle.laplace3d("FE", 40, 14, 14), None), ("7pt 35x13x14", oracle.laplace3d("FD", 35, 13, 14), None),
+           ("27pt 9x33x17", oracle.laplace3d("FE", 9, 33, 17), None)]
+    # a clean truncated 7-point stencil (every boundary row is a subset whose missing entries point outside): no gather rows
+    nx, ny, nz = 33, 6, 21
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    rows, cols = [], []
+    for dk, dj, di in ((-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0)):
+        ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < ny) & (k + dk >= 0) & (k + dk < nz)
+        rows.append((k * ny * nx + j * nx + i)[ok]); cols.append(((k + dk) * ny * nx + (j + dj) * nx + i + di)[ok])
+    rows = np.concatenate(rows); cols = np.concatenate(cols)
+    order = np.lexsort((cols, rows)); rows = rows[order]; cols = cols[order]
+    n = nx * ny * nz
+    rm = np.zeros(n + 1, dtype=np.int64); np.add.at(rm, rows + 1, 1); rm = np.cumsum(rm)
+    vals = np.random.default_rng(12).random(rows.size) + 0.5
+    clean = oracle.Crs(n, n, rm, cols.astype(np.int32), vals)
+    out.append(("7pt clean 33x6x21", clean, 0))
+    # the same with rows that break the pattern: an extra coupling, a dropped interior entry, an emptied row, a wrap-around entry
+    rm2 = rm.copy(); ent = cols.astype(np.int32).copy(); val = vals.copy()
+    def drop(r, pos):
+        nonlocal rm2, ent, val
+        at = rm2[r] + pos
+        ent = np.delete(ent, at); val = np.delete(val, at); rm2[r + 1:] -= 1
+    def add(r, col):
+        nonlocal rm2, ent, val
+        seg = ent[rm2[r]:rm2[r + 1]]
+        at = rm2[r] + int(np.searchsorted(seg, col))
+        ent = np.insert(ent, at, col); val = np.insert(val, at, 0.25); rm2[r + 1:] += 1
+    mid = (10 * ny + 3) * nx + 17
+    drop(mid, 2); add(mid + 1, mid + 9); add(mid + 2 * nx, 5)
+    for _ in range(int(rm2[mid + 40 + 1] - rm2[mid + 40])):
+        drop(mid + 40, 0)
+    out.append(("7pt + broken rows", oracle.Crs(n, n, rm2, ent, val), 4))
     return out
 
 

@@ -142,9 +142,38 @@ def test_mv3_lds_staged(be):
                          knobs={"mv_kernel": 3, "mv_order": 2, "mv_strip_min_kb": 100, "mv_strip_l2_kb": 64}, expect={"mv_order": 2})
     # the staged kernel runs on request only (knob mv_kernel = 3); widths that are not multiples of 8 never take it
     h = pc.check_spmv_mv(be, oracle.laplace3d("FE", 300, 10, 5), 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
-                         knobs={"mv_strip_min_kb": 100, "mv_strip_l2_kb": 160}, expect={"mv_tiles": 0, "mv_order": 2, "mv_period": 3000})
+                         knobs={"mv_kernel": 2, "mv_strip_min_kb": 100, "mv_strip_l2_kb": 160}, expect={"mv_tiles": 0, "mv_order": 2, "mv_period": 3000})
     pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, expect={"mv_tiles": 0})
     pc.check_spmv_mv(be, A0, 12, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 3}, max_val=32.0, expect={"mv_tiles": 0})
+
+
+def test_mv4_plane_marching(be):
+    # rank-2 plane-marching kernel (analysed handles, fp64, right-hand sides in blocks of 16, lattice stencils): every lattice
+    # row it takes (interior and truncated boundary rows) and the rows it leaves to the gather kernel; both layouts (X packed
+    # per call, Y strided), alpha / beta, beta = 0 over NaNs, 64-bit offsets, fp32 values, k-chunks from 1 to nz / 4
+    for name, A0, left in pc.mv4_cases():
+        for nvec, xo, yo, alpha, beta, off in ((16, "C", "C", 1.5, 0.5, np.int32), (16, "C", "C", 1.0, 0.0, np.int64), (32, "C", "C", -1.0, 0.0, np.int32),
+                                               (16, "F", "F", 2.0, 0.0, np.int32), (16, "F", "C", 1.0, -1.0, np.int32), (48, "C", "F", 1.0, 1.0, np.int32)):
+            h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0), offset_dtype=off)
+            assert h.query("mv4_workgroups") > 0, (name, nvec)
+            if left is not None:
+                assert h.query("mv4_other_rows") == left, (name, h.query("mv4_other_rows"))
+    name, A0, _ = pc.mv4_cases()[0]
+    for wg in (1, 64):
+        pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 4, "mv4_wg_per_cu": wg}, max_val=32.0, nans=True)
+    pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, value_dtype=np.float32)
+    # Inf and NaN in X reach exactly the rows the reference lets them reach (no 0 * Inf from halo or pad entries): a corner,
+    # a face, an interior point
+    name, A0, _ = pc.mv4_cases()[3]
+    h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
+                         x_special={0: np.inf, 33 * 6 * 10 + 5: -np.inf, A0.nrows - 1: np.nan, 33 * 6 * 7 + 33 * 2 + 16: np.inf})
+    assert h.query("mv4_workgroups") > 0
+    # not its matrices / widths: no far stride (2-D), too few lattice rows, 8 right-hand sides, no analysis, the gather kernel asked for
+    for A1, nvec, algo, knobs in ((oracle.laplace2d("FE", 130, 41), 16, "SPMV_DEFAULT", None), (oracle.laplace3d("FE", 12, 12, 12), 16, "SPMV_DEFAULT", None),
+                                  (A0, 8, "SPMV_DEFAULT", None), (A0, 16, "SPMV_FAST_SETUP", None), (A0, 16, "SPMV_DEFAULT", {"mv_kernel": 2}),
+                                  (oracle.random_crs(5000, 5000, 9, variance=3, seed=5), 16, "SPMV_DEFAULT", None)):
+        h = pc.check_spmv_mv(be, A1, nvec, "N", 1.0, 0.0, "C", "C", algo=algo, knobs=knobs, max_val=32.0)
+        assert h.query("mv4_workgroups") == 0
 
 
 def test_xcd_group_orders(be):

@@ -167,13 +167,44 @@ def test_mv3_lds_staged(be):
     for order in (0, 1, 2):
         h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 3, "mv_order": order}, max_val=32.0, nans=True)
         assert h.query("mv_tiles") > 0 and h.query("mv_order") == order, (order, h.query("mv_order"))
-    # the default (wave-private gather kernel) takes its row blocks in strip order on the same grid, for every width
+    # the wave-private gather kernel takes its row blocks in strip order on the same grid, for every width
     for nvec, xo, yo in ((16, "C", "C"), (8, "C", "C"), (4, "C", "C"), (16, "F", "F"), (3, "C", "C")):
-        h = pc.check_spmv_mv(be, A0, nvec, "N", 1.5, 0.0, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=True)
+        h = pc.check_spmv_mv(be, A0, nvec, "N", 1.5, 0.0, xo, yo, algo="SPMV_DEFAULT", knobs={"mv_kernel": 2}, max_val=32.0, nans=True)
         assert h.query("mv_tiles") == 0 and h.query("mv_period") == 160 * 120, (nvec, h.query("mv_period"))
         assert h.query("mv_order") == (2 if nvec >= 8 else h.query("mv_order")), (nvec, h.query("mv_order"))
     for order in (0, 1):
-        pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_order": order}, max_val=32.0, expect={"mv_order": 0})
+        pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 2, "mv_order": order}, max_val=32.0, expect={"mv_order": 0})
+
+
+def test_mv4_plane_marching(be):
+    # rank-2 plane-marching kernel (default for analysed handles, fp64, right-hand sides in blocks of 16, lattice stencils):
+    # interior and truncated boundary rows, rows left to the gather kernel, both layouts, alpha / beta, 64-bit offsets, fp32 values
+    for name, A0, left in pc.mv4_cases():
+        for nvec, xo, yo, alpha, beta, off in ((16, "C", "C", 1.5, 0.5, np.int32), (16, "C", "C", 1.0, 0.0, np.int64), (32, "C", "C", -1.0, 0.0, np.int32),
+                                               (16, "F", "F", 2.0, 0.0, np.int32), (16, "F", "C", 1.0, -1.0, np.int32), (48, "C", "F", 1.0, 1.0, np.int32)):
+            h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0), offset_dtype=off)
+            assert h.query("mv4_workgroups") > 0, (name, nvec)
+            if left is not None:
+                assert h.query("mv4_other_rows") == left, (name, h.query("mv4_other_rows"))
+    # grids with many patches and k-chunks; the chunking knob from one chunk to nz / 4
+    for A0 in (oracle.laplace3d("FE", 160, 120, 12), oracle.laplace3d("FD", 70, 50, 90)):
+        for wg in (8, 1, 64):
+            for alpha, beta in ((1.0, 0.0), (0.5, 2.0)):
+                h = pc.check_spmv_mv(be, A0, 16, "N", alpha, beta, "C", "C", algo="SPMV_DEFAULT", knobs={"mv4_wg_per_cu": wg}, max_val=32.0, nans=(beta == 0.0))
+                assert h.query("mv4_workgroups") > 0 and h.query("mv4_other_rows") < 0.02 * A0.nrows
+    name, A0, _ = pc.mv4_cases()[0]
+    pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, value_dtype=np.float32)
+    # Inf and NaN in X reach exactly the rows the reference lets them reach (no 0 * Inf from halo or pad entries)
+    name, A0, _ = pc.mv4_cases()[3]
+    h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
+                         x_special={0: np.inf, 33 * 6 * 10 + 5: -np.inf, A0.nrows - 1: np.nan, 33 * 6 * 7 + 33 * 2 + 16: np.inf})
+    assert h.query("mv4_workgroups") > 0
+    # not its matrices / widths: no far stride (2-D), too few lattice rows, 8 right-hand sides, no analysis, the gather kernel asked for
+    for A1, nvec, algo, knobs in ((oracle.laplace2d("FE", 130, 41), 16, "SPMV_DEFAULT", None), (oracle.laplace3d("FE", 12, 12, 12), 16, "SPMV_DEFAULT", None),
+                                  (A0, 8, "SPMV_DEFAULT", None), (A0, 16, "SPMV_FAST_SETUP", None), (A0, 16, "SPMV_DEFAULT", {"mv_kernel": 2}),
+                                  (oracle.random_crs(5000, 5000, 9, variance=3, seed=5), 16, "SPMV_DEFAULT", None)):
+        h = pc.check_spmv_mv(be, A1, nvec, "N", 1.0, 0.0, "C", "C", algo=algo, knobs=knobs, max_val=32.0)
+        assert h.query("mv4_workgroups") == 0
 
 
 def test_xcd_group_orders(be):
