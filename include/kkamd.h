@@ -141,11 +141,14 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *                       eighth of free HBM, values that changed since the last call are moved into it; 2 the caller promises constant
  *                       values (no comparison either); 0 the reference's atomic scatter.  From "explicit_transpose_min_knnz"
  *   SpMV, rank 2
- *     "mv_kernel"       0 auto (wave-private gather kernel), 1 generic strided kernel, 2 wave-private kernel, 3 LDS-staged X tiles
+ *     "mv_kernel"       0 auto (plane-marching kernel where it applies -- analysed plan, fp64 vectors, right-hand sides in
+ *                       blocks of 16, a matrix that verifies as a radius-1 lattice stencil --, else the wave-private gather
+ *                       kernel), 1 generic strided kernel, 2 wave-private gather kernel, 3 LDS-staged X tiles, 4 = 0
  *     "mv_order"        row-block order: 2 (default) strips from the far stride found in the matrix (falls back to "mv_remap"),
  *                       1 XCD-contiguous (LDS-staged kernel), 0 "mv_remap": 0 dispatch, 1 XCD-contiguous, 2^k grouped (default 16)
  *     "mv_strip_min_kb" / "mv_strip_l2_kb"  when strips engage / how much of an XCD's L2 a strip's X rows may take
  *     "mv_glds"         LDS-staged kernel: X window through global_load_lds (1) or registers (0)
+ *     "mv4_wg_per_cu"   plane-marching kernel: workgroups per CU the split along the far stride aims for (default 8, 1..64)
  *   kkamd_spmv_struct (global only): "struct_remap", "struct_group", "struct_strip" workgroup orders, all off
  *   "verbose" (global): 1 = the library reports what it chose on stdout
  *   SpGEMM (kkamd_set_default only) "spgemm_win_bits" (columns per LDS bitmap pass), "spgemm_val_cap", "spgemm_val_shape",
@@ -157,7 +160,8 @@ int kkamd_set_default(const char* key, int value);
 /* What the analysis of a plan produced: "tile" (nnz per workgroup, 0 = no tiling), "tiles", per-mode tile counts "plain_tiles" /
  * "code_tiles" / "staged_tiles" / "pattern_tiles", "window_codes" (1 if any tile uses the column analysis), "window_staged_x",
  * "plan_bytes" (HBM the analysis keeps), "transpose_cached", rank 2: "mv_tiles", "mv_staged_tiles", "mv_order" (order in use),
- * "mv_period" (far stride found), "mv_plan_bytes". */
+ * "mv_period" (far stride found), "mv_plan_bytes", plane-marching kernel: "mv4_workgroups" (0 = not in use), "mv4_other_rows"
+ * (rows left to its gather kernel), "mv4_stencil" (entries of the stencil), "mv4_near_stride". */
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);
 /* Copies a per-tile array of the analysis to a HOST buffer of `count` int32: "tile_first_row" (tiles + 1 entries: the first row that
  * starts at or after nonzero b * tile, bit 31 set when the tile starts inside a row -- the nnz-split counterpart of the

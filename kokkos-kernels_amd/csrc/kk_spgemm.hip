@@ -260,7 +260,10 @@ template <int H> __device__ __forceinline__ int vt_find(const int* hk, int key) 
 // grows for rows of A with few entries so that the sub-groups (nthreads >> s of them) just cover the row -- a row with
 // 13 entries handled by 1024 work-items runs 16 sub-groups of 64 lanes instead of leaving 115 of 128 idle.
 // Each lane issues kProdUnroll independent B loads per step (a step is latency-bound otherwise): f(a, j, column).
-constexpr int kProdUnroll = 4;
+#ifndef KK_PROD_UNROLL
+#define KK_PROD_UNROLL 4
+#endif
+constexpr int kProdUnroll = KK_PROD_UNROLL;
 template <class OffT, class F>
 __device__ __forceinline__ void for_each_product(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                  const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, int tid,
@@ -312,8 +315,9 @@ __device__ __forceinline__ void for_each_product_v(int64_t row, const OffT* __re
 // offsets, and then product q of the chunk is handled by work-item q mod NT -- consecutive lanes read consecutive B
 // entries, all kProdUnroll loads of a lane are independent, and no lane waits on the entries(A) -> row_map(B) ->
 // entries(B) chain more than once per chunk.  (With sub-groups walking "their" B rows the kernels were bound by that
-// chain: ~135 G products/s on R-MAT; see DESIGN.md.)  A lane finds the B row of its product from the wave's first
-// product (one shared binary search) and only searches on its own when it falls outside that row.
+// chain: ~135 G products/s on R-MAT; see DESIGN.md.)  A work-item takes kProdUnroll NEIGHBOURING products per step: one
+// binary search for the first, a short walk for the rest (with product q on work-item q mod NT every product paid a full
+// search, and the searches were most of the instructions of the R-MAT symbolic kernels).
 // Every work-item of the workgroup must call it.  f(a, j, column) with a, j indices into A's / B's entry arrays.
 template <int NT> struct FlatScratch {
   long long pre[NT + 1];    // product offset of each A entry of the chunk
@@ -344,22 +348,29 @@ __device__ __forceinline__ void flat_products_impl(int64_t row, const OffT* __re
       return lo;
     };
     for (long long base = 0; base < tot; base += (long long)NT * kProdUnroll) {
-      const int seg0 = find(base + (t & ~63), 0);        // the wave's first product (uniform across the wave)
+      // work-item t takes products base + t U .. + U - 1: ONE search per work-item and step, then a short walk (the products of
+      // a lane are neighbours, mostly of one B row); across the lanes of a load the addresses are U entries apart
+      const long long q0 = base + (long long)t * kProdUnroll;
+      int sgc = q0 < tot ? find(q0, 0) : 0;
       int col[kProdUnroll], seg[kProdUnroll];
       long long jj[kProdUnroll];
       typename std::conditional<kVals, VT, int>::type bv[kProdUnroll];
       KK_UNROLL
       for (int u = 0; u < kProdUnroll; ++u) {
-        const long long q = base + (long long)u * NT + t;
+        const long long q = q0 + u;
         col[u] = -1; seg[u] = 0; jj[u] = 0; bv[u] = 0;
         if (q < tot) {
-          const int sg0 = u == 0 ? seg0 : seg[u - 1];
-          seg[u] = (q < sc.pre[sg0 + 1]) ? sg0 : find(q, sg0);
-          jj[u]  = sc.b0[seg[u]] + (q - sc.pre[seg[u]]);
+          while (q >= sc.pre[sgc + 1]) ++sgc;            // also steps over empty B rows; q < tot = pre[n] ends it
+          seg[u] = sgc;
+          jj[u]  = sc.b0[sgc] + (q - sc.pre[sgc]);
+        }
+      }
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u)
+        if (q0 + u < tot) {
           col[u] = entB[jj[u]];
           if constexpr (kVals) bv[u] = valB[jj[u]];
         }
-      }
       KK_UNROLL
       for (int u = 0; u < kProdUnroll; ++u)
         if (col[u] >= 0) {

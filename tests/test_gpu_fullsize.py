@@ -91,7 +91,7 @@ def test_c3_all_columns_against_oracle(be, c2, layout):
     pc.kk.spmv(h, "N", 1.0, A, Xd, 0.0, Yd)
     # the plane-marching kernel engaged; the gather kernel is left the few rows the generator couples across a lattice edge
     assert h.query("mv_period") == 300 * 300 and h.query("mv4_workgroups") > 0 and h.query("mv4_stencil") == 27
-    assert h.query("mv4_other_rows") < 0.001 * A0.nrows, h.query("mv4_other_rows")
+    assert h.query("mv4_other_rows") < 0.005 * A0.nrows, h.query("mv4_other_rows")
     exp = np.zeros((A0.nrows, nv))
     oracle.spmv_mv_omp(rm.astype(np.int32), A0.entries, A0.values, 1.0, X, 0.0, exp)
     tol = 10 * EPS * 27 * 32.0 * 20.0

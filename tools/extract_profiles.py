@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 rnd = sys.argv[1] if len(sys.argv) > 1 else "round2"
 out = os.path.join(ROOT, "gpurun_out", "summary", rnd); os.makedirs(out, exist_ok=True)
 import bench
-UNIT = {"bench": "kk_spmv.hip", "mv": "kk_spmv_mv.hip", "spgemm": "kk_spgemm.hip", "struct": "kk_spmv_struct.hip"}
+UNIT = {"bench": "kk_spmv.hip", "mv": "kk_spmv_mv.hip", "mv4": "kk_spmv_mv.hip", "spgemm": "kk_spgemm.hip", "struct": "kk_spmv_struct.hip"}
 
 
 def find(d, suffix):
@@ -52,7 +52,7 @@ for sq_dir in glob.glob(os.path.join(ROOT, "gpurun_out", "prof_sq_*")):
         g.write("# kernel_source_sha kk_spmv.hip %s kk_spmv_mv.hip %s  (%s)\n" % (bench.kernel_source_sha(), bench.kernel_source_sha("kk_spmv_mv.hip"), os.path.basename(sq_dir)))
         for k, v in sorted(agg.items()):
             if "kk::" in k[0]: g.write("%-110s %-32s launches %3d mean %.4g\n" % (k[0], k[1], len(v), sum(v) / len(v)))
-for name in ("bench.json", "bench_mv3.jsonl", "probe_mfma_f64.txt"):
+for name in ("bench.json", "bench_mv3.jsonl", "bench_mv4.jsonl", "probe_mfma_f64.txt"):
     p = os.path.join(ROOT, "gpurun_out", name)
     if os.path.exists(p): open(os.path.join(out, name), "w").write(open(p).read())
 print("wrote", out, "sha", bench.kernel_source_sha())
