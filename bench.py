@@ -302,10 +302,10 @@ def main():
                     out["roofline"]["traffic_source"] = ("%s is stale (measured on kernel sources %s): traffic not quoted"
                                                          % (os.path.relpath(PMC_FILE, ROOT), d.get("kernel_source_sha")))
                 else:
-                    rd = wr = None
+                    rd = wr = 0.0                     # one SpMV = the per-mode launches of the stream kernel + the fix-up kernel
                     for k, v in d.get("counters", {}).items():
-                        if "spmv_stream3_kernel" in k and "FETCH_SIZE" in k: rd = v["mean_KB"] * 1024 * 2   # gfx950 x2 correction
-                        if "spmv_stream3_kernel" in k and "WRITE_SIZE" in k: wr = v["mean_KB"] * 1024
+                        if "spmv_stream" in k and "FETCH_SIZE" in k: rd += v["mean_KB"] * 1024 * 2   # gfx950 x2 correction
+                        if "spmv_stream" in k and "WRITE_SIZE" in k: wr += v["mean_KB"] * 1024
                     if rd and wr:
                         out["roofline"]["traffic"] = int(rd + wr)
                         # what actually crossed the memory side per second, against the same peak

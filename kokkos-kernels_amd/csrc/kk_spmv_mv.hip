@@ -830,8 +830,8 @@ __global__ __launch_bounds__(kBlock) void mv4_list_kernel(int64_t nrows, const O
 template <class OffT, class AT>
 __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
                                                           const int32_t* __restrict__ entries, const AT* __restrict__ values,
-                                                          const double* __restrict__ X, int64_t xs0, double* __restrict__ Y, int64_t ys0,
-                                                          int64_t ys1, double alpha, double beta) {
+                                                          const double* __restrict__ X, int64_t xs0, int64_t xs1, double* __restrict__ Y,
+                                                          int64_t ys0, int64_t ys1, double alpha, double beta) {
   int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
   const int j = threadIdx.x & 15;
   const bool live = idx < n_list;                      // no early return: the shuffles below want whole groups
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const 
     for (int q = 0; q < 16; ++q) {
       const int32_t col = __shfl(my_col, q, 16);
       const double v    = __shfl(my_val, q, 16);
-      acc += v * X[(int64_t)col * xs0 + j];
+      acc += v * X[(int64_t)col * xs0 + j * xs1];
     }
   }
   if (!live) return;
@@ -855,9 +855,9 @@ __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const 
   *yp = (beta == 0.0) ? alpha * acc : beta * (*yp) + alpha * acc;
 }
 
-template <class OffT, class AT, int NE, bool BETA0>
+template <class OffT, class AT, int NE, bool BETA0, bool XROW>
 __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask, const AT* __restrict__ values, Mv4Tab tab,
-                                                                  const double* __restrict__ X, int64_t xs0, double* __restrict__ Y,
+                                                                  const double* __restrict__ X, int64_t xs0, int64_t xs1, double* __restrict__ Y,
                                                                   int64_t ys0, int64_t ys1, double alpha, double beta, int y_vec_ok, int nx,
                                                                   int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc) {
   constexpr int RI = kMv4RI, RJ = kMv4RJ, W = RI + 2, SLABR = (RJ + 2) * W, SLABB = SLABR * 128, NT = kMv4Threads;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     const int jr = j0 - 1 + xr / W, ir = i0 - 1 + xr % W;
     x_in[it] = jr >= 0 && jr < ny && ir >= 0 && ir < nx;
     const int jq = jr < 0 ? 0 : (jr > ny - 1 ? ny - 1 : jr), iq = ir < 0 ? 0 : (ir > nx - 1 ? nx - 1 : ir);
-    xbase[it] = X + ((int64_t)jq * S1 + iq) * xs0 + part * 2;
+    xbase[it] = X + ((int64_t)jq * S1 + iq) * xs0 + (part * 2) * xs1;
   }
   auto plane_clamped = [&](int kp) -> int64_t { return kp < 0 ? 0 : (kp > nz - 1 ? nz - 1 : kp); };   // scalar
   auto conforms = [&](int k, int u, OffT w) { return lane_ok[u] && k < kend && w >= 0; };
@@ -917,7 +917,10 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
   auto load_slab = [&](int kp, XV (&rx)[NXP]) {        // plane kp of the patch (with its halo): this thread's pieces
     const int64_t off = plane_clamped(kp) * S2 * xs0;
     KK_UNROLL
-    for (int it = 0; it < NXP; ++it) rx[it] = *reinterpret_cast<const XV*>(xbase[it] + off);
+    for (int it = 0; it < NXP; ++it) {
+      if constexpr (XROW) rx[it] = *reinterpret_cast<const XV*>(xbase[it] + off);        // row-major X: the piece is 16 contiguous bytes
+      else { rx[it][0] = xbase[it][off]; rx[it][1] = xbase[it][off + xs1]; }               // any strides (LayoutLeft: a wave's 8 pieces of a column are 64 contiguous bytes)
+    }
   };
   // halo points outside the lattice hold 0 (boundary rows meet them with the value 0: no 0 * Inf): zeros go in when the slot
   // is free, the loaded pieces -- lattice points only, a predicated store, no select on a loaded register -- at the end
@@ -1147,25 +1150,30 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
 }
 
 template <class OffT, class AT>
-static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0, int64_t ys1,
+static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
                       double alpha, double beta, hipStream_t st) {
   const kkamd_mv4_plan* m = plan->mv4;
   const size_t slabs = 4 * (size_t)((kMv4RJ + 2) * (kMv4RI + 2) * 128), rows = kMv4Threads / 8;
   const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
 #ifndef KK_EMU
-#define KK_MV4_ATTR(NE, B0) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, B0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+#define KK_MV4_ATTR(NE, B0, XR) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, B0, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
 #else
-#define KK_MV4_ATTR(NE, B0) (void)0
+#define KK_MV4_ATTR(NE, B0, XR) (void)0
 #endif
-#define KK_MV4B(NE, B0)                                                                                                         \
+#define KK_MV4B(NE, B0, XR)                                                                                                     \
   do {                                                                                                                          \
     const size_t lds = slabs + 4 * rows * mv4_pitch(NE, (int)sizeof(AT)) * sizeof(AT);                                           \
-    KK_MV4_ATTR(NE, B0);                                                                                                        \
-    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, B0>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,                \
-              (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values, m->tab, X, ldx, Y, ys0, ys1, alpha, beta, yv, m->nx, m->ny, m->nz,  \
-              m->S1, m->S2, m->npi, m->npj, m->kc);                                                                              \
+    KK_MV4_ATTR(NE, B0, XR);                                                                                                    \
+    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, B0, XR>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,            \
+              (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values, m->tab, X, xs0, xs1, Y, ys0, ys1, alpha, \
+              beta, yv, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc);                                               \
   } while (0)
-#define KK_MV4(NE) do { if (beta == 0.0) KK_MV4B(NE, true); else KK_MV4B(NE, false); } while (0)
+#define KK_MV4(NE)                                                                                                              \
+  do {                                                                                                                          \
+    if (beta == 0.0) { if (xrow) KK_MV4B(NE, true, true); else KK_MV4B(NE, true, false); }                                       \
+    else { if (xrow) KK_MV4B(NE, false, true); else KK_MV4B(NE, false, false); }                                                 \
+  } while (0)
+  const bool xrow = xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0);
   const int n = m->tab.n;
   if (n <= 8) KK_MV4(8); else if (n <= 16) KK_MV4(16); else if (n <= 20) KK_MV4(20); else if (n <= 24) KK_MV4(24);
   else KK_MV4(28);
@@ -1175,7 +1183,7 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   KK_LAUNCH_CHECK();
   if (m->n_nc > 0) {
     KK_LAUNCH((mv4_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, ldx, Y, ys0, ys1, alpha, beta);
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1, Y, ys0, ys1, alpha, beta);
     KK_LAUNCH_CHECK();
   }
   return KKAMD_OK;
@@ -1201,6 +1209,24 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
   const int mvk = plan ? plan->tune.mv_kernel : g_spmv_default.mv_kernel;      // 0 auto, 1 generic, 2 wave-private row-major, 3 LDS-staged X tiles, 4 plane marching
   const bool a_aligned = ((uintptr_t)A->d_values % 16 == 0) && ((uintptr_t)A->d_entries % 16 == 0);
   if (mvk != 1 && a_aligned) {
+    // plane-marching kernel (mv_kernel 0 = auto, or 4): analysed handles, fp64 vectors, right-hand sides in blocks of 16,
+    // matrices that verify as a radius-1 lattice stencil; the analysis happens on the first such call.  X and Y keep their
+    // strides (row-major X is read with 16-byte loads, anything else with two 8-byte loads per piece): nothing is packed
+    if constexpr (sizeof(YT) == 8) {
+      if (plan && plan->tile != 0 && (mvk == 0 || mvk == 4) && nvec >= 16 && nvec % 16 == 0 && plan->entries == A->d_entries) {
+        if (!plan->mv4 && !plan->mv4_tried) {
+          int rc = mv4_plan_build<OffT>(plan, A, st);
+          if (rc) return rc;
+        }
+        if (plan->mv4) {
+          for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
+            int rc = launch_mv4<OffT, AT>(plan, A, (const double*)X + c0 * xs1, xs0, xs1, (double*)Y + c0 * ys1, ys0, ys1, (double)alpha, (double)beta, st);
+            if (rc) return rc;
+          }
+          return KKAMD_OK;
+        }
+      }
+    }
     const YT* Xr = nullptr; int64_t ldx = 0;
     if (xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0)) { Xr = X; ldx = xs0; }
     else if (plan && nvec >= 2) {
@@ -1229,23 +1255,6 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
         if (plan->mv) {
           if (nv == 16) return launch_mv3<OffT, AT, 16>(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
           return launch_mv3<OffT, AT, 8>(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
-        }
-      }
-    }
-    // plane-marching kernel (mv_kernel 0 = auto, or 4): analysed handles, fp64 vectors, right-hand sides in blocks of 16,
-    // matrices that verify as a radius-1 lattice stencil; the analysis happens on the first such call
-    if constexpr (sizeof(YT) == 8) {
-      if (Xr && plan && plan->tile != 0 && (mvk == 0 || mvk == 4) && nvec >= 16 && nvec % 16 == 0 && plan->entries == A->d_entries) {
-        if (!plan->mv4 && !plan->mv4_tried) {
-          int rc = mv4_plan_build<OffT>(plan, A, st);
-          if (rc) return rc;
-        }
-        if (plan->mv4) {
-          for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
-            int rc = launch_mv4<OffT, AT>(plan, A, (const double*)Xr + c0, ldx, (double*)Y + c0 * ys1, ys0, ys1, (double)alpha, (double)beta, st);
-            if (rc) return rc;
-          }
-          return KKAMD_OK;
         }
       }
     }

@@ -47,3 +47,13 @@ for stencil in (("FE",) if quick else ("FE", "FD")):
                           "max_abs_diff_vs_mv2": err, "max_abs_diff_beta": err_b, "workgroups": h.query("mv4_workgroups"),
                           "other_rows": h.query("mv4_other_rows"), "stencil_entries": h.query("mv4_stencil"),
                           "mv_plan_bytes": h.query("mv_plan_bytes")}), flush=True)
+    # LayoutLeft X and Y (the plane-marching kernel reads X where it lies; the gather kernel packs it per call)
+    Xl = X.t().contiguous().t(); Yl = torch.zeros(nv, rows, dtype=torch.float64, device="cuda").t()
+    for name, knobs in (cases[0], cases[1]):
+        h = kk.SPMVHandle("SPMV_DEFAULT")
+        for k, v in knobs.items(): h.set(k, v)
+        kk.spmv(h, "N", 1.0, A, Xl, 0.0, Yl)
+        err = float((Yl - ref).abs().max())
+        ms = timeit(lambda: kk.spmv(h, "N", 1.0, A, Xl, 0.0, Yl), it=5)
+        print(json.dumps({"case": name, "stencil": stencil, "n": n, "nvec": nv, "layout": "left", "ms": round(ms, 4), "alg_GBps": round(alg / ms / 1e6, 1),
+                          "frac_8TBps": round(alg / ms / 1e6 / 8000, 3), "max_abs_diff_vs_mv2_right": err}), flush=True)

@@ -86,10 +86,11 @@ while time.time() < t_end:
             knobs = {"window_codes_min_knnz": 0, "window_codes": int(rng.integers(1, 3)), "nnz_per_thread": int(rng.choice([0, 4, 8, 16])),
                      "xcd_remap": int(rng.choice([0, 1, 2, 16])), "pattern_codes": int(rng.choice([0, 1, 2, 2])), "pattern_codes_min_knnz": 0,
                      "window_codes_min_pct": int(rng.choice([0, 10, 25, 60]))}
-            if rng.random() < 0.5:     # rank 2 on the same matrix: LDS-staged tiles and the wave-private kernel, every tile order
-                pc.check_spmv_mv(be, M, int(rng.choice([8, 16, 24, 5])), "N", float(rng.integers(-3, 4)), float(rng.integers(-1, 2)), "C", str(rng.choice(["C", "F"])),
-                                 algo="SPMV_DEFAULT", seed=case, max_val=50.0,
-                                 knobs={"mv_kernel": int(rng.choice([2, 3])), "mv_order": int(rng.integers(0, 3)), "mv_strip_min_kb": 50, "mv_strip_l2_kb": int(rng.choice([64, 512]))})
+            if rng.random() < 0.5:     # rank 2 on the same matrix: plane-marching (where it applies), LDS-staged tiles, wave-private kernel, every tile order
+                pc.check_spmv_mv(be, M, int(rng.choice([8, 16, 16, 32, 24, 5])), "N", float(rng.integers(-3, 4)), float(rng.integers(-1, 2)), str(rng.choice(["C", "F"])), str(rng.choice(["C", "F"])),
+                                 algo="SPMV_DEFAULT", seed=case, max_val=50.0, nans=bool(rng.random() < 0.3), offset_dtype=odt,
+                                 knobs={"mv_kernel": int(rng.choice([0, 0, 2, 3])), "mv_order": int(rng.integers(0, 3)), "mv_strip_min_kb": 50, "mv_strip_l2_kb": int(rng.choice([64, 512])),
+                                        "mv4_wg_per_cu": int(rng.choice([1, 8, 64]))})
             for beta in (0.0, float(rng.integers(-2, 3))):
                 pc.check_spmv(be, M, "N", float(rng.integers(-3, 4)), beta, algo="SPMV_DEFAULT", offset_dtype=odt, max_val=50.0, seed=case, knobs=knobs,
                               nans=(beta == 0.0), value_dtype=(vdt if vdt == np.float32 and rng.random() < 0.5 else None))
