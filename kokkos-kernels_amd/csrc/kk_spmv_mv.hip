@@ -753,14 +753,23 @@ __host__ __device__ constexpr int mv4_pitch(int ne, int vbytes) {   // entries p
   return ((ne * vbytes) % 128 == 0) ? ne + 2 * (8 / vbytes) : ne;
 }
 
-struct Mv4Tab { int n; int e[kMv4MaxL]; };   // analysis: n offsets col - row; kernel: n packed entries (dk + 1) | (dj (RI + 2) + di) << 2
+struct Mv4Tab { int n; int e[kMv4MaxL]; };   // analysis: n offsets col - row / the lattice steps of the entries
+// The stencil as the kernel walks it: entries that differ only in their step along the NEAR stride's lines (dj) form a group
+// (dk, di); a lane computes two lattice rows that are neighbours in j, so the four X rows j - 1 .. j + 2 of a group serve both.
+constexpr int kMv4MaxG = 9;
+struct Mv4Groups {
+  int n, ng;                // entries, groups
+  int e[kMv4MaxG];          // (dk + 1) | di << 2
+  int pres[kMv4MaxG];       // bit d: the entry with dj = d - 1 exists
+  int perm[kMv4MaxL];       // entry q -> its position 3 g + (dj + 1) in a row of the value buffer
+};
 
 }  // namespace kk
 
 struct kkamd_mv4_plan {
   int nx = 0, ny = 0, nz = 0, kc = 0;
   int64_t S1 = 0, S2 = 0, npi = 0, npj = 0, nchunk = 0, n_nc = 0;
-  kk::Mv4Tab tab{};                  // packed entries, padded to the kernel's entry count with (centre, value 0)
+  kk::Mv4Groups grp{};               // the stencil in the kernel's order
   void* d_arow = nullptr;            // [rows] offset type of the matrix: where the row's values start when it conforms to the stencil, else -1
   uint32_t* d_amask = nullptr;       // [rows] which entries of the stencil the row holds (all of them away from the lattice boundary)
   int32_t* d_nc = nullptr;           // [n_nc] the rows that do not
@@ -781,7 +790,7 @@ int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what) {
   switch (what) {
     case 0: return p->npi * p->npj * p->nchunk;   // workgroups
     case 1: return p->n_nc;                       // rows outside the stencil
-    case 2: return p->tab.n;
+    case 2: return p->grp.n;
     case 3: return (int64_t)p->bytes;
     case 4: return p->S1;
     default: return 0;
@@ -855,20 +864,21 @@ __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const 
   *yp = (beta == 0.0) ? alpha * acc : beta * (*yp) + alpha * acc;
 }
 
-template <class OffT, class AT, int NE, bool BETA0, bool XROW>
-__global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask, const AT* __restrict__ values, Mv4Tab tab,
+template <class OffT, class AT, int NG, unsigned PRES, bool BETA0, bool XROW>
+__global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask, const AT* __restrict__ values, Mv4Groups G,
                                                                   const double* __restrict__ X, int64_t xs0, int64_t xs1, double* __restrict__ Y,
                                                                   int64_t ys0, int64_t ys1, double alpha, double beta, int y_vec_ok, int nx,
                                                                   int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc) {
   constexpr int RI = kMv4RI, RJ = kMv4RJ, W = RI + 2, SLABR = (RJ + 2) * W, SLABB = SLABR * 128, NT = kMv4Threads;
-  constexpr int ROWS = NT / 8;                         // rows per step: two lines of the patch; two steps per plane
+  constexpr int ROWS = NT / 8;                         // row PAIRS per plane: a lane owns the lattice rows (i, j) and (i, j + 1)
   constexpr int NP = SLABR * 8, NXP = (NP + NT - 1) / NT;   // 16-byte pieces per slab, per thread
-  constexpr int LP = mv4_pitch(NE, (int)sizeof(AT));   // entries per row of the value buffer
-  constexpr int AV = (NE + 7) / 8;                     // values a lane carries for a row: entries c, c + 8, ...
-  constexpr int NLO = NE <= 8 ? 3 : (NE <= 16 ? 9 : NE - 3);   // this instantiation serves stencils of NLO..NE entries
+  constexpr int NPOS = 3 * NG + (NG & 1);              // positions of a row of the value buffer: 3 per group, even
+  constexpr int LP = mv4_pitch(NPOS, (int)sizeof(AT)); // entries per row of the value buffer
+  constexpr int AV = (3 * NG + 7) / 8;                 // values a lane carries for a row: entries c, c + 8, ...
   using XV = kk_f64x2;
   using AV2 = typename vec2<AT>::type;
-  KK_DYN_SMEM(char, smem);                             // [X ring: 4 slabs][values: 2 buffers x 2 steps x ROWS x LP]
+  KK_DYN_SMEM(char, smem);                             // [X ring: 4 slabs][values: 2 buffers x 2 rows of a pair x ROWS x LP]
+  __shared__ int perm_s[kMv4MaxL];
   char* ring = smem;
   AT* abuf   = reinterpret_cast<AT*>(smem + 4 * (size_t)SLABB);
   const int t = threadIdx.x, rs = t >> 3, line = rs / RI, ii = rs % RI, c = t & 7;
@@ -889,7 +899,7 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
   const OffT* wbase[2]; const uint32_t* mbase[2]; double* ybase[2];
   KK_UNROLL
   for (int u = 0; u < 2; ++u) {
-    const int jj = 2 * u + line;
+    const int jj = 2 * line + u;
     lane_ok[u] = jj < njj && i0 + ii < nx;
     const int64_t r0 = lane_ok[u] ? (int64_t)(j0 + jj) * S1 + i0 + ii : 0;
     wbase[u] = arow + r0; mbase[u] = amask + r0;
@@ -944,10 +954,13 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
       if (g < NP && x_in[it]) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = rx[it];
     }
   };
-  const uint32_t full = tab.n >= 32 ? 0xffffffffu : ((1u << tab.n) - 1u);
-  int qoff[AV];                                        // entry c + 8 m of a full row, clamped into the row
+  const uint32_t full = G.n >= 32 ? 0xffffffffu : ((1u << G.n) - 1u);
   KK_UNROLL
-  for (int m = 0; m < AV; ++m) qoff[m] = (c + 8 * m < tab.n) ? c + 8 * m : tab.n - 1;
+  for (int q = 0; q < kMv4MaxL; ++q) if (t == q) perm_s[q] = G.perm[q];
+  __syncthreads();
+  int qoff[AV], qpos[AV];                              // entry c + 8 m of a full row, clamped into the row; its position in the value buffer
+  KK_UNROLL
+  for (int m = 0; m < AV; ++m) { qoff[m] = (c + 8 * m < G.n) ? c + 8 * m : G.n - 1; qpos[m] = perm_s[qoff[m]]; }
   auto load_values = [&](int k, const OffT (&w)[2], const uint32_t (&mk)[2], AT (&ra)[2][AV]) {   // raw; rows that do not conform load the head of the array
     KK_UNROLL
     for (int u = 0; u < 2; ++u) {
@@ -967,12 +980,12 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
       }
     }
   };
-  auto store_values = [&](int buf, const uint32_t (&mk)[2], const AT (&ra)[2][AV]) {      // entries the row lacks, and pad entries, carry 0
+  auto store_values = [&](int buf, const uint32_t (&mk)[2], const AT (&ra)[2][AV]) {      // entries the row lacks carry 0
     KK_UNROLL
     for (int u = 0; u < 2; ++u) {
       AT* dst = abuf + ((size_t)(buf * 2 + u) * ROWS + rs) * LP;
       KK_UNROLL
-      for (int m = 0; m < AV; ++m) { const int q = c + 8 * m; if (q < NE) dst[q] = ((mk[u] >> q) & 1u) ? ra[u][m] : AT(0); }
+      for (int m = 0; m < AV; ++m) { const int q = c + 8 * m; if (q < G.n) dst[qpos[m]] = ((mk[u] >> q) & 1u) ? ra[u][m] : AT(0); }
     }
   };
   auto y_ptr = [&](int k, int u) -> double* { return ybase[u] + (int64_t)k * S2 * ys0; };
@@ -1018,27 +1031,40 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
       load_values(k + 2, w_stage[1 - P], m_stage[1 - P], ra[P]);
       XV yold[2] = {{0.0, 0.0}, {0.0, 0.0}}, out[2] = {{0.0, 0.0}, {0.0, 0.0}};
       if constexpr (!BETA0) load_yold(k, w_cur, yold);
-      KK_UNROLL
-      for (int u = 0; u < 2; ++u) {
-        if (conforms(k, u, w_cur[u])) {
-          const int jj = 2 * u + line;
-          const AT* av = abuf + ((size_t)(P * 2 + u) * ROWS + rs) * LP;
-          const char* own = ring + (((jj + 1) * W + ii + 1) << 7) + c * 16;   // this row's own X row in slot 0, this lane's piece
-          double acc0 = 0.0, acc1 = 0.0;
+      if (conforms(k, 0, w_cur[0]) || conforms(k, 1, w_cur[1])) {           // a row that does not conform computes garbage nobody stores
+        const AT* av0 = abuf + ((size_t)(P * 2) * ROWS + rs) * LP;
+        const AT* av1 = av0 + (size_t)ROWS * LP;
+        const char* own = ring + (((2 * line) * W + ii + 1) << 7) + c * 16; // slab line of lattice line j - 1 of the pair's first row, slot 0, this lane's piece
+        double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+        KK_UNROLL
+        for (int gp = 0; gp < (NG + 1) / 2; ++gp) {                         // two groups = six positions = three 16-byte reads per row
+          AV2 v0[3], v1[3];
           KK_UNROLL
-          for (int q = 0; q < NE; q += 2) {
-            const AV2 v = *reinterpret_cast<const AV2*>(av + q);             // two values per read (the row's 8 lanes: one address)
+          for (int i = 0; i < 3; ++i)
+            if (6 * gp + 2 * i < NPOS) { v0[i] = *reinterpret_cast<const AV2*>(av0 + 6 * gp + 2 * i); v1[i] = *reinterpret_cast<const AV2*>(av1 + 6 * gp + 2 * i); }
+          KK_UNROLL
+          for (int gg = 0; gg < 2; ++gg) {
+            const int g = 2 * gp + gg;
+            if (g >= NG || (!PRES && g >= G.ng)) continue;                    // uniform
+            // PRES != 0: the stencil's pattern (3 bits per group) is a compile-time constant -- straight-line code, every read of the
+            // plane schedulable ahead; PRES == 0: any pattern, scalar branches
+            const int e = G.e[g], pres = PRES ? (int)((PRES >> (3 * g)) & 7u) : G.pres[g];
+            const char* xb = own + ((k + (e & 3) - 1) & 3) * SLABB + (e >> 2) * 128;
+            XV x[4];
             KK_UNROLL
-            for (int h = 0; h < 2; ++h) {
-              if (q + h >= NLO && q + h >= tab.n) continue;                  // pad entries take no part (0 * Inf would be NaN); uniform
-              const int e = tab.e[q + h];                                    // uniform: scalar registers
-              const int sb = ((k + (e & 3) - 1) & 3) * SLABB + (e >> 2) * 128;
-              const XV x = *reinterpret_cast<const XV*>(own + sb);
-              acc0 = __builtin_fma((double)v[h], x[0], acc0); acc1 = __builtin_fma((double)v[h], x[1], acc1);
+            for (int sl = 0; sl < 4; ++sl)                                    // X row j - 1 + sl of the group: the first row's dj = sl - 1, the second row's dj = sl - 2
+              if ((sl < 3 && ((pres >> sl) & 1)) || (sl > 0 && ((pres >> (sl - 1)) & 1))) x[sl] = *reinterpret_cast<const XV*>(xb + sl * (W * 128));
+            KK_UNROLL
+            for (int d = 0; d < 3; ++d) {
+              if (!((pres >> d) & 1)) continue;                               // the stencil has no such entry (0 * Inf would be NaN); uniform
+              const int idx = 3 * gg + d;
+              const double va0 = (double)v0[idx >> 1][idx & 1], va1 = (double)v1[idx >> 1][idx & 1];
+              a00 = __builtin_fma(va0, x[d][0], a00);     a01 = __builtin_fma(va0, x[d][1], a01);
+              a10 = __builtin_fma(va1, x[d + 1][0], a10); a11 = __builtin_fma(va1, x[d + 1][1], a11);
             }
           }
-          out[u][0] = alpha * acc0; out[u][1] = alpha * acc1;
         }
+        out[0][0] = alpha * a00; out[0][1] = alpha * a01; out[1][0] = alpha * a10; out[1][1] = alpha * a11;
       }
       // what the PREVIOUS plane issued: the values of plane k + 1 into the other buffer (last read in plane k - 1), X of plane
       // k + 2 into the slot that held plane k - 2 -- both behind a barrier.  This plane's stores to Y come after the wait:
@@ -1131,13 +1157,20 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
   int32_t* d_nc = m->d_nc;
   KK_LAUNCH((mv4_list_kernel<OffT>), (unsigned)ceil_div(A->num_rows, kBlock), kBlock, 0, st, A->num_rows, (const OffT*)d_arow, d_nc, d_cnt + 1);
   if (hipStreamSynchronize(st) != hipSuccess) return drop();
-  // per entry: plane selector and position relative to the row's own X row inside a slab; the pad entries read the centre
-  m->tab.n = offs.n;
-  for (int q = 0; q < kMv4MaxL; ++q) {
-    if (q >= offs.n) { m->tab.e[q] = 1; continue; }
-    const int64_t d = offs.e[q], dk = mv4_round_div(d, S2), rem = d - dk * S2, dj = mv4_round_div(rem, S1), di = rem - dj * S1;
-    m->tab.e[q] = (int)((dk + 1) | ((dj * (kMv4RI + 2) + di) * 4));
-  }
+  // the kernel's view of the stencil: groups (dk, di), in ascending order of that key, of up to three entries dj = -1, 0, 1
+  m->grp.n = offs.n; m->grp.ng = 0;
+  auto step_of = [&](int q, int64_t& dk, int64_t& dj, int64_t& di) {
+    const int64_t d = offs.e[q]; dk = mv4_round_div(d, S2); const int64_t rem = d - dk * S2; dj = mv4_round_div(rem, S1); di = rem - dj * S1;
+  };
+  for (int kd = -1; kd <= 1; ++kd)
+    for (int id = -1; id <= 1; ++id) {
+      int pres = 0;
+      for (int q = 0; q < offs.n; ++q) { int64_t dk, dj, di; step_of(q, dk, dj, di); if (dk == kd && di == id) pres |= 1 << (int)(dj + 1); }
+      if (!pres) continue;
+      const int g = m->grp.ng++;
+      m->grp.e[g] = (kd + 1) | (id * 4); m->grp.pres[g] = pres;
+      for (int q = 0; q < offs.n; ++q) { int64_t dk, dj, di; step_of(q, dk, dj, di); if (dk == kd && di == id) m->grp.perm[q] = 3 * g + (int)(dj + 1); }
+    }
   m->npi = ceil_div(nx, (int64_t)kMv4RI); m->npj = ceil_div(ny, (int64_t)kMv4RJ);
   // k-chunks: enough workgroups to fill the chip several times over (one workgroup per CU at a time), few halo planes
   int64_t nchunk = ceil_div((int64_t)plan->num_cus * plan->tune.mv4_wg_per_cu, m->npi * m->npj);
@@ -1156,27 +1189,32 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   const size_t slabs = 4 * (size_t)((kMv4RJ + 2) * (kMv4RI + 2) * 128), rows = kMv4Threads / 8;
   const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
 #ifndef KK_EMU
-#define KK_MV4_ATTR(NE, B0, XR) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, B0, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+#define KK_MV4_ATTR(NE, FL, B0, XR) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
 #else
-#define KK_MV4_ATTR(NE, B0, XR) (void)0
+#define KK_MV4_ATTR(NE, FL, B0, XR) (void)0
 #endif
-#define KK_MV4B(NE, B0, XR)                                                                                                     \
+#define KK_MV4B(NE, FL, B0, XR)                                                                                                    \
   do {                                                                                                                          \
-    const size_t lds = slabs + 4 * rows * mv4_pitch(NE, (int)sizeof(AT)) * sizeof(AT);                                           \
-    KK_MV4_ATTR(NE, B0, XR);                                                                                                    \
-    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, B0, XR>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,            \
-              (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values, m->tab, X, xs0, xs1, Y, ys0, ys1, alpha, \
+    const size_t lds = slabs + 4 * rows * mv4_pitch(3 * NE + (NE & 1), (int)sizeof(AT)) * sizeof(AT);                            \
+    KK_MV4_ATTR(NE, FL, B0, XR);                                                                                                  \
+    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,            \
+              (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values, m->grp, X, xs0, xs1, Y, ys0, ys1, alpha, \
               beta, yv, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc);                                               \
   } while (0)
-#define KK_MV4(NE)                                                                                                              \
+#define KK_MV4(NE, FL)                                                                                                          \
   do {                                                                                                                          \
-    if (beta == 0.0) { if (xrow) KK_MV4B(NE, true, true); else KK_MV4B(NE, true, false); }                                       \
-    else { if (xrow) KK_MV4B(NE, false, true); else KK_MV4B(NE, false, false); }                                                 \
+    if (beta == 0.0) { if (xrow) KK_MV4B(NE, FL, true, true); else KK_MV4B(NE, FL, true, false); }                               \
+    else { if (xrow) KK_MV4B(NE, FL, false, true); else KK_MV4B(NE, FL, false, false); }                                         \
   } while (0)
   const bool xrow = xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0);
-  const int n = m->tab.n;
-  if (n <= 8) KK_MV4(8); else if (n <= 16) KK_MV4(16); else if (n <= 20) KK_MV4(20); else if (n <= 24) KK_MV4(24);
-  else KK_MV4(28);
+  unsigned pat = 0;                                    // 3 bits per group: which of dj = -1, 0, 1 it holds
+  for (int g = 0; g < m->grp.ng; ++g) pat |= (unsigned)m->grp.pres[g] << (3 * g);
+  constexpr unsigned kPat27 = 0x7FFFFFFu;              // 9 groups x {-1, 0, 1}: the 27-point stencil
+  constexpr unsigned kPat7  = 2u | 2u << 3 | 7u << 6 | 2u << 9 | 2u << 12;   // (dk, di) = (-1,0) (0,-1) (0,0) (0,1) (1,0): the 7-point stencil
+  if (m->grp.ng == 9 && pat == kPat27) KK_MV4(9, kPat27);
+  else if (m->grp.ng == 5 && pat == kPat7) KK_MV4(5, kPat7);
+  else if (m->grp.ng <= 5) KK_MV4(5, 0u);
+  else KK_MV4(9, 0u);
 #undef KK_MV4B
 #undef KK_MV4
 #undef KK_MV4_ATTR

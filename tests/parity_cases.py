@@ -314,20 +314,28 @@ def mv4_cases():
     that break the pattern"""
     out = [("27pt 40x14x14", oracle.laplace3d("FE", 40, 14, 14), None), ("7pt 35x13x14", oracle.laplace3d("FD", 35, 13, 14), None),
            ("27pt 9x33x17", oracle.laplace3d("FE", 9, 33, 17), None)]
-    # a clean truncated 7-point stencil (every boundary row is a subset whose missing entries point outside): no gather rows
+    # clean truncated stencils (every boundary row is a subset whose missing entries point outside): no gather rows.  7 points =
+    # the kernel's compiled-in pattern; 19 points (faces + edges) and 11 points = its run-time patterns with 9 and 5 groups
+    def truncated(nx, ny, nz, steps, seed):
+        i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+        rows, cols = [], []
+        for dk, dj, di in steps:
+            ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < ny) & (k + dk >= 0) & (k + dk < nz)
+            rows.append((k * ny * nx + j * nx + i)[ok]); cols.append(((k + dk) * ny * nx + (j + dj) * nx + i + di)[ok])
+        rows = np.concatenate(rows); cols = np.concatenate(cols)
+        order = np.lexsort((cols, rows)); rows = rows[order]; cols = cols[order]
+        n = nx * ny * nz
+        rm = np.zeros(n + 1, dtype=np.int64); np.add.at(rm, rows + 1, 1); rm = np.cumsum(rm)
+        return oracle.Crs(n, n, rm, cols.astype(np.int32), np.random.default_rng(seed).random(rows.size) + 0.5)
+    seven = ((-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0))
     nx, ny, nz = 33, 6, 21
-    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
-    rows, cols = [], []
-    for dk, dj, di in ((-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 0, 0)):
-        ok = (i + di >= 0) & (i + di < nx) & (j + dj >= 0) & (j + dj < ny) & (k + dk >= 0) & (k + dk < nz)
-        rows.append((k * ny * nx + j * nx + i)[ok]); cols.append(((k + dk) * ny * nx + (j + dj) * nx + i + di)[ok])
-    rows = np.concatenate(rows); cols = np.concatenate(cols)
-    order = np.lexsort((cols, rows)); rows = rows[order]; cols = cols[order]
-    n = nx * ny * nz
-    rm = np.zeros(n + 1, dtype=np.int64); np.add.at(rm, rows + 1, 1); rm = np.cumsum(rm)
-    vals = np.random.default_rng(12).random(rows.size) + 0.5
-    clean = oracle.Crs(n, n, rm, cols.astype(np.int32), vals)
+    clean = truncated(nx, ny, nz, seven, 12)
+    rm, cols, vals, n = clean.row_map, clean.entries, clean.values, clean.nrows
     out.append(("7pt clean 33x6x21", clean, 0))
+    nineteen = tuple((dk, dj, di) for dk in (-1, 0, 1) for dj in (-1, 0, 1) for di in (-1, 0, 1) if abs(dk) + abs(dj) + abs(di) <= 2)
+    out.append(("19pt clean 20x15x16", truncated(20, 15, 16, nineteen, 13), 0))
+    eleven = seven + ((0, -1, -1), (0, 1, 1), (0, -1, 1), (0, 1, -1))
+    out.append(("11pt clean 36x9x14", truncated(36, 9, 14, eleven, 14), 0))
     # the same with rows that break the pattern: an extra coupling, a dropped interior entry, an emptied row, a wrap-around entry
     rm2 = rm.copy(); ent = cols.astype(np.int32).copy(); val = vals.copy()
     def drop(r, pos):
