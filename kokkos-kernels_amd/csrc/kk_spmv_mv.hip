@@ -741,7 +741,8 @@ static const int32_t* mv2_order(kkamd_spmv_plan* plan, const kkamd_crs_t* A, int
 // times per product instead of once per tile that touches it.  Rows that conform read no column information at all (8 B per
 // nonzero, the values, plus one word per row: where the values start, or -1); the others -- lattice boundaries, anything
 // irregular: 2 % of C3 -- are listed by the analysis and done by a small gather kernel afterwards.
-//   One plane of the patch = two steps of 64 rows (8 lanes per row, two right-hand sides per lane).  One workgroup fits a CU
+//   One plane of the patch = 64 row PAIRS (8 lanes per pair, two right-hand sides per lane; the pair = two lattice rows that are
+// neighbours in j, so that the X rows a stencil group touches serve both: Mv4Groups).  One workgroup fits a CU
 // (133-162 KB of LDS), so HBM latency cannot be hidden by other workgroups; the loop is software-pipelined a whole plane deep
 // instead, TWO planes deep: while plane k is computed out of LDS, the values of planes k + 1 and k + 2, the X slabs of planes
 // k + 2 and k + 3 and the row words of plane k + 3 are in flight to two register sets (about 108 KB per CU), and the older
