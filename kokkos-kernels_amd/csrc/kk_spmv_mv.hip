@@ -730,25 +730,27 @@ static const int32_t* mv2_order(kkamd_spmv_plan* plan, const kkamd_crs_t* A, int
 }
 
 // ================================================================================================================
-// Plane-marching rank-2 kernel (knob mv_kernel 4; analysed handles, 16 fp64 right-hand sides, row-major X).
+// Plane-marching rank-2 kernel (mv_kernel 0 = auto, or 4; analysed handles, fp64, right-hand sides in blocks of 16, any strides).
 //
 // What the two kernels above cannot do is keep X inside the CU across MANY rows: the gather kernel re-reads every X row
 // through the texture path once per nonzero, the LDS-staged tiles re-fetch their window once per 32 rows.  On a matrix whose
 // rows are a radius-1 stencil on an nx x ny x nz lattice -- found, not assumed: the strides S2 (= nx ny) and S1 (= nx) come
-// out of the columns of a few rows, one interior row gives the offset list, and a device pass checks EVERY row against it --
-// a workgroup takes a patch of RI x RJ lattice points and MARCHES along the far stride: the X rows of three consecutive
+// out of the columns of a few rows, the longest sampled row gives the offset list, and a device pass checks EVERY row against
+// it -- a workgroup takes a patch of RI x RJ lattice points and MARCHES along the far stride: the X rows of three consecutive
 // planes of the patch (plus a one-point halo) sit in an LDS ring of four slabs and an X row crosses L2 -> LDS about 1.6
-// times per product instead of once per tile that touches it.  Rows that conform read no column information at all (8 B per
-// nonzero, the values, plus one word per row: where the values start, or -1); the others -- lattice boundaries, anything
-// irregular: 2 % of C3 -- are listed by the analysis and done by a small gather kernel afterwards.
-//   One plane of the patch = 64 row PAIRS (8 lanes per pair, two right-hand sides per lane; the pair = two lattice rows that are
-// neighbours in j, so that the X rows a stencil group touches serve both: Mv4Groups).  One workgroup fits a CU
-// (133-162 KB of LDS), so HBM latency cannot be hidden by other workgroups; the loop is software-pipelined a whole plane deep
-// instead, TWO planes deep: while plane k is computed out of LDS, the values of planes k + 1 and k + 2, the X slabs of planes
-// k + 2 and k + 3 and the row words of plane k + 3 are in flight to two register sets (about 108 KB per CU), and the older
-// set is written to the other half of the value buffer and to the free ring slot just before the plane's single barrier.  (Measured alternatives, profiles/round2: global_load_lds
-// for all three streams -- LDS-DMA sustains about 12 B/clk/CU with 16-byte pieces and a quarter of that with 4-byte ones --
-// 5.9 ms; values one step ahead with a wait per step 4.35 ms.)
+// times per product instead of once per tile that touches it.  Rows that conform -- interior rows, and boundary rows whose
+// missing entries point outside the lattice -- read no column information at all (8 B per nonzero, the values, plus two
+// words per row: where the values start, which entries exist); the others (wrap-around couplings, anything irregular: 0.3 %
+// of C3) are listed by the analysis and done by a small gather kernel afterwards.
+//   One plane of the patch = 64 row PAIRS (8 lanes per pair, two right-hand sides per lane; the pair = two lattice rows that
+// are neighbours in j, so that the X rows a stencil group touches serve both: Mv4Groups).  One workgroup fits a CU (133 KB
+// of LDS), so HBM latency cannot be hidden by other workgroups; the loop is software-pipelined TWO planes deep instead: while
+// plane k is computed out of LDS, the values of planes k + 1 and k + 2, the X slabs of planes k + 2 and k + 3 and the row
+// words of plane k + 3 are in flight to two register sets (about 108 KB per CU), and the older set is written to the other
+// half of the value buffer and to the free ring slot just before the plane's single barrier.  (Measured on the way,
+// DESIGN 4.2 / profiles/round2: global_load_lds for all three streams 5.9 ms -- LDS-DMA sustains about 12 B/clk/CU with
+// 16-byte pieces, a quarter of that with 4-byte ones --; values one step ahead with a wait per step 4.35 ms; one plane deep
+// 4.05 ms; one row per lane 2.97 ms; this form 2.70 ms on C3, 0.96 of the HBM rate a streaming kernel reaches with its mix.)
 constexpr int kMv4Threads = 512, kMv4RI = 32, kMv4RJ = 4, kMv4MaxL = 28;
 __host__ __device__ constexpr int mv4_pitch(int ne, int vbytes) {   // entries per row of the value ring: the 4 rows of a read group on 4 different 16-B slots
   return ((ne * vbytes) % 128 == 0) ? ne + 2 * (8 / vbytes) : ne;
