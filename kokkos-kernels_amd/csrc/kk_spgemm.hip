@@ -889,11 +889,17 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
   const int sg = 1 << sg_log2, sub = t >> sg_log2, nsub = NT >> sg_log2, sl = t & (sg - 1);
   const int sg_shift   = lane & ~(sg - 1);
   const kk_u64 sg_mask = sg == 64 ? ~0ull : ((1ull << sg) - 1ull);
+  // A B row is streamed by a whole wave (UL * 64 entries per step) only when a window is expected to take about a wave's worth
+  // of it: the row's entries spread over cnt / cap windows, so len * cap / cnt of them fall into one.  (With the fixed
+  // threshold kValLong every window re-read 128 entries of every hub row to consume a handful: 17 of the 23.7 ms of this
+  // kernel on R-MAT scale 18 were spent there.)
+  const int64_t long_est = 64 * cnt / (cap > 0 ? cap : 1);
+  const int long_min = (int)(long_est > kValLong ? (long_est < INT_MAX ? long_est : INT_MAX) : kValLong);
   for (int64_t a = t; a < la_c; a += NT) {
     const int32_t kc = entA[a0 + a];
     const int64_t b0 = (int64_t)rmB[kc];
     const int len    = (int)((int64_t)rmB[kc + 1] - b0);
-    s_cur[a] = b0; s_rem[a] = len; s_av[a] = valA[a0 + a]; s_long[a] = len >= kValLong ? 1 : 0;
+    s_cur[a] = b0; s_rem[a] = len; s_av[a] = valA[a0 + a]; s_long[a] = len >= long_min ? 1 : 0;
   }
   for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
   auto accumulate = [&](int c, VT v) {
