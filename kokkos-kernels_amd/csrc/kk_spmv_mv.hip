@@ -1250,21 +1250,25 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
   const int mvk = plan ? plan->tune.mv_kernel : g_spmv_default.mv_kernel;      // 0 auto, 1 generic, 2 wave-private row-major, 3 LDS-staged X tiles, 4 plane marching
   const bool a_aligned = ((uintptr_t)A->d_values % 16 == 0) && ((uintptr_t)A->d_entries % 16 == 0);
   if (mvk != 1 && a_aligned) {
-    // plane-marching kernel (mv_kernel 0 = auto, or 4): analysed handles, fp64 vectors, right-hand sides in blocks of 16,
+    // plane-marching kernel (mv_kernel 0 = auto, or 4): analysed handles, fp64 vectors, right-hand sides in blocks of 16 (a
+    // remainder of fewer than 16 columns goes to the gather kernel),
     // matrices that verify as a radius-1 lattice stencil; the analysis happens on the first such call.  X and Y keep their
     // strides (row-major X is read with 16-byte loads, anything else with two 8-byte loads per piece): nothing is packed
     if constexpr (sizeof(YT) == 8) {
-      if (plan && plan->tile != 0 && (mvk == 0 || mvk == 4) && nvec >= 16 && nvec % 16 == 0 && plan->entries == A->d_entries) {
+      if (plan && plan->tile != 0 && (mvk == 0 || mvk == 4) && nvec >= 16 && plan->entries == A->d_entries) {
         if (!plan->mv4 && !plan->mv4_tried) {
           int rc = mv4_plan_build<OffT>(plan, A, st);
           if (rc) return rc;
         }
         if (plan->mv4) {
-          for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
+          int64_t c0 = 0;
+          for (; c0 + 16 <= nvec; c0 += 16) {
             int rc = launch_mv4<OffT, AT>(plan, A, (const double*)X + c0 * xs1, xs0, xs1, (double*)Y + c0 * ys1, ys0, ys1, (double)alpha, (double)beta, st);
             if (rc) return rc;
           }
-          return KKAMD_OK;
+          if (c0 == nvec) return KKAMD_OK;
+          // the last nvec % 16 columns: the kernels below (fewer than 16 columns never come back here)
+          return spmv_mv_typed<OffT, AT, YT>(plan, A, trans, alpha_d, X + c0 * xs1, xs0, xs1, beta_d, Y + c0 * ys1, ys0, ys1, nvec - c0, st);
         }
       }
     }
