@@ -1180,6 +1180,7 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
   if (nchunk > nz / 4) nchunk = nz / 4;
   if (nchunk < 1) nchunk = 1;
   m->kc = (int)ceil_div(nz, nchunk); m->nchunk = ceil_div(nz, (int64_t)m->kc);
+  if (m->npi * m->npj * m->nchunk > (int64_t)INT32_MAX) return drop();          // more workgroups than a launch takes
   m->bytes = (sizeof(OffT) + sizeof(uint32_t)) * (size_t)A->num_rows + sizeof(int32_t) * (size_t)(m->n_nc > 0 ? m->n_nc : 1);
   plan->mv4 = m;
   return KKAMD_OK;
