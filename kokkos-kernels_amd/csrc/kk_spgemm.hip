@@ -13,7 +13,7 @@
 //      that fits it:
 //      symbolic   flops <= 1365    wave per row, 2048-slot key table (4 rows per workgroup)
 //                 flops <= 2048    256-thread workgroup, 4096-slot table
-//                 flops <= 16384   1024-thread workgroup, 32768-slot table
+//                 flops <= 8192    1024-thread workgroup, 16384-slot table (64 KB: two workgroups per CU)
 //                 above            1024-thread workgroup, k-bit column BITMAP in LDS (2^20 columns per pass), popcount
 //      numeric    nnz <= 256       wave per row, 512-slot key+value table, compaction + rank-by-counting -> sorted
 //                 nnz <= 2048/5461 (only when B is unsorted) workgroup per row, 4096/8192-slot table, bitonic network
@@ -69,7 +69,7 @@ constexpr int kNumBins   = 5;      // 0 empty, 1 wave, 2 block-small, 3 block-la
 constexpr int kHashMul   = 107;
 constexpr int kSymWaveTable = 2048;   // symbolic keys only: 8 KB per wave
 constexpr int kWaveTable = 512;       // numeric keys + values
-constexpr int kSymBlkS = 4096,  kSymBlkL = 32768;
+constexpr int kSymBlkS = 4096,  kSymBlkL = 16384;   // 64 KB of keys: two workgroups per CU (32768 slots: one; R-MAT s20 symbolic 101 -> 94 ms)
 constexpr int kNumBlkS = 4096,  kNumBlkL = 8192;
 constexpr int kDenseBlock = 1024;     // dense-row column kernel: 16 waves around one LDS bitmap
 constexpr int kValBlock   = 512;      // dense-row value kernel
