@@ -336,6 +336,23 @@ def mv4_cases():
     out.append(("19pt clean 20x15x16", truncated(20, 15, 16, nineteen, 13), 0))
     eleven = seven + ((0, -1, -1), (0, 1, 1), (0, -1, 1), (0, 1, -1))
     out.append(("11pt clean 36x9x14", truncated(36, 9, 14, eleven, 14), 0))
+    # periodic in i (wrap-around couplings on two faces: those rows cannot conform) and a lattice whose plane stride is a
+    # multiple of its line stride only by accident of the sizes (nx = ny)
+    per = seven + ((0, 0, 0),)
+    def periodic_i(nx, ny, nz, seed):
+        i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+        rows, cols = [], []
+        for dk, dj, di in seven:
+            ii = (i + di) % nx
+            ok = (j + dj >= 0) & (j + dj < ny) & (k + dk >= 0) & (k + dk < nz)
+            rows.append((k * ny * nx + j * nx + i)[ok]); cols.append(((k + dk) * ny * nx + (j + dj) * nx + ii)[ok])
+        rows = np.concatenate(rows); cols = np.concatenate(cols)
+        order = np.lexsort((cols, rows)); rows = rows[order]; cols = cols[order]
+        n = nx * ny * nz
+        rm_ = np.zeros(n + 1, dtype=np.int64); np.add.at(rm_, rows + 1, 1); rm_ = np.cumsum(rm_)
+        return oracle.Crs(n, n, rm_, cols.astype(np.int32), np.random.default_rng(seed).random(rows.size) + 0.5)
+    out.append(("7pt periodic in i 34x7x20", periodic_i(34, 7, 20, 15), 2 * 7 * 20))
+    out.append(("7pt clean 17x17x17", truncated(17, 17, 17, seven, 16), 0))
     # the same with rows that break the pattern: an extra coupling, a dropped interior entry, an emptied row, a wrap-around entry
     rm2 = rm.copy(); ent = cols.astype(np.int32).copy(); val = vals.copy()
     def drop(r, pos):
