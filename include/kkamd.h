@@ -149,6 +149,8 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *     "mv_strip_min_kb" / "mv_strip_l2_kb"  when strips engage / how much of an XCD's L2 a strip's X rows may take
  *     "mv_glds"         LDS-staged kernel: X window through global_load_lds (1) or registers (0)
  *     "mv4_wg_per_cu"   plane-marching kernel: workgroups per CU the split along the far stride aims for (default 8, 1..64)
+ *     "march"           rank 1 on the plane-marching analysis (fp64 vectors, matrices that verify as lattice stencils): 0 (default)
+ *                       off -- measured equal to the planned stream kernel on C2 --, 1 on; "march_planes" planes per workgroup (20)
  *   kkamd_spmv_struct (global only): "struct_remap", "struct_group", "struct_strip" workgroup orders, all off
  *   "verbose" (global): 1 = the library reports what it chose on stdout
  *   SpGEMM (kkamd_set_default only) "spgemm_win_bits" (columns per LDS bitmap pass), "spgemm_val_cap", "spgemm_val_shape",
@@ -161,7 +163,7 @@ int kkamd_set_default(const char* key, int value);
  * "code_tiles" / "staged_tiles" / "pattern_tiles", "window_codes" (1 if any tile uses the column analysis), "window_staged_x",
  * "plan_bytes" (HBM the analysis keeps), "transpose_cached", rank 2: "mv_tiles", "mv_staged_tiles", "mv_order" (order in use),
  * "mv_period" (far stride found), "mv_plan_bytes", plane-marching kernel: "mv4_workgroups" (0 = not in use), "mv4_other_rows"
- * (rows left to its gather kernel), "mv4_stencil" (entries of the stencil), "mv4_near_stride". */
+ * (rows left to its gather kernel), "mv4_stencil" (entries of the stencil), "mv4_near_stride"; "march_workgroups" (rank-1 marching kernel, 0 = not in use). */
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);
 /* Copies a per-tile array of the analysis to a HOST buffer of `count` int32: "tile_first_row" (tiles + 1 entries: the first row that
  * starts at or after nonzero b * tile, bit 31 set when the tile starts inside a row -- the nnz-split counterpart of the

@@ -1008,6 +1008,14 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
     }
     return run_transpose<OffT, AT, YT>(A, x, y, alpha, beta, st);
   }
+  if constexpr (sizeof(YT) == 8) {
+    // lattice stencils: the plane-marching kernel reads no column index and fetches x once per patch plane (knob march)
+    if (plan && plan->tile != 0 && plan->tune.march && plan->entries == A->d_entries) {
+      int ran = 0;
+      const int rc = march_spmv(plan, A, (const double*)x, (double*)y, (double)alpha, (double)beta, st, &ran);
+      if (rc || ran) return rc;
+    }
+  }
   if (stream_usable(plan, A, (int)sizeof(AT))) return run_stream<OffT, AT, YT>(plan, A, x, y, alpha, beta, st);
   // No analysed plan (handle-less overloads, SPMV_FAST_SETUP): a large matrix is still worth the nnz-split kernel --
   // its "analysis" is one tiny kernel (a binary search per 4096-nnz tile) into a per-thread scratch that is reused
@@ -1078,6 +1086,8 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "mv_strip_l2_kb") { if (value < 1) return bad("positive"); t.mv_strip_l2_kb = value; }
   else if (k == "mv_glds") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv_glds = value; }
   else if (k == "mv4_wg_per_cu") { if (value < 1 || value > 64) return bad("in 1..64"); t.mv4_wg_per_cu = value; }
+  else if (k == "march") { if (value != 0 && value != 1) return bad("0 or 1"); t.march = value; }
+  else if (k == "march_planes") { if (value < 1 || value > 4096) return bad("in 1..4096"); t.march_planes = value; }
   else if (k == "window_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.window_codes = value; }
   else if (k == "window_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.window_codes_min_knnz = value; }
   else if (k == "window_codes_min_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.window_codes_min_pct = value; }
@@ -1433,6 +1443,7 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "mv4_other_rows") *value = kk::mv4_plan_query(plan->mv4, 1);
   else if (k == "mv4_stencil") *value = kk::mv4_plan_query(plan->mv4, 2);
   else if (k == "mv4_near_stride") *value = kk::mv4_plan_query(plan->mv4, 4);
+  else if (k == "march_workgroups") *value = plan->tune.march ? kk::mv4_plan_query(plan->mv4, 5) : 0;
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
   return KKAMD_OK;
 }

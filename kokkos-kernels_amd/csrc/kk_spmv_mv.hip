@@ -765,13 +765,14 @@ struct Mv4Groups {
   int e[kMv4MaxG];          // (dk + 1) | di << 2
   int pres[kMv4MaxG];       // bit d: the entry with dj = d - 1 exists
   int perm[kMv4MaxL];       // entry q -> its position 3 g + (dj + 1) in a row of the value buffer
+  int ent[kMv4MaxL];        // entry q -> (dk + 1) | (dj (RI + 2) + di) << 2: plane and position relative to the row's own point (rank-1 kernel)
 };
 
 }  // namespace kk
 
 struct kkamd_mv4_plan {
-  int nx = 0, ny = 0, nz = 0, kc = 0;
-  int64_t S1 = 0, S2 = 0, npi = 0, npj = 0, nchunk = 0, n_nc = 0;
+  int nx = 0, ny = 0, nz = 0, kc = 0, kc1 = 0, kc1_planes = 0;   // kc1 (knob value seen) / kc1_planes / nchunk1: the k-chunks of the rank-1 kernel
+  int64_t S1 = 0, S2 = 0, npi = 0, npj = 0, nchunk = 0, nchunk1 = 0, n_nc = 0;
   kk::Mv4Groups grp{};               // the stencil in the kernel's order
   void* d_arow = nullptr;            // [rows] offset type of the matrix: where the row's values start when it conforms to the stencil, else -1
   uint32_t* d_amask = nullptr;       // [rows] which entries of the stencil the row holds (all of them away from the lattice boundary)
@@ -796,6 +797,7 @@ int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what) {
     case 2: return p->grp.n;
     case 3: return (int64_t)p->bytes;
     case 4: return p->S1;
+    case 5: return p->npi * p->npj * p->nchunk1;
     default: return 0;
   }
 }
@@ -1174,6 +1176,7 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
       m->grp.e[g] = (kd + 1) | (id * 4); m->grp.pres[g] = pres;
       for (int q = 0; q < offs.n; ++q) { int64_t dk, dj, di; step_of(q, dk, dj, di); if (dk == kd && di == id) m->grp.perm[q] = 3 * g + (int)(dj + 1); }
     }
+  for (int q = 0; q < offs.n; ++q) { int64_t dk, dj, di; step_of(q, dk, dj, di); m->grp.ent[q] = (int)((dk + 1) | ((dj * (kMv4RI + 2) + di) * 4)); }
   m->npi = ceil_div(nx, (int64_t)kMv4RI); m->npj = ceil_div(ny, (int64_t)kMv4RJ);
   // k-chunks: enough workgroups to fill the chip several times over (one workgroup per CU at a time), few halo planes
   int64_t nchunk = ceil_div((int64_t)plan->num_cus * plan->tune.mv4_wg_per_cu, m->npi * m->npj);
@@ -1229,6 +1232,193 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
     KK_LAUNCH_CHECK();
   }
   return KKAMD_OK;
+}
+
+// ================================================================================================================
+// Rank 1 on the same analysis (knob march): the patch, the marching order and the X ring of the kernel above with 8-byte X
+// rows -- a plane of the patch with its halo is 1.6 KB, so four workgroups share a CU and occupancy, not a register pipeline,
+// hides the latency.  8 lanes per row pair; lane c multiplies entries c, c + 8, ... of both rows (their values come straight
+// from HBM into that lane: 64-byte pieces, no staging), the 8 partial sums meet in three xor-shuffles.  No column index is
+// read: values 8 B per nonzero, 8 B of row words per row, x once per patch plane.
+template <class OffT, class AT, bool BETA0>
+__global__ __launch_bounds__(kMv4Threads) void spmv_march1_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask,
+                                                                  const AT* __restrict__ values, Mv4Groups G, const double* __restrict__ x,
+                                                                  double* __restrict__ y, double alpha, double beta, int nx, int ny, int nz,
+                                                                  int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc) {
+  constexpr int RI = kMv4RI, RJ = kMv4RJ, W = RI + 2, SLABR = (RJ + 2) * W;
+  constexpr int AV = (kMv4MaxL + 7) / 8;
+  __shared__ double ring[4][SLABR];
+  __shared__ int ent_s[kMv4MaxL];
+  const int t = threadIdx.x, rs = t >> 3, line = rs / RI, ii = rs % RI, c = t & 7;
+  const int64_t b = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t npatch = npi * npj;
+  const int64_t ch = b / npatch, p = b % npatch;
+  const int i0 = (int)(p % npi) * RI, j0 = (int)(p / npi) * RJ;
+  const int kbeg = (int)ch * kc, kend = (kbeg + kc < nz) ? kbeg + kc : nz;
+  const int njj = (j0 + RJ <= ny) ? RJ : ny - j0;
+  KK_UNROLL
+  for (int q = 0; q < kMv4MaxL; ++q) if (t == q) ent_s[q] = G.ent[q];
+  bool lane_ok[2];
+  int64_t r0[2];
+  KK_UNROLL
+  for (int u = 0; u < 2; ++u) {
+    const int jj = 2 * line + u;
+    lane_ok[u] = jj < njj && i0 + ii < nx;
+    r0[u] = lane_ok[u] ? (int64_t)(j0 + jj) * S1 + i0 + ii : 0;
+  }
+  // this thread's point of a slab (threads below SLABR): clamped address, zero when it lies outside the lattice
+  const int xg = t < SLABR ? t : SLABR - 1;
+  const int xjr = j0 - 1 + xg / W, xir = i0 - 1 + xg % W;
+  const bool x_in = xjr >= 0 && xjr < ny && xir >= 0 && xir < nx;
+  const double* xpt = x + (int64_t)(xjr < 0 ? 0 : (xjr > ny - 1 ? ny - 1 : xjr)) * S1 + (xir < 0 ? 0 : (xir > nx - 1 ? nx - 1 : xir));
+  auto plane_clamped = [&](int kp) -> int64_t { return kp < 0 ? 0 : (kp > nz - 1 ? nz - 1 : kp); };
+  auto conforms = [&](int k, int u, OffT w) { return lane_ok[u] && k < kend && w >= 0; };
+  auto load_words = [&](int kp, OffT (&w)[2], uint32_t (&mk)[2]) {
+    const int64_t off = plane_clamped(kp) * S2;
+    KK_UNROLL
+    for (int u = 0; u < 2; ++u) { w[u] = arow[r0[u] + off]; mk[u] = amask[r0[u] + off]; }
+  };
+  auto put_slab = [&](int kp, double v) {               // into ring slot kp & 3; planes and points outside the lattice hold 0
+    if (t < SLABR && kp <= kend) ring[kp & 3][t] = (x_in && kp >= 0 && kp < nz) ? v : 0.0;
+  };
+  const uint32_t full = G.n >= 32 ? 0xffffffffu : ((1u << G.n) - 1u);
+  __syncthreads();
+  int qoff[AV], edk[AV], erel[AV];                     // this lane's entries c + 8 m: clamped index, plane selector, position relative to the row's point
+  KK_UNROLL
+  for (int m = 0; m < AV; ++m) {
+    qoff[m] = (c + 8 * m < G.n) ? c + 8 * m : G.n - 1;
+    const int e = ent_s[qoff[m]];
+    edk[m] = e & 3; erel[m] = e >> 2;
+  }
+  auto load_values = [&](int k, const OffT (&w)[2], const uint32_t (&mk)[2], AT (&ra)[2][AV]) {
+    KK_UNROLL
+    for (int u = 0; u < 2; ++u) {
+      const bool cf = conforms(k, u, w[u]);
+      const AT* vb = values + (cf ? (int64_t)w[u] : 0);
+      const bool part = cf && mk[u] != full;
+      if (!__any(part)) {
+        KK_UNROLL
+        for (int m = 0; m < AV; ++m) ra[u][m] = vb[qoff[m]];
+      } else {
+        const uint32_t mask = cf ? mk[u] : 1u;
+        KK_UNROLL
+        for (int m = 0; m < AV; ++m) {
+          const int q = c + 8 * m;
+          ra[u][m] = vb[((mask >> q) & 1u) ? __popc(mask & ((1u << q) - 1u)) : 0];
+        }
+      }
+    }
+  };
+  // Three register sets in rotation (the plane loop is unrolled by three so that every index is static): at the top of plane k
+  // the values of plane k + 2, the row words of plane k + 3 and the x plane k + 3 are requested; what plane k computes with was
+  // requested two planes ago.  Row words are moved from their stage into the set of their plane one plane after their load.
+  OffT w[3][2], w_stage[2];
+  uint32_t mk[3][2], m_stage[2];
+  AT ra[3][2][AV];
+  double xs[3];
+  load_words(kbeg, w[0], mk[0]); load_words(kbeg + 1, w[1], mk[1]); load_words(kbeg + 2, w_stage, m_stage);
+  load_values(kbeg, w[0], mk[0], ra[0]);
+  load_values(kbeg + 1, w[1], mk[1], ra[1]);
+  for (int kp = kbeg - 1; kp <= kbeg + 1; ++kp) put_slab(kp, xpt[plane_clamped(kp) * S2]);
+  xs[2] = xpt[plane_clamped(kbeg + 2) * S2];            // set 2 plays "requested in plane kbeg - 1"
+  __syncthreads();
+  for (int kk = kbeg; kk < kend; kk += 3) {
+    KK_UNROLL
+    for (int P = 0; P < 3; ++P) {
+      const int k = kk + P;
+      if (k >= kend) break;
+      constexpr int dummy = 0; (void)dummy;
+      const int N2 = (P + 2) % 3;                      // the set of plane k + 2 (it held plane k - 1)
+      KK_UNROLL
+      for (int u = 0; u < 2; ++u) { w[N2][u] = w_stage[u]; mk[N2][u] = m_stage[u]; }
+      load_words(k + 3, w_stage, m_stage);
+      xs[P] = xpt[plane_clamped(k + 3) * S2];
+      load_values(k + 2, w[N2], mk[N2], ra[N2]);
+      double acc[2] = {0.0, 0.0};
+      KK_UNROLL
+      for (int u = 0; u < 2; ++u) {
+        if (conforms(k, u, w[P][u])) {
+          const int own = (2 * line + u + 1) * W + ii + 1;
+          KK_UNROLL
+          for (int m = 0; m < AV; ++m) {
+            const int q = c + 8 * m;
+            if (q < G.n && ((mk[P][u] >> q) & 1u)) acc[u] = __builtin_fma((double)ra[P][u][m], ring[(k + edk[m] - 1) & 3][own + erel[m]], acc[u]);
+          }
+        }
+      }
+      KK_UNROLL
+      for (int u = 0; u < 2; ++u) {
+        acc[u] += __shfl_xor(acc[u], 1, 64);
+        acc[u] += __shfl_xor(acc[u], 2, 64);
+        acc[u] += __shfl_xor(acc[u], 4, 64);
+      }
+      put_slab(k + 2, xs[N2]);                          // requested in plane k - 1; its slot held plane k - 2, read for the last time before the previous barrier
+      // lane 0 of a pair writes its first row, lane 1 the second: the wave's 8 pairs are neighbours in i, 64 contiguous bytes each
+      if (c < 2) {
+        const OffT wu = c == 0 ? w[P][0] : w[P][1];
+        if (conforms(k, c, wu)) {
+          double* yp = y + (c == 0 ? r0[0] : r0[1]) + (int64_t)k * S2;
+          const double sres = alpha * (c == 0 ? acc[0] : acc[1]);
+          *yp = BETA0 ? sres : beta * (*yp) + sres;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// rows outside the stencil pattern, rank 1: 16 lanes per row
+template <class OffT, class AT>
+__global__ __launch_bounds__(kBlock) void march1_rows_kernel(int64_t n_list, const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
+                                                             const int32_t* __restrict__ entries, const AT* __restrict__ values,
+                                                             const double* __restrict__ x, double* __restrict__ y, double alpha, double beta) {
+  int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
+  const int j = threadIdx.x & 15;
+  const bool live = idx < n_list;
+  if (!live) idx = n_list - 1;
+  const int64_t r = list[idx];
+  double acc = 0.0;
+  for (int64_t a = (int64_t)row_map[r] + j; a < (int64_t)row_map[r + 1]; a += 16) acc += (double)values[a] * x[entries[a]];
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+  if (live && j == 0) y[r] = (beta == 0.0) ? alpha * acc : beta * y[r] + alpha * acc;
+}
+
+template <class OffT, class AT>
+static int march1_launch(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* x, double* y, double alpha, double beta, hipStream_t st) {
+  kkamd_mv4_plan* m = plan->mv4;
+  if (m->kc1 != plan->tune.march_planes || m->nchunk1 == 0) {       // the k-chunks of this kernel: about march_planes planes each
+    int kc1 = plan->tune.march_planes < m->nz ? plan->tune.march_planes : m->nz;
+    m->nchunk1 = ceil_div((int64_t)m->nz, (int64_t)kc1);
+    m->kc1 = plan->tune.march_planes;
+    m->kc1_planes = (int)ceil_div((int64_t)m->nz, m->nchunk1);
+  }
+  const unsigned grid = (unsigned)(m->npi * m->npj * m->nchunk1);
+  if (beta == 0.0)
+    KK_LAUNCH((spmv_march1_kernel<OffT, AT, true>), grid, kMv4Threads, 0, st, (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values,
+              m->grp, x, y, alpha, beta, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc1_planes);
+  else
+    KK_LAUNCH((spmv_march1_kernel<OffT, AT, false>), grid, kMv4Threads, 0, st, (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values,
+              m->grp, x, y, alpha, beta, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc1_planes);
+  KK_LAUNCH_CHECK();
+  if (m->n_nc > 0) {
+    KK_LAUNCH((march1_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, x, y, alpha, beta);
+    KK_LAUNCH_CHECK();
+  }
+  return KKAMD_OK;
+}
+
+int march_spmv(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* x, double* y, double alpha, double beta, hipStream_t st, int* ran) {
+  *ran = 0;
+  if (!plan->mv4 && !plan->mv4_tried) {
+    const int rc = A->offset_type == KKAMD_I64 ? mv4_plan_build<int64_t>(plan, A, st) : mv4_plan_build<int32_t>(plan, A, st);
+    if (rc) return rc;
+  }
+  if (!plan->mv4) return KKAMD_OK;
+  *ran = 1;
+  if (A->offset_type == KKAMD_I64)
+    return A->value_type == KKAMD_F64 ? march1_launch<int64_t, double>(plan, A, x, y, alpha, beta, st) : march1_launch<int64_t, float>(plan, A, x, y, alpha, beta, st);
+  return A->value_type == KKAMD_F64 ? march1_launch<int32_t, double>(plan, A, x, y, alpha, beta, st) : march1_launch<int32_t, float>(plan, A, x, y, alpha, beta, st);
 }
 
 template <class OffT, class AT, class YT>

@@ -35,6 +35,8 @@ struct SpmvTuning {
   int mv_strip_l2_kb  = 2500;  // ... and are sized so that three periods' worth of a strip's X rows stay below this
   int mv_glds        = 1;  // rank-2 LDS-staged kernel: X window through global_load_lds (1) or through registers (0)
   int mv4_wg_per_cu  = 8;  // rank-2 plane-marching kernel: workgroups per CU the k-chunking aims for (one is resident at a time)
+  int march          = 0;  // rank 1 on the plane-marching analysis (lattice stencils, fp64 vectors): 0 off, 1 on
+  int march_planes   = 20; // ... planes a workgroup marches (its k-chunk)
   int explicit_transpose = 1;   // modes T/H with an analysed handle: 1 = cache A^T in the plan (when it fits an eighth of free HBM), move the
                                 // values that changed since the last call into it and run the N kernel on it; 2 = same, the caller promises
                                 // constant values (no comparison); 0 = the reference's atomic scatter
@@ -124,6 +126,8 @@ int64_t mv_plan_query(const kkamd_mv_plan* mv, int what);   // 0 tiles, 1 patter
 void mv4_plan_destroy(kkamd_mv4_plan* p);
 int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what);  // 0 workgroups, 1 rows outside the stencil, 2 stencil entries, 3 bytes, 4 near stride
 int  release_transient();
+// rank 1 on the rank-2 plane-marching analysis (kk_spmv_mv.hip): builds the analysis on first use; returns 1 when it ran
+int  march_spmv(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* x, double* y, double alpha, double beta, hipStream_t st, int* ran);
 
 // native 2-element vectors (accepted by __builtin_nontemporal_load; same syntax under clang and gcc)
 typedef double kk_f64x2 __attribute__((vector_size(16)));

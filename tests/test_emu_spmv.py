@@ -178,6 +178,27 @@ def test_mv4_plane_marching(be):
         assert h.query("mv4_workgroups") == 0
 
 
+def test_march_rank1(be):
+    # rank 1 on the plane-marching analysis (knob march): every lattice matrix of the rank-2 cases, alpha / beta, beta = 0 over
+    # NaNs, 64-bit offsets, fp32 values, k-chunks of 1 plane, a few planes, the whole lattice; mode T through the cached transpose
+    for ci, (name, A0, left) in enumerate(pc.mv4_cases()):
+        for alpha, beta, off, planes in ((1.0, 0.0, np.int32, 20), (1.5, -0.5, np.int64, 3), (2.0, 1.0, np.int32, 1000))[:3 if ci < 3 else 1]:
+            h = pc.check_spmv(be, A0, "N", alpha, beta, "SPMV_DEFAULT", nans=(beta == 0.0), offset_dtype=off, max_val=32.0,
+                              knobs={"march": 1, "march_planes": planes})
+            assert h.query("march_workgroups") > 0, name
+            if left is not None:
+                assert h.query("mv4_other_rows") == left, (name, h.query("mv4_other_rows"))
+    name, A0, _ = pc.mv4_cases()[0]
+    pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=32.0, knobs={"march": 1, "march_planes": 1})
+    pc.check_spmv(be, A0, "N", 1.0, 0.5, "SPMV_DEFAULT", max_val=32.0, knobs={"march": 1}, value_dtype=np.float32)
+    pc.check_spmv(be, A0, "T", 1.0, 0.0, "SPMV_DEFAULT", max_val=32.0, knobs={"march": 1})
+    # off by default; matrices that are not lattices keep the planned stream kernel
+    h = pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=32.0)
+    assert h.query("march_workgroups") == 0
+    h = pc.check_spmv(be, oracle.random_crs(5000, 5000, 9, variance=3, seed=5), "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"march": 1})
+    assert h.query("march_workgroups") == 0
+
+
 def test_xcd_group_orders(be):
     # grouped tile orders (xcd_remap / mv_remap = G): whole blocks of 8G tiles are permuted, the incomplete last block is not
     for nrows in (64 * 15 + 5, 64 * 16, 64 * 17 + 1, 64 * 130):

@@ -208,6 +208,19 @@ def test_mv4_plane_marching(be):
         assert h.query("mv4_workgroups") == 0
 
 
+def test_march_rank1(be):
+    # rank 1 on the plane-marching analysis (knob march, off by default): lattice matrices incl. boundary and broken rows
+    for name, A0, left in pc.mv4_cases() + [("27pt 160x120x12", oracle.laplace3d("FE", 160, 120, 12), None), ("7pt 70x50x90", oracle.laplace3d("FD", 70, 50, 90), None)]:
+        for alpha, beta, off, planes in ((1.0, 0.0, np.int32, 20), (1.5, -0.5, np.int64, 3), (2.0, 1.0, np.int32, 1000)):
+            h = pc.check_spmv(be, A0, "N", alpha, beta, "SPMV_DEFAULT", nans=(beta == 0.0), offset_dtype=off, max_val=32.0,
+                              knobs={"march": 1, "march_planes": planes})
+            assert h.query("march_workgroups") > 0, name
+    name, A0, _ = pc.mv4_cases()[0]
+    pc.check_spmv(be, A0, "N", 1.0, 0.5, "SPMV_DEFAULT", max_val=32.0, knobs={"march": 1}, value_dtype=np.float32)
+    h = pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=32.0)
+    assert h.query("march_workgroups") == 0
+
+
 def test_xcd_group_orders(be):
     # grouped tile orders (xcd_remap / mv_remap = G): whole blocks of 8G tiles are permuted, the incomplete last block is not
     for nrows in (64 * 255 + 5, 64 * 256, 64 * 257 + 1, 64 * 1030):
