@@ -142,7 +142,7 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *                       values (no comparison either); 0 the reference's atomic scatter.  From "explicit_transpose_min_knnz"
  *   SpMV, rank 2
  *     "mv_kernel"       0 auto (plane-marching kernel where it applies -- analysed plan, fp64 vectors, right-hand sides in
- *                       blocks of 16 (a remainder goes to the gather kernel), a matrix that verifies as a radius-1 lattice stencil --, else the wave-private gather
+ *                       blocks of 16 (a remainder: one more pass over the last 16 columns when beta = 0, else the gather kernel), a matrix that verifies as a radius-1 lattice stencil --, else the wave-private gather
  *                       kernel), 1 generic strided kernel, 2 wave-private gather kernel, 3 LDS-staged X tiles, 4 = 0
  *     "mv_order"        row-block order: 2 (default) strips from the far stride found in the matrix (falls back to "mv_remap"),
  *                       1 XCD-contiguous (LDS-staged kernel), 0 "mv_remap": 0 dispatch, 1 XCD-contiguous, 2^k grouped (default 16)

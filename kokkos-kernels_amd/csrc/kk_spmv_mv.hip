@@ -1458,7 +1458,10 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
             if (rc) return rc;
           }
           if (c0 == nvec) return KKAMD_OK;
-          // the last nvec % 16 columns: the kernels below (fewer than 16 columns never come back here)
+          // the last nvec % 16 columns.  beta = 0: one more pass over the LAST 16 columns (it recomputes what the previous pass
+          // wrote to the columns they share -- the same values); otherwise the kernels below (fewer than 16 columns never come back here)
+          if (beta_d == 0.0)
+            return launch_mv4<OffT, AT>(plan, A, (const double*)X + (nvec - 16) * xs1, xs0, xs1, (double*)Y + (nvec - 16) * ys1, ys0, ys1, (double)alpha, 0.0, st);
           return spmv_mv_typed<OffT, AT, YT>(plan, A, trans, alpha_d, X + c0 * xs1, xs0, xs1, beta_d, Y + c0 * ys1, ys0, ys1, nvec - c0, st);
         }
       }
