@@ -1327,7 +1327,6 @@ __global__ __launch_bounds__(kMv4Threads) void spmv_march1_kernel(const OffT* __
     for (int P = 0; P < 3; ++P) {
       const int k = kk + P;
       if (k >= kend) break;
-      constexpr int dummy = 0; (void)dummy;
       const int N2 = (P + 2) % 3;                      // the set of plane k + 2 (it held plane k - 1)
       KK_UNROLL
       for (int u = 0; u < 2; ++u) { w[N2][u] = w_stage[u]; mk[N2][u] = m_stage[u]; }
