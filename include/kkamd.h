@@ -242,20 +242,26 @@ int kkamd_spgemm_numeric(kkamd_spgemm_handle_t* handle, int64_t m, int64_t n, in
  * sparse/src/KokkosKernels_Handle.hpp:380-465).  Set before the phase they shape.
  *   "algorithm"            SPGEMMAlgorithm value: SPGEMM_KK (default) and its aliases KK_MEMORY / KK_SPEED / KK_MEMSPEED / KK_LP run the
  *                          LDS hash-accumulator numeric; SPGEMM_KK_DENSE runs the dense-accumulator numeric (impl_speed.hpp:28-150);
- *                          SPGEMM_DEBUG / SPGEMM_SERIAL (host-sequential) return KKAMD_ERR_UNSUPPORTED: the caller diverts to native
+ *                          SPGEMM_DEBUG / SPGEMM_SERIAL (host-sequential in the reference; every algorithm's C leaves the public
+ *                          spgemm_numeric sorted, numeric_spec.hpp:138-140, so their C is everybody's C) run the hash algorithm
  *   "accumulator"          SPGEMMAccumulator: 1 = dense (same as SPGEMM_KK_DENSE), 0 / 2 = hash
  *   "compression"          B compression for the symbolic phase (impl_compression.hpp): 0 off (default), 1 keep when it pays, 2 always
  *   "compression_cut_off"  keep the compressed B when it leaves at most this share of the symbolic work (default 0.85)
  *   "verbose"              1: chosen algorithm, row bins, kernels and compression decision on stdout (KOKKOSKERNELS_VERBOSE)
- *   "sort_option"          rows of C always leave column-sorted; asking for unsorted output (0) returns KKAMD_ERR_UNSUPPORTED
- * Team / vector / shared-memory sizes and hash-scale knobs of the reference's kernels ("team_work_size", "shmem_size",
- * "suggested_team_size", "suggested_vector_size", "dynamic_scheduling", "min_hash_size_scale", "first_level_hash_cut_off") have no
- * counterpart: KKAMD_ERR_UNSUPPORTED, never silently accepted. */
+ * Hints -- accepted, recorded, reported under "verbose", without effect, exactly as the reference's rocSPARSE / cuSPARSE paths treat
+ * them (the reference's driver and unit tests set them before every spgemm: perf_test/sparse/KokkosSparse_spgemm.cpp:311-317,378-399,
+ * sparse/unit_test/Test_Sparse_spgemm.hpp:91-92): "team_work_size", "shmem_size", "suggested_team_size", "suggested_vector_size",
+ * "dynamic_scheduling", "min_hash_size_scale", "first_level_hash_cut_off", "mkl_sort_option", "mkl_keep_output",
+ * "mkl_convert_to_1base", "multi_color_scale", "read_write_cost_calc", "compression_steps", "max_col_dense_acc", "sort_option"
+ * (rows of C always leave column-sorted).  Any other key: KKAMD_ERR_INVALID_ARG. */
 int kkamd_spgemm_set(kkamd_spgemm_handle_t* handle, const char* key, double value);
 /* what: 0 c_nnz, 1 total multiplications (the reference's original_overall_flops / 2),
  * 2 max row flops, 3 max nnz in a row of C, 4 symbolic called, 5 numeric called, 6 B was compressed for the symbolic phase,
- * 7 symbolic insertions after compression, 8 numeric algorithm in use (0 hash, 1 dense accumulator). */
+ * 7 symbolic insertions after compression, 8 numeric algorithm in use (0 hash, 1 dense accumulator), 9 the SPGEMMAlgorithm value the
+ * caller set (4 = SPGEMM_DEFAULT until then), 10 number of distinct hints recorded. */
 int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);
+/* the recorded value of a hint key (the reference's get_* of the same setter); KKAMD_ERR_INVALID_ARG when the key was never set */
+int kkamd_spgemm_get_hint(kkamd_spgemm_handle_t* handle, const char* key, double* value);
 
 /* ------------------------------------------------------------------------------------------------
  * Helpers either side of the path (KokkosSparse::sort_crs_matrix, sparse/src/KokkosSparse_SortCrs.hpp:43-120;

@@ -75,9 +75,14 @@ static int rccl_exchange(void* ctx, int nsend, const void* const* d_send, const 
                          void* const* d_recv, const int64_t* recv_bytes, const int* recv_peer, kkamd_stream_t stream) {
   RcclCtx* c = static_cast<RcclCtx*>(ctx);
   KK_NCCL(rccl().GroupStart());
-  for (int i = 0; i < nsend; ++i) KK_NCCL(rccl().Send(d_send[i], (size_t)send_bytes[i], kNcclInt8, send_peer[i], c->comm, to_hip(stream)));
-  for (int i = 0; i < nrecv; ++i) KK_NCCL(rccl().Recv(d_recv[i], (size_t)recv_bytes[i], kNcclInt8, recv_peer[i], c->comm, to_hip(stream)));
-  KK_NCCL(rccl().GroupEnd());
+  // once the group is open it is always closed: a thread that returns between GroupStart and GroupEnd leaves RCCL's
+  // per-thread group depth at one and every later collective of the process (torch's too) queues behind it for ever
+  int first = 0; const char* what = "";
+  for (int i = 0; i < nsend && !first; ++i) { first = rccl().Send(d_send[i], (size_t)send_bytes[i], kNcclInt8, send_peer[i], c->comm, to_hip(stream)); what = "ncclSend"; }
+  for (int i = 0; i < nrecv && !first; ++i) { first = rccl().Recv(d_recv[i], (size_t)recv_bytes[i], kNcclInt8, recv_peer[i], c->comm, to_hip(stream)); what = "ncclRecv"; }
+  const int end = rccl().GroupEnd();
+  if (first) return kk::fail(KKAMD_ERR_HIP, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(first) : "?");
+  if (end) return kk::fail(KKAMD_ERR_HIP, "ncclGroupEnd failed: %s", rccl().GetErrorString ? rccl().GetErrorString(end) : "?");
   return KKAMD_OK;
 }
 
@@ -353,6 +358,9 @@ int kkamd_dist_spmv_query(const kkamd_dist_spmv_t* op, const char* key, int64_t*
 int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_shard, double beta, void* d_y_shard, int what,
                           kkamd_stream_t stream) {
   if (!op) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_apply: null operator");
+  if (what < 0 || what > 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_apply: what = %d is not 0 (exchange + SpMV), 1 (exchange) or 2 (SpMV)", what);
+  if (what != 1 && !d_y_shard && op->offsets[op->rank + 1] > op->offsets[op->rank])
+    return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_apply: null y shard");
   hipStream_t st = kk::to_hip(stream);
   const int vt = op->elem == 8 ? KKAMD_F64 : KKAMD_F32;
   const int64_t me0 = op->offsets[op->rank], mrows = op->offsets[op->rank + 1] - me0;

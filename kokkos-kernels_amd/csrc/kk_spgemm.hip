@@ -36,6 +36,7 @@
 #include "kk_common.h"
 #include "kk_scan.h"
 #include <climits>
+#include <map>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -1172,6 +1173,8 @@ struct kkamd_spgemm_handle {
                                    // 64 % of the insertions -- the phase is not insertion-bound here), 1 compress and keep it if it pays, 2 always keep it
   double compression_cutoff = 0.85;  // kept when compressed work <= cutoff * original work (impl_compression.hpp:718)
   int verbose = 0;
+  int requested_algorithm = 4;     // the SPGEMMAlgorithm the caller named (SPGEMM_DEFAULT until set)
+  std::map<std::string, double> hints;   // accepted-and-ignored tuning hints of the reference, by key
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -1611,13 +1614,15 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* h, const char* key, double value) {
     // SPGEMMAlgorithm (sparse/src/KokkosSparse_spgemm_handle.hpp:44-93): 0 KK, 1 KK_DENSE, 2 KK_MEMORY, 3 KK_LP, 4 DEFAULT, 5 DEBUG,
     // 6 SERIAL, 7 KK_SPEED, 8 KK_MEMSPEED
     const int a = (int)value;
-    if (a == 5 || a == 6)
-      return kk::fail(KKAMD_ERR_UNSUPPORTED, "SPGEMM_DEBUG / SPGEMM_SERIAL are the reference's host-sequential algorithms: no device implementation here "
-                                             "(the caller diverts to the native path)");
     if (a < 0 || a > 8) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: unknown SPGEMMAlgorithm %d", a);
-    const int alg = (a == 1) ? 1 : 0;                             // KK_MEMORY / KK_SPEED / KK_MEMSPEED / KK_LP are variants of the hash algorithm
+    // KK_MEMORY / KK_SPEED / KK_MEMSPEED / KK_LP are variants of the hash algorithm.  SPGEMM_DEBUG / SPGEMM_SERIAL are the
+    // reference's host-sequential algorithms (spgemm_debug_symbolic / _numeric copy the device arrays to the host); the public
+    // spgemm_numeric sorts every algorithm's rows afterwards (sparse/impl/KokkosSparse_spgemm_numeric_spec.hpp:138-140), so
+    // their C is the C of every other algorithm: they run the device hash algorithm here, and say so under verbose.
+    const int alg = (a == 1) ? 1 : 0;
     if (alg != h->algorithm) h->numeric_bins_ready = false;
-    h->algorithm = alg;
+    h->algorithm = alg; h->requested_algorithm = a;
+    if (h->verbose && (a == 5 || a == 6)) printf("kkamd spgemm: %s requested: host-sequential in the reference, runs the LDS hash algorithm on the device here\n", a == 5 ? "SPGEMM_DEBUG" : "SPGEMM_SERIAL");
   } else if (k == "accumulator") {                               // SPGEMMAccumulator: 0 default, 1 dense, 2 sparse
     const int a = (int)value;
     if (a < 0 || a > 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: unknown SPGEMMAccumulator %d", a);
@@ -1631,16 +1636,29 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* h, const char* key, double value) {
     h->compression_cutoff = value;
   } else if (k == "verbose") {
     h->verbose = value != 0;
-  } else if (k == "sort_option") {
-    // the numeric kernels emit every row column-sorted (the reference's post-numeric sort is built in): nothing to switch
-    if ((int)value == 0) return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spgemm_set: unsorted output (sort_option 0) is not available: rows of C always leave sorted");
-  } else if (k == "team_work_size" || k == "shmem_size" || k == "suggested_team_size" || k == "suggested_vector_size" || k == "dynamic_scheduling" ||
-             k == "min_hash_size_scale" || k == "first_level_hash_cut_off" || k == "mkl_sort_option" || k == "multi_color_scale") {
-    return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spgemm_set: '%s' tunes Kokkos team launches / two-level hash tables of the reference's kernels and has no "
-                                           "counterpart here (LDS tables are sized from the row bins)", key);
+  } else if (k == "sort_option" || k == "team_work_size" || k == "shmem_size" || k == "suggested_team_size" || k == "suggested_vector_size" ||
+             k == "dynamic_scheduling" || k == "min_hash_size_scale" || k == "first_level_hash_cut_off" || k == "mkl_sort_option" ||
+             k == "mkl_keep_output" || k == "mkl_convert_to_1base" || k == "multi_color_scale" || k == "read_write_cost_calc" ||
+             k == "compression_steps" || k == "max_col_dense_acc") {
+    // Hints of the reference (sparse/src/KokkosKernels_Handle.hpp:380-465, KokkosSparse_spgemm_handle.hpp:295-317,684): they size Kokkos
+    // team launches, the two-level hash tables and the MKL path of the reference's kernels.  The reference's own TPL paths
+    // (rocSPARSE, cuSPARSE) take and ignore them, and its driver and unit tests set them before every spgemm
+    // (perf_test/sparse/KokkosSparse_spgemm.cpp:311-317,378-399, unit_test/Test_Sparse_spgemm.hpp:91-92): accepted, recorded
+    // (kkamd_spgemm_get_hint), reported under verbose, without effect -- LDS tables and launch shapes follow the row bins, and rows of C
+    // always leave sorted whatever sort_option says.
+    h->hints[k] = value;
+    if (h->verbose) printf("kkamd spgemm: hint %s = %g recorded (no effect on gfx950)\n", key, value);
   } else {
     return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: unknown key '%s'", key);
   }
+  return KKAMD_OK;
+}
+
+int kkamd_spgemm_get_hint(kkamd_spgemm_handle_t* h, const char* key, double* value) {
+  if (!h || !key || !value) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get_hint: null argument");
+  const auto it = h->hints.find(key);
+  if (it == h->hints.end()) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get_hint: '%s' was never set", key);
+  *value = it->second;
   return KKAMD_OK;
 }
 
@@ -1656,6 +1674,8 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 6: *value = h->compressed ? 1 : 0; break;
     case 7: *value = h->compressed_mults; break;
     case 8: *value = h->algorithm; break;
+    case 9: *value = h->requested_algorithm; break;
+    case 10: *value = (int64_t)h->hints.size(); break;
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
   return KKAMD_OK;

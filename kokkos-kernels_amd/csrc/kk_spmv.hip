@@ -872,6 +872,14 @@ __global__ void refresh_changed_kernel(const AT* __restrict__ val, AT* __restric
     if (!same_bits(v, shadow[i])) { shadow[i] = v; t_val[inv[i]] = v; }
   }
 }
+// the first refresh after the transpose was built moves every value: no bit pattern of the shadow stands for "never seen"
+template <class OffT, class AT>
+__global__ void refresh_all_kernel(const AT* __restrict__ val, AT* __restrict__ shadow, const OffT* __restrict__ inv, AT* __restrict__ t_val, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const AT v = val[i];
+    shadow[i] = v; t_val[inv[i]] = v;
+  }
+}
 // the cached transpose is a convenience, not a right: it is only built when it (and the 16 bytes per nonzero its construction
 // needs on top) fit an eighth of the HBM that is free at that moment
 template <class OffT, class AT>
@@ -915,7 +923,7 @@ static int ensure_transpose(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_
                            p->d_t_rm, p->d_t_ent, d_tmp, reinterpret_cast<kkamd_stream_t>(st));
   if (rc != KKAMD_OK) { fail_clean(); return rc; }
   KK_LAUNCH((invert_perm_kernel<OffT>), grid, kBlock, 0, st, (const double*)d_tmp, (OffT*)p->d_t_perm, A->nnz);     // d_t_perm: position of A's entry i in A^T
-  (void)hipMemsetAsync(p->d_t_shadow, 0xFF, sizeof(AT) * nnz, st);             // a NaN pattern no stored value compares equal to: the first call moves everything
+  p->t_shadow_valid = false;                                                   // the first refresh scatters every value (refresh_all_kernel)
   if (hipStreamSynchronize(st) != hipSuccess) return fail_clean();
   (void)hipFree(d_iota); (void)hipFree(d_tmp); d_iota = d_tmp = nullptr;
   kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, p->d_t_rm, p->d_t_ent, p->d_t_val, A->offset_type, A->value_type};
@@ -999,8 +1007,14 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
         transpose_fits<OffT, AT>(plan, A) && ensure_transpose<OffT, AT>(plan, A, st) == KKAMD_OK) {
       if (plan->tune.explicit_transpose != 2 || !plan->t_values_valid) {
         const unsigned grid = (unsigned)(ceil_div(A->nnz, kBlock) < 65536 ? ceil_div(A->nnz, kBlock) : 65536);
-        KK_LAUNCH((refresh_changed_kernel<OffT, AT>), grid, kBlock, 0, st, (const AT*)A->d_values, (AT*)plan->d_t_shadow, (const OffT*)plan->d_t_perm,
-                  (AT*)plan->d_t_val, A->nnz);
+        if (plan->t_shadow_valid) {
+          KK_LAUNCH((refresh_changed_kernel<OffT, AT>), grid, kBlock, 0, st, (const AT*)A->d_values, (AT*)plan->d_t_shadow, (const OffT*)plan->d_t_perm,
+                    (AT*)plan->d_t_val, A->nnz);
+        } else {
+          KK_LAUNCH((refresh_all_kernel<OffT, AT>), grid, kBlock, 0, st, (const AT*)A->d_values, (AT*)plan->d_t_shadow, (const OffT*)plan->d_t_perm,
+                    (AT*)plan->d_t_val, A->nnz);
+          plan->t_shadow_valid = true;
+        }
         plan->t_values_valid = true;
       }
       kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, plan->d_t_rm, plan->d_t_ent, plan->d_t_val, A->offset_type, A->value_type};
@@ -1048,7 +1062,7 @@ int check_crs(const kkamd_crs_t* A) {
 int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   if (!p) return KKAMD_OK;
   if (p->num_rows != A->num_rows || p->num_cols != A->num_cols || p->nnz != A->nnz || p->row_map != A->d_row_map ||
-      p->offset_type != A->offset_type || p->value_type != A->value_type || ((p->d_tinfo || p->mv) && p->entries != A->d_entries))
+      p->offset_type != A->offset_type || p->value_type != A->value_type || ((p->d_tinfo || p->mv || p->mv4 || p->t_ready) && p->entries != A->d_entries))
     return fail(KKAMD_ERR_STATE, "kkamd_spmv: plan was created for a different matrix (a handle is bound to one matrix)");
   return KKAMD_OK;
 }

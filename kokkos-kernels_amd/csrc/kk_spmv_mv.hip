@@ -1128,6 +1128,11 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
       const int64_t d = cols[q] - r, dk = mv4_round_div(d, S2), rem = d - dk * S2, dj = mv4_round_div(rem, cand), di = rem - dj * cand;
       okr = dk >= -1 && dk <= 1 && dj >= -1 && dj <= 1 && di >= -1 && di <= 1;
     }
+    // a row that stores one column twice (the reference sums duplicates) is no pattern: two of its entries would land in
+    // the same slot of the value buffer.  With a duplicate-free pattern the in-order match of mv4_verify_kernel sends
+    // every row that does hold a duplicate to the gather rows.
+    for (int q = 0; q < len && okr; ++q)
+      for (int p = 0; p < q && okr; ++p) okr = cols[p] != cols[q];
     if (!okr) continue;
     S1 = cand; offs.n = len;
     for (int q = 0; q < len; ++q) offs.e[q] = (int)(cols[q] - r);

@@ -98,7 +98,7 @@ struct kkamd_spmv_plan {
   // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
   void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr; void* d_t_shadow = nullptr;
   kkamd_spmv_plan* t_plan = nullptr;
-  bool t_ready = false, t_failed = false, t_values_valid = false;
+  bool t_ready = false, t_failed = false, t_values_valid = false, t_shadow_valid = false;
   bool win_failed = false;       // the codes are not worth it on this matrix (or HBM cannot hold them): plain entries
   // rank-2 analysis (LDS-staged X tiles), built by the first rank-2 call that can use it
   kkamd_mv_plan* mv = nullptr;

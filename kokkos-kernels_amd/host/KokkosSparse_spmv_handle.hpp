@@ -45,10 +45,15 @@ struct SPMVHandleImpl {
   SPMVAlgorithm get_algorithm() const { return algo; }
   const SPMVAlgorithm algo = SPMV_DEFAULT;
   kkamd_spmv_plan_t* plan  = nullptr;     // the reference's tpl_rank1 / tpl_rank2
-  // Expert knobs.  Of the reference's public members (:243-252) only vector_length has a meaning here: lanes per row of the
-  // no-analysis row kernel (knob "lanes_per_row"; -1 = automatic from nnz / row, like the reference).  team_size,
-  // rows_per_thread and force_static/dynamic_schedule describe Kokkos TeamPolicy / RangePolicy launches that do not exist
-  // in this implementation, so they are NOT declared: code that sets them fails to compile instead of being ignored.
+  // Expert knobs: the reference's public members (:243-252), assignable directly as there.  vector_length has a meaning
+  // here: lanes per row of the no-analysis row kernel (knob "lanes_per_row"; -1 = automatic from nnz / row, like the
+  // reference).  team_size, rows_per_thread and force_static / force_dynamic_schedule shape Kokkos TeamPolicy / RangePolicy
+  // launches of the reference's native kernels; a TPL path of the reference (rocSPARSE, cuSPARSE) never reads them, and
+  // neither do the gfx950 kernels: they are kept so that code which sets them compiles and runs unchanged.
+  int team_size               = -1;
+  int64_t rows_per_thread     = -1;
+  bool force_static_schedule  = false;
+  bool force_dynamic_schedule = false;
   int vector_length = -1;
   // any plan knob of include/kkamd.h by name (applied when the plan is created, or to the live plan)
   void set_knob(const char* key, int value) {

@@ -119,6 +119,29 @@ void test_all_interfaces() {
   KokkosSparse::spmv(&h2, "N", 2.0, A, X, 0.0, Y); Kokkos::fence(); check2();
   KokkosSparse::spmv(space, "N", 2.0, A, X, 0.0, Y); space.fence(); check2();
   KokkosSparse::spmv("N", 2.0, A, X, 0.0, Y); Kokkos::fence(); check2();
+  // a handle whose FIRST call is mode T gets its plan, and with it the cached transpose; the reference's
+  // public expert members are assignable (sparse/src/KokkosSparse_spmv_handle.hpp:243-252)
+  {
+    KokkosSparse::SPMVHandle<device, M, V1, V1> ht(KokkosSparse::SPMV_DEFAULT);
+    ht.team_size = 64; ht.vector_length = 8; ht.rows_per_thread = 4; ht.force_static_schedule = true; ht.force_dynamic_schedule = false;
+    ht.set_knob("explicit_transpose_min_knnz", 0);
+    V1 xt("xt", m), yt("yt", n);
+    std::vector<double> hxt(m), hyt(n, 0.0);
+    for (int i = 0; i < m; ++i) hxt[i] = (g() % 1000) / 1000.0;
+    for (int i = 0; i < m; ++i) for (int j = rm[i]; j < rm[i + 1]; ++j) hyt[ent[j]] += 2.0 * val[j] * hxt[i];
+    Kokkos::deep_copy(xt, Kokkos::View<double*, Kokkos::HostSpace>(hxt.data(), m));
+    for (int rep = 0; rep < 2; ++rep) {
+      Kokkos::deep_copy(yt, -7.0);
+      KokkosSparse::spmv(space, &ht, "T", 2.0, A, xt, 0.0, yt); space.fence();
+      auto h = Kokkos::create_mirror_view(yt); Kokkos::deep_copy(h, yt);
+      double e = 0; for (int i = 0; i < n; ++i) e = std::max(e, std::fabs(h(i) - hyt[i]));
+      EXPECT(e < 1e-12);
+    }
+    EXPECT(ht.plan != nullptr);
+    int64_t cached = 0;
+    if (ht.plan) KokkosSparse::Impl::kkamd_check(kkamd_spmv_plan_query(ht.plan, "transpose_cached", &cached));
+    EXPECT(cached == 1);
+  }
   // error behaviour: dimension mismatch and BSR-only algorithm on a CrsMatrix
   bool threw = false;
   try { V1 bad("bad", n + 1); KokkosSparse::spmv("N", 1.0, A, bad, 0.0, y1); } catch (const std::runtime_error& e) { threw = std::string(e.what()).find("Dimensions do not match") != std::string::npos; }
@@ -197,17 +220,74 @@ void test_spgemm() {
   kh3.get_spgemm_handle()->set_compression(false);
   KokkosSparse::spgemm_numeric(kh3, A, false, B, false, C3);
   compare(C3);
+  // The reference driver's own call sequence, unchanged (perf_test/sparse/KokkosSparse_spgemm.cpp:310-317,345-352,377-399) with its
+  // default parameters (perf_test/sparse/KokkosSparse_spgemm.cpp parameters: chunk 16, shmem 16128, team / vector -1): hints are
+  // accepted and remembered, SPGEMM_SERIAL (its check_output path) gives the same C
+  {
+    const int chunk_size = 16, shmemsize = 16128, team_size = -1, vector_size = -1, use_dynamic_scheduling = 1, verbose = 0;
+    KH drv;
+    drv.set_team_work_size(chunk_size);
+    drv.set_shmem_size(shmemsize);
+    drv.set_suggested_team_size(team_size);
+    drv.set_suggested_vector_size(vector_size);
+    if (use_dynamic_scheduling) drv.set_dynamic_scheduling(true);
+    if (verbose) drv.set_verbose(true);
+    EXPECT(drv.get_set_team_work_size() == 16 && drv.get_shmem_size() == 16128 && drv.is_dynamic_scheduling());
+    EXPECT(drv.get_team_work_size(256, 0, 0) == 16);
+    KH seq;
+    seq.set_team_work_size(chunk_size); seq.set_shmem_size(shmemsize); seq.set_suggested_team_size(team_size);
+    seq.create_spgemm_handle(KokkosSparse::SPGEMM_SERIAL);
+    if (use_dynamic_scheduling) seq.set_dynamic_scheduling(true);
+    M Cref;
+    KokkosSparse::spgemm_symbolic(seq, A, false, B, false, Cref);
+    KokkosSparse::spgemm_numeric(seq, A, false, B, false, Cref);
+    compare(Cref);
+    for (int algorithm : {(int)KokkosSparse::SPGEMM_KK, (int)KokkosSparse::SPGEMM_KK_MEMORY, (int)KokkosSparse::SPGEMM_DEBUG}) {
+      drv.create_spgemm_handle(KokkosSparse::SPGEMMAlgorithm(algorithm));
+      drv.get_spgemm_handle()->mkl_keep_output = true;
+      drv.get_spgemm_handle()->set_mkl_sort_option(7);
+      drv.get_spgemm_handle()->mkl_convert_to_1base = true;
+      drv.get_spgemm_handle()->MaxColDenseAcc = 250000;
+      drv.get_spgemm_handle()->set_read_write_cost_calc(false);
+      drv.get_spgemm_handle()->set_compression_steps(true);
+      drv.get_spgemm_handle()->set_min_hash_size_scale(1);
+      drv.get_spgemm_handle()->set_first_level_hash_cut_off(0.5);
+      drv.get_spgemm_handle()->set_compression_cut_off(0.85);
+      EXPECT(drv.get_spgemm_handle()->get_min_hash_size_scale() == 1 && drv.get_spgemm_handle()->get_first_level_hash_cut_off() == 0.5);
+      EXPECT(drv.get_spgemm_handle()->get_algorithm_type() == KokkosSparse::SPGEMMAlgorithm(algorithm));
+      // view-level calls with the driver's own allocation order (:393-414)
+      typedef typename M::values_type::non_const_type scalar_view_t;
+      typedef typename M::row_map_type::non_const_type lno_view_t;
+      typedef typename M::index_type::non_const_type lno_nnz_view_t;
+      lno_view_t row_mapC("non_const_lnow_row", m + 1);
+      lno_nnz_view_t entriesC("entriesC (empty)", 0);
+      scalar_view_t valuesC("valuesC (empty)", 0);
+      KokkosSparse::spgemm_symbolic(&drv, m, n, k, A.graph.row_map, A.graph.entries, false, B.graph.row_map, B.graph.entries, false, row_mapC);
+      Kokkos::HIP().fence();
+      size_type c_nnz_size = drv.get_spgemm_handle()->get_c_nnz();
+      EXPECT((size_t)c_nnz_size == (size_t)Cref.nnz());
+      if (c_nnz_size) {
+        entriesC = lno_nnz_view_t(Kokkos::view_alloc(Kokkos::WithoutInitializing, "entriesC"), c_nnz_size);
+        valuesC  = scalar_view_t(Kokkos::view_alloc(Kokkos::WithoutInitializing, "valuesC"), c_nnz_size);
+      }
+      KokkosSparse::spgemm_numeric(&drv, m, n, k, A.graph.row_map, A.graph.entries, A.values, false, B.graph.row_map, B.graph.entries, B.values,
+                                   false, row_mapC, entriesC, valuesC);
+      Kokkos::HIP().fence();
+      M Cd("CrsMatrixC", m, k, valuesC.extent(0), valuesC, row_mapC, entriesC);
+      compare(Cd);
+    }
+    // the unit test's sequence (sparse/unit_test/Test_Sparse_spgemm.hpp:90-99)
+    KH ut; ut.set_team_work_size(16); ut.set_dynamic_scheduling(true);
+    ut.create_spgemm_handle(KokkosSparse::SPGEMM_KK);
+    M Cu;
+    KokkosSparse::spgemm_symbolic(ut, A, false, B, false, Cu);
+    KokkosSparse::spgemm_numeric(ut, A, false, B, false, Cu);
+    compare(Cu);
+  }
+  // an unknown option still fails loudly
   auto throws = [&](auto&& fn) { bool t = false; try { fn(); } catch (const std::runtime_error&) { t = true; } return t; };
-  EXPECT(throws([&] { kh3.set_shmem_size(16128); }));
-  EXPECT(throws([&] { kh3.set_team_work_size(16); }));
-  EXPECT(throws([&] { kh3.set_suggested_team_size(64); }));
-  EXPECT(throws([&] { kh3.set_suggested_vector_size(8); }));
-  EXPECT(throws([&] { kh3.set_dynamic_scheduling(true); }));
-  EXPECT(throws([&] { kh3.get_spgemm_handle()->set_min_hash_size_scale(2); }));
-  EXPECT(throws([&] { kh3.get_spgemm_handle()->set_first_level_hash_cut_off(0.5); }));
-  EXPECT(throws([&] { kh3.get_spgemm_handle()->set_sort_option(0); }));
-  EXPECT(throws([&] { KH k4; k4.create_spgemm_handle(KokkosSparse::SPGEMM_DEBUG); }));
-  EXPECT(throws([&] { KH k4; k4.create_spgemm_handle(KokkosSparse::SPGEMM_SERIAL); }));
+  EXPECT(throws([&] { kh3.get_spgemm_handle()->set("no_such_option", 1.0); }));
+  kh3.get_spgemm_handle()->set_sort_option(0);
   kh3.get_spgemm_handle()->set_sort_option(1);
 }
 

@@ -248,8 +248,14 @@ class _SpgemmHandle:
 
     def set(self, key, value):
         """SPGEMMHandle / KokkosKernelsHandle option setters (kkamd_spgemm_set): "algorithm", "accumulator", "compression",
-        "compression_cut_off", "verbose", "sort_option"; the reference's team / shared-memory knobs raise KkamdError(UNSUPPORTED)"""
+        "compression_cut_off", "verbose" act; the reference's team / shared-memory / hash-scale hints are accepted and recorded
+        (get_hint), without effect; unknown keys raise KkamdError(INVALID_ARG)"""
         check(self.backend.lib, self.backend.lib.kkamd_spgemm_set(self.h, key.encode(), float(value)))
+
+    def get_hint(self, key):
+        v = C.c_double()
+        check(self.backend.lib, self.backend.lib.kkamd_spgemm_get_hint(self.h, key.encode(), C.byref(v)))
+        return float(v.value)
 
     def get_c_nnz(self): return self.get(0)
     def is_symbolic_called(self): return bool(self.get(4))

@@ -390,6 +390,16 @@ def spgemm_kkmem_omp(A, B, sort=True, timings=None):
     return Cm
 
 
+def spgemm_symbolic_kkmem_omp(A, B):
+    """row_map of C = A*B by the OpenMP port of the KKMEM symbolic kernel alone (counts, no entries): what the full-size
+    SpGEMM test compares against where the host cannot hold C itself"""
+    rmC = np.zeros(A.nrows + 1, dtype=np.int64)
+    nnz = lib().kko_spgemm_kkmem_omp(C.c_int(0), C.c_int32(A.nrows), C.c_int32(A.ncols), C.c_int32(B.ncols), _p(A.row_map), _p(A.entries), None,
+                                     _p(B.row_map), _p(B.entries), None, _p(rmC), None, None)
+    assert nnz >= 0 and nnz == rmC[-1]
+    return rmC
+
+
 def spmv_mv_omp(row_map_i32, entries, values, alpha, X, beta, Y):
     e = 8
     lib().kko_spmv_mv_omp_i32(_i64(len(row_map_i32) - 1), _i64(X.shape[1]), _p(row_map_i32), _p(entries), _p(values),

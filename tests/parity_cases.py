@@ -372,6 +372,24 @@ def mv4_cases():
     return out
 
 
+def mv4_duplicate_cases():
+    """(name, matrix, plane-marching plan expected, rows it must leave to the gather kernel) -- lattice stencils whose rows store
+    a column twice (the reference adds duplicates up: spmv_impl.hpp:240-303 walks entries, not columns).  A pattern row with a
+    duplicate would put two values into one slot of the value buffer: such rows are never the pattern and never conform."""
+    base = [c for c in mv4_cases() if c[0] == "7pt clean 33x6x21"][0][1]
+    def dup_diag(rows_with_dup):
+        rm = base.row_map.astype(np.int64); ent = base.entries; val = base.values
+        r_of = np.repeat(np.arange(base.nrows), np.diff(rm))
+        diag_at = np.flatnonzero(ent == r_of)
+        pick = diag_at[rows_with_dup]
+        ent2 = np.insert(ent, pick, ent[pick]); val2 = np.insert(val, pick, 0.375 + 0.001 * np.arange(pick.size))
+        add = np.zeros(base.nrows + 1, dtype=np.int64); add[np.asarray(rows_with_dup) + 1] = 1
+        return oracle.Crs(base.nrows, base.ncols, rm + np.cumsum(add), ent2.astype(np.int32), val2)
+    some = np.arange(7, base.nrows, 83)
+    return [("7pt, diagonal stored twice in every row", dup_diag(np.arange(base.nrows)), False, 0),
+            ("7pt, diagonal stored twice in %d rows" % some.size, dup_diag(some), True, int(some.size))]
+
+
 def mv3_cases():
     """(name, matrix, staged tiles expected) for the LDS-staged rank-2 kernel"""
     out = [("27pt", oracle.laplace3d("FE", 37, 11, 9), True), ("7pt", oracle.laplace3d("FD", 50, 12, 7), True),

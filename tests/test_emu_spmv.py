@@ -178,6 +178,19 @@ def test_mv4_plane_marching(be):
         assert h.query("mv4_workgroups") == 0
 
 
+def test_mv4_duplicate_entries(be):
+    # a lattice row that stores one column twice must never become the plane-marching pattern, and a row
+    # with a duplicate must go to the gather rows (the reference sums duplicates); rank 2 and the rank-1 marching kernel
+    for name, A0, planned, left in pc.mv4_duplicate_cases():
+        for knobs in (None, {"mv_kernel": 4}):
+            h = pc.check_spmv_mv(be, A0, 16, "N", 1.5, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs=knobs, max_val=32.0, nans=True)
+            assert (h.query("mv4_workgroups") > 0) == planned, (name, knobs)
+            if planned:
+                assert h.query("mv4_other_rows") == left, (name, h.query("mv4_other_rows"))
+        h = pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, max_val=32.0, knobs={"march": 1})
+        assert (h.query("march_workgroups") > 0) == planned, name
+
+
 def test_march_rank1(be):
     # rank 1 on the plane-marching analysis (knob march): every lattice matrix of the rank-2 cases, alpha / beta, beta = 0 over
     # NaNs, 64-bit offsets, fp32 values, k-chunks of 1 plane, a few planes, the whole lattice; mode T through the cached transpose

@@ -135,6 +135,61 @@ def test_spgemm_rmat_against_oracle(be):
     print("spgemm R-MAT scale %d: nnz(C) %d identical structure, max rel value error %.2e" % (scale, G.nnz, worst))
 
 
+def test_spgemm_rmat_s20_without_a_host_copy_of_c(be):
+    """The largest single-GPU member of BASELINE config 4 (R-MAT scale 20, edge factor 16: nnz(C) = 9.69e9, 116 GB -- no host
+    copy of C is possible).  Checked through what does not need one: (1) row_map of C bit-exact against the OpenMP KKMEM
+    symbolic kernel of the oracle (counts only); (2) every row of C strictly ascending in its columns, all inside [0, k) -- with
+    (1), each row holds exactly as many DISTINCT columns as the reference's; (3) C x == A (A x) for a positive x, C x on the
+    device, A (A x) by the host oracle SpMV -- ties every value to its column; (4) numeric again on the same handle with new
+    values of A (the reference's reuse case, Test_Sparse_spgemm.hpp:243-252): entries(C) untouched, C' x == A' (A x)."""
+    import torch
+    if torch.cuda.mem_get_info()[0] < 200 * 2**30:
+        pytest.skip("needs 200 GB of free HBM")
+    R = oracle.rmat(20, 16)
+    A = pc.dev(be, R, offset_dtype=np.int64)
+    kh = pc.kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+    Cd = pc.kk.spgemm_symbolic(kh, A, False, A, False)
+    rm_gold = oracle.spgemm_symbolic_kkmem_omp(R, R)
+    assert Cd.nnz() == int(rm_gold[-1]), (Cd.nnz(), int(rm_gold[-1]))
+    assert torch.equal(Cd.graph.row_map.cpu(), torch.from_numpy(rm_gold)), "row_map differs from the KKMEM symbolic kernel's"
+    pc.kk.spgemm_numeric(kh, A, False, A, False, Cd)
+    ent, rm = Cd.graph.entries, Cd.graph.row_map
+    nnz = Cd.nnz()
+    starts = torch.zeros(nnz + 1, dtype=torch.bool, device="cuda")
+    starts[rm] = True                                                        # entry j starts a row (empty rows mark the same place twice)
+    lo = int(ent.min().item()); hi = int(ent.max().item())
+    assert lo >= 0 and hi < R.ncols, (lo, hi)
+    step = 1 << 28
+    for s in range(0, nnz - 1, step):                                        # chunked: no 40-GB temporaries
+        e = min(nnz - 1, s + step)
+        asc = (ent[s + 1:e + 1] > ent[s:e]) | starts[s + 1:e + 1]
+        assert bool(asc.all().item()), "a row of C is not strictly ascending near entry %d" % s
+    del starts
+    rng = np.random.default_rng(20)
+    x = 0.5 + rng.random(R.ncols)
+    xd = torch.from_numpy(x).cuda()
+
+    def check(Rh, tag):
+        ax = oracle.spmv_omp(R.row_map, R.entries, R.values, 1.0, x, 0.0, np.zeros(R.nrows))          # B = A keeps its values
+        gold = oracle.spmv_omp(Rh.row_map, Rh.entries, Rh.values, 1.0, ax, 0.0, np.zeros(R.nrows))
+        yd = torch.full((R.nrows,), float("nan"), dtype=torch.float64, device="cuda")
+        pc.kk.spmv("N", 1.0, Cd, xd, 0.0, yd)
+        got = yd.cpu().numpy()
+        den = np.abs(gold) + np.abs(got)
+        rel = float((np.abs(got - gold) / np.where(den > 0, den, 1.0)).max())
+        assert rel <= 1e-12, "%s: C x differs from A (A x): max rel %g" % (tag, rel)             # all terms positive: no cancellation
+        return rel
+    rel1 = check(R, "numeric")
+    ent_sum = int(ent[::1009].to(torch.int64).sum().item())
+    R2 = oracle.Crs(R.nrows, R.ncols, R.row_map, R.entries, 1.0 + 49.0 * rng.random(R.nnz))
+    A2 = pc.kk.CrsMatrix(R.nrows, R.ncols, A.graph.row_map, A.graph.entries, torch.from_numpy(R2.values).cuda(), backend=be)
+    pc.kk.spgemm_numeric(kh, A2, False, A, False, Cd)
+    assert int(Cd.graph.entries[::1009].to(torch.int64).sum().item()) == ent_sum, "numeric reuse changed entries(C)"
+    rel2 = check(R2, "numeric reuse")
+    print("spgemm R-MAT scale 20: nnz(C) %d, row_map identical to the KKMEM symbolic kernel, rows strictly ascending, C x vs A (A x) max rel %.2e / %.2e (reuse)"
+          % (nnz, rel1, rel2))
+
+
 def _check_unstructured(be, A0, name, expect_codes=None):
     import torch
     rng = np.random.default_rng(3)

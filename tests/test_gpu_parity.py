@@ -208,6 +208,19 @@ def test_mv4_plane_marching(be):
         assert h.query("mv4_workgroups") == 0
 
 
+def test_mv4_duplicate_entries(be):
+    # a lattice row that stores one column twice must never become the plane-marching pattern, and a row
+    # with a duplicate must go to the gather rows (the reference sums duplicates); rank 2 and the rank-1 marching kernel
+    for name, A0, planned, left in pc.mv4_duplicate_cases():
+        for knobs in (None, {"mv_kernel": 4}):
+            h = pc.check_spmv_mv(be, A0, 16, "N", 1.5, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs=knobs, max_val=32.0, nans=True)
+            assert (h.query("mv4_workgroups") > 0) == planned, (name, knobs)
+            if planned:
+                assert h.query("mv4_other_rows") == left, (name, h.query("mv4_other_rows"))
+        h = pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, max_val=32.0, knobs={"march": 1})
+        assert (h.query("march_workgroups") > 0) == planned, name
+
+
 def test_march_rank1(be):
     # rank 1 on the plane-marching analysis (knob march, off by default): lattice matrices incl. boundary and broken rows
     for name, A0, left in pc.mv4_cases() + [("27pt 160x120x12", oracle.laplace3d("FE", 160, 120, 12), None), ("7pt 70x50x90", oracle.laplace3d("FD", 70, 50, 90), None)]:
@@ -656,6 +669,102 @@ def test_spgemm_handle_contract(be):
     Cn = pc.kk.spgemm(A, False, B, False)
     ok, msg = oracle.is_same_matrix(oracle.Crs(40, 20, *[np.asarray(v) for v in Cn.to_host()]), oracle.spgemm(A0, B0))
     assert ok, msg
+
+
+def _set_default(be, key, value):
+    pc.kk._capi.check(be.lib, be.lib.kkamd_set_default(key.encode(), int(value)))
+
+
+def test_spgemm_compression(be):
+    """a18 on the HIP build: B compressed into 32-column sets + masks for the symbolic phase (impl_compression.hpp), kept by the
+    0.85 rule on stencils, dropped on matrices without column runs, forced through every symbolic row bin (wave, block-small,
+    block-large, bitmap with one and several windows), both offset types; numeric reuse after a compressed symbolic
+    (sparse/unit_test/Test_Sparse_spgemm.hpp:243-252,485-504)"""
+    L = pc.randomized(oracle.laplace3d("FE", 60, 60, 60))
+    pc.check_spgemm(be, L, L, expect_compressed=False)                                  # off unless asked for
+    pc.check_spgemm(be, L, L, options={"compression": 1}, expect_compressed=True)       # runs of three neighbours: pays
+    pc.check_spgemm(be, L, L, options={"compression": 2}, expect_compressed=True, offset_dtype=np.int64)
+    pc.check_spgemm(be, L, L, options={"compression": 1, "compression_cut_off": 0.1}, expect_compressed=False)
+    R = oracle.rmat(13, 8, seed=7)
+    pc.check_spgemm(be, R, R, options={"compression": 1}, expect_compressed=False)      # scattered columns: dropped by the rule
+    pc.check_spgemm(be, R, R, options={"compression": 2}, expect_compressed=True)       # ... unless forced (hub rows: bitmap kernel)
+    pc.check_spgemm(be, R, R, options={"compression": 2}, expect_compressed=True, offset_dtype=np.int64, value_dtype=np.float32)
+    band = pc.randomized(oracle.random_crs(6000, 6000, 40, variance=10, seed=5, bandwidth=150, sorted_rows=True))
+    lens = [3, 40, 200, 900, 2500, 0, 60]
+    rm = np.concatenate([[0], np.cumsum(lens)])
+    rng = np.random.default_rng(9)
+    ent = np.concatenate([np.sort(rng.choice(6000, size=l, replace=False)) for l in lens]).astype(np.int32)
+    A0 = oracle.Crs(len(lens), 6000, rm, ent, 1 + 49 * rng.random(int(rm[-1])))
+    for odt in (np.int32, np.int64):
+        pc.check_spgemm(be, A0, band, offset_dtype=odt, options={"compression": 2}, expect_compressed=True)
+    try:
+        _set_default(be, "spgemm_win_bits", 4096)
+        pc.check_spgemm(be, A0, band, options={"compression": 2}, expect_compressed=True)
+    finally:
+        _set_default(be, "spgemm_win_bits", 1 << 20)
+    U = pc.randomized(oracle.random_crs(300, 300, 8, variance=3, seed=8))               # unsorted B cannot be compressed
+    pc.check_spgemm(be, U, U, options={"compression": 2}, expect_compressed=False)
+
+
+def test_spgemm_dense_accumulator_algorithm(be):
+    """a21 on the HIP build: SPGEMM_KK_DENSE / SPGEMM_ACC_DENSE -- every row through a k-wide dense accumulator
+    (impl_speed.hpp:28-150), int32 / int64 offsets, fp64 / fp32 values, numeric reuse with new values"""
+    for A0, B0 in ((pc.randomized(oracle.laplace3d("FE", 30, 25, 20)),) * 2,
+                   (oracle.rmat(12, 8, seed=3),) * 2,
+                   (pc.randomized(oracle.random_crs(120, 900, 11, variance=6, seed=4, sorted_rows=True)),
+                    pc.randomized(oracle.random_crs(900, 700, 9, variance=5, seed=6, sorted_rows=True))),
+                   (pc.hub_matrix(30, 2000, 6, {3: 700}, seed=2), pc.randomized(oracle.random_crs(2000, 1500, 10, variance=4, seed=7, sorted_rows=True)))):
+        pc.check_spgemm(be, A0, B0, algo="SPGEMM_KK_DENSE")
+        pc.check_spgemm(be, A0, B0, options={"accumulator": 1}, offset_dtype=np.int64, value_dtype=np.float32)
+    kh = pc.kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK_DENSE")
+    assert kh.get_spgemm_handle().get(8) == 1
+    kh.get_spgemm_handle().set("accumulator", 2)                 # back to the hash accumulators
+    assert kh.get_spgemm_handle().get(8) == 0
+    for alias in ("SPGEMM_KK_MEMORY", "SPGEMM_KK_SPEED", "SPGEMM_KK_MEMSPEED", "SPGEMM_KK_LP", "SPGEMM_DEFAULT", "SPGEMM_DEBUG", "SPGEMM_SERIAL"):
+        kh.create_spgemm_handle(alias)
+        assert kh.get_spgemm_handle().get(8) == 0
+
+
+def test_spgemm_options_act_or_are_recorded(be, capfd):
+    """kkamd_spgemm_set on the HIP build: options act, the reference's hints are accepted and recorded, unknown keys fail; the
+    host-sequential algorithms of the reference give the same C"""
+    kh = pc.kk.KokkosKernelsHandle(be)
+    L = pc.randomized(oracle.laplace3d("FE", 12, 10, 8))
+    for algo in ("SPGEMM_DEBUG", "SPGEMM_SERIAL"):
+        kh.create_spgemm_handle(algo)
+        assert kh.get_spgemm_handle().get(9) == pc.kk.sparse._SPGEMM_ALGOS[algo]
+        pc.check_spgemm(be, L, L, algo=algo)
+    with pytest.raises(RuntimeError):
+        kh.create_spgemm_handle("SPGEMM_CUSPARSE")
+    kh.create_spgemm_handle()
+    sh = kh.get_spgemm_handle()
+    hints = ("team_work_size", "shmem_size", "suggested_team_size", "suggested_vector_size", "dynamic_scheduling", "min_hash_size_scale",
+             "first_level_hash_cut_off", "mkl_sort_option", "read_write_cost_calc", "compression_steps", "max_col_dense_acc", "sort_option")
+    for i, key in enumerate(hints):
+        sh.set(key, 16 + i)
+        assert sh.get_hint(key) == 16 + i
+    assert sh.get(10) == len(hints)
+    for bad_key, bad_val in (("no_such_option", 1), ("compression", 3), ("compression_cut_off", 0.0), ("algorithm", 9), ("accumulator", 5)):
+        with pytest.raises(pc.kk.KkamdError) as e:
+            sh.set(bad_key, bad_val)
+        assert e.value.status == pc.kk._capi.ERR_INVALID_ARG
+    sh.set("verbose", 1); sh.set("compression", 1); sh.set("team_work_size", 256)
+    A = pc.dev(be, L)
+    Cm = pc.kk.spgemm_symbolic(kh, A, False, A, False)
+    pc.kk.spgemm_numeric(kh, A, False, A, False, Cm)
+    out = capfd.readouterr().out
+    assert "kkamd spgemm symbolic" in out and "compression kept" in out and "kkamd spgemm numeric (SPGEMM_KK)" in out, out
+    assert "hint team_work_size = 256 recorded" in out, out
+
+
+def test_fuzz_slice(be):
+    """a 60-second slice of the randomised sweep (tests/fuzz_cases.py; tools/fuzz_gpu.py runs it for minutes): every kind of case at
+    least once -- SpGEMM skewed / R-MAT with compression and dense-accumulator options / unsorted / long rows, SpMV on irregular
+    rows and through every plan mode and rank-2 kernel, sort / merge / transpose, spmv_struct"""
+    import fuzz_cases
+    n_ok, per_kind, last = fuzz_cases.run(be, 60.0, seed0=3_000_000)
+    print("fuzz slice: %d cases, per kind %s, seeds 3000000..%d" % (n_ok, per_kind, last))
+    assert n_ok >= 16 and min(per_kind) >= 1, (n_ok, per_kind)
 
 
 # ------------------------------------------------------------------------------------------- full-size properties
