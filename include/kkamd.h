@@ -248,6 +248,10 @@ int kkamd_spgemm_numeric(kkamd_spgemm_handle_t* handle, int64_t m, int64_t n, in
  *   "compression"          B compression for the symbolic phase (impl_compression.hpp): 0 off (default), 1 keep when it pays, 2 always
  *   "compression_cut_off"  keep the compressed B when it leaves at most this share of the symbolic work (default 0.85)
  *   "verbose"              1: chosen algorithm, row bins, kernels and compression decision on stdout (KOKKOSKERNELS_VERBOSE)
+ *   "entries_computed"     the reference's are_entries_computed() as the caller knows it: 0 forces the next numeric call to write
+ *                          entries(C) again (re-allocated / overwritten arrays); 1 leaves the decision to the handle, which keeps
+ *                          entries(C) across numeric calls only when it wrote them into the same row_map / entries arrays itself
+ *                          (numeric reuse, sparse/tpls/KokkosSparse_spgemm_numeric_tpl_spec_decl.hpp:288-329)
  * Hints -- accepted, recorded, reported under "verbose", without effect, exactly as the reference's rocSPARSE / cuSPARSE paths treat
  * them (the reference's driver and unit tests set them before every spgemm: perf_test/sparse/KokkosSparse_spgemm.cpp:311-317,378-399,
  * sparse/unit_test/Test_Sparse_spgemm.hpp:91-92): "team_work_size", "shmem_size", "suggested_team_size", "suggested_vector_size",
@@ -258,7 +262,8 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* handle, const char* key, double valu
 /* what: 0 c_nnz, 1 total multiplications (the reference's original_overall_flops / 2),
  * 2 max row flops, 3 max nnz in a row of C, 4 symbolic called, 5 numeric called, 6 B was compressed for the symbolic phase,
  * 7 symbolic insertions after compression, 8 numeric algorithm in use (0 hash, 1 dense accumulator), 9 the SPGEMMAlgorithm value the
- * caller set (4 = SPGEMM_DEFAULT until then), 10 number of distinct hints recorded. */
+ * caller set (4 = SPGEMM_DEFAULT until then), 10 number of distinct hints recorded, 11 the last numeric call kept the entries(C)
+ * of the dense rows from the previous call (numeric reuse). */
 int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);
 /* the recorded value of a hint key (the reference's get_* of the same setter); KKAMD_ERR_INVALID_ARG when the key was never set */
 int kkamd_spgemm_get_hint(kkamd_spgemm_handle_t* handle, const char* key, double* value);

@@ -1175,6 +1175,9 @@ struct kkamd_spgemm_handle {
   int verbose = 0;
   int requested_algorithm = 4;     // the SPGEMMAlgorithm the caller named (SPGEMM_DEFAULT until set)
   std::map<std::string, double> hints;   // accepted-and-ignored tuning hints of the reference, by key
+  bool entries_valid = false;      // entries(C) as the last numeric call left them are still what entC_ptr holds (numeric reuse)
+  bool entries_reused = false;     // the last numeric call kept them
+  const void *entC_ptr = nullptr, *rmC_ptr = nullptr;
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -1190,8 +1193,9 @@ static int pick_sg_log2(int64_t nnzB, int64_t n) {
 
 static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLimits& L, int32_t* d_perm,
                      BinOffsets* off, hipStream_t st) {
-  unsigned long long* d_cnt = nullptr;
-  KK_HIP(hipMalloc((void**)&d_cnt, sizeof(unsigned long long) * 2 * kNumBins));
+  DevBuf cnt_b;                              // frees itself on every return
+  KK_HIP(cnt_b.alloc(sizeof(unsigned long long) * 2 * kNumBins));
+  unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
   KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * 2 * kNumBins, st));
   const unsigned grid = (unsigned)ceil_div(m, kBlock);
   KK_LAUNCH(spgemm_bin_count_kernel, grid, kBlock, 0, st, m, d_sizes, cap, L, d_cnt);
@@ -1203,7 +1207,6 @@ static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLi
   KK_LAUNCH(spgemm_bin_scatter_kernel, grid, kBlock, 0, st, m, d_sizes, cap, L, *off, d_cnt + kNumBins, d_perm);
   hipError_t e = hipGetLastError();
   hipError_t e2 = hipStreamSynchronize(st);
-  (void)hipFree(d_cnt);
   if (e != hipSuccess || e2 != hipSuccess) return fail(KKAMD_ERR_HIP, "spgemm binning failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   return KKAMD_OK;
 }
@@ -1232,8 +1235,9 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   const OffT* rmB = (const OffT*)rmB_;
   OffT* rmC       = (OffT*)rmC_;
   KK_HIP(hipMemsetAsync(rmC, 0, sizeof(OffT) * (size_t)(m + 1), st));
-  unsigned long long* d_stats = nullptr;
-  KK_HIP(hipMalloc((void**)&d_stats, 2 * sizeof(unsigned long long)));
+  DevBuf stats_b;                            // frees itself on every return
+  KK_HIP(stats_b.alloc(2 * sizeof(unsigned long long)));
+  unsigned long long* d_stats = stats_b.as<unsigned long long>();
   KK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), st));
   {
     const int64_t nbk = ceil_div(m * 8, kBlock);
@@ -1284,7 +1288,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   } else {
     (void)hipGetLastError();
   }
-  KK_HIP(hipFree(d_stats)); d_stats = nullptr;
+  stats_b.reset(); d_stats = nullptr;
   if (h->verbose)
     KK_VERBOSE("\tkkamd spgemm symbolic: m %lld n %lld k %lld, multiplications %lld (max per row %lld), B %s, compression %s (%.3f of the work)\n",
            (long long)m, (long long)n, (long long)k, (long long)h->mults, (long long)h->max_row_flops, h->b_sorted ? "sorted" : "unsorted",
@@ -1372,9 +1376,11 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     const int64_t nd = h->num_off.off[5] - h->num_off.off[4];
     if (nd > 0) {
       // dense bin -> [ A row <= kValLa | A row <= kHubLa | the rest ]; everything is "the rest" when B is not sorted
-      int32_t* d_tmp = nullptr; unsigned long long* d_cnt = nullptr; unsigned long long h_cnt[2] = {0, 0};
-      KK_HIP(hipMalloc((void**)&d_tmp, sizeof(int32_t) * (size_t)nd));
-      KK_HIP(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
+      DevBuf tmp_b, cnt_b;                     // free themselves on every early return below
+      unsigned long long h_cnt[2] = {0, 0};
+      KK_HIP(tmp_b.alloc(sizeof(int32_t) * (size_t)nd));
+      KK_HIP(cnt_b.alloc(2 * sizeof(unsigned long long)));
+      int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
       int32_t* seg = h->d_perm + h->num_off.off[4];
       int64_t lo = 0, len = nd;
       const int64_t la_max[2] = {g_spgemm.val_la < kValLa ? g_spgemm.val_la : kValLa, kHubLa};
@@ -1389,7 +1395,6 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         first[pass] = (int64_t)h_cnt[0];
         lo += first[pass]; len -= first[pass];
       }
-      KK_HIP(hipFree(d_tmp)); KK_HIP(hipFree(d_cnt));
       h->n_dense_lds = first[0]; h->n_dense_hub_lds = first[1];
     }
     h->numeric_bins_ready = true;
@@ -1408,11 +1413,20 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
                        (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
   if (nb(3)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkL>), (unsigned)nb(3), kBlock, 0, st, nb(3),
                        (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
+  DevBuf acc_b;
   VT* d_acc = nullptr;
+  // The reference's plug-in contract fills entries(C) only while !are_entries_computed()
+  // (sparse/tpls/KokkosSparse_spgemm_numeric_tpl_spec_decl.hpp:288-329): a repeated numeric call on the same handle and the same
+  // C arrays (new values of A / B, same structure) keeps the entries the previous call wrote.  What is skipped is the separate
+  // structure pass of the dense rows (the LDS bitmap kernel: 116 of 398 ms on R-MAT scale 20); the hash kernels of the short
+  // rows emit entries and values in one pass and rewrite the same entries.
+  const bool keep_entries = h->entries_valid && h->entC_ptr == (const void*)entC && h->rmC_ptr == rmC_;
+  h->entries_reused = false;
   if (nb(4)) {
     const int32_t* dperm = h->d_perm + off.off[4];
     // entries(C) of every dense row, column-sorted
-    if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
+    if (keep_entries) h->entries_reused = true;
+    else if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
     const int64_t n_lds = h->n_dense_lds, n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_lds - n_hubl;
     if (n_hubl) {      // heaviest rows first
       int cap = g_spgemm.val_cap;
@@ -1448,7 +1462,8 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       if (G > n_hub) G = n_hub;
       int64_t bx = 1024 / G;
       bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
-      KK_HIP(hipMalloc((void**)&d_acc, (size_t)k * sizeof(VT) * (size_t)G));
+      KK_HIP(acc_b.alloc((size_t)k * sizeof(VT) * (size_t)G));
+      d_acc = acc_b.as<VT>();
       KK_HIP(hipMemsetAsync(d_acc, 0, (size_t)k * sizeof(VT) * (size_t)G, st));
       for (int64_t r0 = 0; r0 < n_hub; r0 += G) {
         const unsigned g = (unsigned)(n_hub - r0 < G ? n_hub - r0 : G);
@@ -1460,8 +1475,8 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   }
   hipError_t e = hipGetLastError();
   hipError_t e2 = hipStreamSynchronize(st);   // the reference's numeric phase fences too (impl_kkmem.hpp:1440,1467)
-  if (d_acc) (void)hipFree(d_acc);
-  if (e != hipSuccess || e2 != hipSuccess) return fail(KKAMD_ERR_HIP, "spgemm numeric failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  if (e != hipSuccess || e2 != hipSuccess) { h->entries_valid = false; return fail(KKAMD_ERR_HIP, "spgemm numeric failed: %s", hipGetErrorString(e != hipSuccess ? e : e2)); }
+  h->entries_valid = true; h->entC_ptr = entC; h->rmC_ptr = rmC_;
   return KKAMD_OK;
 }
 
@@ -1530,7 +1545,7 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
     return KKAMD_OK;
   }
   h->m = m; h->n = n; h->k = k; h->offset_type = offset_type; h->rmA = d_row_mapA; h->rmB = d_row_mapB;
-  h->symbolic_called = false; h->numeric_called = false; h->numeric_bins_ready = false;
+  h->symbolic_called = false; h->numeric_called = false; h->numeric_bins_ready = false; h->entries_valid = false;
   h->c_nnz = 0; h->mults = 0; h->max_row_flops = 0; h->max_row_nnz = 0;
   // empty product: zero row_map (:100-107; the rocSPARSE wrapper memsets too)
   int64_t nnzA = 0, nnzB = 0;
@@ -1564,15 +1579,15 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
   if (offset_type == KKAMD_I32 && total < 0)
     return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: nnz(C) overflows 32-bit offsets; use 64-bit offsets");
   // max nnz in a C row (the reference's set_max_result_nnz, impl_symbolic.hpp:1501-1505)
-  unsigned long long* d_mx = nullptr; unsigned long long h_mx = 0;
-  KK_HIP(hipMalloc((void**)&d_mx, sizeof(unsigned long long)));
+  kk::DevBuf mx_b; unsigned long long h_mx = 0;
+  KK_HIP(mx_b.alloc(sizeof(unsigned long long)));
+  unsigned long long* d_mx = mx_b.as<unsigned long long>();
   KK_HIP(hipMemsetAsync(d_mx, 0, sizeof(unsigned long long), st));
   const int64_t nbk = kk::ceil_div(m, kk::kBlock);
   if (offset_type == KKAMD_I64) { KK_LAUNCH((kk::max_diff_kernel<int64_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int64_t*)d_row_mapC, d_mx); }
   else { KK_LAUNCH((kk::max_diff_kernel<int32_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int32_t*)d_row_mapC, d_mx); }
   KK_HIP(hipMemcpyAsync(&h_mx, d_mx, sizeof h_mx, hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
-  KK_HIP(hipFree(d_mx));
   h->max_row_nnz = (int64_t)h_mx;
   h->c_nnz = total; h->symbolic_called = true;
   if (c_nnz) *c_nnz = total;
@@ -1620,13 +1635,13 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* h, const char* key, double value) {
     // spgemm_numeric sorts every algorithm's rows afterwards (sparse/impl/KokkosSparse_spgemm_numeric_spec.hpp:138-140), so
     // their C is the C of every other algorithm: they run the device hash algorithm here, and say so under verbose.
     const int alg = (a == 1) ? 1 : 0;
-    if (alg != h->algorithm) h->numeric_bins_ready = false;
+    if (alg != h->algorithm) { h->numeric_bins_ready = false; h->entries_valid = false; }
     h->algorithm = alg; h->requested_algorithm = a;
     if (h->verbose && (a == 5 || a == 6)) printf("kkamd spgemm: %s requested: host-sequential in the reference, runs the LDS hash algorithm on the device here\n", a == 5 ? "SPGEMM_DEBUG" : "SPGEMM_SERIAL");
   } else if (k == "accumulator") {                               // SPGEMMAccumulator: 0 default, 1 dense, 2 sparse
     const int a = (int)value;
     if (a < 0 || a > 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: unknown SPGEMMAccumulator %d", a);
-    if ((a == 1) != (h->algorithm == 1)) h->numeric_bins_ready = false;
+    if ((a == 1) != (h->algorithm == 1)) { h->numeric_bins_ready = false; h->entries_valid = false; }
     h->algorithm = a == 1 ? 1 : 0;
   } else if (k == "compression") {
     if (value != 0 && value != 1 && value != 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: compression is 0 (off), 1 (keep if it pays) or 2 (always)");
@@ -1636,6 +1651,11 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* h, const char* key, double value) {
     h->compression_cutoff = value;
   } else if (k == "verbose") {
     h->verbose = value != 0;
+  } else if (k == "entries_computed") {
+    // the reference's SPGEMMHandle::are_entries_computed() as the caller sees it: 0 = entries(C) must be written again by the next
+    // numeric call (the caller re-allocated or overwrote them); 1 = leave the decision to the handle (it keeps them only when it
+    // wrote them itself into the same arrays)
+    if (value == 0) h->entries_valid = false;
   } else if (k == "sort_option" || k == "team_work_size" || k == "shmem_size" || k == "suggested_team_size" || k == "suggested_vector_size" ||
              k == "dynamic_scheduling" || k == "min_hash_size_scale" || k == "first_level_hash_cut_off" || k == "mkl_sort_option" ||
              k == "mkl_keep_output" || k == "mkl_convert_to_1base" || k == "multi_color_scale" || k == "read_write_cost_calc" ||
@@ -1676,6 +1696,7 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 8: *value = h->algorithm; break;
     case 9: *value = h->requested_algorithm; break;
     case 10: *value = (int64_t)h->hints.size(); break;
+    case 11: *value = h->entries_reused ? 1 : 0; break;
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
   return KKAMD_OK;

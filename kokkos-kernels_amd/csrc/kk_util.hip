@@ -480,8 +480,9 @@ int kkamd_transpose(int64_t num_rows, int64_t num_cols, int64_t nnz, const void*
   if (!d_row_map || !d_entries || !d_t_entries || (d_values && !d_t_values)) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_transpose: null pointer");
   const int64_t nb1 = kk::ceil_div(nnz, kk::kBlock), nb2 = kk::ceil_div(num_rows * 8, kk::kBlock);
   const unsigned g1 = (unsigned)(nb1 < 65536 ? nb1 : 65536), g2 = (unsigned)(nb2 < 65536 ? nb2 : 65536);
-  void* d_cursor = nullptr;
-  KK_HIP(hipMalloc(&d_cursor, osz * (size_t)(num_cols + 1)));
+  kk::DevBuf cursor_b;                       // frees itself on every return
+  KK_HIP(cursor_b.alloc(osz * (size_t)(num_cols + 1)));
+  void* d_cursor = cursor_b.p;
   int rc = KKAMD_OK;
 #define KK_TR(OT)                                                                                                              \
   do {                                                                                                                         \
@@ -497,7 +498,6 @@ int kkamd_transpose(int64_t num_rows, int64_t num_cols, int64_t nnz, const void*
   if (offset_type == KKAMD_I64) KK_TR(int64_t); else KK_TR(int32_t);
 #undef KK_TR
   hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);
-  (void)hipFree(d_cursor);
   if (rc) return rc;
   if (e1 != hipSuccess || e2 != hipSuccess) return kk::fail(KKAMD_ERR_HIP, "kkamd_transpose failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   // deterministic order inside every transposed row

@@ -685,9 +685,13 @@ def test_spgemm_compression(be):
     pc.check_spgemm(be, L, L, options={"compression": 1}, expect_compressed=True)       # runs of three neighbours: pays
     pc.check_spgemm(be, L, L, options={"compression": 2}, expect_compressed=True, offset_dtype=np.int64)
     pc.check_spgemm(be, L, L, options={"compression": 1, "compression_cut_off": 0.1}, expect_compressed=False)
+    S = pc.randomized(oracle.random_crs(4000, 300000, 9, variance=4, seed=2, sorted_rows=True))
+    St = pc.randomized(oracle.random_crs(300000, 400000, 7, variance=3, seed=3, sorted_rows=True))
+    pc.check_spgemm(be, S, St, options={"compression": 1}, expect_compressed=False)     # scattered columns: dropped by the rule
+    pc.check_spgemm(be, S, St, options={"compression": 2}, expect_compressed=True)      # ... unless forced
     R = oracle.rmat(13, 8, seed=7)
-    pc.check_spgemm(be, R, R, options={"compression": 1}, expect_compressed=False)      # scattered columns: dropped by the rule
-    pc.check_spgemm(be, R, R, options={"compression": 2}, expect_compressed=True)       # ... unless forced (hub rows: bitmap kernel)
+    pc.check_spgemm(be, R, R, options={"compression": 1}, expect_compressed=True)       # 8192 columns, hub rows: 0.43 of the insertions left
+    pc.check_spgemm(be, R, R, options={"compression": 2}, expect_compressed=True)       # hub rows: bitmap kernel on masks
     pc.check_spgemm(be, R, R, options={"compression": 2}, expect_compressed=True, offset_dtype=np.int64, value_dtype=np.float32)
     band = pc.randomized(oracle.random_crs(6000, 6000, 40, variance=10, seed=5, bandwidth=150, sorted_rows=True))
     lens = [3, 40, 200, 900, 2500, 0, 60]
@@ -723,6 +727,40 @@ def test_spgemm_dense_accumulator_algorithm(be):
     for alias in ("SPGEMM_KK_MEMORY", "SPGEMM_KK_SPEED", "SPGEMM_KK_MEMSPEED", "SPGEMM_KK_LP", "SPGEMM_DEFAULT", "SPGEMM_DEBUG", "SPGEMM_SERIAL"):
         kh.create_spgemm_handle(alias)
         assert kh.get_spgemm_handle().get(8) == 0
+
+
+def test_spgemm_numeric_reuse_keeps_entries(be):
+    """numeric reuse (sparse/tpls/KokkosSparse_spgemm_numeric_tpl_spec_decl.hpp:288-329, Test_Sparse_spgemm.hpp:243-252): a repeated
+    numeric call on the same handle and the same C arrays keeps entries(C) of the dense rows (no second structure pass); new C
+    arrays, or the caller saying the entries are gone, write them again"""
+    B0 = pc.hub_matrix(60, 30000, 20, {0: 9000, 1: 7000, 5: 12000}, seed=11)
+    A0 = pc.randomized(oracle.random_crs(40, 60, 12, variance=4, seed=3, sorted_rows=True))
+    A, B = pc.dev(be, A0), pc.dev(be, B0)
+    gold = oracle.spgemm(A0, B0)
+    kh = pc.kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+    sh = kh.get_spgemm_handle()
+    Cm = pc.kk.spgemm_symbolic(kh, A, False, B, False)
+
+    def check(tag, Ah=A0, Ad=A, Cd=None):
+        Cd = Cd or Cm
+        pc.kk.spgemm_numeric(kh, Ad, False, B, False, Cd)
+        rm, ent, val = Cd.to_host()
+        g = gold if Ah is A0 else oracle.spgemm(Ah, B0)
+        ok, msg = oracle.is_same_matrix(oracle.Crs(A0.nrows, B0.ncols, rm.astype(np.int64), ent, val), g)
+        assert ok, tag + ": " + msg
+    check("first numeric"); assert sh.get(11) == 0
+    A2 = pc.randomized(A0, seed=77)
+    Ad2 = pc.kk.CrsMatrix(A0.nrows, A0.ncols, A.graph.row_map, A.graph.entries, be.from_numpy(A2.values), backend=be)
+    check("reuse, new values", A2, Ad2); assert sh.get(11) == 1, "the structure pass of the dense rows ran again"
+    Cm.graph.entries[:] = -1                               # the caller clobbered entries(C) and says so
+    sh.set("entries_computed", 0)
+    check("entries_computed = 0", A2, Ad2); assert sh.get(11) == 0
+    check("reuse again", A0, A); assert sh.get(11) == 1
+    C2 = pc.kk.CrsMatrix(A0.nrows, B0.ncols, Cm.graph.row_map, be.empty(Cm.nnz(), np.int32), be.empty(Cm.nnz(), np.float64), backend=be)
+    C2.graph.entries[:] = -7
+    check("other C arrays", A0, A, C2); assert sh.get(11) == 0
+    sh.set("algorithm", pc.kk.sparse._SPGEMM_ALGOS["SPGEMM_KK_DENSE"])     # other row bins: nothing may be kept
+    check("algorithm changed", A0, A, C2); assert sh.get(11) == 0
 
 
 def test_spgemm_options_act_or_are_recorded(be, capfd):
