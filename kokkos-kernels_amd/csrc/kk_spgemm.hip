@@ -90,6 +90,8 @@ struct SpgemmTuning {
 #endif
   int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
+  int val_hub_flat   = 0;         // 1 = A rows above kValLa through the flat value kernel too (measured slower, see numeric_typed)
+  int val_kernel     = 2;         // dense rows with short A rows: 2 = flat walk with the lists cut per window group (default), 1 = wave-per-list streaming
 };
 static SpgemmTuning g_spgemm;
 
@@ -1027,11 +1029,159 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
   }
 }
 
+// dense rows, values, second form (default; B rows column-sorted, at most kValLa entries in the A row): the same windows of
+// `cap` consecutive C entries hashed into a clean LDS table, but the B side is walked FLAT.  Every list (one per A entry: a
+// sorted B row scaled by the A value) is cut at the upper column of each of the next G windows by a binary search -- G * la
+// independent searches spread over the workgroup, once per group of G windows, instead of every wave discovering the end of
+// "its" list by streaming 128 entries at a time.  With the cuts known a window is: one scan of the lists' in-window counts,
+// then product q goes to work-item q / U (U neighbouring products per work-item, all loads independent, nothing read that is
+// not consumed), the hash is probed for a column known to be present, ds_add.  The first form (spgemm_dense_vals_kernel) gave
+// the long lists of a window to one wave each: on R-MAT three of a row's sixteen lists carry the products, so one to three
+// waves of eight worked through sequential 128-entry round trips while the others sat at the barrier (R-MAT scale 20:
+// 158 ms for 1.4e10 products, VALU busy 6 %).
+template <class OffT, class VT, int H, int NT, int G>
+__global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* __restrict__ perm,
+                                                                       const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                       const VT* __restrict__ valA, const OffT* __restrict__ rmB,
+                                                                       const int32_t* __restrict__ entB, const VT* __restrict__ valB,
+                                                                       const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
+                                                                       VT* __restrict__ valC, int cap KK_DBG_PARAM) {
+  static_assert(NT >= kValLa, "one work-item per list in the scan");
+  __shared__ int hk[H];
+  __shared__ VT hv[H];
+  __shared__ long long s_cur[kValLa];     // first unconsumed entry of list a (index into entries / values of B)
+  __shared__ int s_rem[kValLa];           // entries left in it
+  __shared__ VT s_av[kValLa];
+  __shared__ int s_pos[G][kValLa];        // entries of list a, counted from s_cur[a], with column <= upper column of window g of the group
+  __shared__ int s_pre[kValLa + 1];       // product offsets of the lists inside the current window
+  __shared__ int s_whi[G];
+  __shared__ int s_wave[NT / 64];
+  constexpr int U   = kProdUnroll;
+  constexpr int KPT = (H / 2 + NT - 1) / NT;   // C entries of a window per work-item
+  const int t = threadIdx.x;
+  const int64_t row = perm[blockIdx.x];
+  const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
+  const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
+  for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
+  // A rows longer than kValLa are taken kValLa lists at a time: every pass walks all windows of the row, the first one stores
+  // its sums, the others add theirs (the same workgroup, one pass after the other: no atomics)
+  for (int64_t ach = 0; ach < la; ach += kValLa) {
+    const int la_c = (int)(la - ach < kValLa ? la - ach : kValLa);
+    const bool first_pass = ach == 0;
+    if (t < la_c) {
+      const int32_t kc = entA[a0 + ach + t];
+      const int64_t b0 = (int64_t)rmB[kc];
+      s_cur[t] = b0; s_rem[t] = (int)((int64_t)rmB[kc + 1] - b0); s_av[t] = valA[a0 + ach + t];
+    }
+    int curk[KPT], slot[KPT];
+    KK_UNROLL
+    for (int q = 0; q < KPT; ++q) { const int i = t + q * NT; curk[q] = (i < cap && i < cnt) ? entC[base + i] : -1; }
+    __syncthreads();
+    for (int64_t gdone = 0; gdone < cnt; gdone += (int64_t)G * cap) {
+      const int ng = (int)((cnt - gdone + cap - 1) / cap < G ? (cnt - gdone + cap - 1) / cap : G);     // windows in this group
+      if (t < ng) {
+        const int64_t last = gdone + (int64_t)(t + 1) * cap;
+        s_whi[t] = last >= cnt ? INT_MAX : entC[base + last - 1];      // the row's last window takes whatever is left
+      }
+      __syncthreads();
+      // cut every list at every window's upper column: ng * la_c independent lower-bound searches
+      for (int idx = t; idx < ng * la_c; idx += NT) {
+        const int g = idx / la_c, a = idx - g * la_c;
+        const int whi = s_whi[g];
+        const int rem = s_rem[a];
+        int lo = 0;
+        if (whi == INT_MAX) lo = rem;
+        else if (KK_DBG(2048)) lo = (int)((long long)rem * (g + 1) / (ng + 1));      // measurement build: no searches
+        else {
+          const int32_t* eb = entB + s_cur[a];
+          int hi = rem;
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (eb[mid] <= whi) lo = mid + 1; else hi = mid; }
+        }
+        s_pos[g][a] = lo;
+      }
+      __syncthreads();
+      for (int g = 0; g < ng; ++g) {
+        const int64_t done = gdone + (int64_t)g * cap;
+        // build: this window's columns into the (clean) table; the slot of every column stays in a register for the end
+        KK_UNROLL
+        for (int q = 0; q < KPT; ++q) slot[q] = curk[q] >= 0 ? vt_insert<H>(hk, curk[q]) : -1;
+        int nxtk[KPT];        // next window's columns: in flight while this window is walked
+        KK_UNROLL
+        for (int q = 0; q < KPT; ++q) {
+          const int i = t + q * NT;
+          nxtk[q]     = (i < cap && done + cap + i < cnt) ? entC[base + done + cap + i] : -1;
+        }
+        // in-window counts of the lists -> product offsets
+        const int from = (t < la_c && g > 0) ? s_pos[g - 1][t] : 0;
+        const int n_in = t < la_c ? s_pos[g][t] - from : 0;
+        int tot;
+        const int excl = block_exclusive_scan_n<int, NT>(n_in, &tot, s_wave);     // two barriers: the table is built when it returns
+        if (t < la_c) s_pre[t] = excl;
+        if (t == 0) s_pre[la_c] = tot;
+        __syncthreads();
+        auto find = [&](int q) {               // largest a in [0, la_c) with pre[a] <= q
+          int lo = 0, len2 = la_c;
+          while (len2 > 1) { const int half = len2 >> 1; lo += (s_pre[lo + half] <= q) ? half : 0; len2 -= half; }
+          return lo;
+        };
+        if (!KK_DBG(4096)) for (int pbase = 0; pbase < tot; pbase += NT * U) {
+          const int q0 = pbase + t * U;
+          int a = q0 < tot ? find(q0) : 0;
+          int col[U];
+          VT bv[U], av[U];
+          long long jj[U];
+          KK_UNROLL
+          for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            jj[u] = -1;
+            if (q < tot) {
+              while (q >= s_pre[a + 1]) ++a;            // also steps over lists with nothing in the window; q < tot = pre[la_c] ends it
+              jj[u] = s_cur[a] + (g > 0 ? s_pos[g - 1][a] : 0) + (q - s_pre[a]);
+              av[u] = s_av[a];
+            }
+          }
+          KK_UNROLL
+          for (int u = 0; u < U; ++u) { col[u] = jj[u] >= 0 ? entB[jj[u]] : -1; bv[u] = jj[u] >= 0 ? valB[jj[u]] : VT(0); }
+          KK_UNROLL
+          for (int u = 0; u < U; ++u)
+            if (col[u] >= 0 && !KK_DBG(8192)) {
+              const int hh = vt_find<H>(hk, col[u]);
+              if (hh >= 0) KK_ATOMIC_FADD(&hv[hh], av[u] * bv[u]);
+            }
+        }
+        __syncthreads();
+        // sums leave in C order (coalesced); every work-item cleans the slots it filled, so the table is clean again
+        KK_UNROLL
+        for (int q = 0; q < KPT; ++q) {
+          if (slot[q] >= 0) {
+            VT* out = valC + base + done + t + q * NT;
+            *out = first_pass ? hv[slot[q]] : *out + hv[slot[q]];
+            hk[slot[q]] = -1; hv[slot[q]] = VT(0);
+          }
+          curk[q] = nxtk[q];
+        }
+        __syncthreads();
+      }
+      if (t < la_c) { const int adv = s_pos[ng - 1][t]; s_cur[t] += adv; s_rem[t] -= adv; }
+      __syncthreads();
+    }
+  }
+}
+
 // dense rows, values, A rows of kValLa < entries <= kHubLa (B sorted): same windows and table as above, but with
 // thousands of A entries most of them have nothing inside a given window, so visiting each one per window (a global
 // load each) would dominate.  Here the NEXT unconsumed column of every A entry is cached in LDS next to its cursor:
 // a window starts with an LDS-only sweep that lists the entries whose next column falls inside the window, and only
 // those are streamed (sub-groups of 16 lanes, persistent over the list).  One workgroup of 16 waves per CU.
+// lanes per listed entry and loads per lane and step.  An entry of an A row with thousands of them has a handful of columns inside
+// a window (R-MAT scale 20: 4.5 on average), so a step of 2 x 16 entries reads seven times what it uses -- and still 8 lanes x 1
+// load measured SLOWER (numeric 351 -> 385 ms): the 128 sub-groups then park and re-fetch twice as many entries per window.
+#ifndef KK_HUB_SG
+#define KK_HUB_SG 16
+#endif
+#ifndef KK_HUB_US
+#define KK_HUB_US 2
+#endif
 template <class OffT, class VT>
 __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int32_t* __restrict__ perm,
                                                                       const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
@@ -1039,7 +1189,8 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
                                                                       const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                       const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
                                                                       VT* __restrict__ valC, int cap) {
-  constexpr int H = kValTable, NT = kDenseBlock, KPT = (H / 2 + NT - 1) / NT, SG = 16, NSUB = NT / SG, US = 2;
+  constexpr int H = kValTable, NT = kDenseBlock, KPT = (H / 2 + NT - 1) / NT, SG = KK_HUB_SG, NSUB = NT / SG, US = KK_HUB_US, EL = 4;
+  constexpr unsigned long long kSgMask = (1ull << SG) - 1ull;
   __shared__ int hk[H];
   __shared__ VT hv[H];
   __shared__ long long s_cur[kHubLa];
@@ -1095,45 +1246,67 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
     }
     __syncthreads();
     const int nact = s_nact;
-    int li = sub, a = 0, rem = 0;
-    int64_t p = 0;
-    VT av = VT(0);
-    bool have = false;
-    auto fetch = [&]() {
-      have = li < nact;
-      if (have) { a = s_list[li]; p = s_cur[a]; rem = s_rem[a]; av = valA[a0 + a]; }
-    };
-    fetch();
-    while (true) {
-      int c[US];
-      VT v[US];
+    // Every sub-group walks EL listed entries at a time: their first steps are requested together (with one entry per sub-group
+    // and step, a window was a chain of nact / NSUB dependent round trips -- 44 of them for an A row of 2800 entries, R-MAT scale 20).
+    // The trip counts are the same for every wave (ballots inside).
+    for (int it = 0; it * NSUB * EL < nact; ++it) {
+      int a[EL], rem[EL], c[EL][US];
+      int64_t p[EL];
+      VT av[EL], v[EL][US];
+      bool have[EL];
       KK_UNROLL
-      for (int u = 0; u < US; ++u) {
-        const int idx = u * SG + sl;
-        const bool ok = have && idx < rem;
-        c[u] = ok ? entB[p + idx] : INT_MAX;
-        v[u] = ok ? valB[p + idx] : VT(0);
+      for (int e = 0; e < EL; ++e) {
+        const int li = (it * EL + e) * NSUB + sub;
+        have[e] = li < nact;
+        a[e] = 0; p[e] = 0; rem[e] = 0; av[e] = VT(0);
+        if (have[e]) { a[e] = s_list[li]; p[e] = s_cur[a[e]]; rem[e] = s_rem[a[e]]; av[e] = valA[a0 + a[e]]; }
       }
-      int nin = 0;
       KK_UNROLL
-      for (int u = 0; u < US; ++u) {
-        const bool in = c[u] <= whi;
-        if (in) {
-          const int hh = vt_find<H>(hk, c[u]);
-          if (hh >= 0) KK_ATOMIC_FADD(&hv[hh], av * v[u]);
+      for (int e = 0; e < EL; ++e) {
+        KK_UNROLL
+        for (int u = 0; u < US; ++u) {
+          const int idx = u * SG + sl;
+          const bool ok = have[e] && idx < rem[e];
+          c[e][u] = ok ? entB[p[e] + idx] : INT_MAX;
+          v[e][u] = ok ? valB[p[e] + idx] : VT(0);
         }
-        nin += __popcll((__ballot(in) >> sg_shift) & 0xffffull);
       }
-      if (have) {
-        if (nin < US * SG) {       // done with this entry for the window: the first column left out becomes its next column
+      // consume entry by entry (called with constant indices so that everything stays in registers)
+      auto consume = [&](bool open, int ae, int64_t pe, int reme, VT ave, int (&ce)[US], VT (&ve)[US]) {
+        while (true) {
+          int nin = 0;
           KK_UNROLL
-          for (int u = 0; u < US; ++u) if (u * SG + sl == nin) s_next[a] = c[u];
-          if (sl == 0) { s_cur[a] = p + nin; s_rem[a] = rem - nin; }
-          li += NSUB;
-          fetch();
-        } else { p += nin; rem -= nin; }
-      }
-      if (__ballot(have) == 0ull) break;
+          for (int u = 0; u < US; ++u) {
+            const bool in = ce[u] <= whi;
+            if (in) {
+              const int hh = vt_find<H>(hk, ce[u]);
+              if (hh >= 0) KK_ATOMIC_FADD(&hv[hh], ave * ve[u]);
+            }
+            nin += __popcll((__ballot(in) >> sg_shift) & kSgMask);
+          }
+          if (open) {
+            if (nin < US * SG) {     // done with this entry for the window: the first column left out becomes its next column
+              KK_UNROLL
+              for (int u = 0; u < US; ++u) if (u * SG + sl == nin) s_next[ae] = ce[u];
+              if (sl == 0) { s_cur[ae] = pe + nin; s_rem[ae] = reme - nin; }
+              open = false;
+            } else { pe += nin; reme -= nin; }
+          }
+          if (__ballot(open) == 0ull) break;
+          KK_UNROLL
+          for (int u = 0; u < US; ++u) {        // rare: more than US * SG entries of one B row inside the window
+            const int idx = u * SG + sl;
+            const bool ok = open && idx < reme;
+            ce[u] = ok ? entB[pe + idx] : INT_MAX;
+            ve[u] = ok ? valB[pe + idx] : VT(0);
+          }
+        }
+      };
+      static_assert(EL == 4, "four explicit calls below");
+      consume(have[0], a[0], p[0], rem[0], av[0], c[0], v[0]);
+      consume(have[1], a[1], p[1], rem[1], av[1], c[1], v[1]);
+      consume(have[2], a[2], p[2], rem[2], av[2], c[2], v[2]);
+      consume(have[3], a[3], p[3], rem[3], av[3], c[3], v[3]);
     }
     __syncthreads();
     KK_UNROLL
@@ -1427,7 +1600,18 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     // entries(C) of every dense row, column-sorted
     if (keep_entries) h->entries_reused = true;
     else if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
-    const int64_t n_lds = h->n_dense_lds, n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_lds - n_hubl;
+    const int64_t n_lds = h->n_dense_lds; int64_t n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_lds - n_hubl;
+    const bool flat_vals = g_spgemm.val_kernel == 2 && h->dense_lds;
+    if (flat_vals && g_spgemm.val_hub_flat) {
+      // measured and not kept as the default: A rows above kValLa through the flat kernel, kValLa lists per pass (R-MAT scale 20:
+      // numeric 353 -> 479 ms -- with thousands of lists a group of windows costs 8 x 512 searches per pass and a pass finds a
+      // handful of products per list and window; the cached-next-column sweep of spgemm_hub_vals_kernel skips the empty lists for free)
+      int cap = g_spgemm.val_cap;
+      cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
+      if (n_hubl + n_hub) KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8>), (unsigned)(n_hubl + n_hub), kValBlock, 0, st, dperm + n_lds,
+                                    rmA, entA, valA, rmB, entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
+      n_hubl = 0; n_hub = 0;
+    }
     if (n_hubl) {      // heaviest rows first
       int cap = g_spgemm.val_cap;
       cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
@@ -1443,7 +1627,11 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     KK_LAUNCH((spgemm_dense_vals_kernel<OffT, VT, HH, NTT>), (unsigned)n_lds, NTT, 0, st, dperm, rmA, entA, valA, rmB, \
               entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);                                      \
   } while (0)
-      switch (g_spgemm.val_shape) {
+      if (flat_vals) {
+        if (cap > kValTable / 2) cap = kValTable / 2;
+        KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8>), (unsigned)n_lds, kValBlock, 0, st, dperm, rmA, entA, valA, rmB,
+                  entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
+      } else switch (g_spgemm.val_shape) {
         case 1: KK_VALS(8192, 1024); break;
         case 2: KK_VALS(8192, 512); break;
         case 3: KK_VALS(2048, 256); break;
@@ -1504,6 +1692,8 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_debug") g_spgemm.debug = value;
 #endif
   else if (k == "spgemm_val_shape") g_spgemm.val_shape = value;
+  else if (k == "spgemm_val_hub_flat") g_spgemm.val_hub_flat = value != 0;
+  else if (k == "spgemm_val_kernel") { if (value != 1 && value != 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_kernel is 1 or 2"); g_spgemm.val_kernel = value; }
   else if (k == "spgemm_val_la") g_spgemm.val_la = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "kkamd_set_default: unknown key '%s'", k.c_str());
   return KKAMD_OK;
