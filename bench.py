@@ -11,8 +11,17 @@
 
 Protocol (mirrors perf_test/sparse/KokkosSparse_kk_spmv.cpp:121-167): inputs generated in HBM, handle/plan
 creation outside the timed region, W warm-ups, then exactly K steps bracketed by barrier + device sync,
-max over ranks.  alpha = 1, beta = 0 (the driver's default), x/y = integers in [-20, 20) as fp64.
+max over ranks; EVERY step is followed by a fence of the execution space and timed on its own, as the reference's
+loop does (`space.fence(); timer.reset(); spmv; space.fence(); totalTime += timer.seconds()`), so the line carries the
+mean (= ms_per_step), min and max of the per-call times (--no-fence queues the K steps back to back instead; --flush
+adds the reference's --flush option: 4 x 1 GB of fills between calls, outside the per-call timers, reported beside).
+alpha = 1, beta = 0 (the driver's default), x/y = integers in [-20, 20) as fp64.
 GFLOP/s = 2 * stored nnz / t (stored zeros counted, like the reference's drivers).
+
+N = 1 also measures, under a time cap (--extras-seconds, default 150; 0 = off), the other SURVEY 8(d) metrics so that the
+driver's record holds them: "spmv_mv" = BASELINE config 3 (the same matrix x 16 right-hand sides, LayoutRight and
+LayoutLeft X / Y) and "spgemm" = the largest single-GPU member of config 4 (C = A*A on R-MAT scale 20, edge factor 16:
+symbolic, numeric, numeric reuse), each with its CPU baseline (OpenMP ports in oracle/, bounded samples).
 
 The JSON line also carries
   roofline     algorithmic bytes of ONE local SpMV (nnz*12 + (rows+1)*4 + x touched*8 + rows*8)
@@ -30,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a plain copy reaches
-PMC_FILE = os.path.join(ROOT, "profiles", "round2", "bench_n1_pmc_hbm.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round3", "bench_n1_pmc_hbm.json")
 
 
 def kernel_source_sha(unit="kk_spmv.hip"):
@@ -82,6 +91,130 @@ def cpu_baseline(sample_n=300, min_seconds=6.0):
                       % (note, sample_n, A.nrows, A.nnz, it, gbps)}
 
 
+def _fenced(fn, sync, reps, flush=None):
+    """the reference's timing loop (KokkosSparse_kk_spmv.cpp:139-167): fence, timer, call, fence -- per call"""
+    ts = []
+    for _ in range(reps):
+        if flush is not None:
+            for rep in range(4): flush.fill_(rep + 1)
+        sync()
+        t_ = time.perf_counter(); fn(); sync()
+        ts.append((time.perf_counter() - t_) * 1e3)
+    return {"mean_ms": round(sum(ts) / len(ts), 5), "min_ms": round(min(ts), 5), "max_ms": round(max(ts), 5), "calls": len(ts)}
+
+
+def bench_spmv_mv(kk, torch, A, budget_s, cpu):
+    """BASELINE config 3: Y = A X with 16 fp64 right-hand sides on the bench matrix (27-pt 300^3), X / Y LayoutRight (row-major)
+    and LayoutLeft (column-major, the reference's default layout), one analysed handle each, the reference's per-call-fence loop.
+    Algorithmic bytes (beta = 0): nnz*12 + (rows+1)*4 + 2*rows*16*8."""
+    t_start = time.perf_counter()
+    nv, rows, nnz = 16, A.numRows(), A.nnz()
+    alg = nnz * 12 + (rows + 1) * 4 + 2 * rows * nv * 8
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    X = torch.randint(-20, 20, (A.numCols(), nv), device="cuda", generator=g).double()
+    out = {"workload": "spmv_mv_crs_27pt_FE_laplacian_300^3_x16_fp64", "nvec": nv, "algorithmic_bytes_per_call": alg, "bound": "hbm", "peak_GBps": HBM_PEAK_GBPS}
+    ref = None
+    for layout in ("right", "left"):
+        Xl = X if layout == "right" else X.t().contiguous().t()
+        Y = torch.full((rows, nv), float("nan"), dtype=torch.float64, device="cuda") if layout == "right" \
+            else torch.full((nv, rows), float("nan"), dtype=torch.float64, device="cuda").t()
+        h = kk.SPMVHandle("SPMV_DEFAULT")
+        fn = lambda: kk.spmv(h, "N", 1.0, A, Xl, 0.0, Y)
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
+        r = _fenced(fn, torch.cuda.synchronize, 20)
+        if ref is None: ref = Y.clone()
+        else: assert float((Y - ref).abs().max()) == 0.0, "spmv_mv: layouts disagree"
+        r.update(GFLOPs=round(2.0 * nnz * nv / r["mean_ms"] / 1e6, 1), achieved_GBps=round(alg / r["mean_ms"] / 1e6, 1),
+                 frac=round(alg / r["mean_ms"] / 1e6 / HBM_PEAK_GBPS, 4),
+                 kernel="kk::spmv_mv4_kernel (plane marching)" if h.query("mv4_workgroups") else "kk::spmv_mv2_kernel (gather)")
+        out["layout_" + layout] = r
+        del h, Y
+    if cpu and time.perf_counter() - t_start < budget_s:
+        out["cpu_baseline"] = cpu_baseline_mv(nv)
+    return out
+
+
+def cpu_baseline_mv(nv, n=300, min_seconds=6.0):
+    """the reference's host SpMV_MV functor (OpenMP port, oracle/kk_oracle_omp.c) on the workload's own matrix, LayoutRight"""
+    import numpy as np
+    import oracle
+    oracle.set_omp_threads(oracle.usable_cpus())
+    A = oracle.laplace3d("FE", n, n, n)
+    ft = oracle.first_touch
+    rm32 = ft(A.row_map.astype(np.int32)); ent = ft(A.entries); val = ft(A.values)
+    rng = np.random.default_rng(3)
+    X = ft(rng.integers(-20, 20, size=(A.ncols, nv)).astype(np.float64)); Y = ft(np.zeros((A.nrows, nv)))
+    oracle.spmv_mv_omp(rm32, ent, val, 1.0, X, 0.0, Y)
+    t0 = time.perf_counter(); it = 0
+    while True:
+        oracle.spmv_mv_omp(rm32, ent, val, 1.0, X, 0.0, Y); it += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds and it >= 3: break
+    return {"value": round(2.0 * A.nnz * nv * it / el / 1e9, 3), "unit": "GFLOP/s", "cores": oracle.omp_threads(), "kind": "port",
+            "sample": "the full workload: 27-pt FE Laplacian %d^3 x %d right-hand sides, LayoutRight, %d iterations" % (n, nv, it)}
+
+
+def bench_spgemm(kk, torch, budget_s, cpu, scale=20):
+    """BASELINE config 4 family: C = A*A on R-MAT (edge factor 16, 64-bit offsets), the largest scale whose C fits one GPU
+    (scale 20: nnz(C) 9.69e9 = 116 GB; scale 22 as specified needs 863 GB).  Per repetition a fresh handle: symbolic, numeric,
+    numeric again on the same handle (the reference's reuse case).  Gather model of SURVEY 8(d): symbolic nnz(A)*4 + mults*4 +
+    2 row maps, numeric nnz(A)*12 + mults*12 + nnz(C)*12 + 2 row maps, against 8 TB/s."""
+    import numpy as np
+    import oracle
+    t_start = time.perf_counter()
+    if torch.cuda.mem_get_info()[0] < 170 * 2**30: scale = 18
+    R = oracle.rmat(scale, 16)
+    M = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, offset_dtype=np.int64)
+    sync = torch.cuda.synchronize
+    runs = []
+    for rep in range(4):                       # repetition 0 is the warm-up (first use of every kernel), not counted
+        kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle()
+        sync(); t0 = time.perf_counter()
+        Cm = kk.spgemm_symbolic(kh, M, False, M, False)
+        sync(); t1 = time.perf_counter()
+        kk.spgemm_numeric(kh, M, False, M, False, Cm)
+        sync(); t2 = time.perf_counter()
+        kk.spgemm_numeric(kh, M, False, M, False, Cm)
+        sync(); t3 = time.perf_counter()
+        sh = kh.get_spgemm_handle(); mults = sh.get(1); nnzC = Cm.nnz()
+        if rep > 0: runs.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+        kh.destroy_spgemm_handle(); del Cm
+        if runs and time.perf_counter() - t_start > budget_s: break
+    sym, num, reuse = (sum(r[i] for r in runs) / len(runs) for i in range(3))
+    b_sym = R.nnz * 4 + 2 * (R.nrows + 1) * 8 + mults * 4
+    b_num = R.nnz * 12 + 2 * (R.nrows + 1) * 8 + mults * 12 + nnzC * 12
+    out = {"workload": "spgemm_AxA_rmat_scale%d_ef16_fp64_int32_ordinals_int64_offsets" % scale, "rows": R.nrows, "nnz_A": R.nnz,
+           "multiplications": mults, "nnz_C": nnzC, "repetitions": len(runs), "protocol": "one warm-up, then a fresh handle per repetition, fence after every phase, mean of the repetitions",
+           "symbolic_ms": round(sym, 3), "numeric_ms": round(num, 3), "numeric_reuse_ms": round(reuse, 3), "total_ms": round(sym + num, 3),
+           "min_ms": {"symbolic": round(min(r[0] for r in runs), 3), "numeric": round(min(r[1] for r in runs), 3), "numeric_reuse": round(min(r[2] for r in runs), 3)},
+           "GFLOPs": round(2.0 * mults / (sym + num) / 1e6, 1), "numeric_GFLOPs": round(2.0 * mults / num / 1e6, 1),
+           "roofline": {"bound": "hbm", "model": "gather model, SURVEY 8(d)", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "symbolic": {"bytes": b_sym, "achieved": round(b_sym / sym / 1e6, 1), "frac": round(b_sym / sym / 1e6 / HBM_PEAK_GBPS, 4)},
+                        "numeric": {"bytes": b_num, "achieved": round(b_num / num / 1e6, 1), "frac": round(b_num / num / 1e6 / HBM_PEAK_GBPS, 4)},
+                        "numeric_reuse": {"bytes": b_num - nnzC * 4, "achieved": round((b_num - nnzC * 4) / reuse / 1e6, 1),
+                                          "frac": round((b_num - nnzC * 4) / reuse / 1e6 / HBM_PEAK_GBPS, 4)}}}
+    del M
+    if cpu and time.perf_counter() - t_start < budget_s:
+        out["cpu_baseline"] = cpu_baseline_spgemm()
+    return out
+
+
+def cpu_baseline_spgemm(scale=18):
+    """SPGEMM_KK on the host cores: OpenMP port of the reference's KKMEM hash kernels (oracle/kk_oracle_omp.c) + its row sort, on a
+    bounded sample of the same family (R-MAT scale 18: 2.9e9 multiplications)"""
+    import oracle
+    oracle.set_omp_threads(oracle.usable_cpus())
+    R = oracle.rmat(scale, 16)
+    tm = {}
+    Cm = oracle.spgemm_kkmem_omp(R, R, sort=True, timings=tm)
+    mults = oracle.spgemm_mults(R, R)[0]
+    tot = tm["symbolic_s"] + tm["numeric_s"] + tm["sort_s"]
+    return {"value": round(2.0 * mults / tot / 1e9, 3), "unit": "GFLOP/s", "cores": oracle.omp_threads(), "kind": "port",
+            "symbolic_ms": round(tm["symbolic_s"] * 1e3, 1), "numeric_ms": round(tm["numeric_s"] * 1e3, 1), "sort_ms": round(tm["sort_s"] * 1e3, 1),
+            "sample": "R-MAT scale %d ef 16, C = A*A (%d multiplications, nnz(C) %d): symbolic + numeric + row sort" % (scale, mults, Cm.nnz)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +227,10 @@ def main():
     ap.add_argument("--algo", default="SPMV_DEFAULT")
     ap.add_argument("--knob", action="append", default=[], help="key=value expert knob for the SpMV plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fence", action="store_true", help="queue the K timed steps back to back (no per-call fence, no per-call times)")
+    ap.add_argument("--flush", action="store_true", help="also report the per-call times with the reference's --flush (4 x 1 GB of fills between calls)")
+    ap.add_argument("--extras-seconds", type=float, default=150.0,
+                    help="N = 1: time cap for the spmv_mv (config 3) and spgemm (config 4) sections of the line; 0 skips them")
     ap.add_argument("--emulate", action="store_true",
                     help="debug / CI: run the whole flow on CPU -- gloo instead of RCCL, the kernels under the SIMT emulator of "
                          "tests/emu, a tiny grid -- to exercise the multi-process control flow without GPUs (numbers are meaningless)")
@@ -189,20 +326,32 @@ def main():
     for _ in range(args.warmup):
         step(w0, w1)
     barrier()
+    per_call = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(*evs[i])
+        if args.no_fence:
+            step(*evs[i])
+        else:                                   # the reference's loop: fence, timer, call, fence
+            tc = time.perf_counter(); step(*evs[i]); device_sync()
+            per_call.append((time.perf_counter() - tc) * 1e3)
     barrier()
     t1 = time.perf_counter()
     ms_step = (t1 - t0) * 1e3 / args.steps
     kern_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps      # local SpMV kernels (N > 1 with overlap: incl. the wait for the halo)
 
     nnz_total = torch.tensor([float(nnz_local)], device=dev, dtype=torch.float64)
-    tmax = torch.tensor([ms_step, kern_ms], device=dev, dtype=torch.float64)
+    pc_min, pc_max = (min(per_call), max(per_call)) if per_call else (0.0, 0.0)
+    tmax = torch.tensor([ms_step, kern_ms, pc_min, pc_max], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(nnz_total, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    nnz_global = int(nnz_total.item()); ms_step, kern_ms = tmax.tolist()
+    nnz_global = int(nnz_total.item()); ms_step, kern_ms, pc_min, pc_max = tmax.tolist()
+    flushed = None
+    if args.flush and not emu:
+        fl = torch.empty(1 << 30, dtype=torch.int8, device=dev)
+        w2 = (Event(enable_timing=True), Event(enable_timing=True))
+        flushed = _fenced(lambda: step(*w2), barrier, max(3, min(args.steps, 20)), flush=fl)
+        del fl
 
     # ---- N > 1: what each exchange costs (outside the timed region above): halo and all-gather steps, and the exchange alone ----
     xchg = None
@@ -271,6 +420,8 @@ def main():
                        "knobs": args.knob},
             "achieved_hbm_GBps_per_gpu": round(achieved, 1),
             "spmv_kernel_ms": round(kern_ms, 5),
+            "protocol": ("per-call fence (KokkosSparse_kk_spmv.cpp:139-167): ms_per_step is the mean over the K calls incl. the fence" if not args.no_fence
+                         else "K calls queued back to back between two fences"),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "kernel": "kk::spmv_stream3_kernel (+ fix-up kernel), HIP events around the launch",
@@ -314,10 +465,31 @@ def main():
                                                              "FETCH_SIZE x2 per MI355X_MICROARCH.md)" % os.path.relpath(PMC_FILE, ROOT))
             except Exception:
                 pass
+        if per_call:
+            out["per_call_ms"] = {"mean": round(sum(per_call) / len(per_call), 5) if world == 1 else round(ms_step, 5),
+                                  "min": round(pc_min, 5), "max": round(pc_max, 5)}
+        if flushed is not None:
+            out["per_call_ms_flushed"] = flushed
         if xchg is not None:
             out["exchange"] = xchg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        # ---- the other SURVEY 8(d) metrics, driver-visible: config 3 (SpMV_MV) and config 4 (SpGEMM), each under its share of the cap
+        if world == 1 and not emu and not args.n and args.extras_seconds > 0:
+            t_x = time.perf_counter()
+            del x_shard, y_shard, chk
+            try:
+                out["spmv_mv"] = bench_spmv_mv(kk, torch, A, 0.4 * args.extras_seconds, not args.no_cpu_baseline)
+            except Exception as e:
+                out["spmv_mv"] = {"error": repr(e)[:200]}
+            del handle
+            A = None
+            torch.cuda.empty_cache()
+            try:
+                left = args.extras_seconds - (time.perf_counter() - t_x)
+                out["spgemm"] = bench_spgemm(kk, torch, max(20.0, left), not args.no_cpu_baseline) if left > 20 else {"skipped": "time cap"}
+            except Exception as e:
+                out["spgemm"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -319,7 +319,7 @@ int kko_spgemm_numeric(int32_t m, int32_t n, int32_t k, const int64_t* row_mapA,
  * itself sparse/src/KokkosSparse_SortCrs.hpp:43-120): each row's (column,
  * value) pairs ordered by ascending column.  A stable insertion/merge sort is
  * used; C rows have unique columns so stability is not observable there.     */
-static void kko_sort_row(int64_t len, int32_t* e, double* v, int32_t* te, double* tv) {
+void kko_sort_row(int64_t len, int32_t* e, double* v, int32_t* te, double* tv) {
   if (len < 2) return;
   if (len <= 32) {
     for (int64_t i = 1; i < len; ++i) {

@@ -101,4 +101,6 @@ int kko_spmv_mv_omp_i32(int64_t nrows, int64_t nvec, const int32_t* row_map, con
 #ifdef __cplusplus
 }
 #endif
+/* merge sort of one row's (column, value) pairs; te / tv: scratch of the row's length (used by kko_sort_crs and its OpenMP form) */
+void kko_sort_row(int64_t len, int32_t* e, double* v, int32_t* te, double* tv);
 #endif

@@ -383,8 +383,9 @@ def spgemm_kkmem_omp(A, B, sort=True, timings=None):
     t3 = time.perf_counter()
     assert rc == nnz
     Cm = Crs(A.nrows, B.ncols, rmC, entC, valC)
-    if sort:
-        sort_crs(Cm)
+    if sort:                       # rows sorted in parallel, as the reference's sort_crs_matrix does
+        rc = L.kko_sort_crs_omp(_i64(Cm.nrows), _p(Cm.row_map), _p(Cm.entries), _p(Cm.values))
+        assert rc == 0
     if timings is not None:
         timings.update(symbolic_s=t1 - t0, numeric_s=t3 - t2, sort_s=time.perf_counter() - t3)
     return Cm

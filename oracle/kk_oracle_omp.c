@@ -178,3 +178,28 @@ int64_t kko_spgemm_kkmem_omp(int phase, int32_t m, int32_t n, int32_t k, const i
   }
   return row_mapC[m];
 }
+
+/* sort_crs_matrix on the host cores: rows in parallel, like the reference (sparse/src/KokkosSparse_SortCrs.hpp:43-120 sorts every
+ * row inside one parallel_for) -- the baseline's SpGEMM ends with this pass (impl/KokkosSparse_spgemm_numeric_spec.hpp:138-140). */
+#include "kk_oracle.h"
+int kko_sort_crs_omp(int64_t nrows, const int64_t* row_map, int32_t* entries, double* values) {
+  int64_t maxlen = 0;
+#pragma omp parallel for schedule(static) reduction(max : maxlen)
+  for (int64_t i = 0; i < nrows; ++i) { const int64_t l = row_map[i + 1] - row_map[i]; if (l > maxlen) maxlen = l; }
+  int fail = 0;
+#pragma omp parallel
+  {
+    int32_t* te = (int32_t*)malloc(sizeof(int32_t) * (size_t)(maxlen + 1));
+    double* tv  = (double*)malloc(sizeof(double) * (size_t)(maxlen + 1));
+    if (!te || !tv) {
+#pragma omp atomic write
+      fail = 1;
+    } else {
+#pragma omp for schedule(dynamic, 16)
+      for (int64_t i = 0; i < nrows; ++i)
+        kko_sort_row(row_map[i + 1] - row_map[i], entries + row_map[i], values ? values + row_map[i] : 0, te, tv);
+    }
+    free(te); free(tv);
+  }
+  return fail ? -1 : 0;
+}

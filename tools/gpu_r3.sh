@@ -22,7 +22,7 @@ prof() {   # prof <tag> <command...>: kernel stats + FETCH_SIZE and WRITE_SIZE i
   done
   cd $R
 }
-if has profbench; then prof bench python $R/bench.py --steps 30 --no-cpu-baseline; fi
+if has profbench; then prof bench python $R/bench.py --steps 30 --no-cpu-baseline --extras-seconds 0; fi
 if has profmv;    then prof mv python $R/tools/bench_mv3.py 300 quick; fi
 if has profmv4;   then prof mv4 python $R/tools/bench_mv4.py 300 quick; fi
 if has profspgemm; then prof spgemm python $R/tools/bench_spgemm_quick.py ${SPGEMM_SCALE:-20}; fi
@@ -31,7 +31,7 @@ if has sq; then
   cd /tmp
   for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
     tag=$(echo $grp | cut -d' ' -f1)
-    timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/prof_sq_$tag -o p -- ${SQ_CMD:-python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline} > $OUT/prof_sq_$tag.log 2>&1; echo "sq [$grp] rc=$?"
+    timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/prof_sq_$tag -o p -- ${SQ_CMD:-python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --extras-seconds 0} > $OUT/prof_sq_$tag.log 2>&1; echo "sq [$grp] rc=$?"
   done
   cd $R
 fi
