@@ -176,8 +176,13 @@ int kkamd_spmv_plan_export(const kkamd_spmv_plan_t* plan, const char* what, void
  * [row_offsets[r], row_offsets[r+1]) of A (LOCAL row_map, GLOBAL column indices), the matching slab of y and shard of x; one
  * exchange of x entries per SpMV (RCCL over xGMI), no other communication.  The reference has no counterpart (upstream this is
  * Tpetra's job); the local SpMV is kkamd_spmv.
- *   exchange  0 auto (halo when it moves less than half of the all-gather), 1 halo (only the x ranges the slab's columns
- *             touch, point to point), 2 all-gather (every shard to every rank);
+ *   exchange  0 auto (the column-range halo when it moves less than half of the all-gather, else the column-set halo when that
+ *             does, else the all-gather), 1 halo by column RANGE (the x ranges the slab's columns span, contiguous pieces point to
+ *             point straight into x), 2 all-gather (every shard to every rank through the transport's collective), 3 all-gather
+ *             by peer-to-peer pulls (every rank maps the others' x buffers through hipIpc once and pulls world - 1 shards with
+ *             concurrent copies between two 8-byte barrier collectives: all 7 xGMI links at once, no ring), 4 halo by column SET
+ *             (the general importer: exactly the x entries the slab's off-slab columns name -- per-peer index lists agreed once,
+ *             a pack kernel, point-to-point pieces, a scatter kernel);
  *   overlap   1: rows that reference only the rank's own x entries are computed while the halo is in flight.
  * Transport: by default RCCL, bound at run time from the librccl.so.1 already in the process; rank 0 obtains the 128-byte id
  * with kkamd_dist_unique_id and the host's launcher (MPI, torch.distributed, a file) hands it to every rank.  A host that
@@ -207,7 +212,8 @@ int kkamd_dist_spmv_x_local(kkamd_dist_spmv_t* op, void** d_x_local, void** d_x_
  * (measurement aids: 1 and 2 split a step into its two costs). */
 int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_shard, double beta, void* d_y_shard, int what,
                           kkamd_stream_t stream);
-/* "exchange" (0 local, 1 halo, 2 all-gather), "exchange_bytes" (received per SpMV), "interior_rows", "parts", "sends", "recvs" */
+/* "exchange" (0 local, 1 halo by column range, 2 all-gather, 3 all-gather by peer-to-peer pulls, 4 halo by column set), "exchange_bytes"
+ * (received per SpMV), "interior_rows", "parts", "sends", "recvs" */
 int kkamd_dist_spmv_query(const kkamd_dist_spmv_t* op, const char* key, int64_t* value);
 
 /* ------------------------------------------------------------------------------------------------
@@ -267,6 +273,31 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* handle, const char* key, double valu
 int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);
 /* the recorded value of a hint key (the reference's get_* of the same setter); KKAMD_ERR_INVALID_ARG when the key was never set */
 int kkamd_spgemm_get_hint(kkamd_spgemm_handle_t* handle, const char* key, double* value);
+
+/* Row-partitioned SpGEMM over the GPUs of one node: rank r owns the row slab [row_offsets[r], row_offsets[r+1]) of A (LOCAL row_map)
+ * and of C = A*B; B is replicated on every GPU, so there is no data-path communication at all (this is what lets BASELINE config 4
+ * as specified -- R-MAT scale 22, nnz(C) = 7.2e10 = 863 GB -- fit eight GPUs).  No reference counterpart (upstream: Tpetra).
+ *   _partition  contiguous slabs of near-equal MULTIPLICATIONS (row flops of sparse/impl/KokkosSparse_spgemm_impl_symbolic.hpp:1108-1185,
+ *               computed on the device from the full A and B structure): fills row_offsets[world + 1] (host) and, when given,
+ *               the multiplications of every slab; every rank that calls it with the same A and B gets the same answer.
+ *   _symbolic / _numeric   kkamd_spgemm_symbolic / _numeric on the rank's slab (checked against the partition), state in the operator;
+ *   _handle     the operator's SpGEMM handle, for kkamd_spgemm_set / _get;
+ *   _query      "row0", "rows_local", "rows_global", "c_nnz_local", "mults_local". */
+typedef struct kkamd_dist_spgemm kkamd_dist_spgemm_t;
+int kkamd_dist_spgemm_partition(int64_t m, const void* d_row_mapA, const int32_t* d_entriesA, const void* d_row_mapB, int offset_type, int world,
+                                int64_t* row_offsets /* host, world + 1 */, int64_t* mults_per_rank /* host, world, or NULL */, kkamd_stream_t stream);
+int kkamd_dist_spgemm_create(kkamd_dist_spgemm_t** op, int world, int rank, const int64_t* row_offsets /* host, world + 1 */);
+int kkamd_dist_spgemm_destroy(kkamd_dist_spgemm_t* op);
+kkamd_spgemm_handle_t* kkamd_dist_spgemm_handle(kkamd_dist_spgemm_t* op);
+int kkamd_dist_spgemm_symbolic(kkamd_dist_spgemm_t* op, int64_t m_local, int64_t n, int64_t k, const void* d_row_mapA_local, const int32_t* d_entriesA_local,
+                               const void* d_row_mapB, const int32_t* d_entriesB, void* d_row_mapC_local, int offset_type, int64_t* c_nnz_local,
+                               kkamd_stream_t stream);
+int kkamd_dist_spgemm_numeric(kkamd_dist_spgemm_t* op, int64_t m_local, int64_t n, int64_t k, const void* d_row_mapA_local, const int32_t* d_entriesA_local,
+                              const void* d_valuesA_local, const void* d_row_mapB, const int32_t* d_entriesB, const void* d_valuesB,
+                              const void* d_row_mapC_local, int32_t* d_entriesC_local, void* d_valuesC_local, int offset_type, int value_type,
+                              kkamd_stream_t stream);
+int kkamd_dist_spgemm_query(const kkamd_dist_spgemm_t* op, const char* key, int64_t* value);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Helpers either side of the path (KokkosSparse::sort_crs_matrix, sparse/src/KokkosSparse_SortCrs.hpp:43-120;

@@ -14,6 +14,8 @@ EXPORTS = [
     "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows", "kkamd_bench_read",
     "kkamd_dist_unique_id", "kkamd_dist_spmv_create", "kkamd_dist_spmv_destroy", "kkamd_dist_spmv_x_local", "kkamd_dist_spmv_apply",
     "kkamd_dist_spmv_query",
+    "kkamd_dist_spgemm_partition", "kkamd_dist_spgemm_create", "kkamd_dist_spgemm_destroy", "kkamd_dist_spgemm_handle", "kkamd_dist_spgemm_symbolic",
+    "kkamd_dist_spgemm_numeric", "kkamd_dist_spgemm_query",
 ]
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -78,9 +80,18 @@ def bind(lib):
     lib.kkamd_dist_spmv_x_local.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.kkamd_dist_spmv_apply.argtypes = [vp, dbl, vp, dbl, vp, ci, vp]
     lib.kkamd_dist_spmv_query.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
+    lib.kkamd_dist_spgemm_partition.argtypes = [i64, vp, vp, vp, ci, ci, C.POINTER(i64), C.POINTER(i64), vp]
+    lib.kkamd_dist_spgemm_create.argtypes = [C.POINTER(vp), ci, ci, C.POINTER(i64)]
+    lib.kkamd_dist_spgemm_destroy.argtypes = [vp]
+    lib.kkamd_dist_spgemm_handle.argtypes = [vp]
+    lib.kkamd_dist_spgemm_symbolic.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, ci, C.POINTER(i64), vp]
+    lib.kkamd_dist_spgemm_numeric.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, vp]
+    lib.kkamd_dist_spgemm_query.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("kkamd_last_error",):
+        if name == "kkamd_dist_spgemm_handle":
+            fn.restype = vp
+        elif name not in ("kkamd_last_error",):
             fn.restype = ci
     return lib
 

@@ -9,6 +9,18 @@
 //               slab it receives from each peer the piece of that range the peer owns -- grouped ncclSend / ncclRecv,
 //               point to point over xGMI.  For a slab of a 3-D stencil that is one grid plane per neighbour (5.8 MB per
 //               rank at 600^3) instead of 1.5 GB.  Default when it moves less than half of the all-gather.
+//   halo (column set)  for slabs whose columns are scattered (graphs: the column range is everything) the range halo degenerates
+//               to the all-gather.  The importer instead finds the SET of off-slab columns the slab references (a flag per
+//               column, compacted), tells every owner once which of its entries it wants, and per SpMV every rank packs the
+//               requested entries of its shard (one gather kernel), the packed pieces travel point to point, and a scatter
+//               kernel drops them into the full-length x -- the matrix keeps its global column indices.  Chosen by `auto`
+//               when it moves less than half of what the range halo moves.
+//   all-gather, peer to peer  the same result as the all-gather without a ring: every rank maps every other rank's x buffer
+//               (hipIpc handles exchanged once) and PULLS the other shards with world - 1 concurrent copies on their own
+//               streams, between two 8-byte collectives of the transport that act as stream-ordered barriers (all shards in
+//               place before anybody pulls; all pulls done before anybody overwrites its shard).  xGMI is point to point
+//               (7 links per GPU): seven concurrent 1/8-size copies use all links at once, where a ring all-gather is bound by
+//               one link (SURVEY section 5 / 8e asks for this fallback in case RCCL schedules a ring).
 // x lives in a full-length buffer owned by the operator (kkamd_dist_spmv_x_local hands out the rank's own window of it, so a
 // solver that keeps its x there never copies it).  Overlap (halo mode): the rows that reference only the rank's own x
 // entries -- the longest contiguous run of them -- are the INTERIOR, with their own plan over a zero-copy row-range view
@@ -109,6 +121,26 @@ __global__ void halo_rows_kernel(int64_t nrows, const OffT* __restrict__ row_map
   for (OffT j = row_map[r]; j < row_map[r + 1]; ++j) { const int c = entries[j]; f |= (c < c0 || c >= c1) ? 1 : 0; }
   flag[r] = f;
 }
+// flag[c] = 1 for every column c outside [c0, c1) that the slab references
+__global__ void mark_offslab_cols_kernel(const int32_t* __restrict__ entries, int64_t nnz, int c0, int c1, unsigned char* __restrict__ flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = entries[i];
+    if (c < c0 || c >= c1) flag[c] = 1;
+  }
+}
+// dst[i] = src[idx[i]] (pack: src = the rank's shard, idx = what the peers asked for) / dst[idx[i]] = src[i] (scatter into x)
+template <class T> __global__ void gather_idx_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, int64_t n, T* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+template <class T> __global__ void scatter_idx_kernel(const T* __restrict__ src, const int32_t* __restrict__ idx, int64_t n, T* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[idx[i]] = src[i];
+}
+__global__ void rebase_idx_kernel(int32_t* __restrict__ idx, int64_t n, int base) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] -= base;
+}
 template <class OffT>
 __global__ void rebase_kernel(const OffT* __restrict__ row_map, int64_t a, int64_t count, OffT* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,7 +156,7 @@ struct kkamd_dist_spmv {
   kkamd_transport_t tr{};
   kk::RcclCtx rccl_ctx;                      // when the built-in transport is used
   bool own_comm = false;
-  int mode = 0;                              // 0 local, 1 halo, 2 all-gather
+  int mode = 0;                              // 0 local, 1 halo (column range), 2 all-gather, 3 all-gather by peer-to-peer pulls, 4 halo (column set)
   bool equal = true;
   int64_t exchange_bytes = 0, interior_rows = 0;
   void* d_x_full = nullptr;
@@ -132,6 +164,15 @@ struct kkamd_dist_spmv {
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   std::vector<const void*> send_ptr; std::vector<int64_t> send_bytes; std::vector<int> send_peer;
   std::vector<void*> recv_ptr; std::vector<int64_t> recv_bytes; std::vector<int> recv_peer;
+  // column-set halo (mode 4): what the peers want of my shard (local indices, peer after peer) and what I want (global columns)
+  int32_t *d_send_idx = nullptr, *d_need_col = nullptr;
+  void *d_pack = nullptr, *d_unpack = nullptr;
+  int64_t n_send_idx = 0, n_need = 0;
+  // peer-to-peer all-gather (mode 3): every rank's x buffer mapped here, one copy stream + event per peer, two barrier tokens
+  std::vector<void*> peer_x;
+  std::vector<hipStream_t> p2p_stream; std::vector<hipEvent_t> p2p_event;
+  hipEvent_t ev_b1 = nullptr;
+  void* d_tok = nullptr;
   struct Part { kkamd_crs_t A{}; kkamd_spmv_plan_t* plan = nullptr; void* d_rm = nullptr; int64_t row0 = 0; };
   std::vector<Part> parts;                   // whole slab, or interior first and then the boundary parts
 };
@@ -141,6 +182,13 @@ namespace kk {
 static void dist_free(kkamd_dist_spmv* op) {
   if (!op) return;
   for (auto& p : op->parts) { if (p.plan) kkamd_spmv_plan_destroy(p.plan); if (p.d_rm) (void)hipFree(p.d_rm); }
+#ifndef KK_EMU
+  for (size_t p = 0; p < op->peer_x.size(); ++p) if (op->peer_x[p] && (int)p != op->rank) (void)hipIpcCloseMemHandle(op->peer_x[p]);
+#endif
+  for (auto s_ : op->p2p_stream) if (s_) (void)hipStreamDestroy(s_);
+  for (auto e_ : op->p2p_event) if (e_) (void)hipEventDestroy(e_);
+  if (op->ev_b1) (void)hipEventDestroy(op->ev_b1);
+  for (void* b : {(void*)op->d_send_idx, (void*)op->d_need_col, op->d_pack, op->d_unpack, op->d_tok}) if (b) (void)hipFree(b);
   if (op->d_x_full) (void)hipFree(op->d_x_full);
   if (op->ev_ready) (void)hipEventDestroy(op->ev_ready);
   if (op->ev_done) (void)hipEventDestroy(op->ev_done);
@@ -213,31 +261,136 @@ static int dist_setup(kkamd_dist_spmv* op, int exchange, int overlap, hipStream_
     if (hi > lo) { op->send_ptr.push_back(xf + es * lo); op->send_bytes.push_back(es * (hi - lo)); op->send_peer.push_back(p); }
   }
   const int64_t full_bytes = es * (n - (me1 - me0));
-  // every rank must take the same decision: the largest halo fraction over the ranks decides
+  // the SET of off-slab columns the slab references (needed for the set halo, and to choose it): a flag per column, compacted on the host
+  std::vector<std::vector<int32_t>> need((size_t)world);               // global columns wanted from each peer, ascending
+  int64_t set_elems = 0;
+  if (exchange == 0 || exchange == 4) {
+    DevBuf flag;
+    KK_HIP(flag.alloc((size_t)n));
+    KK_HIP(hipMemsetAsync(flag.p, 0, (size_t)n, st));
+    if (op->A.nnz > 0) {
+      unsigned char* d_colflag = flag.as<unsigned char>();     // (the emulator's launch captures its arguments by value)
+      KK_LAUNCH(mark_offslab_cols_kernel, 1024, kBlock, 0, st, (const int32_t*)op->A.d_entries, op->A.nnz, (int)me0, (int)me1, d_colflag);
+      KK_LAUNCH_CHECK();
+    }
+    std::vector<unsigned char> h_flag((size_t)n);
+    KK_HIP(hipMemcpyAsync(h_flag.data(), flag.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    for (int p = 0; p < world; ++p)
+      for (int64_t c = op->offsets[p]; c < op->offsets[p + 1]; ++c) if (h_flag[(size_t)c]) need[(size_t)p].push_back((int32_t)c);
+    for (int p = 0; p < world; ++p) set_elems += (int64_t)need[(size_t)p].size();
+  }
+  // every rank must take the same decision: the largest fractions over the ranks decide
   double frac = full_bytes > 0 ? (double)halo_bytes / (double)full_bytes : 0.0;
+  double sfrac = full_bytes > 0 ? (double)(es * set_elems) / (double)full_bytes : 0.0;
   {
-    double h_frac[2] = {frac, 0.0};
+    double h_frac[2] = {frac, sfrac};
     KK_HIP(hipMemcpyAsync(mm.p, h_frac, sizeof h_frac, hipMemcpyHostToDevice, st));
     if ((rc = op->tr.all_gather(op->tr.ctx, mm.p, all.p, 2 * sizeof(int64_t), reinterpret_cast<kkamd_stream_t>(st)))) return rc;
     std::vector<double> h_f(2 * (size_t)world);
     KK_HIP(hipMemcpyAsync(h_f.data(), all.p, sizeof(double) * h_f.size(), hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
-    for (int p = 0; p < world; ++p) frac = h_f[2 * p] > frac ? h_f[2 * p] : frac;
+    for (int p = 0; p < world; ++p) { frac = h_f[2 * p] > frac ? h_f[2 * p] : frac; sfrac = h_f[2 * p + 1] > sfrac ? h_f[2 * p + 1] : sfrac; }
   }
-  const bool use_halo = exchange == 1 || (exchange == 0 && frac < 0.5);
-  if (!use_halo) {
-    op->mode = 2; op->exchange_bytes = full_bytes;
+  // auto: the range halo when it moves less than half of the all-gather (contiguous pieces straight into x, no pack / scatter
+  // kernels); else the set halo when THAT moves less than half of the all-gather; else the all-gather
+  int chosen = exchange;
+  if (exchange == 0) chosen = frac < 0.5 ? 1 : (sfrac < 0.5 ? 4 : 2);
+  if (chosen == 2 || chosen == 3) {
+    op->mode = chosen; op->exchange_bytes = full_bytes;
     op->send_ptr.clear(); op->send_bytes.clear(); op->send_peer.clear(); op->recv_ptr.clear(); op->recv_bytes.clear(); op->recv_peer.clear();
-    if (!op->equal) {                                          // unequal shards: every shard to every peer, point to point
+    if (chosen == 2 && !op->equal) {                           // unequal shards: every shard to every peer, point to point
       for (int p = 0; p < world; ++p) {
         if (p == me) continue;
         op->send_ptr.push_back(xf + es * me0); op->send_bytes.push_back(es * (me1 - me0)); op->send_peer.push_back(p);
         op->recv_ptr.push_back(xf + es * op->offsets[p]); op->recv_bytes.push_back(es * (op->offsets[p + 1] - op->offsets[p])); op->recv_peer.push_back(p);
       }
     }
+    if (chosen == 3) {
+#ifdef KK_EMU
+      return fail(KKAMD_ERR_UNSUPPORTED, "kkamd_dist: the peer-to-peer all-gather maps device memory between processes (hipIpc): not under the emulator");
+#else
+      // every rank's x buffer, mapped once: 64-byte handles through the transport
+      hipIpcMemHandle_t mine;
+      KK_HIP(hipIpcGetMemHandle(&mine, op->d_x_full));
+      static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+      DevBuf hs, ha;
+      KK_HIP(hs.alloc(64)); KK_HIP(ha.alloc(64 * (size_t)world));
+      KK_HIP(hipMemcpyAsync(hs.p, &mine, 64, hipMemcpyHostToDevice, st));
+      if ((rc = op->tr.all_gather(op->tr.ctx, hs.p, ha.p, 64, reinterpret_cast<kkamd_stream_t>(st)))) return rc;
+      std::vector<hipIpcMemHandle_t> handles((size_t)world);
+      KK_HIP(hipMemcpyAsync(handles.data(), ha.p, 64 * (size_t)world, hipMemcpyDeviceToHost, st));
+      KK_HIP(hipStreamSynchronize(st));
+      op->peer_x.assign((size_t)world, nullptr);
+      op->peer_x[(size_t)me] = op->d_x_full;
+      for (int p = 0; p < world; ++p) {
+        if (p == me) continue;
+        if (hipIpcOpenMemHandle(&op->peer_x[(size_t)p], handles[(size_t)p], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+          (void)hipGetLastError();
+          return fail(KKAMD_ERR_HIP, "kkamd_dist: hipIpcOpenMemHandle of rank %d's x buffer failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set? peer access between the devices?)", p);
+        }
+        hipStream_t s2 = nullptr; hipEvent_t e2 = nullptr;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess)
+          return fail(KKAMD_ERR_HIP, "kkamd_dist: could not create a copy stream");
+        op->p2p_stream.push_back(s2); op->p2p_event.push_back(e2);
+      }
+      KK_HIP(hipEventCreateWithFlags(&op->ev_b1, hipEventDisableTiming));
+      KK_HIP(hipMalloc(&op->d_tok, 8 * (size_t)(world + 1)));
+      KK_HIP(hipMemsetAsync(op->d_tok, 0, 8 * (size_t)(world + 1), st));
+#endif
+    }
     return dist_add_part<OffT>(op, 0, op->A.num_rows, h_rm, st);
   }
-  op->mode = 1; op->exchange_bytes = halo_bytes;
+  if (chosen == 4) {
+    // tell every owner which of its entries I want: counts first (so that everybody can size its buffers), then the index lists
+    op->send_ptr.clear(); op->send_bytes.clear(); op->send_peer.clear(); op->recv_ptr.clear(); op->recv_bytes.clear(); op->recv_peer.clear();
+    DevBuf cnt_s, cnt_a;
+    KK_HIP(cnt_s.alloc(sizeof(int64_t) * (size_t)world)); KK_HIP(cnt_a.alloc(sizeof(int64_t) * (size_t)world * (size_t)world));
+    std::vector<int64_t> h_cnt((size_t)world), h_cnt_all((size_t)world * (size_t)world);
+    for (int p = 0; p < world; ++p) h_cnt[(size_t)p] = (int64_t)need[(size_t)p].size();
+    KK_HIP(hipMemcpyAsync(cnt_s.p, h_cnt.data(), sizeof(int64_t) * (size_t)world, hipMemcpyHostToDevice, st));
+    if ((rc = op->tr.all_gather(op->tr.ctx, cnt_s.p, cnt_a.p, (int64_t)sizeof(int64_t) * world, reinterpret_cast<kkamd_stream_t>(st)))) return rc;
+    KK_HIP(hipMemcpyAsync(h_cnt_all.data(), cnt_a.p, sizeof(int64_t) * h_cnt_all.size(), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    int64_t n_send = 0;                                        // what the peers want of my shard: row p of the count matrix, column me
+    for (int p = 0; p < world; ++p) if (p != me) n_send += h_cnt_all[(size_t)p * world + me];
+    op->n_need = set_elems; op->n_send_idx = n_send;
+    KK_HIP(hipMalloc((void**)&op->d_need_col, sizeof(int32_t) * (size_t)(set_elems > 0 ? set_elems : 1)));
+    KK_HIP(hipMalloc((void**)&op->d_send_idx, sizeof(int32_t) * (size_t)(n_send > 0 ? n_send : 1)));
+    KK_HIP(hipMalloc(&op->d_pack, (size_t)es * (size_t)(n_send > 0 ? n_send : 1)));
+    KK_HIP(hipMalloc(&op->d_unpack, (size_t)es * (size_t)(set_elems > 0 ? set_elems : 1)));
+    {
+      std::vector<int32_t> h_need; h_need.reserve((size_t)set_elems);
+      for (int p = 0; p < world; ++p) h_need.insert(h_need.end(), need[(size_t)p].begin(), need[(size_t)p].end());
+      if (set_elems) KK_HIP(hipMemcpyAsync(op->d_need_col, h_need.data(), sizeof(int32_t) * (size_t)set_elems, hipMemcpyHostToDevice, st));
+      KK_HIP(hipStreamSynchronize(st));                        // h_need goes out of scope
+    }
+    // index lists: my wants go to the owners (as global columns; the owner rebases them), theirs come to me
+    std::vector<const void*> sp; std::vector<int64_t> sb; std::vector<int> spr; std::vector<void*> rp; std::vector<int64_t> rb; std::vector<int> rpr;
+    int64_t need_off = 0, send_off = 0;
+    for (int p = 0; p < world; ++p) {
+      const int64_t wn = (int64_t)need[(size_t)p].size(), ws = p == me ? 0 : h_cnt_all[(size_t)p * world + me];
+      if (p != me && wn) {
+        sp.push_back(op->d_need_col + need_off); sb.push_back(4 * wn); spr.push_back(p);
+        op->recv_ptr.push_back((char*)op->d_unpack + es * need_off); op->recv_bytes.push_back(es * wn); op->recv_peer.push_back(p);       // per SpMV: values arrive here
+      }
+      if (p != me && ws) {
+        rp.push_back(op->d_send_idx + send_off); rb.push_back(4 * ws); rpr.push_back(p);
+        op->send_ptr.push_back((char*)op->d_pack + es * send_off); op->send_bytes.push_back(es * ws); op->send_peer.push_back(p);          // per SpMV: values leave from here
+      }
+      need_off += wn; send_off += ws;
+    }
+    if ((rc = op->tr.exchange(op->tr.ctx, (int)spr.size(), sp.data(), sb.data(), spr.data(), (int)rpr.size(), rp.data(), rb.data(), rpr.data(),
+                              reinterpret_cast<kkamd_stream_t>(st)))) return rc;
+    if (n_send) {                                              // global columns -> indices into my shard
+      int32_t* d_sidx = op->d_send_idx;
+      KK_LAUNCH(rebase_idx_kernel, (unsigned)ceil_div(n_send, kBlock), kBlock, 0, st, d_sidx, n_send, (int)me0);
+      KK_LAUNCH_CHECK();
+    }
+    KK_HIP(hipStreamSynchronize(st));
+    halo_bytes = es * set_elems;
+  }
+  op->mode = chosen; op->exchange_bytes = halo_bytes;           // 1 (column range) or 4 (column set)
   // interior = the longest contiguous run of rows that reference only this rank's own x entries
   int64_t r_lo = 0, r_hi = 0;
   const int64_t m = op->A.num_rows;
@@ -292,7 +445,8 @@ int kkamd_dist_spmv_create(kkamd_dist_spmv_t** out, const kkamd_crs_t* A_local, 
   int rc = kk::check_crs(A_local);
   if (rc) return rc;
   if (!row_offsets || world < 1 || rank < 0 || rank >= world) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: bad partition");
-  if (exchange < 0 || exchange > 2) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: exchange %d is not 0 (auto), 1 (halo) or 2 (all-gather)", exchange);
+  if (exchange < 0 || exchange > 4)
+    return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: exchange %d is not 0 (auto), 1 (halo, column range), 2 (all-gather), 3 (all-gather by peer-to-peer pulls) or 4 (halo, column set)", exchange);
   if (vector_type != KKAMD_F32 && vector_type != KKAMD_F64) return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_dist_spmv_create: unsupported vector_type %d", vector_type);
   for (int r = 0; r < world; ++r) if (row_offsets[r + 1] < row_offsets[r]) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: row offsets must ascend");
   if (row_offsets[0] != 0 || A_local->num_rows != row_offsets[rank + 1] - row_offsets[rank])
@@ -344,7 +498,7 @@ int kkamd_dist_spmv_x_local(kkamd_dist_spmv_t* op, void** d_x_local, void** d_x_
 int kkamd_dist_spmv_query(const kkamd_dist_spmv_t* op, const char* key, int64_t* value) {
   if (!op || !key || !value) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_query: null argument");
   const std::string k(key);
-  if (k == "exchange") *value = op->mode;                        // 0 local, 1 halo, 2 all-gather
+  if (k == "exchange") *value = op->mode;                        // 0 local, 1 halo (range), 2 all-gather, 3 all-gather peer to peer, 4 halo (set)
   else if (k == "exchange_bytes") *value = op->exchange_bytes;   // bytes this rank receives per SpMV
   else if (k == "interior_rows") *value = op->interior_rows;     // rows computed while the halo is in flight
   else if (k == "parts") *value = (int64_t)op->parts.size();
@@ -374,7 +528,39 @@ int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_s
       KK_HIP(hipEventRecord(op->ev_ready, st));                  // x_local is in place, and earlier SpMVs are done with the halo
       KK_HIP(hipStreamWaitEvent(cs, op->ev_ready, 0));
       kkamd_stream_t kcs = reinterpret_cast<kkamd_stream_t>(cs);
-      if (op->mode == 2 && op->equal) rc = op->tr.all_gather(op->tr.ctx, x_local, op->d_x_full, (int64_t)op->elem * mrows, kcs);
+      if (op->mode == 3) {
+        // barrier (every shard is in place), world - 1 concurrent pulls on their own streams, barrier (nobody still reads a shard)
+        char* tok = (char*)op->d_tok;
+        if ((rc = op->tr.all_gather(op->tr.ctx, tok, tok + 8, 8, kcs))) return rc;
+        KK_HIP(hipEventRecord(op->ev_b1, cs));
+        size_t q = 0;
+        for (int p = 0; p < op->world; ++p) {
+          if (p == op->rank) continue;
+          const int64_t off = (int64_t)op->elem * op->offsets[p], len = (int64_t)op->elem * (op->offsets[p + 1] - op->offsets[p]);
+          hipStream_t s2 = op->p2p_stream[q];
+          KK_HIP(hipStreamWaitEvent(s2, op->ev_b1, 0));
+          if (len > 0) KK_HIP(hipMemcpyAsync((char*)op->d_x_full + off, (const char*)op->peer_x[(size_t)p] + off, (size_t)len, hipMemcpyDeviceToDevice, s2));
+          KK_HIP(hipEventRecord(op->p2p_event[q], s2));
+          KK_HIP(hipStreamWaitEvent(cs, op->p2p_event[q], 0));
+          ++q;
+        }
+        rc = op->tr.all_gather(op->tr.ctx, tok, tok + 8, 8, kcs);
+      } else if (op->mode == 4) {
+        // pack what the peers asked for, the packed pieces travel point to point, scatter what arrived into the full-length x
+        const int64_t ns = op->n_send_idx, nn = op->n_need;
+        const int32_t* sidx = op->d_send_idx; const int32_t* ncol = op->d_need_col;
+        void* pack = op->d_pack; void* unpack = op->d_unpack; void* xfull = op->d_x_full;
+        if (ns) {
+          if (op->elem == 8) KK_LAUNCH((kk::gather_idx_kernel<uint64_t>), (unsigned)kk::ceil_div(ns, kk::kBlock), kk::kBlock, 0, cs, (const uint64_t*)x_local, sidx, ns, (uint64_t*)pack);
+          else KK_LAUNCH((kk::gather_idx_kernel<uint32_t>), (unsigned)kk::ceil_div(ns, kk::kBlock), kk::kBlock, 0, cs, (const uint32_t*)x_local, sidx, ns, (uint32_t*)pack);
+        }
+        rc = op->tr.exchange(op->tr.ctx, (int)op->send_peer.size(), op->send_ptr.data(), op->send_bytes.data(), op->send_peer.data(),
+                             (int)op->recv_peer.size(), op->recv_ptr.data(), op->recv_bytes.data(), op->recv_peer.data(), kcs);
+        if (!rc && nn) {
+          if (op->elem == 8) KK_LAUNCH((kk::scatter_idx_kernel<uint64_t>), (unsigned)kk::ceil_div(nn, kk::kBlock), kk::kBlock, 0, cs, (const uint64_t*)unpack, ncol, nn, (uint64_t*)xfull);
+          else KK_LAUNCH((kk::scatter_idx_kernel<uint32_t>), (unsigned)kk::ceil_div(nn, kk::kBlock), kk::kBlock, 0, cs, (const uint32_t*)unpack, ncol, nn, (uint32_t*)xfull);
+        }
+      } else if (op->mode == 2 && op->equal) rc = op->tr.all_gather(op->tr.ctx, x_local, op->d_x_full, (int64_t)op->elem * mrows, kcs);
       else rc = op->tr.exchange(op->tr.ctx, (int)op->send_peer.size(), op->send_ptr.data(), op->send_bytes.data(), op->send_peer.data(),
                                 (int)op->recv_peer.size(), op->recv_ptr.data(), op->recv_bytes.data(), op->recv_peer.data(), kcs);
       if (rc) return rc;

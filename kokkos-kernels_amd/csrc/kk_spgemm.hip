@@ -40,6 +40,7 @@
 #include <new>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #define KK_VERBOSE(...) do { printf(__VA_ARGS__); fflush(stdout); } while (0)
 
@@ -1889,6 +1890,99 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 11: *value = h->entries_reused ? 1 : 0; break;
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
+  return KKAMD_OK;
+}
+
+// ---- row-partitioned SpGEMM over the GPUs of one node (the path shards by rows of A; B is replicated) -----------
+struct kkamd_dist_spgemm {
+  int world = 1, rank = 0;
+  std::vector<int64_t> offsets;
+  kkamd_spgemm_handle_t* h = nullptr;
+};
+
+int kkamd_dist_spgemm_partition(int64_t m, const void* d_row_mapA, const int32_t* d_entriesA, const void* d_row_mapB, int offset_type, int world,
+                                int64_t* row_offsets, int64_t* mults_per_rank, kkamd_stream_t stream) {
+  if (m < 0 || world < 1 || !row_offsets) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spgemm_partition: bad argument");
+  if (offset_type != KKAMD_I32 && offset_type != KKAMD_I64) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spgemm_partition: unknown offset_type %d", offset_type);
+  if (m > 0 && (!d_row_mapA || !d_row_mapB)) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spgemm_partition: null row_map");
+  hipStream_t st = kk::to_hip(stream);
+  std::vector<int64_t> flops((size_t)m);
+  if (m > 0) {
+    kk::DevBuf f_b, s_b;
+    KK_HIP(f_b.alloc(sizeof(int64_t) * (size_t)m)); KK_HIP(s_b.alloc(2 * sizeof(unsigned long long)));
+    KK_HIP(hipMemsetAsync(s_b.p, 0, 2 * sizeof(unsigned long long), st));
+    int64_t* d_f = f_b.as<int64_t>(); unsigned long long* d_s = s_b.as<unsigned long long>();
+    const int64_t nbk = kk::ceil_div(m * 8, kk::kBlock);
+    if (offset_type == KKAMD_I64) { KK_LAUNCH((kk::spgemm_flops_kernel<int64_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int64_t*)d_row_mapA, d_entriesA, (const int64_t*)d_row_mapB, d_f, d_s); }
+    else { KK_LAUNCH((kk::spgemm_flops_kernel<int32_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int32_t*)d_row_mapA, d_entriesA, (const int32_t*)d_row_mapB, d_f, d_s); }
+    KK_HIP(hipMemcpyAsync(flops.data(), d_f, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+  }
+  // contiguous slabs of near-equal multiplications: cut where the running sum passes r / world of the total
+  long double total = 0; for (int64_t v : flops) total += (long double)v;
+  row_offsets[0] = 0;
+  long double run = 0; int64_t row = 0;
+  for (int r = 1; r < world; ++r) {
+    const long double target = total * (long double)r / (long double)world;
+    while (row < m && run + (long double)flops[(size_t)row] <= target) { run += (long double)flops[(size_t)row]; ++row; }
+    row_offsets[r] = row;
+  }
+  row_offsets[world] = m;
+  if (mults_per_rank)
+    for (int r = 0; r < world; ++r) { int64_t sum = 0; for (int64_t i = row_offsets[r]; i < row_offsets[r + 1]; ++i) sum += flops[(size_t)i]; mults_per_rank[r] = sum; }
+  return KKAMD_OK;
+}
+
+int kkamd_dist_spgemm_create(kkamd_dist_spgemm_t** out, int world, int rank, const int64_t* row_offsets) {
+  if (!out) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spgemm_create: null output pointer");
+  *out = nullptr;
+  if (!row_offsets || world < 1 || rank < 0 || rank >= world || row_offsets[0] != 0) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spgemm_create: bad partition");
+  for (int r = 0; r < world; ++r) if (row_offsets[r + 1] < row_offsets[r]) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spgemm_create: row offsets must ascend");
+  kkamd_dist_spgemm* op = new (std::nothrow) kkamd_dist_spgemm();
+  if (!op) return kk::fail(KKAMD_ERR_ALLOC, "kkamd_dist_spgemm_create: out of host memory");
+  op->world = world; op->rank = rank; op->offsets.assign(row_offsets, row_offsets + world + 1);
+  const int rc = kkamd_spgemm_create(&op->h);
+  if (rc) { delete op; return rc; }
+  *out = op;
+  return KKAMD_OK;
+}
+int kkamd_dist_spgemm_destroy(kkamd_dist_spgemm_t* op) {
+  if (!op) return KKAMD_OK;
+  (void)kkamd_spgemm_destroy(op->h);
+  delete op;
+  return KKAMD_OK;
+}
+kkamd_spgemm_handle_t* kkamd_dist_spgemm_handle(kkamd_dist_spgemm_t* op) { return op ? op->h : nullptr; }
+
+static int dist_spgemm_rows(const kkamd_dist_spgemm_t* op, int64_t m_local, const char* who) {
+  if (!op) return kk::fail(KKAMD_ERR_INVALID_ARG, "%s: null operator", who);
+  const int64_t want = op->offsets[(size_t)op->rank + 1] - op->offsets[(size_t)op->rank];
+  if (m_local != want) return kk::fail(KKAMD_ERR_INVALID_ARG, "%s: the slab of A has %lld rows, the partition gives rank %d %lld", who, (long long)m_local, op->rank, (long long)want);
+  return KKAMD_OK;
+}
+int kkamd_dist_spgemm_symbolic(kkamd_dist_spgemm_t* op, int64_t m_local, int64_t n, int64_t k, const void* d_row_mapA_local, const int32_t* d_entriesA_local,
+                               const void* d_row_mapB, const int32_t* d_entriesB, void* d_row_mapC_local, int offset_type, int64_t* c_nnz_local, kkamd_stream_t stream) {
+  const int rc = dist_spgemm_rows(op, m_local, "kkamd_dist_spgemm_symbolic");
+  if (rc) return rc;
+  return kkamd_spgemm_symbolic(op->h, m_local, n, k, d_row_mapA_local, d_entriesA_local, d_row_mapB, d_entriesB, d_row_mapC_local, offset_type, c_nnz_local, stream);
+}
+int kkamd_dist_spgemm_numeric(kkamd_dist_spgemm_t* op, int64_t m_local, int64_t n, int64_t k, const void* d_row_mapA_local, const int32_t* d_entriesA_local,
+                              const void* d_valuesA_local, const void* d_row_mapB, const int32_t* d_entriesB, const void* d_valuesB, const void* d_row_mapC_local,
+                              int32_t* d_entriesC_local, void* d_valuesC_local, int offset_type, int value_type, kkamd_stream_t stream) {
+  const int rc = dist_spgemm_rows(op, m_local, "kkamd_dist_spgemm_numeric");
+  if (rc) return rc;
+  return kkamd_spgemm_numeric(op->h, m_local, n, k, d_row_mapA_local, d_entriesA_local, d_valuesA_local, d_row_mapB, d_entriesB, d_valuesB, d_row_mapC_local,
+                              d_entriesC_local, d_valuesC_local, offset_type, value_type, stream);
+}
+int kkamd_dist_spgemm_query(const kkamd_dist_spgemm_t* op, const char* key, int64_t* value) {
+  if (!op || !key || !value) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spgemm_query: null argument");
+  const std::string k(key);
+  if (k == "row0") *value = op->offsets[(size_t)op->rank];
+  else if (k == "rows_local") *value = op->offsets[(size_t)op->rank + 1] - op->offsets[(size_t)op->rank];
+  else if (k == "rows_global") *value = op->offsets[(size_t)op->world];
+  else if (k == "c_nnz_local") *value = op->h->c_nnz;
+  else if (k == "mults_local") *value = op->h->mults;
+  else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spgemm_query: unknown key '%s'", key);
   return KKAMD_OK;
 }
 

@@ -1,7 +1,9 @@
 """1-D row-partitioned SpMV across the GPUs of one node -- a thin caller of the C ABI (kkamd_dist_spmv_*, include/kkamd.h,
 csrc/kk_dist.hip).  Rank r owns the contiguous row slab [offsets[r], offsets[r+1]) of A (local row_map, GLOBAL column
 indices), the matching slab of y and shard of x; the library exchanges the x entries a slab references (halo: grouped
-ncclSend / ncclRecv of the column range each slab touches; all-gather: every shard to every rank), overlaps the interior
+ncclSend / ncclRecv of the column range each slab touches; halo_set: of the column SET it touches, packed / scattered by two
+small kernels -- the general importer for slabs with scattered columns; all-gather: every shard to every rank, through the
+collective or, allgather_p2p, by world - 1 concurrent peer-to-peer pulls between two barriers), overlaps the interior
 rows with the exchange, and runs the planned local SpMV.  What happens here:
 
   * GPU (torch backend, process group "nccl"): the library's built-in RCCL transport; rank 0 obtains the 128-byte RCCL id from
@@ -18,7 +20,7 @@ from . import _capi
 from ._capi import check
 from .sparse import _ALGOS, _scalar_type
 
-_EXCHANGE = {"auto": 0, "halo": 1, "allgather": 2}
+_EXCHANGE = {"auto": 0, "halo": 1, "allgather": 2, "allgather_p2p": 3, "halo_set": 4}
 
 
 def slab_offsets(nrows, world, align=1):
@@ -44,13 +46,77 @@ def work_balanced_offsets(work_per_row, world):
     return offs
 
 
-def spgemm_row_slab(A_slab, B):
-    """Row-partitioned SpGEMM: rank r owns a contiguous row slab of A (local row_map) and the matching row slab of
-    C = A * B; B is replicated, so there is NO data-path communication (partition where the path shards).
-    With slabs balanced by multiplications (work_balanced_offsets) this is what makes BASELINE config C4 as specified
-    (R-MAT scale 22: nnz(C) = 7.2e10 = 863 GB) fit: 108 GB of C per GPU on eight GPUs."""
-    from .sparse import spgemm
-    return spgemm(A_slab, False, B, False)
+class DistSpgemm:
+    """Row-partitioned SpGEMM behind the C ABI (kkamd_dist_spgemm_*): rank r owns a contiguous row slab of A (local row_map) and
+    the matching row slab of C = A * B; B is replicated, so there is NO data-path communication (partition where the
+    path shards).  With slabs balanced by multiplications (partition) this is what makes BASELINE config 4 as specified (R-MAT
+    scale 22: nnz(C) = 7.2e10 = 863 GB) fit: ~108 GB of C per GPU on eight GPUs."""
+
+    @staticmethod
+    def partition(A, B, world):
+        """contiguous row slabs of A of near-equal multiplications, from the full A and B on this device: (offsets, mults per rank)"""
+        be, lib = A.backend, A.backend.lib
+        offs = (C.c_int64 * (world + 1))(); mults = (C.c_int64 * world)()
+        da, db = A.desc(), B.desc()
+        check(lib, lib.kkamd_dist_spgemm_partition(A.numRows(), da.d_row_map, da.d_entries, db.d_row_map, da.offset_type, world, offs, mults, be.stream()))
+        return [int(v) for v in offs], [int(v) for v in mults]
+
+    def __init__(self, offsets, rank, backend):
+        self.be, self.lib = backend, backend.lib
+        self.offsets, self.rank, self.world = [int(o) for o in offsets], int(rank), len(offsets) - 1
+        op = C.c_void_p()
+        check(self.lib, self.lib.kkamd_dist_spgemm_create(C.byref(op), self.world, self.rank, (C.c_int64 * (self.world + 1))(*self.offsets)))
+        self._op = op
+
+    def set(self, key, value):
+        check(self.lib, self.lib.kkamd_spgemm_set(C.c_void_p(self.lib.kkamd_dist_spgemm_handle(self._op)), key.encode(), float(value)))
+
+    def query(self, key):
+        v = C.c_int64(0)
+        check(self.lib, self.lib.kkamd_dist_spgemm_query(self._op, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    def symbolic(self, A_slab, B):
+        """row_map of the rank's slab of C; entries / values are allocated from the slab's nnz"""
+        from .sparse import CrsMatrix, _np_dtype
+        be = self.be
+        da, db = A_slab.desc(), B.desc()
+        m, n, k = A_slab.numRows(), A_slab.numCols(), B.numCols()
+        if n != B.numRows():
+            raise RuntimeError("DistSpgemm: A has %d columns, B %d rows" % (n, B.numRows()))
+        odt = _np_dtype(A_slab.graph.row_map)
+        rmC = be.empty(m + 1, odt)
+        nnz = C.c_int64(0)
+        check(self.lib, self.lib.kkamd_dist_spgemm_symbolic(self._op, m, n, k, da.d_row_map, da.d_entries, db.d_row_map, db.d_entries, be.ptr(rmC),
+                                                            da.offset_type, C.byref(nnz), be.stream()))
+        vdt = _np_dtype(A_slab.values)
+        return CrsMatrix(m, k, rmC, be.empty(max(nnz.value, 1), np.int32)[:nnz.value], be.empty(max(nnz.value, 1), vdt)[:nnz.value], backend=be)
+
+    def numeric(self, A_slab, B, C_slab):
+        be = self.be
+        da, db, dc = A_slab.desc(), B.desc(), C_slab.desc()
+        check(self.lib, self.lib.kkamd_dist_spgemm_numeric(self._op, A_slab.numRows(), A_slab.numCols(), B.numCols(), da.d_row_map, da.d_entries, da.d_values,
+                                                           db.d_row_map, db.d_entries, db.d_values, dc.d_row_map, dc.d_entries, dc.d_values,
+                                                           da.offset_type, da.value_type, be.stream()))
+        return C_slab
+
+    def __del__(self):
+        try:
+            if self._op:
+                self.lib.kkamd_dist_spgemm_destroy(self._op)
+        except Exception:
+            pass
+        self._op = None
+
+
+def spgemm_row_slab(A_slab, B, offsets=None, rank=0):
+    """one rank's slab of C = A * B through the row-partitioned operator (symbolic + numeric); without a partition the slab is
+    taken as the whole of a one-rank job"""
+    offs = offsets if offsets is not None else [0, A_slab.numRows()]
+    op = DistSpgemm(offs, rank, A_slab.backend)
+    Cs = op.symbolic(A_slab, B)
+    op.numeric(A_slab, B, Cs)
+    return Cs
 
 
 class _GlooTransport:
@@ -91,6 +157,51 @@ class _GlooTransport:
                 return 3
 
         self._ag, self._ex = _capi.ALL_GATHER_FN(all_gather), _capi.EXCHANGE_FN(exchange)     # keep the callbacks alive
+        self.struct = _capi.Transport(None, self._ag, self._ex)
+
+
+class _GlooDeviceTransport(_GlooTransport):
+    """kkamd_transport_t over a CPU process group for DEVICE buffers (staged through the host, device-synchronous): for ranks that
+    share one GPU -- where RCCL refuses to form a communicator -- e.g. the two-process GPU tests of the exchange modes."""
+
+    def __init__(self, group, world):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.world = torch, dist, group, world
+
+        def view(ptr, nbytes):
+            return torch.as_tensor(_DeviceView(ptr, nbytes, "|u1"), device="cuda")
+
+        def all_gather(ctx, d_send, d_recv, nbytes, stream):
+            try:
+                torch.cuda.synchronize()
+                outs = [torch.empty(int(nbytes), dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(outs, view(d_send, nbytes).cpu(), group=group)
+                view(d_recv, nbytes * world).copy_(torch.cat(outs))
+                torch.cuda.synchronize()
+                return 0
+            except Exception as e:             # never raise through the C frame
+                print("gloo device transport all_gather failed:", e, flush=True)
+                return 3
+
+        def exchange(ctx, nsend, d_send, send_bytes, send_peer, nrecv, d_recv, recv_bytes, recv_peer, stream):
+            try:
+                torch.cuda.synchronize()
+                ops = [dist.P2POp(dist.isend, view(d_send[i], send_bytes[i]).cpu(), int(send_peer[i]), group=group) for i in range(nsend)]
+                bufs = [torch.empty(int(recv_bytes[i]), dtype=torch.uint8) for i in range(nrecv)]
+                ops += [dist.P2POp(dist.irecv, bufs[i], int(recv_peer[i]), group=group) for i in range(nrecv)]
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                for i in range(nrecv):
+                    view(d_recv[i], recv_bytes[i]).copy_(bufs[i])
+                torch.cuda.synchronize()
+                return 0
+            except Exception as e:
+                print("gloo device transport exchange failed:", e, flush=True)
+                return 3
+
+        self._ag, self._ex = _capi.ALL_GATHER_FN(all_gather), _capi.EXCHANGE_FN(exchange)
         self.struct = _capi.Transport(None, self._ag, self._ex)
 
 
@@ -144,7 +255,7 @@ class DistSpmv:
         check(self.lib, self.lib.kkamd_dist_spmv_create(C.byref(op), C.byref(d), offs, self.world, self.rank, id_buf, tr_ptr,
                                                         _ALGOS[algo], _EXCHANGE[exchange], 1 if overlap else 0, vt, self.be.stream()))
         self._op = op
-        self.exchange_mode = ("local", "halo", "allgather")[self.query("exchange")]
+        self.exchange_mode = ("local", "halo", "allgather", "allgather_p2p", "halo_set")[self.query("exchange")]
         self.exchange_bytes = self.query("exchange_bytes")
         self.interior_rows = self.query("interior_rows")
 

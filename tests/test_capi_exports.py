@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_header_symbols_are_exported():
     kk = kk_loader.load()
     hdr = open(os.path.join(ROOT, "include", "kkamd.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(kkamd_[a-z0-9_]+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|const char\*|kkamd_spgemm_handle_t\*)\s+(kkamd_[a-z0-9_]+)\s*\(", hdr, re.M))
     assert len(declared) >= 18
     lib = C.CDLL(kk.LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]

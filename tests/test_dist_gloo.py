@@ -84,35 +84,119 @@ def test_row_partitioned_spmv_world2(ragged, exchange):
                 assert mode == "allgather"
 
 
+def _scattered_matrix(n, seed=5):
+    """a band of +-2 plus, in every tenth row, two far columns anywhere: the column RANGE of a slab is everything, the column SET small"""
+    import oracle
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for r in range(n):
+        c = {max(0, r - 2), max(0, r - 1), r, min(n - 1, r + 1), min(n - 1, r + 2)}
+        if r % 10 == 3: c |= {int(v) for v in rng.integers(0, n, size=2)}
+        for v in sorted(c): rows.append(r); cols.append(v)
+    rows = np.array(rows); cols = np.array(cols, dtype=np.int32)
+    rm = np.zeros(n + 1, dtype=np.int64); np.add.at(rm, rows + 1, 1); rm = np.cumsum(rm)
+    return oracle.Crs(n, n, rm, cols, 0.5 + rng.random(cols.size))
+
+
+def _worker_set(rank, world, port, exchange, ret):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import kk_loader
+    import oracle
+    from emu import emu_backend
+    kk = kk_loader.load()
+    from kokkos_kernels_amd.dist import DistSpmv
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = emu_backend.backend()
+    n = 700
+    A0 = _scattered_matrix(n)
+    offs = [0, 230, 470, n] if world == 3 else [0, 330, n]
+    r0, r1 = offs[rank], offs[rank + 1]
+    sl = slice(A0.row_map[r0], A0.row_map[r1])
+    A = kk.CrsMatrix.from_host(r1 - r0, n, A0.row_map[r0:r1 + 1] - A0.row_map[r0], A0.entries[sl], A0.values[sl], backend=be)
+    rng = np.random.default_rng(1)
+    x = rng.random(n); y0 = rng.random(n)
+    op = DistSpmv(A, offs, rank, to_backend=lambda t: t.numpy(), exchange=exchange)
+    err = 0.0
+    for scale, alpha, beta in ((1.0, 2.0, 0.5), (3.0, 1.0, 0.0), (-1.0, 1.0, 1.0)):      # x changes between the calls: stale halo entries would show
+        xs = torch.from_numpy(scale * x[r0:r1]); ys = torch.from_numpy(y0[r0:r1].copy())
+        op.apply(alpha, xs, beta, ys)
+        exp = oracle.spmv_serial("N", A0, alpha, scale * x, beta, y0.copy())[r0:r1]
+        err = max(err, float(np.abs(ys.numpy() - exp).max()))
+    # what the importer must move: the distinct off-slab columns of the slab
+    want = np.unique(A0.entries[sl]); want = want[(want < r0) | (want >= r1)]
+    ret[rank] = (err, oracle.spmv_max_error(A0, 3.0, 1.0, max_val=2.0), op.exchange_mode, op.exchange_bytes, int(want.size) * 8, op.query("recvs"), op.query("parts"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("exchange", ["auto", "halo_set"])
+def test_column_set_halo(world, exchange):
+    """the general importer.  A slab whose columns are scattered gets the entries of x its SET of off-slab columns
+    names (per-peer index lists agreed once, pack kernel, point-to-point pieces, scatter kernel) -- auto picks it because the
+    column range would be the whole vector; results against the serial oracle over three calls with changing x"""
+    import torch.multiprocessing as mp
+    port = 30500 + (os.getpid() % 1500) + 31 * world + (5 if exchange == "auto" else 0)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_set, args=(world, port, exchange, ret), nprocs=world, join=True)
+        assert len(ret) == world
+        for r in range(world):
+            err, tol, mode, nbytes, want_bytes, recvs, parts = ret[r]
+            assert err <= tol, "rank %d: %g > %g" % (r, err, tol)
+            assert mode == "halo_set", (r, mode)
+            assert nbytes == want_bytes and nbytes < 0.25 * 8 * 700, (r, nbytes, want_bytes)
+            assert 1 <= recvs <= world - 1
+
+
+def _check_spgemm_slabs(be, kk, oracle, R, world):
+    """the slabs of C computed independently through the C ABI (kkamd_dist_spgemm_*) concatenate to the full product; the
+    partition balances multiplications"""
+    from kokkos_kernels_amd.dist import DistSpgemm, work_balanced_offsets
+    lenB = np.diff(R.row_map)
+    flops = np.array([lenB[R.entries[R.row_map[i]:R.row_map[i + 1]]].sum() for i in range(R.nrows)])
+    B = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, backend=be)
+    offs, mults = DistSpgemm.partition(B, B, world)
+    assert offs[0] == 0 and offs[-1] == R.nrows and all(a <= b for a, b in zip(offs, offs[1:]))
+    assert mults == [int(flops[a:b].sum()) for a, b in zip(offs, offs[1:])] and sum(mults) == int(flops.sum())
+    assert max(mults) <= flops.sum() / world + flops.max()
+    ref = work_balanced_offsets(flops, world)                  # the host helper cuts at the same places, give or take a row
+    assert all(abs(a - b) <= 1 for a, b in zip(offs, ref)), (offs, ref)
+    gold = oracle.spgemm(R, R)
+    rm_all, ent_all, val_all = [0], [], []
+    for rank, (a, b) in enumerate(zip(offs, offs[1:])):
+        sl = slice(R.row_map[a], R.row_map[b])
+        A_slab = kk.CrsMatrix.from_host(b - a, R.ncols, R.row_map[a:b + 1] - R.row_map[a], R.entries[sl], R.values[sl], backend=be)
+        op = DistSpgemm(offs, rank, be)
+        Cs = op.symbolic(A_slab, B)
+        assert op.query("rows_local") == b - a and op.query("row0") == a and op.query("rows_global") == R.nrows
+        assert op.query("c_nnz_local") == Cs.nnz() and op.query("mults_local") == mults[rank]
+        op.numeric(A_slab, B, Cs)
+        op.numeric(A_slab, B, Cs)                              # numeric reuse on the slab
+        r, e, v = Cs.to_host()
+        rm_all += list(np.asarray(r[1:], dtype=np.int64) + rm_all[-1]); ent_all.append(e); val_all.append(v)
+        if b - a > 0:
+            with pytest.raises(kk.KkamdError):                 # a slab of the wrong height is refused
+                wrong = kk.CrsMatrix.from_host(b - a - 1, R.ncols, (R.row_map[a:b] - R.row_map[a]), R.entries[R.row_map[a]:R.row_map[b - 1]],
+                                               R.values[R.row_map[a]:R.row_map[b - 1]], backend=be)
+                op.symbolic(wrong, B)
+    got = oracle.Crs(R.nrows, R.ncols, np.array(rm_all), np.concatenate(ent_all), np.concatenate(val_all))
+    ok, msg = oracle.is_same_matrix(got, gold)
+    assert ok, msg
+
+
 def test_row_partitioned_spgemm_slabs():
-    """SpGEMM shards by rows of A with B replicated and no exchange at all: the slabs of C, computed independently
-    (here one after the other under the emulator), concatenate to the full product; slabs are balanced by work."""
+    """SpGEMM shards by rows of A with B replicated and no exchange at all (kkamd_dist_spgemm_*, here under the emulator, one rank
+    after the other)"""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import kk_loader
     import oracle
     from emu import emu_backend
     kk = kk_loader.load()
-    from kokkos_kernels_amd.dist import work_balanced_offsets, spgemm_row_slab
-    be = emu_backend.backend()
-    R = oracle.rmat(9, 8)
-    lenB = np.diff(R.row_map)
-    flops = np.array([lenB[R.entries[R.row_map[i]:R.row_map[i + 1]]].sum() for i in range(R.nrows)])
-    offs = work_balanced_offsets(flops, 4)
-    assert offs[0] == 0 and offs[-1] == R.nrows and all(a <= b for a, b in zip(offs, offs[1:]))
-    per = [flops[a:b].sum() for a, b in zip(offs, offs[1:])]
-    assert max(per) <= 1.5 * flops.sum() / 4 + flops.max()
-    B = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, backend=be)
-    gold = oracle.spgemm(R, R)
-    rm_all, ent_all, val_all = [0], [], []
-    for a, b in zip(offs, offs[1:]):
-        sl = slice(R.row_map[a], R.row_map[b])
-        A_slab = kk.CrsMatrix.from_host(b - a, R.ncols, R.row_map[a:b + 1] - R.row_map[a], R.entries[sl], R.values[sl], backend=be)
-        Cs = spgemm_row_slab(A_slab, B)
-        r, e, v = Cs.to_host()
-        rm_all += list(np.asarray(r[1:], dtype=np.int64) + rm_all[-1]); ent_all.append(e); val_all.append(v)
-    got = oracle.Crs(R.nrows, R.ncols, np.array(rm_all), np.concatenate(ent_all), np.concatenate(val_all))
-    ok, msg = oracle.is_same_matrix(got, gold)
-    assert ok, msg
+    _check_spgemm_slabs(emu_backend.backend(), kk, oracle, oracle.rmat(9, 8), 4)
 
 
 def test_bench_two_process_flow_emulated():

@@ -474,6 +474,13 @@ def test_dist_operator_on_device_with_loopback_transport(be):
     del op
 
 
+def test_row_partitioned_spgemm_through_the_c_abi(be):
+    """kkamd_dist_spgemm_* on the GPU: work-balanced partition from the device, the four slabs of C computed one after the other
+    concatenate to the oracle's product (R-MAT scale 12), numeric reuse on every slab, a slab of the wrong height refused"""
+    from test_dist_gloo import _check_spgemm_slabs
+    _check_spgemm_slabs(be, pc.kk, oracle, oracle.rmat(12, 8), 4)
+
+
 def test_transposed_modes_through_cached_explicit_transpose(be):
     import torch
     for A0 in (oracle.laplace3d("FE", 60, 50, 40), oracle.rmat(14, 16)):                  # >= 1e6 nnz: the cached-transpose path
