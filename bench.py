@@ -236,7 +236,7 @@ def main():
                          "tests/emu, a tiny grid -- to exercise the multi-process control flow without GPUs (numbers are meaningless)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1, halo exchange: do not split the slab into interior / boundary rows (no compute-communication overlap)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "halo_set", "allgather", "allgather_p2p"],
                     help="N > 1: how the x entries a slab references reach it (auto = column-range halo when it is smaller)")
     args = ap.parse_args()
 
@@ -364,11 +364,23 @@ def main():
             return (time.perf_counter() - t_) * 1e3 / n
         xchg = {}
         ops = {op.exchange_mode: op}
-        other = "allgather" if op.exchange_mode == "halo" else "halo"
-        try:
-            ops[other] = DistSpmv(A, offsets, rank, algo=args.algo, exchange=other, overlap=not args.no_overlap, to_backend=tb if emu else None)
-        except Exception as e:                     # e.g. not enough memory for a second operator: report what there is
-            xchg["note"] = "no %s operator: %s" % (other, str(e)[:80])
+        # every exchange the library has, side by side: the column-range halo, the column-set halo, the all-gather through the
+        # collective and the all-gather by peer-to-peer pulls (the fallback if RCCL's schedule is a ring; it maps
+        # device memory between processes, so not under --emulate)
+        for other in ("halo", "halo_set", "allgather") + (() if emu else ("allgather_p2p",)):
+            if other in ops: continue
+            o_new, ok_ = None, 1.0
+            try:
+                o_new = DistSpmv(A, offsets, rank, algo=args.algo, exchange=other, overlap=not args.no_overlap, to_backend=tb if emu else None)
+            except Exception as e:                 # e.g. not enough memory for another operator: report what there is
+                ok_ = 0.0
+                xchg.setdefault("notes", []).append("no %s operator on rank %d: %s" % (other, rank, str(e)[:120]))
+            okt = torch.tensor([ok_], device=dev, dtype=torch.float64)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)          # an operator only counts when EVERY rank has it (else the collectives would not match)
+            if okt.item() == 1.0: ops[other] = o_new
+            else:
+                del o_new
+                if ok_ == 1.0: xchg.setdefault("notes", []).append("no %s operator: another rank could not create it" % other)
         for name, o in ops.items():
             xs_ = o.x_local()
             if o is not op: xs_.copy_(x_shard)

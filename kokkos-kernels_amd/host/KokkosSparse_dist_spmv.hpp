@@ -11,7 +11,7 @@
 
 namespace KokkosSparse { namespace Experimental {
 
-enum DistExchange { DIST_EXCHANGE_AUTO = 0, DIST_EXCHANGE_HALO = 1, DIST_EXCHANGE_ALLGATHER = 2 };
+enum DistExchange { DIST_EXCHANGE_AUTO = 0, DIST_EXCHANGE_HALO = 1, DIST_EXCHANGE_ALLGATHER = 2, DIST_EXCHANGE_ALLGATHER_P2P = 3, DIST_EXCHANGE_HALO_SET = 4 };
 
 template <class AMatrix>
 class DistributedSpMV {
