@@ -845,9 +845,10 @@ template <class OffT, class AT>
 __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
                                                           const int32_t* __restrict__ entries, const AT* __restrict__ values,
                                                           const double* __restrict__ X, int64_t xs0, int64_t xs1, double* __restrict__ Y,
-                                                          int64_t ys0, int64_t ys1, double alpha, double beta) {
+                                                          int64_t ys0, int64_t ys1, double alpha, double beta, int ncv) {
   int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
-  const int j = threadIdx.x & 15;
+  const int j  = threadIdx.x & 15;                     // the lane's entry of a chunk of the row, and its column of the block
+  const int jc = j < ncv ? j : ncv - 1;                // a block of fewer than 16 columns: the spare lanes read a valid column and store nothing
   const bool live = idx < n_list;                      // no early return: the shuffles below want whole groups
   if (!live) idx = n_list - 1;
   const int64_t r = list[idx];
@@ -861,19 +862,23 @@ __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const 
     for (int q = 0; q < 16; ++q) {
       const int32_t col = __shfl(my_col, q, 16);
       const double v    = __shfl(my_val, q, 16);
-      acc += v * X[(int64_t)col * xs0 + j * xs1];
+      acc += v * X[(int64_t)col * xs0 + jc * xs1];
     }
   }
-  if (!live) return;
+  if (!live || j >= ncv) return;
   double* yp = Y + r * ys0 + j * ys1;
   *yp = (beta == 0.0) ? alpha * acc : beta * (*yp) + alpha * acc;
 }
 
-template <class OffT, class AT, int NG, unsigned PRES, bool BETA0, bool XROW>
+// PART: a block of ncv < 16 right-hand sides (the remainder of a width that is no multiple of 16, or a narrow multivector): lane c
+// still carries the columns 2 c and 2 c + 1, columns past the block are clamped to its last one when X is read (the same cache
+// lines again: no extra traffic) and masked when Y is read or written.  Row-major X with an even ncv keeps the 16-byte loads
+// (XROW: pieces past the block re-read its last piece); anything else goes element by element.
+template <class OffT, class AT, int NG, unsigned PRES, bool BETA0, bool XROW, bool PART = false>
 __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask, const AT* __restrict__ values, Mv4Groups G,
                                                                   const double* __restrict__ X, int64_t xs0, int64_t xs1, double* __restrict__ Y,
                                                                   int64_t ys0, int64_t ys1, double alpha, double beta, int y_vec_ok, int nx,
-                                                                  int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc) {
+                                                                  int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc, int ncv) {
   constexpr int RI = kMv4RI, RJ = kMv4RJ, W = RI + 2, SLABR = (RJ + 2) * W, SLABB = SLABR * 128, NT = kMv4Threads;
   constexpr int ROWS = NT / 8;                         // row PAIRS per plane: a lane owns the lattice rows (i, j) and (i, j + 1)
   constexpr int NP = SLABR * 8, NXP = (NP + NT - 1) / NT;   // 16-byte pieces per slab, per thread
@@ -910,7 +915,9 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     wbase[u] = arow + r0; mbase[u] = amask + r0;
     ybase[u] = Y + r0 * ys0 + (2 * c) * ys1;
   }
+  const bool ycol0 = !PART || 2 * c < ncv, ycol1 = !PART || 2 * c + 1 < ncv;      // which of the lane's two columns the block has
   const double* xbase[NXP];
+  unsigned xsec_none = 0;
   bool x_in[NXP];                                      // the piece is a lattice point of the plane (else the halo holds 0)
   KK_UNROLL
   for (int it = 0; it < NXP; ++it) {
@@ -920,7 +927,9 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     const int jr = j0 - 1 + xr / W, ir = i0 - 1 + xr % W;
     x_in[it] = jr >= 0 && jr < ny && ir >= 0 && ir < nx;
     const int jq = jr < 0 ? 0 : (jr > ny - 1 ? ny - 1 : jr), iq = ir < 0 ? 0 : (ir > nx - 1 ? nx - 1 : ir);
-    xbase[it] = X + ((int64_t)jq * S1 + iq) * xs0 + (part * 2) * xs1;
+    const int col0 = !PART ? 2 * part : (XROW ? (2 * part + 1 < ncv ? 2 * part : ncv - 2) : (2 * part < ncv ? 2 * part : ncv - 1));
+    xbase[it] = X + ((int64_t)jq * S1 + iq) * xs0 + col0 * xs1;
+    if (PART && !XROW && 2 * part + 1 >= ncv) xsec_none |= 1u << it;       // the piece's second column is past the block: it reads the first again
   }
   auto plane_clamped = [&](int kp) -> int64_t { return kp < 0 ? 0 : (kp > nz - 1 ? nz - 1 : kp); };   // scalar
   auto conforms = [&](int k, int u, OffT w) { return lane_ok[u] && k < kend && w >= 0; };
@@ -934,6 +943,7 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     KK_UNROLL
     for (int it = 0; it < NXP; ++it) {
       if constexpr (XROW) rx[it] = *reinterpret_cast<const XV*>(xbase[it] + off);        // row-major X: the piece is 16 contiguous bytes
+      else if constexpr (PART) { rx[it][0] = xbase[it][off]; rx[it][1] = xbase[it][off + (((xsec_none >> it) & 1u) ? 0 : xs1)]; }
       else { rx[it][0] = xbase[it][off]; rx[it][1] = xbase[it][off + xs1]; }               // any strides (LayoutLeft: a wave's 8 pieces of a column are 64 contiguous bytes)
     }
   };
@@ -999,7 +1009,8 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     for (int u = 0; u < 2; ++u) {
       if (conforms(k, u, w[u])) {
         const double* yp = y_ptr(k, u);
-        if (y_vec_ok) yo[u] = *reinterpret_cast<const XV*>(yp); else { yo[u][0] = yp[0]; yo[u][1] = yp[ys1]; }
+        if constexpr (PART) { if (ycol1 && y_vec_ok) yo[u] = *reinterpret_cast<const XV*>(yp); else { if (ycol0) yo[u][0] = yp[0]; if (ycol1) yo[u][1] = yp[ys1]; } }
+        else if (y_vec_ok) yo[u] = *reinterpret_cast<const XV*>(yp); else { yo[u][0] = yp[0]; yo[u][1] = yp[ys1]; }
       }
     }
   };
@@ -1081,7 +1092,8 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
         if (conforms(k, u, w_cur[u])) {
           double* yp = y_ptr(k, u);
           if constexpr (!BETA0) { out[u][0] += beta * yold[u][0]; out[u][1] += beta * yold[u][1]; }
-          if (y_vec_ok) *reinterpret_cast<XV*>(yp) = out[u]; else { yp[0] = out[u][0]; yp[ys1] = out[u][1]; }
+          if constexpr (PART) { if (ycol1 && y_vec_ok) *reinterpret_cast<XV*>(yp) = out[u]; else { if (ycol0) yp[0] = out[u][0]; if (ycol1) yp[ys1] = out[u][1]; } }
+          else if (y_vec_ok) *reinterpret_cast<XV*>(yp) = out[u]; else { yp[0] = out[u][0]; yp[ys1] = out[u][1]; }
         }
       }
       __syncthreads();
@@ -1196,28 +1208,33 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
 
 template <class OffT, class AT>
 static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
-                      double alpha, double beta, hipStream_t st) {
+                      double alpha, double beta, hipStream_t st, int ncv = 16) {
   const kkamd_mv4_plan* m = plan->mv4;
   const size_t slabs = 4 * (size_t)((kMv4RJ + 2) * (kMv4RI + 2) * 128), rows = kMv4Threads / 8;
   const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
 #ifndef KK_EMU
-#define KK_MV4_ATTR(NE, FL, B0, XR) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+#define KK_MV4_ATTR(NE, FL, B0, XR, PT) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR, PT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
 #else
-#define KK_MV4_ATTR(NE, FL, B0, XR) (void)0
+#define KK_MV4_ATTR(NE, FL, B0, XR, PT) (void)0
 #endif
-#define KK_MV4B(NE, FL, B0, XR)                                                                                                    \
+#define KK_MV4B(NE, FL, B0, XR, PT)                                                                                                \
   do {                                                                                                                          \
     const size_t lds = slabs + 4 * rows * mv4_pitch(3 * NE + (NE & 1), (int)sizeof(AT)) * sizeof(AT);                            \
-    KK_MV4_ATTR(NE, FL, B0, XR);                                                                                                  \
-    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,            \
+    KK_MV4_ATTR(NE, FL, B0, XR, PT);                                                                                              \
+    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR, PT>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,        \
               (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values, m->grp, X, xs0, xs1, Y, ys0, ys1, alpha, \
-              beta, yv, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc);                                               \
+              beta, yv, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc, ncv);                                          \
   } while (0)
 #define KK_MV4(NE, FL)                                                                                                          \
   do {                                                                                                                          \
-    if (beta == 0.0) { if (xrow) KK_MV4B(NE, FL, true, true); else KK_MV4B(NE, FL, true, false); }                               \
-    else { if (xrow) KK_MV4B(NE, FL, false, true); else KK_MV4B(NE, FL, false, false); }                                         \
+    if (part) {                                                                                                                 \
+      if (beta == 0.0) { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, true, true, true); else KK_MV4B(NE, FL, true, false, true); }  \
+      else { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, false, true, true); else KK_MV4B(NE, FL, false, false, true); }            \
+    }                                                                                                                           \
+    else if (beta == 0.0) { if (xrow) KK_MV4B(NE, FL, true, true, false); else KK_MV4B(NE, FL, true, false, false); }            \
+    else { if (xrow) KK_MV4B(NE, FL, false, true, false); else KK_MV4B(NE, FL, false, false, false); }                           \
   } while (0)
+  const bool part = ncv < 16;
   const bool xrow = xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0);
   unsigned pat = 0;                                    // 3 bits per group: which of dj = -1, 0, 1 it holds
   for (int g = 0; g < m->grp.ng; ++g) pat |= (unsigned)m->grp.pres[g] << (3 * g);
@@ -1233,7 +1250,7 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   KK_LAUNCH_CHECK();
   if (m->n_nc > 0) {
     KK_LAUNCH((mv4_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1, Y, ys0, ys1, alpha, beta);
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1, Y, ys0, ys1, alpha, beta, ncv);
     KK_LAUNCH_CHECK();
   }
   return KKAMD_OK;
@@ -1450,7 +1467,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
     // matrices that verify as a radius-1 lattice stencil; the analysis happens on the first such call.  X and Y keep their
     // strides (row-major X is read with 16-byte loads, anything else with two 8-byte loads per piece): nothing is packed
     if constexpr (sizeof(YT) == 8) {
-      if (plan && plan->tile != 0 && (mvk == 0 || mvk == 4) && nvec >= 16 && plan->entries == A->d_entries) {
+      if (plan && plan->tile != 0 && (mvk == 0 || mvk == 4) && nvec >= plan->tune.mv4_min_nvec && plan->entries == A->d_entries) {
         if (!plan->mv4 && !plan->mv4_tried) {
           int rc = mv4_plan_build<OffT>(plan, A, st);
           if (rc) return rc;
@@ -1462,11 +1479,8 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
             if (rc) return rc;
           }
           if (c0 == nvec) return KKAMD_OK;
-          // the last nvec % 16 columns.  beta = 0: one more pass over the LAST 16 columns (it recomputes what the previous pass
-          // wrote to the columns they share -- the same values); otherwise the kernels below (fewer than 16 columns never come back here)
-          if (beta_d == 0.0)
-            return launch_mv4<OffT, AT>(plan, A, (const double*)X + (nvec - 16) * xs1, xs0, xs1, (double*)Y + (nvec - 16) * ys1, ys0, ys1, (double)alpha, 0.0, st);
-          return spmv_mv_typed<OffT, AT, YT>(plan, A, trans, alpha_d, X + c0 * xs1, xs0, xs1, beta_d, Y + c0 * ys1, ys0, ys1, nvec - c0, st);
+          // the last nvec % 16 columns (or a multivector narrower than 16): one pass of the partial-block form of the kernel
+          return launch_mv4<OffT, AT>(plan, A, (const double*)X + c0 * xs1, xs0, xs1, (double*)Y + c0 * ys1, ys0, ys1, (double)alpha, (double)beta, st, (int)(nvec - c0));
         }
       }
     }

@@ -34,6 +34,7 @@ struct SpmvTuning {
   int mv_strip_min_kb = 3000;  // ... strips engage when three periods' worth of X rows exceed this (an XCD's L2 holds 4 MB)
   int mv_strip_l2_kb  = 2500;  // ... and are sized so that three periods' worth of a strip's X rows stay below this
   int mv_glds        = 1;  // rank-2 LDS-staged kernel: X window through global_load_lds (1) or through registers (0)
+  int mv4_min_nvec   = 4;  // narrowest multivector the plane-marching kernel takes (a block of fewer than 16 columns runs its partial-block form)
   int mv4_wg_per_cu  = 8;  // rank-2 plane-marching kernel: workgroups per CU the k-chunking aims for (one is resident at a time)
   int march          = 0;  // rank 1 on the plane-marching analysis (lattice stencils, fp64 vectors): 0 off, 1 on
   int march_planes   = 20; // ... planes a workgroup marches (its k-chunk)

@@ -153,7 +153,7 @@ def test_mv4_plane_marching(be):
     # per call, Y strided), alpha / beta, beta = 0 over NaNs, 64-bit offsets, fp32 values, k-chunks from 1 to nz / 4
     combos = ((16, "C", "C", 1.5, 0.5, np.int32), (16, "C", "C", 1.0, 0.0, np.int64), (32, "C", "C", -1.0, 0.0, np.int32),
               (16, "F", "F", 2.0, 0.0, np.int32), (16, "F", "C", 1.0, -1.0, np.int32), (48, "C", "F", 1.0, 1.0, np.int32),
-              (21, "C", "C", 0.5, 0.0, np.int32), (37, "F", "F", 1.0, 2.0, np.int32))     # 16 + 5, 32 + 5: the remainder takes the gather kernel
+              (21, "C", "C", 0.5, 0.0, np.int32), (37, "F", "F", 1.0, 2.0, np.int32))     # 16 + 5, 32 + 5: the remainder is a partial block
     for ci, (name, A0, left) in enumerate(pc.mv4_cases()):
         for nvec, xo, yo, alpha, beta, off in (combos if ci < 3 else (combos[0], combos[3], combos[6])):    # all of them on the first three matrices
             h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0), offset_dtype=off)
@@ -170,9 +170,15 @@ def test_mv4_plane_marching(be):
     h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
                          x_special={0: np.inf, 33 * 6 * 10 + 5: -np.inf, A0.nrows - 1: np.nan, 33 * 6 * 7 + 33 * 2 + 16: np.inf})
     assert h.query("mv4_workgroups") > 0
-    # not its matrices / widths: no far stride (2-D), too few lattice rows, 8 right-hand sides, no analysis, the gather kernel asked for
+    # narrow multivectors and remainders run the partial-block form (columns past the block clamped on the X side, masked on the Y side):
+    # every width from 4 to 15, both layouts, beta != 0 over the masked columns' neighbours
+    for nvec in (4, 5, 8, 11, 12, 15):
+        for xo, yo, beta in (("C", "C", 0.0), ("F", "F", 0.5), ("C", "F", -1.0)):
+            h = pc.check_spmv_mv(be, A0, nvec, "N", 1.5, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0))
+            assert h.query("mv4_workgroups") > 0, (nvec, xo, yo)
+    # not its matrices / widths: no far stride (2-D), too few lattice rows, 3 right-hand sides (below mv4_min_nvec), no analysis, the gather kernel asked for
     for A1, nvec, algo, knobs in ((oracle.laplace2d("FE", 130, 41), 16, "SPMV_DEFAULT", None), (oracle.laplace3d("FE", 12, 12, 12), 16, "SPMV_DEFAULT", None),
-                                  (A0, 8, "SPMV_DEFAULT", None), (A0, 16, "SPMV_FAST_SETUP", None), (A0, 16, "SPMV_DEFAULT", {"mv_kernel": 2}),
+                                  (A0, 3, "SPMV_DEFAULT", None), (A0, 8, "SPMV_DEFAULT", {"mv4_min_nvec": 16}), (A0, 16, "SPMV_FAST_SETUP", None), (A0, 16, "SPMV_DEFAULT", {"mv_kernel": 2}),
                                   (oracle.random_crs(5000, 5000, 9, variance=3, seed=5), 16, "SPMV_DEFAULT", None)):
         h = pc.check_spmv_mv(be, A1, nvec, "N", 1.0, 0.0, "C", "C", algo=algo, knobs=knobs, max_val=32.0)
         assert h.query("mv4_workgroups") == 0

@@ -1,5 +1,5 @@
 import json, os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, kk_loader
 kk = kk_loader.load()
 def timeit(fn, it=8):
@@ -12,7 +12,7 @@ def timeit(fn, it=8):
     return a.elapsed_time(b) / it
 A = kk.laplace_matrix("FE", 300, 300, 300)
 nnz, rows = A.nnz(), A.numRows()
-for nv in (32, 48, 24, 8):
+for nv in (4, 8, 12, 24, 32, 40):
     X = torch.rand(rows, nv, dtype=torch.float64, device="cuda"); Y = torch.zeros(rows, nv, dtype=torch.float64, device="cuda")
     alg = nnz * 12 + (rows + 1) * 4 + 2 * rows * nv * 8
     res = {}
