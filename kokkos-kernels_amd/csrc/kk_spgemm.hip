@@ -91,6 +91,8 @@ struct SpgemmTuning {
 #endif
   int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
+  int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
+  int col_quads      = 1;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads (0 = one 4-byte load per product)
   int val_hub_flat   = 0;         // 1 = A rows above kValLa through the flat value kernel too (measured slower, see numeric_typed)
   int val_kernel     = 2;         // dense rows with short A rows: 2 = flat walk with the lists cut per window group (default), 1 = wave-per-list streaming
 };
@@ -400,6 +402,84 @@ __device__ __forceinline__ void flat_products_v(int64_t row, const OffT* __restr
   flat_products_impl<NT, OffT, VT>(row, rmA, entA, rmB, entB, valB, sc, f);
 }
 
+// Columns only, 16 bytes at a time (the dense-row bitmap kernels: symbolic count and entries(C)).  The flat walk above issues one
+// 4-byte load per product; the bitmap kernels are bound by how many loads a work-item keeps in flight (16 waves per CU around one
+// 128 KB bitmap: R-MAT scale 20, 2.0e10 products in 57 ms = 350 G products/s, 1.4 TB/s), not by bytes.  Here the unit of work is
+// an ALIGNED quad of entries(B): a B row [b0, b1) is covered by the quads (b0 >> 2) .. ((b1 + 3) >> 2) - 1, a scan of the quad
+// counts lets work-item q take Q neighbouring quads per step -- one 16-byte load each, four times the products per load
+// instruction -- and the lanes of a quad that lie before b0 (they belong to the previous row) or past b1 are masked.  The quad at
+// the end of a row is read entry by entry (a 16-byte load there could reach past the end of the array).  f(column).
+template <int NT> struct FlatScratchQ {
+  long long pre[NT + 1];    // quad offset of each A entry of the chunk
+  long long b0[NT], b1[NT]; // its B row
+  long long wave[NT / 64];
+};
+template <int NT, class OffT, class F>
+__device__ __forceinline__ void flat_columns_quads(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                   const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, FlatScratchQ<NT>& sc, F f) {
+#ifndef KK_COL_QUADS
+#define KK_COL_QUADS 4
+#endif
+  constexpr int Q = KK_COL_QUADS;
+  const int t = threadIdx.x;
+  const int64_t a_beg = (int64_t)rmA[row], a_end = (int64_t)rmA[row + 1];
+  for (int64_t chunk = a_beg; chunk < a_end; chunk += NT) {
+    const int n = (int)(a_end - chunk < NT ? a_end - chunk : NT);
+    long long nq = 0, b0 = 0, b1 = 0;
+    if (t < n) {
+      const int32_t c = entA[chunk + t];
+      b0 = (long long)rmB[c]; b1 = (long long)rmB[c + 1];
+      if (b1 > b0) nq = ((b1 + 3) >> 2) - (b0 >> 2);
+    }
+    long long tot;
+    const long long excl = block_exclusive_scan_n<long long, NT>(nq, &tot, sc.wave);
+    if (t < n) { sc.pre[t] = excl; sc.b0[t] = b0; sc.b1[t] = b1; }
+    if (t == 0) sc.pre[n] = tot;
+    __syncthreads();
+    auto find = [&](long long q) {      // largest s in [0, n) with pre[s] <= q
+      int lo = 0, len2 = n;
+      while (len2 > 1) { const int half = len2 >> 1; lo += (sc.pre[lo + half] <= q) ? half : 0; len2 -= half; }
+      return lo;
+    };
+    for (long long base = 0; base < tot; base += (long long)NT * Q) {
+      const long long q0 = base + (long long)t * Q;
+      int seg = q0 < tot ? find(q0) : 0;
+      long long at[Q], lo[Q], hi[Q];
+      KK_UNROLL
+      for (int u = 0; u < Q; ++u) {
+        const long long q = q0 + u;
+        at[u] = -1; lo[u] = 0; hi[u] = 0;
+        if (q < tot) {
+          while (q >= sc.pre[seg + 1]) ++seg;            // also steps over empty B rows; q < tot = pre[n] ends it
+          const long long sb0 = sc.b0[seg], sb1 = sc.b1[seg];
+          at[u] = (((sb0 >> 2) + (q - sc.pre[seg])) << 2);
+          lo[u] = sb0 > at[u] ? sb0 : at[u];
+          hi[u] = sb1 < at[u] + 4 ? sb1 : at[u] + 4;
+        }
+      }
+      int col[Q][4];
+      KK_UNROLL
+      for (int u = 0; u < Q; ++u) {
+        if (at[u] < 0) continue;
+        if (hi[u] == at[u] + 4) {                        // the whole quad lies before the end of the row: one 16-byte load
+          const int4 v = *reinterpret_cast<const int4*>(entB + at[u]);
+          col[u][0] = v.x; col[u][1] = v.y; col[u][2] = v.z; col[u][3] = v.w;
+        } else {
+          KK_UNROLL
+          for (int e = 0; e < 4; ++e) col[u][e] = (at[u] + e >= lo[u] && at[u] + e < hi[u]) ? entB[at[u] + e] : -1;
+        }
+      }
+      KK_UNROLL
+      for (int u = 0; u < Q; ++u) {
+        if (at[u] < 0) continue;
+        KK_UNROLL
+        for (int e = 0; e < 4; ++e) if (at[u] + e >= lo[u] && at[u] + e < hi[u]) f(col[u][e]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Wave-wide flat iteration (wave-per-row kernels): the same idea as flat_products for one wave -- lane l looks up the
 // l-th A entry of the row (all B row lookups of up to 64 entries in ONE dependent chain instead of one chain per group
 // of entries), a shuffle scan turns the lengths into product offsets kept in wave-private LDS, then lane (q mod 64)
@@ -614,12 +694,14 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
                                                                         OffT* __restrict__ counts, const OffT* __restrict__ rmC,
                                                                         int32_t* __restrict__ entC, int64_t k, int win_bits,
                                                                         int sg_log2, int force_chunked, const OffT* __restrict__ endB,
-                                                                        const unsigned* __restrict__ maskB KK_DBG_PARAM) {
+                                                                        const unsigned* __restrict__ maskB, int quads KK_DBG_PARAM) {
   // endB / maskB (symbolic count only): B is compressed -- entB holds set indices, a product ORs its 32-column mask into the bitmap
   KK_DYN_SMEM(kk_u64, bm);
   __shared__ int s_min, s_max;
   __shared__ int s_wave[kDenseBlock / 64];
-  __shared__ FlatScratch<kDenseBlock> s_flat;
+  __shared__ FlatScratchQ<kDenseBlock> s_flatq;
+  FlatScratch<kDenseBlock>& s_flat = *reinterpret_cast<FlatScratch<kDenseBlock>*>(&s_flatq);     // the compressed path's scratch: a prefix of the same memory
+  static_assert(sizeof(FlatScratch<kDenseBlock>) <= sizeof(FlatScratchQ<kDenseBlock>), "scratch overlay");
   const int t       = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
   int64_t total     = 0;
@@ -640,14 +722,18 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
           cmin = c < cmin ? c : cmin; cmax = (c + 31 < nbits ? c + 31 : nbits - 1) > cmax ? (c + 31 < nbits ? c + 31 : nbits - 1) : cmax;
         }
       }, endB);
-    } else if (!KK_DBG(2)) flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int cb) {
-      const int64_t c64 = (int64_t)cb - c0;
-      if (c64 >= 0 && c64 < nbits) {
-        const int c = (int)c64;
-        if (!KK_DBG(256)) atomicOr(&bm[c >> 6], 1ull << (c & 63));
-        cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
-      }
-    });
+    } else if (!KK_DBG(2)) {
+      auto mark = [&](int cb) {
+        const int64_t c64 = (int64_t)cb - c0;
+        if (c64 >= 0 && c64 < nbits) {
+          const int c = (int)c64;
+          if (!KK_DBG(256)) atomicOr(&bm[c >> 6], 1ull << (c & 63));
+          cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
+        }
+      };
+      if (quads) flat_columns_quads<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flatq, mark);
+      else flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int cb) { mark(cb); });
+    }
     if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
     __syncthreads();
     if (s_max >= 0 && !KK_DBG(4)) {
@@ -1202,16 +1288,22 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
   const int t = threadIdx.x, lane = t & 63, sub = t / SG, sl = t & (SG - 1);
   const int sg_shift = lane & ~(SG - 1);
   const int64_t row = perm[blockIdx.x];
-  const int64_t a0 = (int64_t)rmA[row];
-  const int la     = (int)((int64_t)rmA[row + 1] - a0);
+  const int64_t a00 = (int64_t)rmA[row], la_all = (int64_t)rmA[row + 1] - a00;
   const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
+  for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
+  // A rows longer than kHubLa are taken kHubLa entries at a time: every pass walks all windows of the row, the first one stores
+  // its sums, the others add theirs (the same workgroup, one pass after the other: no atomics).  These rows used to accumulate
+  // through L2 atomics into a k-wide HBM accumulator (spgemm_hub_acc_kernel: R-MAT scale 20, 211 rows, 8.8e8 products in 44 ms).
+  for (int64_t ach = 0; ach < la_all; ach += kHubLa) {
+  const bool first_pass = ach == 0;
+  const int64_t a0 = a00 + ach;
+  const int la     = (int)(la_all - ach < kHubLa ? la_all - ach : kHubLa);
   for (int a = t; a < la; a += NT) {
     const int32_t kc = entA[a0 + a];
     const int64_t b0 = (int64_t)rmB[kc];
     const int len    = (int)((int64_t)rmB[kc + 1] - b0);
     s_cur[a] = b0; s_rem[a] = len; s_next[a] = len > 0 ? entB[b0] : INT_MAX;
   }
-  for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
   if (t == 0) s_nact = 0;
   int curk[KPT], slot[KPT];
   KK_UNROLL
@@ -1313,13 +1405,15 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
     KK_UNROLL
     for (int q = 0; q < KPT; ++q) {
       if (slot[q] >= 0) {
-        valC[base + done + t + q * NT] = hv[slot[q]];
+        VT* out = valC + base + done + t + q * NT;
+        *out = first_pass ? hv[slot[q]] : *out + hv[slot[q]];
         hk[slot[q]] = -1; hv[slot[q]] = VT(0);
       }
       curk[q] = nxtk[q];
     }
     if (t == 0) s_nact = 0;
     __syncthreads();
+  }
   }
 }
 
@@ -1398,7 +1492,7 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
   KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,
-            rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked, endB, maskB KK_DBG_ARG);
+            rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked, endB, maskB, (g_spgemm.col_quads && ((uintptr_t)entB % 16 == 0)) ? 1 : 0 KK_DBG_ARG);
   return KKAMD_OK;
 }
 
@@ -1557,7 +1651,8 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
       int32_t* seg = h->d_perm + h->num_off.off[4];
       int64_t lo = 0, len = nd;
-      const int64_t la_max[2] = {g_spgemm.val_la < kValLa ? g_spgemm.val_la : kValLa, kHubLa};
+      // (B sorted: the hub value kernel takes A rows of any length, kHubLa entries per pass; hub_chunked 0 = rows above kHubLa accumulate in HBM)
+      const int64_t la_max[2] = {g_spgemm.val_la < kValLa ? g_spgemm.val_la : kValLa, g_spgemm.hub_chunked ? INT64_MAX : (int64_t)kHubLa};
       int64_t first[2] = {0, 0};
       for (int pass = 0; pass < 2 && len > 0; ++pass) {
         KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
@@ -1694,6 +1789,8 @@ int spgemm_set_default(const char* key, int value) {
 #endif
   else if (k == "spgemm_val_shape") g_spgemm.val_shape = value;
   else if (k == "spgemm_val_hub_flat") g_spgemm.val_hub_flat = value != 0;
+  else if (k == "spgemm_col_quads") g_spgemm.col_quads = value != 0;
+  else if (k == "spgemm_hub_chunked") g_spgemm.hub_chunked = value != 0;
   else if (k == "spgemm_val_kernel") { if (value != 1 && value != 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_kernel is 1 or 2"); g_spgemm.val_kernel = value; }
   else if (k == "spgemm_val_la") g_spgemm.val_la = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "kkamd_set_default: unknown key '%s'", k.c_str());
