@@ -1269,6 +1269,9 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
 #ifndef KK_HUB_US
 #define KK_HUB_US 2
 #endif
+#ifndef KK_HUB_EL
+#define KK_HUB_EL 4          // listed entries a sub-group has in flight
+#endif
 template <class OffT, class VT>
 __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int32_t* __restrict__ perm,
                                                                       const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
@@ -1276,7 +1279,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
                                                                       const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                       const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
                                                                       VT* __restrict__ valC, int cap) {
-  constexpr int H = kValTable, NT = kDenseBlock, KPT = (H / 2 + NT - 1) / NT, SG = KK_HUB_SG, NSUB = NT / SG, US = KK_HUB_US, EL = 4;
+  constexpr int H = kValTable, NT = kDenseBlock, KPT = (H / 2 + NT - 1) / NT, SG = KK_HUB_SG, NSUB = NT / SG, US = KK_HUB_US, EL = KK_HUB_EL;
   constexpr unsigned long long kSgMask = (1ull << SG) - 1ull;
   __shared__ int hk[H];
   __shared__ VT hv[H];
@@ -1395,11 +1398,17 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
           }
         }
       };
-      static_assert(EL == 4, "four explicit calls below");
+      static_assert(EL == 4 || EL == 8, "explicit calls below");
       consume(have[0], a[0], p[0], rem[0], av[0], c[0], v[0]);
       consume(have[1], a[1], p[1], rem[1], av[1], c[1], v[1]);
       consume(have[2], a[2], p[2], rem[2], av[2], c[2], v[2]);
       consume(have[3], a[3], p[3], rem[3], av[3], c[3], v[3]);
+      if constexpr (EL == 8) {
+        consume(have[4], a[4], p[4], rem[4], av[4], c[4], v[4]);
+        consume(have[5], a[5], p[5], rem[5], av[5], c[5], v[5]);
+        consume(have[6], a[6], p[6], rem[6], av[6], c[6], v[6]);
+        consume(have[7], a[7], p[7], rem[7], av[7], c[7], v[7]);
+      }
     }
     __syncthreads();
     KK_UNROLL
