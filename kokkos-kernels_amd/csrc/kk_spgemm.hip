@@ -78,6 +78,7 @@ constexpr int kValBlock   = 512;      // dense-row value kernel
 constexpr int kValTable   = 4096;     // value-window hash table (16 KB keys + 32 KB fp64 sums in LDS: 3 workgroups per CU)
 constexpr int kValCap     = kValTable / 2;   // C entries per value window
 constexpr int kValLa      = 512;      // A entries of a row whose B cursors live in LDS (10 KB)
+constexpr int kValLa2     = 1024;     // ... of the flat value kernel's second shape (1024 work-items, one workgroup per CU)
 constexpr int kValLong    = 128;      // B rows at least this long are streamed by a whole wave
 constexpr int kHubLa      = 4096;     // A rows up to this long keep cursor + next column in LDS (hub value kernel)
 
@@ -91,6 +92,8 @@ struct SpgemmTuning {
 #endif
   int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
+  int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
+  int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
   int col_quads      = 1;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads (0 = one 4-byte load per product)
   int val_hub_flat   = 0;         // 1 = A rows above kValLa through the flat value kernel too (measured slower, see numeric_typed)
@@ -1125,22 +1128,25 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
 // not consumed), the hash is probed for a column known to be present, ds_add.  The first form (spgemm_dense_vals_kernel) gave
 // the long lists of a window to one wave each: on R-MAT three of a row's sixteen lists carry the products, so one to three
 // waves of eight worked through sequential 128-entry round trips while the others sat at the barrier (R-MAT scale 20:
-// 158 ms for 1.4e10 products, VALU busy 6 %).
-template <class OffT, class VT, int H, int NT, int G>
+// 158 ms for 1.4e10 products, VALU busy 6 %).  LA = lists per pass (A rows above LA take several passes): 512 with 512 work-items
+// (78 KB of LDS: two workgroups per CU), 1024 with 1024 work-items and groups of four windows (88 KB: one per CU) for A rows of
+// 513..1024 entries, which the cached-cursor hub kernel below serves at half the rate per product (every window re-fetches the
+// cache lines of ~5 useful entries per list: 7x read amplification).
+template <class OffT, class VT, int H, int NT, int G, int LA>
 __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* __restrict__ perm,
                                                                        const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                        const VT* __restrict__ valA, const OffT* __restrict__ rmB,
                                                                        const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                        const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
                                                                        VT* __restrict__ valC, int cap KK_DBG_PARAM) {
-  static_assert(NT >= kValLa, "one work-item per list in the scan");
+  static_assert(NT >= LA, "one work-item per list in the scan");
   __shared__ int hk[H];
   __shared__ VT hv[H];
-  __shared__ long long s_cur[kValLa];     // first unconsumed entry of list a (index into entries / values of B)
-  __shared__ int s_rem[kValLa];           // entries left in it
-  __shared__ VT s_av[kValLa];
-  __shared__ int s_pos[G][kValLa];        // entries of list a, counted from s_cur[a], with column <= upper column of window g of the group
-  __shared__ int s_pre[kValLa + 1];       // product offsets of the lists inside the current window
+  __shared__ long long s_cur[LA];     // first unconsumed entry of list a (index into entries / values of B)
+  __shared__ int s_rem[LA];           // entries left in it
+  __shared__ VT s_av[LA];
+  __shared__ int s_pos[G][LA];        // entries of list a, counted from s_cur[a], with column <= upper column of window g of the group
+  __shared__ int s_pre[LA + 1];       // product offsets of the lists inside the current window
   __shared__ int s_whi[G];
   __shared__ int s_wave[NT / 64];
   constexpr int U   = kProdUnroll;
@@ -1150,10 +1156,10 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
   const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
   const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
   for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
-  // A rows longer than kValLa are taken kValLa lists at a time: every pass walks all windows of the row, the first one stores
+  // A rows longer than LA are taken LA lists at a time: every pass walks all windows of the row, the first one stores
   // its sums, the others add theirs (the same workgroup, one pass after the other: no atomics)
-  for (int64_t ach = 0; ach < la; ach += kValLa) {
-    const int la_c = (int)(la - ach < kValLa ? la - ach : kValLa);
+  for (int64_t ach = 0; ach < la; ach += LA) {
+    const int la_c = (int)(la - ach < LA ? la - ach : LA);
     const bool first_pass = ach == 0;
     if (t < la_c) {
       const int32_t kc = entA[a0 + ach + t];
@@ -1442,6 +1448,7 @@ struct kkamd_spgemm_handle {
   int64_t nnzA = 0;
   bool b_sorted = false;           // rows of B column-sorted: dense rows may use the windowed LDS value kernel
   bool dense_lds = false;          // decided when the numeric bins are made
+  bool hub_from_mid = false;       // the dense bin is cut [<= kValLa | <= kValLa2 | rest]: flat kernel twice, hub kernel for the rest
   int64_t n_dense_lds = 0;         // leading rows of the dense bin taken by the LDS value kernel,
   int64_t n_dense_hub_lds = 0;     // then rows for the LDS hub kernel; the rest accumulate in HBM
   // options (kkamd_spgemm_set; the reference's SPGEMMHandle / KokkosKernelsHandle setters)
@@ -1661,7 +1668,10 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       int32_t* seg = h->d_perm + h->num_off.off[4];
       int64_t lo = 0, len = nd;
       // (B sorted: the hub value kernel takes A rows of any length, kHubLa entries per pass; hub_chunked 0 = rows above kHubLa accumulate in HBM)
-      const int64_t la_max[2] = {g_spgemm.val_la < kValLa ? g_spgemm.val_la : kValLa, g_spgemm.hub_chunked ? INT64_MAX : (int64_t)kHubLa};
+      // flat value kernel (default): [A row <= kValLa | <= kValLa2 (the flat kernel, 1024 lists per pass) | the rest (hub kernel in passes)]
+      h->hub_from_mid = h->dense_lds && g_spgemm.val_kernel == 2 && g_spgemm.val_mid && g_spgemm.hub_chunked;
+      const int64_t la_max[2] = {g_spgemm.val_la < kValLa ? g_spgemm.val_la : kValLa,
+                                 h->hub_from_mid ? (int64_t)g_spgemm.val_la2 : (g_spgemm.hub_chunked ? INT64_MAX : (int64_t)kHubLa)};
       int64_t first[2] = {0, 0};
       for (int pass = 0; pass < 2 && len > 0; ++pass) {
         KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
@@ -1713,9 +1723,23 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       // handful of products per list and window; the cached-next-column sweep of spgemm_hub_vals_kernel skips the empty lists for free)
       int cap = g_spgemm.val_cap;
       cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
-      if (n_hubl + n_hub) KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8>), (unsigned)(n_hubl + n_hub), kValBlock, 0, st, dperm + n_lds,
+      if (n_hubl + n_hub) KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8, kValLa>), (unsigned)(n_hubl + n_hub), kValBlock, 0, st, dperm + n_lds,
                                     rmA, entA, valA, rmB, entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
       n_hubl = 0; n_hub = 0;
+    }
+    if (n_hub && flat_vals && h->hub_from_mid) {      // A rows above kValLa2 entries (the heaviest rows first): the cached-cursor hub kernel, kHubLa entries per pass
+      int cap = g_spgemm.val_cap;
+      cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
+      KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)n_hub, kDenseBlock, 0, st, dperm + n_lds + n_hubl, rmA, entA, valA, rmB, entB, valB,
+                rmC, (const int32_t*)entC, valC, cap);
+      n_hub = 0;
+    }
+    if (n_hubl && flat_vals && h->hub_from_mid) {    // A rows of kValLa + 1 .. kValLa2 entries: the flat kernel with 1024 lists per pass
+      int cap = g_spgemm.val_cap;
+      cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
+      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kDenseBlock, 4, kValLa2>), (unsigned)n_hubl, kDenseBlock, 0, st, dperm + n_lds,
+                rmA, entA, valA, rmB, entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
+      n_hubl = 0;
     }
     if (n_hubl) {      // heaviest rows first
       int cap = g_spgemm.val_cap;
@@ -1734,7 +1758,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   } while (0)
       if (flat_vals) {
         if (cap > kValTable / 2) cap = kValTable / 2;
-        KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8>), (unsigned)n_lds, kValBlock, 0, st, dperm, rmA, entA, valA, rmB,
+        KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8, kValLa>), (unsigned)n_lds, kValBlock, 0, st, dperm, rmA, entA, valA, rmB,
                   entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
       } else switch (g_spgemm.val_shape) {
         case 1: KK_VALS(8192, 1024); break;
@@ -1800,6 +1824,8 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_val_hub_flat") g_spgemm.val_hub_flat = value != 0;
   else if (k == "spgemm_col_quads") g_spgemm.col_quads = value != 0;
   else if (k == "spgemm_hub_chunked") g_spgemm.hub_chunked = value != 0;
+  else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
+  else if (k == "spgemm_val_la2") { if (value < kValLa2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_la2 must be at least %d", kValLa2); g_spgemm.val_la2 = value; }
   else if (k == "spgemm_val_kernel") { if (value != 1 && value != 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_kernel is 1 or 2"); g_spgemm.val_kernel = value; }
   else if (k == "spgemm_val_la") g_spgemm.val_la = value;
   else return fail(KKAMD_ERR_INVALID_ARG, "kkamd_set_default: unknown key '%s'", k.c_str());
