@@ -92,6 +92,7 @@ struct SpgemmTuning {
 #endif
   int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
+  int keep_bitmaps   = 1;         // symbolic keeps the bitmaps of its densest rows for the first numeric call (0 = every row walks its products twice)
   int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
@@ -690,6 +691,13 @@ __global__ __launch_bounds__(NT) void spgemm_sym_block_kernel(int64_t nbin, cons
 // bits are written out in ascending order, so entries(C) for the row leave the kernel column-sorted.  EMIT = false is
 // the symbolic count; EMIT = true fills entries(C) in the numeric phase (the value kernel below needs them).
 typedef unsigned long long kk_u64;
+struct BitmapStore {                 // where the symbolic count kernel may leave a row's bitmap (words == 0: nowhere)
+  kk_u64* words_out = nullptr;       // [cap][words]
+  int32_t* row_slot = nullptr;       // [m], -1 = not stored
+  unsigned long long* counter = nullptr;
+  long long cap = 0, min_count = 0;
+  int words = 0;
+};
 template <class OffT, bool EMIT>
 __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const int32_t* __restrict__ perm,
                                                                         const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
                                                                         OffT* __restrict__ counts, const OffT* __restrict__ rmC,
                                                                         int32_t* __restrict__ entC, int64_t k, int win_bits,
                                                                         int sg_log2, int force_chunked, const OffT* __restrict__ endB,
-                                                                        const unsigned* __restrict__ maskB, int quads KK_DBG_PARAM) {
+                                                                        const unsigned* __restrict__ maskB, int quads, BitmapStore bs KK_DBG_PARAM) {
   // endB / maskB (symbolic count only): B is compressed -- entB holds set indices, a product ORs its 32-column mask into the bitmap
   KK_DYN_SMEM(kk_u64, bm);
   __shared__ int s_min, s_max;
@@ -785,6 +793,85 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
     __syncthreads();
   }
   if (!EMIT && t == 0) counts[row] = (OffT)total;
+  if constexpr (!EMIT) {
+    // the symbolic phase keeps the bitmaps of its densest rows (BitmapStore): the first numeric call writes their entries(C)
+    // straight from them instead of walking the row's products a second time.  One window only (k <= win_bits).
+    if (bs.words && total >= bs.min_count) {
+      __shared__ long long s_slot;
+      if (t == 0) { const unsigned long long sl = atomicAdd(bs.counter, 1ull); s_slot = sl < (unsigned long long)bs.cap ? (long long)sl : -1; }
+      __syncthreads();
+      const long long slot = s_slot;
+      if (slot >= 0) {
+        kk_u64* dst = bs.words_out + (size_t)slot * (size_t)bs.words;
+        for (int i = t; i < bs.words; i += kDenseBlock) dst[i] = bm[i];
+        if (t == 0) bs.row_slot[row] = (int32_t)slot;
+      }
+    }
+  }
+}
+
+// entries(C) of a row whose bitmap the symbolic phase kept: no products, the set bits in ascending order
+template <class OffT>
+__global__ __launch_bounds__(kDenseBlock) void spgemm_emit_bitmap_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ row_slot,
+                                                                         const kk_u64* __restrict__ store, int words, const OffT* __restrict__ rmC,
+                                                                         int32_t* __restrict__ entC) {
+  __shared__ int s_wave[kDenseBlock / 64];
+  const int t = threadIdx.x;
+  const int64_t row = perm[blockIdx.x];
+  const kk_u64* bm = store + (size_t)row_slot[row] * (size_t)words;
+  // Every wave owns a contiguous range of the row's words and walks it 64 words at a time (lane l owns word base + l): the loads
+  // of a wave are 512 contiguous bytes, neighbouring lanes write neighbouring pieces of entries(C), the offsets inside a wave
+  // come from shuffles and only the 16 wave totals cross the workgroup (one barrier per row).  (One contiguous run of 16 words
+  // per work-item -- the walk of the product kernel's sparse rows -- made every 8-byte load of a wave touch 64 cache lines and
+  // every store a separate 400-byte run; 1024 interleaved words per step cost sixteen workgroup scans per row: 277 -> 321 ms.)
+  constexpr int NW = kDenseBlock / 64, NB = 16;            // 2^20 columns / 64 / 1024 = 16 steps of 64 words per wave
+  const int lane = t & 63, wave = t >> 6;
+  const int wpw = ((words + NW - 1) / NW + 63) & ~63;       // words per wave, a multiple of 64
+  const int w0 = wave * wpw, w1 = (w0 + wpw < words) ? w0 + wpw : words;
+  kk_u64 w[NB];
+  int wsum = 0;
+  KK_UNROLL
+  for (int i = 0; i < NB; ++i) { const int wd = w0 + i * 64 + lane; w[i] = (i * 64 < wpw && wd < w1) ? bm[wd] : 0ull; wsum += __popcll(w[i]); }
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+  if (lane == 0) s_wave[wave] = wsum;
+  __syncthreads();
+  int64_t pos0 = (int64_t)rmC[row];
+  for (int i = 0; i < wave; ++i) pos0 += s_wave[i];
+  KK_UNROLL
+  for (int i = 0; i < NB; ++i) {
+    if (i * 64 >= wpw) break;                              // uniform
+    kk_u64 v = w[i];
+    const int pc = __popcll(v);
+    int inc = pc;
+    for (int o = 1; o < 64; o <<= 1) { const int nb_ = __shfl_up(inc, (unsigned)o, 64); if (lane >= o) inc += nb_; }
+    int64_t pos = pos0 + (inc - pc);
+    const int64_t c0 = (int64_t)(w0 + i * 64 + lane) * 64;
+    while (v) {
+      const int bit = __ffsll(v) - 1;
+      entC[pos++]   = (int32_t)(c0 + bit);
+      v &= v - 1;
+    }
+    pos0 += __shfl(inc, 63, 64);
+  }
+}
+// rows of the dense bin: those with a stored bitmap first, the others from the end
+__global__ __launch_bounds__(kBlock) void spgemm_split_stored_kernel(int64_t nd, const int32_t* __restrict__ perm_in, const int32_t* __restrict__ row_slot,
+                                                                    int32_t* __restrict__ perm_out, unsigned long long* __restrict__ counters /*[2]*/) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane  = threadIdx.x & 63;
+  int32_t row = 0;
+  int cls     = -1;
+  if (i < nd) { row = perm_in[i]; cls = row_slot[row] >= 0 ? 0 : 1; }
+  for (int c = 0; c < 2; ++c) {
+    const kk_u64 m = __ballot(cls == c);
+    unsigned long long start = 0;
+    if (lane == 0 && m) start = atomicAdd(&counters[c], (unsigned long long)__popcll(m));
+    start = __shfl(start, 0, 64);
+    if (cls == c) {
+      const int64_t r = (int64_t)start + __popcll(m & ((1ull << lane) - 1ull));
+      perm_out[c == 0 ? r : nd - 1 - r] = row;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1459,6 +1546,11 @@ struct kkamd_spgemm_handle {
   int verbose = 0;
   int requested_algorithm = 4;     // the SPGEMMAlgorithm the caller named (SPGEMM_DEFAULT until set)
   std::map<std::string, double> hints;   // accepted-and-ignored tuning hints of the reference, by key
+  // bitmaps of the densest rows, kept by the symbolic phase for the first numeric call (freed once entries(C) are written)
+  void* d_bm_store = nullptr; int32_t* d_row_slot = nullptr; unsigned long long* d_bm_counter = nullptr;
+  int64_t bm_cap = 0, bm_stored = 0; int bm_words = 0;
+  int64_t bitmaps_used = 0;        // rows of the last numeric call whose entries(C) came from a stored bitmap
+  int32_t* d_emit_perm = nullptr; int64_t n_emit_stored = 0;    // the dense bin as [rows with a stored bitmap | the others]
   bool entries_valid = false;      // entries(C) as the last numeric call left them are still what entC_ptr holds (numeric reuse)
   bool entries_reused = false;     // the last numeric call kept them
   const void *entC_ptr = nullptr, *rmC_ptr = nullptr;
@@ -1499,7 +1591,7 @@ static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLi
 template <class OffT, bool EMIT>
 static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA, const int32_t* entA, const OffT* rmB,
                              const int32_t* entB, OffT* counts, const OffT* rmC, int32_t* entC, int64_t k, int sg, hipStream_t st,
-                             const OffT* endB = nullptr, const unsigned* maskB = nullptr) {
+                             const OffT* endB = nullptr, const unsigned* maskB = nullptr, BitmapStore bs = BitmapStore()) {
   int64_t win = g_spgemm.win_bits;
   if (win > k) win = ceil_div(k, 64) * 64;
   const size_t smem = (size_t)(win / 8);
@@ -1508,9 +1600,19 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
   KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,
-            rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked, endB, maskB, (g_spgemm.col_quads && ((uintptr_t)entB % 16 == 0)) ? 1 : 0 KK_DBG_ARG);
+            rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked, endB, maskB, (g_spgemm.col_quads && ((uintptr_t)entB % 16 == 0)) ? 1 : 0, bs KK_DBG_ARG);
   return KKAMD_OK;
 }
+
+static void free_bitmap_store(kkamd_spgemm_handle* h) {
+  if (h->d_bm_store) (void)hipFree(h->d_bm_store);
+  if (h->d_row_slot) (void)hipFree(h->d_row_slot);
+  if (h->d_bm_counter) (void)hipFree(h->d_bm_counter);
+  if (h->d_emit_perm) (void)hipFree(h->d_emit_perm);
+  h->d_bm_store = nullptr; h->d_row_slot = nullptr; h->d_bm_counter = nullptr; h->d_emit_perm = nullptr;
+  h->bm_cap = 0; h->bm_stored = 0; h->bm_words = 0; h->n_emit_stored = 0;
+}
+static double words_mb(int words) { return (double)words * 8.0 / 1048576.0; }
 
 template <class OffT>
 static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t k, const void* rmA_, const int32_t* entA,
@@ -1609,8 +1711,34 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
                          (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
     if (nb(4)) {
+      // keep the bitmaps of rows with at least k / 32 entries (the bitmap is then no larger than the row's entries) when one LDS
+      // window covers the columns and an eighth of the free HBM holds them: R-MAT scale 20, 87 K rows (83 % of the products), 11 GB
+      BitmapStore bs;
+      free_bitmap_store(h);
+      if (g_spgemm.keep_bitmaps && k <= (int64_t)g_spgemm.win_bits && k >= 4096) {
+        size_t free_b = 0, total_b = 0;
+        const int words = (int)ceil_div(k, (int64_t)64);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+          int64_t cap = (int64_t)(free_b / 8) / ((int64_t)words * 8);
+          if (cap > nb(4)) cap = nb(4);
+          if (cap >= 1 && hipMalloc(&h->d_bm_store, (size_t)cap * (size_t)words * 8) == hipSuccess && hipMalloc((void**)&h->d_row_slot, sizeof(int32_t) * (size_t)m) == hipSuccess &&
+              hipMalloc((void**)&h->d_bm_counter, sizeof(unsigned long long)) == hipSuccess &&
+              hipMemsetAsync(h->d_row_slot, 0xFF, sizeof(int32_t) * (size_t)m, st) == hipSuccess && hipMemsetAsync(h->d_bm_counter, 0, sizeof(unsigned long long), st) == hipSuccess) {
+            h->bm_cap = cap; h->bm_words = words;
+            bs.words_out = (kk_u64*)h->d_bm_store; bs.row_slot = h->d_row_slot; bs.counter = h->d_bm_counter; bs.cap = cap; bs.min_count = k / 32; bs.words = words;
+          } else { (void)hipGetLastError(); free_bitmap_store(h); }
+        } else (void)hipGetLastError();
+      }
       if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, entB, rmC, (const OffT*)nullptr,
-                                               (int32_t*)nullptr, k, sg, st))) return rc;
+                                               (int32_t*)nullptr, k, sg, st, nullptr, nullptr, bs))) return rc;
+      if (bs.words) {
+        unsigned long long h_n = 0;
+        KK_HIP(hipMemcpyAsync(&h_n, h->d_bm_counter, sizeof h_n, hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+        h->bm_stored = (int64_t)(h_n < (unsigned long long)h->bm_cap ? h_n : (unsigned long long)h->bm_cap);
+        if (h->bm_stored == 0) free_bitmap_store(h);
+        if (h->verbose) KK_VERBOSE("\tkkamd spgemm symbolic: bitmaps of %lld rows kept for the numeric phase (%.1f MB)\n", (long long)h->bm_stored, (double)h->bm_stored * words_mb(h->bm_words));
+      }
     }
   }
   if (h->verbose)
@@ -1686,6 +1814,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       h->n_dense_lds = first[0]; h->n_dense_hub_lds = first[1];
     }
     h->numeric_bins_ready = true;
+    if (h->d_emit_perm) { (void)hipFree(h->d_emit_perm); h->d_emit_perm = nullptr; h->n_emit_stored = 0; }
   }
   const BinOffsets& off = h->num_off;
   const int sg = h->sg_log2;
@@ -1714,6 +1843,28 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     const int32_t* dperm = h->d_perm + off.off[4];
     // entries(C) of every dense row, column-sorted
     if (keep_entries) h->entries_reused = true;
+    else if (h->d_bm_store && h->bm_stored > 0 && h->algorithm == 0) {
+      // rows whose bitmap the symbolic phase kept are written from it; the others walk their products
+      if (!h->d_emit_perm) {
+        DevBuf c2;
+        KK_HIP(c2.alloc(2 * sizeof(unsigned long long)));
+        KK_HIP(hipMemsetAsync(c2.p, 0, 2 * sizeof(unsigned long long), st));
+        KK_HIP(hipMalloc((void**)&h->d_emit_perm, sizeof(int32_t) * (size_t)nb(4)));
+        int32_t* d_ep = h->d_emit_perm; const int32_t* d_rs = h->d_row_slot; unsigned long long* d_c2 = c2.as<unsigned long long>();
+        KK_LAUNCH(spgemm_split_stored_kernel, (unsigned)ceil_div(nb(4), kBlock), kBlock, 0, st, nb(4), dperm, d_rs, d_ep, d_c2);
+        unsigned long long h_c2[2] = {0, 0};
+        KK_HIP(hipMemcpyAsync(h_c2, c2.p, sizeof h_c2, hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+        h->n_emit_stored = (int64_t)h_c2[0];
+      }
+      const int64_t ns = h->n_emit_stored, nr = nb(4) - ns;
+      if (ns) {
+        const int32_t* d_ep = h->d_emit_perm; const int32_t* d_rs = h->d_row_slot; const kk_u64* d_st = (const kk_u64*)h->d_bm_store;
+        KK_LAUNCH((spgemm_emit_bitmap_kernel<OffT>), (unsigned)ns, kDenseBlock, 0, st, d_ep, d_rs, d_st, h->bm_words, rmC, entC);
+      }
+      if (nr && (rc = launch_dense_cols<OffT, true>(nr, h->d_emit_perm + ns, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
+      h->bitmaps_used = ns;
+    }
     else if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
     const int64_t n_lds = h->n_dense_lds; int64_t n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_lds - n_hubl;
     const bool flat_vals = g_spgemm.val_kernel == 2 && h->dense_lds;
@@ -1794,6 +1945,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   hipError_t e2 = hipStreamSynchronize(st);   // the reference's numeric phase fences too (impl_kkmem.hpp:1440,1467)
   if (e != hipSuccess || e2 != hipSuccess) { h->entries_valid = false; return fail(KKAMD_ERR_HIP, "spgemm numeric failed: %s", hipGetErrorString(e != hipSuccess ? e : e2)); }
   h->entries_valid = true; h->entC_ptr = entC; h->rmC_ptr = rmC_;
+  if (h->d_bm_store) { const int64_t used = h->bitmaps_used; free_bitmap_store(h); h->bitmaps_used = used; }    // entries(C) are written: the bitmaps (GBs) are not needed again
   return KKAMD_OK;
 }
 
@@ -1825,6 +1977,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_col_quads") g_spgemm.col_quads = value != 0;
   else if (k == "spgemm_hub_chunked") g_spgemm.hub_chunked = value != 0;
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
+  else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
   else if (k == "spgemm_val_la2") { if (value < kValLa2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_la2 must be at least %d", kValLa2); g_spgemm.val_la2 = value; }
   else if (k == "spgemm_val_kernel") { if (value != 1 && value != 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_kernel is 1 or 2"); g_spgemm.val_kernel = value; }
   else if (k == "spgemm_val_la") g_spgemm.val_la = value;
@@ -1846,6 +1999,7 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (!h) return KKAMD_OK;
   if (h->d_sizes) (void)hipFree(h->d_sizes);
   if (h->d_perm) (void)hipFree(h->d_perm);
+  kk::free_bitmap_store(h);
   delete h;
   return KKAMD_OK;
 }
@@ -1869,6 +2023,7 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
   }
   h->m = m; h->n = n; h->k = k; h->offset_type = offset_type; h->rmA = d_row_mapA; h->rmB = d_row_mapB;
   h->symbolic_called = false; h->numeric_called = false; h->numeric_bins_ready = false; h->entries_valid = false;
+  kk::free_bitmap_store(h); h->bitmaps_used = 0;
   h->c_nnz = 0; h->mults = 0; h->max_row_flops = 0; h->max_row_nnz = 0;
   // empty product: zero row_map (:100-107; the rocSPARSE wrapper memsets too)
   int64_t nnzA = 0, nnzB = 0;
@@ -2020,6 +2175,8 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 9: *value = h->requested_algorithm; break;
     case 10: *value = (int64_t)h->hints.size(); break;
     case 11: *value = h->entries_reused ? 1 : 0; break;
+    case 12: *value = h->bitmaps_used; break;
+    case 13: *value = h->bm_stored; break;
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
   return KKAMD_OK;
