@@ -92,6 +92,7 @@ struct SpgemmTuning {
 #endif
   int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
+  int sym_large      = 0;         // symbolic: rows of 2049..8192 products through the 16384-slot hash kernel; 0 (default) = the bitmap kernel (R-MAT scale 20: the hash kernel spent 21 ms on 137 K such rows, symbolic 78 -> 68 ms without it)
   int keep_bitmaps   = 1;         // symbolic keeps the bitmaps of its densest rows for the first numeric call (0 = every row walks its products twice)
   int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
@@ -104,6 +105,7 @@ static SpgemmTuning g_spgemm;
 
 struct BinLimits { int64_t lim[kNumBins - 1]; };   // size <= lim[b] -> bin b  (lim[0] = 0)
 static const BinLimits kSymLimits = {{0, (kSymWaveTable * 2) / 3, kSymBlkS / 2, kSymBlkL / 2}};
+static const BinLimits kSymLimitsNoLarge = {{0, (kSymWaveTable * 2) / 3, kSymBlkS / 2, kSymBlkS / 2}};   // knob sym_large 0: rows above 2048 products straight to the bitmap kernel
 static const BinLimits kSymLimitsC = {{0, (1024 * 2) / 3, 4096 / 2, 16384 / 2}};     // compressed symbolic (keys + masks: smaller tables)
 static const BinLimits kAllDense = {{0, 0, 0, 0}};                                   // every non-empty row in the last bin
 static const BinLimits kNumLimits = {{0, kWaveTable / 2, kNumBlkS / 2, (kNumBlkL * 2) / 3}};
@@ -137,11 +139,18 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
   for (int64_t r0 = (int64_t)blockIdx.x * (kBlock / 8); r0 < m; r0 += stride) {     // workgroup-uniform trip count
     const int64_t row = r0 + threadIdx.x / 8;
     long long f = 0;
-    if (row < m)
-      for (int64_t a = (int64_t)rmA[row] + lane; a < (int64_t)rmA[row + 1]; a += 8) {
-        const int32_t c = entA[a];
-        f += (long long)(endB ? endB[c] : rmB[c + 1]) - (long long)rmB[c];
+    if (row < m) {
+      // four entries per lane and step, their loads independent: the longest row of A is walked by these 8 lanes alone (R-MAT scale 20:
+      // 39,580 entries = 4,947 dependent entries(A) -> row_map(B) round trips per lane with one entry per step, 5 of the kernel's 7 ms)
+      const int64_t a_end = (int64_t)rmA[row + 1];
+      for (int64_t a = (int64_t)rmA[row] + lane; a < a_end; a += 32) {
+        int32_t c[4];
+        KK_UNROLL
+        for (int u = 0; u < 4; ++u) c[u] = a + 8 * u < a_end ? entA[a + 8 * u] : -1;
+        KK_UNROLL
+        for (int u = 0; u < 4; ++u) if (c[u] >= 0) f += (long long)(endB ? endB[c[u]] : rmB[c[u] + 1]) - (long long)rmB[c[u]];
       }
+    }
     f = group_sum(f, 8);
     if (row < m && lane == 0) { flops[row] = f; sum += f; mx = f > mx ? f : mx; }
   }
@@ -1703,7 +1712,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
                                                (int32_t*)nullptr, k, sg, st, endB, maskB))) return rc;
     }
   } else {
-    if ((rc = make_bins(m, h->d_sizes, k, kSymLimits, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
+    if ((rc = make_bins(m, h->d_sizes, k, g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
     if (nb(1)) KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
                          (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, sg);
     if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
@@ -1978,6 +1987,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_hub_chunked") g_spgemm.hub_chunked = value != 0;
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
+  else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
   else if (k == "spgemm_val_la2") { if (value < kValLa2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_la2 must be at least %d", kValLa2); g_spgemm.val_la2 = value; }
   else if (k == "spgemm_val_kernel") { if (value != 1 && value != 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_kernel is 1 or 2"); g_spgemm.val_kernel = value; }
   else if (k == "spgemm_val_la") g_spgemm.val_la = value;
