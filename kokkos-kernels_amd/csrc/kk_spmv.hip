@@ -1099,6 +1099,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "mv_strip_min_kb") { if (value < 0) return bad("non-negative"); t.mv_strip_min_kb = value; }
   else if (k == "mv_strip_l2_kb") { if (value < 1) return bad("positive"); t.mv_strip_l2_kb = value; }
   else if (k == "mv_glds") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv_glds = value; }
+  else if (k == "mv_long_T") { if (value < 0) return bad("non-negative"); t.mv_long_T = value; }
   else if (k == "mv4_min_nvec") { if (value < 1 || value > 1024) return bad("in 1..1024"); t.mv4_min_nvec = value; }
   else if (k == "mv4_wg_per_cu") { if (value < 1 || value > 64) return bad("in 1..64"); t.mv4_wg_per_cu = value; }
   else if (k == "march") { if (value != 0 && value != 1) return bad("0 or 1"); t.march = value; }
@@ -1394,6 +1395,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_xpack) (void)hipFree(plan->d_xpack);
   if (plan->d_ypack) (void)hipFree(plan->d_ypack);
   if (plan->d_mv2_order) (void)hipFree(plan->d_mv2_order);
+  if (plan->d_mv_long) (void)hipFree(plan->d_mv_long);
   if (plan->mv) kk::mv_plan_destroy(plan->mv);
   if (plan->mv4) kk::mv4_plan_destroy(plan->mv4);
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
@@ -1451,6 +1453,7 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "transpose_cached") *value = plan->t_ready ? 1 : 0;
   else if (k == "mv_tiles") *value = kk::mv_plan_query(plan->mv, 0);
   else if (k == "mv_staged_tiles") *value = kk::mv_plan_query(plan->mv, 1);
+  else if (k == "mv_long_rows") *value = plan->n_mv_long;
   else if (k == "mv_order") *value = plan->mv ? kk::mv_plan_query(plan->mv, 2) : (plan->d_mv2_order ? 2 : 0);
   else if (k == "mv_period") *value = plan->mv_period;
   else if (k == "mv_plan_bytes") *value = kk::mv_plan_query(plan->mv, 3) + kk::mv4_plan_query(plan->mv4, 3);

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
                                                           const AT* __restrict__ values, const YT* __restrict__ X,
                                                           int64_t xs0, YT* __restrict__ Y, int64_t ys0, int64_t ys1,
                                                           int64_t nvec, YT alpha, YT beta, int y_vec_ok, int remap,
-                                                          const int32_t* __restrict__ order) {
+                                                          const int32_t* __restrict__ order, int64_t long_T) {
   // XCD-contiguous workgroup order (remap): the 128-byte X rows a row block touches are shared with the blocks
   // that handle rows i+-1, j+-1 (and k+-1); keeping neighbouring blocks on ONE XCD keeps those X rows in its
   // 4 MiB L2.  With the dispatcher's round-robin order every XCD fetched every X row: rocprof showed 10.7
@@ -111,6 +111,10 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
   const int64_t hi  = (int64_t)row_map[rowN];
   int64_t rs = 0, re = 0;
   if (row < rowN) { rs = (int64_t)row_map[row]; re = (int64_t)row_map[row + 1]; }
+  // a row above long_T entries is not walked here (its row group would work through it alone, the other 15 rows' lanes idle,
+  // the whole wave staging chunk after chunk for it: R-MAT scale 22 x 16 took 37.7 ms): it gets 0 + beta y here and
+  // spmv_mv_long_kernel adds its products afterwards; chunks that hold nothing but such a row are not even staged
+  if (long_T > 0 && re - rs > long_T) re = rs;
   for (int64_t kk = 0; kk < nvec; kk += SW) {
     // piece q of lane l covers right-hand sides kk + q*2*LPRW + 2l and +1: the LPRW lanes of a row then read ONE contiguous
     // 16*LPRW-byte run per load instruction (one 64 B sector of the X row for LPRW = 4) instead of 16 B out of every
@@ -122,6 +126,10 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
     KK_UNROLL
     for (int q = 0; q < RPL; ++q) acc[q] = YT(0);
     for (int64_t c = lo; c < hi; c += CHW) {
+      if (long_T > 0) {
+        const int64_t a_ = rs > c ? rs : c, z_ = re < c + CHW ? re : c + CHW;
+        if (__ballot(row < rowN && a_ < z_) == 0ull) continue;           // nothing of a walked row in this chunk (wave-uniform)
+      }
       KK_WAVE_SYNC();
       if (c + CHW <= nnz) {   // whole window inside the arrays (wave-uniform): three unguarded 16-byte loads per lane and 256 nnz
         KK_UNROLL
@@ -197,6 +205,47 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
         }
       }
     }
+  }
+}
+
+// rows above T entries: count, then list (any order)
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv_long_list_kernel(int64_t nrows, const OffT* __restrict__ row_map, int64_t T, int32_t* __restrict__ list,
+                                                              unsigned long long* __restrict__ count) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r < nrows && (int64_t)row_map[r + 1] - (int64_t)row_map[r] > T) {
+    const unsigned long long at = atomicAdd(count, 1ull);
+    if (list) list[at] = (int32_t)r;
+  }
+}
+// Y(row, :) += alpha * A(row, :) X for the listed rows (the gather kernel left beta * Y there): one workgroup per row and strip of
+// 16 right-hand sides, 16 lanes per entry (one right-hand side each: a 128-byte X row per load when X is row-major), 16 entries in
+// flight per step, the 16 partial sums of a column meet in LDS
+template <class OffT, class AT, class YT>
+__global__ __launch_bounds__(kBlock) void spmv_mv_long_kernel(const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
+                                                              const int32_t* __restrict__ entries, const AT* __restrict__ values,
+                                                              const YT* __restrict__ X, int64_t xs0, int64_t xs1, YT* __restrict__ Y, int64_t ys0,
+                                                              int64_t ys1, int64_t nvec, YT alpha) {
+  __shared__ YT part[kBlock];
+  const int64_t row = list[blockIdx.x];
+  const int j = threadIdx.x & 15, e = threadIdx.x >> 4;
+  const int64_t col0 = (int64_t)blockIdx.y * 16;
+  const int64_t jc = col0 + j < nvec ? col0 + j : nvec - 1;        // the spare lanes of the last strip read a valid column and store nothing
+  const int64_t b = (int64_t)row_map[row], end = (int64_t)row_map[row + 1];
+  YT acc = YT(0);
+  for (int64_t a = b + e; a < end; a += 4 * (kBlock / 16)) {          // four independent entries per lane and step
+    YT v[4]; int32_t c[4];
+    KK_UNROLL
+    for (int u = 0; u < 4; ++u) { const int64_t i = a + u * (kBlock / 16); const bool ok = i < end; c[u] = ok ? entries[i] : entries[b]; v[u] = ok ? (YT)values[i] : YT(0); }
+    KK_UNROLL
+    for (int u = 0; u < 4; ++u) acc += v[u] * X[(int64_t)c[u] * xs0 + jc * xs1];
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    YT sum = YT(0);
+    for (int q = 0; q < kBlock / 16; ++q) sum += part[q * 16 + j];
+    if (col0 + j < nvec) Y[row * ys0 + (col0 + j) * ys1] += alpha * sum;
   }
 }
 
@@ -1442,6 +1491,32 @@ int march_spmv(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* x, dou
   return A->value_type == KKAMD_F64 ? march1_launch<int32_t, double>(plan, A, x, y, alpha, beta, st) : march1_launch<int32_t, float>(plan, A, x, y, alpha, beta, st);
 }
 
+// the rows the wave-per-16-rows gather kernel leaves to spmv_mv_long_kernel: found once per plan
+template <class OffT>
+static int mv_find_long_rows(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st) {
+  plan->mv_long_known = true; plan->n_mv_long = 0; plan->mv_long_T = 0;
+  if (A->num_rows == 0 || A->nnz == 0) return KKAMD_OK;
+  int64_t T = plan->tune.mv_long_T;
+  if (T <= 0) { T = 4 * (A->nnz / A->num_rows); if (T < 64) T = 64; }     // R-MAT scale 22 x 16: 37.7 ms without, 9.5 at 1024, 4.8 at 256, 3.0-3.1 at 64-128
+  DevBuf cnt;
+  KK_HIP(cnt.alloc(sizeof(unsigned long long)));
+  unsigned long long* d_cnt = cnt.as<unsigned long long>();
+  KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+  const unsigned grid = (unsigned)ceil_div(A->num_rows, kBlock);
+  KK_LAUNCH((mv_long_list_kernel<OffT>), grid, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, T, (int32_t*)nullptr, d_cnt);
+  unsigned long long h_n = 0;
+  KK_HIP(hipMemcpyAsync(&h_n, d_cnt, sizeof h_n, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  if (h_n == 0) return KKAMD_OK;
+  KK_HIP(hipMalloc((void**)&plan->d_mv_long, sizeof(int32_t) * (size_t)h_n));
+  KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+  int32_t* d_list = plan->d_mv_long;
+  KK_LAUNCH((mv_long_list_kernel<OffT>), grid, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, T, d_list, d_cnt);
+  KK_HIP(hipStreamSynchronize(st));
+  plan->n_mv_long = (int64_t)h_n; plan->mv_long_T = T;
+  return KKAMD_OK;
+}
+
 template <class OffT, class AT, class YT>
 static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dX,
                          int64_t xs0, int64_t xs1, double beta_d, void* dY, int64_t ys0, int64_t ys1, int64_t nvec,
@@ -1518,13 +1593,27 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
     if (Xr) {
       const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
       const int mv_remap = plan ? plan->tune.mv_remap : g_spmv_default.mv_remap;
+      int64_t long_T = 0;
+      if (plan && plan->row_map == A->d_row_map) {
+        if (!plan->mv_long_known) { const int rc = mv_find_long_rows<OffT>(plan, A, st); if (rc) return rc; }
+        long_T = plan->n_mv_long > 0 ? plan->mv_long_T : 0;
+      }
+      // rows above long_T entries, after the gather kernel has written beta * Y there (called by the launch macro below)
+      auto long_rows = [&]() -> int {
+        if (long_T <= 0) return KKAMD_OK;
+        const int32_t* d_list = plan->d_mv_long;
+        KK_LAUNCH((spmv_mv_long_kernel<OffT, AT, YT>), dim3((unsigned)plan->n_mv_long, (unsigned)ceil_div(nvec, (int64_t)16)), kBlock, 0, st, d_list,
+                  (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xr, ldx, (int64_t)1, Y, ys0, ys1, nvec, alpha);
+        KK_LAUNCH_CHECK();
+        return KKAMD_OK;
+      };
 #define KK_MV2C(L, R, C)                                                                                                 \
       do {                                                                                                               \
         KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R, C>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
                   0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, \
-                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap, mv2_order(plan, A, (kBlock / kWave) * (kWave / L), (int)(nvec < 16 ? nvec : 16) * (int)sizeof(YT), st)); \
+                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap, mv2_order(plan, A, (kBlock / kWave) * (kWave / L), (int)(nvec < 16 ? nvec : 16) * (int)sizeof(YT), st), long_T); \
         KK_LAUNCH_CHECK();                                                                                               \
-        return KKAMD_OK;                                                                                                 \
+        return long_rows();                                                                                              \
       } while (0)
       // staging window: the nnz of the wave's kWave/L rows (+15 % and the 4-alignment slack), rounded up to 256 / 512 / 1024
 #define KK_MV2(L, R)                                                                                                     \

@@ -34,6 +34,7 @@ struct SpmvTuning {
   int mv_strip_min_kb = 3000;  // ... strips engage when three periods' worth of X rows exceed this (an XCD's L2 holds 4 MB)
   int mv_strip_l2_kb  = 2500;  // ... and are sized so that three periods' worth of a strip's X rows stay below this
   int mv_glds        = 1;  // rank-2 LDS-staged kernel: X window through global_load_lds (1) or through registers (0)
+  int mv_long_T      = 0;  // rank-2 gather kernel: rows above this many entries get a workgroup each (0 = automatic: 4 x the average row, at least 64)
   int mv4_min_nvec   = 4;  // narrowest multivector the plane-marching kernel takes (a block of fewer than 16 columns runs its partial-block form)
   int mv4_wg_per_cu  = 8;  // rank-2 plane-marching kernel: workgroups per CU the k-chunking aims for (one is resident at a time)
   int march          = 0;  // rank 1 on the plane-marching analysis (lattice stencils, fp64 vectors): 0 off, 1 on
@@ -109,6 +110,9 @@ struct kkamd_spmv_plan {
   bool mv4_tried = false;
   // rank-2 wave-private kernel: its row blocks in strip order (see mv_build_strip_order)
   int32_t* d_mv2_order = nullptr;
+  // rank 2, gather kernel: rows longer than mv_long_T entries are left out of the wave-per-16-rows walk (one row group of a wave
+  // would chew through them alone) and done by a workgroup each afterwards; found once, at the first rank-2 call
+  int32_t* d_mv_long = nullptr; int64_t n_mv_long = 0, mv_long_T = 0; bool mv_long_known = false;
   int mv2_rb = 0;
   bool mv2_tried = false, mv_period_known = false;
   int64_t mv_period = 0;
