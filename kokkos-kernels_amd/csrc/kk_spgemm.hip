@@ -36,6 +36,7 @@
 #include "kk_common.h"
 #include "kk_scan.h"
 #include <climits>
+#include <algorithm>
 #include <map>
 #include <new>
 #include <string>
@@ -92,6 +93,7 @@ struct SpgemmTuning {
 #endif
   int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
+  int hub_split      = 1;         // hub rows: one workgroup per pass of kHubLa entries (sums of rows with several passes meet through fp64 atomics)
   int sym_large      = 0;         // symbolic: rows of 2049..8192 products through the 16384-slot hash kernel; 0 (default) = the bitmap kernel (R-MAT scale 20: the hash kernel spent 21 ms on 137 K such rows, symbolic 78 -> 68 ms without it)
   int keep_bitmaps   = 1;         // symbolic keeps the bitmaps of its densest rows for the first numeric call (0 = every row walks its products twice)
   int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
@@ -1380,7 +1382,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
                                                                       const VT* __restrict__ valA, const OffT* __restrict__ rmB,
                                                                       const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                       const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
-                                                                      VT* __restrict__ valC, int cap) {
+                                                                      VT* __restrict__ valC, int cap, const int32_t* __restrict__ items) {
   constexpr int H = kValTable, NT = kDenseBlock, KPT = (H / 2 + NT - 1) / NT, SG = KK_HUB_SG, NSUB = NT / SG, US = KK_HUB_US, EL = KK_HUB_EL;
   constexpr unsigned long long kSgMask = (1ull << SG) - 1ull;
   __shared__ int hk[H];
@@ -1392,14 +1394,19 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
   __shared__ int s_whi, s_nact;
   const int t = threadIdx.x, lane = t & 63, sub = t / SG, sl = t & (SG - 1);
   const int sg_shift = lane & ~(SG - 1);
-  const int64_t row = perm[blockIdx.x];
+  // items (optional): workgroup b does ONE pass of one row -- (index into perm, pass) pairs -- and adds its sums with atomics when the
+  // row has several (its values were zeroed before the launch): the heaviest row of R-MAT scale 20 (39,580 entries of A = 10 passes
+  // over 237 windows) kept one CU busy for most of the kernel's 65 ms
+  const int64_t row = perm[items ? items[2 * blockIdx.x] : (int)blockIdx.x];
+  const int only_pass = items ? items[2 * blockIdx.x + 1] : -1;
   const int64_t a00 = (int64_t)rmA[row], la_all = (int64_t)rmA[row + 1] - a00;
   const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
   for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
   // A rows longer than kHubLa are taken kHubLa entries at a time: every pass walks all windows of the row, the first one stores
   // its sums, the others add theirs (the same workgroup, one pass after the other: no atomics).  These rows used to accumulate
   // through L2 atomics into a k-wide HBM accumulator (spgemm_hub_acc_kernel: R-MAT scale 20, 211 rows, 8.8e8 products in 44 ms).
-  for (int64_t ach = 0; ach < la_all; ach += kHubLa) {
+  const bool shared_row = only_pass >= 0 && la_all > kHubLa;        // other workgroups add to the same values
+  for (int64_t ach = only_pass >= 0 ? (int64_t)only_pass * kHubLa : 0; ach < la_all; ach += kHubLa) {
   const bool first_pass = ach == 0;
   const int64_t a0 = a00 + ach;
   const int la     = (int)(la_all - ach < kHubLa ? la_all - ach : kHubLa);
@@ -1517,7 +1524,8 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
     for (int q = 0; q < KPT; ++q) {
       if (slot[q] >= 0) {
         VT* out = valC + base + done + t + q * NT;
-        *out = first_pass ? hv[slot[q]] : *out + hv[slot[q]];
+        if (shared_row) KK_ATOMIC_FADD(out, hv[slot[q]]);        // global_atomic_add_f64 into the row's (zeroed) values
+        else *out = first_pass ? hv[slot[q]] : *out + hv[slot[q]];
         hk[slot[q]] = -1; hv[slot[q]] = VT(0);
       }
       curk[q] = nxtk[q];
@@ -1525,7 +1533,19 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
     if (t == 0) s_nact = 0;
     __syncthreads();
   }
+  if (only_pass >= 0) break;
   }
+}
+// passes per listed row (host builds the (row, pass) items from it) and zeroing of the rows that several workgroups add to
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_hub_passes_kernel(int64_t n, const int32_t* __restrict__ perm, const OffT* __restrict__ rmA, int32_t* __restrict__ passes) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) { const int64_t la = (int64_t)rmA[perm[i] + 1] - (int64_t)rmA[perm[i]]; passes[i] = (int32_t)((la + kHubLa - 1) / kHubLa); }
+}
+template <class OffT, class VT>
+__global__ __launch_bounds__(kBlock) void spgemm_zero_rows_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ idx, const OffT* __restrict__ rmC, VT* __restrict__ valC) {
+  const int64_t row = perm[idx[blockIdx.x]];
+  for (int64_t i = (int64_t)rmC[row] + threadIdx.x; i < (int64_t)rmC[row + 1]; i += kBlock) valC[i] = VT(0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1544,6 +1564,8 @@ struct kkamd_spgemm_handle {
   int64_t nnzA = 0;
   bool b_sorted = false;           // rows of B column-sorted: dense rows may use the windowed LDS value kernel
   bool dense_lds = false;          // decided when the numeric bins are made
+  int32_t* d_hub_items = nullptr; int64_t n_hub_items = 0;      // (index, pass) pairs of the hub rows: one workgroup each
+  int32_t* d_hub_multi = nullptr; int64_t n_hub_multi = 0;      // indices of the hub rows with several passes (zeroed before the launch)
   bool hub_from_mid = false;       // the dense bin is cut [<= kValLa | <= kValLa2 | rest]: flat kernel twice, hub kernel for the rest
   int64_t n_dense_lds = 0;         // leading rows of the dense bin taken by the LDS value kernel,
   int64_t n_dense_hub_lds = 0;     // then rows for the LDS hub kernel; the rest accumulate in HBM
@@ -1824,6 +1846,8 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     }
     h->numeric_bins_ready = true;
     if (h->d_emit_perm) { (void)hipFree(h->d_emit_perm); h->d_emit_perm = nullptr; h->n_emit_stored = 0; }
+    if (h->d_hub_items) { (void)hipFree(h->d_hub_items); h->d_hub_items = nullptr; h->n_hub_items = 0; }
+    if (h->d_hub_multi) { (void)hipFree(h->d_hub_multi); h->d_hub_multi = nullptr; h->n_hub_multi = 0; }
   }
   const BinOffsets& off = h->num_off;
   const int sg = h->sg_log2;
@@ -1890,8 +1914,39 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     if (n_hub && flat_vals && h->hub_from_mid) {      // A rows above kValLa2 entries (the heaviest rows first): the cached-cursor hub kernel, kHubLa entries per pass
       int cap = g_spgemm.val_cap;
       cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
-      KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)n_hub, kDenseBlock, 0, st, dperm + n_lds + n_hubl, rmA, entA, valA, rmB, entB, valB,
-                rmC, (const int32_t*)entC, valC, cap);
+      const int32_t* hperm = dperm + n_lds + n_hubl;
+      if (g_spgemm.hub_split && !h->d_hub_items) {            // (row, pass) items, once per set of bins
+        DevBuf pb;
+        KK_HIP(pb.alloc(sizeof(int32_t) * (size_t)n_hub));
+        int32_t* d_p = pb.as<int32_t>();
+        KK_LAUNCH((spgemm_hub_passes_kernel<OffT>), (unsigned)ceil_div(n_hub, kBlock), kBlock, 0, st, n_hub, hperm, rmA, d_p);
+        std::vector<int32_t> h_p((size_t)n_hub), h_items, h_multi;
+        KK_HIP(hipMemcpyAsync(h_p.data(), d_p, sizeof(int32_t) * (size_t)n_hub, hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+        // the rows with the most passes first: their passes are the longest-running items
+        std::vector<int32_t> ord((size_t)n_hub);
+        for (int64_t i = 0; i < n_hub; ++i) ord[(size_t)i] = (int32_t)i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return h_p[(size_t)x] > h_p[(size_t)y]; });
+        for (int32_t i : ord) {
+          for (int32_t ps = 0; ps < h_p[(size_t)i]; ++ps) { h_items.push_back(i); h_items.push_back(ps); }
+          if (h_p[(size_t)i] > 1) h_multi.push_back(i);
+        }
+        h->n_hub_items = (int64_t)h_items.size() / 2; h->n_hub_multi = (int64_t)h_multi.size();
+        KK_HIP(hipMalloc((void**)&h->d_hub_items, sizeof(int32_t) * (h_items.size() ? h_items.size() : 1)));
+        KK_HIP(hipMalloc((void**)&h->d_hub_multi, sizeof(int32_t) * (h_multi.size() ? h_multi.size() : 1)));
+        if (!h_items.empty()) KK_HIP(hipMemcpyAsync(h->d_hub_items, h_items.data(), sizeof(int32_t) * h_items.size(), hipMemcpyHostToDevice, st));
+        if (!h_multi.empty()) KK_HIP(hipMemcpyAsync(h->d_hub_multi, h_multi.data(), sizeof(int32_t) * h_multi.size(), hipMemcpyHostToDevice, st));
+        KK_HIP(hipStreamSynchronize(st));
+      }
+      if (g_spgemm.hub_split && h->d_hub_items && h->n_hub_items > 0) {
+        const int32_t* d_items = h->d_hub_items; const int32_t* d_multi = h->d_hub_multi;
+        if (h->n_hub_multi) KK_LAUNCH((spgemm_zero_rows_kernel<OffT, VT>), (unsigned)h->n_hub_multi, kBlock, 0, st, hperm, d_multi, rmC, valC);
+        KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)h->n_hub_items, kDenseBlock, 0, st, hperm, rmA, entA, valA, rmB, entB, valB,
+                  rmC, (const int32_t*)entC, valC, cap, d_items);
+      } else {
+        KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)n_hub, kDenseBlock, 0, st, hperm, rmA, entA, valA, rmB, entB, valB,
+                  rmC, (const int32_t*)entC, valC, cap, (const int32_t*)nullptr);
+      }
       n_hub = 0;
     }
     if (n_hubl && flat_vals && h->hub_from_mid) {    // A rows of kValLa + 1 .. kValLa2 entries: the flat kernel with 1024 lists per pass
@@ -1905,7 +1960,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       int cap = g_spgemm.val_cap;
       cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
       KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)n_hubl, kDenseBlock, 0, st, dperm + n_lds, rmA, entA, valA, rmB, entB, valB,
-                rmC, (const int32_t*)entC, valC, cap);
+                rmC, (const int32_t*)entC, valC, cap, (const int32_t*)nullptr);
     }
     if (n_lds) {
       int cap = g_spgemm.val_cap;
@@ -1988,6 +2043,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
+  else if (k == "spgemm_hub_split") g_spgemm.hub_split = value != 0;
   else if (k == "spgemm_val_la2") { if (value < kValLa2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_la2 must be at least %d", kValLa2); g_spgemm.val_la2 = value; }
   else if (k == "spgemm_val_kernel") { if (value != 1 && value != 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_kernel is 1 or 2"); g_spgemm.val_kernel = value; }
   else if (k == "spgemm_val_la") g_spgemm.val_la = value;
@@ -2010,6 +2066,8 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (h->d_sizes) (void)hipFree(h->d_sizes);
   if (h->d_perm) (void)hipFree(h->d_perm);
   kk::free_bitmap_store(h);
+  if (h->d_hub_items) (void)hipFree(h->d_hub_items);
+  if (h->d_hub_multi) (void)hipFree(h->d_hub_multi);
   delete h;
   return KKAMD_OK;
 }
