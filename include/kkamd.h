@@ -95,7 +95,9 @@ int kkamd_spmv_plan_create_knobs(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A,
                                  const int* values, int nknobs, kkamd_stream_t stream);
 int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan);
 /* Frees the calling host thread's scratch of the handle-less route (tile descriptors + carry slots, grown on demand and
- * otherwise kept for the thread's life). */
+ * otherwise kept for the thread's life) and the process-wide buffer the SpGEMM symbolic phase parks row bitmaps in between a
+ * symbolic and the numeric call that consumes them (up to an eighth of the free HBM; kept between uses because allocating and
+ * freeing GBs per handle costs more than the phase itself). */
 int kkamd_release_scratch(void);
 
 /* y := alpha*op(A)*x + beta*y.  mode 'N','C' (== 'N' for real scalars), 'T','H' (== 'T').

@@ -38,6 +38,7 @@
 #include <climits>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -865,6 +866,14 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_emit_bitmap_kernel(const i
     pos0 += __shfl(inc, 63, 64);
   }
 }
+// rows of a bin whose size (products) reaches thr
+__global__ __launch_bounds__(kBlock) void spgemm_count_ge_kernel(int64_t n, const int32_t* __restrict__ perm, const int64_t* __restrict__ sizes, int64_t thr,
+                                                                unsigned long long* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool q = i < n && sizes[perm[i]] >= thr;
+  const kk_u64 m = __ballot(q);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
 // rows of the dense bin: those with a stored bitmap first, the others from the end
 __global__ __launch_bounds__(kBlock) void spgemm_split_stored_kernel(int64_t nd, const int32_t* __restrict__ perm_in, const int32_t* __restrict__ row_slot,
                                                                     int32_t* __restrict__ perm_out, unsigned long long* __restrict__ counters /*[2]*/) {
@@ -1579,7 +1588,7 @@ struct kkamd_spgemm_handle {
   std::map<std::string, double> hints;   // accepted-and-ignored tuning hints of the reference, by key
   // bitmaps of the densest rows, kept by the symbolic phase for the first numeric call (freed once entries(C) are written)
   void* d_bm_store = nullptr; int32_t* d_row_slot = nullptr; unsigned long long* d_bm_counter = nullptr;
-  int64_t bm_cap = 0, bm_stored = 0; int bm_words = 0;
+  int64_t bm_cap = 0, bm_stored = 0; int bm_words = 0; bool bm_pooled = false;
   int64_t bitmaps_used = 0;        // rows of the last numeric call whose entries(C) came from a stored bitmap
   int32_t* d_emit_perm = nullptr; int64_t n_emit_stored = 0;    // the dense bin as [rows with a stored bitmap | the others]
   bool entries_valid = false;      // entries(C) as the last numeric call left them are still what entC_ptr holds (numeric reuse)
@@ -1635,8 +1644,43 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
   return KKAMD_OK;
 }
 
+// The bitmap store is GBs (11.4 on R-MAT scale 20) and lives for one symbolic -> numeric hand-over.  hipMalloc / hipFree of
+// such a buffer is not free: every third or so symbolic phase took 1.3-1.6 s instead of 66 ms with an allocation per handle.  The
+// buffer is therefore kept in a process-wide pool between uses (one user at a time; a second concurrent handle allocates its own);
+// kkamd_release_scratch() gives it back.
+struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; std::mutex m; };
+static BmPool& bm_pool() { static BmPool pool; return pool; }
+int release_bitmap_pool();
+int release_bitmap_pool() {
+  BmPool& pool = bm_pool();
+  std::lock_guard<std::mutex> g(pool.m);
+  if (!pool.in_use && pool.p) { (void)hipFree(pool.p); pool.p = nullptr; pool.bytes = 0; }
+  return KKAMD_OK;
+}
+// `need` bytes for a handle's store: the pool's buffer when it is free (grown when it is less than half of what is wanted), else
+// an allocation of the handle's own.  Returns the bytes obtained (possibly fewer than asked for: the caller lowers its row cap).
+static size_t take_bitmap_store(kkamd_spgemm_handle* h, size_t need) {
+  BmPool& pool = bm_pool();
+  std::lock_guard<std::mutex> g(pool.m);
+  if (!pool.in_use) {
+    if (pool.bytes < need / 2 + 1) {
+      if (pool.p) { (void)hipFree(pool.p); pool.p = nullptr; pool.bytes = 0; }
+      if (hipMalloc(&pool.p, need) != hipSuccess) { (void)hipGetLastError(); pool.p = nullptr; return 0; }
+      pool.bytes = need;
+    }
+    pool.in_use = true; h->bm_pooled = true; h->d_bm_store = pool.p;
+    return pool.bytes < need ? pool.bytes : need;
+  }
+  if (hipMalloc(&h->d_bm_store, need) != hipSuccess) { (void)hipGetLastError(); h->d_bm_store = nullptr; return 0; }
+  h->bm_pooled = false;
+  return need;
+}
 static void free_bitmap_store(kkamd_spgemm_handle* h) {
-  if (h->d_bm_store) (void)hipFree(h->d_bm_store);
+  if (h->d_bm_store) {
+    if (h->bm_pooled) { BmPool& pool = bm_pool(); std::lock_guard<std::mutex> g(pool.m); pool.in_use = false; }
+    else (void)hipFree(h->d_bm_store);
+  }
+  h->bm_pooled = false;
   if (h->d_row_slot) (void)hipFree(h->d_row_slot);
   if (h->d_bm_counter) (void)hipFree(h->d_bm_counter);
   if (h->d_emit_perm) (void)hipFree(h->d_emit_perm);
@@ -1750,9 +1794,23 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
         size_t free_b = 0, total_b = 0;
         const int words = (int)ceil_div(k, (int64_t)64);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-          int64_t cap = (int64_t)(free_b / 8) / ((int64_t)words * 8);
+          int64_t cap = (int64_t)((free_b + bm_pool().bytes) / 8) / ((int64_t)words * 8);     // (what the pool holds is not "used" memory)
+          {
+            // no more slots than rows that can qualify: a row's products bound its entries, so only rows of the bin with at least
+            // k / 32 products can have k / 32 entries
+            DevBuf qc;
+            unsigned long long h_q = 0;
+            if (qc.alloc(sizeof(unsigned long long)) == hipSuccess && hipMemsetAsync(qc.p, 0, sizeof(unsigned long long), st) == hipSuccess) {
+              unsigned long long* d_q = qc.as<unsigned long long>(); const int32_t* d_bin = h->d_perm + off.off[4]; const int64_t* d_fl = h->d_sizes;
+              KK_LAUNCH(spgemm_count_ge_kernel, (unsigned)ceil_div(nb(4), kBlock), kBlock, 0, st, nb(4), d_bin, d_fl, k / 32, d_q);
+              if (hipMemcpyAsync(&h_q, d_q, sizeof h_q, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); h_q = (unsigned long long)nb(4); }
+            } else { (void)hipGetLastError(); h_q = (unsigned long long)nb(4); }
+            if (cap > (int64_t)h_q) cap = (int64_t)h_q;
+          }
           if (cap > nb(4)) cap = nb(4);
-          if (cap >= 1 && hipMalloc(&h->d_bm_store, (size_t)cap * (size_t)words * 8) == hipSuccess && hipMalloc((void**)&h->d_row_slot, sizeof(int32_t) * (size_t)m) == hipSuccess &&
+          const size_t got = cap >= 1 ? take_bitmap_store(h, (size_t)cap * (size_t)words * 8) : 0;
+          cap = (int64_t)(got / ((size_t)words * 8));
+          if (cap >= 1 && hipMalloc((void**)&h->d_row_slot, sizeof(int32_t) * (size_t)m) == hipSuccess &&
               hipMalloc((void**)&h->d_bm_counter, sizeof(unsigned long long)) == hipSuccess &&
               hipMemsetAsync(h->d_row_slot, 0xFF, sizeof(int32_t) * (size_t)m, st) == hipSuccess && hipMemsetAsync(h->d_bm_counter, 0, sizeof(unsigned long long), st) == hipSuccess) {
             h->bm_cap = cap; h->bm_words = words;

@@ -1480,7 +1480,7 @@ int kkamd_spmv_plan_export(const kkamd_spmv_plan_t* plan, const char* what, void
 }
 
 /* frees the calling host thread's scratch of the handle-less route (tile descriptors + carries, grown on demand) */
-int kkamd_release_scratch(void) { return kk::release_transient(); }
+int kkamd_release_scratch(void) { const int rc = kk::release_transient(); const int rc2 = kk::release_bitmap_pool(); return rc ? rc : rc2; }
 
 int kkamd_spmv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double alpha, const void* d_x, double beta,
                void* d_y, int vector_type, kkamd_stream_t stream) {

@@ -131,6 +131,7 @@ int64_t mv_plan_query(const kkamd_mv_plan* mv, int what);   // 0 tiles, 1 patter
 void mv4_plan_destroy(kkamd_mv4_plan* p);
 int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what);  // 0 workgroups, 1 rows outside the stencil, 2 stencil entries, 3 bytes, 4 near stride
 int  release_transient();
+int  release_bitmap_pool();      // kk_spgemm.hip: the pooled bitmap store of the SpGEMM symbolic -> numeric hand-over
 // rank 1 on the rank-2 plane-marching analysis (kk_spmv_mv.hip): builds the analysis on first use; returns 1 when it ran
 int  march_spmv(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* x, double* y, double alpha, double beta, hipStream_t st, int* ran);
 
