@@ -71,6 +71,7 @@ namespace kk {
 
 constexpr int kNumBins   = 5;      // 0 empty, 1 wave, 2 block-small, 3 block-large, 4 dense
 constexpr int kHashMul   = 107;
+constexpr int kFlopsLong = 2048;   // rows of A above this many entries get a workgroup in the row-flops pass
 constexpr int kSymWaveTable = 2048;   // symbolic keys only: 8 KB per wave
 constexpr int kWaveTable = 512;       // numeric keys + values
 constexpr int kSymBlkS = 4096,  kSymBlkL = 16384;   // 64 KB of keys: two workgroups per CU (32768 slots: one; R-MAT s20 symbolic 101 -> 94 ms)
@@ -94,6 +95,7 @@ struct SpgemmTuning {
 #endif
   int val_la         = kValLa;    // A rows up to this long use the cached-cursor value kernel (<= kValLa)
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
+  int emit_win_bits  = 0;         // numeric: bitmap window of the rows whose bitmap was not kept (0 = win_bits)
   int hub_split      = 1;         // hub rows: one workgroup per pass of kHubLa entries (sums of rows with several passes meet through fp64 atomics)
   int sym_large      = 0;         // symbolic: rows of 2049..8192 products through the 16384-slot hash kernel; 0 (default) = the bitmap kernel (R-MAT scale 20: the hash kernel spent 21 ms on 137 K such rows, symbolic 78 -> 68 ms without it)
   int keep_bitmaps   = 1;         // symbolic keeps the bitmaps of its densest rows for the first numeric call (0 = every row walks its products twice)
@@ -142,9 +144,10 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
   for (int64_t r0 = (int64_t)blockIdx.x * (kBlock / 8); r0 < m; r0 += stride) {     // workgroup-uniform trip count
     const int64_t row = r0 + threadIdx.x / 8;
     long long f = 0;
-    if (row < m) {
-      // four entries per lane and step, their loads independent: the longest row of A is walked by these 8 lanes alone (R-MAT scale 20:
-      // 39,580 entries = 4,947 dependent entries(A) -> row_map(B) round trips per lane with one entry per step, 5 of the kernel's 7 ms)
+    const bool mine = row < m && (int64_t)rmA[row + 1] - (int64_t)rmA[row] <= kFlopsLong;     // longer rows: spgemm_flops_long_kernel
+    if (mine) {
+      // four entries per lane and step, their loads independent (R-MAT scale 20: the longest row, 39,580 entries on these 8 lanes, was
+      // 5 of the kernel's 7 ms with one entry per step; rows above kFlopsLong entries now get a whole workgroup)
       const int64_t a_end = (int64_t)rmA[row + 1];
       for (int64_t a = (int64_t)rmA[row] + lane; a < a_end; a += 32) {
         int32_t c[4];
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
       }
     }
     f = group_sum(f, 8);
-    if (row < m && lane == 0) { flops[row] = f; sum += f; mx = f > mx ? f : mx; }
+    if (mine && lane == 0) { flops[row] = f; sum += f; mx = f > mx ? f : mx; }
   }
   sum = group_sum(sum, 64);
   for (int o = 32; o > 0; o >>= 1) { const long long other = __shfl_xor(mx, o, 64); mx = other > mx ? other : mx; }
@@ -170,6 +173,38 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
   }
 }
 
+// rows of A above kFlopsLong entries: every workgroup looks at kBlock rows and walks the long ones among them with all its
+// work-items (there are few: 211 above 4096 on R-MAT scale 20)
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_flops_long_kernel(int64_t m, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                   const OffT* __restrict__ rmB, int64_t* __restrict__ flops,
+                                                                   unsigned long long* __restrict__ stats, const OffT* __restrict__ endB = nullptr) {
+  __shared__ unsigned long long s_part[kBlock / 64];
+  __shared__ int s_long[kBlock];
+  __shared__ int s_n;
+  const int64_t r0 = (int64_t)blockIdx.x * kBlock;
+  const int64_t mine = r0 + threadIdx.x;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  if (mine < m && (int64_t)rmA[mine + 1] - (int64_t)rmA[mine] > kFlopsLong) s_long[atomicAdd(&s_n, 1)] = threadIdx.x;
+  __syncthreads();
+  const int n_long = s_n;
+  for (int i = 0; i < n_long; ++i) {
+    const int64_t row = r0 + s_long[i], b = (int64_t)rmA[row], e = (int64_t)rmA[row + 1];
+    long long f = 0;
+    for (int64_t a = b + threadIdx.x; a < e; a += kBlock) { const int32_t c = entA[a]; f += (long long)(endB ? endB[c] : rmB[c + 1]) - (long long)rmB[c]; }
+    f = group_sum(f, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (unsigned long long)f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long tot = 0;
+      for (int w = 0; w < kBlock / 64; ++w) tot += s_part[w];
+      flops[row] = (int64_t)tot;
+      atomicAdd(&stats[0], tot); atomicMax(&stats[1], tot);
+    }
+  }
+}
 // are the rows of a CRS graph column-sorted (non-strict)?  8 lanes per row; *unsorted is set to 1 otherwise.
 template <class OffT>
 __global__ __launch_bounds__(kBlock) void rows_sorted_kernel(int64_t n, const OffT* __restrict__ rm,
@@ -1631,8 +1666,9 @@ static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLi
 template <class OffT, bool EMIT>
 static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA, const int32_t* entA, const OffT* rmB,
                              const int32_t* entB, OffT* counts, const OffT* rmC, int32_t* entC, int64_t k, int sg, hipStream_t st,
-                             const OffT* endB = nullptr, const unsigned* maskB = nullptr, BitmapStore bs = BitmapStore()) {
+                             const OffT* endB = nullptr, const unsigned* maskB = nullptr, BitmapStore bs = BitmapStore(), int64_t win_cap = 0) {
   int64_t win = g_spgemm.win_bits;
+  if (win_cap > 0 && win > win_cap) win = win_cap;        // lighter rows: smaller windows, more workgroups per CU, several passes
   if (win > k) win = ceil_div(k, 64) * 64;
   const size_t smem = (size_t)(win / 8);
 #ifndef KK_EMU
@@ -1648,7 +1684,7 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
 // such a buffer is not free: every third or so symbolic phase took 1.3-1.6 s instead of 66 ms with an allocation per handle.  The
 // buffer is therefore kept in a process-wide pool between uses (one user at a time; a second concurrent handle allocates its own);
 // kkamd_release_scratch() gives it back.
-struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; std::mutex m; };
+struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; std::mutex m; };
 static BmPool& bm_pool() { static BmPool pool; return pool; }
 int release_bitmap_pool();
 int release_bitmap_pool() {
@@ -1662,11 +1698,13 @@ int release_bitmap_pool() {
 static size_t take_bitmap_store(kkamd_spgemm_handle* h, size_t need) {
   BmPool& pool = bm_pool();
   std::lock_guard<std::mutex> g(pool.m);
-  if (!pool.in_use) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (!pool.in_use && (pool.p == nullptr || pool.device == dev)) {      // the pool belongs to the device that filled it first
     if (pool.bytes < need / 2 + 1) {
       if (pool.p) { (void)hipFree(pool.p); pool.p = nullptr; pool.bytes = 0; }
       if (hipMalloc(&pool.p, need) != hipSuccess) { (void)hipGetLastError(); pool.p = nullptr; return 0; }
-      pool.bytes = need;
+      pool.bytes = need; pool.device = dev;
     }
     pool.in_use = true; h->bm_pooled = true; h->d_bm_store = pool.p;
     return pool.bytes < need ? pool.bytes : need;
@@ -1703,6 +1741,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   {
     const int64_t nbk = ceil_div(m * 8, kBlock);
     KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbk < 4096 ? nbk : 4096), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats);
+    KK_LAUNCH((spgemm_flops_long_kernel<OffT>), (unsigned)ceil_div(m, kBlock), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats);
   }
   unsigned long long h_stats[2] = {0, 0};
   KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
@@ -1738,6 +1777,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
       int64_t* d_cf = cflops.as<int64_t>();
       const int64_t nbf = ceil_div(m * 8, kBlock);
       KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbf < 4096 ? nbf : 4096), kBlock, 0, st, m, rmA, entA, rmB, d_cf, d_stats, (const OffT*)d_end);
+      KK_LAUNCH((spgemm_flops_long_kernel<OffT>), (unsigned)ceil_div(m, kBlock), kBlock, 0, st, m, rmA, entA, rmB, d_cf, d_stats, (const OffT*)d_end);
       KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
       KK_HIP(hipStreamSynchronize(st));
       h->compressed_mults = (int64_t)h_stats[0];
@@ -1953,7 +1993,8 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         const int32_t* d_ep = h->d_emit_perm; const int32_t* d_rs = h->d_row_slot; const kk_u64* d_st = (const kk_u64*)h->d_bm_store;
         KK_LAUNCH((spgemm_emit_bitmap_kernel<OffT>), (unsigned)ns, kDenseBlock, 0, st, d_ep, d_rs, d_st, h->bm_words, rmC, entC);
       }
-      if (nr && (rc = launch_dense_cols<OffT, true>(nr, h->d_emit_perm + ns, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
+      if (nr && (rc = launch_dense_cols<OffT, true>(nr, h->d_emit_perm + ns, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st, nullptr, nullptr,
+                                                    BitmapStore(), (int64_t)g_spgemm.emit_win_bits))) return rc;
       h->bitmaps_used = ns;
     }
     else if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
@@ -2102,6 +2143,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
   else if (k == "spgemm_hub_split") g_spgemm.hub_split = value != 0;
+  else if (k == "spgemm_emit_win_bits") { if (value < 0 || (value & 63)) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_emit_win_bits must be a multiple of 64"); g_spgemm.emit_win_bits = value; }
   else if (k == "spgemm_val_la2") { if (value < kValLa2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_la2 must be at least %d", kValLa2); g_spgemm.val_la2 = value; }
   else if (k == "spgemm_val_kernel") { if (value != 1 && value != 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_kernel is 1 or 2"); g_spgemm.val_kernel = value; }
   else if (k == "spgemm_val_la") g_spgemm.val_la = value;
@@ -2328,8 +2370,14 @@ int kkamd_dist_spgemm_partition(int64_t m, const void* d_row_mapA, const int32_t
     KK_HIP(hipMemsetAsync(s_b.p, 0, 2 * sizeof(unsigned long long), st));
     int64_t* d_f = f_b.as<int64_t>(); unsigned long long* d_s = s_b.as<unsigned long long>();
     const int64_t nbk = kk::ceil_div(m * 8, kk::kBlock);
-    if (offset_type == KKAMD_I64) { KK_LAUNCH((kk::spgemm_flops_kernel<int64_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int64_t*)d_row_mapA, d_entriesA, (const int64_t*)d_row_mapB, d_f, d_s); }
-    else { KK_LAUNCH((kk::spgemm_flops_kernel<int32_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int32_t*)d_row_mapA, d_entriesA, (const int32_t*)d_row_mapB, d_f, d_s); }
+    const unsigned gl = (unsigned)kk::ceil_div(m, (int64_t)kk::kBlock);
+    if (offset_type == KKAMD_I64) {
+      KK_LAUNCH((kk::spgemm_flops_kernel<int64_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int64_t*)d_row_mapA, d_entriesA, (const int64_t*)d_row_mapB, d_f, d_s);
+      KK_LAUNCH((kk::spgemm_flops_long_kernel<int64_t>), gl, kk::kBlock, 0, st, m, (const int64_t*)d_row_mapA, d_entriesA, (const int64_t*)d_row_mapB, d_f, d_s);
+    } else {
+      KK_LAUNCH((kk::spgemm_flops_kernel<int32_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int32_t*)d_row_mapA, d_entriesA, (const int32_t*)d_row_mapB, d_f, d_s);
+      KK_LAUNCH((kk::spgemm_flops_long_kernel<int32_t>), gl, kk::kBlock, 0, st, m, (const int32_t*)d_row_mapA, d_entriesA, (const int32_t*)d_row_mapB, d_f, d_s);
+    }
     KK_HIP(hipMemcpyAsync(flops.data(), d_f, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
   }

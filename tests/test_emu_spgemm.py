@@ -150,7 +150,16 @@ def test_spgemm_dense_row_windows(be):
     B1 = pc.randomized(oracle.random_crs(700, 20000, 12, variance=6, seed=21, sorted_rows=True))
     cols = np.sort(rng.choice(700, size=650, replace=False)).astype(np.int32)
     A1 = oracle.Crs(2, 700, np.array([0, 650, 653]), np.concatenate([cols, [1, 5, 9]]).astype(np.int32), 1 + 49 * rng.random(653))
+    # a row of A above the row-flops pass's workgroup-per-row threshold (2048 entries), next to short ones
+    B2 = pc.randomized(oracle.random_crs(3000, 5000, 3, variance=2, seed=22, sorted_rows=True))
+    cols2 = np.sort(rng.choice(3000, size=2500, replace=False)).astype(np.int32)
+    A2 = oracle.Crs(3, 3000, np.array([0, 2, 2502, 2505]), np.concatenate([[4, 7], cols2, [1, 5, 9]]).astype(np.int32), 1 + 49 * rng.random(2505))
+    pc.check_spgemm(be, A2, B2)
+    pc.check_spgemm(be, A2, B2, offset_dtype=np.int64)
     try:
+        _set(be, "spgemm_emit_win_bits", 4096)               # narrower windows for the numeric emission of rows whose bitmap was not kept
+        pc.check_spgemm(be, A0, B0)
+        _set(be, "spgemm_emit_win_bits", 0)
         _set(be, "spgemm_win_bits", 4096); _set(be, "spgemm_val_cap", 192)
         got = pc.check_spgemm(be, A0, B0)
         assert np.diff(got.row_map).max() > 12000
@@ -166,7 +175,7 @@ def test_spgemm_dense_row_windows(be):
         pc.check_spgemm(be, A1, B1)
     finally:
         _set(be, "spgemm_win_bits", 1 << 20); _set(be, "spgemm_val_cap", 2048); _set(be, "spgemm_force_unsorted", 0)
-        _set(be, "spgemm_emit_chunked", 0)
+        _set(be, "spgemm_emit_chunked", 0); _set(be, "spgemm_emit_win_bits", 0)
     ent, val = B0.entries.copy(), B0.values.copy()          # unsorted B: detected by the symbolic phase, dense rows fall back
     for i in range(B0.nrows):
         lo, hi = B0.row_map[i], B0.row_map[i + 1]
