@@ -142,6 +142,14 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *     "explicit_transpose"  modes T/H with an analysed handle: 1 (default) through a transpose cached in the plan when it fits an
  *                       eighth of free HBM, values that changed since the last call are moved into it; 2 the caller promises constant
  *                       values (no comparison either); 0 the reference's atomic scatter.  From "explicit_transpose_min_knnz"
+ *     "colslab"         mode N on matrices whose x gather defeats the caches (most tiles read plain entries, x is >= 16 MB, from
+ *                       "colslab_min_knnz" thousand nonzeros): 1 (default) the first call builds a second copy of the matrix in
+ *                       column-slab order (entries sorted by 2 MB segments of x, then by row; nnz * (8 + value + offset) bytes),
+ *                       times the CRS kernel and the copy and keeps the copy when it is 10 % faster; every call then re-fingerprints
+ *                       A's values (128 bits per 4096 values) and moves changed tiles into the copy.  Products reach y through
+ *                       atomics: results agree with the CRS kernel to rounding, not bit for bit.  2 = always (no gates, no timing:
+ *                       tests), 0 = never.  "colslab_shift" log2 of the columns per slab (0 = automatic), "colslab_const" 1 = the
+ *                       caller promises constant matrix values (no fingerprint pass)
  *   SpMV, rank 2
  *     "mv_kernel"       0 auto (plane-marching kernel where it applies -- analysed plan, fp64 vectors, right-hand sides in
  *                       blocks of 16 (a remainder: one more pass over the last 16 columns when beta = 0, else the gather kernel), a matrix that verifies as a radius-1 lattice stencil --, else the wave-private gather
@@ -165,7 +173,9 @@ int kkamd_set_default(const char* key, int value);
  * "code_tiles" / "staged_tiles" / "pattern_tiles", "window_codes" (1 if any tile uses the column analysis), "window_staged_x",
  * "plan_bytes" (HBM the analysis keeps), "transpose_cached", rank 2: "mv_tiles", "mv_staged_tiles", "mv_order" (order in use),
  * "mv_period" (far stride found), "mv_plan_bytes", plane-marching kernel: "mv4_workgroups" (0 = not in use), "mv4_other_rows"
- * (rows left to its gather kernel), "mv4_stencil" (entries of the stencil), "mv4_near_stride"; "march_workgroups" (rank-1 marching kernel, 0 = not in use). */
+ * (rows left to its gather kernel), "mv4_stencil" (entries of the stencil), "mv4_near_stride"; "march_workgroups" (rank-1 marching kernel, 0 = not in use);
+ * column-slab copy: "colslab" (1 = in use), "colslab_tried", "colslab_slabs", "colslab_shift", "colslab_bytes", and what the selection
+ * measured, "colslab_crs_us" / "colslab_us" (microseconds per call of the CRS kernel / of the copy; 0 = not measured). */
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);
 /* Copies a per-tile array of the analysis to a HOST buffer of `count` int32: "tile_first_row" (tiles + 1 entries: the first row that
  * starts at or after nonzero b * tile, bit 31 set when the tile starts inside a row -- the nnz-split counterpart of the

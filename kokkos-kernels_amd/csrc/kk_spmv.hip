@@ -996,6 +996,48 @@ static kkamd_spmv_plan* transient_plan(const kkamd_crs_t* A, const SpmvTuning& t
   return &p;
 }
 
+// Column-slab copy (kk_spmv_colslab.hip), decided once per plan at the first mode-N call: the analysis must say "gather-bound"
+// (most tiles read plain entries, x is several L2s large), then both kernels are timed on the caller's x into a scratch y and the
+// copy is kept when it wins by 10 % including its fingerprint pass.  colslab = 2 skips the gates and the timing (tests).
+template <class OffT, class AT, class YT>
+static int colslab_select(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const YT* x, hipStream_t st) {
+  plan->cs_tried = true;
+  const bool force = plan->tune.colslab == 2;
+  if (!force) {
+    const int64_t plain = plan->d_tinfo ? plan->plain_tiles : plan->nblocks;
+    if (A->nnz < (int64_t)plan->tune.colslab_min_knnz * 1000 || (double)A->num_cols * sizeof(YT) < 16.0 * 1048576.0 || 2 * plain < plan->nblocks) return KKAMD_OK;
+  }
+  int rc = cs_build(&plan->cs, A, (int)sizeof(YT), plan->tune.colslab_shift, st);
+  if (rc || !plan->cs || force) return rc;
+#ifdef KK_EMU
+  cs_plan_destroy(plan->cs); plan->cs = nullptr;                 // nothing to time under the emulator
+  return KKAMD_OK;
+#else
+  DevBuf ys;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  auto drop = [&]() { (void)hipGetLastError(); cs_plan_destroy(plan->cs); plan->cs = nullptr; for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); return KKAMD_OK; };
+  if (ys.alloc(sizeof(YT) * (size_t)A->num_rows) != hipSuccess) return drop();
+  for (hipEvent_t& e : ev) if (hipEventCreate(&e) != hipSuccess) return drop();
+  YT* yscr = ys.as<YT>();
+  const bool check = !plan->tune.colslab_const;
+  constexpr int kReps = 5;
+  for (int phase = 0; phase < 2; ++phase) {                     // phase 0 warms both up
+    if (phase == 1 && hipEventRecord(ev[0], st) != hipSuccess) return drop();
+    for (int i = 0; i < (phase ? kReps : 2); ++i) if ((rc = run_stream<OffT, AT, YT>(plan, A, x, yscr, YT(1), YT(0), st))) { drop(); return rc; }
+    if (phase == 1 && hipEventRecord(ev[1], st) != hipSuccess) return drop();
+    for (int i = 0; i < (phase ? kReps : 2); ++i) if ((rc = cs_apply(plan->cs, A, scalar_tag<YT>::value, x, yscr, 1.0, 0.0, check, st))) { drop(); return rc; }
+    if (phase == 1 && hipEventRecord(ev[2], st) != hipSuccess) return drop();
+  }
+  float ms_crs = 0.f, ms_cs = 0.f;
+  if (hipEventSynchronize(ev[2]) != hipSuccess || hipEventElapsedTime(&ms_crs, ev[0], ev[1]) != hipSuccess || hipEventElapsedTime(&ms_cs, ev[1], ev[2]) != hipSuccess) return drop();
+  plan->cs_crs_us = 1e3 * ms_crs / kReps; plan->cs_us = 1e3 * ms_cs / kReps;
+  if (g_verbose) printf("kkamd_spmv: column-slab copy %.1f us against %.1f us for the CRS kernel: %s\n", plan->cs_us, plan->cs_crs_us, plan->cs_us < 0.9 * plan->cs_crs_us ? "kept" : "dropped");
+  if (!(plan->cs_us < 0.9 * plan->cs_crs_us)) { drop(); return KKAMD_OK; }
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  return KKAMD_OK;
+#endif
+}
+
 template <class OffT, class AT, class YT>
 static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dx,
                       double beta_d, void* dy, hipStream_t st) {
@@ -1030,7 +1072,13 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
       if (rc || ran) return rc;
     }
   }
-  if (stream_usable(plan, A, (int)sizeof(AT))) return run_stream<OffT, AT, YT>(plan, A, x, y, alpha, beta, st);
+  if (stream_usable(plan, A, (int)sizeof(AT))) {
+    if (plan->tune.colslab && plan->entries == A->d_entries) {
+      if (!plan->cs_tried) { const int rc = colslab_select<OffT, AT, YT>(plan, A, x, st); if (rc) return rc; }
+      if (plan->cs) return cs_apply(plan->cs, A, scalar_tag<YT>::value, x, y, (double)alpha, (double)beta, !plan->tune.colslab_const, st);
+    }
+    return run_stream<OffT, AT, YT>(plan, A, x, y, alpha, beta, st);
+  }
   // No analysed plan (handle-less overloads, SPMV_FAST_SETUP): a large matrix is still worth the nnz-split kernel --
   // its "analysis" is one tiny kernel (a binary search per 4096-nnz tile) into a per-thread scratch that is reused
   // from call to call, so nothing is allocated or kept per matrix and the call stays asynchronous.
@@ -1062,7 +1110,7 @@ int check_crs(const kkamd_crs_t* A) {
 int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   if (!p) return KKAMD_OK;
   if (p->num_rows != A->num_rows || p->num_cols != A->num_cols || p->nnz != A->nnz || p->row_map != A->d_row_map ||
-      p->offset_type != A->offset_type || p->value_type != A->value_type || ((p->d_tinfo || p->mv || p->mv4 || p->t_ready) && p->entries != A->d_entries))
+      p->offset_type != A->offset_type || p->value_type != A->value_type || ((p->d_tinfo || p->mv || p->mv4 || p->t_ready || p->cs) && p->entries != A->d_entries))
     return fail(KKAMD_ERR_STATE, "kkamd_spmv: plan was created for a different matrix (a handle is bound to one matrix)");
   return KKAMD_OK;
 }
@@ -1109,6 +1157,10 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "window_codes_min_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.window_codes_min_pct = value; }
   else if (k == "pattern_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.pattern_codes = value; }
   else if (k == "pattern_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.pattern_codes_min_knnz = value; }
+  else if (k == "colslab") { if (value < 0 || value > 2) return bad("in 0..2"); t.colslab = value; }
+  else if (k == "colslab_min_knnz") { if (value < 0) return bad("non-negative"); t.colslab_min_knnz = value; }
+  else if (k == "colslab_shift") { if (value != 0 && (value < 2 || value > 30)) return bad("0 or in 2..30"); t.colslab_shift = value; }
+  else if (k == "colslab_const") { if (value != 0 && value != 1) return bad("0 or 1"); t.colslab_const = value; }
   else if (k == "transient_min_knnz") { if (value < 0) return bad("non-negative"); t.transient_min_knnz = value; }
   else if (k == "explicit_transpose") { if (value < 0 || value > 2) return bad("in 0..2"); t.explicit_transpose = value; }
   else if (k == "explicit_transpose_min_knnz") { if (value < 0) return bad("non-negative"); t.explicit_transpose_min_knnz = value; }
@@ -1398,6 +1450,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_mv_long) (void)hipFree(plan->d_mv_long);
   if (plan->mv) kk::mv_plan_destroy(plan->mv);
   if (plan->mv4) kk::mv4_plan_destroy(plan->mv4);
+  if (plan->cs) kk::cs_plan_destroy(plan->cs);
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
   if (plan->d_t_perm) (void)hipFree(plan->d_t_perm);
@@ -1431,6 +1484,11 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
     plan->mv2_tried = false;
   }
   if ((t.mv_order != old.mv_order || t.mv_strip_min_kb != old.mv_strip_min_kb || t.mv_strip_l2_kb != old.mv_strip_l2_kb) && plan->mv) { kk::mv_plan_destroy(plan->mv); plan->mv = nullptr; plan->mv_failed = false; }
+  if (t.colslab != old.colslab || t.colslab_shift != old.colslab_shift || t.colslab_min_knnz != old.colslab_min_knnz) {
+    if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
+    if (plan->cs) { kk::cs_plan_destroy(plan->cs); plan->cs = nullptr; }
+    plan->cs_tried = false; plan->cs_crs_us = plan->cs_us = 0.0;
+  }
   if (t.mv4_wg_per_cu != old.mv4_wg_per_cu && plan->mv4) {
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
     kk::mv4_plan_destroy(plan->mv4); plan->mv4 = nullptr; plan->mv4_tried = false;
@@ -1461,6 +1519,13 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "mv4_other_rows") *value = kk::mv4_plan_query(plan->mv4, 1);
   else if (k == "mv4_stencil") *value = kk::mv4_plan_query(plan->mv4, 2);
   else if (k == "mv4_near_stride") *value = kk::mv4_plan_query(plan->mv4, 4);
+  else if (k == "colslab") *value = plan->cs ? 1 : 0;
+  else if (k == "colslab_tried") *value = plan->cs_tried ? 1 : 0;
+  else if (k == "colslab_slabs") *value = kk::cs_plan_query(plan->cs, 0);
+  else if (k == "colslab_shift") *value = kk::cs_plan_query(plan->cs, 1);
+  else if (k == "colslab_bytes") *value = kk::cs_plan_query(plan->cs, 2);
+  else if (k == "colslab_crs_us") *value = (int64_t)(plan->cs_crs_us + 0.5);
+  else if (k == "colslab_us") *value = (int64_t)(plan->cs_us + 0.5);
   else if (k == "march_workgroups") *value = plan->tune.march ? kk::mv4_plan_query(plan->mv4, 5) : 0;
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: unknown key '%s'", key);
   return KKAMD_OK;

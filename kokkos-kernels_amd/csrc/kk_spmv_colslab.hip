@@ -1,0 +1,323 @@
+// kk_spmv_colslab.hip -- rank-1 y = beta*y + alpha*A*x for matrices whose x gather defeats the caches (uniform random columns:
+// every nonzero pulls its own 128-byte line of x through the fabric; the CRS kernel then runs at 0.09 of its CRS-byte roofline).
+//
+// The plan keeps a second copy of the matrix in COLUMN-SLAB order: the column range is cut into slabs of 2^shift columns whose x
+// segment (2 MB) fits an XCD's 4 MB L2 next to the streams; the entries are stably sorted by slab, so inside a slab they ascend by
+// row (then by position in the row).  The kernel streams (row, column, value) triples in that order: all eight XCDs sweep the same
+// slab at the same time, x comes out of L2, and every product goes to y through a global fp64/fp32 atomic add -- consecutive lanes
+// hold consecutive rows, so a wave's atomics fall into a handful of lines; runs of one row inside a wave are folded first.
+//   measured (tools/proto/colslab.py, one MI355X): uniform random 5e6 x 20: 1.76 -> 0.74 ms; R-MAT scale 22: 0.54 -> 0.43 ms.
+// The matrix values may change between calls (the handle is bound to the matrix, not to its values): every 4096-value tile of
+// A.values carries a 128-bit fingerprint (two independent multiply-add sums with position-dependent odd multipliers: one changed
+// value always changes them, any other change escapes with probability 2^-128); a call first re-fingerprints the values (8 bytes
+// per nonzero read) and moves the tiles that changed into the copy.  Knob colslab_const = 1 promises constant values.
+// Costs nnz * (8 + sizeof(value) + sizeof(offset)) bytes of plan memory.  The summation order differs from the CRS kernel's
+// (slab by slab, atomics): results agree to rounding, not bit for bit, and vary from run to run in the last bits.
+// No reference counterpart: KokkosSparse's native SpMV (sparse/impl/KokkosSparse_spmv_impl.hpp:104-160) and the rocSPARSE
+// wrapper (sparse/tpls/KokkosSparse_spmv_tpl_spec_decl.hpp:383-470) run row-major CRS kernels on these matrices.
+#include "kk_spmv_plan.h"
+
+#ifdef KK_EMU
+#define KK_CS_FADD(p, v) atomicAdd((p), (v))
+#else
+#define KK_CS_FADD(p, v) unsafeAtomicAdd((p), (v))   // global_atomic_add_f64 / _f32, no return
+#endif
+
+struct kkamd_cs_plan {
+  int shift = 0, nslabs = 0, offset_type = 0, value_type = 0;
+  int64_t nnz = 0, ntiles = 0;
+  int32_t* d_row = nullptr;
+  int32_t* d_col = nullptr;
+  void* d_val = nullptr;                 // [nnz] values in slab order
+  void* d_dst = nullptr;                 // [nnz] offset type: where entry i of A sits in the slab order
+  unsigned long long* d_fp = nullptr;    // [2 * ntiles] fingerprints of A.values, tile by tile
+  size_t bytes = 0;
+  double crs_us = 0.0, cs_us = 0.0;      // what the selection measured (0: not measured)
+};
+
+namespace kk {
+
+constexpr int kCsPer      = 16;                 // entries per work-item of a sort / fingerprint tile
+constexpr int kCsTile     = kBlock * kCsPer;    // 4096
+constexpr int kCsMaxSlabs = 256;
+constexpr int kCsU        = 8;                  // entries per work-item of the SpMV kernel
+
+// ------------------------------------------------------------------------------------------------
+// stable counting sort by slab, pass 1: entries per (slab, tile), slab-major so that one prefix sum gives every (slab, tile) its start
+__global__ __launch_bounds__(kBlock) void cs_hist_kernel(int64_t nnz, const int32_t* __restrict__ ent, int shift, int nslabs, int64_t ntiles,
+                                                         int64_t* __restrict__ H) {
+  __shared__ int s_h[kCsMaxSlabs];
+  for (int k = threadIdx.x; k < nslabs; k += kBlock) s_h[k] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kCsTile;
+  for (int u = 0; u < kCsPer; ++u) {
+    const int64_t i = base + (int64_t)u * kBlock + threadIdx.x;
+    if (i < nnz) atomicAdd(&s_h[ent[i] >> shift], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nslabs; k += kBlock) H[(int64_t)k * ntiles + blockIdx.x] = s_h[k];
+}
+
+// largest r in [lo, hi) with rm[r] <= i  (rm[lo] <= i < rm[hi] on entry)
+template <class OffT> __device__ __forceinline__ int64_t cs_row_of(const OffT* __restrict__ rm, int64_t i, int64_t lo, int64_t hi) {
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)rm[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// pass 2: every wave takes a contiguous quarter of the tile in steps of 64 consecutive entries; inside a step the lanes of one slab
+// are ranked by lane (match-any over the slab bits), the steps and waves by their per-slab cursors -- the order inside a slab is the
+// CRS order, i.e. ascending rows
+template <class OffT, class AT>
+__global__ __launch_bounds__(kBlock) void cs_scatter_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ rm, const int32_t* __restrict__ ent,
+                                                            const AT* __restrict__ val, int shift, int nslabs, int nbits, int64_t ntiles,
+                                                            const int64_t* __restrict__ H, int32_t* __restrict__ o_row, int32_t* __restrict__ o_col,
+                                                            AT* __restrict__ o_val, OffT* __restrict__ dst) {
+  __shared__ int s_cnt[kBlock / 64][kCsMaxSlabs];
+  __shared__ int64_t s_start[kBlock / 64][kCsMaxSlabs];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int kQuarter = kCsTile / (kBlock / 64);
+  const int64_t q0 = (int64_t)blockIdx.x * kCsTile + (int64_t)w * kQuarter;
+  for (int k = threadIdx.x; k < (kBlock / 64) * kCsMaxSlabs; k += kBlock) (&s_cnt[0][0])[k] = 0;
+  __syncthreads();
+  for (int s = 0; s < kQuarter / 64; ++s) {
+    const int64_t i = q0 + (int64_t)s * 64 + lane;
+    if (i < nnz) atomicAdd(&s_cnt[w][ent[i] >> shift], 1);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nslabs; k += kBlock) {
+    int64_t b = H[(int64_t)k * ntiles + blockIdx.x];
+    for (int ww = 0; ww < kBlock / 64; ++ww) { s_start[ww][k] = b; b += s_cnt[ww][k]; }
+  }
+  __syncthreads();
+  int64_t r_prev = 0;                                           // rows only go up along the quarter
+  for (int s = 0; s < kQuarter / 64; ++s) {
+    const int64_t i_first = q0 + (int64_t)s * 64;
+    if (i_first >= nnz) break;                                  // wave-uniform
+    const int64_t i_last = i_first + 63 < nnz ? i_first + 63 : nnz - 1;
+    const int64_t i = i_first + lane;
+    const bool ok = i < nnz;
+    const int32_t c = ok ? ent[i] : 0;
+    const int key = c >> shift;
+    unsigned long long mask = __ballot(ok);
+    for (int b = 0; b < nbits; ++b) {
+      const bool bit = (key >> b) & 1;
+      const unsigned long long m = __ballot(ok && bit);
+      mask &= bit ? m : ~m;
+    }
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull)), total = __popcll(mask);
+    int64_t pos = 0;
+    if (ok) pos = s_start[w][key] + rank;
+    KK_WAVE_SYNC();
+    if (ok && rank == total - 1) s_start[w][key] += total;
+    KK_WAVE_SYNC();
+    const int64_t r_lo = cs_row_of<OffT>(rm, i_first, r_prev, nrows), r_hi = cs_row_of<OffT>(rm, i_last, r_lo, nrows);
+    r_prev = r_hi;
+    if (ok) {
+      const int64_t row = cs_row_of<OffT>(rm, i, r_lo, r_hi + 1);
+      o_row[pos] = (int32_t)row; o_col[pos] = c; o_val[pos] = val[i]; dst[i] = (OffT)pos;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fingerprints of A.values
+__device__ __forceinline__ unsigned long long cs_mix(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned long long cs_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned long long cs_bits(float v) { return (unsigned long long)(unsigned)__float_as_int(v); }
+
+// INIT: record the fingerprints (the copy was just made from these values).  Otherwise: tiles whose fingerprint moved are copied
+// into the slab order again.
+template <class OffT, class AT, bool INIT>
+__global__ __launch_bounds__(kBlock) void cs_check_kernel(int64_t nnz, const AT* __restrict__ val, const OffT* __restrict__ dst, AT* __restrict__ o_val,
+                                                          unsigned long long* __restrict__ fp) {
+  __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
+  __shared__ int s_diff;
+  const int64_t base = (int64_t)blockIdx.x * kCsTile;
+  AT v[kCsPer];
+  unsigned long long a = 0, b = 0;
+  KK_UNROLL
+  for (int u = 0; u < kCsPer; ++u) {
+    const int64_t i = base + (int64_t)u * kBlock + threadIdx.x;
+    v[u] = i < nnz ? val[i] : AT(0);
+    const unsigned long long bits = cs_bits(v[u]);
+    a += bits * (cs_mix((unsigned long long)i) | 1ull);
+    b += ((bits << 29) | (bits >> 35)) * (cs_mix((unsigned long long)i ^ 0x5851F42D4C957F2Dull) | 1ull);
+  }
+  a = group_sum(a, 64); b = group_sum(b, 64);
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long ta = 0, tb = 0;
+    for (int w = 0; w < kBlock / 64; ++w) { ta += s_a[w]; tb += s_b[w]; }
+    const bool diff = INIT || fp[2 * (int64_t)blockIdx.x] != ta || fp[2 * (int64_t)blockIdx.x + 1] != tb;
+    if (diff) { fp[2 * (int64_t)blockIdx.x] = ta; fp[2 * (int64_t)blockIdx.x + 1] = tb; }
+    s_diff = (!INIT && diff) ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_diff) {
+    KK_UNROLL
+    for (int u = 0; u < kCsPer; ++u) {
+      const int64_t i = base + (int64_t)u * kBlock + threadIdx.x;
+      if (i < nnz) o_val[dst[i]] = v[u];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// y += alpha * A * x over the slab order
+template <class AT, class YT>
+__global__ __launch_bounds__(kBlock) void cs_spmv_kernel(int64_t nnz, const int32_t* __restrict__ row, const int32_t* __restrict__ col,
+                                                         const AT* __restrict__ val, int shift, const YT* __restrict__ x, YT* __restrict__ y, YT alpha) {
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * kCsU);
+  const int lane = threadIdx.x & 63;
+  int32_t r[kCsU], c[kCsU];
+  AT v[kCsU];
+  KK_UNROLL
+  for (int u = 0; u < kCsU; ++u) {
+    const int64_t i = base + (int64_t)u * kBlock + threadIdx.x;
+    const bool ok = i < nnz;
+    r[u] = ok ? row[i] : -1; c[u] = ok ? col[i] : 0; v[u] = ok ? val[i] : AT(0);
+  }
+  YT p[kCsU];
+  KK_UNROLL
+  for (int u = 0; u < kCsU; ++u) p[u] = (YT)v[u] * x[c[u]];
+  KK_UNROLL
+  for (int u = 0; u < kCsU; ++u) {
+    // runs of one (slab, row) inside the wave fold into their first lane
+    const int slab = r[u] < 0 ? -1 : (c[u] >> shift);
+    const int rp = __shfl_up(r[u], 1, 64), sp = __shfl_up(slab, 1, 64);
+    const bool head = lane == 0 || rp != r[u] || sp != slab;
+    const unsigned long long heads = __ballot(head);
+    YT s = p[u];
+    if (heads != ~0ull) {                                       // wave-uniform
+      const unsigned long long rest = lane == 63 ? 0ull : heads >> (lane + 1);
+      const int end = rest ? lane + __ffsll(rest) : 64;         // first lane of the next run
+      for (int o = 1; o < 64; o <<= 1) {
+        const YT t = __shfl_down(s, o, 64);
+        if (lane + o < end) s += t;
+      }
+    }
+    if (head && r[u] >= 0) KK_CS_FADD(&y[r[u]], alpha * s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+void cs_plan_destroy(kkamd_cs_plan* cs) {
+  if (!cs) return;
+  void* bufs[] = {cs->d_row, cs->d_col, cs->d_val, cs->d_dst, cs->d_fp};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  delete cs;
+}
+
+int64_t cs_plan_query(const kkamd_cs_plan* cs, int what) {
+  if (!cs) return 0;
+  switch (what) {
+    case 0: return cs->nslabs;
+    case 1: return cs->shift;
+    case 2: return (int64_t)cs->bytes;
+    case 3: return (int64_t)(cs->crs_us + 0.5);
+    case 4: return (int64_t)(cs->cs_us + 0.5);
+    default: return 0;
+  }
+}
+void cs_plan_set_times(kkamd_cs_plan* cs, double crs_us, double cs_us) { if (cs) { cs->crs_us = crs_us; cs->cs_us = cs_us; } }
+
+template <class OffT, class AT>
+static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, hipStream_t st) {
+  *out = nullptr;
+  const int64_t nnz = A->nnz;
+  kkamd_cs_plan* cs = new (std::nothrow) kkamd_cs_plan();
+  if (!cs) return KKAMD_OK;
+  cs->shift = shift; cs->nslabs = (int)ceil_div(A->num_cols, (int64_t)1 << shift);
+  cs->nnz = nnz; cs->ntiles = ceil_div(nnz, (int64_t)kCsTile);
+  cs->offset_type = A->offset_type; cs->value_type = A->value_type;
+  auto give_up = [&]() { (void)hipGetLastError(); cs_plan_destroy(cs); return KKAMD_OK; };      // the copy is an optimisation: no memory, no copy
+  const size_t hn = (size_t)cs->nslabs * (size_t)cs->ntiles + 1;
+  DevBuf hist;
+  if (hipMalloc((void**)&cs->d_row, sizeof(int32_t) * (size_t)nnz) != hipSuccess || hipMalloc((void**)&cs->d_col, sizeof(int32_t) * (size_t)nnz) != hipSuccess ||
+      hipMalloc(&cs->d_val, sizeof(AT) * (size_t)nnz) != hipSuccess || hipMalloc(&cs->d_dst, sizeof(OffT) * (size_t)nnz) != hipSuccess ||
+      hipMalloc((void**)&cs->d_fp, 16 * (size_t)cs->ntiles) != hipSuccess || hist.alloc(sizeof(int64_t) * hn) != hipSuccess)
+    return give_up();
+  cs->bytes = (size_t)nnz * (8 + sizeof(AT) + sizeof(OffT)) + 16 * (size_t)cs->ntiles;
+  int64_t* H = hist.as<int64_t>();
+  int nbits = 0;
+  while ((1 << nbits) < cs->nslabs) ++nbits;
+  if (hipMemsetAsync(H + (hn - 1), 0, sizeof(int64_t), st) != hipSuccess) return give_up();
+  KK_LAUNCH(cs_hist_kernel, (unsigned)cs->ntiles, kBlock, 0, st, nnz, (const int32_t*)A->d_entries, shift, cs->nslabs, cs->ntiles, H);
+  int rc = kkamd_exclusive_scan(H, (int64_t)hn, KKAMD_I64, reinterpret_cast<kkamd_stream_t>(st));
+  if (rc) { cs_plan_destroy(cs); return rc; }
+  int32_t* o_row = cs->d_row; int32_t* o_col = cs->d_col; AT* o_val = (AT*)cs->d_val; OffT* dst = (OffT*)cs->d_dst;
+  unsigned long long* fp = cs->d_fp;
+  const int nslabs = cs->nslabs; const int64_t ntiles = cs->ntiles;
+  KK_LAUNCH((cs_scatter_kernel<OffT, AT>), (unsigned)ntiles, kBlock, 0, st, A->num_rows, nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries,
+            (const AT*)A->d_values, shift, nslabs, nbits, ntiles, (const int64_t*)H, o_row, o_col, o_val, dst);
+  KK_LAUNCH((cs_check_kernel<OffT, AT, true>), (unsigned)ntiles, kBlock, 0, st, nnz, (const AT*)A->d_values, (const OffT*)dst, o_val, fp);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return give_up();
+  *out = cs;
+  return KKAMD_OK;
+}
+
+// Builds the slab-order copy (nullptr in *out when HBM cannot hold it).  x_elem: bytes per x element (sizes the slabs).
+int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st) {
+  *out = nullptr;
+  if (A->nnz <= 0 || A->num_rows <= 0 || A->num_cols <= 0) return KKAMD_OK;
+  int shift = shift_knob;
+  if (shift <= 0) {
+    // 2 MB of x per slab; up to 8 MB when the rows are so short that a slab would hold less than half an entry per row (the
+    // atomics of a wave then scatter over y: 2e7 rows x 8 at 2 / 4 / 8 MB slabs 4.97 / 3.72 / 2.85 ms, 1e7 x 12: 2.14 / 1.48 / 1.76)
+    shift = x_elem == 8 ? 18 : 19;
+    const double per_row = (double)A->nnz / (double)A->num_rows;
+    for (int widen = 0; widen < 2 && per_row * (double)((int64_t)1 << shift) < 0.5 * (double)A->num_cols; ++widen) ++shift;
+  }
+  while (ceil_div(A->num_cols, (int64_t)1 << shift) > kCsMaxSlabs) ++shift;
+  const size_t off_b = A->offset_type == KKAMD_I64 ? 8 : 4, val_b = A->value_type == KKAMD_F64 ? 8 : 4;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
+  const double need = (double)A->nnz * (8.0 + val_b + off_b) + 8.0 * (double)ceil_div(A->num_cols, (int64_t)1 << shift) * (double)ceil_div(A->nnz, (int64_t)kCsTile);
+  if (need > (double)free_b / 4.0) return KKAMD_OK;
+  const bool o64 = A->offset_type == KKAMD_I64;
+  if (A->value_type == KKAMD_F64) return o64 ? cs_build_typed<int64_t, double>(out, A, shift, st) : cs_build_typed<int32_t, double>(out, A, shift, st);
+  return o64 ? cs_build_typed<int64_t, float>(out, A, shift, st) : cs_build_typed<int32_t, float>(out, A, shift, st);
+}
+
+template <class OffT, class AT, class YT>
+static int cs_apply_typed(kkamd_cs_plan* cs, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, bool check, hipStream_t st) {
+  const int64_t nnz = cs->nnz;
+  AT* o_val = (AT*)cs->d_val;
+  if (check) {
+    const OffT* dst = (const OffT*)cs->d_dst; unsigned long long* fp = cs->d_fp;
+    KK_LAUNCH((cs_check_kernel<OffT, AT, false>), (unsigned)cs->ntiles, kBlock, 0, st, nnz, (const AT*)A->d_values, dst, o_val, fp);
+  }
+  int rc = launch_scale<YT>(y, A->num_rows, 1, 1, 0, beta, st);
+  if (rc) return rc;
+  const int32_t* row = cs->d_row; const int32_t* col = cs->d_col; const int shift = cs->shift;
+  KK_LAUNCH((cs_spmv_kernel<AT, YT>), (unsigned)ceil_div(nnz, (int64_t)kBlock * kCsU), kBlock, 0, st, nnz, row, col, (const AT*)o_val, shift, x, y, alpha);
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+
+int cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, bool check, hipStream_t st) {
+  if (cs->nnz != A->nnz || cs->offset_type != A->offset_type || cs->value_type != A->value_type)
+    return fail(KKAMD_ERR_STATE, "kkamd_spmv: the column-slab copy belongs to another matrix");
+  const bool o64 = A->offset_type == KKAMD_I64;
+  if (A->value_type == KKAMD_F64 && vector_type == KKAMD_F64)
+    return o64 ? cs_apply_typed<int64_t, double, double>(cs, A, (const double*)x, (double*)y, alpha, beta, check, st)
+               : cs_apply_typed<int32_t, double, double>(cs, A, (const double*)x, (double*)y, alpha, beta, check, st);
+  if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F32)
+    return o64 ? cs_apply_typed<int64_t, float, float>(cs, A, (const float*)x, (float*)y, (float)alpha, (float)beta, check, st)
+               : cs_apply_typed<int32_t, float, float>(cs, A, (const float*)x, (float*)y, (float)alpha, (float)beta, check, st);
+  if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F64)
+    return o64 ? cs_apply_typed<int64_t, float, double>(cs, A, (const double*)x, (double*)y, alpha, beta, check, st)
+               : cs_apply_typed<int32_t, float, double>(cs, A, (const double*)x, (double*)y, alpha, beta, check, st);
+  return fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv: unsupported (value,vector) type pair (%d,%d)", A->value_type, vector_type);
+}
+
+}  // namespace kk

@@ -50,6 +50,12 @@ struct SpmvTuning {
   int pattern_codes = 1;           // staged-x tiles: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one
                                    // (27-pt 300^3 1.349 -> 1.267 ms, 7-pt 400^3 1.025 -> 0.940 ms), 2 = whenever any tile has one, 0 = never
   int pattern_codes_min_knnz = 10000;  // ... from this many thousand nnz (5-pt 1000^2, 5e6 nnz: 17.5 -> 18.3 us with the records)
+  int colslab = 1;                 // rank 1, mode N, matrices whose x gather defeats the caches (kk_spmv_colslab.hip): 1 = build the column-slab copy
+                                   // at the first call when the analysis says "gather-bound", time both kernels and keep the faster; 2 = always
+                                   // use the copy (tests); 0 = never
+  int colslab_min_knnz = 20000;    // ... from this many thousand nnz
+  int colslab_shift = 0;           // ... log2 of the columns per slab (0 = 2 MB of x)
+  int colslab_const = 0;           // ... 1 = the caller promises constant matrix values (no fingerprint pass per call)
 #ifdef KK_ABLATE                   // measurement build only (tools/, libkkamd_ablate.so): never part of libkkamd.so
   int ablate         = 0;          // switches parts of the kernels off (see the kernels)
   int lds_pad_kb     = 0;          // extra dynamic LDS per workgroup (caps workgroups per CU)
@@ -68,6 +74,7 @@ constexpr int kTilePlain = 0, kTileCodes = 1, kTileStaged = 2, kTilePattern = 3;
 
 struct kkamd_mv_plan;   // kk_spmv_mv.hip
 struct kkamd_mv4_plan;  // kk_spmv_mv.hip
+struct kkamd_cs_plan;   // kk_spmv_colslab.hip
 
 struct kkamd_spmv_plan {
   int64_t num_rows = 0, num_cols = 0, nnz = 0;
@@ -113,6 +120,10 @@ struct kkamd_spmv_plan {
   // rank 2, gather kernel: rows longer than mv_long_T entries are left out of the wave-per-16-rows walk (one row group of a wave
   // would chew through them alone) and done by a workgroup each afterwards; found once, at the first rank-2 call
   int32_t* d_mv_long = nullptr; int64_t n_mv_long = 0, mv_long_T = 0; bool mv_long_known = false;
+  // rank 1, column-slab copy (kk_spmv_colslab.hip): decided at the first mode-N call that can use it
+  kkamd_cs_plan* cs = nullptr;
+  bool cs_tried = false;
+  double cs_crs_us = 0.0, cs_us = 0.0;     // what the selection measured, kept when the copy lost and was freed
   int mv2_rb = 0;
   bool mv2_tried = false, mv_period_known = false;
   int64_t mv_period = 0;
@@ -130,6 +141,10 @@ void mv_plan_destroy(kkamd_mv_plan* mv);
 int64_t mv_plan_query(const kkamd_mv_plan* mv, int what);   // 0 tiles, 1 pattern tiles, 2 order in use, 3 bytes
 void mv4_plan_destroy(kkamd_mv4_plan* p);
 int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what);  // 0 workgroups, 1 rows outside the stencil, 2 stencil entries, 3 bytes, 4 near stride
+void cs_plan_destroy(kkamd_cs_plan* cs);
+int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes
+int  cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st);
+int  cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, bool check, hipStream_t st);
 int  release_transient();
 int  release_bitmap_pool();      // kk_spgemm.hip: the pooled bitmap store of the SpGEMM symbolic -> numeric hand-over
 // rank 1 on the rank-2 plane-marching analysis (kk_spmv_mv.hip): builds the analysis on first use; returns 1 when it ran

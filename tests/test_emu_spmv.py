@@ -476,3 +476,52 @@ def test_tile_descriptors_against_merge_path(be):
             while ended < A0.nrows and rm[ended + 1] == rm[ended] and rm[ended] == p: ended += 1   # empty rows at p belong to neither side
             assert (got[b] & 0x7fffffff) == first and bool(got[b] >> 31 & 1) == bool(inside), (b, got[b], first, inside)
             assert first == ended + (1 if inside else 0) or rm[first] == p, (b, first, ended, inside)
+
+
+def test_column_slab_copy(be):
+    # kk_spmv_colslab.hip: forced (colslab = 2) with narrow slabs so that small matrices have many of them; the stable sort by slab,
+    # the wave fold of equal rows, the tail tile, empty rows, duplicate entries and the int64 / float variants
+    cases = [oracle.random_crs(3000, 3000, 9, variance=4, seed=3),                       # ~27 K entries: 7 sort tiles
+             _custom([0, 0, 700, 1, 0, 5000, 3, 0, 0, 64, 65, 0], 4000, seed=4),        # rows longer than a tile, empty rows
+             oracle.random_crs(500, 9000, 40, variance=10, seed=6)]                      # wide: more columns than rows
+    r, e = cases[0].row_map, cases[0].entries.copy()
+    e[r[10]:r[10] + 3] = e[r[10]]                                                        # duplicate columns inside a row
+    cases.append(oracle.Crs(3000, 3000, r, e, cases[0].values))
+    for A0 in cases:
+        for shift in (4, 7, 12):
+            kn = {"colslab": 2, "colslab_shift": shift}
+            h = pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=50.0, expect={"colslab": 1, "colslab_shift": max(shift, int(np.ceil(np.log2(A0.ncols / 256))))})
+            assert h.query("colslab_slabs") == -(-A0.ncols // (1 << h.query("colslab_shift")))
+            pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs=kn, max_val=50.0, nans=True)
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0, offset_dtype=np.int64, value_dtype=np.float32)
+        pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6, "colslab_const": 1}, max_val=50.0, value_dtype=np.float32, vec_dtype=np.float32)
+        pc.check_spmv(be, A0, "T", 1.0, 0.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0)          # mode T never takes the copy of A
+    # the automatic mode does nothing on a small matrix, and nothing at all under the emulator (there is nothing to time)
+    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 1})
+    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 0}, expect={"colslab": 0, "colslab_tried": 0})
+
+
+def test_column_slab_follows_value_changes(be):
+    # the copy holds its own values: a call fingerprints A.values tile by tile and moves the tiles that changed
+    A0 = oracle.random_crs(2500, 2500, 10, variance=3, seed=8)
+    rng = np.random.default_rng(1)
+    x = rng.random(A0.ncols)
+    A = pc.dev(be, A0)
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT"); h.set("colslab", 2); h.set("colslab_shift", 5)
+    xd, yd = be.from_numpy(x), be.from_numpy(np.zeros(A0.nrows))
+    def run_and_check(vals):
+        pc.kk.spmv(h, "N", 1.0, A, xd, 0.0, yd)
+        exp = oracle.spmv_serial("N", oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, vals), 1.0, x, 0.0, np.zeros(A0.nrows))
+        np.testing.assert_allclose(be.to_numpy(yd), exp, rtol=1e-12, atol=1e-12)
+    run_and_check(A0.values)
+    assert h.query("colslab") == 1
+    v = A0.values.copy()
+    v[5000] = -7.25                                       # one value in one tile
+    A.values[:] = be.from_numpy(v)
+    run_and_check(v)
+    v = v * 3.0 + 1.0                                     # every value
+    A.values[:] = be.from_numpy(v)
+    run_and_check(v)
+    v[[0, len(v) - 1]] = v[[len(v) - 1, 0]]               # two values swapped (the plain sum of the bits does not move)
+    A.values[:] = be.from_numpy(v)
+    run_and_check(v)

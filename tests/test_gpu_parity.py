@@ -869,3 +869,60 @@ def test_full_size_27pt_properties(be):
     ys = torch.zeros_like(y)
     pc.kk.spmv_struct("N", 2, (n, n, n), 1.0, A, x1, 0.0, ys)
     assert (ys - y1).abs().max().item() <= tol
+
+
+def test_column_slab_copy(be):
+    # rank 1 on gather-bound matrices (kk_spmv_colslab.hip): the column-slab copy forced with narrow slabs (many slabs on small matrices),
+    # every type pair, beta 0 over NaNs, duplicates, rows longer than a sort tile, empty rows
+    base = oracle.random_crs(30000, 30000, 12, variance=5, seed=3)
+    r, e = base.row_map, base.entries.copy()
+    e[r[10]:r[10] + 3] = e[r[10]]
+    cases = [base, oracle.Crs(30000, 30000, r, e, base.values), pc.hub_matrix(3000, 9000, 6, {5: 7000, 17: 1500, 2999: 4200}, seed=3),
+             oracle.random_crs(500, 90000, 40, variance=10, seed=6)]
+    for A0 in cases:
+        for shift in (4, 9, 14):
+            kn = {"colslab": 2, "colslab_shift": shift}
+            h = pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=50.0, expect={"colslab": 1})
+            assert h.query("colslab_slabs") == -(-A0.ncols // (1 << h.query("colslab_shift"))) <= 256
+            pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs=kn, max_val=50.0, nans=True)
+        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0, offset_dtype=np.int64, value_dtype=np.float32)
+        pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6, "colslab_const": 1}, max_val=50.0, value_dtype=np.float32, vec_dtype=np.float32)
+        pc.check_spmv(be, A0, "T", 1.0, 0.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0)
+    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 1})       # small matrix: the gates say no
+    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 0}, expect={"colslab": 0, "colslab_tried": 0})
+
+
+def test_column_slab_follows_value_changes(be):
+    # the copy holds its own values; a call fingerprints A.values tile by tile and moves the tiles that changed
+    A0 = oracle.random_crs(25000, 25000, 10, variance=3, seed=8)
+    rng = np.random.default_rng(1)
+    x = rng.random(A0.ncols)
+    A = pc.dev(be, A0)
+    h = pc.kk.SPMVHandle("SPMV_DEFAULT"); h.set("colslab", 2); h.set("colslab_shift", 8)
+    xd, yd = be.from_numpy(x), be.from_numpy(np.zeros(A0.nrows))
+    def run_and_check(vals):
+        pc.kk.spmv(h, "N", 1.0, A, xd, 0.0, yd)
+        exp = oracle.spmv_serial("N", oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, vals), 1.0, x, 0.0, np.zeros(A0.nrows))
+        np.testing.assert_allclose(be.to_numpy(yd), exp, rtol=1e-12, atol=1e-12)
+    run_and_check(A0.values)
+    assert h.query("colslab") == 1
+    v = A0.values.copy()
+    v[50000] = -7.25
+    A.values[:] = be.from_numpy(v); run_and_check(v)
+    v = v * 3.0 + 1.0
+    A.values[:] = be.from_numpy(v); run_and_check(v)
+    v[[0, len(v) - 1]] = v[[len(v) - 1, 0]]
+    A.values[:] = be.from_numpy(v); run_and_check(v)
+
+
+def test_column_slab_selection_on_a_gather_bound_matrix(be):
+    # the automatic mode: uniform random columns over 3e6 columns (x = 24 MB, six L2s): the analysis calls it gather-bound, both
+    # kernels are timed on the first call and whichever is kept, the result is the oracle's
+    n, k = 3_000_000, 8
+    rng = np.random.default_rng(12)
+    ent = np.sort(rng.integers(0, n, size=(n, k), dtype=np.int64), axis=1).astype(np.int32).reshape(-1)
+    A0 = oracle.Crs(n, n, np.arange(0, n * k + 1, k, dtype=np.int64), ent, rng.random(n * k) + 0.5)
+    h = pc.check_spmv(be, A0, "N", 1.5, 0.0, "SPMV_DEFAULT", max_val=2.0, nans=True, knobs={"colslab_min_knnz": 20000}, expect={"colslab_tried": 1})
+    assert h.query("colslab_crs_us") > 0 and h.query("colslab_us") > 0, (h.query("colslab_crs_us"), h.query("colslab_us"))
+    print("column-slab selection: CRS %d us, copy %d us, kept %d" % (h.query("colslab_crs_us"), h.query("colslab_us"), h.query("colslab")))
+    h2 = pc.check_spmv(be, A0, "N", 1.0, 0.5, "SPMV_DEFAULT", max_val=2.0, knobs={"colslab": 2}, expect={"colslab": 1, "colslab_shift": 18, "colslab_slabs": 12})

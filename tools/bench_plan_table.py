@@ -68,9 +68,15 @@ for name, A in matrices():
     t0 = time.perf_counter()
     h = kk.SPMVHandle("SPMV_DEFAULT"); kk.spmv(h, "N", 1.0, A, x, 0.0, y1); torch.cuda.synchronize()
     t_analysis = time.perf_counter() - t0
-    hp = kk.SPMVHandle("SPMV_DEFAULT"); hp.set("window_codes", 0); kk.spmv(hp, "N", 1.0, A, x, 0.0, y0)
+    hp = kk.SPMVHandle("SPMV_DEFAULT"); hp.set("window_codes", 0); hp.set("colslab", 0); kk.spmv(hp, "N", 1.0, A, x, 0.0, y0)
     diff = float((y1 - y0).abs().max().item())
     ms = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y1)); ms_plain = timeit(lambda: kk.spmv(hp, "N", 1.0, A, x, 0.0, y0))
+    cs = {"colslab": h.query("colslab"), "colslab_selection_us": [h.query("colslab_crs_us"), h.query("colslab_us")]}
+    if h.query("colslab_tried") and h.query("colslab_crs_us"):       # the column-slab copy was considered: what it does with constant values promised
+        hc = kk.SPMVHandle("SPMV_DEFAULT"); hc.set("colslab", 2); hc.set("colslab_const", 1); kk.spmv(hc, "N", 1.0, A, x, 0.0, y0)
+        cs["ms_colslab_const_values"] = round(timeit(lambda: kk.spmv(hc, "N", 1.0, A, x, 0.0, y0)), 4)
+        cs["colslab_bytes_per_nnz"] = round(hc.query("colslab_bytes") / nnz, 2); cs["colslab_slabs"] = hc.query("colslab_slabs")
+        del hc
     alg = nnz * 12 + (nr + 1) * 4 + nc * 8 + nr * 8
     tiles, tile = h.query("tiles"), h.query("tile")
     pat, code, plain = h.query("pattern_tiles"), h.query("code_tiles"), h.query("plain_tiles")
@@ -82,6 +88,6 @@ for name, A in matrices():
                       "frac_8TBps_streamed_bytes": round(streamed / ms / 1e6 / 8000, 3), "GFLOPs": round(2 * nnz / ms / 1e6, 1),
                       "tiles": tiles, "tile_nnz": tile, "pattern_tiles": pat, "code_tiles": code, "staged_tiles": h.query("staged_tiles"),
                       "plain_tiles": plain, "plan_bytes_per_nnz": round(h.query("plan_bytes") / nnz, 4), "first_call_incl_analysis_ms": round(t_analysis * 1e3, 1),
-                      "max_abs_diff_vs_plain": diff}), flush=True)
+                      "max_abs_diff_vs_plain": diff, **cs}), flush=True)
     del A, h, hp, x, y0, y1
     torch.cuda.empty_cache()
