@@ -848,12 +848,13 @@ static bool stream_usable(const kkamd_spmv_plan* p, const kkamd_crs_t* A, int el
 // Modes T / H.  The reference scatters with atomics (spmv_impl.hpp:383-513, "functional, not performant"): 11.2 ms on 27-pt
 // 300^3.  An analysed handle instead caches the TRANSPOSE -- structure, values in transposed order, and for every
 // entry of A its position in A^T -- and runs the planned N kernel on A^T: deterministic, no atomics.  The matrix values may
-// change between calls (the structure may not): every call compares A's values with the copy the plan saw last (two
-// coalesced streams, no gather) and moves only the entries that changed into their transposed places;
+// change between calls (the structure may not): every call re-fingerprints A's values (128 bits per 4096 values, one coalesced
+// stream of 8 bytes per nonzero -- kk_spmv_colslab.hip says what the fingerprints are) and moves the tiles that changed into
+// their transposed places;
 //   explicit_transpose = 1 (default from explicit_transpose_min_knnz when the plan memory fits an eighth of free HBM): that;
 //   explicit_transpose = 2: the caller promises constant values, the comparison is skipped too;
 //   explicit_transpose = 0: the reference's atomic scatter.
-// Costs nnz * (4 + sizeof(offset) + 2 sizeof(value)) bytes of plan memory and 0.3 s once for the transpose; falls back to the
+// Costs nnz * (4 + sizeof(offset) + sizeof(value)) bytes of plan memory and 0.3 s once for the transpose; falls back to the
 // atomic kernel if the memory cannot be had.
 __global__ void iota_f64_kernel(double* __restrict__ p, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (double)i;
@@ -861,24 +862,6 @@ __global__ void iota_f64_kernel(double* __restrict__ p, int64_t n) {
 // inv[perm[j]] = j: where entry i of A sits in A^T
 template <class OffT> __global__ void invert_perm_kernel(const double* __restrict__ perm_f64, OffT* __restrict__ inv, int64_t n) {
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) inv[(int64_t)perm_f64[j]] = (OffT)j;
-}
-__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
-__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_int(a) == __float_as_int(b); }
-// entries of A whose value differs (bitwise) from what the plan saw last are copied into the shadow and into their place in A^T
-template <class OffT, class AT>
-__global__ void refresh_changed_kernel(const AT* __restrict__ val, AT* __restrict__ shadow, const OffT* __restrict__ inv, AT* __restrict__ t_val, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const AT v = val[i];
-    if (!same_bits(v, shadow[i])) { shadow[i] = v; t_val[inv[i]] = v; }
-  }
-}
-// the first refresh after the transpose was built moves every value: no bit pattern of the shadow stands for "never seen"
-template <class OffT, class AT>
-__global__ void refresh_all_kernel(const AT* __restrict__ val, AT* __restrict__ shadow, const OffT* __restrict__ inv, AT* __restrict__ t_val, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const AT v = val[i];
-    shadow[i] = v; t_val[inv[i]] = v;
-  }
 }
 // the cached transpose is a convenience, not a right: it is only built when it (and the 16 bytes per nonzero its construction
 // needs on top) fit an eighth of the HBM that is free at that moment
@@ -888,7 +871,7 @@ static bool transpose_fits(kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   if (p->t_failed) return false;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
-  const double need = (double)A->nnz * (4.0 + sizeof(OffT) + 2.0 * sizeof(AT) + 16.0) + (double)A->num_cols * sizeof(OffT);
+  const double need = (double)A->nnz * (4.0 + sizeof(OffT) + sizeof(AT) + 16.0) + (double)A->num_cols * sizeof(OffT);
   if (need > (double)free_b / 8.0) { p->t_failed = true; return false; }
   return true;
 }
@@ -905,15 +888,15 @@ static int ensure_transpose(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_
     if (p->d_t_rm) (void)hipFree(p->d_t_rm);
     if (p->d_t_ent) (void)hipFree(p->d_t_ent);
     if (p->d_t_perm) (void)hipFree(p->d_t_perm);
-    if (p->d_t_shadow) (void)hipFree(p->d_t_shadow);
+    if (p->d_t_fp) (void)hipFree(p->d_t_fp);
     if (p->d_t_val) (void)hipFree(p->d_t_val);
-    p->d_t_rm = nullptr; p->d_t_ent = nullptr; p->d_t_perm = nullptr; p->d_t_val = nullptr; p->d_t_shadow = nullptr;
+    p->d_t_rm = nullptr; p->d_t_ent = nullptr; p->d_t_perm = nullptr; p->d_t_val = nullptr; p->d_t_fp = nullptr;
     p->t_failed = true;
     return KKAMD_ERR_ALLOC;
   };
   if (hipMalloc(&p->d_t_rm, sizeof(OffT) * (size_t)(A->num_cols + 1)) != hipSuccess || hipMalloc((void**)&p->d_t_ent, sizeof(int32_t) * nnz) != hipSuccess ||
       hipMalloc(&p->d_t_perm, sizeof(OffT) * nnz) != hipSuccess || hipMalloc(&p->d_t_val, sizeof(AT) * nnz) != hipSuccess ||
-      hipMalloc(&p->d_t_shadow, sizeof(AT) * nnz) != hipSuccess ||
+      hipMalloc((void**)&p->d_t_fp, 16 * (size_t)values_fp_tiles(A->nnz)) != hipSuccess ||
       hipMalloc((void**)&d_iota, sizeof(double) * nnz) != hipSuccess || hipMalloc((void**)&d_tmp, sizeof(double) * nnz) != hipSuccess)
     return fail_clean();
   const unsigned grid = (unsigned)(ceil_div(A->nnz, kBlock) < 65536 ? ceil_div(A->nnz, kBlock) : 65536);
@@ -923,7 +906,7 @@ static int ensure_transpose(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_
                            p->d_t_rm, p->d_t_ent, d_tmp, reinterpret_cast<kkamd_stream_t>(st));
   if (rc != KKAMD_OK) { fail_clean(); return rc; }
   KK_LAUNCH((invert_perm_kernel<OffT>), grid, kBlock, 0, st, (const double*)d_tmp, (OffT*)p->d_t_perm, A->nnz);     // d_t_perm: position of A's entry i in A^T
-  p->t_shadow_valid = false;                                                   // the first refresh scatters every value (refresh_all_kernel)
+  p->t_fp_valid = false;                                                       // the first refresh moves every value
   if (hipStreamSynchronize(st) != hipSuccess) return fail_clean();
   (void)hipFree(d_iota); (void)hipFree(d_tmp); d_iota = d_tmp = nullptr;
   kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, p->d_t_rm, p->d_t_ent, p->d_t_val, A->offset_type, A->value_type};
@@ -1048,15 +1031,9 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
     if (plan && plan->tile != 0 && plan->tune.explicit_transpose && A->nnz >= (int64_t)plan->tune.explicit_transpose_min_knnz * 1000 &&
         transpose_fits<OffT, AT>(plan, A) && ensure_transpose<OffT, AT>(plan, A, st) == KKAMD_OK) {
       if (plan->tune.explicit_transpose != 2 || !plan->t_values_valid) {
-        const unsigned grid = (unsigned)(ceil_div(A->nnz, kBlock) < 65536 ? ceil_div(A->nnz, kBlock) : 65536);
-        if (plan->t_shadow_valid) {
-          KK_LAUNCH((refresh_changed_kernel<OffT, AT>), grid, kBlock, 0, st, (const AT*)A->d_values, (AT*)plan->d_t_shadow, (const OffT*)plan->d_t_perm,
-                    (AT*)plan->d_t_val, A->nnz);
-        } else {
-          KK_LAUNCH((refresh_all_kernel<OffT, AT>), grid, kBlock, 0, st, (const AT*)A->d_values, (AT*)plan->d_t_shadow, (const OffT*)plan->d_t_perm,
-                    (AT*)plan->d_t_val, A->nnz);
-          plan->t_shadow_valid = true;
-        }
+        const int rc = values_refresh(A->offset_type, A->value_type, A->nnz, A->d_values, plan->d_t_perm, plan->d_t_val, plan->d_t_fp, plan->t_fp_valid ? 0 : 2, st);
+        if (rc) return rc;
+        plan->t_fp_valid = true;
         plan->t_values_valid = true;
       }
       kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, plan->d_t_rm, plan->d_t_ent, plan->d_t_val, A->offset_type, A->value_type};
@@ -1454,7 +1431,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
   if (plan->d_t_perm) (void)hipFree(plan->d_t_perm);
-  if (plan->d_t_shadow) (void)hipFree(plan->d_t_shadow);
+  if (plan->d_t_fp) (void)hipFree(plan->d_t_fp);
   if (plan->d_t_val) (void)hipFree(plan->d_t_val);
   if (plan->t_plan) kkamd_spmv_plan_destroy(plan->t_plan);
   delete plan;

@@ -133,9 +133,9 @@ __device__ __forceinline__ unsigned long long cs_mix(unsigned long long z) {
 __device__ __forceinline__ unsigned long long cs_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 __device__ __forceinline__ unsigned long long cs_bits(float v) { return (unsigned long long)(unsigned)__float_as_int(v); }
 
-// INIT: record the fingerprints (the copy was just made from these values).  Otherwise: tiles whose fingerprint moved are copied
-// into the slab order again.
-template <class OffT, class AT, bool INIT>
+// MODE 0: tiles whose fingerprint moved are copied into their places (o_val[dst[i]] = val[i]) again; 1: record the fingerprints only
+// (the copy was just made from these values); 2: record them and copy every tile (the copy holds nothing yet)
+template <class OffT, class AT, int MODE>
 __global__ __launch_bounds__(kBlock) void cs_check_kernel(int64_t nnz, const AT* __restrict__ val, const OffT* __restrict__ dst, AT* __restrict__ o_val,
                                                           unsigned long long* __restrict__ fp) {
   __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(kBlock) void cs_check_kernel(int64_t nnz, const AT*
   if (threadIdx.x == 0) {
     unsigned long long ta = 0, tb = 0;
     for (int w = 0; w < kBlock / 64; ++w) { ta += s_a[w]; tb += s_b[w]; }
-    const bool diff = INIT || fp[2 * (int64_t)blockIdx.x] != ta || fp[2 * (int64_t)blockIdx.x + 1] != tb;
+    const bool diff = MODE != 0 || fp[2 * (int64_t)blockIdx.x] != ta || fp[2 * (int64_t)blockIdx.x + 1] != tb;
     if (diff) { fp[2 * (int64_t)blockIdx.x] = ta; fp[2 * (int64_t)blockIdx.x + 1] = tb; }
-    s_diff = (!INIT && diff) ? 1 : 0;
+    s_diff = (MODE != 1 && diff) ? 1 : 0;
   }
   __syncthreads();
   if (s_diff) {
@@ -169,6 +169,26 @@ __global__ __launch_bounds__(kBlock) void cs_check_kernel(int64_t nnz, const AT*
       if (i < nnz) o_val[dst[i]] = v[u];
     }
   }
+}
+
+template <class OffT, class AT>
+static int values_refresh_typed(int64_t nnz, const void* val, const void* dst, void* o_val, unsigned long long* fp, int mode, hipStream_t st) {
+  const unsigned grid = (unsigned)ceil_div(nnz, (int64_t)kCsTile);
+  const AT* v = (const AT*)val; const OffT* d = (const OffT*)dst; AT* o = (AT*)o_val;
+  if (mode == 0)      { KK_LAUNCH((cs_check_kernel<OffT, AT, 0>), grid, kBlock, 0, st, nnz, v, d, o, fp); }
+  else if (mode == 1) { KK_LAUNCH((cs_check_kernel<OffT, AT, 1>), grid, kBlock, 0, st, nnz, v, d, o, fp); }
+  else                { KK_LAUNCH((cs_check_kernel<OffT, AT, 2>), grid, kBlock, 0, st, nnz, v, d, o, fp); }
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+// A re-ordered copy of a matrix's values (o_val[dst[i]] = val[i]) kept current through per-tile fingerprints fp[2 * ceil(nnz / 4096)]
+// (see the head of this file); also what the cached transpose of modes T / H uses (kk_spmv.hip)
+int64_t values_fp_tiles(int64_t nnz) { return ceil_div(nnz, (int64_t)kCsTile); }
+int values_refresh(int offset_type, int value_type, int64_t nnz, const void* val, const void* dst, void* o_val, unsigned long long* fp, int mode, hipStream_t st) {
+  if (nnz <= 0) return KKAMD_OK;
+  const bool o64 = offset_type == KKAMD_I64;
+  if (value_type == KKAMD_F64) return o64 ? values_refresh_typed<int64_t, double>(nnz, val, dst, o_val, fp, mode, st) : values_refresh_typed<int32_t, double>(nnz, val, dst, o_val, fp, mode, st);
+  return o64 ? values_refresh_typed<int64_t, float>(nnz, val, dst, o_val, fp, mode, st) : values_refresh_typed<int32_t, float>(nnz, val, dst, o_val, fp, mode, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,7 +264,7 @@ static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, 
   DevBuf hist;
   if (hipMalloc((void**)&cs->d_row, sizeof(int32_t) * (size_t)nnz) != hipSuccess || hipMalloc((void**)&cs->d_col, sizeof(int32_t) * (size_t)nnz) != hipSuccess ||
       hipMalloc(&cs->d_val, sizeof(AT) * (size_t)nnz) != hipSuccess || hipMalloc(&cs->d_dst, sizeof(OffT) * (size_t)nnz) != hipSuccess ||
-      hipMalloc((void**)&cs->d_fp, 16 * (size_t)cs->ntiles) != hipSuccess || hist.alloc(sizeof(int64_t) * hn) != hipSuccess)
+      hipMalloc((void**)&cs->d_fp, 16 * (size_t)values_fp_tiles(nnz)) != hipSuccess || hist.alloc(sizeof(int64_t) * hn) != hipSuccess)
     return give_up();
   cs->bytes = (size_t)nnz * (8 + sizeof(AT) + sizeof(OffT)) + 16 * (size_t)cs->ntiles;
   int64_t* H = hist.as<int64_t>();
@@ -259,7 +279,7 @@ static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, 
   const int nslabs = cs->nslabs; const int64_t ntiles = cs->ntiles;
   KK_LAUNCH((cs_scatter_kernel<OffT, AT>), (unsigned)ntiles, kBlock, 0, st, A->num_rows, nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries,
             (const AT*)A->d_values, shift, nslabs, nbits, ntiles, (const int64_t*)H, o_row, o_col, o_val, dst);
-  KK_LAUNCH((cs_check_kernel<OffT, AT, true>), (unsigned)ntiles, kBlock, 0, st, nnz, (const AT*)A->d_values, (const OffT*)dst, o_val, fp);
+  if (values_refresh(A->offset_type, A->value_type, nnz, A->d_values, dst, o_val, fp, 1, st)) return give_up();
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return give_up();
   *out = cs;
   return KKAMD_OK;
@@ -292,11 +312,9 @@ template <class OffT, class AT, class YT>
 static int cs_apply_typed(kkamd_cs_plan* cs, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, bool check, hipStream_t st) {
   const int64_t nnz = cs->nnz;
   AT* o_val = (AT*)cs->d_val;
-  if (check) {
-    const OffT* dst = (const OffT*)cs->d_dst; unsigned long long* fp = cs->d_fp;
-    KK_LAUNCH((cs_check_kernel<OffT, AT, false>), (unsigned)cs->ntiles, kBlock, 0, st, nnz, (const AT*)A->d_values, dst, o_val, fp);
-  }
-  int rc = launch_scale<YT>(y, A->num_rows, 1, 1, 0, beta, st);
+  int rc = check ? values_refresh(A->offset_type, A->value_type, nnz, A->d_values, cs->d_dst, o_val, cs->d_fp, 0, st) : KKAMD_OK;
+  if (rc) return rc;
+  rc = launch_scale<YT>(y, A->num_rows, 1, 1, 0, beta, st);
   if (rc) return rc;
   const int32_t* row = cs->d_row; const int32_t* col = cs->d_col; const int shift = cs->shift;
   KK_LAUNCH((cs_spmv_kernel<AT, YT>), (unsigned)ceil_div(nnz, (int64_t)kBlock * kCsU), kBlock, 0, st, nnz, row, col, (const AT*)o_val, shift, x, y, alpha);

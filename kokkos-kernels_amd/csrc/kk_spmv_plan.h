@@ -105,9 +105,9 @@ struct kkamd_spmv_plan {
   int64_t plain_tiles = 0;       // tiles that read entries (mode 0)
   size_t plan_bytes = 0;         // HBM the analysis keeps
   // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
-  void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr; void* d_t_shadow = nullptr;
+  void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr; unsigned long long* d_t_fp = nullptr;
   kkamd_spmv_plan* t_plan = nullptr;
-  bool t_ready = false, t_failed = false, t_values_valid = false, t_shadow_valid = false;
+  bool t_ready = false, t_failed = false, t_values_valid = false, t_fp_valid = false;
   bool win_failed = false;       // the codes are not worth it on this matrix (or HBM cannot hold them): plain entries
   // rank-2 analysis (LDS-staged X tiles), built by the first rank-2 call that can use it
   kkamd_mv_plan* mv = nullptr;
@@ -145,6 +145,9 @@ void cs_plan_destroy(kkamd_cs_plan* cs);
 int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes
 int  cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st);
 int  cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, bool check, hipStream_t st);
+int64_t values_fp_tiles(int64_t nnz);
+// mode 0: move the 4096-value tiles whose fingerprint changed (o_val[dst[i]] = val[i]); 1: record fingerprints; 2: record and move all
+int  values_refresh(int offset_type, int value_type, int64_t nnz, const void* val, const void* dst, void* o_val, unsigned long long* fp, int mode, hipStream_t st);
 int  release_transient();
 int  release_bitmap_pool();      // kk_spgemm.hip: the pooled bitmap store of the SpGEMM symbolic -> numeric hand-over
 // rank 1 on the rank-2 plane-marching analysis (kk_spmv_mv.hip): builds the analysis on first use; returns 1 when it ran

@@ -419,6 +419,20 @@ def test_transposed_modes_through_cached_explicit_transpose(be):
             assert np.allclose(be.to_numpy(y), exp, rtol=1e-13, atol=1e-13)
             if rep == 0: A.values[:] = rng.random(A0.nnz) + rep             # in place: same device array, new numbers
             else: A.values[::3] = rng.random(len(A.values[::3])) - rep      # ... and only some of them
+        # several fingerprint tiles (4096 values each); one value changes, then two swap places
+        A0 = oracle.random_crs(1500, 1200, 9, variance=3, seed=7, sorted_rows=True)
+        A = pc.dev(be, A0)
+        h = pc.kk.SPMVHandle("SPMV_DEFAULT"); h.set("explicit_transpose", 1)
+        x = rng.random(A0.nrows)
+        v = A0.values.copy()
+        for rep in range(4):
+            y = be.from_numpy(np.zeros(A0.ncols))
+            pc.kk.spmv(h, "T", 1.0, A, be.from_numpy(x), 0.0, y)
+            exp = oracle.spmv_sequential("T", oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, v), 1.0, x, 0.0, np.zeros(A0.ncols))
+            assert np.allclose(be.to_numpy(y), exp, rtol=1e-13, atol=1e-13), rep
+            if rep == 0: v[9000] = -3.5
+            elif rep == 1: v[[10, len(v) - 1]] = v[[len(v) - 1, 10]]
+            A.values[:] = be.from_numpy(v)
         # the atomic kernel stays reachable
         pc.check_spmv(be, oracle.laplace3d("FE", 9, 8, 7), "T", 1.0, 0.0, algo="SPMV_DEFAULT", knobs={"explicit_transpose": 0}, max_val=32.0)
     finally:
