@@ -738,6 +738,44 @@ __global__ __launch_bounds__(NT) void spgemm_sym_block_kernel(int64_t nbin, cons
 // bits are written out in ascending order, so entries(C) for the row leave the kernel column-sorted.  EMIT = false is
 // the symbolic count; EMIT = true fills entries(C) in the numeric phase (the value kernel below needs them).
 typedef unsigned long long kk_u64;
+// The set bits of bm[0 .. words) (LDS or HBM), as columns col0 + bit index in ascending order, to entC[pos0 ...]; returns their number.
+// Every wave owns a contiguous range of the words and walks it 64 words at a time (lane l owns word base + l): the loads of a wave
+// are 512 contiguous bytes, neighbouring lanes write neighbouring pieces of entries(C), the offsets inside a wave come from shuffles
+// and only the 16 wave totals cross the workgroup (one barrier).  (One contiguous run of words per work-item made every store of a
+// wave 64 separate short runs: 4-byte stores into 64 different sectors; 1024 interleaved words per step cost sixteen workgroup scans
+// per row.)  words <= 16384 (2^20 columns).  All kDenseBlock work-items call it; s_wave must be free (a barrier since its last use).
+__device__ __forceinline__ int emit_bits_by_wave(const kk_u64* __restrict__ bm, int words, int64_t col0, int64_t pos0, int32_t* __restrict__ entC, int* s_wave) {
+  constexpr int NW = kDenseBlock / 64, NB = 16;            // 2^20 columns / 64 / 1024 = 16 steps of 64 words per wave
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wpw = ((words + NW - 1) / NW + 63) & ~63;       // words per wave, a multiple of 64
+  const int w0 = wave * wpw, w1 = (w0 + wpw < words) ? w0 + wpw : words;
+  kk_u64 w[NB];
+  int wsum = 0;
+  KK_UNROLL
+  for (int i = 0; i < NB; ++i) { const int wd = w0 + i * 64 + lane; w[i] = (i * 64 < wpw && wd < w1) ? bm[wd] : 0ull; wsum += __popcll(w[i]); }
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+  if (lane == 0) s_wave[wave] = wsum;
+  __syncthreads();
+  int tot = 0;
+  for (int i = 0; i < NW; ++i) { if (i == wave) pos0 += tot; tot += s_wave[i]; }
+  KK_UNROLL
+  for (int i = 0; i < NB; ++i) {
+    if (i * 64 >= wpw) break;                              // uniform
+    kk_u64 v = w[i];
+    const int pc = __popcll(v);
+    int inc = pc;
+    for (int o = 1; o < 64; o <<= 1) { const int nb_ = __shfl_up(inc, (unsigned)o, 64); if (lane >= o) inc += nb_; }
+    int64_t pos = pos0 + (inc - pc);
+    const int64_t c0 = col0 + (int64_t)(w0 + i * 64 + lane) * 64;
+    while (v) {
+      const int bit = __ffsll(v) - 1;
+      entC[pos++]   = (int32_t)(c0 + bit);
+      v &= v - 1;
+    }
+    pos0 += __shfl(inc, 63, 64);
+  }
+  return tot;
+}
 struct BitmapStore {                 // where the symbolic count kernel may leave a row's bitmap (words == 0: nowhere)
   kk_u64* words_out = nullptr;       // [cap][words]
   int32_t* row_slot = nullptr;       // [m], -1 = not stored
@@ -798,7 +836,8 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
       const int w_lo = s_min >> 6, w_hi = s_max >> 6, nw = w_hi - w_lo + 1;
       // sparse bitmaps (fewer than 4 columns per touched word on average; always when only counting): every
       // work-item takes one contiguous run of words -- one workgroup scan per window instead of one per 1024 words.
-      // Dense bitmaps keep the interleaved walk, whose stores to entries(C) coalesce.
+      // Dense bitmaps keep the interleaved walk, whose stores to entries(C) coalesce.  (The wave-contiguous walk of
+      // emit_bits_by_wave, which serves the stored bitmaps, measured slower here on the sparse rows: R-MAT scale 20 numeric 261 -> 271 ms.)
       const bool chunked = !EMIT || force_chunked || (int64_t)rmC[row + 1] - (int64_t)rmC[row] < 4 * (int64_t)nw;
       if (chunked) {
         const int per = (nw + kDenseBlock - 1) / kDenseBlock;
@@ -863,43 +902,8 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_emit_bitmap_kernel(const i
                                                                          const kk_u64* __restrict__ store, int words, const OffT* __restrict__ rmC,
                                                                          int32_t* __restrict__ entC) {
   __shared__ int s_wave[kDenseBlock / 64];
-  const int t = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
-  const kk_u64* bm = store + (size_t)row_slot[row] * (size_t)words;
-  // Every wave owns a contiguous range of the row's words and walks it 64 words at a time (lane l owns word base + l): the loads
-  // of a wave are 512 contiguous bytes, neighbouring lanes write neighbouring pieces of entries(C), the offsets inside a wave
-  // come from shuffles and only the 16 wave totals cross the workgroup (one barrier per row).  (One contiguous run of 16 words
-  // per work-item -- the walk of the product kernel's sparse rows -- made every 8-byte load of a wave touch 64 cache lines and
-  // every store a separate 400-byte run; 1024 interleaved words per step cost sixteen workgroup scans per row: 277 -> 321 ms.)
-  constexpr int NW = kDenseBlock / 64, NB = 16;            // 2^20 columns / 64 / 1024 = 16 steps of 64 words per wave
-  const int lane = t & 63, wave = t >> 6;
-  const int wpw = ((words + NW - 1) / NW + 63) & ~63;       // words per wave, a multiple of 64
-  const int w0 = wave * wpw, w1 = (w0 + wpw < words) ? w0 + wpw : words;
-  kk_u64 w[NB];
-  int wsum = 0;
-  KK_UNROLL
-  for (int i = 0; i < NB; ++i) { const int wd = w0 + i * 64 + lane; w[i] = (i * 64 < wpw && wd < w1) ? bm[wd] : 0ull; wsum += __popcll(w[i]); }
-  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
-  if (lane == 0) s_wave[wave] = wsum;
-  __syncthreads();
-  int64_t pos0 = (int64_t)rmC[row];
-  for (int i = 0; i < wave; ++i) pos0 += s_wave[i];
-  KK_UNROLL
-  for (int i = 0; i < NB; ++i) {
-    if (i * 64 >= wpw) break;                              // uniform
-    kk_u64 v = w[i];
-    const int pc = __popcll(v);
-    int inc = pc;
-    for (int o = 1; o < 64; o <<= 1) { const int nb_ = __shfl_up(inc, (unsigned)o, 64); if (lane >= o) inc += nb_; }
-    int64_t pos = pos0 + (inc - pc);
-    const int64_t c0 = (int64_t)(w0 + i * 64 + lane) * 64;
-    while (v) {
-      const int bit = __ffsll(v) - 1;
-      entC[pos++]   = (int32_t)(c0 + bit);
-      v &= v - 1;
-    }
-    pos0 += __shfl(inc, 63, 64);
-  }
+  (void)emit_bits_by_wave(store + (size_t)row_slot[row] * (size_t)words, words, 0, (int64_t)rmC[row], entC, s_wave);
 }
 // rows of a bin whose size (products) reaches thr
 __global__ __launch_bounds__(kBlock) void spgemm_count_ge_kernel(int64_t n, const int32_t* __restrict__ perm, const int64_t* __restrict__ sizes, int64_t thr,
