@@ -57,8 +57,9 @@ def test_window_codes(be):
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"stream_variant": 6}, max_val=32.0, expect={"window_codes": ok})
         # the default kernel tries the codes by itself from window_codes_min_knnz on, and never with window_codes = 0
         pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0}, max_val=32.0, expect={"window_codes": ok, "tile": 2048})
-        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", max_val=32.0, expect={"window_codes": 0})
-        pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "window_codes": 0}, max_val=32.0, expect={"window_codes": 0})
+        if ci < 2:                                              # (the GPU suite runs every case through all of these)
+            pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", max_val=32.0, expect={"window_codes": 0})
+            pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "window_codes": 0}, max_val=32.0, expect={"window_codes": 0})
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"stream_variant": 6}, max_val=32.0, offset_dtype=np.int64,
                       value_dtype=np.float32, expect={"window_codes": ok})
         # window_codes 2: the codes without the staged x window
@@ -73,8 +74,9 @@ def test_window_codes(be):
                           expect={"window_codes": 1} if staged is None else {"window_codes": 1, "window_staged_x": staged})
         if staged is None: assert 0 < h.query("staged_tiles") < h.query("tiles")
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", nans=True, knobs={"stream_variant": 6, "nnz_per_thread": npt}, max_val=32.0)
-        pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"stream_variant": 6, "nnz_per_thread": npt}, max_val=32.0, offset_dtype=np.int64,
-                      value_dtype=np.float32, expect={"window_codes": 1})
+        if npt != 8 or staged is None:                          # the other tile sizes and the mixed case also with 64-bit offsets / fp32 values
+            pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"stream_variant": 6, "nnz_per_thread": npt}, max_val=32.0, offset_dtype=np.int64,
+                          value_dtype=np.float32, expect={"window_codes": 1})
 
 
 def test_pattern_codes(be):
@@ -96,8 +98,8 @@ def test_pattern_codes(be):
 def test_mixed_tiles(be):
     # the column analysis is per tile: tiles the windows cannot cover read entries, the others keep codes / staged x / records
     for name, A0 in pc.mixed_tile_cases():
-        for npt in (4, 8, 16):
-            for pat in (0, 2):
+        for npt, pat in ((8, 0), (8, 2), (4, 2), (16, 0)):         # (the GPU suite runs all six combinations)
+            if True:
                 kn = {"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": pat, "window_codes_min_pct": 10}
                 h = pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=32.0, expect={"window_codes": 1})
                 assert 0 < h.query("plain_tiles") < h.query("tiles"), (name, npt, h.query("plain_tiles"), h.query("tiles"))
@@ -174,7 +176,7 @@ def test_mv4_plane_marching(be):
     # narrow multivectors and remainders run the partial-block form (columns past the block clamped on the X side, masked on the Y side):
     # every width from 4 to 15, both layouts, beta != 0 over the masked columns' neighbours
     for nvec in (4, 5, 8, 11, 12, 15):
-        for xo, yo, beta in (("C", "C", 0.0), ("F", "F", 0.5), ("C", "F", -1.0)):
+        for xo, yo, beta in ((("C", "C", 0.0), ("F", "F", 0.5), ("C", "F", -1.0)) if nvec in (5, 12) else (("C", "C", 0.0), ("F", "F", 0.5))[nvec % 2:][:1]):
             h = pc.check_spmv_mv(be, A0, nvec, "N", 1.5, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0))
             assert h.query("mv4_workgroups") > 0, (nvec, xo, yo)
     # not its matrices / widths: no far stride (2-D), too few lattice rows, 3 right-hand sides (below mv4_min_nvec), no analysis, the gather kernel asked for
