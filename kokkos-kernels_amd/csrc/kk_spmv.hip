@@ -1126,6 +1126,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "mv_glds") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv_glds = value; }
   else if (k == "mv_long_T") { if (value < 0) return bad("non-negative"); t.mv_long_T = value; }
   else if (k == "mv4_min_nvec") { if (value < 1 || value > 1024) return bad("in 1..1024"); t.mv4_min_nvec = value; }
+  else if (k == "mv4_xcol") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv4_xcol = value; }
   else if (k == "mv4_wg_per_cu") { if (value < 1 || value > 64) return bad("in 1..64"); t.mv4_wg_per_cu = value; }
   else if (k == "march") { if (value != 0 && value != 1) return bad("0 or 1"); t.march = value; }
   else if (k == "march_planes") { if (value < 1 || value > 4096) return bad("in 1..4096"); t.march_planes = value; }

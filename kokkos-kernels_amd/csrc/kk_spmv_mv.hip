@@ -923,11 +923,13 @@ __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const 
 // still carries the columns 2 c and 2 c + 1, columns past the block are clamped to its last one when X is read (the same cache
 // lines again: no extra traffic) and masked when Y is read or written.  Row-major X with an even ncv keeps the 16-byte loads
 // (XROW: pieces past the block re-read its last piece); anything else goes element by element.
-template <class OffT, class AT, int NG, unsigned PRES, bool BETA0, bool XROW, bool PART = false>
+template <class OffT, class AT, int NG, unsigned PRES, bool BETA0, int XM, bool PART = false>
 __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask, const AT* __restrict__ values, Mv4Groups G,
                                                                   const double* __restrict__ X, int64_t xs0, int64_t xs1, double* __restrict__ Y,
                                                                   int64_t ys0, int64_t ys1, double alpha, double beta, int y_vec_ok, int nx,
                                                                   int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc, int ncv) {
+  constexpr bool XROW = XM == 1;                       // row-major X, 16-byte pieces
+  constexpr bool XT   = XM == 2;                       // column-major X (unit stride along the rows): pieces dealt out column-wise, slab rows swizzled
   constexpr int RI = kMv4RI, RJ = kMv4RJ, W = RI + 2, SLABR = (RJ + 2) * W, SLABB = SLABR * 128, NT = kMv4Threads;
   constexpr int ROWS = NT / 8;                         // row PAIRS per plane: a lane owns the lattice rows (i, j) and (i, j + 1)
   constexpr int NP = SLABR * 8, NXP = (NP + NT - 1) / NT;   // 16-byte pieces per slab, per thread
@@ -968,11 +970,23 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
   const double* xbase[NXP];
   unsigned xsec_none = 0;
   bool x_in[NXP];                                      // the piece is a lattice point of the plane (else the halo holds 0)
+  // Column-major X (XT): a piece is two 8-byte loads, and with eight consecutive lanes on the eight pieces of one X row a wave's
+  // load touches 8 columns x 64 bytes.  There the pieces are dealt out the other way round -- 16 consecutive slab rows of one piece
+  // to 16 consecutive lanes, a wave covers 4 pieces x 16 rows: whole 128-byte lines of 4 columns -- and the slab's rows are
+  // swizzled in LDS (piece p of a row whose point is i sits at slot p ^ (i & 7)) so that these column-wise stores spread over all
+  // banks; the compute phase reads a row's eight pieces as before, permuted inside the same 128 bytes.
+  int x_dst[XT ? NXP : 1];                             // XT: byte offset of the piece inside its slab
+  unsigned x_live = 0;                                 // XT: the thread has a piece in this round
   KK_UNROLL
   for (int it = 0; it < NXP; ++it) {
     int g = it * NT + t;
-    g = g < NP ? g : NP - 1;
-    const int xr = g >> 3, part = g & 7;
+    int xr, part;
+    if constexpr (!XT) { g = g < NP ? g : NP - 1; xr = g >> 3; part = g & 7; }
+    else {
+      xr = (g >> 7) * 16 + (g & 15); part = (g >> 4) & 7;
+      if (xr < SLABR) x_live |= 1u << it; else xr = SLABR - 1;
+      x_dst[it] = (xr * 8 + (part ^ ((xr % W) & 7))) * 16;
+    }
     const int jr = j0 - 1 + xr / W, ir = i0 - 1 + xr % W;
     x_in[it] = jr >= 0 && jr < ny && ir >= 0 && ir < nx;
     const int jq = jr < 0 ? 0 : (jr > ny - 1 ? ny - 1 : jr), iq = ir < 0 ? 0 : (ir > nx - 1 ? nx - 1 : ir);
@@ -1005,8 +1019,12 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     const XV zero = {0.0, 0.0};
     KK_UNROLL
     for (int it = 0; it < NXP; ++it) {
-      const int g = it * NT + t;
-      if (g < NP && !(plane_in && x_in[it])) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = zero;
+      if constexpr (!XT) {
+        const int g = it * NT + t;
+        if (g < NP && !(plane_in && x_in[it])) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = zero;
+      } else {
+        if (((x_live >> it) & 1u) && !(plane_in && x_in[it])) *reinterpret_cast<XV*>(dst + x_dst[it]) = zero;
+      }
     }
   };
   auto store_slab = [&](int kp, const XV (&rx)[NXP]) {
@@ -1014,8 +1032,12 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     char* dst = ring + (size_t)(kp & 3) * SLABB;
     KK_UNROLL
     for (int it = 0; it < NXP; ++it) {
-      const int g = it * NT + t;
-      if (g < NP && x_in[it]) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = rx[it];
+      if constexpr (!XT) {
+        const int g = it * NT + t;
+        if (g < NP && x_in[it]) *reinterpret_cast<XV*>(dst + (size_t)g * 16) = rx[it];
+      } else {
+        if (((x_live >> it) & 1u) && x_in[it]) *reinterpret_cast<XV*>(dst + x_dst[it]) = rx[it];
+      }
     }
   };
   const uint32_t full = G.n >= 32 ? 0xffffffffu : ((1u << G.n) - 1u);
@@ -1099,7 +1121,9 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
       if (conforms(k, 0, w_cur[0]) || conforms(k, 1, w_cur[1])) {           // a row that does not conform computes garbage nobody stores
         const AT* av0 = abuf + ((size_t)(P * 2) * ROWS + rs) * LP;
         const AT* av1 = av0 + (size_t)ROWS * LP;
-        const char* own = ring + (((2 * line) * W + ii + 1) << 7) + c * 16; // slab line of lattice line j - 1 of the pair's first row, slot 0, this lane's piece
+        const char* own = ring + (((2 * line) * W + ii + 1) << 7) + (XT ? 0 : c * 16); // slab line of lattice line j - 1 of the pair's first row, slot 0, this lane's piece
+        // XT: the lane's piece of the X row at point ii + 1 + di sits at slot c ^ ((ii + 1 + di) & 7) (see x_dst)
+        const char* own_d[3] = {own + ((c ^ (ii & 7)) << 4), own + ((c ^ ((ii + 1) & 7)) << 4), own + ((c ^ ((ii + 2) & 7)) << 4)};
         double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
         KK_UNROLL
         for (int gp = 0; gp < (NG + 1) / 2; ++gp) {                         // two groups = six positions = three 16-byte reads per row
@@ -1114,7 +1138,8 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
             // PRES != 0: the stencil's pattern (3 bits per group) is a compile-time constant -- straight-line code, every read of the
             // plane schedulable ahead; PRES == 0: any pattern, scalar branches
             const int e = G.e[g], pres = PRES ? (int)((PRES >> (3 * g)) & 7u) : G.pres[g];
-            const char* xb = own + ((k + (e & 3) - 1) & 3) * SLABB + (e >> 2) * 128;
+            const int d_i = XT ? (((e >> 2) + W + 1) % W) : 0;                 // di + 1 of the group (uniform)
+            const char* xb = (!XT ? own : (d_i == 0 ? own_d[0] : (d_i == 1 ? own_d[1] : own_d[2]))) + ((k + (e & 3) - 1) & 3) * SLABB + (e >> 2) * 128;
             XV x[4];
             KK_UNROLL
             for (int sl = 0; sl < 4; ++sl)                                    // X row j - 1 + sl of the group: the first row's dj = sl - 1, the second row's dj = sl - 2
@@ -1277,14 +1302,15 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
 #define KK_MV4(NE, FL)                                                                                                          \
   do {                                                                                                                          \
     if (part) {                                                                                                                 \
-      if (beta == 0.0) { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, true, true, true); else KK_MV4B(NE, FL, true, false, true); }  \
-      else { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, false, true, true); else KK_MV4B(NE, FL, false, false, true); }            \
+      if (beta == 0.0) { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, true, 1, true); else KK_MV4B(NE, FL, true, 0, true); }        \
+      else { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, false, 1, true); else KK_MV4B(NE, FL, false, 0, true); }                  \
     }                                                                                                                           \
-    else if (beta == 0.0) { if (xrow) KK_MV4B(NE, FL, true, true, false); else KK_MV4B(NE, FL, true, false, false); }            \
-    else { if (xrow) KK_MV4B(NE, FL, false, true, false); else KK_MV4B(NE, FL, false, false, false); }                           \
+    else if (beta == 0.0) { if (xrow) KK_MV4B(NE, FL, true, 1, false); else if (xcol) KK_MV4B(NE, FL, true, 2, false); else KK_MV4B(NE, FL, true, 0, false); }    \
+    else { if (xrow) KK_MV4B(NE, FL, false, 1, false); else if (xcol) KK_MV4B(NE, FL, false, 2, false); else KK_MV4B(NE, FL, false, 0, false); }                 \
   } while (0)
   const bool part = ncv < 16;
   const bool xrow = xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0);
+  const bool xcol = xs0 == 1 && plan->tune.mv4_xcol;   // column-major X: the column-wise piece order with swizzled slab rows
   unsigned pat = 0;                                    // 3 bits per group: which of dj = -1, 0, 1 it holds
   for (int g = 0; g < m->grp.ng; ++g) pat |= (unsigned)m->grp.pres[g] << (3 * g);
   constexpr unsigned kPat27 = 0x7FFFFFFu;              // 9 groups x {-1, 0, 1}: the 27-point stencil

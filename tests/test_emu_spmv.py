@@ -167,6 +167,10 @@ def test_mv4_plane_marching(be):
     for wg in (1, 64):
         pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv_kernel": 4, "mv4_wg_per_cu": wg}, max_val=32.0, nans=True)
     pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, value_dtype=np.float32)
+    # column-major X takes the column-wise piece order with swizzled slab rows by default; mv4_xcol 0 keeps the general-stride order
+    for xcol in (0, 1):
+        h = pc.check_spmv_mv(be, A0, 32, "N", 1.5, 0.0, "F", "F", algo="SPMV_DEFAULT", knobs={"mv4_xcol": xcol}, max_val=32.0, nans=True)
+        assert h.query("mv4_workgroups") > 0
     # Inf and NaN in X reach exactly the rows the reference lets them reach (no 0 * Inf from halo or pad entries): a corner,
     # a face, an interior point
     name, A0, _ = pc.mv4_cases()[3]

@@ -195,6 +195,12 @@ def test_mv4_plane_marching(be):
                 assert h.query("mv4_workgroups") > 0 and h.query("mv4_other_rows") < 0.02 * A0.nrows
     name, A0, _ = pc.mv4_cases()[0]
     pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, value_dtype=np.float32)
+    # column-major X takes the column-wise piece order with swizzled slab rows by default; mv4_xcol 0 keeps the general-stride order
+    for xcol in (0, 1):
+        for name_, A1, _ in pc.mv4_cases()[:4]:
+            h = pc.check_spmv_mv(be, A1, 32, "N", 1.5, 0.0, "F", "F", algo="SPMV_DEFAULT", knobs={"mv4_xcol": xcol}, max_val=32.0, nans=True)
+            assert h.query("mv4_workgroups") > 0
+            pc.check_spmv_mv(be, A1, 16, "N", -1.0, 0.5, "F", "C", algo="SPMV_DEFAULT", knobs={"mv4_xcol": xcol}, max_val=32.0)
     # Inf and NaN in X reach exactly the rows the reference lets them reach (no 0 * Inf from halo or pad entries)
     name, A0, _ = pc.mv4_cases()[3]
     h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
