@@ -50,7 +50,9 @@ def run(be, budget, seed0=0, max_cases=None):
                 M = hubby(rng, int(rng.integers(100, 5000)), int(rng.integers(100, 5000)), int(rng.integers(1, 40)), int(rng.integers(0, 4)), 3000, sort=bool(rng.integers(0, 2)))
                 for algo in (None, "SPMV_DEFAULT", "SPMV_MERGE_PATH"):
                     for mode in "NT":
-                        pc.check_spmv(be, M, mode, float(rng.integers(-3, 4)), float(rng.integers(-2, 3)), algo=algo, offset_dtype=odt, max_val=50.0, seed=case)
+                        # analysed handles also through the column-slab copy (forced: slabs of 2^4 .. 2^12 columns) and the fingerprint-refreshed transpose
+                        kn = {"colslab": 2, "colslab_shift": int(rng.integers(4, 13)), "colslab_const": int(rng.integers(0, 2)), "explicit_transpose_min_knnz": 0} if algo and rng.random() < 0.5 else None
+                        pc.check_spmv(be, M, mode, float(rng.integers(-3, 4)), float(rng.integers(-2, 3)), algo=algo, offset_dtype=odt, max_val=50.0, seed=case, knobs=kn)
             elif kind == 4:    # sort / merge / transpose
                 M = hubby(rng, int(rng.integers(5, 300)), int(rng.integers(50, 40000)), int(rng.integers(1, 30)), int(rng.integers(0, 3)), int(rng.integers(9000, 40000)), sort=False)
                 M.entries[rng.integers(0, M.nnz, size=M.nnz // 7)] = M.entries[rng.integers(0, M.nnz, size=M.nnz // 7)]   # duplicates
