@@ -1302,8 +1302,8 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
 #define KK_MV4(NE, FL)                                                                                                          \
   do {                                                                                                                          \
     if (part) {                                                                                                                 \
-      if (beta == 0.0) { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, true, 1, true); else KK_MV4B(NE, FL, true, 0, true); }        \
-      else { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, false, 1, true); else KK_MV4B(NE, FL, false, 0, true); }                  \
+      if (beta == 0.0) { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, true, 1, true); else if (xcol) KK_MV4B(NE, FL, true, 2, true); else KK_MV4B(NE, FL, true, 0, true); }   \
+      else { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, false, 1, true); else if (xcol) KK_MV4B(NE, FL, false, 2, true); else KK_MV4B(NE, FL, false, 0, true); }             \
     }                                                                                                                           \
     else if (beta == 0.0) { if (xrow) KK_MV4B(NE, FL, true, 1, false); else if (xcol) KK_MV4B(NE, FL, true, 2, false); else KK_MV4B(NE, FL, true, 0, false); }    \
     else { if (xrow) KK_MV4B(NE, FL, false, 1, false); else if (xcol) KK_MV4B(NE, FL, false, 2, false); else KK_MV4B(NE, FL, false, 0, false); }                 \
