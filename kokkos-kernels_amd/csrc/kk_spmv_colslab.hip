@@ -32,7 +32,6 @@ struct kkamd_cs_plan {
   void* d_dst = nullptr;                 // [nnz] offset type: where entry i of A sits in the slab order
   unsigned long long* d_fp = nullptr;    // [2 * ntiles] fingerprints of A.values, tile by tile
   size_t bytes = 0;
-  double crs_us = 0.0, cs_us = 0.0;      // what the selection measured (0: not measured)
 };
 
 namespace kk {
@@ -243,12 +242,9 @@ int64_t cs_plan_query(const kkamd_cs_plan* cs, int what) {
     case 0: return cs->nslabs;
     case 1: return cs->shift;
     case 2: return (int64_t)cs->bytes;
-    case 3: return (int64_t)(cs->crs_us + 0.5);
-    case 4: return (int64_t)(cs->cs_us + 0.5);
     default: return 0;
   }
 }
-void cs_plan_set_times(kkamd_cs_plan* cs, double crs_us, double cs_us) { if (cs) { cs->crs_us = crs_us; cs->cs_us = cs_us; } }
 
 template <class OffT, class AT>
 static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, hipStream_t st) {
