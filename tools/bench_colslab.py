@@ -25,10 +25,12 @@ def matrices():
     c = torch.sort(torch.randint(0, n, (n, k), device=dev, generator=g), dim=1).values
     rm = (torch.arange(n + 1, device=dev, dtype=torch.int64) * k).to(torch.int32)
     val = torch.rand(n * k, device=dev, dtype=torch.float64, generator=g) + 0.5
-    yield "uniform random, 5e6 rows x 20", kk.CrsMatrix(n, n, rm, c.reshape(-1).to(torch.int32).contiguous(), val)
-    if quick: return
+    if "rmat" not in sys.argv: yield "uniform random, 5e6 rows x 20", kk.CrsMatrix(n, n, rm, c.reshape(-1).to(torch.int32).contiguous(), val)
+    del c, rm, val
+    if quick and "rmat" not in sys.argv: return
     R = oracle.rmat(22, 16)
     yield "R-MAT scale 22, edge factor 16", kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values)
+    if quick: return
     n, k = 20_000_000, 8
     c = torch.sort(torch.randint(0, n, (n, k), device=dev, generator=g), dim=1).values
     rm = (torch.arange(n + 1, device=dev, dtype=torch.int64) * k)
