@@ -99,12 +99,11 @@ def test_mixed_tiles(be):
     # the column analysis is per tile: tiles the windows cannot cover read entries, the others keep codes / staged x / records
     for name, A0 in pc.mixed_tile_cases():
         for npt, pat in ((8, 0), (8, 2), (4, 2), (16, 0)):         # (the GPU suite runs all six combinations)
-            if True:
-                kn = {"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": pat, "window_codes_min_pct": 10}
-                h = pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=32.0, expect={"window_codes": 1})
-                assert 0 < h.query("plain_tiles") < h.query("tiles"), (name, npt, h.query("plain_tiles"), h.query("tiles"))
-                assert h.query("code_tiles") + h.query("pattern_tiles") + h.query("plain_tiles") == h.query("tiles")
-                pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs=kn, max_val=32.0, nans=True, offset_dtype=np.int64, value_dtype=np.float32)
+            kn = {"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": pat, "window_codes_min_pct": 10}
+            h = pc.check_spmv(be, A0, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=32.0, expect={"window_codes": 1})
+            assert 0 < h.query("plain_tiles") < h.query("tiles"), (name, npt, h.query("plain_tiles"), h.query("tiles"))
+            assert h.query("code_tiles") + h.query("pattern_tiles") + h.query("plain_tiles") == h.query("tiles")
+            pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs=kn, max_val=32.0, nans=True, offset_dtype=np.int64, value_dtype=np.float32)
         # too few coverable tiles for the threshold: plain kernel
         pc.check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs={"window_codes_min_knnz": 0, "window_codes_min_pct": 100}, max_val=32.0,
                       expect={"window_codes": 0})
