@@ -155,6 +155,37 @@ def cpu_baseline_mv(nv, n=300, min_seconds=6.0):
             "sample": "the full workload: 27-pt FE Laplacian %d^3 x %d right-hand sides, LayoutRight, %d iterations" % (n, nv, it)}
 
 
+def bench_rank1_gather_bound(kk, torch):
+    """Rank-1 SpMV off the stencil: uniform random columns, 5e6 rows x 20 (1e8 nonzeros, x = 40 MB), fp64.  The CRS
+    stream kernel, the default handle (which may select the column-slab copy, DESIGN 4.1.1) and the copy with constant values promised;
+    fractions are CRS bytes (nnz*12 + (rows+1)*4 + cols*8 + rows*8) at 8 TB/s."""
+    n, k = 5_000_000, 20
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    c = torch.sort(torch.randint(0, n, (n, k), device="cuda", generator=g), dim=1).values
+    rm = (torch.arange(n + 1, device="cuda", dtype=torch.int64) * k).to(torch.int32)
+    val = torch.rand(n * k, device="cuda", dtype=torch.float64, generator=g) + 0.5
+    A = kk.CrsMatrix(n, n, rm, c.reshape(-1).to(torch.int32).contiguous(), val); del c
+    x = torch.randint(-20, 20, (n,), device="cuda", generator=g).double(); y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    alg = A.nnz() * 12 + (n + 1) * 4 + 2 * n * 8
+    out = {"workload": "spmv_crs_uniform_random_5e6x20_fp64", "nnz": A.nnz(), "algorithmic_bytes_per_call": alg, "peak_GBps": HBM_PEAK_GBPS}
+    ref = None
+    for tag, knobs in (("crs_stream_kernel", {"colslab": 0}), ("default_handle", {}), ("column_slab_copy_constant_values", {"colslab": 2, "colslab_const": 1})):
+        h = kk.SPMVHandle("SPMV_DEFAULT")
+        for k_, v_ in knobs.items(): h.set(k_, v_)
+        fn = lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y)
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        r = _fenced(fn, torch.cuda.synchronize, 20)
+        r["frac"] = round(alg / r["mean_ms"] / 1e6 / HBM_PEAK_GBPS, 4)
+        if ref is None: ref = y.clone()
+        r["max_rel_diff_vs_crs"] = float(((y - ref).abs().max() / ref.abs().max()).item())
+        assert r["max_rel_diff_vs_crs"] < 1e-12, "rank-1 gather-bound case: kernels disagree"
+        if tag == "default_handle": r["column_slab_copy_selected"] = int(h.query("colslab")); r["selection_us_crs_vs_copy"] = [h.query("colslab_crs_us"), h.query("colslab_us")]
+        out[tag] = r
+        del h
+    return out
+
+
 def bench_spgemm(kk, torch, budget_s, cpu, scale=20):
     """BASELINE config 4 family: C = A*A on R-MAT (edge factor 16, 64-bit offsets), the largest scale whose C fits one GPU
     (scale 20: nnz(C) 9.69e9 = 116 GB; scale 22 as specified needs 863 GB).  Per repetition a fresh handle: symbolic, numeric,
@@ -496,6 +527,11 @@ def main():
                 out["spmv_mv"] = {"error": repr(e)[:200]}
             del handle
             A = None
+            torch.cuda.empty_cache()
+            try:
+                out["spmv_gather_bound"] = bench_rank1_gather_bound(kk, torch)
+            except Exception as e:
+                out["spmv_gather_bound"] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
             try:
                 left = args.extras_seconds - (time.perf_counter() - t_x)
