@@ -158,6 +158,8 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *                       1 XCD-contiguous (LDS-staged kernel), 0 "mv_remap": 0 dispatch, 1 XCD-contiguous, 2^k grouped (default 16)
  *     "mv_strip_min_kb" / "mv_strip_l2_kb"  when strips engage / how much of an XCD's L2 a strip's X rows may take
  *     "mv_glds"         LDS-staged kernel: X window through global_load_lds (1) or registers (0)
+ *     "mv4_2d"          plane-marching kernel on 2-D lattices (lines grouped 32..128 at a time into the planes it marches through;
+ *                       the first and last line of a group go to its gather rows): 1 (default) on, 0 off
  *     "mv4_xcol"        plane-marching kernel, column-major X (LayoutLeft): 1 (default) the X pieces of a plane are fetched column-wise
  *                       (whole cache lines per load) into slab rows swizzled in LDS; 0 the order used for general strides
  *     "mv4_wg_per_cu"   plane-marching kernel: workgroups per CU the split along the far stride aims for (default 8, 1..64)

@@ -1126,6 +1126,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "mv_glds") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv_glds = value; }
   else if (k == "mv_long_T") { if (value < 0) return bad("non-negative"); t.mv_long_T = value; }
   else if (k == "mv4_min_nvec") { if (value < 1 || value > 1024) return bad("in 1..1024"); t.mv4_min_nvec = value; }
+  else if (k == "mv4_2d") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv4_2d = value; }
   else if (k == "mv4_xcol") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv4_xcol = value; }
   else if (k == "mv4_wg_per_cu") { if (value < 1 || value > 64) return bad("in 1..64"); t.mv4_wg_per_cu = value; }
   else if (k == "march") { if (value != 0 && value != 1) return bad("0 or 1"); t.march = value; }
@@ -1467,7 +1468,7 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
     if (plan->cs) { kk::cs_plan_destroy(plan->cs); plan->cs = nullptr; }
     plan->cs_tried = false; plan->cs_crs_us = plan->cs_us = 0.0;
   }
-  if (t.mv4_wg_per_cu != old.mv4_wg_per_cu && plan->mv4) {
+  if ((t.mv4_wg_per_cu != old.mv4_wg_per_cu || t.mv4_2d != old.mv4_2d) && (plan->mv4 || plan->mv4_tried)) {
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
     kk::mv4_plan_destroy(plan->mv4); plan->mv4 = nullptr; plan->mv4_tried = false;
   }

@@ -1189,11 +1189,27 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
   plan->mv4_tried = true;
   if (A->num_rows != A->num_cols || A->num_rows < 4096) return KKAMD_OK;
   if (!plan->mv_period_known) { plan->mv_period = detect_period_rows<OffT>(A, st); plan->mv_period_known = true; }
-  const int64_t S2 = plan->mv_period;
+  int64_t S2 = plan->mv_period;
   if (S2 <= 0 || A->num_rows % S2) return KKAMD_OK;
   // the near stride and the offset list: the longest of a few scattered rows whose offsets all decompose as
   // dk S2 + dj S1 + di with |dk|, |dj|, |di| <= 1 (a shorter one is a boundary row)
   int64_t S1 = 0; Mv4Tab offs{};
+  int64_t S1_fixed = 0;                                // 2-D lattices (second attempt below): the near stride is given
+  for (int attempt = 0; attempt < 2 && !S1; ++attempt) {
+  if (attempt == 1) {
+    // No near stride below the far one: a 2-D lattice whose only stride is the line length.  Its lines are taken m at a time as
+    // the "planes" the kernel marches through (S1 = line length, S2 = m lines): the first and the last line of every group then
+    // miss the neighbours the lattice of m lines says they should not have -- mv4_verify_kernel sends them (2 / m of the rows)
+    // to the gather rows, everything else marches.  m: a divisor of the number of lines, 32..128, a multiple of the patch's 4 lines if possible.
+    if (!plan->tune.mv4_2d) break;
+    const int64_t line = plan->mv_period, nlines = A->num_rows / line;
+    int64_t m_best = 0;
+    for (int pass = 0; pass < 2 && !m_best; ++pass)
+      for (int64_t mm = 128; mm >= 32; --mm)
+        if (nlines % mm == 0 && nlines / mm >= 4 && (pass == 1 || mm % kMv4RJ == 0)) { m_best = mm; break; }
+    if (!m_best || line < 8) break;
+    S1_fixed = line; S2 = line * m_best;
+  }
   for (int s = 1; s <= 32; ++s) {
     const int64_t r = (int64_t)((((unsigned long long)s * 0x9E3779B97F4A7C15ull) >> 11) % (unsigned long long)A->num_rows);
     OffT rm[2];
@@ -1205,9 +1221,9 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
         hipStreamSynchronize(st) != hipSuccess) return KKAMD_OK;
     int64_t near[kMv4MaxL]; int nn = 0;                // offsets between the unit neighbours and the far cluster: S1 - 1, S1, S1 + 1
     for (int q = 0; q < len; ++q) { const int64_t d = cols[q] - r; if (d > 1 && 2 * d < S2) near[nn++] = d; }
-    if (!nn) continue;
+    if (!nn && !S1_fixed) continue;
     for (int a = 1; a < nn; ++a) { const int64_t v = near[a]; int e = a - 1; while (e >= 0 && near[e] > v) { near[e + 1] = near[e]; --e; } near[e + 1] = v; }
-    const int64_t cand = near[nn / 2];
+    const int64_t cand = S1_fixed ? S1_fixed : near[nn / 2];
     if (cand < 3 || S2 % cand) continue;
     bool okr = true;
     for (int q = 0; q < len && okr; ++q) {
@@ -1222,6 +1238,7 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
     if (!okr) continue;
     S1 = cand; offs.n = len;
     for (int q = 0; q < len; ++q) offs.e[q] = (int)(cols[q] - r);
+  }
   }
   if (!S1) return KKAMD_OK;
   const int64_t nx = S1, ny = S2 / S1, nz = A->num_rows / S2;

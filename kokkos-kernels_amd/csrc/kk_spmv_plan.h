@@ -37,6 +37,7 @@ struct SpmvTuning {
   int mv_long_T      = 0;  // rank-2 gather kernel: rows above this many entries get a workgroup each (0 = automatic: 4 x the average row, at least 64)
   int mv4_min_nvec   = 4;  // narrowest multivector the plane-marching kernel takes (a block of fewer than 16 columns runs its partial-block form)
   int mv4_xcol       = 1;  // rank-2 plane-marching kernel, column-major X: 1 = pieces dealt out column-wise + swizzled slab rows (whole cache lines per load), 0 = as for general strides
+  int mv4_2d         = 1;  // rank-2 plane-marching kernel on 2-D lattices (lines grouped into planes): 1 on, 0 off
   int mv4_wg_per_cu  = 8;  // rank-2 plane-marching kernel: workgroups per CU the k-chunking aims for (one is resident at a time)
   int march          = 0;  // rank 1 on the plane-marching analysis (lattice stencils, fp64 vectors): 0 off, 1 on
   int march_planes   = 20; // ... planes a workgroup marches (its k-chunk)

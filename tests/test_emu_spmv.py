@@ -182,7 +182,16 @@ def test_mv4_plane_marching(be):
         for xo, yo, beta in ((("C", "C", 0.0), ("F", "F", 0.5), ("C", "F", -1.0)) if nvec in (5, 12) else (("C", "C", 0.0), ("F", "F", 0.5))[nvec % 2:][:1]):
             h = pc.check_spmv_mv(be, A0, nvec, "N", 1.5, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0))
             assert h.query("mv4_workgroups") > 0, (nvec, xo, yo)
-    # not its matrices / widths: no far stride (2-D), too few lattice rows, 3 right-hand sides (below mv4_min_nvec), no analysis, the gather kernel asked for
+    # 2-D lattices: the lines are grouped m at a time into "planes" (m: a divisor of the line count in 32..128); the first and last
+    # line of every group go to the gather rows, the rest marches
+    for st, nxl, nyl, m_ in (("FE", 70, 128, 32), ("FD", 40, 256, 64)):
+        A2 = oracle.laplace2d(st, nxl, nyl)
+        for nvec, xo, yo, beta in ((16, "C", "C", 0.0), (32, "F", "F", 0.5), (5, "C", "F", 0.0)):
+            h = pc.check_spmv_mv(be, A2, nvec, "N", 1.5, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0))
+            assert h.query("mv4_workgroups") > 0 and h.query("mv4_other_rows") == 2 * (nyl // m_ - 1) * nxl, (st, h.query("mv4_workgroups"), h.query("mv4_other_rows"))
+        h = pc.check_spmv_mv(be, A2, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv4_2d": 0}, max_val=32.0)
+        assert h.query("mv4_workgroups") == 0
+    # not its matrices / widths: no far stride and no usable line count (2-D, 41 lines), too few lattice rows, 3 right-hand sides (below mv4_min_nvec), no analysis, the gather kernel asked for
     for A1, nvec, algo, knobs in ((oracle.laplace2d("FE", 130, 41), 16, "SPMV_DEFAULT", None), (oracle.laplace3d("FE", 12, 12, 12), 16, "SPMV_DEFAULT", None),
                                   (A0, 3, "SPMV_DEFAULT", None), (A0, 8, "SPMV_DEFAULT", {"mv4_min_nvec": 16}), (A0, 16, "SPMV_FAST_SETUP", None), (A0, 16, "SPMV_DEFAULT", {"mv_kernel": 2}),
                                   (oracle.random_crs(5000, 5000, 9, variance=3, seed=5), 16, "SPMV_DEFAULT", None)):

@@ -201,6 +201,14 @@ def test_mv4_plane_marching(be):
             h = pc.check_spmv_mv(be, A1, 32, "N", 1.5, 0.0, "F", "F", algo="SPMV_DEFAULT", knobs={"mv4_xcol": xcol}, max_val=32.0, nans=True)
             assert h.query("mv4_workgroups") > 0
             pc.check_spmv_mv(be, A1, 16, "N", -1.0, 0.5, "F", "C", algo="SPMV_DEFAULT", knobs={"mv4_xcol": xcol}, max_val=32.0)
+    # 2-D lattices: the lines are grouped m at a time into "planes"; the first and last line of every group go to the gather rows
+    for st, nxl, nyl, m_ in (("FE", 70, 128, 32), ("FD", 40, 256, 64), ("FE", 500, 400, 100)):
+        A2 = oracle.laplace2d(st, nxl, nyl)
+        for nvec, xo, yo, beta in ((16, "C", "C", 0.0), (32, "F", "F", 0.5), (5, "C", "F", 0.0), (12, "F", "F", -1.0)):
+            h = pc.check_spmv_mv(be, A2, nvec, "N", 1.5, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0))
+            assert h.query("mv4_workgroups") > 0 and h.query("mv4_other_rows") == 2 * (nyl // m_ - 1) * nxl, (st, h.query("mv4_workgroups"), h.query("mv4_other_rows"))
+        h = pc.check_spmv_mv(be, A2, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", knobs={"mv4_2d": 0}, max_val=32.0)
+        assert h.query("mv4_workgroups") == 0
     # Inf and NaN in X reach exactly the rows the reference lets them reach (no 0 * Inf from halo or pad entries)
     name, A0, _ = pc.mv4_cases()[3]
     h = pc.check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, nans=True,
