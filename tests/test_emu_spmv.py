@@ -115,7 +115,8 @@ def test_knob_validation(be):
     kk = kk_loader.load()
     A0 = oracle.random_crs(3000, 3000, 9, seed=1)
     for key, val in (("xcd_remap", 3), ("xcd_remap", 6), ("mv_remap", 12), ("nnz_per_thread", 5), ("stream_variant", 2), ("ablate", 1),
-                     ("lds_pad_kb", 8), ("nontemporal", 1), ("kernel", 7), ("window_codes", 9)):
+                     ("lds_pad_kb", 8), ("nontemporal", 1), ("kernel", 7), ("window_codes", 9), ("colslab", 3), ("colslab_shift", 1), ("colslab_shift", 31),
+                     ("colslab_const", 2), ("colslab_min_knnz", -1), ("mv4_xcol", 2), ("mv4_2d", -1)):
         h = kk.SPMVHandle("SPMV_DEFAULT"); h.set(key, val)
         with pytest.raises(kk.KkamdError):
             pc.check_spmv(be, A0, "N", 1.0, 0.0, None) if False else kk.spmv(h, "N", 1.0, pc.dev(be, A0), be.from_numpy(np.ones(3000)), 0.0, be.from_numpy(np.zeros(3000)))
