@@ -486,6 +486,26 @@ def main():
                                            "plan_bytes": h_.query("plan_bytes"), "streamed_bytes_per_launch": streamed_}
         except Exception:
             pass
+        # The device's own streaming-read rate next to the 8 TB/s spec ("re-measure on the build box and quote both"): the
+        # matrix values (5.8 GB on C2) through kkamd_bench_read -- 16-byte loads, 256 lanes, 4 independent loads in flight per lane.
+        if world == 1 and not emu:
+            try:
+                vals_ = A.values; nbytes_ = int(vals_.numel() * vals_.element_size()) // 16 * 16
+                sink_ = torch.zeros(8, dtype=torch.float64, device=dev)
+                lib_ = kk.torch_backend().lib
+                st_ = torch.cuda.current_stream().cuda_stream
+                run_ = lambda: kk._capi.check(lib_, lib_.kkamd_bench_read(vals_.data_ptr(), nbytes_, 4, 0, 0, sink_.data_ptr(), st_))
+                for _ in range(3): run_()
+                e0_, e1_ = Event(enable_timing=True), Event(enable_timing=True)
+                e0_.record()
+                for _ in range(10): run_()
+                e1_.record(); torch.cuda.synchronize()
+                rd_gbps = nbytes_ * 10 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9
+                out["roofline"]["measured_stream_read_GBps"] = round(rd_gbps, 1)
+                out["roofline"]["frac_of_measured_stream_read"] = round(achieved / rd_gbps, 4)
+            except Exception as e:
+                out["roofline"]["measured_stream_read_GBps"] = None
+                out["roofline"]["measured_stream_read_error"] = repr(e)[:120]
         # Memory-side traffic comes from rocprofv3 PMC passes of this same command (it cannot be counted live); the file is
         # stamped with the hash of the kernel sources it was measured on and is IGNORED when that differs from the sources here.
         out["roofline"]["kernel_source_sha"] = kernel_source_sha()
@@ -504,6 +524,8 @@ def main():
                         out["roofline"]["traffic"] = int(rd + wr)
                         # what actually crossed the memory side per second, against the same peak
                         out["roofline"]["moved_frac"] = round((rd + wr) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                        if out["roofline"].get("measured_stream_read_GBps"):
+                            out["roofline"]["moved_frac_of_measured_stream_read"] = round((rd + wr) / (kern_ms * 1e-3) / 1e9 / out["roofline"]["measured_stream_read_GBps"], 4)
                         out["roofline"]["traffic_source"] = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                                                              "FETCH_SIZE x2 per MI355X_MICROARCH.md)" % os.path.relpath(PMC_FILE, ROOT))
             except Exception:
