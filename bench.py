@@ -246,6 +246,21 @@ def cpu_baseline_spgemm(scale=18):
             "sample": "R-MAT scale %d ef 16, C = A*A (%d multiplications, nnz(C) %d): symbolic + numeric + row sort" % (scale, mults, Cm.nnz)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): run the same command line as N ranks of one node
+    under torch.distributed.run -- one process per GPU, rendezvous on 127.0.0.1 at a free port -- and pass its output and exit code
+    through.  Under torch.distributed.run (the driver's form) WORLD_SIZE is set and this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching %s\n" % (n, " ".join(cmd[1:9])))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,6 +285,8 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "halo_set", "allgather", "allgather_p2p"],
                     help="N > 1: how the x entries a slab references reach it (auto = column-range halo when it is smaller)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
 
     import numpy as np
     import torch

@@ -153,7 +153,15 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *   SpMV, rank 2
  *     "mv_kernel"       0 auto (plane-marching kernel where it applies -- analysed plan, fp64 vectors, right-hand sides in
  *                       blocks of 16 (a remainder: one more pass over the last 16 columns when beta = 0, else the gather kernel), a matrix that verifies as a radius-1 lattice stencil --, else the wave-private gather
- *                       kernel), 1 generic strided kernel, 2 wave-private gather kernel, 3 LDS-staged X tiles, 4 = 0
+ *                       kernel), 1 generic strided kernel, 2 wave-private gather kernel, 3 LDS-staged X tiles, 4 = 0 without the matrix-core
+ *                       kernel, 5 = 0 (the matrix-core kernel where its analysis accepts the matrix, see "mv5")
+ *     "mv5"             matrix-core kernel (v_mfma_f64_16x16x4f64; analysed plan, fp64 vectors, any width and strides; not on matrices
+ *                       the plane-marching kernel takes): the rows are cut into tiles of 16, a tile is DESCRIBED by the union of its
+ *                       columns in blocks of four plus a 64-bit occupancy mask per block (24 B per block instead of 4 B per entry;
+ *                       the values stay where they are) when its rows ascend strictly, it holds 1..2048 entries and at least
+ *                       "mv5_min_fill_pct" (default 25) percent of its 16 x 4 operand slots hold an entry; the other tiles' rows go to a
+ *                       gather kernel.  1 (default) = use it when at most "mv5_max_other_pct" (default 50) percent of the rows are
+ *                       left to the gather rows, 2 = whenever a tile can be described (no fill threshold: tests), 0 = never
  *     "mv_order"        row-block order: 2 (default) strips from the far stride found in the matrix (falls back to "mv_remap"),
  *                       1 XCD-contiguous (LDS-staged kernel), 0 "mv_remap": 0 dispatch, 1 XCD-contiguous, 2^k grouped (default 16)
  *     "mv_strip_min_kb" / "mv_strip_l2_kb"  when strips engage / how much of an XCD's L2 a strip's X rows may take
@@ -177,7 +185,8 @@ int kkamd_set_default(const char* key, int value);
  * "code_tiles" / "staged_tiles" / "pattern_tiles", "window_codes" (1 if any tile uses the column analysis), "window_staged_x",
  * "plan_bytes" (HBM the analysis keeps), "transpose_cached", rank 2: "mv_tiles", "mv_staged_tiles", "mv_order" (order in use),
  * "mv_period" (far stride found), "mv_plan_bytes", plane-marching kernel: "mv4_workgroups" (0 = not in use), "mv4_other_rows"
- * (rows left to its gather kernel), "mv4_stencil" (entries of the stencil), "mv4_near_stride"; "march_workgroups" (rank-1 marching kernel, 0 = not in use);
+ * (rows left to its gather kernel), "mv4_stencil" (entries of the stencil), "mv4_near_stride"; matrix-core kernel: "mv5_tiles" (described
+ * 16-row tiles, 0 = not in use), "mv5_other_rows", "mv5_blocks" (column blocks = MFMA instructions per pass), "mv5_fill_permille"; "march_workgroups" (rank-1 marching kernel, 0 = not in use);
  * column-slab copy: "colslab" (1 = in use), "colslab_tried", "colslab_slabs", "colslab_shift", "colslab_bytes", and what the selection
  * measured, "colslab_crs_us" / "colslab_us" (microseconds per call of the CRS kernel / of the copy; 0 = not measured). */
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);

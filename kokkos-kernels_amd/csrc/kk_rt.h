@@ -20,6 +20,9 @@
 #define KK_UMUL24(a, b) ((unsigned)(a) * (unsigned)(b))
 #define KK_GLDS16(gsrc, lds_wave_base, lane) std::memcpy((char*)(lds_wave_base) + 16 * (lane), (const void*)(gsrc), 16)
 #define KK_GLDS_WAIT()
+// v_mfma_f64_16x16x4f64 under the emulator: the operand layout probed on gfx950 (tools/probes/probe_mfma_f64.hip)
+#define KK_MFMA_F64_16X16X4(a, b, c) kk_emu::mfma_f64_16x16x4((a), (b), (c))
+#define KK_UNIFORM(v) (v)
 #else
 #include <hip/hip_runtime.h>
 #define KK_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -44,4 +47,10 @@
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                          \
                                    (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #define KK_GLDS_WAIT() __builtin_amdgcn_s_waitcnt(0)
+// D(16x16) += A(16x4) B(4x16) on the matrix core, fp64.  Lane l holds A[l % 16][l / 16], B[l / 16][l % 16] and, in register r of
+// the accumulator, D[4 r + l / 16][l % 16] (layout probed on the hardware: tools/probes/probe_mfma_f64.hip, profiles/round2)
+#define KK_MFMA_F64_16X16X4(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+// a 32-bit value the program knows to be the same in every lane of the wave, moved to a scalar register
+#define KK_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)
 #endif
+typedef double kk_f64x4 __attribute__((vector_size(32)));

@@ -1602,6 +1602,17 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
         }
       }
     }
+    // matrix-core kernel (mv_kernel 0 = auto, or 5; kk_spmv_mvblk.hip): analysed handles, fp64 vectors, matrices whose 16-row tiles share
+    // enough columns (block-structured, multi-dof finite elements); any width, any strides.  The analysis happens on the first such call
+    if constexpr (sizeof(YT) == 8) {
+      if (plan && plan->tile != 0 && plan->tune.mv5 != 0 && (mvk == 0 || mvk == 5) && !plan->mv4 && plan->entries == A->d_entries) {
+        if (!plan->mv5 && !plan->mv5_tried) {
+          int rc = mv5_plan_build(plan, A, st);
+          if (rc) return rc;
+        }
+        if (plan->mv5) return mv5_spmv(plan, A, (const double*)X, xs0, xs1, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
+      }
+    }
     const YT* Xr = nullptr; int64_t ldx = 0;
     if (xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0)) { Xr = X; ldx = xs0; }
     else if (plan && nvec >= 2) {

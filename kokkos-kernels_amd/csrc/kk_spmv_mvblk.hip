@@ -1,0 +1,401 @@
+// kk_spmv_mvblk.hip -- rank-2 CSR SpMV (SpMV_MV) on the matrix cores of gfx950, for matrices whose neighbouring rows share columns
+// (block-structured and multi-degree-of-freedom finite-element matrices, dense bands).
+//
+// Reference: sparse/impl/KokkosSparse_spmv_impl.hpp:634-1004 (SPMV_MV_LayoutLeft_Functor: every row gathers the X row of each of its
+// entries); the reference's own matrix-core path exists for BSR only (sparse/impl/KokkosSparse_spmv_bsrmatrix_impl.hpp:74-89,
+// 16 x 16 x 16 wmma tiles over dense blocks).  Here the CSR matrix keeps its arrays and the ANALYSIS finds the blocks:
+//
+//   * a TILE is 16 consecutive rows (M of v_mfma_f64_16x16x4f64).  The plan keeps the sorted union U of the tile's columns in BLOCKS
+//     of four (K of the instruction; the four columns of a block need not be adjacent) and, per block, a 64-bit mask: bit 4 i + k
+//     says that row i of the tile holds column U[4 b + k].  24 bytes per block replace the 4 bytes per entry of `entries`: with every
+//     slot filled that is 0.375 B per nonzero, at a quarter filled 1.5 B.
+//   * the KERNEL gives a wave a tile: the tile's values (one contiguous piece of the caller's value array -- nothing is copied into the
+//     plan, so values may change between calls) are laid down in wave-private LDS with coalesced 16-byte loads; per block, lane
+//     (k = lane / 16, j = lane % 16) loads X(U[4 b + k], j) -- the 16 lanes of a k cover one 128-byte X row, four rows per
+//     instruction -- and, as lane (i = lane % 16, k), picks A(i, U[4 b + k]) out of LDS: a row's entries ascend, so the entry's place in
+//     the row is the number of mask bits of the row seen so far (a running count per lane and a 4-bit popcount).  One MFMA does the
+//     16 x 4 x 16 contraction.  An X row is fetched once per TILE instead of once per entry: on a block-diagonal 32 x 32 matrix that is
+//     32 gathers instead of 512 per tile, which is what bounds the gather kernel (the texture path).
+//   * what the instruction multiplies that the reference does not -- an absent entry (operand 0) with the X value of a column some
+//     other row of the tile holds -- is harmless unless that X value is Inf or NaN (0 * Inf).  The lanes watch the exponent of every
+//     X value they load; a tile that saw a non-finite one recomputes its rows entry by entry from `entries` (exactly the reference's
+//     products), so Inf / NaN propagate to the rows that hold the column and to no other.
+//   * tiles the plan cannot describe (a row that does not ascend strictly, more than 2048 entries, fewer than `mv5_min_fill_pct` of the
+//     operand slots filled, no entries) leave their rows to a 16-lanes-per-row gather kernel.
+//   * LayoutLeft Y: the operands swap roles (D^T = X^T A^T), so that a lane's accumulator registers hold one ROW of the tile in four
+//     columns and a store instruction writes four whole 128-byte lines of Y; X is read where it lies for any strides.
+#include "kk_spmv_plan.h"
+#include "kk_scan.h"
+#include <new>
+#include <climits>
+
+namespace kk {
+constexpr int kMv5Rows = 16;     // rows per tile
+constexpr int kMv5Cap  = 2048;   // entries of a described tile (16 KB of values per wave at most)
+}  // namespace kk
+
+struct kkamd_mv5_plan {
+  int64_t ntiles = 0, tiles_on = 0, nblocks = 0, n_other = 0, nnz_on = 0, rows_on = 0;
+  int cap = 0;                                   // LDS values per wave of the kernel instantiation (512 / 1024 / 2048)
+  int64_t* d_blk_off = nullptr;                  // [ntiles + 1] first block of every tile (a tile without blocks is not described)
+  int32_t* d_cols = nullptr;                     // [4 * nblocks] the union columns, -1 past the end of a tile's union
+  unsigned long long* d_masks = nullptr;         // [nblocks]
+  int32_t* d_other = nullptr;                    // [n_other] rows of the tiles that are not described
+  size_t bytes = 0;
+};
+
+namespace kk {
+
+void mv5_plan_destroy(kkamd_mv5_plan* p) {
+  if (!p) return;
+  if (p->d_blk_off) (void)hipFree(p->d_blk_off);
+  if (p->d_cols) (void)hipFree(p->d_cols);
+  if (p->d_masks) (void)hipFree(p->d_masks);
+  if (p->d_other) (void)hipFree(p->d_other);
+  delete p;
+}
+int64_t mv5_plan_query(const kkamd_mv5_plan* p, int what) {
+  if (!p) return 0;
+  switch (what) {
+    case 0: return p->tiles_on;
+    case 1: return p->n_other;
+    case 2: return p->nblocks;
+    case 3: return (int64_t)p->bytes;
+    case 4: return p->nblocks ? (1000 * p->nnz_on) / (64 * p->nblocks) : 0;
+    case 5: return p->cap;
+    default: return 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Analysis, one workgroup per tile.  FILL = false: blk[tile] = number of column blocks (0: the tile is not described) and the
+// statistics; FILL = true (blk holds the offsets by then): the union columns and the masks.
+// stats: [0] blocks, [1] entries, [2] tiles, [3] rows of the described tiles, [4] most entries in one of them
+template <class OffT, bool FILL>
+__global__ __launch_bounds__(kBlock) void mv5_tile_kernel(int64_t nrows, const OffT* __restrict__ row_map, const int32_t* __restrict__ entries,
+                                                          int min_fill_pct, int64_t* __restrict__ blk, int32_t* __restrict__ cols,
+                                                          unsigned long long* __restrict__ masks, unsigned long long* __restrict__ stats) {
+  constexpr int PER = kMv5Cap / kBlock;
+  __shared__ int s_key[kMv5Cap];
+  __shared__ int s_uni[kMv5Cap];
+  __shared__ unsigned s_mask[kMv5Cap / 2];
+  __shared__ long long s_rm[kMv5Rows + 1];
+  __shared__ int s_bad;
+  __shared__ int s_wave[kBlock / 64];
+  const int t = threadIdx.x;
+  const int64_t tile = blockIdx.x;
+  const int64_t row0 = tile * kMv5Rows, rowN = (row0 + kMv5Rows < nrows) ? row0 + kMv5Rows : nrows;
+  if (t <= kMv5Rows) s_rm[t] = (long long)row_map[(row0 + t < rowN) ? row0 + t : rowN];
+  if (t == 0) s_bad = 0;
+  __syncthreads();
+  const long long a0 = s_rm[0];
+  const long long n64 = s_rm[kMv5Rows] - a0;
+  int64_t b0 = 0;
+  if (FILL) {
+    b0 = blk[tile];
+    if (blk[tile + 1] == b0) return;                             // workgroup-uniform
+  } else if (n64 == 0 || n64 > kMv5Cap) {
+    if (t == 0) blk[tile] = 0;
+    return;
+  }
+  const int n = (int)n64;
+  int N = 64;
+  while (N < n) N <<= 1;
+  for (int p = t; p < N; p += kBlock) {
+    int key = INT_MAX;
+    if (p < n) {
+      key = entries[a0 + p];
+      if (!FILL && p > 0) {                                      // a row must ascend strictly: an entry's place in its row is its rank in the union
+        bool start = false;
+        for (int q = 1; q < kMv5Rows; ++q) start |= (s_rm[q] - a0 == p);
+        if (!start && key <= entries[a0 + p - 1]) s_bad = 1;
+      }
+      if (!FILL && (key < 0 || key == INT_MAX)) s_bad = 1;
+    }
+    s_key[p] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1) {                             // bitonic sort of the tile's columns
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int p = t; p < N; p += kBlock) {
+        const int q = p ^ j;
+        if (q > p) {
+          const int x = s_key[p], y = s_key[q];
+          const bool up = (p & k) == 0;
+          if ((x > y) == up) { s_key[p] = y; s_key[q] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // the distinct columns, in order
+  int flag[PER], cnt = 0;
+  KK_UNROLL
+  for (int q = 0; q < PER; ++q) {
+    const int p = t * PER + q;
+    flag[q] = 0;
+    if (p < N) { const int key = s_key[p]; flag[q] = (key != INT_MAX && (p == 0 || key != s_key[p - 1])) ? 1 : 0; }
+    cnt += flag[q];
+  }
+  int nU = 0;
+  int at = block_exclusive_scan<int>(cnt, &nU, s_wave);
+  KK_UNROLL
+  for (int q = 0; q < PER; ++q) if (flag[q]) s_uni[at++] = s_key[t * PER + q];
+  const int nb = (nU + 3) / 4;
+  if (!FILL) {
+    __syncthreads();
+    if (t == 0) {
+      const bool on = !s_bad && (long long)n * 100 >= (long long)min_fill_pct * nb * 64;
+      blk[tile] = on ? nb : 0;
+      if (on) {
+        atomicAdd(&stats[0], (unsigned long long)nb); atomicAdd(&stats[1], (unsigned long long)n); atomicAdd(&stats[2], 1ull);
+        atomicAdd(&stats[3], (unsigned long long)(rowN - row0)); atomicMax(&stats[4], (unsigned long long)n);
+      }
+    }
+    return;
+  }
+  for (int q = t; q < 2 * nb; q += kBlock) s_mask[q] = 0u;
+  __syncthreads();
+  for (int p = t; p < n; p += kBlock) {
+    const int c = entries[a0 + p];
+    int i = 0;
+    for (int q = 1; q < kMv5Rows; ++q) i += (s_rm[q] - a0 <= p) ? 1 : 0;
+    int lo = 0, hi = nU;                                         // the column's place in the union
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_uni[mid] < c) lo = mid + 1; else hi = mid; }
+    const int bit = 4 * i + (lo & 3);
+    atomicOr(&s_mask[2 * (lo >> 2) + (bit >> 5)], 1u << (bit & 31));
+  }
+  __syncthreads();
+  for (int u = t; u < 4 * nb; u += kBlock) cols[4 * b0 + u] = u < nU ? s_uni[u] : -1;
+  for (int b = t; b < nb; b += kBlock) masks[b0 + b] = (unsigned long long)s_mask[2 * b] | ((unsigned long long)s_mask[2 * b + 1] << 32);
+}
+
+// rows of the tiles that are not described (any order)
+__global__ __launch_bounds__(kBlock) void mv5_other_kernel(int64_t nrows, const int64_t* __restrict__ blk_off, int32_t* __restrict__ list,
+                                                           unsigned long long* __restrict__ cursor) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= nrows) return;
+  const int64_t tile = r / kMv5Rows;
+  if (blk_off[tile + 1] == blk_off[tile]) list[atomicAdd(cursor, 1ull)] = (int32_t)r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool mv5_nonfinite(double v) {
+  return ((unsigned long long)__double_as_longlong(v) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+}
+
+// One wave per tile, four tiles per workgroup, no workgroup barrier.  ncv = valid right-hand sides of this block of 16 (the spare
+// lanes of a narrower block read its last column and store nothing).  SWAP: D^T = X^T A^T (column-major Y, see the file header).
+template <class OffT, class AT, int CAP, bool SWAP>
+__global__ __launch_bounds__(kBlock) void spmv_mv5_kernel(int64_t nrows, int64_t nnz, int64_t ntiles, const OffT* __restrict__ row_map,
+                                                          const int32_t* __restrict__ entries, const AT* __restrict__ values,
+                                                          const int64_t* __restrict__ blk_off, const int32_t* __restrict__ cols,
+                                                          const unsigned long long* __restrict__ masks, const double* __restrict__ X, int64_t xs0,
+                                                          int64_t xs1, double* __restrict__ Y, int64_t ys0, int64_t ys1, double alpha, double beta,
+                                                          int ncv, int remap) {
+  using AV = typename vec2<AT>::type;
+  __shared__ AT s_val_all[kBlock / kWave][CAP + 2];
+  const int lane = threadIdx.x & 63;
+  const int w = KK_UNIFORM((int)(threadIdx.x >> 6));
+  const int64_t tile = xcd_order(blockIdx.x, gridDim.x, remap) * (kBlock / kWave) + w;
+  if (tile >= ntiles) return;
+  const int64_t b0 = blk_off[tile], b1 = blk_off[tile + 1];
+  if (b0 == b1) return;                                          // not described: its rows are on the gather list
+  AT* s_val = s_val_all[w];
+  const int i = lane & 15, kq = lane >> 4;
+  const int64_t row0 = tile * kMv5Rows, rowN = (row0 + kMv5Rows < nrows) ? row0 + kMv5Rows : nrows;
+  const int64_t rs = (int64_t)row_map[(row0 + i < rowN) ? row0 + i : rowN];
+  const int64_t v0 = (int64_t)row_map[row0], v1 = (int64_t)row_map[rowN];
+  const int64_t a = v0 & ~(int64_t)1;                            // the value array is 16-byte aligned: pairs start at even entries
+  for (int64_t p = a + 2 * lane; p < v1; p += 2 * kWave) {
+    if (p + 1 < nnz) { const AV v = *reinterpret_cast<const AV*>(values + p); s_val[p - a] = v[0]; s_val[p - a + 1] = v[1]; }
+    else s_val[p - a] = values[p];
+  }
+  KK_WAVE_SYNC();
+  int cur = (int)(rs - a);                                       // where the next entry of the lane's row sits in the wave's LDS
+  const int jc = (i < ncv) ? i : ncv - 1;
+  const double* __restrict__ xcol = X + jc * xs1;
+  kk_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  bool bad = false;
+  for (int64_t b = b0; b < b1; b += 4) {
+    int c[4]; unsigned long long m[4]; double xv[4];
+    KK_UNROLL
+    for (int u = 0; u < 4; ++u) { const int64_t bb = (b + u < b1) ? b + u : b1 - 1; c[u] = cols[4 * bb + kq]; m[u] = masks[bb]; }
+    KK_UNROLL
+    for (int u = 0; u < 4; ++u) { xv[u] = 0.0; if (c[u] >= 0) xv[u] = xcol[(int64_t)c[u] * xs0]; }
+    KK_UNROLL
+    for (int u = 0; u < 4; ++u) {
+      if (b + u < b1) {                                          // wave-uniform
+        const unsigned nib = (unsigned)(m[u] >> (4 * i)) & 15u;
+        double av = 0.0;
+        if ((nib >> kq) & 1u) av = (double)s_val[cur + __popc(nib & ((1u << kq) - 1u))];
+        cur += __popc(nib);
+        bad |= mv5_nonfinite(xv[u]);
+        if (SWAP) acc = KK_MFMA_F64_16X16X4(xv[u], av, acc);
+        else      acc = KK_MFMA_F64_16X16X4(av, xv[u], acc);
+      }
+    }
+  }
+  // accumulator register r of lane (i, kq): row 4 r + kq, column i -- SWAP: row i, column 4 r + kq
+  if (__ballot(bad) != 0ull) {
+    // an Inf / NaN among the tile's X values: absent entries met it as 0 * Inf.  The reference's products, entry by entry:
+    KK_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + (SWAP ? i : 4 * r + kq);
+      const int col = SWAP ? 4 * r + kq : i;
+      const double* xc = X + (int64_t)(col < ncv ? col : ncv - 1) * xs1;
+      double s = 0.0;
+      if (row < nrows)
+        for (int64_t p = (int64_t)row_map[row]; p < (int64_t)row_map[row + 1]; ++p) s += (double)values[p] * xc[(int64_t)entries[p] * xs0];
+      acc[r] = s;
+    }
+  }
+  KK_UNROLL
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = row0 + (SWAP ? i : 4 * r + kq);
+    const int col = SWAP ? 4 * r + kq : i;
+    if (row < nrows && col < ncv) {
+      double* yp = Y + row * ys0 + col * ys1;
+      const double out = alpha * acc[r];
+      *yp = (beta == 0.0) ? out : beta * (*yp) + out;
+    }
+  }
+}
+
+// rows of the tiles that are not described: 16 lanes per row (one right-hand side each).  The lanes fetch 16 entries of the row at a
+// time (one each), then every lane walks all 16; a product is only added where the row has an entry
+template <class OffT, class AT>
+__global__ __launch_bounds__(kBlock) void mv5_rows_kernel(int64_t n_list, const int32_t* __restrict__ list, const OffT* __restrict__ row_map,
+                                                          const int32_t* __restrict__ entries, const AT* __restrict__ values,
+                                                          const double* __restrict__ X, int64_t xs0, int64_t xs1, double* __restrict__ Y,
+                                                          int64_t ys0, int64_t ys1, double alpha, double beta, int ncv) {
+  int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
+  const int j  = threadIdx.x & 15;
+  const int jc = j < ncv ? j : ncv - 1;
+  const bool live = idx < n_list;                                // no early return: the shuffles below want whole waves
+  if (!live) idx = n_list - 1;
+  const int64_t r = list[idx];
+  const int64_t b = (int64_t)row_map[r], e = (int64_t)row_map[r + 1];
+  // the longest row of the wave decides the trip count (the shuffles are wave-wide rendezvous under the emulator)
+  int64_t len = e - b;
+  for (int o = 16; o < 64; o <<= 1) { const long long other = __shfl_xor((long long)len, o, 64); len = other > len ? other : len; }
+  double acc = 0.0;
+  for (int64_t a = b; a < b + len; a += 16) {
+    const bool in = a + j < e;
+    const int32_t my_col = in ? entries[a + j] : 0;
+    const double my_val  = in ? (double)values[a + j] : 0.0;
+    KK_UNROLL
+    for (int q = 0; q < 16; ++q) {
+      const int32_t col = __shfl(my_col, q, 16);
+      const double v    = __shfl(my_val, q, 16);
+      if (a + q < e) acc += v * X[(int64_t)col * xs0 + jc * xs1];
+    }
+  }
+  if (!live || j >= ncv) return;
+  double* yp = Y + r * ys0 + j * ys1;
+  *yp = (beta == 0.0) ? alpha * acc : beta * (*yp) + alpha * acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+template <class OffT>
+static int mv5_plan_build_t(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st) {
+  plan->mv5_tried = true;
+  if (A->num_rows < kMv5Rows || A->nnz == 0 || A->num_rows > (int64_t)INT_MAX) return KKAMD_OK;
+  const int mode = plan->tune.mv5;
+  const int64_t ntiles = ceil_div(A->num_rows, kMv5Rows);
+  if (ntiles > (int64_t)INT_MAX) return KKAMD_OK;
+  kkamd_mv5_plan* p = new (std::nothrow) kkamd_mv5_plan();
+  if (!p) return fail(KKAMD_ERR_ALLOC, "kkamd_spmv_mv: out of host memory");
+  struct Guard { kkamd_mv5_plan* p; ~Guard() { if (p) mv5_plan_destroy(p); } } guard{p};
+  p->ntiles = ntiles;
+  DevBuf stats;
+  if (hipMalloc((void**)&p->d_blk_off, sizeof(int64_t) * (size_t)(ntiles + 1)) != hipSuccess || stats.alloc(8 * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError();
+    return KKAMD_OK;                                             // no memory for the analysis: the gather kernel serves the matrix
+  }
+  unsigned long long* d_stats = stats.as<unsigned long long>();
+  KK_HIP(hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long), st));
+  KK_HIP(hipMemsetAsync(p->d_blk_off + ntiles, 0, sizeof(int64_t), st));
+  const int min_fill = mode == 2 ? 0 : plan->tune.mv5_min_fill_pct;
+  KK_LAUNCH((mv5_tile_kernel<OffT, false>), (unsigned)ntiles, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries,
+            min_fill, p->d_blk_off, (int32_t*)nullptr, (unsigned long long*)nullptr, d_stats);
+  KK_LAUNCH_CHECK();
+  int rc = exclusive_scan_inplace<int64_t>(p->d_blk_off, ntiles + 1, st);
+  if (rc) return rc;
+  unsigned long long h[8];
+  KK_HIP(hipMemcpyAsync(h, d_stats, sizeof h, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  p->nblocks = (int64_t)h[0]; p->nnz_on = (int64_t)h[1]; p->tiles_on = (int64_t)h[2]; p->rows_on = (int64_t)h[3];
+  p->n_other = A->num_rows - p->rows_on;
+  if (g_verbose)
+    printf("kkamd_spmv_mv: matrix-core analysis: %lld of %lld tiles described, %lld column blocks, fill %.3f, %lld rows left to the gather rows\n",
+           (long long)p->tiles_on, (long long)ntiles, (long long)p->nblocks, p->nblocks ? (double)p->nnz_on / (64.0 * (double)p->nblocks) : 0.0,
+           (long long)p->n_other);
+  if (p->tiles_on == 0) return KKAMD_OK;
+  if (mode != 2 && p->n_other * 100 > (int64_t)plan->tune.mv5_max_other_pct * A->num_rows) return KKAMD_OK;
+  p->cap = h[4] <= 512 ? 512 : (h[4] <= 1024 ? 1024 : kMv5Cap);
+  if (hipMalloc((void**)&p->d_cols, sizeof(int32_t) * 4 * (size_t)p->nblocks) != hipSuccess ||
+      hipMalloc((void**)&p->d_masks, sizeof(unsigned long long) * (size_t)p->nblocks) != hipSuccess ||
+      (p->n_other > 0 && hipMalloc((void**)&p->d_other, sizeof(int32_t) * (size_t)p->n_other) != hipSuccess)) {
+    (void)hipGetLastError();
+    return KKAMD_OK;
+  }
+  KK_LAUNCH((mv5_tile_kernel<OffT, true>), (unsigned)ntiles, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries,
+            min_fill, p->d_blk_off, p->d_cols, p->d_masks, d_stats);
+  KK_LAUNCH_CHECK();
+  if (p->n_other > 0) {
+    KK_HIP(hipMemsetAsync(d_stats, 0, sizeof(unsigned long long), st));
+    KK_LAUNCH((mv5_other_kernel), (unsigned)ceil_div(A->num_rows, kBlock), kBlock, 0, st, A->num_rows, (const int64_t*)p->d_blk_off, p->d_other, d_stats);
+    KK_LAUNCH_CHECK();
+  }
+  KK_HIP(hipStreamSynchronize(st));
+  p->bytes = sizeof(int64_t) * (size_t)(ntiles + 1) + 24 * (size_t)p->nblocks + sizeof(int32_t) * (size_t)p->n_other;
+  plan->mv5 = p;
+  guard.p = nullptr;
+  return KKAMD_OK;
+}
+
+int mv5_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st) {
+  return A->offset_type == KKAMD_I64 ? mv5_plan_build_t<int64_t>(plan, A, st) : mv5_plan_build_t<int32_t>(plan, A, st);
+}
+
+template <class OffT, class AT>
+static int mv5_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+                      int64_t nvec, double alpha, double beta, hipStream_t st) {
+  const kkamd_mv5_plan* p = plan->mv5;
+  const unsigned grid = (unsigned)ceil_div(p->ntiles, kBlock / kWave);
+  const bool swap = ys0 < ys1;                                   // column-major Y
+  const int remap = plan->tune.mv_remap;
+  for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
+    const int ncv = (int)(nvec - c0 < 16 ? nvec - c0 : 16);
+    const double* Xb = X + c0 * xs1;
+    double* Yb = Y + c0 * ys1;
+#define KK_MV5(CAP, SW)                                                                                                             \
+    KK_LAUNCH((spmv_mv5_kernel<OffT, AT, CAP, SW>), grid, kBlock, 0, st, A->num_rows, A->nnz, p->ntiles, (const OffT*)A->d_row_map,   \
+              (const int32_t*)A->d_entries, (const AT*)A->d_values, (const int64_t*)p->d_blk_off, (const int32_t*)p->d_cols,          \
+              (const unsigned long long*)p->d_masks, Xb, xs0, xs1, Yb, ys0, ys1, alpha, beta, ncv, remap)
+    if (p->cap == 512)       { if (swap) KK_MV5(512, true);  else KK_MV5(512, false); }
+    else if (p->cap == 1024) { if (swap) KK_MV5(1024, true); else KK_MV5(1024, false); }
+    else                     { if (swap) KK_MV5(2048, true); else KK_MV5(2048, false); }
+#undef KK_MV5
+    KK_LAUNCH_CHECK();
+    if (p->n_other > 0) {
+      KK_LAUNCH((mv5_rows_kernel<OffT, AT>), (unsigned)ceil_div(p->n_other * 16, kBlock), kBlock, 0, st, p->n_other, (const int32_t*)p->d_other,
+                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xb, xs0, xs1, Yb, ys0, ys1, alpha, beta, ncv);
+      KK_LAUNCH_CHECK();
+    }
+  }
+  return KKAMD_OK;
+}
+
+int mv5_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+             int64_t nvec, double alpha, double beta, hipStream_t st) {
+  const bool o64 = A->offset_type == KKAMD_I64;
+  if (A->value_type == KKAMD_F64)
+    return o64 ? mv5_launch<int64_t, double>(plan, A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, st)
+               : mv5_launch<int32_t, double>(plan, A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, st);
+  return o64 ? mv5_launch<int64_t, float>(plan, A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, st)
+             : mv5_launch<int32_t, float>(plan, A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, st);
+}
+
+}  // namespace kk

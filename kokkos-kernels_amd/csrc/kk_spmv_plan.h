@@ -39,6 +39,10 @@ struct SpmvTuning {
   int mv4_xcol       = 1;  // rank-2 plane-marching kernel, column-major X: 1 = pieces dealt out column-wise + swizzled slab rows (whole cache lines per load), 0 = as for general strides
   int mv4_2d         = 1;  // rank-2 plane-marching kernel on 2-D lattices (lines grouped into planes): 1 on, 0 off
   int mv4_wg_per_cu  = 8;  // rank-2 plane-marching kernel: workgroups per CU the k-chunking aims for (one is resident at a time)
+  int mv5            = 1;  // rank-2 matrix-core kernel (kk_spmv_mvblk.hip: 16-row tiles whose rows share columns, v_mfma_f64_16x16x4): 1 = when the
+                           // analysis finds the tiles dense enough, 2 = whenever a tile can be described (tests), 0 = never
+  int mv5_min_fill_pct = 25;  // ... a tile takes the matrix core when at least this share of its 16 x 4 operand slots holds an entry
+  int mv5_max_other_pct = 50; // ... and the kernel is used when at most this share of the rows is left to the gather rows
   int march          = 0;  // rank 1 on the plane-marching analysis (lattice stencils, fp64 vectors): 0 off, 1 on
   int march_planes   = 20; // ... planes a workgroup marches (its k-chunk)
   int explicit_transpose = 1;   // modes T/H with an analysed handle: 1 = cache A^T in the plan (when it fits an eighth of free HBM), move the
@@ -77,6 +81,7 @@ constexpr int kTilePlain = 0, kTileCodes = 1, kTileStaged = 2, kTilePattern = 3;
 struct kkamd_mv_plan;   // kk_spmv_mv.hip
 struct kkamd_mv4_plan;  // kk_spmv_mv.hip
 struct kkamd_cs_plan;   // kk_spmv_colslab.hip
+struct kkamd_mv5_plan;  // kk_spmv_mvblk.hip
 
 struct kkamd_spmv_plan {
   int64_t num_rows = 0, num_cols = 0, nnz = 0;
@@ -117,6 +122,9 @@ struct kkamd_spmv_plan {
   // rank-2 analysis of the plane-marching kernel (lattice strides, per-row conformity), built by the first call that asks for it
   kkamd_mv4_plan* mv4 = nullptr;
   bool mv4_tried = false;
+  // rank-2 matrix-core kernel: per 16-row tile the union of its columns in blocks of four and a 64-bit occupancy mask per block
+  kkamd_mv5_plan* mv5 = nullptr;
+  bool mv5_tried = false;
   // rank-2 wave-private kernel: its row blocks in strip order (see mv_build_strip_order)
   int32_t* d_mv2_order = nullptr;
   // rank 2, gather kernel: rows longer than mv_long_T entries are left out of the wave-per-16-rows walk (one row group of a wave
@@ -143,6 +151,12 @@ void mv_plan_destroy(kkamd_mv_plan* mv);
 int64_t mv_plan_query(const kkamd_mv_plan* mv, int what);   // 0 tiles, 1 pattern tiles, 2 order in use, 3 bytes
 void mv4_plan_destroy(kkamd_mv4_plan* p);
 int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what);  // 0 workgroups, 1 rows outside the stencil, 2 stencil entries, 3 bytes, 4 near stride
+void mv5_plan_destroy(kkamd_mv5_plan* p);
+int64_t mv5_plan_query(const kkamd_mv5_plan* p, int what);  // 0 tiles on the matrix core, 1 rows left to the gather rows, 2 column blocks, 3 bytes, 4 fill in 1/1000
+// builds the analysis on first use (plan->mv5 stays null when the matrix does not qualify); then one pass per 16 right-hand sides
+int  mv5_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st);
+int  mv5_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+              int64_t nvec, double alpha, double beta, hipStream_t st);
 void cs_plan_destroy(kkamd_cs_plan* cs);
 int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes
 int  cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st);

@@ -191,6 +191,27 @@ template <class T> inline T exchange(T v, int src_lane_in_wave) {
   return out;
 }
 inline int lane() { return (int)(S().cur % KK_EMU_WAVE); }
+// v_mfma_f64_16x16x4f64 with the operand layout of gfx950: lane l holds A[l % 16][l / 16] and B[l / 16][l % 16]; register r of the
+// accumulator of lane l is D[4 r + l / 16][l % 16].  All 64 lanes of the wave must take part (as on the hardware).
+typedef double f64x4 __attribute__((vector_size(32)));
+inline f64x4 mfma_f64_16x16x4(double a, double b, f64x4 c) {
+  State& s = S(); unsigned me = s.cur, w = me / KK_EMU_WAVE; const int l = (int)(me % KK_EMU_WAVE);
+  double ab[2] = {a, b};
+  std::memcpy(&s.slots[(size_t)me * 16], ab, 16);
+  sync_wave();
+  const int j = l % 16, g = l / 16;
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + g;
+    for (int k = 0; k < 4; ++k) {
+      double av[2], bv[2];
+      std::memcpy(av, &s.slots[(size_t)(w * KK_EMU_WAVE + i + 16 * k) * 16], 16);
+      std::memcpy(bv, &s.slots[(size_t)(w * KK_EMU_WAVE + j + 16 * k) * 16], 16);
+      c[r] += av[0] * bv[1];
+    }
+  }
+  sync_wave();
+  return c;
+}
 inline int quad_perm(int v, int ctrl) { int l = lane(); return exchange(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3)); }
 }  // namespace kk_emu
 

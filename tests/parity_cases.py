@@ -106,6 +106,37 @@ def check_spmv_mv(be, A0, nvec, mode="N", alpha=1.0, beta=0.0, x_order="F", y_or
     return h
 
 
+def check_mv5(be, light=False):
+    combos = ((16, "C", "C", 1.5, 0.5, np.int32), (16, "F", "F", 1.0, 0.0, np.int64), (5, "C", "F", 2.0, 0.0, np.int32), (37, "F", "C", -1.0, 1.0, np.int32),
+              (32, "C", "C", 1.0, 0.0, np.int32))
+    for ci, (name, A0, tiles, other) in enumerate(mv5_cases()):
+        for nvec, xo, yo, alpha, beta, off in (combos if (ci < 3 or not light) else combos[:2]):
+            h = check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=1.5, nans=(beta == 0.0), offset_dtype=off)
+            got = h.query("mv5_tiles")
+            assert (got > 0) if tiles is None else (got == tiles), (name, nvec, got, tiles)
+            if other is not None and got > 0:
+                assert h.query("mv5_other_rows") == other, (name, h.query("mv5_other_rows"))
+    name, A0, _, _ = mv5_cases()[0]
+    h = check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", max_val=1.5, value_dtype=np.float32)
+    assert h.query("mv5_tiles") > 0 and h.query("mv5_fill_permille") == 1000
+    # Inf / NaN in X: the rows that hold the column get it, the other rows of the tile do not (block 0: rows 0..31 hold column 3;
+    # the band matrix: rows 90..110 hold column 100)
+    for yo in ("C", "F"):
+        h = check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", yo, algo="SPMV_DEFAULT", max_val=1.5, nans=True, x_special={3: np.inf, 40: np.nan, 1279: -np.inf})
+        assert h.query("mv5_tiles") > 0
+        h = check_spmv_mv(be, mv5_cases()[3][1], 7, "N", 1.0, 0.0, "F", yo, algo="SPMV_DEFAULT", max_val=1.5, nans=True, x_special={100: np.inf, 499: np.nan})
+        assert h.query("mv5_tiles") > 0
+    # forced (mv5 = 2: no fill threshold) on matrices it would not take, off (mv5 = 0), the gather kernel asked for, no analysis
+    sparse = oracle.random_crs(800, 800, 9, variance=3, seed=5, sorted_rows=True)
+    h = check_spmv_mv(be, sparse, 16, "N", 1.5, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=1.5, nans=True, knobs={"mv5": 2})
+    assert h.query("mv5_tiles") > 10 and h.query("mv5_fill_permille") < 100, (h.query("mv5_tiles"), h.query("mv5_fill_permille"))
+    h = check_spmv_mv(be, oracle.laplace2d("FE", 130, 41), 21, "N", 1.0, 1.0, "F", "F", algo="SPMV_DEFAULT", max_val=32.0, knobs={"mv5": 2})
+    assert h.query("mv5_tiles") > 0
+    for algo, knobs in (("SPMV_DEFAULT", {"mv5": 0}), ("SPMV_DEFAULT", {"mv_kernel": 2}), ("SPMV_FAST_SETUP", None)):
+        h = check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo=algo, knobs=knobs, max_val=1.5)
+        assert h.query("mv5_tiles") == 0
+
+
 def _to_dev_2d(be, M):
     """device 2-D array with the same logical layout (Fortran order kept through a transposed view)"""
     if be.name == "emu":
@@ -388,6 +419,71 @@ def mv4_duplicate_cases():
     some = np.arange(7, base.nrows, 83)
     return [("7pt, diagonal stored twice in every row", dup_diag(np.arange(base.nrows)), False, 0),
             ("7pt, diagonal stored twice in %d rows" % some.size, dup_diag(some), True, int(some.size))]
+
+
+def _from_dense_mask(mask, seed, ncols=None):
+    """CRS matrix with an entry wherever mask is set (rows ascending), random values in [0.5, 1.5)"""
+    n = mask.shape[0]
+    rows, cols = np.nonzero(mask)
+    rm = np.zeros(n + 1, dtype=np.int64); np.add.at(rm, rows + 1, 1); rm = np.cumsum(rm)
+    return oracle.Crs(n, ncols or mask.shape[1], rm, cols.astype(np.int32), np.random.default_rng(seed).random(rows.size) + 0.5)
+
+
+def block_diagonal(nblocks, bs, seed=0):
+    n = nblocks * bs
+    rm = np.arange(n + 1, dtype=np.int64) * bs
+    ent = (np.repeat(np.arange(nblocks), bs * bs) * bs + np.tile(np.arange(bs), n)).astype(np.int32)
+    return oracle.Crs(n, n, rm, ent, np.random.default_rng(seed).random(n * bs) + 0.5)
+
+
+def multi_dof(A0, ndof, seed=0):
+    """every entry of A0 becomes a dense ndof x ndof block (a vector-valued finite-element matrix on A0's mesh)"""
+    n = A0.nrows
+    lens = np.diff(A0.row_map)
+    rm = np.zeros(n * ndof + 1, dtype=np.int64)
+    rm[1:] = np.cumsum(np.repeat(lens * ndof, ndof))
+    ent = np.empty(int(rm[-1]), dtype=np.int32)
+    for r in range(n):
+        c = (A0.entries[A0.row_map[r]:A0.row_map[r + 1]].astype(np.int64)[:, None] * ndof + np.arange(ndof)[None, :]).reshape(-1)
+        for d in range(ndof):
+            ent[rm[r * ndof + d]:rm[r * ndof + d + 1]] = c
+    return oracle.Crs(n * ndof, A0.ncols * ndof, rm, ent, np.random.default_rng(seed).random(ent.size) + 0.5)
+
+
+def mv5_cases():
+    """(name, matrix, 16-row tiles the matrix-core rank-2 kernel must describe: None = some, 0 = the kernel must not engage, rows
+    it must leave to its gather rows: None = any) under the default thresholds"""
+    out = [("block diagonal 32x32", block_diagonal(40, 32, 1), 80, 0),
+           ("block diagonal 5x5, 403 rows", _crop_rows(block_diagonal(81, 5, 2), 403), 25, 3),
+           ("3 dof on 27-pt 6x5x4", multi_dof(oracle.laplace3d("FE", 6, 5, 4), 3, 3), None, None)]
+    n = 500                                                                      # a dense band of 21 diagonals
+    ii = np.arange(n)
+    out.append(("band of 21 diagonals", _from_dense_mask(np.abs(ii[:, None] - ii[None, :]) <= 10, 4), 31, 4))
+    # described tiles first, then rows with columns all over a wide matrix (their tiles fall below the fill threshold)
+    top = block_diagonal(20, 16, 5)
+    wide = oracle.random_crs(160, 200000, 12, variance=0, seed=6, sorted_rows=True)
+    rm = np.concatenate([top.row_map, wide.row_map[1:] + top.row_map[-1]])
+    out.append(("blocks then scattered rows", oracle.Crs(480, 200000, rm, np.concatenate([top.entries, wide.entries]), np.concatenate([top.values, wide.values])), 20, 160))
+    # tiles the plan cannot describe between tiles it can: a row that descends, a column stored twice, a tile of more than 2048
+    # entries, a tile without entries; and a described tile with empty rows inside
+    B = block_diagonal(12, 16, 7)
+    rm = B.row_map.copy(); ent = B.entries.copy(); val = B.values.copy()
+    ent[rm[17]:rm[18]] = ent[rm[17]:rm[18]][::-1]                                 # tile 1: row 17 descends
+    ent[rm[35] + 3] = ent[rm[35] + 2]                                             # tile 2: row 35 stores a column twice
+    keep = np.ones(ent.size, bool); keep[rm[48]:rm[64]] = False                   # tile 3: no entries at all
+    keep[rm[83]:rm[85]] = False                                                   # tile 5: two empty rows inside a described tile
+    lens = np.diff(rm); lens[48:64] = 0; lens[83:85] = 0
+    rm2 = np.zeros(B.nrows + 1, np.int64); rm2[1:] = np.cumsum(lens)
+    out.append(("tiles that cannot be described", oracle.Crs(B.nrows, B.ncols, rm2, ent[keep], val[keep]), 9, 48))
+    big = _from_dense_mask(np.ones((32, 150), bool), 8)                           # 16 x 150 = 2400 entries per tile
+    out.append(("tiles above 2048 entries", big, 0, None))
+    out.append(("uniform random", oracle.random_crs(800, 800, 9, variance=3, seed=5), 0, None))
+    return out
+
+
+def _crop_rows(A0, n):
+    e = int(A0.row_map[n])
+    return oracle.Crs(n, A0.ncols, A0.row_map[:n + 1].copy(), A0.entries[:e].copy(), A0.values[:e].copy())
 
 
 def mv3_cases():

@@ -199,17 +199,23 @@ def test_row_partitioned_spgemm_slabs():
     _check_spgemm_slabs(emu_backend.backend(), kk, oracle, oracle.rmat(9, 8), 4)
 
 
-def test_bench_two_process_flow_emulated():
-    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with
+@pytest.mark.parametrize("launcher", ["torchrun", "plain"])
+def test_bench_two_process_flow_emulated(launcher):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank) and started plainly
+    (`python bench.py --gpus 2`: no WORLD_SIZE in the environment, bench.py launches its own ranks), with
     --emulate: gloo instead of RCCL and the kernels under the SIMT emulator.  Checks the whole multi-process control
     flow -- slab generation, halo plan, interior/boundary overlap, barriers, max-over-ranks timing, the A*1 self-check,
     the single JSON line from rank 0 -- without a GPU."""
     import json
     import subprocess
     port = 29900 + (os.getpid() % 500)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--emulate", "--grid-edge", "32"]
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--emulate", "--grid-edge", "32"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]

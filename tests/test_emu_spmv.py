@@ -200,6 +200,13 @@ def test_mv4_plane_marching(be):
         assert h.query("mv4_workgroups") == 0
 
 
+def test_mv5_matrix_core(be):
+    # rank-2 matrix-core kernel (kk_spmv_mvblk.hip: 16-row tiles, union of columns in blocks of four, one v_mfma_f64_16x16x4 per block):
+    # described tiles and the rows left to its gather rows, every width, the four layout pairs (column-major Y swaps the operands),
+    # beta = 0 over NaNs, 64-bit offsets, fp32 values, Inf / NaN in X (a tile that sees one recomputes entry by entry)
+    pc.check_mv5(be, light=True)
+
+
 def test_mv_long_rows(be):
     # rank 2 on a matrix with a few very long rows (R-MAT-like hubs): the wave-private gather kernel leaves rows above 32 x the average
     # length (at least 1024 entries) to spmv_mv_long_kernel (a workgroup per row); every width, both layouts, beta 0 over NaNs and != 0

@@ -228,6 +228,13 @@ def test_mv4_plane_marching(be):
         assert h.query("mv4_workgroups") == 0
 
 
+def test_mv5_matrix_core(be):
+    # rank-2 matrix-core kernel (v_mfma_f64_16x16x4 over 16-row tiles whose rows share columns, kk_spmv_mvblk.hip): every case of
+    # pc.mv5_cases() x widths 16 / 5 / 37 / 32 x the four layout pairs, described tiles and gather rows as expected, Inf / NaN in X,
+    # fp32 values, 64-bit offsets, forced on sparse matrices, off
+    pc.check_mv5(be, light=False)
+
+
 def test_mv_long_rows(be):
     # rank 2 on a matrix with a few very long rows (R-MAT-like hubs): the wave-private gather kernel leaves rows above 32 x the average
     # length (at least 1024 entries) to spmv_mv_long_kernel (a workgroup per row); every width, both layouts, beta 0 over NaNs and != 0
