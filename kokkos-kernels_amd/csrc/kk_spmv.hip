@@ -1087,7 +1087,7 @@ int check_crs(const kkamd_crs_t* A) {
 int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   if (!p) return KKAMD_OK;
   if (p->num_rows != A->num_rows || p->num_cols != A->num_cols || p->nnz != A->nnz || p->row_map != A->d_row_map ||
-      p->offset_type != A->offset_type || p->value_type != A->value_type || ((p->d_tinfo || p->mv || p->mv4 || p->mv5 || p->t_ready || p->cs) && p->entries != A->d_entries))
+      p->offset_type != A->offset_type || p->value_type != A->value_type || ((p->d_tinfo || p->mv || p->mv4 || p->mv5 || p->mv6 || p->t_ready || p->cs) && p->entries != A->d_entries))
     return fail(KKAMD_ERR_STATE, "kkamd_spmv: plan was created for a different matrix (a handle is bound to one matrix)");
   return KKAMD_OK;
 }
@@ -1117,7 +1117,9 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "lanes_per_row") { if (value < 0 || value > 64) return bad("in 0..64"); t.lanes_per_row = value; }
   else if (k == "nnz_per_thread") { if (value != 0 && value != 4 && value != 8 && value != 16) return bad("0, 4, 8 or 16"); t.nnz_per_thread = value; }
   else if (k == "xcd_remap") { if (!valid_order_knob(value)) return bad("0, 1 or a power of two"); t.xcd_remap = value; }
-  else if (k == "mv_kernel") { if (value < 0 || value > 5) return bad("in 0..5"); t.mv_kernel = value; }
+  else if (k == "mv_kernel") { if (value < 0 || value > 6) return bad("in 0..6"); t.mv_kernel = value; }
+  else if (k == "mv6") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv6 = value; }
+  else if (k == "mv6_min_long_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.mv6_min_long_pct = value; }
   else if (k == "mv5") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv5 = value; }
   else if (k == "mv5_min_fill_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.mv5_min_fill_pct = value; }
   else if (k == "mv5_max_other_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.mv5_max_other_pct = value; }
@@ -1433,6 +1435,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->mv) kk::mv_plan_destroy(plan->mv);
   if (plan->mv4) kk::mv4_plan_destroy(plan->mv4);
   if (plan->mv5) kk::mv5_plan_destroy(plan->mv5);
+  if (plan->mv6) kk::mv6_plan_destroy(plan->mv6);
   if (plan->cs) kk::cs_plan_destroy(plan->cs);
   if (plan->d_t_rm) (void)hipFree(plan->d_t_rm);
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
@@ -1480,10 +1483,14 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
     kk::mv5_plan_destroy(plan->mv5); plan->mv5 = nullptr; plan->mv5_tried = false;
   }
+  if ((t.mv6 != old.mv6) && (plan->mv6 || plan->mv6_tried) && t.mv6 == 0) {
+    if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
+    kk::mv6_plan_destroy(plan->mv6); plan->mv6 = nullptr; plan->mv6_tried = false;
+  }
   if (t.mv_long_T != old.mv_long_T && plan->mv_long_known) {          // the list of long rows was made for the old threshold
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
     if (plan->d_mv_long) { KK_HIP(hipFree(plan->d_mv_long)); plan->d_mv_long = nullptr; }
-    plan->mv_long_known = false; plan->n_mv_long = 0; plan->mv_long_T = 0;
+    plan->mv_long_known = false; plan->n_mv_long = 0; plan->mv_long_T = 0; plan->mv_long_nnz = 0;
   }
   return KKAMD_OK;
 }
@@ -1506,11 +1513,14 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "mv_long_rows") *value = plan->n_mv_long;
   else if (k == "mv_order") *value = plan->mv ? kk::mv_plan_query(plan->mv, 2) : (plan->d_mv2_order ? 2 : 0);
   else if (k == "mv_period") *value = plan->mv_period;
-  else if (k == "mv_plan_bytes") *value = kk::mv_plan_query(plan->mv, 3) + kk::mv4_plan_query(plan->mv4, 3) + kk::mv5_plan_query(plan->mv5, 3);
+  else if (k == "mv_plan_bytes") *value = kk::mv_plan_query(plan->mv, 3) + kk::mv4_plan_query(plan->mv4, 3) + kk::mv5_plan_query(plan->mv5, 3) + kk::mv6_plan_query(plan->mv6, 2);
   else if (k == "mv4_workgroups") *value = kk::mv4_plan_query(plan->mv4, 0);
   else if (k == "mv4_other_rows") *value = kk::mv4_plan_query(plan->mv4, 1);
   else if (k == "mv4_stencil") *value = kk::mv4_plan_query(plan->mv4, 2);
   else if (k == "mv4_near_stride") *value = kk::mv4_plan_query(plan->mv4, 4);
+  else if (k == "mv6_chunks") *value = kk::mv6_plan_query(plan->mv6, 0);
+  else if (k == "mv6_empty_rows") *value = kk::mv6_plan_query(plan->mv6, 1);
+  else if (k == "mv_long_nnz") *value = plan->mv_long_nnz;
   else if (k == "mv5_tiles") *value = kk::mv5_plan_query(plan->mv5, 0);
   else if (k == "mv5_other_rows") *value = kk::mv5_plan_query(plan->mv5, 1);
   else if (k == "mv5_blocks") *value = kk::mv5_plan_query(plan->mv5, 2);

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(kBlock) void mv_long_list_kernel(int64_t nrows, con
   if (r < nrows && (int64_t)row_map[r + 1] - (int64_t)row_map[r] > T) {
     const unsigned long long at = atomicAdd(count, 1ull);
     if (list) list[at] = (int32_t)r;
+    else atomicAdd(count + 1, (unsigned long long)((int64_t)row_map[r + 1] - (int64_t)row_map[r]));   // counting pass: their entries too
   }
 }
 // Y(row, :) += alpha * A(row, :) X for the listed rows (the gather kernel left beta * Y there): one workgroup per row and strip of
@@ -1537,19 +1538,21 @@ int march_spmv(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* x, dou
 // the rows the wave-per-16-rows gather kernel leaves to spmv_mv_long_kernel: found once per plan
 template <class OffT>
 static int mv_find_long_rows(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st) {
-  plan->mv_long_known = true; plan->n_mv_long = 0; plan->mv_long_T = 0;
+  plan->mv_long_known = true; plan->n_mv_long = 0; plan->mv_long_T = 0; plan->mv_long_nnz = 0;
   if (A->num_rows == 0 || A->nnz == 0) return KKAMD_OK;
   int64_t T = plan->tune.mv_long_T;
   if (T <= 0) { T = 4 * (A->nnz / A->num_rows); if (T < 64) T = 64; }     // R-MAT scale 22 x 16: 37.7 ms without, 9.5 at 1024, 4.8 at 256, 3.0-3.1 at 64-128
   DevBuf cnt;
-  KK_HIP(cnt.alloc(sizeof(unsigned long long)));
+  KK_HIP(cnt.alloc(2 * sizeof(unsigned long long)));
   unsigned long long* d_cnt = cnt.as<unsigned long long>();
-  KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+  KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
   const unsigned grid = (unsigned)ceil_div(A->num_rows, kBlock);
   KK_LAUNCH((mv_long_list_kernel<OffT>), grid, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, T, (int32_t*)nullptr, d_cnt);
-  unsigned long long h_n = 0;
-  KK_HIP(hipMemcpyAsync(&h_n, d_cnt, sizeof h_n, hipMemcpyDeviceToHost, st));
+  unsigned long long h_c[2] = {0, 0};
+  KK_HIP(hipMemcpyAsync(h_c, d_cnt, sizeof h_c, hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
+  const unsigned long long h_n = h_c[0];
+  plan->mv_long_nnz = (int64_t)h_c[1];
   if (h_n == 0) return KKAMD_OK;
   KK_HIP(hipMalloc((void**)&plan->d_mv_long, sizeof(int32_t) * (size_t)h_n));
   KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
@@ -1651,6 +1654,15 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
       if (plan && plan->row_map == A->d_row_map) {
         if (!plan->mv_long_known) { const int rc = mv_find_long_rows<OffT>(plan, A, st); if (rc) return rc; }
         long_T = plan->n_mv_long > 0 ? plan->mv_long_T : 0;
+      }
+      // nonzero-split kernel (mv_kernel 0 = auto, or 6; kk_spmv_mvnnz.hip): analysed handles, fp64 vectors; by default on matrices with a
+      // share of their nonzeros in long rows (power-law graphs), where a row-based assignment leaves most lanes idle
+      if constexpr (sizeof(YT) == 8) {
+        if (plan && plan->tile != 0 && plan->tune.mv6 != 0 && (mvk == 0 || mvk == 6) && plan->entries == A->d_entries && plan->row_map == A->d_row_map &&
+            (plan->tune.mv6 == 2 || plan->mv_long_nnz * 100 >= (int64_t)plan->tune.mv6_min_long_pct * A->nnz)) {
+          if (!plan->mv6 && !plan->mv6_tried) { const int rc = mv6_plan_build(plan, A, st); if (rc) return rc; }
+          if (plan->mv6) return mv6_spmv(plan, A, (const double*)Xr, ldx, 1, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
+        }
       }
       // rows above long_T entries, after the gather kernel has written beta * Y there (called by the launch macro below)
       auto long_rows = [&]() -> int {

@@ -30,13 +30,14 @@
 #include <climits>
 
 namespace kk {
+typedef int kk_i32x4v __attribute__((vector_size(16)));
 constexpr int kMv5Rows = 16;     // rows per tile
 constexpr int kMv5Cap  = 2048;   // entries of a described tile (16 KB of values per wave at most)
 }  // namespace kk
 
 struct kkamd_mv5_plan {
   int64_t ntiles = 0, tiles_on = 0, nblocks = 0, n_other = 0, nnz_on = 0, rows_on = 0;
-  int cap = 0;                                   // LDS values per wave of the kernel instantiation (512 / 1024 / 2048)
+  int cap = 0;                                   // LDS values per wave (the largest described tile, rounded up)
   int64_t* d_blk_off = nullptr;                  // [ntiles + 1] first block of every tile (a tile without blocks is not described)
   int32_t* d_cols = nullptr;                     // [4 * nblocks] the union columns, -1 past the end of a tile's union
   unsigned long long* d_masks = nullptr;         // [nblocks]
@@ -184,80 +185,124 @@ __device__ __forceinline__ bool mv5_nonfinite(double v) {
   return ((unsigned long long)__double_as_longlong(v) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
 }
 
-// One wave per tile, four tiles per workgroup, no workgroup barrier.  ncv = valid right-hand sides of this block of 16 (the spare
-// lanes of a narrower block read its last column and store nothing).  SWAP: D^T = X^T A^T (column-major Y, see the file header).
-template <class OffT, class AT, int CAP, bool SWAP>
-__global__ __launch_bounds__(kBlock) void spmv_mv5_kernel(int64_t nrows, int64_t nnz, int64_t ntiles, const OffT* __restrict__ row_map,
-                                                          const int32_t* __restrict__ entries, const AT* __restrict__ values,
-                                                          const int64_t* __restrict__ blk_off, const int32_t* __restrict__ cols,
-                                                          const unsigned long long* __restrict__ masks, const double* __restrict__ X, int64_t xs0,
-                                                          int64_t xs1, double* __restrict__ Y, int64_t ys0, int64_t ys1, double alpha, double beta,
-                                                          int ncv, int remap) {
+// One wave per tile and one wave per workgroup (LDS is then granted per wave: capv values + one chunk of block descriptors, sized by the
+// plan's largest described tile, so a CU holds as many tiles in flight as its LDS allows -- the kernel lives on memory latency).
+// Per chunk of kMv5Chunk column blocks the descriptors (four columns and a mask per block, contiguous in the plan) arrive with one
+// 16-byte and one 8-byte load per lane; per batch of UB blocks all X loads are issued before the first MFMA consumes one.
+// NC = blocks of 16 right-hand sides per pass (2: A, the descriptors and the masks are read once for 32 columns);
+// ncv = valid right-hand sides of this pass (the spare lanes of a narrower block read its last column and store nothing).
+// SWAP: D^T = X^T A^T (column-major Y, see the file header).
+constexpr int kMv5Chunk = 64;
+template <class OffT, class AT, int NC, bool SWAP>
+__global__ __launch_bounds__(kWave) void spmv_mv5_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ row_map,
+                                                         const int32_t* __restrict__ entries, const AT* __restrict__ values,
+                                                         const int64_t* __restrict__ blk_off, const int32_t* __restrict__ cols,
+                                                         const unsigned long long* __restrict__ masks, const double* __restrict__ X, int64_t xs0,
+                                                         int64_t xs1, double* __restrict__ Y, int64_t ys0, int64_t ys1, double alpha, double beta,
+                                                         int ncv, int remap, int capv) {
   using AV = typename vec2<AT>::type;
-  __shared__ AT s_val_all[kBlock / kWave][CAP + 2];
-  const int lane = threadIdx.x & 63;
-  const int w = KK_UNIFORM((int)(threadIdx.x >> 6));
-  const int64_t tile = xcd_order(blockIdx.x, gridDim.x, remap) * (kBlock / kWave) + w;
-  if (tile >= ntiles) return;
+  constexpr int UB = 16 / NC;
+  KK_DYN_SMEM(char, smem);
+  AT* s_val = reinterpret_cast<AT*>(smem);
+  int32_t* s_cols = reinterpret_cast<int32_t*>(smem + (size_t)capv * sizeof(double));
+  unsigned long long* s_masks = reinterpret_cast<unsigned long long*>(smem + (size_t)capv * sizeof(double) + kMv5Chunk * 16);
+  const int lane = threadIdx.x;
+  const int64_t tile = xcd_order(blockIdx.x, gridDim.x, remap);
   const int64_t b0 = blk_off[tile], b1 = blk_off[tile + 1];
   if (b0 == b1) return;                                          // not described: its rows are on the gather list
-  AT* s_val = s_val_all[w];
   const int i = lane & 15, kq = lane >> 4;
   const int64_t row0 = tile * kMv5Rows, rowN = (row0 + kMv5Rows < nrows) ? row0 + kMv5Rows : nrows;
   const int64_t rs = (int64_t)row_map[(row0 + i < rowN) ? row0 + i : rowN];
   const int64_t v0 = (int64_t)row_map[row0], v1 = (int64_t)row_map[rowN];
   const int64_t a = v0 & ~(int64_t)1;                            // the value array is 16-byte aligned: pairs start at even entries
-  for (int64_t p = a + 2 * lane; p < v1; p += 2 * kWave) {
-    if (p + 1 < nnz) { const AV v = *reinterpret_cast<const AV*>(values + p); s_val[p - a] = v[0]; s_val[p - a + 1] = v[1]; }
-    else s_val[p - a] = values[p];
-  }
-  KK_WAVE_SYNC();
-  int cur = (int)(rs - a);                                       // where the next entry of the lane's row sits in the wave's LDS
-  const int jc = (i < ncv) ? i : ncv - 1;
-  const double* __restrict__ xcol = X + jc * xs1;
-  kk_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  bool bad = false;
-  for (int64_t b = b0; b < b1; b += 4) {
-    int c[4]; unsigned long long m[4]; double xv[4];
-    KK_UNROLL
-    for (int u = 0; u < 4; ++u) { const int64_t bb = (b + u < b1) ? b + u : b1 - 1; c[u] = cols[4 * bb + kq]; m[u] = masks[bb]; }
-    KK_UNROLL
-    for (int u = 0; u < 4; ++u) { xv[u] = 0.0; if (c[u] >= 0) xv[u] = xcol[(int64_t)c[u] * xs0]; }
+  for (int64_t p0 = a + 2 * lane; p0 < v1; p0 += 8 * kWave) {    // four 16-byte loads per lane in flight
+    AV v[4];
     KK_UNROLL
     for (int u = 0; u < 4; ++u) {
-      if (b + u < b1) {                                          // wave-uniform
-        const unsigned nib = (unsigned)(m[u] >> (4 * i)) & 15u;
-        double av = 0.0;
-        if ((nib >> kq) & 1u) av = (double)s_val[cur + __popc(nib & ((1u << kq) - 1u))];
-        cur += __popc(nib);
-        bad |= mv5_nonfinite(xv[u]);
-        if (SWAP) acc = KK_MFMA_F64_16X16X4(xv[u], av, acc);
-        else      acc = KK_MFMA_F64_16X16X4(av, xv[u], acc);
+      const int64_t p = p0 + 2 * kWave * u;
+      if (p < v1) {
+        if (p + 1 < nnz) v[u] = *reinterpret_cast<const AV*>(values + p);
+        else { v[u][0] = values[p]; v[u][1] = AT(0); }             // the array's last entry: no pair to read
+      }
+    }
+    KK_UNROLL
+    for (int u = 0; u < 4; ++u) {
+      const int64_t p = p0 + 2 * kWave * u;
+      if (p < v1) { s_val[p - a] = v[u][0]; s_val[p - a + 1] = v[u][1]; }
+    }
+  }
+  int cur = (int)(rs - a);                                       // where the next entry of the lane's row sits in the wave's LDS
+  const double* __restrict__ xcol[NC];
+  KK_UNROLL
+  for (int q = 0; q < NC; ++q) { const int col = 16 * q + i; xcol[q] = X + (int64_t)(col < ncv ? col : ncv - 1) * xs1; }
+  kk_f64x4 acc[NC];
+  KK_UNROLL
+  for (int q = 0; q < NC; ++q) acc[q] = kk_f64x4{0.0, 0.0, 0.0, 0.0};
+  bool bad = false;
+  for (int64_t bc = b0; bc < b1; bc += kMv5Chunk) {
+    const int nbc = (int)(b1 - bc < kMv5Chunk ? b1 - bc : kMv5Chunk);
+    KK_WAVE_SYNC();                                              // the previous chunk's descriptors have been consumed
+    {
+      const int64_t bl = bc + (lane < nbc ? lane : nbc - 1);
+      const kk_i32x4v c4 = *reinterpret_cast<const kk_i32x4v*>(cols + 4 * bl);
+      const unsigned long long mk = masks[bl];
+      s_cols[4 * lane] = c4[0]; s_cols[4 * lane + 1] = c4[1]; s_cols[4 * lane + 2] = c4[2]; s_cols[4 * lane + 3] = c4[3];
+      s_masks[lane] = mk;
+    }
+    KK_WAVE_SYNC();                                              // ... and, in the first chunk, the tile's values are in place
+    for (int bl = 0; bl < nbc; bl += UB) {
+      double xv[UB][NC];
+      KK_UNROLL
+      for (int u = 0; u < UB; ++u) {
+        const int c = s_cols[4 * (bl + u < nbc ? bl + u : nbc - 1) + kq];
+        KK_UNROLL
+        for (int q = 0; q < NC; ++q) { xv[u][q] = 0.0; if (c >= 0) xv[u][q] = xcol[q][(int64_t)c * xs0]; }
+      }
+      KK_UNROLL
+      for (int u = 0; u < UB; ++u) {
+        if (bl + u < nbc) {                                      // wave-uniform
+          const unsigned nib = (unsigned)(s_masks[bl + u] >> (4 * i)) & 15u;
+          double av = 0.0;
+          if ((nib >> kq) & 1u) av = (double)s_val[cur + __popc(nib & ((1u << kq) - 1u))];
+          cur += __popc(nib);
+          KK_UNROLL
+          for (int q = 0; q < NC; ++q) {
+            bad |= mv5_nonfinite(xv[u][q]);
+            if (SWAP) acc[q] = KK_MFMA_F64_16X16X4(xv[u][q], av, acc[q]);
+            else      acc[q] = KK_MFMA_F64_16X16X4(av, xv[u][q], acc[q]);
+          }
+        }
       }
     }
   }
-  // accumulator register r of lane (i, kq): row 4 r + kq, column i -- SWAP: row i, column 4 r + kq
+  // accumulator register r of lane (i, kq), block q: row 4 r + kq, column 16 q + i -- SWAP: row i, column 16 q + 4 r + kq
   if (__ballot(bad) != 0ull) {
     // an Inf / NaN among the tile's X values: absent entries met it as 0 * Inf.  The reference's products, entry by entry:
     KK_UNROLL
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = row0 + (SWAP ? i : 4 * r + kq);
-      const int col = SWAP ? 4 * r + kq : i;
-      const double* xc = X + (int64_t)(col < ncv ? col : ncv - 1) * xs1;
-      double s = 0.0;
-      if (row < nrows)
-        for (int64_t p = (int64_t)row_map[row]; p < (int64_t)row_map[row + 1]; ++p) s += (double)values[p] * xc[(int64_t)entries[p] * xs0];
-      acc[r] = s;
+    for (int q = 0; q < NC; ++q) {
+      KK_UNROLL
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + (SWAP ? i : 4 * r + kq);
+        const int col = 16 * q + (SWAP ? 4 * r + kq : i);
+        const double* xc = X + (int64_t)(col < ncv ? col : ncv - 1) * xs1;
+        double s = 0.0;
+        if (row < nrows)
+          for (int64_t p = (int64_t)row_map[row]; p < (int64_t)row_map[row + 1]; ++p) s += (double)values[p] * xc[(int64_t)entries[p] * xs0];
+        acc[q][r] = s;
+      }
     }
   }
   KK_UNROLL
-  for (int r = 0; r < 4; ++r) {
-    const int64_t row = row0 + (SWAP ? i : 4 * r + kq);
-    const int col = SWAP ? 4 * r + kq : i;
-    if (row < nrows && col < ncv) {
-      double* yp = Y + row * ys0 + col * ys1;
-      const double out = alpha * acc[r];
-      *yp = (beta == 0.0) ? out : beta * (*yp) + out;
+  for (int q = 0; q < NC; ++q) {
+    KK_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + (SWAP ? i : 4 * r + kq);
+      const int col = 16 * q + (SWAP ? 4 * r + kq : i);
+      if (row < nrows && col < ncv) {
+        double* yp = Y + row * ys0 + col * ys1;
+        const double out = alpha * acc[q][r];
+        *yp = (beta == 0.0) ? out : beta * (*yp) + out;
+      }
     }
   }
 }
@@ -333,7 +378,7 @@ static int mv5_plan_build_t(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStre
            (long long)p->n_other);
   if (p->tiles_on == 0) return KKAMD_OK;
   if (mode != 2 && p->n_other * 100 > (int64_t)plan->tune.mv5_max_other_pct * A->num_rows) return KKAMD_OK;
-  p->cap = h[4] <= 512 ? 512 : (h[4] <= 1024 ? 1024 : kMv5Cap);
+  p->cap = (int)((h[4] + 2 + 63) / 64 * 64);                     // LDS values per wave: the largest described tile (+ the pair that starts one entry early)
   if (hipMalloc((void**)&p->d_cols, sizeof(int32_t) * 4 * (size_t)p->nblocks) != hipSuccess ||
       hipMalloc((void**)&p->d_masks, sizeof(unsigned long long) * (size_t)p->nblocks) != hipSuccess ||
       (p->n_other > 0 && hipMalloc((void**)&p->d_other, sizeof(int32_t) * (size_t)p->n_other) != hipSuccess)) {
@@ -363,27 +408,33 @@ template <class OffT, class AT>
 static int mv5_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
                       int64_t nvec, double alpha, double beta, hipStream_t st) {
   const kkamd_mv5_plan* p = plan->mv5;
-  const unsigned grid = (unsigned)ceil_div(p->ntiles, kBlock / kWave);
+  const unsigned grid = (unsigned)p->ntiles;
   const bool swap = ys0 < ys1;                                   // column-major Y
   const int remap = plan->tune.mv_remap;
-  for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
-    const int ncv = (int)(nvec - c0 < 16 ? nvec - c0 : 16);
+  const size_t lds = (size_t)p->cap * sizeof(double) + kMv5Chunk * 24;
+  for (int64_t c0 = 0; c0 < nvec;) {
+    const int nc = (nvec - c0 > 16) ? 2 : 1;                     // 17..32 columns left: one pass over A for two blocks of 16
+    const int ncv = (int)(nvec - c0 < 16 * nc ? nvec - c0 : 16 * nc);
     const double* Xb = X + c0 * xs1;
     double* Yb = Y + c0 * ys1;
-#define KK_MV5(CAP, SW)                                                                                                             \
-    KK_LAUNCH((spmv_mv5_kernel<OffT, AT, CAP, SW>), grid, kBlock, 0, st, A->num_rows, A->nnz, p->ntiles, (const OffT*)A->d_row_map,   \
+#define KK_MV5(NC_, SW)                                                                                                             \
+    KK_LAUNCH((spmv_mv5_kernel<OffT, AT, NC_, SW>), grid, kWave, lds, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map,             \
               (const int32_t*)A->d_entries, (const AT*)A->d_values, (const int64_t*)p->d_blk_off, (const int32_t*)p->d_cols,          \
-              (const unsigned long long*)p->d_masks, Xb, xs0, xs1, Yb, ys0, ys1, alpha, beta, ncv, remap)
-    if (p->cap == 512)       { if (swap) KK_MV5(512, true);  else KK_MV5(512, false); }
-    else if (p->cap == 1024) { if (swap) KK_MV5(1024, true); else KK_MV5(1024, false); }
-    else                     { if (swap) KK_MV5(2048, true); else KK_MV5(2048, false); }
+              (const unsigned long long*)p->d_masks, Xb, xs0, xs1, Yb, ys0, ys1, alpha, beta, ncv, remap, p->cap)
+    if (nc == 2) { if (swap) KK_MV5(2, true); else KK_MV5(2, false); }
+    else         { if (swap) KK_MV5(1, true); else KK_MV5(1, false); }
 #undef KK_MV5
     KK_LAUNCH_CHECK();
     if (p->n_other > 0) {
-      KK_LAUNCH((mv5_rows_kernel<OffT, AT>), (unsigned)ceil_div(p->n_other * 16, kBlock), kBlock, 0, st, p->n_other, (const int32_t*)p->d_other,
-                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xb, xs0, xs1, Yb, ys0, ys1, alpha, beta, ncv);
-      KK_LAUNCH_CHECK();
+      for (int q = 0; q < nc && c0 + 16 * q < nvec; ++q) {
+        const int nq = (int)(nvec - c0 - 16 * q < 16 ? nvec - c0 - 16 * q : 16);
+        KK_LAUNCH((mv5_rows_kernel<OffT, AT>), (unsigned)ceil_div(p->n_other * 16, kBlock), kBlock, 0, st, p->n_other, (const int32_t*)p->d_other,
+                  (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xb + 16 * q * xs1, xs0, xs1, Yb + 16 * q * ys1, ys0,
+                  ys1, alpha, beta, nq);
+        KK_LAUNCH_CHECK();
+      }
     }
+    c0 += 16 * nc;
   }
   return KKAMD_OK;
 }

@@ -1,0 +1,236 @@
+// kk_spmv_mvnnz.hip -- rank-2 CSR SpMV (SpMV_MV) split by NONZEROS, for matrices whose rows differ wildly in length (power-law
+// graphs: R-MAT scale 22 has rows of 0 and of 1e5 entries around an average of 15).
+//
+// Reference: sparse/impl/KokkosSparse_spmv_impl.hpp:634-1004 gives every row to a team of fixed size, so a hub row keeps its team
+// busy while the others idle; the rank-1 merge path (sparse/impl/KokkosSparse_spmv_impl_merge.hpp:37-330) balances by nonzeros but
+// has no rank-2 form and finishes cut rows with atomics.  The wave-private gather kernel of kk_spmv_mv.hip (16 rows per wave, the
+// longest row of the 16 sets the wave's trip count, rows above a threshold handed to a workgroup each) ran R-MAT scale 22 x 16 in
+// 1.28 + 1.83 ms.  Here:
+//
+//   * the nonzero stream is cut into CHUNKS of 128 entries, one per 16-lane group (four chunks per wave).  Lane j of a group carries
+//     right-hand side j: an X row is one 128-byte load of the group, a wave instruction gathers four X rows.  A group walks its chunk
+//     16 entries at a time: the 16 (column, row, value) triples arrive with one coalesced load each and are laid down in wave-private
+//     LDS, all 16 X gathers are issued, then the products are added up run by run of equal row index.
+//   * the plan keeps the ROW INDEX of every nonzero (4 bytes per nonzero, built once from row_map): a group finds its row boundaries
+//     without searching row_map, and every group does the same amount of work whatever the row lengths.
+//   * a run that ends inside the chunk is a finished row: y = beta y + alpha sum, stored by the group.  The first run of a chunk when it
+//     continues the previous chunk's row, and the last run when the next chunk continues it, go to a CARRY slot of the chunk (head /
+//     tail, 16 doubles each); a second small kernel adds the pieces of every cut row in chunk order and stores the row.  No atomics,
+//     no pre-scaling pass, the same summation order on every run (deterministic).
+//   * rows without entries are listed by the plan and get beta y from a third, tiny kernel.
+#include "kk_spmv_plan.h"
+#include <new>
+#include <climits>
+
+namespace kk {
+constexpr int kMv6E = 128;       // entries per chunk (per 16-lane group)
+struct alignas(16) Mv6Ent { int col, row; double val; };
+}  // namespace kk
+
+struct kkamd_mv6_plan {
+  int64_t nchunks = 0, n_empty = 0;
+  int32_t* d_rowid = nullptr;      // [nnz]
+  int32_t* d_empty = nullptr;      // [n_empty] rows without entries
+  double* d_carry = nullptr;       // [nchunks][2][16]: head / tail partial sums of the chunk
+  size_t bytes = 0;
+};
+
+namespace kk {
+
+void mv6_plan_destroy(kkamd_mv6_plan* p) {
+  if (!p) return;
+  if (p->d_rowid) (void)hipFree(p->d_rowid);
+  if (p->d_empty) (void)hipFree(p->d_empty);
+  if (p->d_carry) (void)hipFree(p->d_carry);
+  delete p;
+}
+int64_t mv6_plan_query(const kkamd_mv6_plan* p, int what) {
+  if (!p) return 0;
+  switch (what) {
+    case 0: return p->nchunks;
+    case 1: return p->n_empty;
+    case 2: return (int64_t)p->bytes;
+    default: return 0;
+  }
+}
+
+// row index of every nonzero: the last row whose range starts at or before the entry and is not empty
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv6_rowid_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ row_map, int32_t* __restrict__ rowid) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nnz) return;
+  int64_t lo = 0, hi = nrows;                                    // largest r with row_map[r] <= i (then row_map[r + 1] > i: the row holds i)
+  while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)row_map[mid] <= i) lo = mid; else hi = mid; }
+  rowid[i] = (int32_t)lo;
+}
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv6_empty_list_kernel(int64_t nrows, const OffT* __restrict__ row_map, int32_t* __restrict__ list,
+                                                                unsigned long long* __restrict__ count) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r < nrows && row_map[r + 1] == row_map[r]) {
+    const unsigned long long at = atomicAdd(count, 1ull);
+    if (list) list[at] = (int32_t)r;
+  }
+}
+__global__ __launch_bounds__(kBlock) void mv6_empty_rows_kernel(int64_t n, const int32_t* __restrict__ list, double* __restrict__ Y, int64_t ys0, int64_t ys1,
+                                                                double beta, int ncv) {
+  const int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
+  const int j = threadIdx.x & 15;
+  if (idx >= n || j >= ncv) return;
+  double* yp = Y + (int64_t)list[idx] * ys0 + j * ys1;
+  *yp = (beta == 0.0) ? 0.0 : beta * (*yp);
+}
+
+// carry slots of chunk g: head at (2 g) * 16, tail at (2 g + 1) * 16
+template <class AT>
+__global__ __launch_bounds__(kBlock) void spmv_mv6_kernel(int64_t nnz, const int32_t* __restrict__ entries, const AT* __restrict__ values,
+                                                          const int32_t* __restrict__ rowid, const double* __restrict__ X, int64_t xs0, int64_t xs1,
+                                                          double* __restrict__ Y, int64_t ys0, int64_t ys1, double alpha, double beta, int ncv,
+                                                          double* __restrict__ carry, int remap) {
+  __shared__ Mv6Ent s_ent_all[kBlock / kWave][kWave];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, grp = lane >> 4;
+  Mv6Ent* s_ent = s_ent_all[w];
+  const int64_t wave = xcd_order(blockIdx.x, gridDim.x, remap) * (kBlock / kWave) + w;
+  if (wave * 4 * kMv6E >= nnz) return;                           // the whole wave leaves together
+  const int64_t g = wave * 4 + grp;
+  const int64_t e0 = g * kMv6E < nnz ? g * kMv6E : nnz, e1 = e0 + kMv6E < nnz ? e0 + kMv6E : nnz;
+  const int prev_row = (e0 > 0 && e0 < nnz) ? rowid[e0 - 1] : -1;
+  const int next_row = (e1 < nnz) ? rowid[e1] : -1;
+  const double* __restrict__ xc = X + (int64_t)(j < ncv ? j : ncv - 1) * xs1;
+  double* __restrict__ cg = carry + g * 32;
+  int cur_row = -1;
+  bool open_left = false;
+  double acc = 0.0;
+  auto flush = [&]() {                                           // the run of cur_row ends inside the chunk
+    if (open_left) cg[j] = acc;                                  // ... but began in an earlier chunk: its head piece
+    else if (j < ncv) {
+      double* yp = Y + (int64_t)cur_row * ys0 + j * ys1;
+      *yp = (beta == 0.0) ? alpha * acc : beta * (*yp) + alpha * acc;
+    }
+    open_left = false;
+  };
+  for (int rd = 0; rd < kMv6E / 16; ++rd) {
+    const int64_t base = e0 + rd * 16, idx = base + j;
+    const bool ok = idx < e1;
+    Mv6Ent me;
+    me.col = ok ? entries[idx] : 0; me.row = ok ? rowid[idx] : -1; me.val = ok ? (double)values[idx] : 0.0;
+    KK_WAVE_SYNC();
+    s_ent[lane] = me;
+    KK_WAVE_SYNC();
+    const int nq = (int)(e1 - base < 16 ? (e1 - base > 0 ? e1 - base : 0) : 16);      // entries of this round (the same in the group's 16 lanes)
+    double x[16];
+    KK_UNROLL
+    for (int q = 0; q < 16; ++q) { x[q] = 0.0; if (q < nq) x[q] = xc[(int64_t)s_ent[grp * 16 + q].col * xs0]; }
+    KK_UNROLL
+    for (int q = 0; q < 16; ++q) {
+      if (q < nq) {
+        const Mv6Ent e = s_ent[grp * 16 + q];
+        if (e.row != cur_row) {
+          if (cur_row >= 0) flush();
+          else open_left = (e.row == prev_row);                  // the chunk's first entry
+          cur_row = e.row; acc = 0.0;
+        }
+        acc += e.val * x[q];
+      }
+    }
+  }
+  if (cur_row >= 0) {
+    if (cur_row == next_row) cg[(open_left ? 0 : 16) + j] = acc; // the next chunk goes on with this row: a tail piece (or, when the whole
+    else flush();                                                // chunk is the middle of one row, another head piece)
+  }
+}
+
+// every row cut by a chunk boundary: the chunk that holds the row's LAST-but-open run as its tail (and is not itself all middle) adds the
+// head pieces of the chunks after it, in order, and stores the row.  16 lanes per chunk.
+__global__ __launch_bounds__(kBlock) void mv6_fixup_kernel(int64_t nnz, int64_t nchunks, const int32_t* __restrict__ rowid, const double* __restrict__ carry,
+                                                           double* __restrict__ Y, int64_t ys0, int64_t ys1, double alpha, double beta, int ncv) {
+  const int64_t g = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
+  const int j = threadIdx.x & 15;
+  if (g >= nchunks) return;
+  const int64_t e0 = g * kMv6E, e1 = e0 + kMv6E;
+  if (e1 >= nnz) return;                                         // the last chunk has no successor
+  const int rl = rowid[e1 - 1];
+  if (rl != rowid[e1]) return;                                   // its last run ends with the chunk
+  if (e0 > 0 && rowid[e0] == rl && rowid[e0 - 1] == rl) return;  // all middle: the chunk where the row begins does the sum
+  double sum = carry[g * 32 + 16 + j];
+  for (int64_t c = g + 1; c < nchunks; ++c) {
+    sum += carry[c * 32 + j];
+    const int64_t c1 = (c + 1) * kMv6E;
+    if (!(c1 < nnz && rowid[c * kMv6E] == rowid[c1 - 1] && rowid[c1 - 1] == rowid[c1])) break;   // chunk c was not all middle: the row ended there
+  }
+  if (j < ncv) {
+    double* yp = Y + (int64_t)rl * ys0 + j * ys1;
+    *yp = (beta == 0.0) ? alpha * sum : beta * (*yp) + alpha * sum;
+  }
+}
+
+template <class OffT>
+static int mv6_plan_build_t(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st) {
+  plan->mv6_tried = true;
+  if (A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
+  kkamd_mv6_plan* p = new (std::nothrow) kkamd_mv6_plan();
+  if (!p) return fail(KKAMD_ERR_ALLOC, "kkamd_spmv_mv: out of host memory");
+  struct Guard { kkamd_mv6_plan* p; ~Guard() { if (p) mv6_plan_destroy(p); } } guard{p};
+  p->nchunks = ceil_div(A->nnz, (int64_t)kMv6E);
+  DevBuf cnt;
+  if (hipMalloc((void**)&p->d_rowid, sizeof(int32_t) * (size_t)A->nnz) != hipSuccess ||
+      hipMalloc((void**)&p->d_carry, sizeof(double) * 32 * (size_t)p->nchunks) != hipSuccess || cnt.alloc(sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError();
+    return KKAMD_OK;                                             // no memory for the plan: the row-based gather kernel serves the matrix
+  }
+  KK_LAUNCH((mv6_rowid_kernel<OffT>), (unsigned)ceil_div(A->nnz, kBlock), kBlock, 0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, p->d_rowid);
+  KK_LAUNCH_CHECK();
+  unsigned long long* d_cnt = cnt.as<unsigned long long>();
+  KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+  const unsigned grid = (unsigned)ceil_div(A->num_rows, kBlock);
+  KK_LAUNCH((mv6_empty_list_kernel<OffT>), grid, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, (int32_t*)nullptr, d_cnt);
+  unsigned long long h_n = 0;
+  KK_HIP(hipMemcpyAsync(&h_n, d_cnt, sizeof h_n, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  if (h_n > 0) {
+    if (hipMalloc((void**)&p->d_empty, sizeof(int32_t) * (size_t)h_n) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
+    KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+    KK_LAUNCH((mv6_empty_list_kernel<OffT>), grid, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, p->d_empty, d_cnt);
+    KK_LAUNCH_CHECK();
+  }
+  KK_HIP(hipStreamSynchronize(st));
+  p->n_empty = (int64_t)h_n;
+  p->bytes = sizeof(int32_t) * (size_t)A->nnz + 256 * (size_t)p->nchunks + sizeof(int32_t) * (size_t)h_n;
+  plan->mv6 = p;
+  guard.p = nullptr;
+  return KKAMD_OK;
+}
+int mv6_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st) {
+  return A->offset_type == KKAMD_I64 ? mv6_plan_build_t<int64_t>(plan, A, st) : mv6_plan_build_t<int32_t>(plan, A, st);
+}
+
+template <class AT>
+static int mv6_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+                      int64_t nvec, double alpha, double beta, hipStream_t st) {
+  const kkamd_mv6_plan* p = plan->mv6;
+  const unsigned grid = (unsigned)ceil_div(p->nchunks, (int64_t)4 * (kBlock / kWave));
+  for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
+    const int ncv = (int)(nvec - c0 < 16 ? nvec - c0 : 16);
+    const double* Xb = X + c0 * xs1;
+    double* Yb = Y + c0 * ys1;
+    KK_LAUNCH((spmv_mv6_kernel<AT>), grid, kBlock, 0, st, A->nnz, (const int32_t*)A->d_entries, (const AT*)A->d_values, (const int32_t*)p->d_rowid, Xb, xs0, xs1,
+              Yb, ys0, ys1, alpha, beta, ncv, p->d_carry, plan->tune.mv_remap);
+    KK_LAUNCH_CHECK();
+    KK_LAUNCH(mv6_fixup_kernel, (unsigned)ceil_div(p->nchunks * 16, kBlock), kBlock, 0, st, A->nnz, p->nchunks, (const int32_t*)p->d_rowid,
+              (const double*)p->d_carry, Yb, ys0, ys1, alpha, beta, ncv);
+    KK_LAUNCH_CHECK();
+    if (p->n_empty > 0) {
+      KK_LAUNCH(mv6_empty_rows_kernel, (unsigned)ceil_div(p->n_empty * 16, kBlock), kBlock, 0, st, p->n_empty, (const int32_t*)p->d_empty, Yb, ys0, ys1, beta, ncv);
+      KK_LAUNCH_CHECK();
+    }
+  }
+  return KKAMD_OK;
+}
+
+int mv6_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+             int64_t nvec, double alpha, double beta, hipStream_t st) {
+  if (A->value_type == KKAMD_F64) return mv6_launch<double>(plan, A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, st);
+  return mv6_launch<float>(plan, A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, st);
+}
+
+}  // namespace kk

@@ -43,6 +43,10 @@ struct SpmvTuning {
                            // analysis finds the tiles dense enough, 2 = whenever a tile can be described (tests), 0 = never
   int mv5_min_fill_pct = 25;  // ... a tile takes the matrix core when at least this share of its 16 x 4 operand slots holds an entry
   int mv5_max_other_pct = 50; // ... and the kernel is used when at most this share of the rows is left to the gather rows
+  int mv6            = 1;  // rank-2 nonzero-split kernel (kk_spmv_mvnnz.hip: 128-entry chunks per 16-lane group, row index per nonzero in the plan, cut
+                           // rows finished from carries): 1 = on matrices with long rows ("mv6_min_long_pct"), 2 = whenever the gather kernel would
+                           // run, 0 = never
+  int mv6_min_long_pct = 10;  // ... at least this share of the nonzeros sits in rows above the long-row threshold (4 x the average, at least 64)
   int march          = 0;  // rank 1 on the plane-marching analysis (lattice stencils, fp64 vectors): 0 off, 1 on
   int march_planes   = 20; // ... planes a workgroup marches (its k-chunk)
   int explicit_transpose = 1;   // modes T/H with an analysed handle: 1 = cache A^T in the plan (when it fits an eighth of free HBM), move the
@@ -82,6 +86,7 @@ struct kkamd_mv_plan;   // kk_spmv_mv.hip
 struct kkamd_mv4_plan;  // kk_spmv_mv.hip
 struct kkamd_cs_plan;   // kk_spmv_colslab.hip
 struct kkamd_mv5_plan;  // kk_spmv_mvblk.hip
+struct kkamd_mv6_plan;  // kk_spmv_mvnnz.hip
 
 struct kkamd_spmv_plan {
   int64_t num_rows = 0, num_cols = 0, nnz = 0;
@@ -125,11 +130,14 @@ struct kkamd_spmv_plan {
   // rank-2 matrix-core kernel: per 16-row tile the union of its columns in blocks of four and a 64-bit occupancy mask per block
   kkamd_mv5_plan* mv5 = nullptr;
   bool mv5_tried = false;
+  // rank-2 nonzero-split kernel: row index per nonzero, empty rows, carry slots
+  kkamd_mv6_plan* mv6 = nullptr;
+  bool mv6_tried = false;
   // rank-2 wave-private kernel: its row blocks in strip order (see mv_build_strip_order)
   int32_t* d_mv2_order = nullptr;
   // rank 2, gather kernel: rows longer than mv_long_T entries are left out of the wave-per-16-rows walk (one row group of a wave
   // would chew through them alone) and done by a workgroup each afterwards; found once, at the first rank-2 call
-  int32_t* d_mv_long = nullptr; int64_t n_mv_long = 0, mv_long_T = 0; bool mv_long_known = false;
+  int32_t* d_mv_long = nullptr; int64_t n_mv_long = 0, mv_long_T = 0, mv_long_nnz = 0; bool mv_long_known = false;
   // rank 1, column-slab copy (kk_spmv_colslab.hip): decided at the first mode-N call that can use it
   kkamd_cs_plan* cs = nullptr;
   bool cs_tried = false;
@@ -156,6 +164,11 @@ int64_t mv5_plan_query(const kkamd_mv5_plan* p, int what);  // 0 tiles on the ma
 // builds the analysis on first use (plan->mv5 stays null when the matrix does not qualify); then one pass per 16 right-hand sides
 int  mv5_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st);
 int  mv5_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+              int64_t nvec, double alpha, double beta, hipStream_t st);
+void mv6_plan_destroy(kkamd_mv6_plan* p);
+int64_t mv6_plan_query(const kkamd_mv6_plan* p, int what);  // 0 chunks, 1 empty rows, 2 bytes
+int  mv6_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st);
+int  mv6_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
               int64_t nvec, double alpha, double beta, hipStream_t st);
 void cs_plan_destroy(kkamd_cs_plan* cs);
 int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes

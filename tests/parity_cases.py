@@ -137,6 +137,50 @@ def check_mv5(be, light=False):
         assert h.query("mv5_tiles") == 0
 
 
+def mv6_cases():
+    """(name, matrix) for the nonzero-split rank-2 kernel: chunks of 128 entries; rows cut by one and by many chunk boundaries, runs
+    that end exactly at a boundary, empty rows (leading, trailing, in between), fewer entries than a chunk, one row only"""
+    out = [("hubs", hub_matrix(3000, 9000, 6, {5: 7000, 17: 1500, 1234: 1025, 2999: 4000, 40: 1024}, seed=3))]
+    rng = np.random.default_rng(31)
+    def from_lens(lens, ncols, seed):
+        lens = np.asarray(lens, dtype=np.int64)
+        rm = np.zeros(lens.size + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+        r_ = np.random.default_rng(seed)
+        ent = np.concatenate([np.sort(r_.choice(ncols, size=int(l), replace=False)) for l in lens] + [np.empty(0, np.int64)]).astype(np.int32)
+        return oracle.Crs(lens.size, ncols, rm, ent, r_.random(int(rm[-1])) + 0.5)
+    # every row exactly one chunk; rows of 64 (two per chunk); 128 + 1 (every boundary cuts a row one entry in)
+    out.append(("rows of 128", from_lens([128] * 40, 4000, 1)))
+    out.append(("rows of 64", from_lens([64] * 50, 4000, 2)))
+    out.append(("rows of 129", from_lens([129] * 33, 4000, 3)))
+    # empty rows everywhere, a row of 1000 in the middle, short rows
+    lens = rng.integers(0, 9, 600); lens[:5] = 0; lens[-7:] = 0; lens[100:140] = 0; lens[300] = 1000; lens[301] = 0; lens[302] = 300
+    out.append(("empty rows + long", from_lens(lens, 5000, 4)))
+    out.append(("tiny", from_lens([3, 0, 5, 1], 50, 5)))
+    out.append(("one row", from_lens([700], 2000, 6)))
+    return out
+
+
+def check_mv6(be, light=False):
+    combos = ((16, "C", "C", 1.5, 0.5, np.int32), (16, "F", "F", 1.0, 0.0, np.int64), (5, "C", "F", 2.0, 0.0, np.int32), (33, "F", "C", -1.0, 1.0, np.int32))
+    for ci, (name, A0) in enumerate(mv6_cases()):
+        for nvec, xo, yo, alpha, beta, off in (combos if (ci < 2 or not light) else combos[:2]):
+            h = check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=50.0, nans=(beta == 0.0), offset_dtype=off, knobs={"mv6": 2})
+            assert h.query("mv6_chunks") == -(-A0.nnz // 128), (name, h.query("mv6_chunks"))
+            assert h.query("mv6_empty_rows") == int((np.diff(A0.row_map) == 0).sum()), name
+    name, A0 = mv6_cases()[0]
+    # by default on matrices with a tenth of their entries in long rows; fp32 values; Inf / NaN in X
+    h = check_spmv_mv(be, A0, 16, "N", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", max_val=50.0, value_dtype=np.float32)
+    assert h.query("mv6_chunks") > 0 and h.query("mv_long_nnz") == 7000 + 1500 + 1025 + 4000 + 1024
+    h = check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=50.0, nans=True, x_special={int(A0.entries[0]): np.inf, 40: np.nan, 8999: -np.inf})
+    assert h.query("mv6_chunks") > 0
+    # not its matrices / off / the gather kernel asked for / no analysis
+    h = check_spmv_mv(be, randomized(oracle.random_crs(2000, 2000, 9, variance=3, seed=5)), 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT")
+    assert h.query("mv6_chunks") == 0
+    for algo, knobs in (("SPMV_DEFAULT", {"mv6": 0}), ("SPMV_DEFAULT", {"mv_kernel": 2}), ("SPMV_FAST_SETUP", None)):
+        h = check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo=algo, knobs=knobs, max_val=50.0)
+        assert h.query("mv6_chunks") == 0
+
+
 def _to_dev_2d(be, M):
     """device 2-D array with the same logical layout (Fortran order kept through a transposed view)"""
     if be.name == "emu":

@@ -235,14 +235,20 @@ def test_mv5_matrix_core(be):
     pc.check_mv5(be, light=False)
 
 
+def test_mv6_nonzero_split(be):
+    # rank-2 nonzero-split kernel (kk_spmv_mvnnz.hip): chunks of 128 entries per 16-lane group, cut rows finished from carries, empty
+    # rows from the plan's list; every width / layout pair, beta = 0 over NaNs, 64-bit offsets, fp32 values, Inf / NaN in X
+    pc.check_mv6(be, light=False)
+
+
 def test_mv_long_rows(be):
     # rank 2 on a matrix with a few very long rows (R-MAT-like hubs): the wave-private gather kernel leaves rows above 32 x the average
     # length (at least 1024 entries) to spmv_mv_long_kernel (a workgroup per row); every width, both layouts, beta 0 over NaNs and != 0
     A0 = pc.hub_matrix(3000, 9000, 6, {5: 7000, 17: 1500, 1234: 1025, 2999: 4000, 40: 1024}, seed=3)
     for nvec, xo, yo, alpha, beta in ((16, "C", "C", 1.5, 0.0), (16, "F", "F", 1.0, 0.5), (5, "C", "C", 2.0, -1.0), (33, "C", "F", 1.0, 0.0), (2, "C", "C", 1.0, 1.0)):
-        h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=50.0, nans=(beta == 0.0), knobs={"mv_long_T": 1024})
+        h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=50.0, nans=(beta == 0.0), knobs={"mv_long_T": 1024, "mv6": 0})
         assert h.query("mv_long_rows") == 4, h.query("mv_long_rows")            # 7000, 1500, 1025, 4000 (1024 itself stays)
-        h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=50.0, nans=(beta == 0.0))
+        h = pc.check_spmv_mv(be, A0, nvec, "N", alpha, beta, xo, yo, algo="SPMV_DEFAULT", max_val=50.0, nans=(beta == 0.0), knobs={"mv6": 0})
         assert h.query("mv_long_rows") == 5, h.query("mv_long_rows")            # automatic threshold: 4 x the average row, at least 64
     h = pc.check_spmv_mv(be, pc.randomized(oracle.random_crs(2000, 2000, 9, variance=3, seed=5)), 16, "N", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT")
     assert h.query("mv_long_rows") == 0

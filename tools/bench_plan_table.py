@@ -52,7 +52,7 @@ def multi_dof(A, ndof):
 
 def matrices(only=""):
     for name, make in _matrix_makers():
-        if only and only not in name: continue
+        if only and not any(o in name for o in only.split('|')): continue
         yield name, make()
 
 
