@@ -139,22 +139,32 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *     "pattern_codes"   staged-x tiles: row-pattern records instead of per-nonzero codes; 1 (default) when >= 90 % of the tiles
  *                       decompose, 2 whenever one does, 0 never; from "pattern_codes_min_knnz" thousand nonzeros
  *     "transient_min_knnz"  handle-less / FAST_SETUP calls analyse on the fly from this many thousand nonzeros (0 never)
- *     "explicit_transpose"  modes T/H with an analysed handle: 1 (default) through a transpose cached in the plan when it fits an
- *                       eighth of free HBM, values that changed since the last call are moved into it; 2 the caller promises constant
- *                       values (no comparison either); 0 the reference's atomic scatter.  From "explicit_transpose_min_knnz"
+ *     "explicit_transpose"  modes T/H with an analysed handle (rank 1 and rank 2): 1 (default) through a transpose cached in the plan when
+ *                       it fits an eighth of free HBM, its values follow "values_tracking"; 2 the caller promises constant
+ *                       values (no tracking pass either); 0 the reference's atomic scatter.  From "explicit_transpose_min_knnz"
+ *     "values_tracking" how a re-ordered copy of A.values (cached transpose; column-slab copy) follows value changes: 0 (default) EXACT --
+ *                       a shadow copy of A.values in A's order, compared bit for bit at every call (two streams of 8 B per nonzero),
+ *                       changed 4096-value tiles are moved; without memory for the shadow every call copies all values; 1 NOTIFY --
+ *                       kkamd_spmv_plan_values_changed says when, nothing is read in between; 2 FINGERPRINTS -- 128 bits per tile, one
+ *                       stream, no shadow: a heuristic (a changed tile with an unchanged fingerprint is missed)
  *     "colslab"         mode N on matrices whose x gather defeats the caches (most tiles read plain entries, x is >= 16 MB, from
- *                       "colslab_min_knnz" thousand nonzeros): 1 (default) the first call builds a second copy of the matrix in
+ *                       "colslab_min_knnz" thousand nonzeros): 0 (default) never; 1 the first call builds a second copy of the matrix in
  *                       column-slab order (entries sorted by 2 MB segments of x, then by row; nnz * (8 + value + offset) bytes),
- *                       times the CRS kernel and the copy and keeps the copy when it is 10 % faster; every call then re-fingerprints
- *                       A's values (128 bits per 4096 values) and moves changed tiles into the copy.  Products reach y through
- *                       atomics: results agree with the CRS kernel to rounding, not bit for bit.  2 = always (no gates, no timing:
- *                       tests), 0 = never.  "colslab_shift" log2 of the columns per slab (0 = automatic), "colslab_const" 1 = the
- *                       caller promises constant matrix values (no fingerprint pass)
+ *                       times the CRS kernel and the copy ON THE CALLER'S STREAM (the call blocks) and keeps the copy when it is 10 %
+ *                       faster; the values follow "values_tracking".  Products reach y through atomics: results agree with the CRS
+ *                       kernel to rounding, not bit for bit, and vary in the last bits from run to run -- which is why it is opt-in.
+ *                       2 = always (no gates, no timing: tests).  "colslab_shift" log2 of the columns per slab (0 = automatic),
+ *                       "colslab_const" 1 = the caller promises constant matrix values (no tracking pass)
  *   SpMV, rank 2
+ *     "mv6"             nonzero-split kernel (kk_spmv_mvnnz.hip; analysed plan, fp64 vectors): the nonzeros are cut into chunks of 128 per
+ *                       16-lane group, the plan keeps the row index of every nonzero (4 B per nonzero), rows cut by a chunk boundary are
+ *                       finished from carry slots (no atomics, deterministic).  1 (default) on matrices with at least
+ *                       "mv6_min_long_pct" (10) percent of their nonzeros in rows above 4 x the average length (at least 64): power-law
+ *                       graphs; 2 whenever the gather kernel would run; 0 never
  *     "mv_kernel"       0 auto (plane-marching kernel where it applies -- analysed plan, fp64 vectors, right-hand sides in
  *                       blocks of 16 (a remainder: one more pass over the last 16 columns when beta = 0, else the gather kernel), a matrix that verifies as a radius-1 lattice stencil --, else the wave-private gather
  *                       kernel), 1 generic strided kernel, 2 wave-private gather kernel, 3 LDS-staged X tiles, 4 = 0 without the matrix-core
- *                       kernel, 5 = 0 (the matrix-core kernel where its analysis accepts the matrix, see "mv5")
+ *                       kernel, 5 = 0 (the matrix-core kernel where its analysis accepts the matrix, see "mv5"), 6 = the nonzero-split or the gather kernel
  *     "mv5"             matrix-core kernel (v_mfma_f64_16x16x4f64; analysed plan, fp64 vectors, any width and strides; not on matrices
  *                       the plane-marching kernel takes): the rows are cut into tiles of 16, a tile is DESCRIBED by the union of its
  *                       columns in blocks of four plus a 64-bit occupancy mask per block (24 B per block instead of 4 B per entry;
@@ -181,12 +191,19 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  * measurement build libkkamd_ablate.so (csrc: make ablate, -DKK_ABLATE); libkkamd.so answers KKAMD_ERR_INVALID_ARG. */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);
 int kkamd_set_default(const char* key, int value);
+/* The caller has written to A.values since the plan's last SpMV.  The native CRS kernels read A.values at every call and need no
+ * notice; a plan that keeps a RE-ORDERED COPY of the values (the cached transpose of modes T / H; the opt-in column-slab copy) copies
+ * them again at its next call.  Under "values_tracking" 0 (default) and 2 the plan notices changes itself and this call is optional;
+ * under 1 it is the only way the copies learn of a change.  No reference counterpart: the reference's handle holds no values
+ * (sparse/src/KokkosSparse_spmv_handle.hpp:273-277), vendor analyses of this kind ask for the same call (rocsparse update-values). */
+int kkamd_spmv_plan_values_changed(kkamd_spmv_plan_t* plan);
 /* What the analysis of a plan produced: "tile" (nnz per workgroup, 0 = no tiling), "tiles", per-mode tile counts "plain_tiles" /
  * "code_tiles" / "staged_tiles" / "pattern_tiles", "window_codes" (1 if any tile uses the column analysis), "window_staged_x",
  * "plan_bytes" (HBM the analysis keeps), "transpose_cached", rank 2: "mv_tiles", "mv_staged_tiles", "mv_order" (order in use),
  * "mv_period" (far stride found), "mv_plan_bytes", plane-marching kernel: "mv4_workgroups" (0 = not in use), "mv4_other_rows"
  * (rows left to its gather kernel), "mv4_stencil" (entries of the stencil), "mv4_near_stride"; matrix-core kernel: "mv5_tiles" (described
- * 16-row tiles, 0 = not in use), "mv5_other_rows", "mv5_blocks" (column blocks = MFMA instructions per pass), "mv5_fill_permille"; "march_workgroups" (rank-1 marching kernel, 0 = not in use);
+ * 16-row tiles, 0 = not in use), "mv5_other_rows", "mv5_blocks" (column blocks = MFMA instructions per pass), "mv5_fill_permille"; nonzero-split kernel: "mv6_chunks" (0 = not in use),
+ * "mv6_empty_rows"; "mv_long_rows" / "mv_long_nnz" (rows above the long-row threshold and their entries); "march_workgroups" (rank-1 marching kernel, 0 = not in use);
  * column-slab copy: "colslab" (1 = in use), "colslab_tried", "colslab_slabs", "colslab_shift", "colslab_bytes", and what the selection
  * measured, "colslab_crs_us" / "colslab_us" (microseconds per call of the CRS kernel / of the copy; 0 = not measured). */
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value);

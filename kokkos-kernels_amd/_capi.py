@@ -9,7 +9,7 @@ SPMV_DEFAULT, SPMV_FAST_SETUP, SPMV_NATIVE, SPMV_MERGE_PATH, SPMV_NATIVE_MERGE_P
 
 EXPORTS = [
     "kkamd_last_error", "kkamd_version", "kkamd_device_info", "kkamd_trace_push", "kkamd_trace_pop", "kkamd_spmv_plan_create", "kkamd_spmv_plan_create_knobs", "kkamd_release_scratch", "kkamd_spmv_plan_destroy",
-    "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_sort_and_merge", "kkamd_transpose", "kkamd_spmv_plan_set", "kkamd_spmv_plan_query", "kkamd_spmv_plan_export", "kkamd_set_default", "kkamd_spgemm_create",
+    "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_sort_and_merge", "kkamd_transpose", "kkamd_spmv_plan_set", "kkamd_spmv_plan_values_changed", "kkamd_spmv_plan_query", "kkamd_spmv_plan_export", "kkamd_set_default", "kkamd_spgemm_create",
     "kkamd_spgemm_destroy", "kkamd_spgemm_set", "kkamd_spgemm_symbolic", "kkamd_spgemm_numeric", "kkamd_spgemm_get", "kkamd_spgemm_get_hint", "kkamd_sort_crs",
     "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows", "kkamd_bench_read",
     "kkamd_dist_unique_id", "kkamd_dist_spmv_create", "kkamd_dist_spmv_destroy", "kkamd_dist_spmv_x_local", "kkamd_dist_spmv_apply",
@@ -57,6 +57,7 @@ def bind(lib):
     lib.kkamd_spmv_mv.argtypes = [vp, C.POINTER(CrsDesc), C.c_char, dbl, vp, i64, i64, dbl, vp, i64, i64, i64, ci, vp]
     lib.kkamd_spmv_struct.argtypes = [C.POINTER(CrsDesc), C.c_char, ci, ci, C.POINTER(i64), dbl, vp, dbl, vp, ci, vp]
     lib.kkamd_spmv_plan_set.argtypes = [vp, C.c_char_p, ci]
+    lib.kkamd_spmv_plan_values_changed.argtypes = [vp]
     lib.kkamd_set_default.argtypes = [C.c_char_p, ci]
     lib.kkamd_spmv_plan_query.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     lib.kkamd_spmv_plan_export.argtypes = [vp, C.c_char_p, vp, i64]

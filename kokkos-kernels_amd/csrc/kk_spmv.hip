@@ -906,12 +906,14 @@ static int ensure_transpose(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_
                            p->d_t_rm, p->d_t_ent, d_tmp, reinterpret_cast<kkamd_stream_t>(st));
   if (rc != KKAMD_OK) { fail_clean(); return rc; }
   KK_LAUNCH((invert_perm_kernel<OffT>), grid, kBlock, 0, st, (const double*)d_tmp, (OffT*)p->d_t_perm, A->nnz);     // d_t_perm: position of A's entry i in A^T
-  p->t_fp_valid = false;                                                       // the first refresh moves every value
+  p->t_fp_valid = false; p->t_shadow_valid = false; p->t_stale = true;          // the first refresh moves every value
   if (hipStreamSynchronize(st) != hipSuccess) return fail_clean();
   (void)hipFree(d_iota); (void)hipFree(d_tmp); d_iota = d_tmp = nullptr;
   kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, p->d_t_rm, p->d_t_ent, p->d_t_val, A->offset_type, A->value_type};
   rc = kkamd_spmv_plan_create(&p->t_plan, &At, p->algorithm, reinterpret_cast<kkamd_stream_t>(st));
   if (rc != KKAMD_OK) { fail_clean(); return rc; }
+  p->t_plan->tune.colslab = 0;            // A^T's values are this plan's own copy: no second re-ordered copy to keep current behind it
+  p->t_plan->tune.explicit_transpose = 0;
   p->t_ready = true;
   return KKAMD_OK;
 }
@@ -979,6 +981,27 @@ static kkamd_spmv_plan* transient_plan(const kkamd_crs_t* A, const SpmvTuning& t
   return &p;
 }
 
+// The cached transpose of an analysed handle with its values brought up to date under the "values_tracking" policy (exact by default),
+// or *tplan = nullptr when the handle has none (not analysed, knob off, matrix too small, no memory).
+template <class OffT, class AT>
+static int transpose_view_t(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st, kkamd_crs_t* At, kkamd_spmv_plan** tplan) {
+  *tplan = nullptr;
+  if (!(plan && plan->tile != 0 && plan->tune.explicit_transpose && A->nnz >= (int64_t)plan->tune.explicit_transpose_min_knnz * 1000 &&
+        transpose_fits<OffT, AT>(plan, A) && ensure_transpose<OffT, AT>(plan, A, st) == KKAMD_OK))
+    return KKAMD_OK;
+  const int rc = values_track(plan->tune.values_tracking, plan->tune.explicit_transpose == 2, A->offset_type, A->value_type, A->nnz, A->d_values, plan->d_t_perm,
+                              plan->d_t_val, plan->d_t_fp, &plan->d_t_shadow, &plan->t_fp_valid, &plan->t_shadow_valid, &plan->t_shadow_failed, &plan->t_stale, st);
+  if (rc) return rc;
+  *At = kkamd_crs_t{A->num_cols, A->num_rows, A->nnz, plan->d_t_rm, plan->d_t_ent, plan->d_t_val, A->offset_type, A->value_type};
+  *tplan = plan->t_plan;
+  return KKAMD_OK;
+}
+int transpose_view(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st, kkamd_crs_t* At, kkamd_spmv_plan** tplan) {
+  const bool o64 = A->offset_type == KKAMD_I64;
+  if (A->value_type == KKAMD_F64) return o64 ? transpose_view_t<int64_t, double>(plan, A, st, At, tplan) : transpose_view_t<int32_t, double>(plan, A, st, At, tplan);
+  return o64 ? transpose_view_t<int64_t, float>(plan, A, st, At, tplan) : transpose_view_t<int32_t, float>(plan, A, st, At, tplan);
+}
+
 // Column-slab copy (kk_spmv_colslab.hip), decided once per plan at the first mode-N call: the analysis must say "gather-bound"
 // (most tiles read plain entries, x is several L2s large), then both kernels are timed on the caller's x into a scratch y and the
 // copy is kept when it wins by 10 % including its fingerprint pass.  colslab = 2 skips the gates and the timing (tests).
@@ -1002,7 +1025,7 @@ static int colslab_select(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const YT*
   if (ys.alloc(sizeof(YT) * (size_t)A->num_rows) != hipSuccess) return drop();
   for (hipEvent_t& e : ev) if (hipEventCreate(&e) != hipSuccess) return drop();
   YT* yscr = ys.as<YT>();
-  const bool check = !plan->tune.colslab_const;
+  const int check = plan->tune.colslab_const ? -1 : plan->tune.values_tracking;
   constexpr int kReps = 5;
   for (int phase = 0; phase < 2; ++phase) {                     // phase 0 warms both up
     if (phase == 1 && hipEventRecord(ev[0], st) != hipSuccess) return drop();
@@ -1028,17 +1051,10 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
   const YT* x    = (const YT*)dx;
   YT* y          = (YT*)dy;
   if (trans) {
-    if (plan && plan->tile != 0 && plan->tune.explicit_transpose && A->nnz >= (int64_t)plan->tune.explicit_transpose_min_knnz * 1000 &&
-        transpose_fits<OffT, AT>(plan, A) && ensure_transpose<OffT, AT>(plan, A, st) == KKAMD_OK) {
-      if (plan->tune.explicit_transpose != 2 || !plan->t_values_valid) {
-        const int rc = values_refresh(A->offset_type, A->value_type, A->nnz, A->d_values, plan->d_t_perm, plan->d_t_val, plan->d_t_fp, plan->t_fp_valid ? 0 : 2, st);
-        if (rc) return rc;
-        plan->t_fp_valid = true;
-        plan->t_values_valid = true;
-      }
-      kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, plan->d_t_rm, plan->d_t_ent, plan->d_t_val, A->offset_type, A->value_type};
-      return spmv_typed<OffT, AT, YT>(plan->t_plan, &At, false, alpha_d, dx, beta_d, dy, st);
-    }
+    kkamd_crs_t At{}; kkamd_spmv_plan* tplan = nullptr;
+    const int rc = transpose_view_t<OffT, AT>(plan, A, st, &At, &tplan);
+    if (rc) return rc;
+    if (tplan) return spmv_typed<OffT, AT, YT>(tplan, &At, false, alpha_d, dx, beta_d, dy, st);
     return run_transpose<OffT, AT, YT>(A, x, y, alpha, beta, st);
   }
   if constexpr (sizeof(YT) == 8) {
@@ -1052,7 +1068,7 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
   if (stream_usable(plan, A, (int)sizeof(AT))) {
     if (plan->tune.colslab && plan->entries == A->d_entries) {
       if (!plan->cs_tried) { const int rc = colslab_select<OffT, AT, YT>(plan, A, x, st); if (rc) return rc; }
-      if (plan->cs) return cs_apply(plan->cs, A, scalar_tag<YT>::value, x, y, (double)alpha, (double)beta, !plan->tune.colslab_const, st);
+      if (plan->cs) return cs_apply(plan->cs, A, scalar_tag<YT>::value, x, y, (double)alpha, (double)beta, plan->tune.colslab_const ? -1 : plan->tune.values_tracking, st);
     }
     return run_stream<OffT, AT, YT>(plan, A, x, y, alpha, beta, st);
   }
@@ -1144,6 +1160,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "colslab") { if (value < 0 || value > 2) return bad("in 0..2"); t.colslab = value; }
   else if (k == "colslab_min_knnz") { if (value < 0) return bad("non-negative"); t.colslab_min_knnz = value; }
   else if (k == "colslab_shift") { if (value != 0 && (value < 2 || value > 30)) return bad("0 or in 2..30"); t.colslab_shift = value; }
+  else if (k == "values_tracking") { if (value < 0 || value > 2) return bad("in 0..2"); t.values_tracking = value; }
   else if (k == "colslab_const") { if (value != 0 && value != 1) return bad("0 or 1"); t.colslab_const = value; }
   else if (k == "transient_min_knnz") { if (value < 0) return bad("non-negative"); t.transient_min_knnz = value; }
   else if (k == "explicit_transpose") { if (value < 0 || value > 2) return bad("in 0..2"); t.explicit_transpose = value; }
@@ -1441,6 +1458,7 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   if (plan->d_t_ent) (void)hipFree(plan->d_t_ent);
   if (plan->d_t_perm) (void)hipFree(plan->d_t_perm);
   if (plan->d_t_fp) (void)hipFree(plan->d_t_fp);
+  if (plan->d_t_shadow) (void)hipFree(plan->d_t_shadow);
   if (plan->d_t_val) (void)hipFree(plan->d_t_val);
   if (plan->t_plan) kkamd_spmv_plan_destroy(plan->t_plan);
   delete plan;
@@ -1483,6 +1501,11 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
     kk::mv5_plan_destroy(plan->mv5); plan->mv5 = nullptr; plan->mv5_tried = false;
   }
+  if (t.values_tracking != old.values_tracking || t.explicit_transpose != old.explicit_transpose || t.colslab_const != old.colslab_const) {
+    // another policy: whatever the copies recorded under the old one is void, the next call copies every value
+    plan->t_stale = true; plan->t_fp_valid = false; plan->t_shadow_valid = false;
+    kk::cs_reset_tracking(plan->cs);
+  }
   if ((t.mv6 != old.mv6) && (plan->mv6 || plan->mv6_tried) && t.mv6 == 0) {
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
     kk::mv6_plan_destroy(plan->mv6); plan->mv6 = nullptr; plan->mv6_tried = false;
@@ -1492,6 +1515,14 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
     if (plan->d_mv_long) { KK_HIP(hipFree(plan->d_mv_long)); plan->d_mv_long = nullptr; }
     plan->mv_long_known = false; plan->n_mv_long = 0; plan->mv_long_T = 0; plan->mv_long_nnz = 0;
   }
+  return KKAMD_OK;
+}
+
+/* the caller changed A.values: re-ordered copies the plan keeps (cached transpose, column-slab copy) copy them again at the next call */
+int kkamd_spmv_plan_values_changed(kkamd_spmv_plan_t* plan) {
+  if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_values_changed: null plan");
+  plan->t_stale = true;
+  kk::cs_mark_stale(plan->cs);
   return KKAMD_OK;
 }
 

@@ -7,10 +7,18 @@
 // slab at the same time, x comes out of L2, and every product goes to y through a global fp64/fp32 atomic add -- consecutive lanes
 // hold consecutive rows, so a wave's atomics fall into a handful of lines; runs of one row inside a wave are folded first.
 //   measured (tools/proto/colslab.py, one MI355X): uniform random 5e6 x 20: 1.76 -> 0.74 ms; R-MAT scale 22: 0.54 -> 0.43 ms.
-// The matrix values may change between calls (the handle is bound to the matrix, not to its values): every 4096-value tile of
-// A.values carries a 128-bit fingerprint (two independent multiply-add sums with position-dependent odd multipliers: one changed
-// value always changes them, any other change escapes with probability 2^-128); a call first re-fingerprints the values (8 bytes
-// per nonzero read) and moves the tiles that changed into the copy.  Knob colslab_const = 1 promises constant values.
+// The matrix values may change between calls (the handle is bound to the matrix, not to its values; the reference's plug-ins read
+// A.values through the pointer at every call, sparse/tpls/KokkosSparse_spmv_tpl_spec_decl.hpp:386-425), so a re-ordered copy of them must
+// be kept current.  Knob "values_tracking" (it also governs the cached transpose of modes T / H, kk_spmv.hip):
+//   0 (default) EXACT: the plan keeps a shadow copy of A.values in A's own order; every call streams both (2 x 8 bytes per nonzero),
+//     compares them bit for bit tile by tile (4096 values) and moves the tiles that differ into the re-ordered copy (and the shadow);
+//   1 NOTIFY: the caller says when the values changed (kkamd_spmv_plan_values_changed); the next call then copies all of them, calls in
+//     between read nothing extra;
+//   2 FINGERPRINTS: 128 bits per tile (two sums of products of the value's two 32-bit halves, each mixed with position-dependent
+//     constants: not linear in the values), one stream of 8 bytes per nonzero, no shadow copy.  A changed tile whose fingerprint does
+//     not change is missed -- for unstructured changes that takes a 2^-64-ish coincidence per sum, but it is a heuristic, not a proof;
+//     callers who need certainty use 0 or 1.
+// "colslab_const" = 1 promises constant values (no pass at all; = NOTIFY without notifications).
 // Costs nnz * (8 + sizeof(value) + sizeof(offset)) bytes of plan memory.  The summation order differs from the CRS kernel's
 // (slab by slab, atomics): results agree to rounding, not bit for bit, and vary from run to run in the last bits.
 // No reference counterpart: KokkosSparse's native SpMV (sparse/impl/KokkosSparse_spmv_impl.hpp:104-160) and the rocSPARSE
@@ -30,7 +38,9 @@ struct kkamd_cs_plan {
   int32_t* d_col = nullptr;
   void* d_val = nullptr;                 // [nnz] values in slab order
   void* d_dst = nullptr;                 // [nnz] offset type: where entry i of A sits in the slab order
-  unsigned long long* d_fp = nullptr;    // [2 * ntiles] fingerprints of A.values, tile by tile
+  unsigned long long* d_fp = nullptr;    // [2 * ntiles] fingerprints of A.values, tile by tile (values_tracking 2)
+  void* d_shadow = nullptr;              // [nnz] A.values as the copy last saw them (values_tracking 0; allocated on first use)
+  bool fp_valid = false, shadow_valid = false, shadow_failed = false, stale = false;
   size_t bytes = 0;
 };
 
@@ -133,22 +143,53 @@ __device__ __forceinline__ unsigned long long cs_bits(double v) { return (unsign
 __device__ __forceinline__ unsigned long long cs_bits(float v) { return (unsigned long long)(unsigned)__float_as_int(v); }
 
 // MODE 0: tiles whose fingerprint moved are copied into their places (o_val[dst[i]] = val[i]) again; 1: record the fingerprints only
-// (the copy was just made from these values); 2: record them and copy every tile (the copy holds nothing yet)
+// (the copy was just made from these values); 2: record them and copy every tile (the copy holds nothing yet); 3: EXACT -- tiles that
+// differ from the shadow copy bit for bit are copied (into the shadow too); 4: copy every tile (and fill the shadow when there is one)
 template <class OffT, class AT, int MODE>
 __global__ __launch_bounds__(kBlock) void cs_check_kernel(int64_t nnz, const AT* __restrict__ val, const OffT* __restrict__ dst, AT* __restrict__ o_val,
-                                                          unsigned long long* __restrict__ fp) {
+                                                          unsigned long long* __restrict__ fp, AT* __restrict__ shadow) {
   __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
   __shared__ int s_diff;
   const int64_t base = (int64_t)blockIdx.x * kCsTile;
   AT v[kCsPer];
+  if (MODE >= 3) {
+    if (MODE == 3) {
+      if (threadIdx.x == 0) s_diff = 0;
+      __syncthreads();
+      bool diff = false;
+      KK_UNROLL
+      for (int u = 0; u < kCsPer; ++u) {
+        const int64_t i = base + (int64_t)u * kBlock + threadIdx.x;
+        v[u] = i < nnz ? val[i] : AT(0);
+        const AT old = i < nnz ? shadow[i] : AT(0);
+        diff |= cs_bits(v[u]) != cs_bits(old);
+      }
+      if (diff) s_diff = 1;
+      __syncthreads();
+      if (!s_diff) return;
+    } else {
+      KK_UNROLL
+      for (int u = 0; u < kCsPer; ++u) { const int64_t i = base + (int64_t)u * kBlock + threadIdx.x; v[u] = i < nnz ? val[i] : AT(0); }
+    }
+    KK_UNROLL
+    for (int u = 0; u < kCsPer; ++u) {
+      const int64_t i = base + (int64_t)u * kBlock + threadIdx.x;
+      if (i < nnz) { o_val[dst[i]] = v[u]; if (shadow) shadow[i] = v[u]; }
+    }
+    return;
+  }
   unsigned long long a = 0, b = 0;
   KK_UNROLL
   for (int u = 0; u < kCsPer; ++u) {
     const int64_t i = base + (int64_t)u * kBlock + threadIdx.x;
     v[u] = i < nnz ? val[i] : AT(0);
     const unsigned long long bits = cs_bits(v[u]);
-    a += bits * (cs_mix((unsigned long long)i) | 1ull);
-    b += ((bits << 29) | (bits >> 35)) * (cs_mix((unsigned long long)i ^ 0x5851F42D4C957F2Dull) | 1ull);
+    // products of the value's halves, each first mixed with a constant of its position: not linear in the value bits (flipping the
+    // sign of an even number of values, or scaling by two, moved the round-3 linear sums by 0 or by a multiple of a power of two)
+    const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+    const unsigned k1 = ((unsigned)i * 0x9E3779B1u) ^ ((unsigned)((unsigned long long)i >> 32) * 0x85EBCA6Bu), k2 = (k1 << 16 | k1 >> 16) ^ 0xC2B2AE35u;
+    a += (unsigned long long)(lo ^ k1) * (unsigned long long)((hi + k2) | 1u);
+    b += (unsigned long long)(((lo << 13) | (lo >> 19)) + k2) * (unsigned long long)(((hi ^ (lo >> 7)) ^ k1) | 1u) + (bits ^ ((unsigned long long)k2 << 32 | k1));
   }
   a = group_sum(a, 64); b = group_sum(b, 64);
   if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
@@ -171,23 +212,45 @@ __global__ __launch_bounds__(kBlock) void cs_check_kernel(int64_t nnz, const AT*
 }
 
 template <class OffT, class AT>
-static int values_refresh_typed(int64_t nnz, const void* val, const void* dst, void* o_val, unsigned long long* fp, int mode, hipStream_t st) {
+static int values_refresh_typed(int64_t nnz, const void* val, const void* dst, void* o_val, unsigned long long* fp, void* shadow, int mode, hipStream_t st) {
   const unsigned grid = (unsigned)ceil_div(nnz, (int64_t)kCsTile);
-  const AT* v = (const AT*)val; const OffT* d = (const OffT*)dst; AT* o = (AT*)o_val;
-  if (mode == 0)      { KK_LAUNCH((cs_check_kernel<OffT, AT, 0>), grid, kBlock, 0, st, nnz, v, d, o, fp); }
-  else if (mode == 1) { KK_LAUNCH((cs_check_kernel<OffT, AT, 1>), grid, kBlock, 0, st, nnz, v, d, o, fp); }
-  else                { KK_LAUNCH((cs_check_kernel<OffT, AT, 2>), grid, kBlock, 0, st, nnz, v, d, o, fp); }
+  const AT* v = (const AT*)val; const OffT* d = (const OffT*)dst; AT* o = (AT*)o_val; AT* sh = (AT*)shadow;
+  if (mode == 0)      { KK_LAUNCH((cs_check_kernel<OffT, AT, 0>), grid, kBlock, 0, st, nnz, v, d, o, fp, sh); }
+  else if (mode == 1) { KK_LAUNCH((cs_check_kernel<OffT, AT, 1>), grid, kBlock, 0, st, nnz, v, d, o, fp, sh); }
+  else if (mode == 2) { KK_LAUNCH((cs_check_kernel<OffT, AT, 2>), grid, kBlock, 0, st, nnz, v, d, o, fp, sh); }
+  else if (mode == 3) { KK_LAUNCH((cs_check_kernel<OffT, AT, 3>), grid, kBlock, 0, st, nnz, v, d, o, fp, sh); }
+  else                { KK_LAUNCH((cs_check_kernel<OffT, AT, 4>), grid, kBlock, 0, st, nnz, v, d, o, fp, sh); }
   KK_LAUNCH_CHECK();
   return KKAMD_OK;
 }
-// A re-ordered copy of a matrix's values (o_val[dst[i]] = val[i]) kept current through per-tile fingerprints fp[2 * ceil(nnz / 4096)]
-// (see the head of this file); also what the cached transpose of modes T / H uses (kk_spmv.hip)
+// A re-ordered copy of a matrix's values (o_val[dst[i]] = val[i]) kept current (see the head of this file); also what the cached
+// transpose of modes T / H uses (kk_spmv.hip).  mode: the MODE of cs_check_kernel (0..2 want fp, 3 wants shadow, 4 takes it when given)
 int64_t values_fp_tiles(int64_t nnz) { return ceil_div(nnz, (int64_t)kCsTile); }
-int values_refresh(int offset_type, int value_type, int64_t nnz, const void* val, const void* dst, void* o_val, unsigned long long* fp, int mode, hipStream_t st) {
+int values_refresh(int offset_type, int value_type, int64_t nnz, const void* val, const void* dst, void* o_val, unsigned long long* fp, void* shadow, int mode, hipStream_t st) {
   if (nnz <= 0) return KKAMD_OK;
   const bool o64 = offset_type == KKAMD_I64;
-  if (value_type == KKAMD_F64) return o64 ? values_refresh_typed<int64_t, double>(nnz, val, dst, o_val, fp, mode, st) : values_refresh_typed<int32_t, double>(nnz, val, dst, o_val, fp, mode, st);
-  return o64 ? values_refresh_typed<int64_t, float>(nnz, val, dst, o_val, fp, mode, st) : values_refresh_typed<int32_t, float>(nnz, val, dst, o_val, fp, mode, st);
+  if (value_type == KKAMD_F64) return o64 ? values_refresh_typed<int64_t, double>(nnz, val, dst, o_val, fp, shadow, mode, st) : values_refresh_typed<int32_t, double>(nnz, val, dst, o_val, fp, shadow, mode, st);
+  return o64 ? values_refresh_typed<int64_t, float>(nnz, val, dst, o_val, fp, shadow, mode, st) : values_refresh_typed<int32_t, float>(nnz, val, dst, o_val, fp, shadow, mode, st);
+}
+// One policy for both re-ordered copies.  tracking: the knob (0 exact, 1 notify, 2 fingerprints); promise: the caller's constant-values
+// promise; the flags are the copy's state (the copy is current when this returns).
+int values_track(int tracking, bool promise, int offset_type, int value_type, int64_t nnz, const void* val, const void* dst, void* o_val,
+                 unsigned long long* fp, void** shadow, bool* fp_valid, bool* shadow_valid, bool* shadow_failed, bool* stale, hipStream_t st) {
+  const size_t vb = value_type == KKAMD_F64 ? 8 : 4;
+  int rc = KKAMD_OK;
+  if (promise || tracking == 1) {
+    if (*stale) { rc = values_refresh(offset_type, value_type, nnz, val, dst, o_val, fp, nullptr, 4, st); *fp_valid = false; *shadow_valid = false; }
+  } else if (tracking == 2) {
+    rc = values_refresh(offset_type, value_type, nnz, val, dst, o_val, fp, nullptr, (*fp_valid && !*stale) ? 0 : 2, st);
+    *fp_valid = true; *shadow_valid = false;
+  } else {
+    if (!*shadow && !*shadow_failed && hipMalloc(shadow, vb * (size_t)nnz) != hipSuccess) { (void)hipGetLastError(); *shadow = nullptr; *shadow_failed = true; }
+    if (*shadow) { rc = values_refresh(offset_type, value_type, nnz, val, dst, o_val, fp, *shadow, (*shadow_valid && !*stale) ? 3 : 4, st); *shadow_valid = true; }
+    else rc = values_refresh(offset_type, value_type, nnz, val, dst, o_val, fp, nullptr, 4, st);      // no memory for the shadow: copy everything, every call
+    *fp_valid = false;
+  }
+  *stale = false;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -231,10 +294,13 @@ __global__ __launch_bounds__(kBlock) void cs_spmv_kernel(int64_t nnz, const int3
 // ------------------------------------------------------------------------------------------------
 void cs_plan_destroy(kkamd_cs_plan* cs) {
   if (!cs) return;
-  void* bufs[] = {cs->d_row, cs->d_col, cs->d_val, cs->d_dst, cs->d_fp};
+  void* bufs[] = {cs->d_row, cs->d_col, cs->d_val, cs->d_dst, cs->d_fp, cs->d_shadow};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete cs;
 }
+
+void cs_mark_stale(kkamd_cs_plan* cs) { if (cs) cs->stale = true; }
+void cs_reset_tracking(kkamd_cs_plan* cs) { if (cs) { cs->stale = true; cs->fp_valid = false; cs->shadow_valid = false; } }
 
 int64_t cs_plan_query(const kkamd_cs_plan* cs, int what) {
   if (!cs) return 0;
@@ -275,7 +341,7 @@ static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, 
   const int nslabs = cs->nslabs; const int64_t ntiles = cs->ntiles;
   KK_LAUNCH((cs_scatter_kernel<OffT, AT>), (unsigned)ntiles, kBlock, 0, st, A->num_rows, nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries,
             (const AT*)A->d_values, shift, nslabs, nbits, ntiles, (const int64_t*)H, o_row, o_col, o_val, dst);
-  if (values_refresh(A->offset_type, A->value_type, nnz, A->d_values, dst, o_val, fp, 1, st)) return give_up();
+  // the scatter kernel copied the values: the copy is current, nothing is recorded yet (the first tracked call fills shadow / fingerprints)
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return give_up();
   *out = cs;
   return KKAMD_OK;
@@ -305,10 +371,12 @@ int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_kn
 }
 
 template <class OffT, class AT, class YT>
-static int cs_apply_typed(kkamd_cs_plan* cs, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, bool check, hipStream_t st) {
+static int cs_apply_typed(kkamd_cs_plan* cs, const kkamd_crs_t* A, const YT* x, YT* y, YT alpha, YT beta, int tracking, hipStream_t st) {
   const int64_t nnz = cs->nnz;
   AT* o_val = (AT*)cs->d_val;
-  int rc = check ? values_refresh(A->offset_type, A->value_type, nnz, A->d_values, cs->d_dst, o_val, cs->d_fp, 0, st) : KKAMD_OK;
+  // tracking: the "values_tracking" knob, or -1 = the caller promised constant values
+  int rc = values_track(tracking < 0 ? 1 : tracking, tracking < 0, A->offset_type, A->value_type, nnz, A->d_values, cs->d_dst, o_val, cs->d_fp, &cs->d_shadow,
+                        &cs->fp_valid, &cs->shadow_valid, &cs->shadow_failed, &cs->stale, st);
   if (rc) return rc;
   rc = launch_scale<YT>(y, A->num_rows, 1, 1, 0, beta, st);
   if (rc) return rc;
@@ -318,19 +386,19 @@ static int cs_apply_typed(kkamd_cs_plan* cs, const kkamd_crs_t* A, const YT* x, 
   return KKAMD_OK;
 }
 
-int cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, bool check, hipStream_t st) {
+int cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, int tracking, hipStream_t st) {
   if (cs->nnz != A->nnz || cs->offset_type != A->offset_type || cs->value_type != A->value_type)
     return fail(KKAMD_ERR_STATE, "kkamd_spmv: the column-slab copy belongs to another matrix");
   const bool o64 = A->offset_type == KKAMD_I64;
   if (A->value_type == KKAMD_F64 && vector_type == KKAMD_F64)
-    return o64 ? cs_apply_typed<int64_t, double, double>(cs, A, (const double*)x, (double*)y, alpha, beta, check, st)
-               : cs_apply_typed<int32_t, double, double>(cs, A, (const double*)x, (double*)y, alpha, beta, check, st);
+    return o64 ? cs_apply_typed<int64_t, double, double>(cs, A, (const double*)x, (double*)y, alpha, beta, tracking, st)
+               : cs_apply_typed<int32_t, double, double>(cs, A, (const double*)x, (double*)y, alpha, beta, tracking, st);
   if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F32)
-    return o64 ? cs_apply_typed<int64_t, float, float>(cs, A, (const float*)x, (float*)y, (float)alpha, (float)beta, check, st)
-               : cs_apply_typed<int32_t, float, float>(cs, A, (const float*)x, (float*)y, (float)alpha, (float)beta, check, st);
+    return o64 ? cs_apply_typed<int64_t, float, float>(cs, A, (const float*)x, (float*)y, (float)alpha, (float)beta, tracking, st)
+               : cs_apply_typed<int32_t, float, float>(cs, A, (const float*)x, (float*)y, (float)alpha, (float)beta, tracking, st);
   if (A->value_type == KKAMD_F32 && vector_type == KKAMD_F64)
-    return o64 ? cs_apply_typed<int64_t, float, double>(cs, A, (const double*)x, (double*)y, alpha, beta, check, st)
-               : cs_apply_typed<int32_t, float, double>(cs, A, (const double*)x, (double*)y, alpha, beta, check, st);
+    return o64 ? cs_apply_typed<int64_t, float, double>(cs, A, (const double*)x, (double*)y, alpha, beta, tracking, st)
+               : cs_apply_typed<int32_t, float, double>(cs, A, (const double*)x, (double*)y, alpha, beta, tracking, st);
   return fail(KKAMD_ERR_UNSUPPORTED, "kkamd_spmv: unsupported (value,vector) type pair (%d,%d)", A->value_type, vector_type);
 }
 

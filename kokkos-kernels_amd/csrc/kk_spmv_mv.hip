@@ -1572,6 +1572,14 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
   YT* Y          = (YT*)dY;
   const int remap = (plan ? plan->tune.xcd_remap : g_spmv_default.xcd_remap) == 1;
   if (trans) {
+    // an analysed handle runs the rank-2 dispatch for mode N on its cached transpose (built on first use, values kept current under the
+    // "values_tracking" policy; kk_spmv.hip): no atomics, deterministic.  Otherwise the reference's scatter (spmv_impl.hpp:547-632)
+    if (plan) {
+      kkamd_crs_t At{}; kkamd_spmv_plan* tplan = nullptr;
+      const int rc = transpose_view(plan, A, st, &At, &tplan);
+      if (rc) return rc;
+      if (tplan) return spmv_mv_typed<OffT, AT, YT>(tplan, &At, false, alpha_d, dX, xs0, xs1, beta_d, dY, ys0, ys1, nvec, st);
+    }
     int rc = launch_scale<YT>(Y, A->num_cols, ys0, nvec, ys1, beta, st);
     if (rc) return rc;
     KK_LAUNCH((spmv_mv_transpose_kernel<OffT, AT, YT>), (unsigned)ceil_div(A->num_rows, kBlock / 16), kBlock, 0, st,
@@ -1661,7 +1669,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
         if (plan && plan->tile != 0 && plan->tune.mv6 != 0 && (mvk == 0 || mvk == 6) && plan->entries == A->d_entries && plan->row_map == A->d_row_map &&
             (plan->tune.mv6 == 2 || plan->mv_long_nnz * 100 >= (int64_t)plan->tune.mv6_min_long_pct * A->nnz)) {
           if (!plan->mv6 && !plan->mv6_tried) { const int rc = mv6_plan_build(plan, A, st); if (rc) return rc; }
-          if (plan->mv6) return mv6_spmv(plan, A, (const double*)Xr, ldx, 1, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
+          if (plan->mv6) return mv6_spmv(plan, A, (const double*)Xr, ldx, (double*)Y, ys0, ys1, nvec, (double)alpha, (double)beta, st);
         }
       }
       // rows above long_T entries, after the gather kernel has written beta * Y there (called by the launch macro below)

@@ -7,10 +7,10 @@
 // longest row of the 16 sets the wave's trip count, rows above a threshold handed to a workgroup each) ran R-MAT scale 22 x 16 in
 // 1.28 + 1.83 ms.  Here:
 //
-//   * the nonzero stream is cut into CHUNKS of 128 entries, one per 16-lane group (four chunks per wave).  Lane j of a group carries
-//     right-hand side j: an X row is one 128-byte load of the group, a wave instruction gathers four X rows.  A group walks its chunk
-//     16 entries at a time: the 16 (column, row, value) triples arrive with one coalesced load each and are laid down in wave-private
-//     LDS, all 16 X gathers are issued, then the products are added up run by run of equal row index.
+//   * the nonzero stream is cut into CHUNKS of 128 entries, one per 8-lane group (eight chunks per wave).  Lane j of a group carries
+//     right-hand sides 2 j and 2 j + 1: an X row is eight 16-byte loads, a wave instruction gathers eight X rows.  A group walks its
+//     chunk 8 entries at a time: the (column, row, value) triples arrive with one coalesced load each and are laid down in wave-private
+//     LDS, all 8 X gathers are issued, then the products are added up run by run of equal row index.
 //   * the plan keeps the ROW INDEX of every nonzero (4 bytes per nonzero, built once from row_map): a group finds its row boundaries
 //     without searching row_map, and every group does the same amount of work whatever the row lengths.
 //   * a run that ends inside the chunk is a finished row: y = beta y + alpha sum, stored by the group.  The first run of a chunk when it
@@ -23,7 +23,7 @@
 #include <climits>
 
 namespace kk {
-constexpr int kMv6E = 128;       // entries per chunk (per 16-lane group)
+constexpr int kMv6E = 128;       // entries per chunk (per 8-lane group)
 struct alignas(16) Mv6Ent { int col, row; double val; };
 }  // namespace kk
 
@@ -81,69 +81,94 @@ __global__ __launch_bounds__(kBlock) void mv6_empty_rows_kernel(int64_t n, const
   *yp = (beta == 0.0) ? 0.0 : beta * (*yp);
 }
 
-// carry slots of chunk g: head at (2 g) * 16, tail at (2 g + 1) * 16
-template <class AT>
+// carry slots of chunk g: head at (2 g) * 16, tail at (2 g + 1) * 16.
+// Eight lanes per chunk, two right-hand sides per lane: an X row is eight 16-byte loads, a wave instruction gathers eight X rows (a
+// 16-byte lane moves 64 B per quad and cycle through the texture path, an 8-byte lane half of that: the first form of this kernel, 16
+// lanes x 8 bytes, ran banded 1e7 x 12 in 2.6 ms where the 16-byte gather kernel takes 1.48).  X must be row-major with an even leading
+// dimension and 16-byte aligned (the caller packs anything else).  Y_VEC: Y rows are 16-byte aligned pairs as well.
+template <class AT, bool Y_VEC>
 __global__ __launch_bounds__(kBlock) void spmv_mv6_kernel(int64_t nnz, const int32_t* __restrict__ entries, const AT* __restrict__ values,
-                                                          const int32_t* __restrict__ rowid, const double* __restrict__ X, int64_t xs0, int64_t xs1,
+                                                          const int32_t* __restrict__ rowid, const double* __restrict__ X, int64_t ldx,
                                                           double* __restrict__ Y, int64_t ys0, int64_t ys1, double alpha, double beta, int ncv,
                                                           double* __restrict__ carry, int remap) {
+  using XV = kk_f64x2;
+  constexpr int GL = 8, NG = kWave / GL;                         // lanes per chunk, chunks per wave
   __shared__ Mv6Ent s_ent_all[kBlock / kWave][kWave];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, grp = lane >> 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & (GL - 1), grp = lane / GL;
   Mv6Ent* s_ent = s_ent_all[w];
   const int64_t wave = xcd_order(blockIdx.x, gridDim.x, remap) * (kBlock / kWave) + w;
-  if (wave * 4 * kMv6E >= nnz) return;                           // the whole wave leaves together
-  const int64_t g = wave * 4 + grp;
+  if (wave * NG * kMv6E >= nnz) return;                          // the whole wave leaves together
+  const int64_t g = wave * NG + grp;
   const int64_t e0 = g * kMv6E < nnz ? g * kMv6E : nnz, e1 = e0 + kMv6E < nnz ? e0 + kMv6E : nnz;
   const int prev_row = (e0 > 0 && e0 < nnz) ? rowid[e0 - 1] : -1;
   const int next_row = (e1 < nnz) ? rowid[e1] : -1;
-  const double* __restrict__ xc = X + (int64_t)(j < ncv ? j : ncv - 1) * xs1;
+  const bool have = 2 * j < ncv, have2 = 2 * j + 1 < ncv;        // the lane's two columns exist in this block
+  const double* __restrict__ xc = X + (have ? 2 * j : 0);
   double* __restrict__ cg = carry + g * 32;
   int cur_row = -1;
   bool open_left = false;
-  double acc = 0.0;
+  double acc0 = 0.0, acc1 = 0.0;
   auto flush = [&]() {                                           // the run of cur_row ends inside the chunk
-    if (open_left) cg[j] = acc;                                  // ... but began in an earlier chunk: its head piece
-    else if (j < ncv) {
-      double* yp = Y + (int64_t)cur_row * ys0 + j * ys1;
-      *yp = (beta == 0.0) ? alpha * acc : beta * (*yp) + alpha * acc;
+    if (open_left) { cg[2 * j] = acc0; cg[2 * j + 1] = acc1; }   // ... but began in an earlier chunk: its head piece
+    else if (have) {
+      double* yp = Y + (int64_t)cur_row * ys0 + 2 * j * ys1;
+      if (Y_VEC && have2) {
+        XV out;
+        if (beta == 0.0) { out[0] = alpha * acc0; out[1] = alpha * acc1; }
+        else { const XV old = *reinterpret_cast<const XV*>(yp); out[0] = beta * old[0] + alpha * acc0; out[1] = beta * old[1] + alpha * acc1; }
+        *reinterpret_cast<XV*>(yp) = out;
+      } else {
+        yp[0] = (beta == 0.0) ? alpha * acc0 : beta * yp[0] + alpha * acc0;
+        if (have2) yp[ys1] = (beta == 0.0) ? alpha * acc1 : beta * yp[ys1] + alpha * acc1;
+      }
     }
     open_left = false;
   };
-  for (int rd = 0; rd < kMv6E / 16; ++rd) {
-    const int64_t base = e0 + rd * 16, idx = base + j;
+  for (int rd = 0; rd < kMv6E / GL; ++rd) {
+    const int64_t base = e0 + rd * GL, idx = base + j;
     const bool ok = idx < e1;
     Mv6Ent me;
     me.col = ok ? entries[idx] : 0; me.row = ok ? rowid[idx] : -1; me.val = ok ? (double)values[idx] : 0.0;
     KK_WAVE_SYNC();
     s_ent[lane] = me;
     KK_WAVE_SYNC();
-    const int nq = (int)(e1 - base < 16 ? (e1 - base > 0 ? e1 - base : 0) : 16);      // entries of this round (the same in the group's 16 lanes)
-    double x[16];
+    const int nq = (int)(e1 - base < GL ? (e1 - base > 0 ? e1 - base : 0) : GL);      // entries of this round (the same in the group's lanes)
+    XV x[GL];
     KK_UNROLL
-    for (int q = 0; q < 16; ++q) { x[q] = 0.0; if (q < nq) x[q] = xc[(int64_t)s_ent[grp * 16 + q].col * xs0]; }
+    for (int q = 0; q < GL; ++q) {
+      x[q] = XV{0.0, 0.0};
+      if (q < nq && have) {
+        const double* xp = xc + (int64_t)s_ent[grp * GL + q].col * ldx;
+        if (have2) x[q] = *reinterpret_cast<const XV*>(xp);
+        else x[q][0] = *xp;                                      // the odd last column of the block: nothing is read past it
+      }
+    }
     KK_UNROLL
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < GL; ++q) {
       if (q < nq) {
-        const Mv6Ent e = s_ent[grp * 16 + q];
+        const Mv6Ent e = s_ent[grp * GL + q];
         if (e.row != cur_row) {
           if (cur_row >= 0) flush();
           else open_left = (e.row == prev_row);                  // the chunk's first entry
-          cur_row = e.row; acc = 0.0;
+          cur_row = e.row; acc0 = 0.0; acc1 = 0.0;
         }
-        acc += e.val * x[q];
+        acc0 += e.val * x[q][0]; acc1 += e.val * x[q][1];
       }
     }
   }
   if (cur_row >= 0) {
-    if (cur_row == next_row) cg[(open_left ? 0 : 16) + j] = acc; // the next chunk goes on with this row: a tail piece (or, when the whole
-    else flush();                                                // chunk is the middle of one row, another head piece)
+    if (cur_row == next_row) { cg[(open_left ? 0 : 16) + 2 * j] = acc0; cg[(open_left ? 0 : 16) + 2 * j + 1] = acc1; }   // the next chunk goes on with
+    else flush();                                                // this row: a tail piece (or, when the whole chunk is the middle of one row, another head piece)
   }
 }
 
-// every row cut by a chunk boundary: the chunk that holds the row's LAST-but-open run as its tail (and is not itself all middle) adds the
-// head pieces of the chunks after it, in order, and stores the row.  16 lanes per chunk.
-__global__ __launch_bounds__(kBlock) void mv6_fixup_kernel(int64_t nnz, int64_t nchunks, const int32_t* __restrict__ rowid, const double* __restrict__ carry,
-                                                           double* __restrict__ Y, int64_t ys0, int64_t ys1, double alpha, double beta, int ncv) {
+// every row cut by a chunk boundary: the chunk that holds the row's first cut -- its last run goes on in the next chunk and is not itself
+// a continuation -- adds the head pieces of the chunks the row reaches into (their number follows from row_map: no search), in order,
+// and stores the row.  16 lanes per chunk, eight independent loads in flight on a long chain.
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv6_fixup_kernel(int64_t nnz, int64_t nchunks, const OffT* __restrict__ row_map, const int32_t* __restrict__ rowid,
+                                                           const double* __restrict__ carry, double* __restrict__ Y, int64_t ys0, int64_t ys1,
+                                                           double alpha, double beta, int ncv) {
   const int64_t g = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
   const int j = threadIdx.x & 15;
   if (g >= nchunks) return;
@@ -152,12 +177,17 @@ __global__ __launch_bounds__(kBlock) void mv6_fixup_kernel(int64_t nnz, int64_t 
   const int rl = rowid[e1 - 1];
   if (rl != rowid[e1]) return;                                   // its last run ends with the chunk
   if (e0 > 0 && rowid[e0] == rl && rowid[e0 - 1] == rl) return;  // all middle: the chunk where the row begins does the sum
+  const int64_t c_last = ((int64_t)row_map[rl + 1] - 1) / kMv6E; // the chunk that holds the row's last entry
   double sum = carry[g * 32 + 16 + j];
-  for (int64_t c = g + 1; c < nchunks; ++c) {
-    sum += carry[c * 32 + j];
-    const int64_t c1 = (c + 1) * kMv6E;
-    if (!(c1 < nnz && rowid[c * kMv6E] == rowid[c1 - 1] && rowid[c1 - 1] == rowid[c1])) break;   // chunk c was not all middle: the row ended there
+  int64_t c = g + 1;
+  for (; c + 8 <= c_last + 1; c += 8) {
+    double t[8];
+    KK_UNROLL
+    for (int u = 0; u < 8; ++u) t[u] = carry[(c + u) * 32 + j];
+    KK_UNROLL
+    for (int u = 0; u < 8; ++u) sum += t[u];
   }
+  for (; c <= c_last; ++c) sum += carry[c * 32 + j];
   if (j < ncv) {
     double* yp = Y + (int64_t)rl * ys0 + j * ys1;
     *yp = (beta == 0.0) ? alpha * sum : beta * (*yp) + alpha * sum;
@@ -204,20 +234,23 @@ int mv6_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st) 
   return A->offset_type == KKAMD_I64 ? mv6_plan_build_t<int64_t>(plan, A, st) : mv6_plan_build_t<int32_t>(plan, A, st);
 }
 
-template <class AT>
-static int mv6_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+template <class OffT, class AT>
+static int mv6_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0, int64_t ys1,
                       int64_t nvec, double alpha, double beta, hipStream_t st) {
   const kkamd_mv6_plan* p = plan->mv6;
-  const unsigned grid = (unsigned)ceil_div(p->nchunks, (int64_t)4 * (kBlock / kWave));
+  const unsigned grid = (unsigned)ceil_div(p->nchunks, (int64_t)8 * (kBlock / kWave));
+  const bool yv = ys1 == 1 && ys0 % 2 == 0 && (uintptr_t)Y % 16 == 0;
   for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
     const int ncv = (int)(nvec - c0 < 16 ? nvec - c0 : 16);
-    const double* Xb = X + c0 * xs1;
+    const double* Xb = X + c0;
     double* Yb = Y + c0 * ys1;
-    KK_LAUNCH((spmv_mv6_kernel<AT>), grid, kBlock, 0, st, A->nnz, (const int32_t*)A->d_entries, (const AT*)A->d_values, (const int32_t*)p->d_rowid, Xb, xs0, xs1,
-              Yb, ys0, ys1, alpha, beta, ncv, p->d_carry, plan->tune.mv_remap);
+    if (yv) KK_LAUNCH((spmv_mv6_kernel<AT, true>), grid, kBlock, 0, st, A->nnz, (const int32_t*)A->d_entries, (const AT*)A->d_values, (const int32_t*)p->d_rowid, Xb, ldx,
+                      Yb, ys0, ys1, alpha, beta, ncv, p->d_carry, plan->tune.mv_remap);
+    else    KK_LAUNCH((spmv_mv6_kernel<AT, false>), grid, kBlock, 0, st, A->nnz, (const int32_t*)A->d_entries, (const AT*)A->d_values, (const int32_t*)p->d_rowid, Xb, ldx,
+                      Yb, ys0, ys1, alpha, beta, ncv, p->d_carry, plan->tune.mv_remap);
     KK_LAUNCH_CHECK();
-    KK_LAUNCH(mv6_fixup_kernel, (unsigned)ceil_div(p->nchunks * 16, kBlock), kBlock, 0, st, A->nnz, p->nchunks, (const int32_t*)p->d_rowid,
-              (const double*)p->d_carry, Yb, ys0, ys1, alpha, beta, ncv);
+    KK_LAUNCH((mv6_fixup_kernel<OffT>), (unsigned)ceil_div(p->nchunks * 16, kBlock), kBlock, 0, st, A->nnz, p->nchunks, (const OffT*)A->d_row_map,
+              (const int32_t*)p->d_rowid, (const double*)p->d_carry, Yb, ys0, ys1, alpha, beta, ncv);
     KK_LAUNCH_CHECK();
     if (p->n_empty > 0) {
       KK_LAUNCH(mv6_empty_rows_kernel, (unsigned)ceil_div(p->n_empty * 16, kBlock), kBlock, 0, st, p->n_empty, (const int32_t*)p->d_empty, Yb, ys0, ys1, beta, ncv);
@@ -227,10 +260,13 @@ static int mv6_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   return KKAMD_OK;
 }
 
-int mv6_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+// X: row-major (element (i, k) at i * ldx + k), ldx even, 16-byte aligned
+int mv6_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0, int64_t ys1,
              int64_t nvec, double alpha, double beta, hipStream_t st) {
-  if (A->value_type == KKAMD_F64) return mv6_launch<double>(plan, A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, st);
-  return mv6_launch<float>(plan, A, X, xs0, xs1, Y, ys0, ys1, nvec, alpha, beta, st);
+  const bool o64 = A->offset_type == KKAMD_I64;
+  if (A->value_type == KKAMD_F64)
+    return o64 ? mv6_launch<int64_t, double>(plan, A, X, ldx, Y, ys0, ys1, nvec, alpha, beta, st) : mv6_launch<int32_t, double>(plan, A, X, ldx, Y, ys0, ys1, nvec, alpha, beta, st);
+  return o64 ? mv6_launch<int64_t, float>(plan, A, X, ldx, Y, ys0, ys1, nvec, alpha, beta, st) : mv6_launch<int32_t, float>(plan, A, X, ldx, Y, ys0, ys1, nvec, alpha, beta, st);
 }
 
 }  // namespace kk

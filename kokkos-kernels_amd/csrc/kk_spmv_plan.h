@@ -60,12 +60,17 @@ struct SpmvTuning {
   int pattern_codes = 1;           // staged-x tiles: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one
                                    // (27-pt 300^3 1.349 -> 1.267 ms, 7-pt 400^3 1.025 -> 0.940 ms), 2 = whenever any tile has one, 0 = never
   int pattern_codes_min_knnz = 10000;  // ... from this many thousand nnz (5-pt 1000^2, 5e6 nnz: 17.5 -> 18.3 us with the records)
-  int colslab = 1;                 // rank 1, mode N, matrices whose x gather defeats the caches (kk_spmv_colslab.hip): 1 = build the column-slab copy
-                                   // at the first call when the analysis says "gather-bound", time both kernels and keep the faster; 2 = always
-                                   // use the copy (tests); 0 = never
+  int colslab = 0;                 // rank 1, mode N, matrices whose x gather defeats the caches (kk_spmv_colslab.hip): 0 (default) = never: its
+                                   // products reach y through atomics (results vary in the last bits from run to run, the reference's are
+                                   // deterministic) and its selection times kernels inside the first call; 1 = build the column-slab copy at the
+                                   // first call when the analysis says "gather-bound", time both kernels and keep the faster; 2 = always use
+                                   // the copy (tests)
   int colslab_min_knnz = 20000;    // ... from this many thousand nnz
   int colslab_shift = 0;           // ... log2 of the columns per slab (0 = 2 MB of x)
-  int colslab_const = 0;           // ... 1 = the caller promises constant matrix values (no fingerprint pass per call)
+  int colslab_const = 0;           // ... 1 = the caller promises constant matrix values (no tracking pass per call)
+  int values_tracking = 0;         // how re-ordered copies of A.values (cached transpose, column-slab copy) follow value changes: 0 exact (bitwise
+                                   // comparison against a shadow copy, every call), 1 the caller notifies (kkamd_spmv_plan_values_changed), 2
+                                   // per-tile fingerprints (one stream, no shadow; a heuristic)
 #ifdef KK_ABLATE                   // measurement build only (tools/, libkkamd_ablate.so): never part of libkkamd.so
   int ablate         = 0;          // switches parts of the kernels off (see the kernels)
   int lds_pad_kb     = 0;          // extra dynamic LDS per workgroup (caps workgroups per CU)
@@ -119,7 +124,8 @@ struct kkamd_spmv_plan {
   // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)
   void* d_t_rm = nullptr; int32_t* d_t_ent = nullptr; void* d_t_perm = nullptr; void* d_t_val = nullptr; unsigned long long* d_t_fp = nullptr;
   kkamd_spmv_plan* t_plan = nullptr;
-  bool t_ready = false, t_failed = false, t_values_valid = false, t_fp_valid = false;
+  void* d_t_shadow = nullptr;    // A.values as the transpose last saw them (values_tracking 0)
+  bool t_ready = false, t_failed = false, t_fp_valid = false, t_shadow_valid = false, t_shadow_failed = false, t_stale = true;
   bool win_failed = false;       // the codes are not worth it on this matrix (or HBM cannot hold them): plain entries
   // rank-2 analysis (LDS-staged X tiles), built by the first rank-2 call that can use it
   kkamd_mv_plan* mv = nullptr;
@@ -168,15 +174,21 @@ int  mv5_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X
 void mv6_plan_destroy(kkamd_mv6_plan* p);
 int64_t mv6_plan_query(const kkamd_mv6_plan* p, int what);  // 0 chunks, 1 empty rows, 2 bytes
 int  mv6_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st);
-int  mv6_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
-              int64_t nvec, double alpha, double beta, hipStream_t st);
+int  mv6_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0, int64_t ys1,
+              int64_t nvec, double alpha, double beta, hipStream_t st);   // X row-major, ldx even, 16-byte aligned
 void cs_plan_destroy(kkamd_cs_plan* cs);
 int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes
 int  cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st);
-int  cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, bool check, hipStream_t st);
+int  cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, int tracking, hipStream_t st);
 int64_t values_fp_tiles(int64_t nnz);
-// mode 0: move the 4096-value tiles whose fingerprint changed (o_val[dst[i]] = val[i]); 1: record fingerprints; 2: record and move all
-int  values_refresh(int offset_type, int value_type, int64_t nnz, const void* val, const void* dst, void* o_val, unsigned long long* fp, int mode, hipStream_t st);
+// keeps a re-ordered copy of A.values (o_val[dst[i]] = val[i]) current under the "values_tracking" policy (kk_spmv_colslab.hip)
+int  values_track(int tracking, bool promise, int offset_type, int value_type, int64_t nnz, const void* val, const void* dst, void* o_val,
+                  unsigned long long* fp, void** shadow, bool* fp_valid, bool* shadow_valid, bool* shadow_failed, bool* stale, hipStream_t st);
+void cs_mark_stale(kkamd_cs_plan* cs);
+void cs_reset_tracking(kkamd_cs_plan* cs);
+// modes T / H of an analysed handle: the cached transpose (built on first use, values brought up to date) as a matrix + its plan;
+// returns KKAMD_OK with *tplan == nullptr when there is none (knob off, too small, no memory): the caller scatters with atomics
+int  transpose_view(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st, kkamd_crs_t* At, kkamd_spmv_plan** tplan);
 int  release_transient();
 int  release_bitmap_pool();      // kk_spgemm.hip: the pooled bitmap store of the SpGEMM symbolic -> numeric hand-over
 // rank 1 on the rank-2 plane-marching analysis (kk_spmv_mv.hip): builds the analysis on first use; returns 1 when it ran

@@ -60,6 +60,9 @@ struct SPMVHandleImpl {
     if (plan) KokkosSparse::Impl::kkamd_check(kkamd_spmv_plan_set(plan, key, value));
     else pending_.emplace_back(key, value);
   }
+  // the caller wrote to A.values: re-ordered copies the plan keeps (cached transpose of modes T / H, column-slab copy) copy them again
+  // at the next call (kkamd_spmv_plan_values_changed; required under the knob values_tracking = 1, optional otherwise)
+  void values_changed() { if (plan) KokkosSparse::Impl::kkamd_check(kkamd_spmv_plan_values_changed(plan)); }
   std::vector<std::pair<std::string, int>> pending_;
 };
 }  // namespace Impl

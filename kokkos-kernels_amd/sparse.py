@@ -128,6 +128,12 @@ class SPMVHandle:
         else:
             check(self.backend.lib, self.backend.lib.kkamd_spmv_plan_set(self._plan, key.encode(), int(value)))
 
+    def values_changed(self):
+        """the caller wrote to A.values: re-ordered copies the plan keeps (cached transpose, column-slab copy) copy them again at the next
+        call (kkamd_spmv_plan_values_changed; required under the knob values_tracking = 1, optional otherwise)"""
+        if self._plan is not None:
+            check(self.backend.lib, self.backend.lib.kkamd_spmv_plan_values_changed(self._plan))
+
     def query(self, key):
         """what the analysis produced (kkamd_spmv_plan_query); None before the first spmv call"""
         if self._plan is None: return None

@@ -181,6 +181,81 @@ def check_mv6(be, light=False):
         assert h.query("mv6_chunks") == 0
 
 
+def check_values_tracking(be):
+    """The re-ordered value copies of a plan (cached transpose, column-slab copy) under the three "values_tracking" policies: 0 exact
+    (default), 1 notify (SPMVHandle.values_changed), 2 fingerprints.  A.values is rewritten in place between calls: one value, every value,
+    two values swapped, a whole 4096-value tile negated and another doubled (the changes the round-3 linear fingerprint was blind or
+    nearly blind to), then nothing."""
+    lib = be.lib
+    kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 0))
+    try:
+        A0 = oracle.random_crs(2500, 2300, 10, variance=3, seed=8, sorted_rows=True)
+        rng = np.random.default_rng(1)
+        for what, mode, knobs in (("transpose", "T", {"explicit_transpose": 1}), ("colslab", "N", {"colslab": 2, "colslab_shift": 5})):
+            nin, nout = (A0.nrows, A0.ncols) if mode == "T" else (A0.ncols, A0.nrows)
+            x = rng.random(nin)
+            for tracking in (0, 1, 2):
+                A = dev(be, A0)
+                h = kk.SPMVHandle("SPMV_DEFAULT")
+                for k_, v_ in knobs.items(): h.set(k_, v_)
+                h.set("values_tracking", tracking)
+                xd, yd = be.from_numpy(x), be.from_numpy(np.zeros(nout))
+                v = A0.values.copy()
+                def run_and_check(tag):
+                    kk.spmv(h, mode, 1.0, A, xd, 0.0, yd)
+                    exp = oracle.spmv_sequential(mode, oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, v), 1.0, x, 0.0, np.zeros(nout))
+                    np.testing.assert_allclose(be.to_numpy(yd), exp, rtol=1e-12, atol=1e-12, err_msg="%s tracking %d after %s" % (what, tracking, tag))
+                run_and_check("the first call")
+                assert h.query("transpose_cached" if mode == "T" else "colslab") == 1
+                steps = (("one value", lambda: v.__setitem__(5000, -7.25)), ("every value", lambda: v.__imul__(3.0)),
+                         ("a swap", lambda: v.__setitem__([0, len(v) - 1], v[[len(v) - 1, 0]])),
+                         ("a tile negated", lambda: v.__setitem__(slice(4096, 8192), -v[4096:8192])),
+                         ("a tile doubled", lambda: v.__setitem__(slice(8192, 12288), 2.0 * v[8192:12288])), ("nothing", lambda: None))
+                for tag, change in steps:
+                    change()
+                    A.values[:] = be.from_numpy(v)
+                    if tracking == 1 and tag != "nothing": h.values_changed()
+                    run_and_check(tag)
+                # a notification is harmless under the other policies, and a change of policy starts over
+                h.values_changed(); run_and_check("a notification without a change")
+                h.set("values_tracking", (tracking + 1) % 3)
+                v[17] = 0.125; A.values[:] = be.from_numpy(v)
+                if (tracking + 1) % 3 == 1: h.values_changed()
+                run_and_check("a change of policy")
+    finally:
+        kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 1000))
+
+
+def check_mv_transpose_cached(be):
+    """Rank 2, modes T / H of an analysed handle run the mode-N dispatch on the cached transpose (no atomics): the four layout pairs,
+    a value update between the calls, a lattice matrix (its transpose takes the plane-marching kernel), a rectangular one, 64-bit
+    offsets; explicit_transpose 0 keeps the reference's atomic scatter."""
+    lib = be.lib
+    kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 0))
+    try:
+        for A0, maxv in ((oracle.random_crs(900, 700, 9, variance=3, seed=7, sorted_rows=True), 1.0), (oracle.laplace3d("FE", 34, 9, 8), 32.0)):
+            for (xo, yo), nvec, off in zip((("C", "C"), ("F", "F"), ("C", "F"), ("F", "C")), (16, 5, 21, 32), (np.int32, np.int64, np.int32, np.int32)):
+                h = check_spmv_mv(be, A0, nvec, "T", 1.5, 0.0, xo, yo, algo="SPMV_DEFAULT", max_val=maxv, nans=True, offset_dtype=off)
+                assert h.query("transpose_cached") == 1
+                check_spmv_mv(be, A0, nvec, "H", 1.0, -0.5, xo, yo, algo="SPMV_DEFAULT", max_val=maxv, offset_dtype=off)
+        A0 = oracle.random_crs(900, 700, 9, variance=3, seed=7, sorted_rows=True)
+        A = dev(be, A0)
+        h = kk.SPMVHandle("SPMV_DEFAULT")
+        rng = np.random.default_rng(4)
+        X = rng.random((A0.nrows, 16)); v = A0.values.copy()
+        for rep in range(3):
+            Yd = _to_dev_2d(be, np.zeros((A0.ncols, 16)))
+            kk.spmv(h, "T", 1.0, A, _to_dev_2d(be, X), 0.0, Yd)
+            exp = oracle.spmv_mv_serial("T", oracle.Crs(A0.nrows, A0.ncols, A0.row_map, A0.entries, v), 1.0, X, 0.0, np.zeros((A0.ncols, 16)))
+            np.testing.assert_allclose(_to_host_2d(be, Yd), exp, rtol=1e-12, atol=1e-12)
+            v = rng.random(A0.nnz) - rep
+            A.values[:] = be.from_numpy(v)
+        h = check_spmv_mv(be, A0, 16, "T", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", knobs={"explicit_transpose": 0})
+        assert h.query("transpose_cached") == 0
+    finally:
+        kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 1000))
+
+
 def _to_dev_2d(be, M):
     """device 2-D array with the same logical layout (Fortran order kept through a transposed view)"""
     if be.name == "emu":

@@ -207,6 +207,16 @@ def test_mv5_matrix_core(be):
     pc.check_mv5(be, light=True)
 
 
+def test_values_tracking_policies(be):
+    # exact (default) / notify / fingerprints for the cached transpose and the column-slab copy; kkamd_spmv_plan_values_changed
+    pc.check_values_tracking(be)
+
+
+def test_mv_transposed_modes_through_cached_transpose(be):
+    # rank 2, modes T / H of an analysed handle: the mode-N dispatch on the cached transpose
+    pc.check_mv_transpose_cached(be)
+
+
 def test_mv6_nonzero_split(be):
     # rank-2 nonzero-split kernel (kk_spmv_mvnnz.hip): chunks of 128 entries per 16-lane group, cut rows finished from carries, empty
     # rows from the plan's list; every width / layout pair, beta = 0 over NaNs, 64-bit offsets, fp32 values, Inf / NaN in X
@@ -539,8 +549,8 @@ def test_column_slab_copy(be):
         pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6, "colslab_const": 1}, max_val=50.0, value_dtype=np.float32, vec_dtype=np.float32)
         pc.check_spmv(be, A0, "T", 1.0, 0.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0)          # mode T never takes the copy of A
     # the automatic mode does nothing on a small matrix, and nothing at all under the emulator (there is nothing to time)
-    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 1})
-    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 0}, expect={"colslab": 0, "colslab_tried": 0})
+    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 1}, expect={"colslab": 0, "colslab_tried": 1})
+    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 0})       # opt-in: the default handle never builds the copy
 
 
 def test_column_slab_follows_value_changes(be):

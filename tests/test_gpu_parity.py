@@ -235,6 +235,16 @@ def test_mv5_matrix_core(be):
     pc.check_mv5(be, light=False)
 
 
+def test_values_tracking_policies(be):
+    # exact (default) / notify / fingerprints for the cached transpose and the column-slab copy; kkamd_spmv_plan_values_changed
+    pc.check_values_tracking(be)
+
+
+def test_mv_transposed_modes_through_cached_transpose(be):
+    # rank 2, modes T / H of an analysed handle: the mode-N dispatch on the cached transpose
+    pc.check_mv_transpose_cached(be)
+
+
 def test_mv6_nonzero_split(be):
     # rank-2 nonzero-split kernel (kk_spmv_mvnnz.hip): chunks of 128 entries per 16-lane group, cut rows finished from carries, empty
     # rows from the plan's list; every width / layout pair, beta = 0 over NaNs, 64-bit offsets, fp32 values, Inf / NaN in X
@@ -915,8 +925,8 @@ def test_column_slab_copy(be):
         pc.check_spmv(be, A0, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0, offset_dtype=np.int64, value_dtype=np.float32)
         pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6, "colslab_const": 1}, max_val=50.0, value_dtype=np.float32, vec_dtype=np.float32)
         pc.check_spmv(be, A0, "T", 1.0, 0.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0)
-    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 1})       # small matrix: the gates say no
-    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 0}, expect={"colslab": 0, "colslab_tried": 0})
+    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 1}, expect={"colslab": 0, "colslab_tried": 1})       # small matrix: the gates say no
+    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 0})       # opt-in: the default handle never builds the copy
 
 
 def test_column_slab_follows_value_changes(be):
@@ -949,7 +959,7 @@ def test_column_slab_selection_on_a_gather_bound_matrix(be):
     rng = np.random.default_rng(12)
     ent = np.sort(rng.integers(0, n, size=(n, k), dtype=np.int64), axis=1).astype(np.int32).reshape(-1)
     A0 = oracle.Crs(n, n, np.arange(0, n * k + 1, k, dtype=np.int64), ent, rng.random(n * k) + 0.5)
-    h = pc.check_spmv(be, A0, "N", 1.5, 0.0, "SPMV_DEFAULT", max_val=2.0, nans=True, knobs={"colslab_min_knnz": 20000}, expect={"colslab_tried": 1})
+    h = pc.check_spmv(be, A0, "N", 1.5, 0.0, "SPMV_DEFAULT", max_val=2.0, nans=True, knobs={"colslab": 1, "colslab_min_knnz": 20000}, expect={"colslab_tried": 1})
     assert h.query("colslab_crs_us") > 0 and h.query("colslab_us") > 0, (h.query("colslab_crs_us"), h.query("colslab_us"))
     print("column-slab selection: CRS %d us, copy %d us, kept %d" % (h.query("colslab_crs_us"), h.query("colslab_us"), h.query("colslab")))
     h2 = pc.check_spmv(be, A0, "N", 1.0, 0.5, "SPMV_DEFAULT", max_val=2.0, knobs={"colslab": 2}, expect={"colslab": 1, "colslab_shift": 18, "colslab_slabs": 12})
