@@ -1689,6 +1689,9 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
 // buffer is therefore kept in a process-wide pool between uses (one user at a time; a second concurrent handle allocates its own);
 // kkamd_release_scratch() gives it back.
 struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; std::mutex m; };
+// kkamd_release_scratch() gives the buffer back at any time; a host that never calls it keeps at most one store (an eighth of the HBM
+// that was free when it was sized) until the process ends.  Kokkos-based hosts: INTEGRATION.md registers kkamd_release_scratch with
+// Kokkos::push_finalize_hook; the C++ drop-in's Kokkos::finalize() calls it.
 static BmPool& bm_pool() { static BmPool pool; return pool; }
 int release_bitmap_pool();
 int release_bitmap_pool() {
@@ -1838,7 +1841,10 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
         size_t free_b = 0, total_b = 0;
         const int words = (int)ceil_div(k, (int64_t)64);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-          int64_t cap = (int64_t)((free_b + bm_pool().bytes) / 8) / ((int64_t)words * 8);     // (what the pool holds is not "used" memory)
+          size_t pooled = 0;                                       // what the pool holds is not "used" memory -- when it is free and on this device
+          { BmPool& pool = bm_pool(); std::lock_guard<std::mutex> g(pool.m); int dev_ = -1;
+            if (!pool.in_use && pool.p && hipGetDevice(&dev_) == hipSuccess && dev_ == pool.device) pooled = pool.bytes; }
+          int64_t cap = (int64_t)((free_b + pooled) / 8) / ((int64_t)words * 8);
           {
             // no more slots than rows that can qualify: a row's products bound its entries, so only rows of the bin with at least
             // k / 32 products can have k / 32 entries

@@ -95,6 +95,10 @@ class DistSpgemm:
     def numeric(self, A_slab, B, C_slab):
         be = self.be
         da, db, dc = A_slab.desc(), B.desc(), C_slab.desc()
+        seen = (id(self), id(C_slab.graph.entries), be.ptr(C_slab.graph.entries))     # see sparse.spgemm_numeric: arrays not yet seen are new
+        if getattr(C_slab, "_kk_numeric_seen", None) != seen:
+            self.set("entries_computed", 0)
+        C_slab._kk_numeric_seen = seen
         check(self.lib, self.lib.kkamd_dist_spgemm_numeric(self._op, A_slab.numRows(), A_slab.numCols(), B.numCols(), da.d_row_map, da.d_entries, da.d_values,
                                                            db.d_row_map, db.d_entries, db.d_values, dc.d_row_map, dc.d_entries, dc.d_values,
                                                            da.offset_type, da.value_type, be.stream()))

@@ -72,7 +72,7 @@ inline ViewAllocProp view_alloc(const std::string& label, WithoutInitializing_t)
 
 inline void initialize(int&, char**) {}
 inline void initialize() {}
-inline void finalize() {}
+inline void finalize() { (void)kkamd_release_scratch(); }   // the library's process-wide scratch (SpGEMM bitmap pool, handle-less SpMV plan) goes with the run time
 inline void fence(const std::string& = std::string()) { (void)hipDeviceSynchronize(); }
 
 namespace Profiling {

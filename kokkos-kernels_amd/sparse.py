@@ -344,6 +344,12 @@ def spgemm_numeric(kh, A, transposeA, B, transposeB, Cmat):
         raise ValueError("KokkosSparse::spgemm_numeric: the given KernelHandle does not have an SpGEMM handle "
                          "associated with it.")
     be, lib = A.backend, A.backend.lib
+    # the library keeps entries(C) across numeric calls into the SAME arrays; whether these are the same it can only judge by address,
+    # and a caching allocator hands a freed address out again: arrays this wrapper has not yet seen through THIS handle are told to be
+    # new ("entries_computed" 0), whatever their address
+    seen = (id(sh), id(Cmat.graph.entries), be.ptr(Cmat.graph.entries))
+    if getattr(Cmat, "_kk_numeric_seen", None) != seen:
+        sh.set("entries_computed", 0)
     try:
         check(lib, lib.kkamd_spgemm_numeric(sh.h, A.numRows(), A.numCols(), B.numCols(), be.ptr(A.graph.row_map),
                                             be.ptr(A.graph.entries), be.ptr(A.values), be.ptr(B.graph.row_map),
@@ -354,6 +360,7 @@ def spgemm_numeric(kh, A, transposeA, B, transposeB, Cmat):
         if e.status == _capi.ERR_STATE:
             raise ValueError(str(e))   # std::invalid_argument in the reference
         raise
+    Cmat._kk_numeric_seen = seen
     return Cmat
 
 
