@@ -255,7 +255,8 @@ int kkamd_dist_spmv_x_local(kkamd_dist_spmv_t* op, void** d_x_local, void** d_x_
 int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_shard, double beta, void* d_y_shard, int what,
                           kkamd_stream_t stream);
 /* "exchange" (0 local, 1 halo by column range, 2 all-gather, 3 all-gather by peer-to-peer pulls, 4 halo by column set), "exchange_bytes"
- * (received per SpMV), "interior_rows", "parts", "sends", "recvs" */
+ * (received per SpMV), "interior_rows", "parts", "sends", "recvs", "part0_rows" (rows of the interior view, or of the slab when it is
+ * not split) and "part0_<key>" = kkamd_spmv_plan_query(<key>) of that view's plan (e.g. "part0_pattern_tiles") */
 int kkamd_dist_spmv_query(const kkamd_dist_spmv_t* op, const char* key, int64_t* value);
 
 /* ------------------------------------------------------------------------------------------------

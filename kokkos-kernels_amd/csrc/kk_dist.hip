@@ -504,6 +504,11 @@ int kkamd_dist_spmv_query(const kkamd_dist_spmv_t* op, const char* key, int64_t*
   else if (k == "parts") *value = (int64_t)op->parts.size();
   else if (k == "sends") *value = (int64_t)op->send_peer.size();
   else if (k == "recvs") *value = (int64_t)op->recv_peer.size();
+  else if (k == "part0_rows") *value = op->parts.empty() ? 0 : op->parts[0].A.num_rows;       // the interior view (or the whole slab) ...
+  else if (k.rfind("part0_", 0) == 0) {                                                       // ... and what its plan's analysis produced: "part0_<plan query key>"
+    if (op->parts.empty() || !op->parts[0].plan) { *value = 0; return KKAMD_OK; }
+    return kkamd_spmv_plan_query(op->parts[0].plan, k.c_str() + 6, value);
+  }
   else return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_query: unknown key '%s'", key);
   return KKAMD_OK;
 }

@@ -97,7 +97,10 @@ __global__ __launch_bounds__(kBlock) void spmv_mv6_kernel(int64_t nnz, const int
                                                           double* __restrict__ carry, int remap) {
   using XV = kk_f64x2;
   constexpr int GL = 8, NG = kWave / GL, R = kMv6E / GL;         // lanes per chunk, chunks per wave, rounds per chunk
-  __shared__ Mv6Ent s_ent_all[kBlock / kWave][2][kWave];
+  // a chunk's 8 triples sit 9 slots apart from the next chunk's: the eight groups of a wave then read from eight different
+  // quads of banks (at 8 slots = 128 bytes apart every group's read hit the same four banks)
+  constexpr int GS = GL + 1;
+  __shared__ Mv6Ent s_ent_all[kBlock / kWave][2][NG * GS];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & (GL - 1), grp = lane / GL;
   const int64_t wave = xcd_order(blockIdx.x, gridDim.x, remap) * (kBlock / kWave) + w;
   if (wave * NG * kMv6E >= nnz) return;                          // the whole wave leaves together
@@ -139,13 +142,13 @@ __global__ __launch_bounds__(kBlock) void spmv_mv6_kernel(int64_t nnz, const int
     Mv6Ent* buf = s_ent_all[w][rd & 1];
     Mv6Ent me; me.col = t_col; me.row = t_row; me.val = (double)t_val;
     KK_WAVE_SYNC();
-    buf[lane] = me;
+    buf[grp * GS + j] = me;
     KK_WAVE_SYNC();
     fetch(rd + 1);                                               // (past the last round: one clamped, unused triple -- no branch around a load)
     const int nq = (int)(e1 - (e0 + rd * GL) < GL ? (e1 - (e0 + rd * GL) > 0 ? e1 - (e0 + rd * GL) : 0) : GL);
     KK_UNROLL
     for (int q = 0; q < GL; ++q) {
-      const double* xp = xc + (int64_t)buf[grp * GL + q].col * ldx;
+      const double* xp = xc + (int64_t)buf[grp * GS + q].col * ldx;
       if (FULL) xs[q] = *reinterpret_cast<const XV*>(xp);
       else {
         xs[q] = XV{0.0, 0.0};
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv6_kernel(int64_t nnz, const int
     KK_UNROLL
     for (int q = 0; q < GL; ++q) {
       if (q < nq) {
-        const Mv6Ent e = buf[grp * GL + q];
+        const Mv6Ent e = buf[grp * GS + q];
         if (e.row != cur_row) {
           if (cur_row >= 0) flush();
           else open_left = (e.row == prev_row);                  // the chunk's first entry

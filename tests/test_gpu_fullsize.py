@@ -220,3 +220,52 @@ def test_unstructured_banded_1e8(be):
     """1e7 rows x 12 random columns inside a band of +-20000: tiles are coverable by windows but share no row pattern"""
     A0 = oracle.random_crs(10_000_000, 10_000_000, 12, variance=0, seed=11, bandwidth=20000, sorted_rows=True)
     _check_unstructured(be, A0, "banded random 1e7 x 12", expect_codes=True)
+
+
+def test_c5_slab_rank3_of_8_against_oracle(be):
+    """BASELINE config 5, one rank's piece at its benchmarked size: rank 3 of 8 of the 27-pt 600^3 Laplacian -- rows 81 M .. 108 M (75
+    planes of 600 x 600), LOCAL row_map, GLOBAL column indices up to 2.16e8, an x of 216 M doubles -- through the multi-GPU operator
+    (kkamd_dist_spmv_*) with a loop-back transport that serves the exchange from the global x.  y of the slab against the Serial
+    restatement for the column-range halo (interior / boundary overlap) and the all-gather; the interior view must take the
+    row-pattern plan (what the N = 8 bench line's per-GPU time rests on)."""
+    import ctypes as C
+    import torch
+    from kokkos_kernels_amd.dist import DistSpmv
+    from dist_loopback import Loopback
+    nx = ny = 600; planes = 75; world = 8; rank = 3
+    plane = nx * ny; rows = plane * planes; n = rows * world
+    offsets = [r * rows for r in range(world + 1)]
+    A = pc.kk.laplace_matrix("FE", nx, ny, planes * world, rows=(rank * rows, rows))
+    assert A.numRows() == 27_000_000 and A.numCols() == 216_000_000
+    rm, ent, val = A.to_host()
+    assert int(ent.max()) == offsets[rank + 1] + plane - 1 and int(ent.min()) == offsets[rank] - plane          # global columns, one plane either side
+    A0 = oracle.Crs(rows, n, rm.astype(np.int64), ent, val)
+    rng = np.random.default_rng(17312837)
+    x = rng.integers(-20, 20, size=n).astype(np.float64)
+    xd = torch.from_numpy(x).cuda()
+    exp = oracle.spmv_serial("N", A0, 1.0, x, 0.0, np.zeros(rows))
+    tol = 10 * EPS * 27 * 32.0 * 20.0
+    ranges = [(max(0, offsets[p] - plane), min(n, offsets[p + 1] + plane) - 1) for p in range(world)]
+    for exchange, mode_name in (("halo", "halo"), ("allgather", "allgather")):
+        tr = Loopback(xd, offsets, rank, ranges)
+        op = DistSpmv(A, offsets, rank, transport=tr, exchange=exchange)
+        assert op.exchange_mode == mode_name, op.exchange_mode
+        p_full = C.c_void_p(); pc.kk._capi.check(be.lib, be.lib.kkamd_dist_spmv_x_local(op._op, None, C.byref(p_full)))
+        tr.base = p_full.value
+        xl = op.x_local(); xl.copy_(xd[offsets[rank]:offsets[rank + 1]])
+        y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+        op.apply(1.0, xl, 0.0, y)
+        _fspmv(exp, y.cpu().numpy(), tol, "C5 slab rank 3 of 8, exchange %s" % exchange)
+        if exchange == "halo":
+            assert op.exchange_bytes == 2 * plane * 8 and op.query("parts") == 3
+            assert rows - 2 * plane - 16 <= op.interior_rows <= rows - 2 * plane
+            # the interior view (73 of the 75 planes) runs the row-pattern plan, like config 2
+            assert op.query("part0_rows") == op.interior_rows
+            assert op.query("part0_pattern_tiles") >= 0.9 * op.query("part0_tiles"), (op.query("part0_pattern_tiles"), op.query("part0_tiles"))
+        else:
+            assert op.exchange_bytes == (world - 1) * rows * 8
+        y2 = torch.from_numpy(rng.integers(-20, 20, size=rows).astype(np.float64)).cuda(); y2h = y2.cpu().numpy().copy()
+        op.apply(2.0, xl, -1.0, y2)                                               # beta != 0 on the same operator
+        _fspmv(2.0 * exp - y2h, y2.cpu().numpy(), 10 * EPS * (20.0 + 2 * 27 * 32.0 * 20.0), "C5 slab beta = -1, exchange %s" % exchange)
+        del op, tr
+        torch.cuda.empty_cache()

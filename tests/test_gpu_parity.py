@@ -476,38 +476,8 @@ def test_dist_operator_on_device_with_loopback_transport(be):
     x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
     ranges = [(max(0, offsets[p] - plane), min(n, offsets[p + 1] + plane) - 1) for p in range(world)]     # column range of every slab
 
-    def view(ptr, nbytes):
-        return torch.as_tensor(_DeviceView(ptr, nbytes, "|u1"), device="cuda")
-
-    class Loopback:
-        def __init__(self):
-            self.calls, self.base, self.log = 0, None, []
-
-            def all_gather(ctx, d_send, d_recv, nbytes, stream):
-                torch.cuda.synchronize()
-                mine = view(d_send, nbytes).clone(); out = view(d_recv, nbytes * world)
-                for p in range(world):
-                    if p == rank: out[p * nbytes:(p + 1) * nbytes] = mine
-                    elif self.calls == 0: out[p * nbytes:(p + 1) * nbytes] = torch.tensor(ranges[p], dtype=torch.int64, device="cuda").view(torch.uint8)
-                    else: out[p * nbytes:(p + 1) * nbytes] = torch.tensor([0.01, 0.0], dtype=torch.float64, device="cuda").view(torch.uint8)
-                self.calls += 1
-                torch.cuda.synchronize()
-                return 0
-
-            def exchange(ctx, nsend, d_send, send_bytes, send_peer, nrecv, d_recv, recv_bytes, recv_peer, stream):
-                torch.cuda.synchronize()
-                for i in range(nrecv):                       # serve every receive from the global x (what the peer would have sent)
-                    lo = (int(d_recv[i]) - self.base) // 8; cnt = int(recv_bytes[i]) // 8
-                    view(d_recv[i], recv_bytes[i]).copy_(x[lo:lo + cnt].view(torch.uint8))
-                    self.log.append(("recv", int(recv_peer[i]), lo, cnt))
-                for i in range(nsend):
-                    self.log.append(("send", int(send_peer[i]), (int(d_send[i]) - self.base) // 8, int(send_bytes[i]) // 8))
-                torch.cuda.synchronize()
-                return 0
-            self._ag, self._ex = _capi.ALL_GATHER_FN(all_gather), _capi.EXCHANGE_FN(exchange)
-            self.struct = _capi.Transport(None, self._ag, self._ex)
-
-    tr = Loopback()
+    from dist_loopback import Loopback
+    tr = Loopback(x, offsets, rank, ranges)
     op = DistSpmv(A, offsets, rank, transport=tr)
     assert op.exchange_mode == "halo" and op.exchange_bytes == 2 * plane * 8 and op.query("parts") == 3
     assert rows - 2 * plane - 16 <= op.interior_rows <= rows - 2 * plane
