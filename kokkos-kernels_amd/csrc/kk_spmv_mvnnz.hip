@@ -19,6 +19,7 @@
 //     no pre-scaling pass, the same summation order on every run (deterministic).
 //   * rows without entries are listed by the plan and get beta y from a third, tiny kernel.
 #include "kk_spmv_plan.h"
+#include "kk_scan.h"
 #include <new>
 #include <climits>
 
@@ -63,14 +64,16 @@ __global__ __launch_bounds__(kBlock) void mv6_rowid_kernel(int64_t nrows, int64_
   while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)row_map[mid] <= i) lo = mid; else hi = mid; }
   rowid[i] = (int32_t)lo;
 }
+// rows without entries, in ascending order (their beta y stores then fall into neighbouring lines): flag, prefix sum, compaction
 template <class OffT>
-__global__ __launch_bounds__(kBlock) void mv6_empty_list_kernel(int64_t nrows, const OffT* __restrict__ row_map, int32_t* __restrict__ list,
-                                                                unsigned long long* __restrict__ count) {
+__global__ __launch_bounds__(kBlock) void mv6_empty_flag_kernel(int64_t nrows, const OffT* __restrict__ row_map, int64_t* __restrict__ pos) {
   const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (r < nrows && row_map[r + 1] == row_map[r]) {
-    const unsigned long long at = atomicAdd(count, 1ull);
-    if (list) list[at] = (int32_t)r;
-  }
+  if (r < nrows) pos[r] = (row_map[r + 1] == row_map[r]) ? 1 : 0;
+  else if (r == nrows) pos[r] = 0;
+}
+__global__ __launch_bounds__(kBlock) void mv6_empty_compact_kernel(int64_t nrows, const int64_t* __restrict__ pos, int32_t* __restrict__ list) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r < nrows && pos[r + 1] != pos[r]) list[pos[r]] = (int32_t)r;
 }
 __global__ __launch_bounds__(kBlock) void mv6_empty_rows_kernel(int64_t n, const int32_t* __restrict__ list, double* __restrict__ Y, int64_t ys0, int64_t ys1,
                                                                 double beta, int ncv) {
@@ -94,7 +97,7 @@ template <class AT, bool Y_VEC, bool FULL>
 __global__ __launch_bounds__(kBlock) void spmv_mv6_kernel(int64_t nnz, const int32_t* __restrict__ entries, const AT* __restrict__ values,
                                                           const int32_t* __restrict__ rowid, const double* __restrict__ X, int64_t ldx,
                                                           double* __restrict__ Y, int64_t ys0, int64_t ys1, double alpha, double beta, int ncv,
-                                                          double* __restrict__ carry, int remap) {
+                                                          double* __restrict__ carry, int remap, int x24) {
   using XV = kk_f64x2;
   constexpr int GL = 8, NG = kWave / GL, R = kMv6E / GL;         // lanes per chunk, chunks per wave, rounds per chunk
   // a chunk's 8 triples sit 9 slots apart from the next chunk's: the eight groups of a wave then read from eight different
@@ -110,6 +113,10 @@ __global__ __launch_bounds__(kBlock) void spmv_mv6_kernel(int64_t nnz, const int
   const int next_row = (e1 < nnz) ? rowid[e1] : -1;
   const bool have = FULL || 2 * j < ncv, have2 = FULL || 2 * j + 1 < ncv;   // the lane's two columns exist in this block
   const double* __restrict__ xc = X + (have ? 2 * j : 0);
+  // X rows by 24-bit multiply + one 64-bit add when the column count and the leading dimension allow it (the general 64-bit product is
+  // six instructions, two of them quarter rate, per gather)
+  const bool small = x24 != 0;
+  const unsigned ldx24 = (unsigned)ldx;
   double* __restrict__ cg = carry + g * 32;
   int cur_row = -1;
   bool open_left = false;
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(kBlock) void spmv_mv6_kernel(int64_t nnz, const int
     const int nq = (int)(e1 - (e0 + rd * GL) < GL ? (e1 - (e0 + rd * GL) > 0 ? e1 - (e0 + rd * GL) : 0) : GL);
     KK_UNROLL
     for (int q = 0; q < GL; ++q) {
-      const double* xp = xc + (int64_t)buf[grp * GS + q].col * ldx;
+      const int col = buf[grp * GS + q].col;
+      const double* xp = small ? xc + KK_UMUL24((unsigned)col, ldx24) : xc + (int64_t)col * ldx;
       if (FULL) xs[q] = *reinterpret_cast<const XV*>(xp);
       else {
         xs[q] = XV{0.0, 0.0};
@@ -231,25 +239,27 @@ static int mv6_plan_build_t(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStre
   if (!p) return fail(KKAMD_ERR_ALLOC, "kkamd_spmv_mv: out of host memory");
   struct Guard { kkamd_mv6_plan* p; ~Guard() { if (p) mv6_plan_destroy(p); } } guard{p};
   p->nchunks = ceil_div(A->nnz, (int64_t)kMv6E);
-  DevBuf cnt;
   if (hipMalloc((void**)&p->d_rowid, sizeof(int32_t) * (size_t)A->nnz) != hipSuccess ||
-      hipMalloc((void**)&p->d_carry, sizeof(double) * 32 * (size_t)p->nchunks) != hipSuccess || cnt.alloc(sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc((void**)&p->d_carry, sizeof(double) * 32 * (size_t)p->nchunks) != hipSuccess) {
     (void)hipGetLastError();
     return KKAMD_OK;                                             // no memory for the plan: the row-based gather kernel serves the matrix
   }
   KK_LAUNCH((mv6_rowid_kernel<OffT>), (unsigned)ceil_div(A->nnz, kBlock), kBlock, 0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, p->d_rowid);
   KK_LAUNCH_CHECK();
-  unsigned long long* d_cnt = cnt.as<unsigned long long>();
-  KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-  const unsigned grid = (unsigned)ceil_div(A->num_rows, kBlock);
-  KK_LAUNCH((mv6_empty_list_kernel<OffT>), grid, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, (int32_t*)nullptr, d_cnt);
-  unsigned long long h_n = 0;
-  KK_HIP(hipMemcpyAsync(&h_n, d_cnt, sizeof h_n, hipMemcpyDeviceToHost, st));
+  DevBuf posb;
+  if (posb.alloc(sizeof(int64_t) * (size_t)(A->num_rows + 1)) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
+  int64_t* d_pos = posb.as<int64_t>();
+  const unsigned grid = (unsigned)ceil_div(A->num_rows + 1, kBlock);
+  KK_LAUNCH((mv6_empty_flag_kernel<OffT>), grid, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, d_pos);
+  KK_LAUNCH_CHECK();
+  int rc = exclusive_scan_inplace<int64_t>(d_pos, A->num_rows + 1, st);
+  if (rc) return rc;
+  int64_t h_n = 0;
+  KK_HIP(hipMemcpyAsync(&h_n, d_pos + A->num_rows, sizeof h_n, hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
   if (h_n > 0) {
     if (hipMalloc((void**)&p->d_empty, sizeof(int32_t) * (size_t)h_n) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
-    KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-    KK_LAUNCH((mv6_empty_list_kernel<OffT>), grid, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, p->d_empty, d_cnt);
+    KK_LAUNCH(mv6_empty_compact_kernel, grid, kBlock, 0, st, A->num_rows, (const int64_t*)d_pos, p->d_empty);
     KK_LAUNCH_CHECK();
   }
   KK_HIP(hipStreamSynchronize(st));
@@ -269,13 +279,14 @@ static int mv6_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   const kkamd_mv6_plan* p = plan->mv6;
   const unsigned grid = (unsigned)ceil_div(p->nchunks, (int64_t)8 * (kBlock / kWave));
   const bool yv = ys1 == 1 && ys0 % 2 == 0 && (uintptr_t)Y % 16 == 0;
+  const int x24 = (A->num_cols < (1 << 24) && ldx < (1 << 24) && (double)A->num_cols * (double)ldx < 4.0e9) ? 1 : 0;
   for (int64_t c0 = 0; c0 < nvec; c0 += 16) {
     const int ncv = (int)(nvec - c0 < 16 ? nvec - c0 : 16);
     const double* Xb = X + c0;
     double* Yb = Y + c0 * ys1;
 #define KK_MV6(YV, FU)                                                                                                                          \
     KK_LAUNCH((spmv_mv6_kernel<AT, YV, FU>), grid, kBlock, 0, st, A->nnz, (const int32_t*)A->d_entries, (const AT*)A->d_values, (const int32_t*)p->d_rowid, \
-              Xb, ldx, Yb, ys0, ys1, alpha, beta, ncv, p->d_carry, plan->tune.mv_remap)
+              Xb, ldx, Yb, ys0, ys1, alpha, beta, ncv, p->d_carry, plan->tune.mv_remap, x24)
     if (ncv == 16) { if (yv) KK_MV6(true, true); else KK_MV6(false, true); }
     else           { if (yv) KK_MV6(true, false); else KK_MV6(false, false); }
 #undef KK_MV6

@@ -24,6 +24,7 @@ prof() {   # prof <tag> <command...>: kernel stats + FETCH_SIZE and WRITE_SIZE i
 }
 if has profx; then prof ${PROF_TAG:-x} bash -c "$PROF_CMD"; fi
 if has statsx; then cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${PROF_TAG:-x}_stats -o p -- bash -c "$PROF_CMD" > $OUT/prof_${PROF_TAG:-x}_stats.log 2>&1; echo "stats rc=$?"; cd $R; fi
+if has pmcx; then cd /tmp; timeout 900 rocprofv3 --kernel-trace --pmc $PMC_LIST --output-format csv -d $OUT/prof_sq_${PROF_TAG:-x} -o p -- bash -c "$PROF_CMD" > $OUT/prof_sq_${PROF_TAG:-x}.log 2>&1; echo "pmcx rc=$?"; cd $R; fi
 if has profbench; then prof bench python $R/bench.py --steps 30 --no-cpu-baseline --extras-seconds 0; fi
 if has profmv;    then prof mv python $R/tools/bench_mv3.py 300 quick; fi
 if has profmv4;   then prof mv4 python $R/tools/bench_mv4.py 300 quick; fi
