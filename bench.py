@@ -127,11 +127,53 @@ def bench_spmv_mv(kk, torch, A, budget_s, cpu):
         else: assert float((Y - ref).abs().max()) == 0.0, "spmv_mv: layouts disagree"
         r.update(GFLOPs=round(2.0 * nnz * nv / r["mean_ms"] / 1e6, 1), achieved_GBps=round(alg / r["mean_ms"] / 1e6, 1),
                  frac=round(alg / r["mean_ms"] / 1e6 / HBM_PEAK_GBPS, 4),
-                 kernel="kk::spmv_mv4_kernel (plane marching)" if h.query("mv4_workgroups") else "kk::spmv_mv2_kernel (gather)")
+                 kernel=_mv_kernel_name(h))
         out["layout_" + layout] = r
         del h, Y
     if cpu and time.perf_counter() - t_start < budget_s:
         out["cpu_baseline"] = cpu_baseline_mv(nv)
+    return out
+
+
+def _mv_kernel_name(h):
+    if h.query("mv4_workgroups"): return "kk::spmv_mv4_kernel (plane marching)"
+    if h.query("mv5_tiles"): return "kk::spmv_mv5_kernel (matrix core, v_mfma_f64_16x16x4)"
+    if h.query("mv6_chunks"): return "kk::spmv_mv6_kernel (nonzero split)"
+    return "kk::spmv_mv2_kernel (gather)"
+
+
+def bench_spmv_mv_off_lattice(kk, torch, budget_s):
+    """SpMV_MV with 16 fp64 right-hand sides OFF the lattice: a block-diagonal matrix (32 x 32 blocks, 2e6 rows) and a
+    3-dof-per-node 27-pt finite-element matrix (100^3 nodes) -- both taken by the matrix-core kernel --, and R-MAT scale 22 (the
+    nonzero-split kernel); LayoutRight, and LayoutLeft for the first.  Algorithmic bytes nnz*12 + (rows+1)*4 + (rows+cols)*16*8."""
+    import numpy as np
+    t_start = time.perf_counter()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_plan_table as pt
+    out = {"nvec": 16, "peak_GBps": HBM_PEAK_GBPS, "cases": {}}
+    for name, layouts in (("block diagonal, 32 x 32 blocks, 2e6 rows", ("right", "left")), ("3 dof per node on 27-pt FE 100^3", ("right",)), ("R-MAT scale 22, edge factor 16", ("right",))):
+        if time.perf_counter() - t_start > budget_s: break
+        (_, A), = list(pt.matrices(name))
+        rows, cols, nnz, nv = A.numRows(), A.numCols(), A.nnz(), 16
+        alg = nnz * 12 + (rows + 1) * 4 + (rows + cols) * nv * 8
+        g = torch.Generator(device="cuda"); g.manual_seed(7)
+        X = torch.rand(cols, nv, dtype=torch.float64, device="cuda", generator=g)
+        case = {"rows": rows, "nnz": nnz, "algorithmic_bytes_per_call": alg}
+        for layout in layouts:
+            Xl = X if layout == "right" else X.t().contiguous().t()
+            Y = torch.zeros(rows, nv, dtype=torch.float64, device="cuda") if layout == "right" else torch.zeros(nv, rows, dtype=torch.float64, device="cuda").t()
+            h = kk.SPMVHandle("SPMV_DEFAULT")
+            fn = lambda: kk.spmv(h, "N", 1.0, A, Xl, 0.0, Y)
+            for _ in range(3): fn()
+            torch.cuda.synchronize()
+            r = _fenced(fn, torch.cuda.synchronize, 20)
+            r.update(frac=round(alg / r["mean_ms"] / 1e6 / HBM_PEAK_GBPS, 4), kernel=_mv_kernel_name(h))
+            if h.query("mv5_tiles"): r["mfma_instructions_per_call"] = h.query("mv5_blocks"); r["operand_fill"] = h.query("mv5_fill_permille") / 1000
+            case["layout_" + layout] = r
+            del h, Y
+        out["cases"][name] = case
+        del A, X
+        torch.cuda.empty_cache()
     return out
 
 
@@ -156,9 +198,10 @@ def cpu_baseline_mv(nv, n=300, min_seconds=6.0):
 
 
 def bench_rank1_gather_bound(kk, torch):
-    """Rank-1 SpMV off the stencil: uniform random columns, 5e6 rows x 20 (1e8 nonzeros, x = 40 MB), fp64.  The CRS
-    stream kernel, the default handle (which may select the column-slab copy, DESIGN 4.1.1) and the copy with constant values promised;
-    fractions are CRS bytes (nnz*12 + (rows+1)*4 + cols*8 + rows*8) at 8 TB/s."""
+    """Rank-1 SpMV off the stencil: uniform random columns, 5e6 rows x 20 (1e8 nonzeros, x = 40 MB), fp64.  The default
+    handle (the deterministic CRS stream kernel: the column-slab copy is opt-in since round 4), the copy when asked for (knob colslab 1: it
+    is selected by timing; its values follow A.values exactly through a shadow comparison) and the copy with the caller notifying value
+    changes (values_tracking 1: no per-call pass); fractions are CRS bytes (nnz*12 + (rows+1)*4 + cols*8 + rows*8) at 8 TB/s."""
     n, k = 5_000_000, 20
     g = torch.Generator(device="cuda"); g.manual_seed(11)
     c = torch.sort(torch.randint(0, n, (n, k), device="cuda", generator=g), dim=1).values
@@ -169,7 +212,7 @@ def bench_rank1_gather_bound(kk, torch):
     alg = A.nnz() * 12 + (n + 1) * 4 + 2 * n * 8
     out = {"workload": "spmv_crs_uniform_random_5e6x20_fp64", "nnz": A.nnz(), "algorithmic_bytes_per_call": alg, "peak_GBps": HBM_PEAK_GBPS}
     ref = None
-    for tag, knobs in (("crs_stream_kernel", {"colslab": 0}), ("default_handle", {}), ("column_slab_copy_constant_values", {"colslab": 2, "colslab_const": 1})):
+    for tag, knobs in (("default_handle", {}), ("column_slab_copy_opt_in", {"colslab": 1}), ("column_slab_copy_caller_notifies", {"colslab": 2, "values_tracking": 1})):
         h = kk.SPMVHandle("SPMV_DEFAULT")
         for k_, v_ in knobs.items(): h.set(k_, v_)
         fn = lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y)
@@ -180,7 +223,7 @@ def bench_rank1_gather_bound(kk, torch):
         if ref is None: ref = y.clone()
         r["max_rel_diff_vs_crs"] = float(((y - ref).abs().max() / ref.abs().max()).item())
         assert r["max_rel_diff_vs_crs"] < 1e-12, "rank-1 gather-bound case: kernels disagree"
-        if tag == "default_handle": r["column_slab_copy_selected"] = int(h.query("colslab")); r["selection_us_crs_vs_copy"] = [h.query("colslab_crs_us"), h.query("colslab_us")]
+        if tag == "column_slab_copy_opt_in": r["column_slab_copy_selected"] = int(h.query("colslab")); r["selection_us_crs_vs_copy"] = [h.query("colslab_crs_us"), h.query("colslab_us")]
         out[tag] = r
         del h
     return out
@@ -275,7 +318,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fence", action="store_true", help="queue the K timed steps back to back (no per-call fence, no per-call times)")
     ap.add_argument("--flush", action="store_true", help="also report the per-call times with the reference's --flush (4 x 1 GB of fills between calls)")
-    ap.add_argument("--extras-seconds", type=float, default=150.0,
+    ap.add_argument("--extras-seconds", type=float, default=180.0,
                     help="N = 1: time cap for the spmv_mv (config 3) and spgemm (config 4) sections of the line; 0 skips them")
     ap.add_argument("--emulate", action="store_true",
                     help="debug / CI: run the whole flow on CPU -- gloo instead of RCCL, the kernels under the SIMT emulator of "
@@ -571,6 +614,12 @@ def main():
                 out["spmv_gather_bound"] = bench_rank1_gather_bound(kk, torch)
             except Exception as e:
                 out["spmv_gather_bound"] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+            try:
+                left = args.extras_seconds - (time.perf_counter() - t_x)
+                out["spmv_mv_off_lattice"] = bench_spmv_mv_off_lattice(kk, torch, min(40.0, 0.3 * left)) if left > 60 else {"skipped": "time cap"}
+            except Exception as e:
+                out["spmv_mv_off_lattice"] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
             try:
                 left = args.extras_seconds - (time.perf_counter() - t_x)

@@ -147,6 +147,9 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *                       changed 4096-value tiles are moved; without memory for the shadow every call copies all values; 1 NOTIFY --
  *                       kkamd_spmv_plan_values_changed says when, nothing is read in between; 2 FINGERPRINTS -- 128 bits per tile, one
  *                       stream, no shadow: a heuristic (a changed tile with an unchanged fingerprint is missed)
+ *     "check_entries"   debug aid, 0 (default) / 1: every call hashes the matrix's column array (one pass + a stream synchronisation) and
+ *                       returns KKAMD_ERR_STATE when it differs from what the handle first saw: a structure edited in place under a live
+ *                       handle (the pointer comparison of every call cannot see that; rocSPARSE's analysis has the same contract)
  *     "colslab"         mode N on matrices whose x gather defeats the caches (most tiles read plain entries, x is >= 16 MB, from
  *                       "colslab_min_knnz" thousand nonzeros): 0 (default) never; 1 the first call builds a second copy of the matrix in
  *                       column-slab order (entries sorted by 2 MB segments of x, then by row; nnz * (8 + value + offset) bytes),

@@ -1108,6 +1108,37 @@ int check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   return KKAMD_OK;
 }
 
+// knob check_entries (debug aid): an order-independent 64-bit hash of (position, column) over the matrix's column array, taken when the
+// handle first sees the matrix and again at every call.  The analysis (tile modes, pattern records, lattice plans, cached transpose) is
+// only valid for the structure it was made from; check_plan can compare pointers and sizes, this compares content.
+__global__ __launch_bounds__(kBlock) void entries_hash_kernel(int64_t nnz, const int32_t* __restrict__ ent, unsigned long long* __restrict__ out) {
+  unsigned long long h = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * kBlock) {
+    unsigned long long z = ((unsigned long long)(unsigned)ent[i] << 32 | (unsigned long long)(i & 0xffffffffll)) + 0x9E3779B97F4A7C15ull * (unsigned long long)(i >> 32);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    h += z ^ (z >> 31);
+  }
+  h = group_sum(h, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+int check_entries_content(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
+  if (!p || !p->tune.check_entries || A->nnz == 0 || p->entries != A->d_entries) return KKAMD_OK;
+  DevBuf buf;
+  KK_HIP(buf.alloc(sizeof(unsigned long long)));
+  KK_HIP(hipMemsetAsync(buf.p, 0, sizeof(unsigned long long), st));
+  const int64_t nb = ceil_div(A->nnz, kBlock);
+  unsigned long long* d_h = buf.as<unsigned long long>();
+  KK_LAUNCH(entries_hash_kernel, (unsigned)(nb < 4096 ? nb : 4096), kBlock, 0, st, A->nnz, (const int32_t*)A->d_entries, d_h);
+  KK_LAUNCH_CHECK();
+  unsigned long long h = 0;
+  KK_HIP(hipMemcpyAsync(&h, buf.p, sizeof h, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  if (!p->entries_hash_known) { p->entries_hash = h; p->entries_hash_known = true; return KKAMD_OK; }
+  if (h != p->entries_hash)
+    return fail(KKAMD_ERR_STATE, "kkamd_spmv: the matrix's column indices changed in place since the handle analysed them (check_entries)");
+  return KKAMD_OK;
+}
+
 // TPL_SpMV_Data::set_exec_space (sparse/src/KokkosSparse_spmv_handle.hpp:95-104): a handle's scratch (carry slots, packed
 // X / Y) is ordered by the stream it was last used on; when the caller switches streams, the old one is fenced first.
 int bind_stream(kkamd_spmv_plan* p, hipStream_t st) {
@@ -1144,6 +1175,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "mv_order") { if (value < 0 || value > 2) return bad("in 0..2"); t.mv_order = value; }
   else if (k == "mv_strip_min_kb") { if (value < 0) return bad("non-negative"); t.mv_strip_min_kb = value; }
   else if (k == "mv_strip_l2_kb") { if (value < 1) return bad("positive"); t.mv_strip_l2_kb = value; }
+  else if (k == "mv_nt") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv_nt = value; }
   else if (k == "mv_glds") { if (value != 0 && value != 1) return bad("0 or 1"); t.mv_glds = value; }
   else if (k == "mv_long_T") { if (value < 0) return bad("non-negative"); t.mv_long_T = value; }
   else if (k == "mv4_min_nvec") { if (value < 1 || value > 1024) return bad("in 1..1024"); t.mv4_min_nvec = value; }
@@ -1161,6 +1193,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "colslab_min_knnz") { if (value < 0) return bad("non-negative"); t.colslab_min_knnz = value; }
   else if (k == "colslab_shift") { if (value != 0 && (value < 2 || value > 30)) return bad("0 or in 2..30"); t.colslab_shift = value; }
   else if (k == "values_tracking") { if (value < 0 || value > 2) return bad("in 0..2"); t.values_tracking = value; }
+  else if (k == "check_entries") { if (value != 0 && value != 1) return bad("0 or 1"); t.check_entries = value; }
   else if (k == "colslab_const") { if (value != 0 && value != 1) return bad("0 or 1"); t.colslab_const = value; }
   else if (k == "transient_min_knnz") { if (value < 0) return bad("non-negative"); t.transient_min_knnz = value; }
   else if (k == "explicit_transpose") { if (value < 0 || value > 2) return bad("in 0..2"); t.explicit_transpose = value; }
@@ -1604,6 +1637,7 @@ int kkamd_spmv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, double 
   }
   if (xlen > 0 && !d_x) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv: null x");
   if ((rc = kk::bind_stream(plan, st))) return rc;
+  if ((rc = kk::check_entries_content(plan, A, st))) return rc;
   kk::TraceRange range(A->value_type == KKAMD_F64 ? "KokkosSparse::spmv[TPL_KKAMD,double]" : "KokkosSparse::spmv[TPL_KKAMD,float]");
   KK_DISPATCH_TYPES(kk::spmv_typed, plan, A, trans, alpha, d_x, beta, d_y, st);
 }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void spmv_mv_kernel(int64_t nrows, const Of
 // 4 rows in flight and is bound by the texture path at ~13 % of the HBM roofline).  The wave's contiguous CSR
 // range is staged through its private LDS slice with 16-byte loads (4-aligned windows), no workgroup barrier.
 typedef int kk_i32x4 __attribute__((vector_size(16)));
-template <class OffT, class AT, class YT, int LPRW, int RPL, int CHW>
+template <class OffT, class AT, class YT, int LPRW, int RPL, int CHW, bool NT = false>
 __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ row_map,
                                                           const int32_t* __restrict__ entries,
                                                           const AT* __restrict__ values, const YT* __restrict__ X,
@@ -134,9 +134,10 @@ __global__ __launch_bounds__(kBlock) void spmv_mv2_kernel(int64_t nrows, int64_t
       if (c + CHW <= nnz) {   // whole window inside the arrays (wave-uniform): three unguarded 16-byte loads per lane and 256 nnz
         KK_UNROLL
         for (int sub = 0; sub < CHW; sub += 256) {
-          const kk_i32x4 cc = *reinterpret_cast<const kk_i32x4*>(entries + c + sub + lane64 * 4);
-          const AV va = *reinterpret_cast<const AV*>(values + c + sub + lane64 * 2);
-          const AV vb = *reinterpret_cast<const AV*>(values + c + sub + 128 + lane64 * 2);
+          // NT: the matrix streams are read once -- nontemporal loads keep them from pushing X rows out of the XCD's L2
+          const kk_i32x4 cc = NT ? KK_NT_LOAD(reinterpret_cast<const kk_i32x4*>(entries + c + sub + lane64 * 4)) : *reinterpret_cast<const kk_i32x4*>(entries + c + sub + lane64 * 4);
+          const AV va = NT ? KK_NT_LOAD(reinterpret_cast<const AV*>(values + c + sub + lane64 * 2)) : *reinterpret_cast<const AV*>(values + c + sub + lane64 * 2);
+          const AV vb = NT ? KK_NT_LOAD(reinterpret_cast<const AV*>(values + c + sub + 128 + lane64 * 2)) : *reinterpret_cast<const AV*>(values + c + sub + 128 + lane64 * 2);
           s_col[sub + lane64 * 4] = cc[0]; s_col[sub + lane64 * 4 + 1] = cc[1]; s_col[sub + lane64 * 4 + 2] = cc[2]; s_col[sub + lane64 * 4 + 3] = cc[3];
           s_val[sub + lane64 * 2] = va[0]; s_val[sub + lane64 * 2 + 1] = va[1];
           s_val[sub + 128 + lane64 * 2] = vb[0]; s_val[sub + 128 + lane64 * 2 + 1] = vb[1];
@@ -1658,6 +1659,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
     if (Xr) {
       const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
       const int mv_remap = plan ? plan->tune.mv_remap : g_spmv_default.mv_remap;
+      const bool mv_nt = (plan ? plan->tune.mv_nt : g_spmv_default.mv_nt) != 0;
       int64_t long_T = 0;
       if (plan && plan->row_map == A->d_row_map) {
         if (!plan->mv_long_known) { const int rc = mv_find_long_rows<OffT>(plan, A, st); if (rc) return rc; }
@@ -1681,11 +1683,13 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
         KK_LAUNCH_CHECK();
         return KKAMD_OK;
       };
+#define KK_MV2L(L, R, C, N)                                                                                              \
+        KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R, C, N>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
+                  0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, \
+                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap, mv2_order(plan, A, (kBlock / kWave) * (kWave / L), (int)(nvec < 16 ? nvec : 16) * (int)sizeof(YT), st), long_T)
 #define KK_MV2C(L, R, C)                                                                                                 \
       do {                                                                                                               \
-        KK_LAUNCH((spmv_mv2_kernel<OffT, AT, YT, L, R, C>), (unsigned)ceil_div(A->num_rows, (kBlock / kWave) * (kWave / L)), kBlock, \
-                  0, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, \
-                  Xr, ldx, Y, ys0, ys1, nvec, alpha, beta, yv, mv_remap, mv2_order(plan, A, (kBlock / kWave) * (kWave / L), (int)(nvec < 16 ? nvec : 16) * (int)sizeof(YT), st), long_T); \
+        if (mv_nt) KK_MV2L(L, R, C, true); else KK_MV2L(L, R, C, false);                                                  \
         KK_LAUNCH_CHECK();                                                                                               \
         return long_rows();                                                                                              \
       } while (0)
@@ -1702,6 +1706,7 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
       if (nvec >= 3) KK_MV2(2, 2);
       KK_MV2(1, 2);
 #undef KK_MV2C
+#undef KK_MV2L
 #undef KK_MV2
     }
   }
@@ -1736,6 +1741,7 @@ int kkamd_spmv_mv(kkamd_spmv_plan_t* plan, const kkamd_crs_t* A, char mode, doub
   }
   if (!d_X) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_mv: null X");
   if ((rc = kk::bind_stream(plan, st))) return rc;
+  if ((rc = kk::check_entries_content(plan, A, st))) return rc;
   kk::TraceRange range(A->value_type == KKAMD_F64 ? "KokkosSparse::spmv[TPL_KKAMD,double]" : "KokkosSparse::spmv[TPL_KKAMD,float]");
   // one contiguous column: the rank-1 path (sparse/src/KokkosSparse_spmv.hpp:203-217)
   if (nvec == 1 && x_stride0 == 1 && y_stride0 == 1) return kkamd_spmv(plan, A, mode, alpha, d_X, beta, d_Y, vector_type, stream);

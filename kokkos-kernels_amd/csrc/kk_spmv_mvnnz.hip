@@ -77,11 +77,14 @@ __global__ __launch_bounds__(kBlock) void mv6_empty_compact_kernel(int64_t nrows
 }
 __global__ __launch_bounds__(kBlock) void mv6_empty_rows_kernel(int64_t n, const int32_t* __restrict__ list, double* __restrict__ Y, int64_t ys0, int64_t ys1,
                                                                 double beta, int ncv) {
-  const int64_t idx = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
+  // 16 lanes (one right-hand side each) take 16 consecutive rows of the list (the list ascends: neighbouring rows, neighbouring lines)
+  const int64_t g = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 16;
   const int j = threadIdx.x & 15;
-  if (idx >= n || j >= ncv) return;
-  double* yp = Y + (int64_t)list[idx] * ys0 + j * ys1;
-  *yp = (beta == 0.0) ? 0.0 : beta * (*yp);
+  if (j >= ncv) return;
+  for (int64_t idx = g * 16; idx < n && idx < g * 16 + 16; ++idx) {
+    double* yp = Y + (int64_t)list[idx] * ys0 + j * ys1;
+    *yp = (beta == 0.0) ? 0.0 : beta * (*yp);
+  }
 }
 
 // carry slots of chunk g: head at (2 g) * 16, tail at (2 g + 1) * 16.
@@ -295,7 +298,7 @@ static int mv6_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
               (const int32_t*)p->d_rowid, (const double*)p->d_carry, Yb, ys0, ys1, alpha, beta, ncv);
     KK_LAUNCH_CHECK();
     if (p->n_empty > 0) {
-      KK_LAUNCH(mv6_empty_rows_kernel, (unsigned)ceil_div(p->n_empty * 16, kBlock), kBlock, 0, st, p->n_empty, (const int32_t*)p->d_empty, Yb, ys0, ys1, beta, ncv);
+      KK_LAUNCH(mv6_empty_rows_kernel, (unsigned)ceil_div(ceil_div(p->n_empty, (int64_t)16) * 16, kBlock), kBlock, 0, st, p->n_empty, (const int32_t*)p->d_empty, Yb, ys0, ys1, beta, ncv);
       KK_LAUNCH_CHECK();
     }
   }

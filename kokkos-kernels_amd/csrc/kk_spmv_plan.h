@@ -33,6 +33,7 @@ struct SpmvTuning {
   int mv_order       = 2;  // rank-2 LDS-staged kernel, tile order: 0 dispatch, 1 XCD-contiguous, 2 strips from the detected grid strides (falls back to 1)
   int mv_strip_min_kb = 3000;  // ... strips engage when three periods' worth of X rows exceed this (an XCD's L2 holds 4 MB)
   int mv_strip_l2_kb  = 2500;  // ... and are sized so that three periods' worth of a strip's X rows stay below this
+  int mv_nt          = 0;  // rank-2 gather kernel: nontemporal loads of the matrix streams (entries, values)
   int mv_glds        = 1;  // rank-2 LDS-staged kernel: X window through global_load_lds (1) or through registers (0)
   int mv_long_T      = 0;  // rank-2 gather kernel: rows above this many entries get a workgroup each (0 = automatic: 4 x the average row, at least 64)
   int mv4_min_nvec   = 4;  // narrowest multivector the plane-marching kernel takes (a block of fewer than 16 columns runs its partial-block form)
@@ -67,6 +68,9 @@ struct SpmvTuning {
                                    // the copy (tests)
   int colslab_min_knnz = 20000;    // ... from this many thousand nnz
   int colslab_shift = 0;           // ... log2 of the columns per slab (0 = 2 MB of x)
+  int check_entries = 0;           // debug aid: 1 = every call hashes the matrix's column array and compares it with the hash the analysis saw (one
+                                   // extra pass over entries and a stream synchronisation per call): a structure edited in place under a live handle
+                                   // is reported (KKAMD_ERR_STATE) instead of silently multiplied with the old analysis
   int colslab_const = 0;           // ... 1 = the caller promises constant matrix values (no tracking pass per call)
   int values_tracking = 0;         // how re-ordered copies of A.values (cached transpose, column-slab copy) follow value changes: 0 exact (bitwise
                                    // comparison against a shadow copy, every call), 1 the caller notifies (kkamd_spmv_plan_values_changed), 2
@@ -155,12 +159,14 @@ struct kkamd_spmv_plan {
   // (TPL_SpMV_Data::set_exec_space, sparse/src/KokkosSparse_spmv_handle.hpp:95-104)
   hipStream_t last_stream = nullptr;
   bool used = false;
+  unsigned long long entries_hash = 0; bool entries_hash_known = false;     // knob check_entries
 };
 
 namespace kk {
 // the plan's scratch (carry, packs) is stream-ordered: when the stream changes, the old one is fenced first
 int  bind_stream(kkamd_spmv_plan* p, hipStream_t st);
 int  check_plan(const kkamd_spmv_plan* p, const kkamd_crs_t* A);
+int  check_entries_content(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st);   // knob check_entries; no-op otherwise
 void mv_plan_destroy(kkamd_mv_plan* mv);
 int64_t mv_plan_query(const kkamd_mv_plan* mv, int what);   // 0 tiles, 1 pattern tiles, 2 order in use, 3 bytes
 void mv4_plan_destroy(kkamd_mv4_plan* p);

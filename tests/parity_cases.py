@@ -226,6 +226,25 @@ def check_values_tracking(be):
         kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 1000))
 
 
+def check_entries_guard(be):
+    """knob check_entries: a column array edited in place under a live handle is reported, an untouched one is not"""
+    import pytest
+    A0 = oracle.laplace3d("FE", 12, 11, 10)
+    A = dev(be, A0)
+    h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("check_entries", 1)
+    x, y = be.from_numpy(np.ones(A0.ncols)), be.from_numpy(np.zeros(A0.nrows))
+    kk.spmv(h, "N", 1.0, A, x, 0.0, y); kk.spmv(h, "N", 1.0, A, x, 0.0, y)
+    A.values[:] = be.from_numpy(A0.values * 2.0)                     # values may change
+    kk.spmv(h, "N", 1.0, A, x, 0.0, y)
+    e = be.to_numpy(A.graph.entries).copy(); e[5], e[6] = e[6], e[5]
+    A.graph.entries[:] = be.from_numpy(e)                            # the structure may not
+    with pytest.raises(kk.KkamdError) as ei:
+        kk.spmv(h, "N", 1.0, A, x, 0.0, y)
+    assert ei.value.status == kk._capi.ERR_STATE
+    h2 = kk.SPMVHandle("SPMV_DEFAULT")                               # without the knob nothing is checked (and nothing is paid)
+    kk.spmv(h2, "N", 1.0, A, x, 0.0, y)
+
+
 def check_mv_transpose_cached(be):
     """Rank 2, modes T / H of an analysed handle run the mode-N dispatch on the cached transpose (no atomics): the four layout pairs,
     a value update between the calls, a lattice matrix (its transpose takes the plane-marching kernel), a rectangular one, 64-bit

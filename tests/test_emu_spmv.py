@@ -207,6 +207,10 @@ def test_mv5_matrix_core(be):
     pc.check_mv5(be, light=True)
 
 
+def test_check_entries_knob(be):
+    pc.check_entries_guard(be)
+
+
 def test_values_tracking_policies(be):
     # exact (default) / notify / fingerprints for the cached transpose and the column-slab copy; kkamd_spmv_plan_values_changed
     pc.check_values_tracking(be)

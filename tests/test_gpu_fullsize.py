@@ -168,6 +168,10 @@ def test_spgemm_rmat_s20_without_a_host_copy_of_c(be):
     rng = np.random.default_rng(20)
     x = 0.5 + rng.random(R.ncols)
     xd = torch.from_numpy(x).cuda()
+    # a second probe with mixed signs: sums cancel, so the bound is relative to the row's norm -- |C| |x| row by row, which is
+    # A (A |x|) for the non-negative A -- not to the result
+    xs = (0.5 + rng.random(R.ncols)) * np.where(rng.random(R.ncols) < 0.5, -1.0, 1.0)
+    xsd = torch.from_numpy(xs).cuda()
 
     def check(Rh, tag):
         ax = oracle.spmv_omp(R.row_map, R.entries, R.values, 1.0, x, 0.0, np.zeros(R.nrows))          # B = A keeps its values
@@ -178,7 +182,15 @@ def test_spgemm_rmat_s20_without_a_host_copy_of_c(be):
         den = np.abs(gold) + np.abs(got)
         rel = float((np.abs(got - gold) / np.where(den > 0, den, 1.0)).max())
         assert rel <= 1e-12, "%s: C x differs from A (A x): max rel %g" % (tag, rel)             # all terms positive: no cancellation
-        return rel
+        axs = oracle.spmv_omp(R.row_map, R.entries, R.values, 1.0, xs, 0.0, np.zeros(R.nrows))
+        golds = oracle.spmv_omp(Rh.row_map, Rh.entries, Rh.values, 1.0, axs, 0.0, np.zeros(R.nrows))
+        axa = oracle.spmv_omp(R.row_map, R.entries, R.values, 1.0, np.abs(xs), 0.0, np.zeros(R.nrows))
+        norm = oracle.spmv_omp(Rh.row_map, Rh.entries, Rh.values, 1.0, axa, 0.0, np.zeros(R.nrows))      # sum_j |C_ij| |x_j|
+        pc.kk.spmv("N", 1.0, Cd, xsd, 0.0, yd)
+        gots = yd.cpu().numpy()
+        rels = float((np.abs(gots - golds) / np.where(norm > 0, norm, 1.0)).max())
+        assert rels <= 1e-12, "%s: C x differs from A (A x) for the mixed-sign probe: max error relative to the row norm %g" % (tag, rels)
+        return max(rel, rels)
     rel1 = check(R, "numeric")
     ent_sum = int(ent[::1009].to(torch.int64).sum().item())
     R2 = oracle.Crs(R.nrows, R.ncols, R.row_map, R.entries, 1.0 + 49.0 * rng.random(R.nnz))
