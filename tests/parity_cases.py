@@ -245,15 +245,19 @@ def check_entries_guard(be):
     kk.spmv(h2, "N", 1.0, A, x, 0.0, y)
 
 
-def check_mv_transpose_cached(be):
+def check_mv_transpose_cached(be, light=False):
     """Rank 2, modes T / H of an analysed handle run the mode-N dispatch on the cached transpose (no atomics): the four layout pairs,
     a value update between the calls, a lattice matrix (its transpose takes the plane-marching kernel), a rectangular one, 64-bit
     offsets; explicit_transpose 0 keeps the reference's atomic scatter."""
     lib = be.lib
     kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 0))
     try:
-        for A0, maxv in ((oracle.random_crs(900, 700, 9, variance=3, seed=7, sorted_rows=True), 1.0), (oracle.laplace3d("FE", 34, 9, 8), 32.0)):
-            for (xo, yo), nvec, off in zip((("C", "C"), ("F", "F"), ("C", "F"), ("F", "C")), (16, 5, 21, 32), (np.int32, np.int64, np.int32, np.int32)):
+        mats = ((oracle.random_crs(900, 700, 9, variance=3, seed=7, sorted_rows=True), 1.0), (oracle.laplace3d("FE", 34, 9, 8), 32.0))
+        combos = list(zip((("C", "C"), ("F", "F"), ("C", "F"), ("F", "C")), (16, 5, 21, 32), (np.int32, np.int64, np.int32, np.int32)))
+        if light:                                                  # the emulator: the unstructured matrix, two layout pairs (the GPU suite runs them all)
+            mats, combos = mats[:1], combos[:2]
+        for A0, maxv in mats:
+            for (xo, yo), nvec, off in combos:
                 h = check_spmv_mv(be, A0, nvec, "T", 1.5, 0.0, xo, yo, algo="SPMV_DEFAULT", max_val=maxv, nans=True, offset_dtype=off)
                 assert h.query("transpose_cached") == 1
                 check_spmv_mv(be, A0, nvec, "H", 1.0, -0.5, xo, yo, algo="SPMV_DEFAULT", max_val=maxv, offset_dtype=off)

@@ -218,7 +218,7 @@ def test_values_tracking_policies(be):
 
 def test_mv_transposed_modes_through_cached_transpose(be):
     # rank 2, modes T / H of an analysed handle: the mode-N dispatch on the cached transpose
-    pc.check_mv_transpose_cached(be)
+    pc.check_mv_transpose_cached(be, light=True)
 
 
 def test_mv6_nonzero_split(be):
