@@ -316,7 +316,8 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* handle, const char* key, double valu
  * 7 symbolic insertions after compression, 8 numeric algorithm in use (0 hash, 1 dense accumulator), 9 the SPGEMMAlgorithm value the
  * caller set (4 = SPGEMM_DEFAULT until then), 10 number of distinct hints recorded, 11 the last numeric call kept the entries(C)
  * of the dense rows from the previous call (numeric reuse), 12 rows whose entries(C) the last numeric call wrote from a bitmap kept by the
- * symbolic phase, 13 bitmaps the symbolic phase holds at this moment (they are freed by the numeric call that uses them). */
+ * symbolic phase, 13 bitmaps the symbolic phase holds at this moment (they are freed by the numeric call that uses them), 14 rows whose entries(C) the
+ * last numeric call copied from the entry lists the symbolic phase left (dense rows whose bitmap is not kept). */
 int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);
 /* the recorded value of a hint key (the reference's get_* of the same setter); KKAMD_ERR_INVALID_ARG when the key was never set */
 int kkamd_spgemm_get_hint(kkamd_spgemm_handle_t* handle, const char* key, double* value);

@@ -99,6 +99,7 @@ struct SpgemmTuning {
   int hub_split      = 1;         // hub rows: one workgroup per pass of kHubLa entries (sums of rows with several passes meet through fp64 atomics)
   int sym_large      = 0;         // symbolic: rows of 2049..8192 products through the 16384-slot hash kernel; 0 (default) = the bitmap kernel (R-MAT scale 20: the hash kernel spent 21 ms on 137 K such rows, symbolic 78 -> 68 ms without it)
   int keep_bitmaps   = 1;         // symbolic keeps the bitmaps of its densest rows for the first numeric call (0 = every row walks its products twice)
+  int keep_lists     = 1;         // ... and the entry lists of the other dense rows, in a pool behind the bitmaps (0 = those rows walk their products twice)
   int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
@@ -782,6 +783,12 @@ struct BitmapStore {                 // where the symbolic count kernel may leav
   unsigned long long* counter = nullptr;
   long long cap = 0, min_count = 0;
   int words = 0;
+  // ... or its ENTRIES, for the rows whose bitmap is not kept (fewer than min_count entries, or no slot left): the set bits in ascending
+  // order at pool[pool_off[row] ...], space taken from the cursor row by row
+  int32_t* pool = nullptr;
+  long long* pool_off = nullptr;     // [m], -1 = not written
+  unsigned long long* pool_cursor = nullptr;
+  long long pool_cap = 0;
 };
 template <class OffT, bool EMIT>
 __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const int32_t* __restrict__ perm,
@@ -801,6 +808,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
   const int t       = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
   int64_t total     = 0;
+  int ch_a = 0, ch_z = 0, ch_excl = 0;                             // (count only) the work-item's run of words in the last window and its offset
   (void)sg_log2;
   for (int64_t c0 = 0; c0 < k; c0 += win_bits) {
     const int nbits  = (int)((k - c0 < (int64_t)win_bits) ? k - c0 : (int64_t)win_bits);
@@ -846,6 +854,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
         for (int wd = a; wd < z; ++wd) cnt += __popcll(bm[wd]);
         int tot;
         const int excl = block_exclusive_scan_n<int, kDenseBlock>(cnt, &tot, s_wave);
+        ch_a = a; ch_z = z; ch_excl = excl;
         if (EMIT && !KK_DBG(1)) {
           int64_t pos = (int64_t)rmC[row] + total + excl;
           for (int wd = a; wd < z; ++wd) {
@@ -882,6 +891,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
   if constexpr (!EMIT) {
     // the symbolic phase keeps the bitmaps of its densest rows (BitmapStore): the first numeric call writes their entries(C)
     // straight from them instead of walking the row's products a second time.  One window only (k <= win_bits).
+    bool kept = false;
     if (bs.words && total >= bs.min_count) {
       __shared__ long long s_slot;
       if (t == 0) { const unsigned long long sl = atomicAdd(bs.counter, 1ull); s_slot = sl < (unsigned long long)bs.cap ? (long long)sl : -1; }
@@ -891,6 +901,26 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
         kk_u64* dst = bs.words_out + (size_t)slot * (size_t)bs.words;
         for (int i = t; i < bs.words; i += kDenseBlock) dst[i] = bm[i];
         if (t == 0) bs.row_slot[row] = (int32_t)slot;
+        kept = true;
+      }
+    }
+    // the other rows leave their ENTRIES: the bitmap is still in LDS and every work-item knows where its run of words starts in the row
+    // (ch_excl), so the first numeric call copies the list instead of walking the row's products again (R-MAT scale 20: 370 K rows, 47 ms)
+    if (bs.pool && !kept && total > 0 && k <= (int64_t)win_bits) {              // workgroup-uniform
+      __shared__ long long s_poff;
+      if (t == 0) {
+        const unsigned long long o = atomicAdd(bs.pool_cursor, (unsigned long long)total);
+        s_poff = (o + (unsigned long long)total <= (unsigned long long)bs.pool_cap) ? (long long)o : -1;
+      }
+      __syncthreads();
+      const long long poff = s_poff;
+      if (poff >= 0) {
+        int32_t* dst = bs.pool + poff + ch_excl;
+        for (int wd = ch_a; wd < ch_z; ++wd) {
+          kk_u64 v = bm[wd];
+          while (v) { const int bit = __ffsll(v) - 1; *dst++ = (int32_t)((int64_t)wd * 64 + bit); v &= v - 1; }
+        }
+        if (t == 0) bs.pool_off[row] = poff;
       }
     }
   }
@@ -914,7 +944,17 @@ __global__ __launch_bounds__(kBlock) void spgemm_count_ge_kernel(int64_t n, cons
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
 }
 // rows of the dense bin: those with a stored bitmap first, the others from the end
-__global__ __launch_bounds__(kBlock) void spgemm_split_stored_kernel(int64_t nd, const int32_t* __restrict__ perm_in, const int32_t* __restrict__ row_slot,
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_copy_pool_kernel(const int32_t* __restrict__ perm, const long long* __restrict__ pool_off, const int32_t* __restrict__ pool,
+                                                                 const OffT* __restrict__ rmC, int32_t* __restrict__ entC) {
+  // entries(C) of a row whose list the symbolic phase left in the pool
+  const int64_t row = perm[blockIdx.x];
+  const int64_t b = (int64_t)rmC[row], n = (int64_t)rmC[row + 1] - b;
+  const int32_t* src = pool + pool_off[row];
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) entC[b + i] = src[i];
+}
+template <class SlotT>
+__global__ __launch_bounds__(kBlock) void spgemm_split_stored_kernel(int64_t nd, const int32_t* __restrict__ perm_in, const SlotT* __restrict__ row_slot,
                                                                     int32_t* __restrict__ perm_out, unsigned long long* __restrict__ counters /*[2]*/) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int lane  = threadIdx.x & 63;
@@ -1630,6 +1670,10 @@ struct kkamd_spgemm_handle {
   int64_t bm_cap = 0, bm_stored = 0; int bm_words = 0; bool bm_pooled = false;
   int64_t bitmaps_used = 0;        // rows of the last numeric call whose entries(C) came from a stored bitmap
   int32_t* d_emit_perm = nullptr; int64_t n_emit_stored = 0;    // the dense bin as [rows with a stored bitmap | the others]
+  // entry lists of the dense rows whose bitmap is not kept, left by the symbolic phase in the tail of the same buffer
+  int32_t* d_ent_pool = nullptr; long long* d_pool_off = nullptr; int64_t pool_cap = 0, pool_used = 0;
+  int32_t* d_emit_perm2 = nullptr; int64_t n_emit_pooled = 0;   // "the others" as [rows with a pooled list | rows that walk their products]
+  int64_t pooled_used = 0;         // rows of the last numeric call whose entries(C) were copied from the pool
   bool entries_valid = false;      // entries(C) as the last numeric call left them are still what entC_ptr holds (numeric reuse)
   bool entries_reused = false;     // the last numeric call kept them
   const void *entC_ptr = nullptr, *rmC_ptr = nullptr;
@@ -1729,7 +1773,10 @@ static void free_bitmap_store(kkamd_spgemm_handle* h) {
   if (h->d_row_slot) (void)hipFree(h->d_row_slot);
   if (h->d_bm_counter) (void)hipFree(h->d_bm_counter);
   if (h->d_emit_perm) (void)hipFree(h->d_emit_perm);
+  if (h->d_emit_perm2) (void)hipFree(h->d_emit_perm2);
+  if (h->d_pool_off) (void)hipFree(h->d_pool_off);
   h->d_bm_store = nullptr; h->d_row_slot = nullptr; h->d_bm_counter = nullptr; h->d_emit_perm = nullptr;
+  h->d_emit_perm2 = nullptr; h->d_pool_off = nullptr; h->d_ent_pool = nullptr; h->pool_cap = 0; h->pool_used = 0; h->n_emit_pooled = 0;
   h->bm_cap = 0; h->bm_stored = 0; h->bm_words = 0; h->n_emit_stored = 0;
 }
 static double words_mb(int words) { return (double)words * 8.0 / 1048576.0; }
@@ -1858,24 +1905,38 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
             if (cap > (int64_t)h_q) cap = (int64_t)h_q;
           }
           if (cap > nb(4)) cap = nb(4);
-          const size_t got = cap >= 1 ? take_bitmap_store(h, (size_t)cap * (size_t)words * 8) : 0;
-          cap = (int64_t)(got / ((size_t)words * 8));
+          // behind the bitmaps, room for the ENTRY LISTS of the rows whose bitmap is not kept: a tenth of the free HBM (the caller still
+          // has entries(C) and values(C) to allocate between the phases)
+          const size_t store_need = cap >= 1 ? (size_t)cap * (size_t)words * 8 : 0;
+          const size_t pool_need = g_spgemm.keep_lists ? (((size_t)((double)(free_b + pooled) / 10.0)) & ~(size_t)255) : 0;
+          const size_t got = cap >= 1 ? take_bitmap_store(h, store_need + pool_need) : 0;
+          const size_t got_store = got < store_need ? got : store_need;
+          cap = (int64_t)(got_store / ((size_t)words * 8));
+          const int64_t pool_cap = (int64_t)((got - got_store) / sizeof(int32_t));
           if (cap >= 1 && hipMalloc((void**)&h->d_row_slot, sizeof(int32_t) * (size_t)m) == hipSuccess &&
-              hipMalloc((void**)&h->d_bm_counter, sizeof(unsigned long long)) == hipSuccess &&
-              hipMemsetAsync(h->d_row_slot, 0xFF, sizeof(int32_t) * (size_t)m, st) == hipSuccess && hipMemsetAsync(h->d_bm_counter, 0, sizeof(unsigned long long), st) == hipSuccess) {
+              hipMalloc((void**)&h->d_bm_counter, 2 * sizeof(unsigned long long)) == hipSuccess &&
+              hipMemsetAsync(h->d_row_slot, 0xFF, sizeof(int32_t) * (size_t)m, st) == hipSuccess && hipMemsetAsync(h->d_bm_counter, 0, 2 * sizeof(unsigned long long), st) == hipSuccess) {
             h->bm_cap = cap; h->bm_words = words;
             bs.words_out = (kk_u64*)h->d_bm_store; bs.row_slot = h->d_row_slot; bs.counter = h->d_bm_counter; bs.cap = cap; bs.min_count = k / 32; bs.words = words;
+            if (pool_cap > 0 && hipMalloc((void**)&h->d_pool_off, sizeof(long long) * (size_t)m) == hipSuccess &&
+                hipMemsetAsync(h->d_pool_off, 0xFF, sizeof(long long) * (size_t)m, st) == hipSuccess) {
+              h->d_ent_pool = (int32_t*)((char*)h->d_bm_store + got_store); h->pool_cap = pool_cap;
+              bs.pool = h->d_ent_pool; bs.pool_off = h->d_pool_off; bs.pool_cursor = h->d_bm_counter + 1; bs.pool_cap = pool_cap;
+            } else (void)hipGetLastError();
           } else { (void)hipGetLastError(); free_bitmap_store(h); }
         } else (void)hipGetLastError();
       }
       if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, entB, rmC, (const OffT*)nullptr,
                                                (int32_t*)nullptr, k, sg, st, nullptr, nullptr, bs))) return rc;
       if (bs.words) {
-        unsigned long long h_n = 0;
-        KK_HIP(hipMemcpyAsync(&h_n, h->d_bm_counter, sizeof h_n, hipMemcpyDeviceToHost, st));
+        unsigned long long h_c[2] = {0, 0};
+        KK_HIP(hipMemcpyAsync(h_c, h->d_bm_counter, sizeof h_c, hipMemcpyDeviceToHost, st));
         KK_HIP(hipStreamSynchronize(st));
+        const unsigned long long h_n = h_c[0];
         h->bm_stored = (int64_t)(h_n < (unsigned long long)h->bm_cap ? h_n : (unsigned long long)h->bm_cap);
-        if (h->bm_stored == 0) free_bitmap_store(h);
+        h->pool_used = bs.pool ? (int64_t)h_c[1] : 0;              // (the cursor runs past the capacity when rows did not fit: those rows have no list)
+        if (h->verbose && bs.pool) KK_VERBOSE("\tkkamd spgemm symbolic: entry lists kept for the numeric phase: %.1f of %.1f MB\n", 4e-6 * (double)h->pool_used, 4e-6 * (double)h->pool_cap);
+        if (h->bm_stored == 0 && h->pool_used == 0) free_bitmap_store(h);
         if (h->verbose) KK_VERBOSE("\tkkamd spgemm symbolic: bitmaps of %lld rows kept for the numeric phase (%.1f MB)\n", (long long)h->bm_stored, (double)h->bm_stored * words_mb(h->bm_words));
       }
     }
@@ -1954,6 +2015,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     }
     h->numeric_bins_ready = true;
     if (h->d_emit_perm) { (void)hipFree(h->d_emit_perm); h->d_emit_perm = nullptr; h->n_emit_stored = 0; }
+    if (h->d_emit_perm2) { (void)hipFree(h->d_emit_perm2); h->d_emit_perm2 = nullptr; h->n_emit_pooled = 0; }
     if (h->d_hub_items) { (void)hipFree(h->d_hub_items); h->d_hub_items = nullptr; h->n_hub_items = 0; }
     if (h->d_hub_multi) { (void)hipFree(h->d_hub_multi); h->d_hub_multi = nullptr; h->n_hub_multi = 0; }
   }
@@ -1984,7 +2046,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     const int32_t* dperm = h->d_perm + off.off[4];
     // entries(C) of every dense row, column-sorted
     if (keep_entries) h->entries_reused = true;
-    else if (h->d_bm_store && h->bm_stored > 0 && h->algorithm == 0) {
+    else if (h->d_bm_store && (h->bm_stored > 0 || h->pool_used > 0) && h->algorithm == 0) {
       // rows whose bitmap the symbolic phase kept are written from it; the others walk their products
       if (!h->d_emit_perm) {
         DevBuf c2;
@@ -1992,7 +2054,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         KK_HIP(hipMemsetAsync(c2.p, 0, 2 * sizeof(unsigned long long), st));
         KK_HIP(hipMalloc((void**)&h->d_emit_perm, sizeof(int32_t) * (size_t)nb(4)));
         int32_t* d_ep = h->d_emit_perm; const int32_t* d_rs = h->d_row_slot; unsigned long long* d_c2 = c2.as<unsigned long long>();
-        KK_LAUNCH(spgemm_split_stored_kernel, (unsigned)ceil_div(nb(4), kBlock), kBlock, 0, st, nb(4), dperm, d_rs, d_ep, d_c2);
+        KK_LAUNCH((spgemm_split_stored_kernel<int32_t>), (unsigned)ceil_div(nb(4), kBlock), kBlock, 0, st, nb(4), dperm, d_rs, d_ep, d_c2);
         unsigned long long h_c2[2] = {0, 0};
         KK_HIP(hipMemcpyAsync(h_c2, c2.p, sizeof h_c2, hipMemcpyDeviceToHost, st));
         KK_HIP(hipStreamSynchronize(st));
@@ -2003,9 +2065,30 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         const int32_t* d_ep = h->d_emit_perm; const int32_t* d_rs = h->d_row_slot; const kk_u64* d_st = (const kk_u64*)h->d_bm_store;
         KK_LAUNCH((spgemm_emit_bitmap_kernel<OffT>), (unsigned)ns, kDenseBlock, 0, st, d_ep, d_rs, d_st, h->bm_words, rmC, entC);
       }
-      if (nr && (rc = launch_dense_cols<OffT, true>(nr, h->d_emit_perm + ns, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st, nullptr, nullptr,
-                                                    BitmapStore(), (int64_t)g_spgemm.emit_win_bits))) return rc;
-      h->bitmaps_used = ns;
+      int64_t np = 0;                                            // of the others: rows whose entry list the symbolic phase left in the pool
+      const int32_t* rest = h->d_emit_perm + ns;
+      if (nr && h->d_pool_off && h->pool_used > 0) {
+        if (!h->d_emit_perm2) {
+          DevBuf c3;
+          KK_HIP(c3.alloc(2 * sizeof(unsigned long long)));
+          KK_HIP(hipMemsetAsync(c3.p, 0, 2 * sizeof(unsigned long long), st));
+          KK_HIP(hipMalloc((void**)&h->d_emit_perm2, sizeof(int32_t) * (size_t)nr));
+          int32_t* d_ep2 = h->d_emit_perm2; const long long* d_po = h->d_pool_off; unsigned long long* d_c3 = c3.as<unsigned long long>();
+          KK_LAUNCH((spgemm_split_stored_kernel<long long>), (unsigned)ceil_div(nr, kBlock), kBlock, 0, st, nr, rest, d_po, d_ep2, d_c3);
+          unsigned long long h_c3[2] = {0, 0};
+          KK_HIP(hipMemcpyAsync(h_c3, c3.p, sizeof h_c3, hipMemcpyDeviceToHost, st));
+          KK_HIP(hipStreamSynchronize(st));
+          h->n_emit_pooled = (int64_t)h_c3[0];
+        }
+        np = h->n_emit_pooled; rest = h->d_emit_perm2;
+        if (np) {
+          const long long* d_po = h->d_pool_off; const int32_t* d_pl = h->d_ent_pool;
+          KK_LAUNCH((spgemm_copy_pool_kernel<OffT>), (unsigned)np, kBlock, 0, st, rest, d_po, d_pl, rmC, entC);
+        }
+      }
+      if (nr - np && (rc = launch_dense_cols<OffT, true>(nr - np, rest + np, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st, nullptr, nullptr,
+                                                         BitmapStore(), (int64_t)g_spgemm.emit_win_bits))) return rc;
+      h->bitmaps_used = ns; h->pooled_used = np;
     }
     else if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
     const int64_t n_lds = h->n_dense_lds; int64_t n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_lds - n_hubl;
@@ -2151,6 +2234,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_hub_chunked") g_spgemm.hub_chunked = value != 0;
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
+  else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
   else if (k == "spgemm_hub_split") g_spgemm.hub_split = value != 0;
   else if (k == "spgemm_emit_win_bits") { if (value < 0 || (value & 63)) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_emit_win_bits must be a multiple of 64"); g_spgemm.emit_win_bits = value; }
@@ -2355,6 +2439,7 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 11: *value = h->entries_reused ? 1 : 0; break;
     case 12: *value = h->bitmaps_used; break;
     case 13: *value = h->bm_stored; break;
+    case 14: *value = h->pooled_used; break;
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
   return KKAMD_OK;
