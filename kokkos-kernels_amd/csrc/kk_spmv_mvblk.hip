@@ -193,7 +193,7 @@ __device__ __forceinline__ bool mv5_nonfinite(double v) {
 // ncv = valid right-hand sides of this pass (the spare lanes of a narrower block read its last column and store nothing).
 // SWAP: D^T = X^T A^T (column-major Y, see the file header).
 constexpr int kMv5Chunk = 64;
-template <class OffT, class AT, int NC, bool SWAP, bool XT>
+template <class OffT, class AT, int NC, bool SWAP>
 __global__ __launch_bounds__(kWave) void spmv_mv5_kernel(int64_t nrows, int64_t nnz, const OffT* __restrict__ row_map,
                                                          const int32_t* __restrict__ entries, const AT* __restrict__ values,
                                                          const int64_t* __restrict__ blk_off, const int32_t* __restrict__ cols,
@@ -206,12 +206,6 @@ __global__ __launch_bounds__(kWave) void spmv_mv5_kernel(int64_t nrows, int64_t 
   AT* s_val = reinterpret_cast<AT*>(smem);
   int32_t* s_cols = reinterpret_cast<int32_t*>(smem + (size_t)capv * sizeof(double));
   unsigned long long* s_masks = reinterpret_cast<unsigned long long*>(smem + (size_t)capv * sizeof(double) + kMv5Chunk * 16);
-  // XT (column-major X): the X values of a batch of blocks pass through LDS -- a lane loads ONE union column for 16 right-hand sides
-  // (neighbouring lanes, neighbouring union columns: contiguous bytes of a column of X wherever the union's columns are adjacent) and
-  // the operand layout is read back from rows padded to an odd length.  Loading them in operand order made every wave instruction
-  // touch 64 different lines of X (block diagonal 32 x 32 x 16: 0.30 ms against 0.20 for row-major X).
-  constexpr int NU = 4 * UB, XP = 16 * NC + 1;                   // union columns per batch, padded row of the X staging
-  double* s_x = reinterpret_cast<double*>(smem + (size_t)capv * sizeof(double) + kMv5Chunk * 24);
   const int lane = threadIdx.x;
   const int64_t tile = xcd_order(blockIdx.x, gridDim.x, remap);
   const int64_t b0 = blk_off[tile], b1 = blk_off[tile + 1];
@@ -258,29 +252,11 @@ __global__ __launch_bounds__(kWave) void spmv_mv5_kernel(int64_t nrows, int64_t 
     KK_WAVE_SYNC();                                              // ... and, in the first chunk, the tile's values are in place
     for (int bl = 0; bl < nbc; bl += UB) {
       double xv[UB][NC];
-      if (XT) {
-        const int u_ = lane % NU, jh = lane / NU;                  // the lane's union column of the batch, its half of the right-hand sides (NC = 2)
-        const int at = 4 * bl + u_;
-        const int cu = at < 4 * nbc ? s_cols[at] : -1;
-        double tx[16];
+      KK_UNROLL
+      for (int u = 0; u < UB; ++u) {
+        const int c = s_cols[4 * (bl + u < nbc ? bl + u : nbc - 1) + kq];
         KK_UNROLL
-        for (int jj = 0; jj < 16; ++jj) { const int jcol = 16 * jh + jj; tx[jj] = 0.0; if (cu >= 0 && jcol < ncv) tx[jj] = X[(int64_t)cu * xs0 + (int64_t)jcol * xs1]; }
-        KK_WAVE_SYNC();                                            // the previous batch has been read out of s_x
-        KK_UNROLL
-        for (int jj = 0; jj < 16; ++jj) s_x[u_ * XP + 16 * jh + jj] = tx[jj];
-        KK_WAVE_SYNC();
-        KK_UNROLL
-        for (int u = 0; u < UB; ++u) {
-          KK_UNROLL
-          for (int q = 0; q < NC; ++q) xv[u][q] = s_x[(4 * u + kq) * XP + 16 * q + i];
-        }
-      } else {
-        KK_UNROLL
-        for (int u = 0; u < UB; ++u) {
-          const int c = s_cols[4 * (bl + u < nbc ? bl + u : nbc - 1) + kq];
-          KK_UNROLL
-          for (int q = 0; q < NC; ++q) { xv[u][q] = 0.0; if (c >= 0) xv[u][q] = xcol[q][(int64_t)c * xs0]; }
-        }
+        for (int q = 0; q < NC; ++q) { xv[u][q] = 0.0; if (c >= 0) xv[u][q] = xcol[q][(int64_t)c * xs0]; }
       }
       KK_UNROLL
       for (int u = 0; u < UB; ++u) {
@@ -435,21 +411,18 @@ static int mv5_launch(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   const unsigned grid = (unsigned)p->ntiles;
   const bool swap = ys0 < ys1;                                   // column-major Y
   const int remap = plan->tune.mv_remap;
-  const bool xt = xs0 < xs1;                                     // column-major X
-  const size_t lds = (size_t)p->cap * sizeof(double) + kMv5Chunk * 24 + (xt ? 64 * 17 * sizeof(double) : 0);
+  const size_t lds = (size_t)p->cap * sizeof(double) + kMv5Chunk * 24;
   for (int64_t c0 = 0; c0 < nvec;) {
     const int nc = (nvec - c0 > 16) ? 2 : 1;                     // 17..32 columns left: one pass over A for two blocks of 16
     const int ncv = (int)(nvec - c0 < 16 * nc ? nvec - c0 : 16 * nc);
     const double* Xb = X + c0 * xs1;
     double* Yb = Y + c0 * ys1;
-#define KK_MV5(NC_, SW, XT_)                                                                                                        \
-    KK_LAUNCH((spmv_mv5_kernel<OffT, AT, NC_, SW, XT_>), grid, kWave, lds, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map,        \
+#define KK_MV5(NC_, SW)                                                                                                             \
+    KK_LAUNCH((spmv_mv5_kernel<OffT, AT, NC_, SW>), grid, kWave, lds, st, A->num_rows, A->nnz, (const OffT*)A->d_row_map,             \
               (const int32_t*)A->d_entries, (const AT*)A->d_values, (const int64_t*)p->d_blk_off, (const int32_t*)p->d_cols,          \
               (const unsigned long long*)p->d_masks, Xb, xs0, xs1, Yb, ys0, ys1, alpha, beta, ncv, remap, p->cap)
-#define KK_MV5X(NC_, SW) do { if (xt) KK_MV5(NC_, SW, true); else KK_MV5(NC_, SW, false); } while (0)
-    if (nc == 2) { if (swap) KK_MV5X(2, true); else KK_MV5X(2, false); }
-    else         { if (swap) KK_MV5X(1, true); else KK_MV5X(1, false); }
-#undef KK_MV5X
+    if (nc == 2) { if (swap) KK_MV5(2, true); else KK_MV5(2, false); }
+    else         { if (swap) KK_MV5(1, true); else KK_MV5(1, false); }
 #undef KK_MV5
     KK_LAUNCH_CHECK();
     if (p->n_other > 0) {
