@@ -53,6 +53,14 @@ def run(be, budget, seed0=0, max_cases=None):
                         # analysed handles also through the column-slab copy (forced: slabs of 2^4 .. 2^12 columns) and the fingerprint-refreshed transpose
                         kn = {"colslab": 2, "colslab_shift": int(rng.integers(4, 13)), "colslab_const": int(rng.integers(0, 2)), "explicit_transpose_min_knnz": 0} if algo and rng.random() < 0.5 else None
                         pc.check_spmv(be, M, mode, float(rng.integers(-3, 4)), float(rng.integers(-2, 3)), algo=algo, offset_dtype=odt, max_val=50.0, seed=case, knobs=kn)
+                # rank 2 on the same matrix: the nonzero-split kernel (forced, or chosen by the long-row share), the gather kernels, and modes T / H
+                # through the cached transpose under a random value-tracking policy
+                for mode in "NT":
+                    beta = float(rng.integers(-1, 2))
+                    pc.check_spmv_mv(be, M, int(rng.choice([2, 5, 16, 16, 21, 32])), mode, float(rng.integers(-3, 4)), beta, str(rng.choice(["C", "F"])), str(rng.choice(["C", "F"])),
+                                     algo="SPMV_DEFAULT", seed=case, max_val=50.0, nans=(beta == 0.0 and rng.random() < 0.5), offset_dtype=odt,
+                                     knobs={"mv6": int(rng.choice([0, 1, 2, 2])), "explicit_transpose_min_knnz": 0, "explicit_transpose": int(rng.choice([0, 1, 1])),
+                                            "values_tracking": int(rng.integers(0, 3))})
             elif kind == 4:    # sort / merge / transpose
                 M = hubby(rng, int(rng.integers(5, 300)), int(rng.integers(50, 40000)), int(rng.integers(1, 30)), int(rng.integers(0, 3)), int(rng.integers(9000, 40000)), sort=False)
                 M.entries[rng.integers(0, M.nnz, size=M.nnz // 7)] = M.entries[rng.integers(0, M.nnz, size=M.nnz // 7)]   # duplicates
@@ -69,7 +77,7 @@ def run(be, budget, seed0=0, max_cases=None):
                 A = hubby(rng, int(rng.integers(2, 12)), n, 3, int(rng.integers(1, 4)), int(rng.integers(600, min(n, 6500))))
                 pc.check_spgemm(be, A, B, offset_dtype=odt, value_dtype=vdt)
             elif kind == 7:    # SpMV through an analysed handle with the 16-bit window codes forced on: structured, clustered, banded, random
-                sub = int(rng.integers(0, 4))
+                sub = int(rng.integers(0, 5))
                 if sub == 0:       # several diagonals at random offsets
                     n = int(rng.integers(500, 30000)); nc = int(rng.integers(n, 40 * n)); step = max(1, nc // n)
                     offs = np.unique(rng.integers(0, nc - step * n + 1, size=int(rng.integers(2, 30))))
@@ -85,6 +93,11 @@ def run(be, budget, seed0=0, max_cases=None):
                     if rng.random() < 0.5: dims = (int(rng.integers(150, 700)),) + tuple(int(rng.integers(3, 12)) for _ in range(nd - 1))   # long grid lines
                     st = "FE" if rng.random() < 0.5 else "FD"
                     M = oracle.laplace2d(st, *dims) if nd == 2 else oracle.laplace3d(st, *dims)
+                elif sub == 4:     # block structure: a stencil with 2 .. 4 degrees of freedom per node, or dense diagonal blocks (the matrix-core rank-2 kernel)
+                    if rng.random() < 0.5:
+                        M = pc.multi_dof(oracle.laplace2d("FE" if rng.random() < 0.5 else "FD", int(rng.integers(3, 40)), int(rng.integers(3, 30))), int(rng.integers(2, 5)), seed=case)
+                    else:
+                        bs = int(rng.integers(2, 70)); M = pc._crop_rows(pc.block_diagonal(int(rng.integers(2, 60)), bs, seed=case), int(rng.integers(bs, 2 * bs + 1)) if rng.random() < 0.2 else bs * 2)
                 else:              # banded random with duplicates / unsorted rows
                     n = int(rng.integers(200, 20000))
                     M = oracle.random_crs(n, n + int(rng.integers(0, 50)), int(rng.integers(1, 40)), variance=int(rng.integers(0, 10)), seed=int(rng.integers(1, 1 << 30)),
@@ -95,8 +108,8 @@ def run(be, budget, seed0=0, max_cases=None):
                 if rng.random() < 0.5:     # rank 2 on the same matrix: plane-marching (where it applies), LDS-staged tiles, wave-private kernel, every tile order
                     pc.check_spmv_mv(be, M, int(rng.choice([8, 16, 16, 32, 24, 5])), "N", float(rng.integers(-3, 4)), float(rng.integers(-1, 2)), str(rng.choice(["C", "F"])), str(rng.choice(["C", "F"])),
                                      algo="SPMV_DEFAULT", seed=case, max_val=50.0, nans=bool(rng.random() < 0.3), offset_dtype=odt,
-                                     knobs={"mv_kernel": int(rng.choice([0, 0, 2, 3])), "mv_order": int(rng.integers(0, 3)), "mv_strip_min_kb": 50, "mv_strip_l2_kb": int(rng.choice([64, 512])),
-                                            "mv4_wg_per_cu": int(rng.choice([1, 8, 64]))})
+                                     knobs={"mv_kernel": int(rng.choice([0, 0, 2, 3, 5])), "mv_order": int(rng.integers(0, 3)), "mv_strip_min_kb": 50, "mv_strip_l2_kb": int(rng.choice([64, 512])),
+                                            "mv4_wg_per_cu": int(rng.choice([1, 8, 64])), "mv5": int(rng.choice([1, 1, 2, 0])), "mv5_min_fill_pct": int(rng.choice([25, 5, 60]))})
                 for beta in (0.0, float(rng.integers(-2, 3))):
                     pc.check_spmv(be, M, "N", float(rng.integers(-3, 4)), beta, algo="SPMV_DEFAULT", offset_dtype=odt, max_val=50.0, seed=case, knobs=knobs,
                                   nans=(beta == 0.0), value_dtype=(vdt if vdt == np.float32 and rng.random() < 0.5 else None))
