@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Timing of the transposed SpMV modes (atomic kernels) next to the explicit alternative: transpose_matrix once, then a
-planned 'N' SpMV on the transpose."""
-import os, sys
+"""Modes T / H of an analysed handle on the bench matrix (27-pt 300^3), rank 1 and rank 2 (16 right-hand sides): the cached transpose
+under the three value-tracking policies (0 exact shadow comparison = default, 1 caller notifies, 2 fingerprints) and the reference's
+atomic scatter (explicit_transpose 0).  One JSON line."""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, kk_loader
 kk = kk_loader.load()
@@ -13,21 +14,29 @@ def timeit(fn, it=20):
     for _ in range(it): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / it
-for name, A in (("27pt 100^3", kk.laplace_matrix("FE", 100, 100, 100)), ("C2 27pt 300^3", kk.laplace_matrix("FE", 300, 300, 300))):
-    x = torch.rand(A.numRows(), dtype=torch.float64, device="cuda"); y = torch.zeros(A.numCols(), dtype=torch.float64, device="cuda")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+A = kk.laplace_matrix("FE", n, n, n)
+rows, nnz = A.numRows(), A.nnz()
+res = {"matrix": "27-pt FE %d^3" % n, "nnz": nnz}
+x = torch.rand(rows, dtype=torch.float64, device="cuda"); y = torch.zeros(A.numCols(), dtype=torch.float64, device="cuda")
+alg1 = nnz * 12 + (rows + 1) * 4 + 2 * rows * 8
+ref = None
+for tag, knobs in (("exact_default", {}), ("caller_notifies", {"values_tracking": 1}), ("fingerprints", {"values_tracking": 2}), ("atomic_scatter", {"explicit_transpose": 0})):
     h = kk.SPMVHandle("SPMV_DEFAULT")
-    t_T = timeit(lambda: kk.spmv(h, "T", 1.0, A, x, 0.0, y)); yT = y.clone()
-    hc = kk.SPMVHandle("SPMV_DEFAULT"); hc.set("explicit_transpose", 1)
-    torch.cuda.synchronize(); import time; t0 = time.perf_counter()
-    kk.spmv(hc, "T", 1.0, A, x, 0.0, y); torch.cuda.synchronize(); t_first = (time.perf_counter() - t0) * 1e3
-    t_C = timeit(lambda: kk.spmv(hc, "T", 1.0, A, x, 0.0, y))
-    h2c = kk.SPMVHandle("SPMV_DEFAULT"); h2c.set("explicit_transpose", 2)
-    t_C2 = timeit(lambda: kk.spmv(h2c, "T", 1.0, A, x, 0.0, y))
-    print("%-14s mode T, cached transpose, constant values promised: %.3f ms per call" % (name, t_C2))
-    print("%-14s mode T with the cached transpose: first call %.1f ms, then %.3f ms per call (max diff vs atomics %.2g)" % (name, t_first, t_C, (y - yT).abs().max().item()))
-    torch.cuda.synchronize(); import time; t0 = time.perf_counter()
-    At = kk.transpose_matrix(A); torch.cuda.synchronize(); t_tr = (time.perf_counter() - t0) * 1e3
-    h2 = kk.SPMVHandle("SPMV_DEFAULT")
-    t_N = timeit(lambda: kk.spmv(h2, "N", 1.0, At, x, 0.0, y))
-    print("%-14s mode T (atomics) %.3f ms | transpose_matrix %.1f ms once, then N on A^T %.3f ms | max diff %.2g"
-          % (name, t_T, t_tr, t_N, (y - yT).abs().max().item()))
+    for k, v in knobs.items(): h.set(k, v)
+    ms = timeit(lambda: kk.spmv(h, "T", 1.0, A, x, 0.0, y))
+    if ref is None: ref = y.clone()
+    res["rank1_" + tag] = {"ms": round(ms, 4), "frac_8TBps": round(alg1 / ms / 1e6 / 8000, 3), "max_diff_vs_exact": float((y - ref).abs().max())}
+    del h
+nv = 16
+X = torch.rand(rows, nv, dtype=torch.float64, device="cuda"); Y = torch.zeros(A.numCols(), nv, dtype=torch.float64, device="cuda")
+alg2 = nnz * 12 + (rows + 1) * 4 + 2 * rows * nv * 8
+ref = None
+for tag, knobs in (("exact_default", {}), ("caller_notifies", {"values_tracking": 1}), ("atomic_scatter", {"explicit_transpose": 0})):
+    h = kk.SPMVHandle("SPMV_DEFAULT")
+    for k, v in knobs.items(): h.set(k, v)
+    ms = timeit(lambda: kk.spmv(h, "T", 1.0, A, X, 0.0, Y), it=10)
+    if ref is None: ref = Y.clone()
+    res["rank2_x16_" + tag] = {"ms": round(ms, 4), "frac_8TBps": round(alg2 / ms / 1e6 / 8000, 3), "max_diff_vs_exact": float((Y - ref).abs().max())}
+    del h
+print(json.dumps(res))
