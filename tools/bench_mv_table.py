@@ -22,5 +22,5 @@ for name, A in pt.matrices(only):
         ms = pt.timeit(lambda: kk.spmv(h, "N", 1.0, A, Xl, 0.0, Yl), it=10)
         res[lay] = {"ms": round(ms, 4), "frac_8TBps": round(alg / ms / 1e6 / 8000, 3), "kernel": "mv4" if h.query("mv4_workgroups") else ("mv5" if h.query("mv5_tiles") else ("mv6" if h.query("mv6_chunks") else "mv2")), "mv5_fill": h.query("mv5_fill_permille") / 1000, "mv5_other_rows": h.query("mv5_other_rows"), "mv_order": h.query("mv_order"), "long_rows": h.query("mv_long_rows")}
         del h
-    print(json.dumps({"matrix": name, "nvec": nv, "rows": rows, "nnz": nnz, "alg_GB": round(alg / 1e9, 3), **res}), flush=True)
+    print(json.dumps({"matrix": name, "nvec": nv, "rows": rows, "nnz": nnz, "alg_GB": round(alg / 1e9, 3), "knobs": os.environ.get("KK_KNOBS", ""), **res}), flush=True)
     del A, X, Y
