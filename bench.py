@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a plain copy reaches
-PMC_FILE = os.path.join(ROOT, "profiles", "round3", "bench_n1_pmc_hbm.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round4", "bench_n1_pmc_hbm.json")
 
 
 def kernel_source_sha(unit="kk_spmv.hip"):
