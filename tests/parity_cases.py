@@ -341,6 +341,37 @@ def check_spgemm(be, A0, B0, offset_dtype=np.int32, reuse=True, value_dtype=np.f
     return got
 
 
+def check_spgemm_kept_structure(be):
+    """The symbolic phase keeps, for the first numeric call, the bitmaps of its densest rows (>= k/32 entries) and the ENTRY LISTS of the
+    other dense rows (round 4; lists above 6144 entries leave LDS in several rounds): structure identical to the oracle's, both sources
+    used, numeric reuse keeps the entries, and with the lists switched off the same C comes out"""
+    import fuzz_cases as fz
+    rng = np.random.default_rng(5)
+    n, k = 60, 400000
+    B = fz.hubby(rng, n, k, 3000, 0, 3000)            # rows of B: 0 .. 6000 entries
+    A = fz.hubby(rng, 10, n, 3, 2, 20)                # rows of A: 0 .. 6 entries, two of about 20
+    gold = oracle.spgemm(A, B)
+    for lists in (1, 0):
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_keep_lists", lists))
+        try:
+            kh = kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+            Ad, Bd = dev(be, A), dev(be, B)
+            Cm = kk.spgemm_symbolic(kh, Ad, False, Bd, False)
+            kk.spgemm_numeric(kh, Ad, False, Bd, False, Cm)
+            sh = kh.get_spgemm_handle()
+            assert sh.get(12) > 0 and (sh.get(14) > 0) == bool(lists), (sh.get(12), sh.get(14))
+            rm, ent, val = Cm.to_host()
+            ok, msg = oracle.is_same_matrix(oracle.Crs(A.nrows, B.ncols, rm.astype(np.int64), ent, val.astype(np.float64)), gold)
+            assert ok, msg
+            kk.spgemm_numeric(kh, Ad, False, Bd, False, Cm)            # reuse: entries kept
+            assert sh.get(11) == 1
+            rm2, ent2, val2 = Cm.to_host()
+            assert np.array_equal(ent, ent2) and np.allclose(val, val2, rtol=1e-13)
+            kh.destroy_spgemm_handle()
+        finally:
+            kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_keep_lists", 1))
+
+
 def randomized(A0, seed=5):
     """values re-drawn in [1,50) as the reference's SpGEMM tests do (Test_Sparse_spgemm.hpp:62-72)"""
     rng = np.random.default_rng(seed)

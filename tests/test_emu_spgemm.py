@@ -187,6 +187,10 @@ def test_spgemm_dense_row_windows(be):
         _set(be, "spgemm_win_bits", 100)
 
 
+def test_spgemm_structure_kept_by_the_symbolic_phase(be):
+    pc.check_spgemm_kept_structure(be)
+
+
 def test_spgemm_issue402(be):
     g = np.load(os.path.join(GOLD, "matrix_issue402.npz"))
     A0 = oracle.Crs(1813, 1813, g["row_map"], g["entries"], g["values"])
