@@ -915,25 +915,12 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
       __syncthreads();
       const long long poff = s_poff;
       if (poff >= 0) {
-        // through LDS, so that the stores are whole lines: a work-item's run of words holds a few dozen entries of a sparse row, and
-        // writing them where they stand made every store instruction 64 four-byte pieces in 64 different lines (2.4e9 of them on
-        // R-MAT scale 20: +16 ms).  The product walk's scratch is free by now: 6144 entries per round, a row of 32 K entries takes six.
-        int32_t* stage = reinterpret_cast<int32_t*>(&s_flatq);
-        constexpr int kStage = (int)(sizeof(FlatScratchQ<kDenseBlock>) / sizeof(int32_t)) / 1024 * 1024;
-        for (long long base = 0; base < total; base += kStage) {           // workgroup-uniform
-          long long pos = ch_excl;
-          for (int wd = ch_a; wd < ch_z; ++wd) {
-            kk_u64 v = bm[wd];
-            while (v) {
-              const int bit = __ffsll(v) - 1;
-              if (pos >= base && pos < base + kStage) stage[pos - base] = (int32_t)((int64_t)wd * 64 + bit);
-              ++pos; v &= v - 1;
-            }
-          }
-          __syncthreads();
-          const int nst = (int)(total - base < kStage ? total - base : kStage);
-          for (int q = t; q < nst; q += kDenseBlock) bs.pool[poff + base + q] = stage[q];
-          __syncthreads();
+        // (staging the list in LDS -- the product walk's scratch -- and writing it out in whole lines, 6144 entries per round, measured
+        // slower: dense_cols<false> 70 -> 115 ms on R-MAT scale 20.  Each work-item writes the entries of its run of words where they stand.)
+        int32_t* dst = bs.pool + poff + ch_excl;
+        for (int wd = ch_a; wd < ch_z; ++wd) {
+          kk_u64 v = bm[wd];
+          while (v) { const int bit = __ffsll(v) - 1; *dst++ = (int32_t)((int64_t)wd * 64 + bit); v &= v - 1; }
         }
         if (t == 0) bs.pool_off[row] = poff;
       }

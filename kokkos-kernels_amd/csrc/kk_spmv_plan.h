@@ -109,7 +109,7 @@ struct kkamd_spmv_plan {
   void* d_carry = nullptr;       // [2*nblocks] 8-byte slots: head partials, then tail partials
   void* d_xpack = nullptr;       // rank-2: row-major packed copy of a column-major X (grown on demand)
   size_t xpack_bytes = 0;
-  void* d_ypack = nullptr;       // rank-2 LDS-staged kernel: row-major Y scratch for a column-major Y
+  void* d_ypack = nullptr;       // rank-2 nonzero-split kernel: row-major Y scratch for a column-major Y
   size_t ypack_bytes = 0;
   const void* entries = nullptr; // the matrix's column array (identity check + analysis)
   // Window codes: per tile up to 16 column windows of 4096 and, per nonzero, a 16-bit code (window << 12 | column - window
@@ -180,7 +180,7 @@ int  mv5_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X
 void mv6_plan_destroy(kkamd_mv6_plan* p);
 int64_t mv6_plan_query(const kkamd_mv6_plan* p, int what);  // 0 chunks, 1 empty rows, 2 bytes
 int  mv6_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st);
-int  mv6_spmv(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0, int64_t ys1,
+int  mv6_spmv(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0, int64_t ys1,
               int64_t nvec, double alpha, double beta, hipStream_t st);   // X row-major, ldx even, 16-byte aligned
 void cs_plan_destroy(kkamd_cs_plan* cs);
 int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes
