@@ -141,6 +141,37 @@ void test_all_interfaces() {
     int64_t cached = 0;
     if (ht.plan) KokkosSparse::Impl::kkamd_check(kkamd_spmv_plan_query(ht.plan, "transpose_cached", &cached));
     EXPECT(cached == 1);
+    // A.values rewritten in place under the live handle (the reference reads them at every call): the cached transpose follows --
+    // exactly by default, and by notification (handle.values_changed()) when the caller asks for "values_tracking" 1
+    auto values_host = Kokkos::create_mirror_view(A.values);
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) ht.set_knob("values_tracking", 1);
+      for (int i = 0; i < (int)val.size(); ++i) { val[i] = (pass ? -1.0 : 3.0) * val[i] + 0.125; values_host(i) = val[i]; }
+      Kokkos::deep_copy(A.values, values_host);
+      if (pass == 1) ht.values_changed();
+      std::fill(hyt.begin(), hyt.end(), 0.0);
+      for (int i = 0; i < m; ++i) for (int j = rm[i]; j < rm[i + 1]; ++j) hyt[ent[j]] += 2.0 * val[j] * hxt[i];
+      Kokkos::deep_copy(yt, -7.0);
+      KokkosSparse::spmv(space, &ht, "T", 2.0, A, xt, 0.0, yt); space.fence();
+      auto h = Kokkos::create_mirror_view(yt); Kokkos::deep_copy(h, yt);
+      double e = 0; for (int i = 0; i < n; ++i) e = std::max(e, std::fabs(h(i) - hyt[i]));
+      EXPECT(e < 1e-11);
+    }
+    // rank 2, mode T, through the same kind of handle (the mode-N dispatch on the cached transpose)
+    KokkosSparse::SPMVHandle<device, M, V2, V2> ht2(KokkosSparse::SPMV_DEFAULT);
+    ht2.set_knob("explicit_transpose_min_knnz", 0);
+    V2 Xt("Xt", m, nv), Yt("Yt", n, nv);
+    std::vector<double> hXt((size_t)m * nv), hYt((size_t)n * nv, 0.0);
+    for (auto& v : hXt) v = (g() % 1000) / 1000.0;
+    for (int i = 0; i < m; ++i) for (int j = rm[i]; j < rm[i + 1]; ++j) for (int c = 0; c < nv; ++c) hYt[idx(ent[j], c, n)] += 2.0 * val[j] * hXt[idx(i, c, m)];
+    Kokkos::deep_copy(Xt, Kokkos::View<double**, layout, Kokkos::HostSpace>(hXt.data(), m, nv));
+    Kokkos::deep_copy(Yt, -7.0);
+    KokkosSparse::spmv(space, &ht2, "T", 2.0, A, Xt, 0.0, Yt); space.fence();
+    auto h2t = Kokkos::create_mirror_view(Yt); Kokkos::deep_copy(h2t, Yt);
+    double e2 = 0; for (int i = 0; i < n; ++i) for (int c = 0; c < nv; ++c) e2 = std::max(e2, std::fabs(h2t(i, c) - hYt[idx(i, c, n)]));
+    EXPECT(e2 < 1e-11);
+    if (ht2.plan) KokkosSparse::Impl::kkamd_check(kkamd_spmv_plan_query(ht2.plan, "transpose_cached", &cached));
+    EXPECT(cached == 1);
   }
   // error behaviour: dimension mismatch and BSR-only algorithm on a CrsMatrix
   bool threw = false;

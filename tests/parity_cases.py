@@ -135,6 +135,11 @@ def check_mv5(be, light=False):
     assert h.query("mv5_tiles") > 10 and h.query("mv5_fill_permille") < 100, (h.query("mv5_tiles"), h.query("mv5_fill_permille"))
     h = check_spmv_mv(be, oracle.laplace2d("FE", 130, 41), 21, "N", 1.0, 1.0, "F", "F", algo="SPMV_DEFAULT", max_val=32.0, knobs={"mv5": 2})
     assert h.query("mv5_tiles") > 0
+    # tiles whose union takes several chunks of 64 column blocks: 16 rows x 100 entries, no column shared (400 blocks per tile)
+    wide = oracle.random_crs(48, 200000, 100, variance=0, seed=9, sorted_rows=True)
+    for nvec, yo in ((16, "C"), (32, "F")):
+        h = check_spmv_mv(be, wide, nvec, "N", 1.5, 0.0, "C", yo, algo="SPMV_DEFAULT", max_val=1.5, nans=True, knobs={"mv5": 2})
+        assert h.query("mv5_tiles") >= 2 and h.query("mv5_blocks") > 2 * 300, (h.query("mv5_tiles"), h.query("mv5_blocks"))
     for algo, knobs in (("SPMV_DEFAULT", {"mv5": 0}), ("SPMV_DEFAULT", {"mv_kernel": 2}), ("SPMV_FAST_SETUP", None)):
         h = check_spmv_mv(be, A0, 16, "N", 1.0, 0.0, "C", "C", algo=algo, knobs=knobs, max_val=1.5)
         assert h.query("mv5_tiles") == 0
