@@ -99,6 +99,7 @@ struct SpgemmTuning {
   int hub_split      = 1;         // hub rows: one workgroup per pass of kHubLa entries (sums of rows with several passes meet through fp64 atomics)
   int sym_large      = 0;         // symbolic: rows of 2049..8192 products through the 16384-slot hash kernel; 0 (default) = the bitmap kernel (R-MAT scale 20: the hash kernel spent 21 ms on 137 K such rows, symbolic 78 -> 68 ms without it)
   int keep_bitmaps   = 1;         // symbolic keeps the bitmaps of its densest rows for the first numeric call (0 = every row walks its products twice)
+  int emit_staged    = 1;         // entries(C) of the stored bitmaps leave through wave-private LDS (whole-line stores); 0 = every lane writes its own run
   int keep_lists     = 1;         // ... and the entry lists of the other dense rows, in a pool behind the bitmaps (0 = those rows walk their products twice)
   int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
@@ -777,6 +778,51 @@ __device__ __forceinline__ int emit_bits_by_wave(const kk_u64* __restrict__ bm, 
   }
   return tot;
 }
+// The same through wave-private LDS: a wave's 64 words are taken 16 at a time -- lane l owns the l-th 16-bit piece of the 16 words, so
+// the pieces ascend with the lanes --, the pieces' columns are laid down in order in 4 KB of LDS, and the (at most 1024) entries leave
+// with store instructions whose 64 lanes write 64 CONSECUTIVE entries.  With the direct form every lane writes its own run of up to
+// 64 entries, i.e. every store instruction is 64 four-byte pieces in 64 different lines: on R-MAT scale 20 the stored bitmaps emit
+// 8e9 entries = 8e9 L2 write requests in 27.9 ms -- the L2's request rate, not its bandwidth (32 GB at 1.15 TB/s).
+__device__ __forceinline__ int emit_bits_by_wave_staged(const kk_u64* __restrict__ bm, int words, int64_t col0, int64_t pos0, int32_t* __restrict__ entC, int* s_wave,
+                                                        int32_t* __restrict__ stage /* [1024] of this wave */) {
+  constexpr int NW = kDenseBlock / 64, NB = 16;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wpw = ((words + NW - 1) / NW + 63) & ~63;
+  const int w0 = wave * wpw, w1 = (w0 + wpw < words) ? w0 + wpw : words;
+  kk_u64 w[NB];
+  int wsum = 0;
+  KK_UNROLL
+  for (int i = 0; i < NB; ++i) { const int wd = w0 + i * 64 + lane; w[i] = (i * 64 < wpw && wd < w1) ? bm[wd] : 0ull; wsum += __popcll(w[i]); }
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+  if (lane == 0) s_wave[wave] = wsum;
+  __syncthreads();
+  int tot = 0;
+  for (int i = 0; i < NW; ++i) { if (i == wave) pos0 += tot; tot += s_wave[i]; }
+  KK_UNROLL
+  for (int i = 0; i < NB; ++i) {
+    if (i * 64 >= wpw) break;                              // uniform
+    if (__ballot(w[i] != 0ull) == 0ull) continue;          // 64 empty words (uniform)
+    for (int sub = 0; sub < 4; ++sub) {                    // 16 words = 64 pieces of 16 bits
+      const int src = sub * 16 + (lane >> 2);
+      const unsigned lo = __shfl((unsigned)w[i], src, 64), hi = __shfl((unsigned)(w[i] >> 32), src, 64);
+      const unsigned half = (lane & 2) ? hi : lo;
+      unsigned piece = (lane & 1) ? (half >> 16) : (half & 0xffffu);
+      const int pc = __popc(piece);
+      int inc = pc;
+      for (int o = 1; o < 64; o <<= 1) { const int nb_ = __shfl_up(inc, (unsigned)o, 64); if (lane >= o) inc += nb_; }
+      const int total = __shfl(inc, 63, 64);
+      if (total == 0) continue;                            // uniform
+      int at = inc - pc;
+      const int c0 = (int)(col0 + ((int64_t)(w0 + i * 64 + src)) * 64 + 16 * (lane & 3));
+      while (piece) { const int bit = __ffs((int)piece) - 1; stage[at++] = c0 + bit; piece &= piece - 1; }
+      KK_WAVE_SYNC();
+      for (int q = lane; q < total; q += 64) entC[pos0 + q] = stage[q];
+      KK_WAVE_SYNC();
+      pos0 += total;
+    }
+  }
+  return tot;
+}
 struct BitmapStore {                 // where the symbolic count kernel may leave a row's bitmap (words == 0: nowhere)
   kk_u64* words_out = nullptr;       // [cap][words]
   int32_t* row_slot = nullptr;       // [m], -1 = not stored
@@ -932,10 +978,12 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
 template <class OffT>
 __global__ __launch_bounds__(kDenseBlock) void spgemm_emit_bitmap_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ row_slot,
                                                                          const kk_u64* __restrict__ store, int words, const OffT* __restrict__ rmC,
-                                                                         int32_t* __restrict__ entC) {
+                                                                         int32_t* __restrict__ entC, int staged) {
   __shared__ int s_wave[kDenseBlock / 64];
+  __shared__ int32_t s_stage[kDenseBlock / 64][1024];
   const int64_t row = perm[blockIdx.x];
-  (void)emit_bits_by_wave(store + (size_t)row_slot[row] * (size_t)words, words, 0, (int64_t)rmC[row], entC, s_wave);
+  if (staged) (void)emit_bits_by_wave_staged(store + (size_t)row_slot[row] * (size_t)words, words, 0, (int64_t)rmC[row], entC, s_wave, s_stage[threadIdx.x >> 6]);
+  else (void)emit_bits_by_wave(store + (size_t)row_slot[row] * (size_t)words, words, 0, (int64_t)rmC[row], entC, s_wave);
 }
 // rows of a bin whose size (products) reaches thr
 __global__ __launch_bounds__(kBlock) void spgemm_count_ge_kernel(int64_t n, const int32_t* __restrict__ perm, const int64_t* __restrict__ sizes, int64_t thr,
@@ -2065,7 +2113,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       const int64_t ns = h->n_emit_stored, nr = nb(4) - ns;
       if (ns) {
         const int32_t* d_ep = h->d_emit_perm; const int32_t* d_rs = h->d_row_slot; const kk_u64* d_st = (const kk_u64*)h->d_bm_store;
-        KK_LAUNCH((spgemm_emit_bitmap_kernel<OffT>), (unsigned)ns, kDenseBlock, 0, st, d_ep, d_rs, d_st, h->bm_words, rmC, entC);
+        KK_LAUNCH((spgemm_emit_bitmap_kernel<OffT>), (unsigned)ns, kDenseBlock, 0, st, d_ep, d_rs, d_st, h->bm_words, rmC, entC, g_spgemm.emit_staged);
       }
       int64_t np = 0;                                            // of the others: rows whose entry list the symbolic phase left in the pool
       const int32_t* rest = h->d_emit_perm + ns;
@@ -2237,6 +2285,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
   else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
+  else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
   else if (k == "spgemm_hub_split") g_spgemm.hub_split = value != 0;
   else if (k == "spgemm_emit_win_bits") { if (value < 0 || (value & 63)) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_emit_win_bits must be a multiple of 64"); g_spgemm.emit_win_bits = value; }
