@@ -81,6 +81,8 @@ constexpr int kValBlock   = 512;      // dense-row value kernel
 constexpr int kValTable   = 4096;     // value-window hash table (16 KB keys + 32 KB fp64 sums in LDS: 3 workgroups per CU)
 constexpr int kValCap     = kValTable / 2;   // C entries per value window
 constexpr int kValLa      = 512;      // A entries of a row whose B cursors live in LDS (10 KB)
+constexpr int kValTableSmall = 2048;  // ... of the light shape for rows with few entries (8 KB + 16 KB) ...
+constexpr int kValLaSmall = 256;      // ... and its lists per pass (256 work-items)
 constexpr int kValLa2     = 1024;     // ... of the flat value kernel's second shape (1024 work-items, one workgroup per CU)
 constexpr int kValLong    = 128;      // B rows at least this long are streamed by a whole wave
 constexpr int kHubLa      = 4096;     // A rows up to this long keep cursor + next column in LDS (hub value kernel)
@@ -102,6 +104,7 @@ struct SpgemmTuning {
   int emit_staged    = 1;         // entries(C) of the stored bitmaps leave through wave-private LDS (whole-line stores); 0 = every lane writes its own run
   int keep_lists     = 1;         // ... and the entry lists of the other dense rows, in a pool behind the bitmaps (0 = those rows walk their products twice)
   int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
+  int val_small_cnt  = 8192;      // rows of C with at most this many entries (and at most kValLaSmall entries in the A row) take the flat value kernel's light shape (0 = none)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
   int col_quads      = 1;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads (0 = one 4-byte load per product)
@@ -1179,6 +1182,31 @@ __global__ __launch_bounds__(kBlock) void spgemm_split_dense_kernel(int64_t nd, 
   }
 }
 
+// ... and the rows of the first group once more: SMALL ones (at most cnt_max entries in the row of C and la_max in the row of A) first, the
+// others from the back.  The small rows get the flat value kernel's light shape (256 work-items, 2048-slot table, 38 KB of LDS: four
+// workgroups per CU instead of two): on R-MAT scale 20 245 K of the 454 K rows of this group have 257 .. 8 K entries -- unions of two
+// to five lists, 4 % of the products -- and a 512-work-item workgroup around a 4096-slot table spent most of its time per row on set-up.
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_split_small_kernel(int64_t nd, const int32_t* __restrict__ perm_in, const OffT* __restrict__ rmA,
+                                                                    const int64_t* __restrict__ sizes, int64_t la_max, int64_t cnt_max,
+                                                                    int32_t* __restrict__ perm_out, unsigned long long* __restrict__ counters /*[2]*/) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane  = threadIdx.x & 63;
+  int32_t row = 0;
+  int cls     = -1;
+  if (i < nd) { row = perm_in[i]; cls = ((int64_t)rmA[row + 1] - (int64_t)rmA[row] <= la_max && sizes[row] <= cnt_max) ? 0 : 1; }
+  for (int c = 0; c < 2; ++c) {
+    const kk_u64 m = __ballot(cls == c);
+    unsigned long long start = 0;
+    if (lane == 0 && m) start = atomicAdd(&counters[c], (unsigned long long)__popcll(m));
+    start = __shfl(start, 0, 64);
+    if (cls == c) {
+      const int64_t r = (int64_t)start + __popcll(m & ((1ull << lane) - 1ull));
+      perm_out[c == 0 ? r : nd - 1 - r] = row;
+    }
+  }
+}
+
 // dense rows, values (B rows column-sorted, at most kValLa entries in the A row): entries(C) of the row are already
 // in place and sorted (spgemm_dense_cols_kernel<EMIT>), so the row is cut into windows of `cap` consecutive C entries.
 // A window's columns are hashed into a clean LDS table (each work-item keeps the slots of its columns in registers).
@@ -1705,6 +1733,7 @@ struct kkamd_spgemm_handle {
   int32_t* d_hub_items = nullptr; int64_t n_hub_items = 0;      // (index, pass) pairs of the hub rows: one workgroup each
   int32_t* d_hub_multi = nullptr; int64_t n_hub_multi = 0;      // indices of the hub rows with several passes (zeroed before the launch)
   bool hub_from_mid = false;       // the dense bin is cut [<= kValLa | <= kValLa2 | rest]: flat kernel twice, hub kernel for the rest
+  int64_t n_dense_small = 0;       // leading rows of THOSE that take the flat value kernel's light shape (few entries in C and in A)
   int64_t n_dense_lds = 0;         // leading rows of the dense bin taken by the LDS value kernel,
   int64_t n_dense_hub_lds = 0;     // then rows for the LDS hub kernel; the rest accumulate in HBM
   // options (kkamd_spgemm_set; the reference's SPGEMMHandle / KokkosKernelsHandle setters)
@@ -2062,6 +2091,17 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         lo += first[pass]; len -= first[pass];
       }
       h->n_dense_lds = first[0]; h->n_dense_hub_lds = first[1];
+      h->n_dense_small = 0;
+      if (first[0] > 0 && h->dense_lds && g_spgemm.val_kernel == 2 && g_spgemm.val_small_cnt > 0) {
+        KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
+        KK_HIP(hipMemcpyAsync(d_tmp, seg, sizeof(int32_t) * (size_t)first[0], hipMemcpyDeviceToDevice, st));
+        const int64_t* d_sz = h->d_sizes;
+        KK_LAUNCH((spgemm_split_small_kernel<OffT>), (unsigned)ceil_div(first[0], kBlock), kBlock, 0, st, first[0], (const int32_t*)d_tmp, rmA, d_sz,
+                  (int64_t)kValLaSmall, (int64_t)g_spgemm.val_small_cnt, seg, d_cnt);
+        KK_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+        h->n_dense_small = (int64_t)h_cnt[0];
+      }
     }
     h->numeric_bins_ready = true;
     if (h->d_emit_perm) { (void)hipFree(h->d_emit_perm); h->d_emit_perm = nullptr; h->n_emit_stored = 0; }
@@ -2215,8 +2255,15 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   } while (0)
       if (flat_vals) {
         if (cap > kValTable / 2) cap = kValTable / 2;
-        KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8, kValLa>), (unsigned)n_lds, kValBlock, 0, st, dperm, rmA, entA, valA, rmB,
-                  entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
+        const int64_t n_small = h->n_dense_small < n_lds ? h->n_dense_small : n_lds;
+        if (n_small) {                                           // the light shape for the rows with few entries (see spgemm_split_small_kernel)
+          const int cap_s = cap > kValTableSmall / 2 ? kValTableSmall / 2 : cap;
+          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTableSmall, kBlock, 8, kValLaSmall>), (unsigned)n_small, kBlock, 0, st, dperm, rmA, entA, valA, rmB,
+                    entB, valB, rmC, (const int32_t*)entC, valC, cap_s KK_DBG_ARG);
+        }
+        if (n_lds - n_small)
+          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8, kValLa>), (unsigned)(n_lds - n_small), kValBlock, 0, st, dperm + n_small, rmA, entA, valA, rmB,
+                    entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
       } else switch (g_spgemm.val_shape) {
         case 1: KK_VALS(8192, 1024); break;
         case 2: KK_VALS(8192, 512); break;
@@ -2285,6 +2332,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
   else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
+  else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
   else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
   else if (k == "spgemm_hub_split") g_spgemm.hub_split = value != 0;
