@@ -83,6 +83,7 @@ constexpr int kValCap     = kValTable / 2;   // C entries per value window
 constexpr int kValLa      = 512;      // A entries of a row whose B cursors live in LDS (10 KB)
 constexpr int kValTableSmall = 2048;  // ... of the light shape for rows with few entries (8 KB + 16 KB) ...
 constexpr int kValLaSmall = 256;      // ... and its lists per pass (256 work-items)
+constexpr int kValTableTiny = 1024, kValLaTiny = 128;    // the lightest shape: 128 work-items (19 KB of LDS: eight workgroups per CU)
 constexpr int kValLa2     = 1024;     // ... of the flat value kernel's second shape (1024 work-items, one workgroup per CU)
 constexpr int kValLong    = 128;      // B rows at least this long are streamed by a whole wave
 constexpr int kHubLa      = 4096;     // A rows up to this long keep cursor + next column in LDS (hub value kernel)
@@ -104,7 +105,9 @@ struct SpgemmTuning {
   int emit_staged    = 1;         // entries(C) of the stored bitmaps leave through wave-private LDS (whole-line stores); 0 = every lane writes its own run
   int keep_lists     = 1;         // ... and the entry lists of the other dense rows, in a pool behind the bitmaps (0 = those rows walk their products twice)
   int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
-  int val_small_cnt  = 8192;      // rows of C with at most this many entries (and at most kValLaSmall entries in the A row) take the flat value kernel's light shape (0 = none)
+  int val_small_cnt  = 65536;     // rows of C with at most this many entries (and at most kValLaSmall entries in the A row) take the flat value kernel's light shape (0 = none;
+                                  // R-MAT scale 20 numeric / reuse: 0: 221.7 / 184.7 ms, 8192: 217.6 / 180.7, 32768: 213.8 / 176.6, 65536: 211.1 / 174.6, 131072: 216.4 / 179.5, all: 219.0 / 182.3)
+  int val_tiny_cnt   = 0;         // ... and at most this many (and kValLaTiny entries in the A row) the lightest one: 128 work-items, 1024-slot table (0 = none)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
   int col_quads      = 1;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads (0 = one 4-byte load per product)
@@ -301,8 +304,8 @@ template <class VT> __device__ __forceinline__ void hash_accumulate(int* keys, V
 // the high bits and a probe loop with no trip counter -- the wave-wide loop runs as long as its slowest lane, so every
 // instruction in it counts.
 template <int H> __device__ __forceinline__ int vt_hash(int key) {
-  constexpr int kBits = H == 2048 ? 11 : (H == 4096 ? 12 : 13);
-  static_assert(H == 2048 || H == 4096 || H == 8192, "value table size");
+  constexpr int kBits = H == 1024 ? 10 : (H == 2048 ? 11 : (H == 4096 ? 12 : 13));
+  static_assert(H == 1024 || H == 2048 || H == 4096 || H == 8192, "value table size");
   return (int)(((unsigned)key * 0x9E3779B1u) >> (32 - kBits));
 }
 template <int H> __device__ __forceinline__ int vt_insert(int* hk, int key) {          // returns the slot
@@ -1733,7 +1736,8 @@ struct kkamd_spgemm_handle {
   int32_t* d_hub_items = nullptr; int64_t n_hub_items = 0;      // (index, pass) pairs of the hub rows: one workgroup each
   int32_t* d_hub_multi = nullptr; int64_t n_hub_multi = 0;      // indices of the hub rows with several passes (zeroed before the launch)
   bool hub_from_mid = false;       // the dense bin is cut [<= kValLa | <= kValLa2 | rest]: flat kernel twice, hub kernel for the rest
-  int64_t n_dense_small = 0;       // leading rows of THOSE that take the flat value kernel's light shape (few entries in C and in A)
+  int64_t n_dense_tiny = 0;        // leading rows of the dense bin that take the flat value kernel's lightest shape,
+  int64_t n_dense_small = 0;       // rows after them that take its light shape (few entries in C and in A)
   int64_t n_dense_lds = 0;         // leading rows of the dense bin taken by the LDS value kernel,
   int64_t n_dense_hub_lds = 0;     // then rows for the LDS hub kernel; the rest accumulate in HBM
   // options (kkamd_spgemm_set; the reference's SPGEMMHandle / KokkosKernelsHandle setters)
@@ -2091,16 +2095,23 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         lo += first[pass]; len -= first[pass];
       }
       h->n_dense_lds = first[0]; h->n_dense_hub_lds = first[1];
-      h->n_dense_small = 0;
-      if (first[0] > 0 && h->dense_lds && g_spgemm.val_kernel == 2 && g_spgemm.val_small_cnt > 0) {
-        KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
-        KK_HIP(hipMemcpyAsync(d_tmp, seg, sizeof(int32_t) * (size_t)first[0], hipMemcpyDeviceToDevice, st));
+      h->n_dense_small = 0; h->n_dense_tiny = 0;
+      if (first[0] > 0 && h->dense_lds && g_spgemm.val_kernel == 2) {
+        // [ lightest shape | light shape | the 512-work-item shape ]
+        const int64_t lim_la[2] = {kValLaTiny, kValLaSmall}, lim_cnt[2] = {g_spgemm.val_tiny_cnt, g_spgemm.val_small_cnt};
+        int64_t got[2] = {0, 0}, at = 0, left = first[0];
         const int64_t* d_sz = h->d_sizes;
-        KK_LAUNCH((spgemm_split_small_kernel<OffT>), (unsigned)ceil_div(first[0], kBlock), kBlock, 0, st, first[0], (const int32_t*)d_tmp, rmA, d_sz,
-                  (int64_t)kValLaSmall, (int64_t)g_spgemm.val_small_cnt, seg, d_cnt);
-        KK_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
-        KK_HIP(hipStreamSynchronize(st));
-        h->n_dense_small = (int64_t)h_cnt[0];
+        for (int lvl = 0; lvl < 2 && left > 0; ++lvl) {
+          if (lim_cnt[lvl] <= 0) continue;
+          KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
+          KK_HIP(hipMemcpyAsync(d_tmp, seg + at, sizeof(int32_t) * (size_t)left, hipMemcpyDeviceToDevice, st));
+          KK_LAUNCH((spgemm_split_small_kernel<OffT>), (unsigned)ceil_div(left, kBlock), kBlock, 0, st, left, (const int32_t*)d_tmp, rmA, d_sz,
+                    lim_la[lvl], lim_cnt[lvl], seg + at, d_cnt);
+          KK_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
+          KK_HIP(hipStreamSynchronize(st));
+          got[lvl] = (int64_t)h_cnt[0]; at += got[lvl]; left -= got[lvl];
+        }
+        h->n_dense_tiny = got[0]; h->n_dense_small = got[1];
       }
     }
     h->numeric_bins_ready = true;
@@ -2255,14 +2266,20 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   } while (0)
       if (flat_vals) {
         if (cap > kValTable / 2) cap = kValTable / 2;
-        const int64_t n_small = h->n_dense_small < n_lds ? h->n_dense_small : n_lds;
-        if (n_small) {                                           // the light shape for the rows with few entries (see spgemm_split_small_kernel)
+        const int64_t n_tiny = h->n_dense_tiny < n_lds ? h->n_dense_tiny : n_lds;
+        const int64_t n_small = h->n_dense_small < n_lds - n_tiny ? h->n_dense_small : n_lds - n_tiny;
+        if (n_tiny) {                                            // the lightest shape (see spgemm_split_small_kernel)
+          const int cap_t = cap > kValTableTiny / 2 ? kValTableTiny / 2 : cap;
+          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTableTiny, 128, 8, kValLaTiny>), (unsigned)n_tiny, 128, 0, st, dperm, rmA, entA, valA, rmB,
+                    entB, valB, rmC, (const int32_t*)entC, valC, cap_t KK_DBG_ARG);
+        }
+        if (n_small) {                                           // the light shape for the rows with few entries
           const int cap_s = cap > kValTableSmall / 2 ? kValTableSmall / 2 : cap;
-          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTableSmall, kBlock, 8, kValLaSmall>), (unsigned)n_small, kBlock, 0, st, dperm, rmA, entA, valA, rmB,
+          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTableSmall, kBlock, 8, kValLaSmall>), (unsigned)n_small, kBlock, 0, st, dperm + n_tiny, rmA, entA, valA, rmB,
                     entB, valB, rmC, (const int32_t*)entC, valC, cap_s KK_DBG_ARG);
         }
-        if (n_lds - n_small)
-          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8, kValLa>), (unsigned)(n_lds - n_small), kValBlock, 0, st, dperm + n_small, rmA, entA, valA, rmB,
+        if (n_lds - n_tiny - n_small)
+          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8, kValLa>), (unsigned)(n_lds - n_tiny - n_small), kValBlock, 0, st, dperm + n_tiny + n_small, rmA, entA, valA, rmB,
                     entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
       } else switch (g_spgemm.val_shape) {
         case 1: KK_VALS(8192, 1024); break;
@@ -2332,6 +2349,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
   else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
+  else if (k == "spgemm_val_tiny_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_tiny_cnt: %d is negative", value); g_spgemm.val_tiny_cnt = value; }
   else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
   else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
