@@ -107,7 +107,8 @@ struct SpgemmTuning {
   int val_la2        = kValLa2;   // ... up to this many entries (above kValLa2: several passes of kValLa2 lists)
   int val_small_cnt  = 65536;     // rows of C with at most this many entries (and at most kValLaSmall entries in the A row) take the flat value kernel's light shape (0 = none;
                                   // R-MAT scale 20 numeric / reuse: 0: 221.7 / 184.7 ms, 8192: 217.6 / 180.7, 32768: 213.8 / 176.6, 65536: 211.1 / 174.6, 131072: 216.4 / 179.5, all: 219.0 / 182.3)
-  int val_tiny_cnt   = 0;         // ... and at most this many (and kValLaTiny entries in the A row) the lightest one: 128 work-items, 1024-slot table (0 = none)
+  int val_tiny_cnt   = 32768;     // ... and at most this many (and kValLaTiny entries in the A row) the lightest one: 128 work-items, 1024-slot table (0 = none;
+                                  // R-MAT scale 20 numeric / reuse with the light shape at 65536: 0: 212.0 / 175.2 ms, 2048: 210.0 / 172.8, 8192: 208.4 / 171.6, 32768: 207.5 / 170.9)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
   int col_quads      = 1;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads (0 = one 4-byte load per product)
