@@ -2209,7 +2209,19 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       int cap = g_spgemm.val_cap;
       cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
       const int32_t* hperm = dperm + n_lds + n_hubl;
-      if (g_spgemm.hub_split && !h->d_hub_items) {            // (row, pass) items, once per set of bins
+      // the passes of a row that has several add into values(C) with global_atomic_add_f64: only into ordinary device memory (hardware
+      // floating-point atomics are not dependable on fine-grained / managed allocations); anything else keeps one workgroup per row, which
+      // runs the passes one after the other without atomics
+      bool plain_valc = true;
+#ifndef KK_EMU
+      {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, (const void*)valC) != hipSuccess) { (void)hipGetLastError(); plain_valc = false; }
+        else plain_valc = attr.type == hipMemoryTypeDevice && !attr.isManaged;
+      }
+#endif
+      const bool hub_split = g_spgemm.hub_split && plain_valc;
+      if (hub_split && !h->d_hub_items) {            // (row, pass) items, once per set of bins
         DevBuf pb;
         KK_HIP(pb.alloc(sizeof(int32_t) * (size_t)n_hub));
         int32_t* d_p = pb.as<int32_t>();
@@ -2232,7 +2244,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         if (!h_multi.empty()) KK_HIP(hipMemcpyAsync(h->d_hub_multi, h_multi.data(), sizeof(int32_t) * h_multi.size(), hipMemcpyHostToDevice, st));
         KK_HIP(hipStreamSynchronize(st));
       }
-      if (g_spgemm.hub_split && h->d_hub_items && h->n_hub_items > 0) {
+      if (hub_split && h->d_hub_items && h->n_hub_items > 0) {
         const int32_t* d_items = h->d_hub_items; const int32_t* d_multi = h->d_hub_multi;
         if (h->n_hub_multi) KK_LAUNCH((spgemm_zero_rows_kernel<OffT, VT>), (unsigned)h->n_hub_multi, kBlock, 0, st, hperm, d_multi, rmC, valC);
         KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)h->n_hub_items, kDenseBlock, 0, st, hperm, rmA, entA, valA, rmB, entB, valB,
