@@ -100,7 +100,6 @@ struct SpgemmTuning {
   int val_shape      = 0;         // value-kernel geometry: 0 = 4096 slots x 512 threads (default), 1..4 alternatives
   int emit_win_bits  = 0;         // numeric: bitmap window of the rows whose bitmap was not kept (0 = win_bits)
   int hub_split      = 1;         // hub rows: one workgroup per pass of kHubLa entries (sums of rows with several passes meet through fp64 atomics)
-  int sym_sort       = 1;         // symbolic: rows of 2049..8192 products counted by sorting their product columns in LDS (256 work-items, four rows per CU); 0 = the bitmap kernel
   int sym_large      = 0;         // symbolic: rows of 2049..8192 products through the 16384-slot hash kernel; 0 (default) = the bitmap kernel (R-MAT scale 20: the hash kernel spent 21 ms on 137 K such rows, symbolic 78 -> 68 ms without it)
   int keep_bitmaps   = 1;         // symbolic keeps the bitmaps of its densest rows for the first numeric call (0 = every row walks its products twice)
   int emit_staged    = 1;         // entries(C) of the stored bitmaps leave through wave-private LDS (whole-line stores); 0 = every lane writes its own run
@@ -742,91 +741,12 @@ __global__ __launch_bounds__(NT) void spgemm_sym_block_kernel(int64_t nbin, cons
   (void)nbin;
 }
 
-typedef unsigned long long kk_u64;
-struct BitmapStore {                 // where the symbolic count kernel may leave a row's bitmap (words == 0: nowhere)
-  kk_u64* words_out = nullptr;       // [cap][words]
-  int32_t* row_slot = nullptr;       // [m], -1 = not stored
-  unsigned long long* counter = nullptr;
-  long long cap = 0, min_count = 0;
-  int words = 0;
-  // ... or its ENTRIES, for the rows whose bitmap is not kept (fewer than min_count entries, or no slot left): the set bits in ascending
-  // order at pool[pool_off[row] ...], space taken from the cursor row by row
-  int32_t* pool = nullptr;
-  long long* pool_off = nullptr;     // [m], -1 = not written
-  unsigned long long* pool_cursor = nullptr;
-  long long pool_cap = 0;
-};
-// Rows of 2049 .. 8192 products, symbolic count BY SORTING: the row's product columns are collected in LDS (32 KB), sorted (bitonic, 256
-// work-items) and counted; the distinct columns are compacted in place and -- when the symbolic phase keeps entry lists (BitmapStore pool)
-// -- leave for the pool with whole-line stores.  38 KB of LDS: four rows per CU.  The bitmap kernel gave each of these rows a workgroup
-// of 1024 and a 128 KB bitmap, i.e. a whole CU (137 K such rows on R-MAT scale 20: ~18 ms of its 54), the 16384-slot hash kernel half a
-// CU (21 ms, round 3).
-template <class OffT, int CAP, int NT>
-__global__ __launch_bounds__(NT) void spgemm_sym_sort_kernel(int64_t nbin, const int32_t* __restrict__ perm, const OffT* __restrict__ rmA,
-                                                             const int32_t* __restrict__ entA, const OffT* __restrict__ rmB,
-                                                             const int32_t* __restrict__ entB, OffT* __restrict__ counts, BitmapStore bs) {
-  __shared__ int s_key[CAP];
-  __shared__ FlatScratch<NT> s_flat;
-  __shared__ int s_wave[NT / 64];
-  __shared__ int s_n;
-  __shared__ long long s_poff;
-  const int t = threadIdx.x;
-  const int64_t row = perm[blockIdx.x];
-  if (t == 0) s_n = 0;
-  __syncthreads();
-  flat_products<NT, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int c) { const int at = atomicAdd(&s_n, 1); if (at < CAP) s_key[at] = c; });
-  __syncthreads();
-  const int n = s_n < CAP ? s_n : CAP;                            // (the bin holds rows of at most CAP products)
-  int N = 64;
-  while (N < n) N <<= 1;
-  for (int p = n + t; p < N; p += NT) s_key[p] = INT_MAX;
-  __syncthreads();
-  for (int k2 = 2; k2 <= N; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int p = t; p < N; p += NT) {
-        const int q = p ^ j;
-        if (q > p) {
-          const int x = s_key[p], y = s_key[q];
-          const bool up = (p & k2) == 0;
-          if ((x > y) == up) { s_key[p] = y; s_key[q] = x; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // the distinct columns, compacted in place NT sorted entries at a time: read (entry and left neighbour), barrier, write
-  int total = 0;
-  for (int base = 0; base < N; base += NT) {                       // workgroup-uniform
-    const int p = base + t;
-    const int key = s_key[p];
-    const int flag = (key != INT_MAX && (p == 0 || key != s_key[p - 1])) ? 1 : 0;
-    int tot;
-    const int excl = block_exclusive_scan_n<int, NT>(flag, &tot, s_wave);    // (its barriers separate the reads above from the writes below)
-    if (flag) s_key[total + excl] = key;
-    total += tot;
-    __syncthreads();
-  }
-  if (t == 0) counts[row] = (OffT)total;
-  if (bs.pool && total > 0) {                                      // workgroup-uniform
-    if (t == 0) {
-      const unsigned long long o = atomicAdd(bs.pool_cursor, (unsigned long long)total);
-      s_poff = (o + (unsigned long long)total <= (unsigned long long)bs.pool_cap) ? (long long)o : -1;
-    }
-    __syncthreads();
-    const long long poff = s_poff;
-    if (poff >= 0) {
-      for (int q = t; q < total; q += NT) bs.pool[poff + q] = s_key[q];
-      if (t == 0) bs.pool_off[row] = poff;
-    }
-  }
-  (void)nbin;
-}
-
 // dense rows, columns: one workgroup of 16 waves per row around a k-bit bitmap in LDS (up to 2^20 columns = 128 KB
 // per pass; wider products take ceil(k / win_bits) passes over the row's products).  Columns are set with ds_or_b64,
 // then the touched word range is walked 1024 words at a time: popcount, workgroup scan, and -- when EMIT -- the set
 // bits are written out in ascending order, so entries(C) for the row leave the kernel column-sorted.  EMIT = false is
 // the symbolic count; EMIT = true fills entries(C) in the numeric phase (the value kernel below needs them).
+typedef unsigned long long kk_u64;
 // The set bits of bm[0 .. words) (LDS or HBM), as columns col0 + bit index in ascending order, to entC[pos0 ...]; returns their number.
 // Every wave owns a contiguous range of the words and walks it 64 words at a time (lane l owns word base + l): the loads of a wave
 // are 512 contiguous bytes, neighbouring lanes write neighbouring pieces of entries(C), the offsets inside a wave come from shuffles
@@ -910,6 +830,19 @@ __device__ __forceinline__ int emit_bits_by_wave_staged(const kk_u64* __restrict
   }
   return tot;
 }
+struct BitmapStore {                 // where the symbolic count kernel may leave a row's bitmap (words == 0: nowhere)
+  kk_u64* words_out = nullptr;       // [cap][words]
+  int32_t* row_slot = nullptr;       // [m], -1 = not stored
+  unsigned long long* counter = nullptr;
+  long long cap = 0, min_count = 0;
+  int words = 0;
+  // ... or its ENTRIES, for the rows whose bitmap is not kept (fewer than min_count entries, or no slot left): the set bits in ascending
+  // order at pool[pool_off[row] ...], space taken from the cursor row by row
+  int32_t* pool = nullptr;
+  long long* pool_off = nullptr;     // [m], -1 = not written
+  unsigned long long* pool_cursor = nullptr;
+  long long pool_cap = 0;
+};
 template <class OffT, bool EMIT>
 __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const int32_t* __restrict__ perm,
                                                                         const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
@@ -2023,16 +1956,13 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
                                                (int32_t*)nullptr, k, sg, st, endB, maskB))) return rc;
     }
   } else {
-    const bool sym_sort = g_spgemm.sym_sort && !g_spgemm.sym_large;   // rows of 2049 .. 8192 products: counted by sorting (default), by the 16384-slot hash (sym_large), or by the bitmap kernel
-    if ((rc = make_bins(m, h->d_sizes, k, (g_spgemm.sym_large || sym_sort) ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
+    if ((rc = make_bins(m, h->d_sizes, k, g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
     if (nb(1)) KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
                          (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, sg);
     if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
                          (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
-    if (nb(3) && !sym_sort) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
-                                      (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
-    if (nb(3) && sym_sort && !nb(4))                           // (with a bitmap bin the sort kernel is launched below, once the entry-list pool exists)
-      KK_LAUNCH((spgemm_sym_sort_kernel<OffT, kSymBlkL / 2, kBlock>), (unsigned)nb(3), kBlock, 0, st, nb(3), (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, BitmapStore());
+    if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
+                         (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
     if (nb(4)) {
       // keep the bitmaps of rows with at least k / 32 entries (the bitmap is then no larger than the row's entries) when one LDS
       // window covers the columns and an eighth of the free HBM holds them: R-MAT scale 20, 87 K rows (83 % of the products), 11 GB
@@ -2079,10 +2009,6 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
             } else (void)hipGetLastError();
           } else { (void)hipGetLastError(); free_bitmap_store(h); }
         } else (void)hipGetLastError();
-      }
-      if (nb(3) && sym_sort) {
-        BitmapStore bs3 = bs; bs3.words = 0; bs3.words_out = nullptr;                  // entry lists only
-        KK_LAUNCH((spgemm_sym_sort_kernel<OffT, kSymBlkL / 2, kBlock>), (unsigned)nb(3), kBlock, 0, st, nb(3), (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, bs3);
       }
       if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, entB, rmC, (const OffT*)nullptr,
                                                (int32_t*)nullptr, k, sg, st, nullptr, nullptr, bs))) return rc;
@@ -2440,7 +2366,6 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
   else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
-  else if (k == "spgemm_sym_sort") g_spgemm.sym_sort = value != 0;
   else if (k == "spgemm_hub_split") g_spgemm.hub_split = value != 0;
   else if (k == "spgemm_emit_win_bits") { if (value < 0 || (value & 63)) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_emit_win_bits must be a multiple of 64"); g_spgemm.emit_win_bits = value; }
   else if (k == "spgemm_val_la2") { if (value < kValLa2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_la2 must be at least %d", kValLa2); g_spgemm.val_la2 = value; }
