@@ -109,9 +109,10 @@ struct SpgemmTuning {
                                   // R-MAT scale 20 numeric / reuse: 0: 221.7 / 184.7 ms, 8192: 217.6 / 180.7, 32768: 213.8 / 176.6, 65536: 211.1 / 174.6, 131072: 216.4 / 179.5, all: 219.0 / 182.3)
   int val_tiny_cnt   = 32768;     // ... and at most this many (and kValLaTiny entries in the A row) the lightest one: 128 work-items, 1024-slot table (0 = none;
                                   // R-MAT scale 20 numeric / reuse with the light shape at 65536: 0: 212.0 / 175.2 ms, 2048: 210.0 / 172.8, 8192: 208.4 / 171.6, 32768: 207.5 / 170.9)
+  int val_steps      = 1;         // steps of a window's product walk a work-item of the flat value kernel keeps in flight (1..3)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
-  int col_quads      = 1;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads (0 = one 4-byte load per product)
+  int col_quads      = 4;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads, 4 or 8 per work-item and step (0 = one 4-byte load per product)
   int val_hub_flat   = 0;         // 1 = A rows above kValLa through the flat value kernel too (measured slower, see numeric_typed)
   int val_kernel     = 2;         // dense rows with short A rows: 2 = flat walk with the lists cut per window group (default), 1 = wave-per-list streaming
 };
@@ -431,15 +432,16 @@ __device__ __forceinline__ void flat_products_impl(int64_t row, const OffT* __re
           jj[u]  = sc.b0[sgc] + (q - sc.pre[sgc]);
         }
       }
+      // UNCONDITIONAL loads (a product past the end reads entry 0 of B, which exists when tot > 0): the compiler branches around a
+      // conditional load and then waits for every load in flight before it issues the next one -- U round trips per step, not one
+      KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u) {
+        col[u] = entB[jj[u]];
+        if constexpr (kVals) bv[u] = valB[jj[u]];
+      }
       KK_UNROLL
       for (int u = 0; u < kProdUnroll; ++u)
         if (q0 + u < tot) {
-          col[u] = entB[jj[u]];
-          if constexpr (kVals) bv[u] = valB[jj[u]];
-        }
-      KK_UNROLL
-      for (int u = 0; u < kProdUnroll; ++u)
-        if (col[u] >= 0) {
           if constexpr (kVals) f(chunk + seg[u], col[u], bv[u]);
           else f(chunk + seg[u], (int64_t)jj[u], col[u]);
         }
@@ -470,19 +472,27 @@ __device__ __forceinline__ void flat_products_v(int64_t row, const OffT* __restr
 // instruction -- and the lanes of a quad that lie before b0 (they belong to the previous row) or past b1 are masked.  The quad at
 // the end of a row is read entry by entry (a 16-byte load there could reach past the end of the array).  f(column).
 template <int NT> struct FlatScratchQ {
-  long long pre[NT + 1];    // quad offset of each A entry of the chunk
+  int pre[NT + 2];          // quad offset of each A entry of the chunk (32-bit: a chunk whose quads do not fit takes the plain loop below)
   long long b0[NT], b1[NT]; // its B row
   long long wave[NT / 64];
 };
-template <int NT, class OffT, class F>
+template <int NT, int Q, class OffT, class F>
 __device__ __forceinline__ void flat_columns_quads(int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
-                                                   const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, FlatScratchQ<NT>& sc, F f) {
-#ifndef KK_COL_QUADS
-#define KK_COL_QUADS 4
-#endif
-  constexpr int Q = KK_COL_QUADS;
+                                                   const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, int64_t nnzB,
+                                                   FlatScratchQ<NT>& sc, F f) {
   const int t = threadIdx.x;
   const int64_t a_beg = (int64_t)rmA[row], a_end = (int64_t)rmA[row + 1];
+  // Every 16-byte load of the walk is UNCONDITIONAL: a load the compiler has to branch around makes it wait for all loads in flight
+  // before it issues the next (the Q quads of a step then cost Q memory round trips instead of one -- how this walk ran until round 4:
+  // 2, 4 and 8 quads per step all measured the same).  A quad that does not exist reads quad 0; the one quad that would reach past
+  // the end of the array (nnz(B) not a multiple of 4: its last 1..3 entries) reads the last full quad instead and takes its entries
+  // from `tail`, loaded once.  nnz(B) >= 4 (the caller's condition for this walk).
+  // The walk's own arithmetic is 32-bit (quad offsets inside the chunk, positions inside a quad): the kernel around it issues 0.8
+  // vector instructions per product on R-MAT and keeps the vector unit half busy, so instructions count.
+  const long long last_full = ((nnzB >> 2) - 1) << 2;              // first entry of the last quad that lies inside the array
+  int tail[3];
+  KK_UNROLL
+  for (int e = 0; e < 3; ++e) { const long long i = last_full + 4 + e; tail[e] = entB[i < nnzB ? i : nnzB - 1]; }
   for (int64_t chunk = a_beg; chunk < a_end; chunk += NT) {
     const int n = (int)(a_end - chunk < NT ? a_end - chunk : NT);
     long long nq = 0, b0 = 0, b1 = 0;
@@ -491,50 +501,75 @@ __device__ __forceinline__ void flat_columns_quads(int64_t row, const OffT* __re
       b0 = (long long)rmB[c]; b1 = (long long)rmB[c + 1];
       if (b1 > b0) nq = ((b1 + 3) >> 2) - (b0 >> 2);
     }
-    long long tot;
-    const long long excl = block_exclusive_scan_n<long long, NT>(nq, &tot, sc.wave);
-    if (t < n) { sc.pre[t] = excl; sc.b0[t] = b0; sc.b1[t] = b1; }
+    long long tot64;
+    const long long excl = block_exclusive_scan_n<long long, NT>(nq, &tot64, sc.wave);
+    if (tot64 > (long long)INT_MAX - 2 * NT * Q) {       // (an A row that names rows of B with 8e9 entries between them: not a real case)
+      for (int a = 0; a < n; ++a) {
+        const int32_t c = entA[chunk + a];
+        for (long long j = (long long)rmB[c] + t; j < (long long)rmB[c + 1]; j += NT) f(entB[j]);
+      }
+      __syncthreads();
+      continue;
+    }
+    const int tot = (int)tot64;
+    if (t < n) { sc.pre[t] = (int)excl; sc.b0[t] = b0; sc.b1[t] = b1; }
     if (t == 0) sc.pre[n] = tot;
     __syncthreads();
-    auto find = [&](long long q) {      // largest s in [0, n) with pre[s] <= q
+    auto find = [&](int q) {            // largest s in [0, n) with pre[s] <= q
       int lo = 0, len2 = n;
       while (len2 > 1) { const int half = len2 >> 1; lo += (sc.pre[lo + half] <= q) ? half : 0; len2 -= half; }
       return lo;
     };
-    for (long long base = 0; base < tot; base += (long long)NT * Q) {
-      const long long q0 = base + (long long)t * Q;
+    // (Measured and not kept: two steps in flight -- the quads of step s + 1 located and requested before those of step s are consumed --
+    // changed nothing, R-MAT scale 20 symbolic 71.1 -> 71.2 ms; eight quads per step instead of four: 72.3 ms.)
+    auto locate = [&](int base, long long (&at)[Q], int (&lo)[Q], int (&hi)[Q]) {
+      KK_UNROLL
+      for (int u = 0; u < Q; ++u) { at[u] = 0; lo[u] = 0; hi[u] = 0; }                  // no quad: nothing between lo and hi
+      if (base >= tot) return;                                                         // uniform
+      const int q0 = base + t * Q;
       int seg = q0 < tot ? find(q0) : 0;
-      long long at[Q], lo[Q], hi[Q];
+      // the B row of the current quad stays in registers: neighbouring quads are mostly of one row (LDS is read when the row changes)
+      int pre_next = sc.pre[seg + 1];
+      long long sb0 = sc.b0[seg], sb1 = sc.b1[seg];
+      long long qbase = ((sb0 >> 2) - sc.pre[seg]) << 2;  // quad q of this row starts at entry qbase + 4 q
       KK_UNROLL
       for (int u = 0; u < Q; ++u) {
-        const long long q = q0 + u;
-        at[u] = -1; lo[u] = 0; hi[u] = 0;
+        const int q = q0 + u;
         if (q < tot) {
-          while (q >= sc.pre[seg + 1]) ++seg;            // also steps over empty B rows; q < tot = pre[n] ends it
-          const long long sb0 = sc.b0[seg], sb1 = sc.b1[seg];
-          at[u] = (((sb0 >> 2) + (q - sc.pre[seg])) << 2);
-          lo[u] = sb0 > at[u] ? sb0 : at[u];
-          hi[u] = sb1 < at[u] + 4 ? sb1 : at[u] + 4;
+          if (q >= pre_next) {
+            do { ++seg; pre_next = sc.pre[seg + 1]; } while (q >= pre_next);     // also steps over empty B rows; q < tot = pre[n] ends it
+            sb0 = sc.b0[seg]; sb1 = sc.b1[seg]; qbase = ((sb0 >> 2) - sc.pre[seg]) << 2;
+          }
+          at[u] = qbase + ((long long)q << 2);
+          lo[u] = sb0 > at[u] ? (int)(sb0 - at[u]) : 0;
+          hi[u] = sb1 < at[u] + 4 ? (int)(sb1 - at[u]) : 4;
         }
       }
-      int col[Q][4];
+    };
+    auto request = [&](const long long (&at)[Q], int4 (&v)[Q]) {
+      KK_UNROLL
+      for (int u = 0; u < Q; ++u) v[u] = *reinterpret_cast<const int4*>(entB + (at[u] <= last_full ? at[u] : last_full));
+    };
+    auto consume = [&](const long long (&at)[Q], const int (&lo)[Q], const int (&hi)[Q], int4 (&v)[Q]) {
+#ifndef KK_EMU
+      // the quads stay whole: left alone, the compiler splits one of them and sinks the 4-byte load of its first entry into the branch
+      // that consumes it -- one more round trip per step
+      KK_UNROLL
+      for (int u = 0; u < Q; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#endif
       KK_UNROLL
       for (int u = 0; u < Q; ++u) {
-        if (at[u] < 0) continue;
-        if (hi[u] == at[u] + 4) {                        // the whole quad lies before the end of the row: one 16-byte load
-          const int4 v = *reinterpret_cast<const int4*>(entB + at[u]);
-          col[u][0] = v.x; col[u][1] = v.y; col[u][2] = v.z; col[u][3] = v.w;
-        } else {
-          KK_UNROLL
-          for (int e = 0; e < 4; ++e) col[u][e] = (at[u] + e >= lo[u] && at[u] + e < hi[u]) ? entB[at[u] + e] : -1;
-        }
-      }
-      KK_UNROLL
-      for (int u = 0; u < Q; ++u) {
-        if (at[u] < 0) continue;
+        const bool past = at[u] > last_full;              // the array's last, partial quad
+        const int col[4] = {past ? tail[0] : v[u].x, past ? tail[1] : v[u].y, past ? tail[2] : v[u].z, v[u].w};
         KK_UNROLL
-        for (int e = 0; e < 4; ++e) if (at[u] + e >= lo[u] && at[u] + e < hi[u]) f(col[u][e]);
+        for (int e = 0; e < 4; ++e) if (e >= lo[u] && e < hi[u]) f(col[e]);
       }
+    };
+    for (int base = 0; base < tot; base += NT * Q) {
+      long long at[Q];
+      int lo[Q], hi[Q];
+      int4 v[Q];
+      locate(base, at, lo, hi); request(at, v); consume(at, lo, hi, v);
     }
     __syncthreads();
   }
@@ -572,23 +607,27 @@ __device__ __forceinline__ void wave_flat_products(bool active, int64_t row, con
     };
     for (int base = 0; base < tot; base += 64 * kProdUnroll) {
       int col[kProdUnroll], seg[kProdUnroll];
+      long long jj[kProdUnroll];
       typename std::conditional<kVals, VT, int>::type bv[kProdUnroll];
       KK_UNROLL
       for (int u = 0; u < kProdUnroll; ++u) {
         const int q = base + u * 64 + lane;
-        col[u] = -1; seg[u] = 0; bv[u] = 0;
+        seg[u] = u == 0 ? 0 : seg[u - 1]; jj[u] = 0;
         if (q < tot) {
-          seg[u] = find(q, u == 0 ? 0 : seg[u - 1]);
-          const long long j = sc.b0[seg[u]] + (q - sc.pre[seg[u]]);
-          col[u] = entB[j];
-          if constexpr (kVals) bv[u] = valB[j];
+          seg[u] = find(q, seg[u]);
+          jj[u] = sc.b0[seg[u]] + (q - sc.pre[seg[u]]);
         }
       }
       KK_UNROLL
+      for (int u = 0; u < kProdUnroll; ++u) {          // unconditional loads (see flat_products_impl): entry 0 of B exists when tot > 0
+        col[u] = entB[jj[u]];
+        if constexpr (kVals) bv[u] = valB[jj[u]];
+      }
+      KK_UNROLL
       for (int u = 0; u < kProdUnroll; ++u)
-        if (col[u] >= 0) {
+        if (base + u * 64 + lane < tot) {
           if constexpr (kVals) f(chunk + seg[u], col[u], bv[u]);
-          else f(chunk + seg[u], (int64_t)(sc.b0[seg[u]] + (base + u * 64 + lane - sc.pre[seg[u]])), col[u]);
+          else f(chunk + seg[u], (int64_t)jj[u], col[u]);
         }
     }
   }
@@ -843,14 +882,15 @@ struct BitmapStore {                 // where the symbolic count kernel may leav
   unsigned long long* pool_cursor = nullptr;
   long long pool_cap = 0;
 };
-template <class OffT, bool EMIT>
+template <class OffT, bool EMIT, int Q = 4>
 __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const int32_t* __restrict__ perm,
                                                                         const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                         const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
                                                                         OffT* __restrict__ counts, const OffT* __restrict__ rmC,
                                                                         int32_t* __restrict__ entC, int64_t k, int win_bits,
                                                                         int sg_log2, int force_chunked, const OffT* __restrict__ endB,
-                                                                        const unsigned* __restrict__ maskB, int quads, BitmapStore bs KK_DBG_PARAM) {
+                                                                        const unsigned* __restrict__ maskB, int64_t quads, BitmapStore bs KK_DBG_PARAM) {
+  // quads: 0, or nnz(B) -- entries(B) is then read as aligned 16-byte quads (flat_columns_quads)
   // endB / maskB (symbolic count only): B is compressed -- entB holds set indices, a product ORs its 32-column mask into the bitmap
   KK_DYN_SMEM(kk_u64, bm);
   __shared__ int s_min, s_max;
@@ -880,15 +920,18 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
         }
       }, endB);
     } else if (!KK_DBG(2)) {
+      // 32-bit arithmetic and 32-bit LDS atomics on the halves of the 64-bit words (bit c of the window = bit c & 31 of half c >> 5)
+      unsigned* bm32 = reinterpret_cast<unsigned*>(bm);
+      const unsigned c0u = (unsigned)c0;                 // c0 < k <= 2^31 - 1
       auto mark = [&](int cb) {
-        const int64_t c64 = (int64_t)cb - c0;
-        if (c64 >= 0 && c64 < nbits) {
-          const int c = (int)c64;
-          if (!KK_DBG(256)) atomicOr(&bm[c >> 6], 1ull << (c & 63));
+        const unsigned cu = (unsigned)cb - c0u;          // a column before the window wraps to something above nbits
+        if (cu < (unsigned)nbits) {
+          const int c = (int)cu;
+          if (!KK_DBG(256)) atomicOr(&bm32[cu >> 5], 1u << (cu & 31u));
           cmin = c < cmin ? c : cmin; cmax = c > cmax ? c : cmax;
         }
       };
-      if (quads) flat_columns_quads<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flatq, mark);
+      if (quads) flat_columns_quads<kDenseBlock, Q, OffT>(row, rmA, entA, rmB, entB, quads, s_flatq, mark);
       else flat_products<kDenseBlock, OffT>(row, rmA, entA, rmB, entB, s_flat, [&](int64_t, int64_t, int cb) { mark(cb); });
     }
     if (cmax >= 0) { atomicMin(&s_min, cmin); atomicMax(&s_max, cmax); }
@@ -1400,7 +1443,10 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals_kernel(const int32_t* __
 // (78 KB of LDS: two workgroups per CU), 1024 with 1024 work-items and groups of four windows (88 KB: one per CU) for A rows of
 // 513..1024 entries, which the cached-cursor hub kernel below serves at half the rate per product (every window re-fetches the
 // cache lines of ~5 useful entries per list: 7x read amplification).
-template <class OffT, class VT, int H, int NT, int G, int LA>
+// ST = steps of a window's walk a work-item has in flight: the addresses of ST * U products are worked out and all their loads issued
+// before the first product is added (a window of 2048 entries holds 3 to 8 thousand products on R-MAT = two to four steps of NT * U,
+// each a dependent chain of LDS searches, two HBM loads, probe and add).
+template <class OffT, class VT, int H, int NT, int G, int LA, int ST = 1>
 __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* __restrict__ perm,
                                                                        const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                        const VT* __restrict__ valA, const OffT* __restrict__ rmB,
@@ -1485,30 +1531,51 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
           while (len2 > 1) { const int half = len2 >> 1; lo += (s_pre[lo + half] <= q) ? half : 0; len2 -= half; }
           return lo;
         };
-        if (!KK_DBG(4096)) for (int pbase = 0; pbase < tot; pbase += NT * U) {
-          const int q0 = pbase + t * U;
-          int a = q0 < tot ? find(q0) : 0;
-          int col[U];
-          VT bv[U], av[U];
-          long long jj[U];
+        if (!KK_DBG(4096)) for (int pbase = 0; pbase < tot; pbase += NT * U * ST) {
+          int col[ST][U];
+          VT bv[ST][U], av[ST][U];
+          long long jj[ST][U];
           KK_UNROLL
-          for (int u = 0; u < U; ++u) {
-            const int q = q0 + u;
-            jj[u] = -1;
-            if (q < tot) {
-              while (q >= s_pre[a + 1]) ++a;            // also steps over lists with nothing in the window; q < tot = pre[la_c] ends it
-              jj[u] = s_cur[a] + (g > 0 ? s_pos[g - 1][a] : 0) + (q - s_pre[a]);
-              av[u] = s_av[a];
+          for (int s = 0; s < ST; ++s) {
+            KK_UNROLL
+            for (int u = 0; u < U; ++u) jj[s][u] = -1;
+            if (s > 0 && pbase + s * NT * U >= tot) continue;                  // uniform: the window ends before this step
+            const int q0 = pbase + (s * NT + t) * U;
+            int a = q0 < tot ? find(q0) : 0;
+            // the list of the current product stays in registers: neighbouring products are mostly of one list
+            int pre_next = s_pre[a + 1];
+            long long jb = s_cur[a] + (g > 0 ? s_pos[g - 1][a] : 0) - s_pre[a];      // product q of this list is entry jb + q of B
+            VT ava = s_av[a];
+            KK_UNROLL
+            for (int u = 0; u < U; ++u) {
+              const int q = q0 + u;
+              if (q < tot) {
+                if (q >= pre_next) {
+                  do { ++a; pre_next = s_pre[a + 1]; } while (q >= pre_next);   // also steps over lists with nothing in the window; q < tot = pre[la_c] ends it
+                  jb = s_cur[a] + (g > 0 ? s_pos[g - 1][a] : 0) - s_pre[a]; ava = s_av[a];
+                }
+                jj[s][u] = jb + q;
+                av[s][u] = ava;
+              }
             }
           }
+          // every load is UNCONDITIONAL (a product that does not exist reads entry 0 of B: tot > 0, so B has one): a load the compiler
+          // has to branch around makes it wait for all loads in flight before the next one is issued -- the walk then pays one memory
+          // round trip per load instead of one per step
           KK_UNROLL
-          for (int u = 0; u < U; ++u) { col[u] = jj[u] >= 0 ? entB[jj[u]] : -1; bv[u] = jj[u] >= 0 ? valB[jj[u]] : VT(0); }
+          for (int s = 0; s < ST; ++s) {
+            KK_UNROLL
+            for (int u = 0; u < U; ++u) { const long long j = jj[s][u] >= 0 ? jj[s][u] : 0; col[s][u] = entB[j]; bv[s][u] = valB[j]; }
+          }
           KK_UNROLL
-          for (int u = 0; u < U; ++u)
-            if (col[u] >= 0 && !KK_DBG(8192)) {
-              const int hh = vt_find<H>(hk, col[u]);
-              if (hh >= 0) KK_ATOMIC_FADD(&hv[hh], av[u] * bv[u]);
-            }
+          for (int s = 0; s < ST; ++s) {
+            KK_UNROLL
+            for (int u = 0; u < U; ++u)
+              if (jj[s][u] >= 0 && !KK_DBG(8192)) {
+                const int hh = vt_find<H>(hk, col[s][u]);
+                if (hh >= 0) KK_ATOMIC_FADD(&hv[hh], av[s][u] * bv[s][u]);
+              }
+          }
         }
         __syncthreads();
         // sums leave in C order (coalesced); every work-item cleans the slots it filled, so the table is clean again
@@ -1731,7 +1798,7 @@ struct kkamd_spgemm_handle {
   int32_t* d_perm  = nullptr;      // [m] rows grouped by numeric bin
   kk::BinOffsets num_off{};
   int sg_log2 = 0;
-  int64_t nnzA = 0;
+  int64_t nnzA = 0, nnzB = 0;
   bool b_sorted = false;           // rows of B column-sorted: dense rows may use the windowed LDS value kernel
   bool dense_lds = false;          // decided when the numeric bins are made
   int32_t* d_hub_items = nullptr; int64_t n_hub_items = 0;      // (index, pass) pairs of the hub rows: one workgroup each
@@ -1797,18 +1864,27 @@ static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLi
 // one workgroup per dense row; dynamic LDS = the bitmap window
 template <class OffT, bool EMIT>
 static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA, const int32_t* entA, const OffT* rmB,
-                             const int32_t* entB, OffT* counts, const OffT* rmC, int32_t* entC, int64_t k, int sg, hipStream_t st,
+                             const int32_t* entB, OffT* counts, const OffT* rmC, int32_t* entC, int64_t k, int64_t nnzB, int sg, hipStream_t st,
                              const OffT* endB = nullptr, const unsigned* maskB = nullptr, BitmapStore bs = BitmapStore(), int64_t win_cap = 0) {
   int64_t win = g_spgemm.win_bits;
   if (win_cap > 0 && win > win_cap) win = win_cap;        // lighter rows: smaller windows, more workgroups per CU, several passes
   if (win > k) win = ceil_div(k, 64) * 64;
   const size_t smem = (size_t)(win / 8);
+  const int64_t quads = (g_spgemm.col_quads && ((uintptr_t)entB % 16 == 0) && nnzB >= 4 && !maskB) ? nnzB : (int64_t)0;
 #ifndef KK_EMU
-  KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_dense_cols_kernel<OffT, EMIT>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#define KK_DC_ATTR(QQ) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_dense_cols_kernel<OffT, EMIT, QQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
+#else
+#define KK_DC_ATTR(QQ) (void)0
 #endif
-  KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,
-            rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked, endB, maskB, (g_spgemm.col_quads && ((uintptr_t)entB % 16 == 0)) ? 1 : 0, bs KK_DBG_ARG);
+#define KK_DC(QQ)                                                                                                                    \
+  do {                                                                                                                               \
+    KK_DC_ATTR(QQ);                                                                                                                  \
+    KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT, QQ>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,  \
+              rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked, endB, maskB, quads, bs KK_DBG_ARG);                                  \
+  } while (0)
+  if (g_spgemm.col_quads == 8) KK_DC(8); else KK_DC(4);
+#undef KK_DC
+#undef KK_DC_ATTR
   return KKAMD_OK;
 }
 
@@ -1885,7 +1961,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
   h->mults = (int64_t)h_stats[0]; h->max_row_flops = (int64_t)h_stats[1];
-  h->sg_log2 = pick_sg_log2(nnzB, n);
+  h->sg_log2 = pick_sg_log2(nnzB, n); h->nnzB = nnzB;
   int rc;
   // sortedness of B decides how the numeric phase handles dense rows, and whether B can be compressed
   {
@@ -1953,7 +2029,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     }
     if (nb(4)) {
       if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, setB, rmC, (const OffT*)nullptr,
-                                               (int32_t*)nullptr, k, sg, st, endB, maskB))) return rc;
+                                               (int32_t*)nullptr, k, (int64_t)0, sg, st, endB, maskB))) return rc;
     }
   } else {
     if ((rc = make_bins(m, h->d_sizes, k, g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
@@ -2011,7 +2087,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
         } else (void)hipGetLastError();
       }
       if ((rc = launch_dense_cols<OffT, false>(nb(4), h->d_perm + off.off[4], rmA, entA, rmB, entB, rmC, (const OffT*)nullptr,
-                                               (int32_t*)nullptr, k, sg, st, nullptr, nullptr, bs))) return rc;
+                                               (int32_t*)nullptr, k, nnzB, sg, st, nullptr, nullptr, bs))) return rc;
       if (bs.words) {
         unsigned long long h_c[2] = {0, 0};
         KK_HIP(hipMemcpyAsync(h_c, h->d_bm_counter, sizeof h_c, hipMemcpyDeviceToHost, st));
@@ -2188,11 +2264,23 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
           KK_LAUNCH((spgemm_copy_pool_kernel<OffT>), (unsigned)np, kBlock, 0, st, rest, d_po, d_pl, rmC, entC);
         }
       }
-      if (nr - np && (rc = launch_dense_cols<OffT, true>(nr - np, rest + np, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st, nullptr, nullptr,
+      if (nr - np && (rc = launch_dense_cols<OffT, true>(nr - np, rest + np, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, h->nnzB, sg, st, nullptr, nullptr,
                                                          BitmapStore(), (int64_t)g_spgemm.emit_win_bits))) return rc;
       h->bitmaps_used = ns; h->pooled_used = np;
     }
-    else if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, sg, st))) return rc;
+    else if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, h->nnzB, sg, st))) return rc;
+#define KK_VALS2(HH, NTT, GG, LAA, GRID, PERM, CAP)                                                                                     \
+  do {                                                                                                                                  \
+    if (g_spgemm.val_steps == 3)                                                                                                        \
+      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 3>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
+                rmC, (const int32_t*)entC, valC, CAP KK_DBG_ARG);                                                                        \
+    else if (g_spgemm.val_steps == 2)                                                                                                   \
+      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 2>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
+                rmC, (const int32_t*)entC, valC, CAP KK_DBG_ARG);                                                                        \
+    else                                                                                                                                \
+      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 1>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
+                rmC, (const int32_t*)entC, valC, CAP KK_DBG_ARG);                                                                        \
+  } while (0)
     const int64_t n_lds = h->n_dense_lds; int64_t n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_lds - n_hubl;
     const bool flat_vals = g_spgemm.val_kernel == 2 && h->dense_lds;
     if (flat_vals && g_spgemm.val_hub_flat) {
@@ -2201,8 +2289,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       // handful of products per list and window; the cached-next-column sweep of spgemm_hub_vals_kernel skips the empty lists for free)
       int cap = g_spgemm.val_cap;
       cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
-      if (n_hubl + n_hub) KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8, kValLa>), (unsigned)(n_hubl + n_hub), kValBlock, 0, st, dperm + n_lds,
-                                    rmA, entA, valA, rmB, entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
+      if (n_hubl + n_hub) KK_VALS2(kValTable, kValBlock, 8, kValLa, n_hubl + n_hub, dperm + n_lds, cap);
       n_hubl = 0; n_hub = 0;
     }
     if (n_hub && flat_vals && h->hub_from_mid) {      // A rows above kValLa2 entries (the heaviest rows first): the cached-cursor hub kernel, kHubLa entries per pass
@@ -2258,8 +2345,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     if (n_hubl && flat_vals && h->hub_from_mid) {    // A rows of kValLa + 1 .. kValLa2 entries: the flat kernel with 1024 lists per pass
       int cap = g_spgemm.val_cap;
       cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
-      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kDenseBlock, 4, kValLa2>), (unsigned)n_hubl, kDenseBlock, 0, st, dperm + n_lds,
-                rmA, entA, valA, rmB, entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
+      KK_VALS2(kValTable, kDenseBlock, 4, kValLa2, n_hubl, dperm + n_lds, cap);
       n_hubl = 0;
     }
     if (n_hubl) {      // heaviest rows first
@@ -2283,17 +2369,14 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         const int64_t n_small = h->n_dense_small < n_lds - n_tiny ? h->n_dense_small : n_lds - n_tiny;
         if (n_tiny) {                                            // the lightest shape (see spgemm_split_small_kernel)
           const int cap_t = cap > kValTableTiny / 2 ? kValTableTiny / 2 : cap;
-          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTableTiny, 128, 8, kValLaTiny>), (unsigned)n_tiny, 128, 0, st, dperm, rmA, entA, valA, rmB,
-                    entB, valB, rmC, (const int32_t*)entC, valC, cap_t KK_DBG_ARG);
+          KK_VALS2(kValTableTiny, 128, 8, kValLaTiny, n_tiny, dperm, cap_t);
         }
         if (n_small) {                                           // the light shape for the rows with few entries
           const int cap_s = cap > kValTableSmall / 2 ? kValTableSmall / 2 : cap;
-          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTableSmall, kBlock, 8, kValLaSmall>), (unsigned)n_small, kBlock, 0, st, dperm + n_tiny, rmA, entA, valA, rmB,
-                    entB, valB, rmC, (const int32_t*)entC, valC, cap_s KK_DBG_ARG);
+          KK_VALS2(kValTableSmall, kBlock, 8, kValLaSmall, n_small, dperm + n_tiny, cap_s);
         }
         if (n_lds - n_tiny - n_small)
-          KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, kValTable, kValBlock, 8, kValLa>), (unsigned)(n_lds - n_tiny - n_small), kValBlock, 0, st, dperm + n_tiny + n_small, rmA, entA, valA, rmB,
-                    entB, valB, rmC, (const int32_t*)entC, valC, cap KK_DBG_ARG);
+          KK_VALS2(kValTable, kValBlock, 8, kValLa, n_lds - n_tiny - n_small, dperm + n_tiny + n_small, cap);
       } else switch (g_spgemm.val_shape) {
         case 1: KK_VALS(8192, 1024); break;
         case 2: KK_VALS(8192, 512); break;
@@ -2302,6 +2385,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         default: KK_VALS(kValTable, kValBlock); break;
       }
 #undef KK_VALS
+#undef KK_VALS2
     }
     if (n_hub) {
       // batches of G rows, each with its own k-wide accumulator (bounded to 1/8 of free HBM), ~256K work-items in flight
@@ -2357,12 +2441,13 @@ int spgemm_set_default(const char* key, int value) {
 #endif
   else if (k == "spgemm_val_shape") g_spgemm.val_shape = value;
   else if (k == "spgemm_val_hub_flat") g_spgemm.val_hub_flat = value != 0;
-  else if (k == "spgemm_col_quads") g_spgemm.col_quads = value != 0;
+  else if (k == "spgemm_col_quads") { if (value != 0 && value != 1 && value != 4 && value != 8) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_col_quads: %d is not 0, 4 or 8", value); g_spgemm.col_quads = value == 1 ? 4 : value; }
   else if (k == "spgemm_hub_chunked") g_spgemm.hub_chunked = value != 0;
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
   else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
   else if (k == "spgemm_val_tiny_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_tiny_cnt: %d is negative", value); g_spgemm.val_tiny_cnt = value; }
+  else if (k == "spgemm_val_steps") { if (value < 1 || value > 3) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_steps: %d is not 1, 2 or 3", value); g_spgemm.val_steps = value; }
   else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
   else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;

@@ -377,6 +377,37 @@ def check_spgemm_kept_structure(be):
             kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_keep_lists", 1))
 
 
+def check_spgemm_val_steps(be):
+    """Flat value kernel with 2 and 3 steps of a window's product walk in flight (`spgemm_val_steps`): rows of C whose windows hold several
+    steps of products (lists that overlap heavily), in the lightest shape (128 work-items: a step is 512 products), the 512-work-item shape
+    (more than 256 lists) and next to rows whose windows end inside the first step.  The last row of B is one of the long lists and
+    nnz(B) is not a multiple of 4: the bitmap kernels' 16-byte walk takes the array's last, partial quad from its tail registers."""
+    rng = np.random.default_rng(17)
+    n, k = 400, 12000
+    rows = [list(range(23)) + [n - 1],                    # 24 lists of ~6000 over 12000 columns: ~12 products per entry of C
+            [0, 30, 31],                                  # one long list and two short ones
+            list(range(20, 320)),                         # 300 lists: the 512-work-item shape
+            [n - 1], [5], []]
+    arm = np.zeros(len(rows) + 1, dtype=np.int64); np.cumsum([len(r) for r in rows], out=arm[1:])
+    A = oracle.Crs(len(rows), n, arm, np.concatenate([np.array(r, dtype=np.int32) for r in rows]), 1 + 49 * rng.random(arm[-1]))
+
+    def make_b(last_len):
+        lens = np.concatenate([np.full(23, 6000), np.full(n - 24, 150), [last_len]])
+        rm = np.zeros(n + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+        ent = np.concatenate([np.sort(rng.choice(k, size=l, replace=False)) for l in lens]).astype(np.int32)
+        return oracle.Crs(n, k, rm, ent, 1 + 49 * rng.random(rm[-1]))
+    try:
+        for steps, last_len in ((2, 6001), (3, 6002), (1, 6003)):
+            B = make_b(last_len)
+            assert B.nnz % 4 == last_len % 4 != 0
+            kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_val_steps", steps))
+            got = check_spgemm(be, A, B)
+            assert np.diff(got.row_map)[0] > 5461
+        check_spgemm(be, A, B, offset_dtype=np.int64, value_dtype=np.float32)
+    finally:
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_val_steps", 1))
+
+
 def randomized(A0, seed=5):
     """values re-drawn in [1,50) as the reference's SpGEMM tests do (Test_Sparse_spgemm.hpp:62-72)"""
     rng = np.random.default_rng(seed)
