@@ -189,7 +189,11 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *   kkamd_spmv_struct (global only): "struct_remap", "struct_group", "struct_strip" workgroup orders, all off
  *   "verbose" (global): 1 = the library reports what it chose on stdout
  *   SpGEMM (kkamd_set_default only) "spgemm_win_bits" (columns per LDS bitmap pass), "spgemm_val_cap", "spgemm_val_shape",
- *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_emit_chunked" (test hooks for alternative code paths).
+ *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_emit_chunked" (test hooks for alternative code paths);
+ *          "spgemm_emit_sort" (1: entries(C) of rows with more than 256 entries out of at most 2048 products are sorted in LDS, eight rows
+ *          per CU; 0: they take the bitmap kernel like every other dense row), "spgemm_col_quads" (0 / 4 / 8: 16-byte loads of entries(B) per
+ *          work-item and step in the bitmap kernels), "spgemm_val_steps" (1..3 steps of a window's product walk in flight in the flat
+ *          value kernel; measured neutral).
  * Knobs that switch parts of kernels OFF ("ablate", "lds_pad_kb", "struct_lds_pad_kb", "spgemm_debug") exist only in the
  * measurement build libkkamd_ablate.so (csrc: make ablate, -DKK_ABLATE); libkkamd.so answers KKAMD_ERR_INVALID_ARG. */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);
@@ -317,7 +321,8 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* handle, const char* key, double valu
  * caller set (4 = SPGEMM_DEFAULT until then), 10 number of distinct hints recorded, 11 the last numeric call kept the entries(C)
  * of the dense rows from the previous call (numeric reuse), 12 rows whose entries(C) the last numeric call wrote from a bitmap kept by the
  * symbolic phase, 13 bitmaps the symbolic phase holds at this moment (they are freed by the numeric call that uses them), 14 rows whose entries(C) the
- * last numeric call copied from the entry lists the symbolic phase left (dense rows whose bitmap is not kept). */
+ * last numeric call copied from the entry lists the symbolic phase left (dense rows whose bitmap is not kept), 15 rows whose entries(C)
+ * the last numeric call sorted in LDS (rows of more than 256 entries out of at most 2048 products). */
 int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);
 /* the recorded value of a hint key (the reference's get_* of the same setter); KKAMD_ERR_INVALID_ARG when the key was never set */
 int kkamd_spgemm_get_hint(kkamd_spgemm_handle_t* handle, const char* key, double* value);

@@ -109,6 +109,7 @@ struct SpgemmTuning {
                                   // R-MAT scale 20 numeric / reuse: 0: 221.7 / 184.7 ms, 8192: 217.6 / 180.7, 32768: 213.8 / 176.6, 65536: 211.1 / 174.6, 131072: 216.4 / 179.5, all: 219.0 / 182.3)
   int val_tiny_cnt   = 32768;     // ... and at most this many (and kValLaTiny entries in the A row) the lightest one: 128 work-items, 1024-slot table (0 = none;
                                   // R-MAT scale 20 numeric / reuse with the light shape at 65536: 0: 212.0 / 175.2 ms, 2048: 210.0 / 172.8, 8192: 208.4 / 171.6, 32768: 207.5 / 170.9)
+  int emit_sort      = 1;         // entries(C) of the dense-bin rows with at most kEmitSortCap products: sorted in LDS, 256 work-items per row (0 = the bitmap kernel)
   int val_steps      = 1;         // steps of a window's product walk a work-item of the flat value kernel keeps in flight (1..3)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
@@ -1053,6 +1054,97 @@ __global__ __launch_bounds__(kBlock) void spgemm_copy_pool_kernel(const int32_t*
   const int32_t* src = pool + pool_off[row];
   for (int64_t i = threadIdx.x; i < n; i += kBlock) entC[b + i] = src[i];
 }
+// entries(C) of a row with FEW PRODUCTS (at most kEmitSortCap, known from the symbolic phase's row flops) but more entries than the
+// wave kernel's table holds: the products' columns are laid down in LDS, sorted by a bitonic network and written without their
+// duplicates -- 256 work-items and 11 KB of LDS per row, so that eight rows share a CU.  The bitmap kernel gives every such row a
+// workgroup of 1024 around a 128 KB bitmap, one row per CU at a time: 15 us per row whatever it holds (1e6 rows of 400 entries, the
+// product of two uniform random matrices with 20 entries per row: 60 ms of a 65 ms numeric call whose values take 4 ms).
+constexpr int kEmitSortCap = 2048;
+__global__ __launch_bounds__(kBlock) void spgemm_flop_class_kernel(int64_t m, const int64_t* __restrict__ flops, int32_t* __restrict__ cls) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < m) cls[i] = flops[i] <= (int64_t)kEmitSortCap ? 0 : -1;
+}
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_emit_sort_kernel(const int32_t* __restrict__ perm, const OffT* __restrict__ rmA,
+                                                                  const int32_t* __restrict__ entA, const OffT* __restrict__ rmB,
+                                                                  const int32_t* __restrict__ entB, const OffT* __restrict__ rmC,
+                                                                  int32_t* __restrict__ entC) {
+  constexpr int CAP = kEmitSortCap, PER = CAP / kBlock, U = 4;
+  __shared__ int s_key[CAP];
+  __shared__ int s_pre[kBlock + 1];
+  __shared__ long long s_b0[kBlock];
+  __shared__ int s_wave[kBlock / 64];
+  const int t = threadIdx.x;
+  const int64_t row = perm[blockIdx.x];
+  const int64_t a_beg = (int64_t)rmA[row], a_end = (int64_t)rmA[row + 1];
+  int filled = 0;                                                // products laid down so far (workgroup-uniform)
+  for (int64_t chunk = a_beg; chunk < a_end; chunk += kBlock) {
+    const int n = (int)(a_end - chunk < kBlock ? a_end - chunk : kBlock);
+    int len = 0; long long b0 = 0;
+    if (t < n) { const int32_t c = entA[chunk + t]; b0 = (long long)rmB[c]; len = (int)((long long)rmB[c + 1] - b0); }
+    int tot;
+    const int excl = block_exclusive_scan_n<int, kBlock>(len, &tot, s_wave);
+    if (t < n) { s_pre[t] = excl; s_b0[t] = b0; }
+    if (t == 0) s_pre[n] = tot;
+    __syncthreads();
+    for (int base = 0; base < tot; base += kBlock * U) {
+      const int q0 = base + t * U;
+      int seg = 0;
+      if (q0 < tot) { int len2 = n; while (len2 > 1) { const int half = len2 >> 1; seg += (s_pre[seg + half] <= q0) ? half : 0; len2 -= half; } }
+      int pre_next = s_pre[seg + 1];
+      long long jb = s_b0[seg] - s_pre[seg];                      // product q of this list is entry jb + q of B
+      long long jj[U];
+      KK_UNROLL
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u;
+        jj[u] = 0;
+        if (q < tot) {
+          if (q >= pre_next) { do { ++seg; pre_next = s_pre[seg + 1]; } while (q >= pre_next); jb = s_b0[seg] - s_pre[seg]; }
+          jj[u] = jb + q;
+        }
+      }
+      int col[U];
+      KK_UNROLL
+      for (int u = 0; u < U; ++u) col[u] = entB[jj[u]];           // unconditional (entry 0 of B exists when tot > 0)
+      KK_UNROLL
+      for (int u = 0; u < U; ++u) if (q0 + u < tot && filled + q0 + u < CAP) s_key[filled + q0 + u] = col[u];
+    }
+    filled += tot;
+    __syncthreads();
+  }
+  if (filled > CAP) filled = CAP;                                // (cannot happen: the row's flops were at most CAP)
+  int N = 64;
+  while (N < filled) N <<= 1;
+  for (int i = filled + t; i < N; i += kBlock) s_key[i] = INT_MAX;
+  __syncthreads();
+  for (int kk2 = 2; kk2 <= N; kk2 <<= 1) {                       // bitonic network
+    for (int j = kk2 >> 1; j > 0; j >>= 1) {
+      for (int p = t; p < N; p += kBlock) {
+        const int q = p ^ j;
+        if (q > p) {
+          const int x = s_key[p], y = s_key[q];
+          const bool up = (p & kk2) == 0;
+          if ((x > y) == up) { s_key[p] = y; s_key[q] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // the distinct columns, in order: work-item t looks at PER consecutive slots
+  int flag[PER], cnt = 0;
+  KK_UNROLL
+  for (int q = 0; q < PER; ++q) {
+    const int p = t * PER + q;
+    flag[q] = (p < filled && (p == 0 || s_key[p] != s_key[p - 1])) ? 1 : 0;
+    cnt += flag[q];
+  }
+  int total;
+  int pos = block_exclusive_scan_n<int, kBlock>(cnt, &total, s_wave);
+  const int64_t base = (int64_t)rmC[row], room = (int64_t)rmC[row + 1] - base;
+  KK_UNROLL
+  for (int q = 0; q < PER; ++q)
+    if (flag[q]) { if (pos < room) entC[base + pos] = s_key[t * PER + q]; ++pos; }
+}
 template <class SlotT>
 __global__ __launch_bounds__(kBlock) void spgemm_split_stored_kernel(int64_t nd, const int32_t* __restrict__ perm_in, const SlotT* __restrict__ row_slot,
                                                                     int32_t* __restrict__ perm_out, unsigned long long* __restrict__ counters /*[2]*/) {
@@ -1825,6 +1917,10 @@ struct kkamd_spgemm_handle {
   int32_t* d_ent_pool = nullptr; long long* d_pool_off = nullptr; int64_t pool_cap = 0, pool_used = 0;
   int32_t* d_emit_perm2 = nullptr; int64_t n_emit_pooled = 0;   // "the others" as [rows with a pooled list | rows that walk their products]
   int64_t pooled_used = 0;         // rows of the last numeric call whose entries(C) were copied from the pool
+  int32_t* d_flop_cls = nullptr;   // [m] 0: the row has at most kEmitSortCap products, -1: more (left by the symbolic phase)
+  int32_t* d_emit_perm3 = nullptr; int64_t n_emit_sort = 0;     // rows that walk their products as [sorted in LDS | through the bitmap kernel] ...
+  const int32_t* emit3_src = nullptr; int64_t emit3_n = 0;      // ... of this list
+  int64_t sorted_used = 0;         // rows of the last numeric call whose entries(C) were sorted in LDS
   bool entries_valid = false;      // entries(C) as the last numeric call left them are still what entC_ptr holds (numeric reuse)
   bool entries_reused = false;     // the last numeric call kept them
   const void *entC_ptr = nullptr, *rmC_ptr = nullptr;
@@ -1934,6 +2030,8 @@ static void free_bitmap_store(kkamd_spgemm_handle* h) {
   if (h->d_bm_counter) (void)hipFree(h->d_bm_counter);
   if (h->d_emit_perm) (void)hipFree(h->d_emit_perm);
   if (h->d_emit_perm2) (void)hipFree(h->d_emit_perm2);
+  if (h->d_emit_perm3) (void)hipFree(h->d_emit_perm3);
+  h->d_emit_perm3 = nullptr; h->emit3_src = nullptr; h->emit3_n = 0; h->n_emit_sort = 0;
   if (h->d_pool_off) (void)hipFree(h->d_pool_off);
   h->d_bm_store = nullptr; h->d_row_slot = nullptr; h->d_bm_counter = nullptr; h->d_emit_perm = nullptr;
   h->d_emit_perm2 = nullptr; h->d_pool_off = nullptr; h->d_ent_pool = nullptr; h->pool_cap = 0; h->pool_used = 0; h->n_emit_pooled = 0;
@@ -1962,6 +2060,11 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   KK_HIP(hipStreamSynchronize(st));
   h->mults = (int64_t)h_stats[0]; h->max_row_flops = (int64_t)h_stats[1];
   h->sg_log2 = pick_sg_log2(nnzB, n); h->nnzB = nnzB;
+  if (h->d_flop_cls) { (void)hipFree(h->d_flop_cls); h->d_flop_cls = nullptr; }
+  if (g_spgemm.emit_sort && hipMalloc((void**)&h->d_flop_cls, sizeof(int32_t) * (size_t)m) == hipSuccess) {
+    int32_t* d_cls = h->d_flop_cls; const int64_t* d_fl = h->d_sizes;
+    KK_LAUNCH(spgemm_flop_class_kernel, (unsigned)ceil_div(m, kBlock), kBlock, 0, st, m, d_fl, d_cls);
+  } else { (void)hipGetLastError(); h->d_flop_cls = nullptr; }
   int rc;
   // sortedness of B decides how the numeric phase handles dense rows, and whether B can be compressed
   {
@@ -2194,6 +2297,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     h->numeric_bins_ready = true;
     if (h->d_emit_perm) { (void)hipFree(h->d_emit_perm); h->d_emit_perm = nullptr; h->n_emit_stored = 0; }
     if (h->d_emit_perm2) { (void)hipFree(h->d_emit_perm2); h->d_emit_perm2 = nullptr; h->n_emit_pooled = 0; }
+    if (h->d_emit_perm3) { (void)hipFree(h->d_emit_perm3); h->d_emit_perm3 = nullptr; h->emit3_src = nullptr; h->emit3_n = 0; h->n_emit_sort = 0; }
     if (h->d_hub_items) { (void)hipFree(h->d_hub_items); h->d_hub_items = nullptr; h->n_hub_items = 0; }
     if (h->d_hub_multi) { (void)hipFree(h->d_hub_multi); h->d_hub_multi = nullptr; h->n_hub_multi = 0; }
   }
@@ -2220,6 +2324,33 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   // rows emit entries and values in one pass and rewrite the same entries.
   const bool keep_entries = h->entries_valid && h->entC_ptr == (const void*)entC && h->rmC_ptr == rmC_;
   h->entries_reused = false;
+  // entries(C) of dense-bin rows that have to walk their products: the rows with few products are sorted in LDS (spgemm_emit_sort_kernel),
+  // the others go through the bitmap kernel.  The split of `list` is made once per handle and list.
+  auto emit_walk = [&](int64_t n, const int32_t* list, int64_t win_cap) -> int {
+    int64_t nsort = 0;
+    h->sorted_used = 0;
+    if (g_spgemm.emit_sort && h->d_flop_cls && h->algorithm == 0 && n > 0) {
+      if (!h->d_emit_perm3 || h->emit3_src != list || h->emit3_n != n) {
+        if (h->d_emit_perm3) { (void)hipFree(h->d_emit_perm3); h->d_emit_perm3 = nullptr; }
+        DevBuf c4;
+        KK_HIP(c4.alloc(2 * sizeof(unsigned long long)));
+        KK_HIP(hipMemsetAsync(c4.p, 0, 2 * sizeof(unsigned long long), st));
+        KK_HIP(hipMalloc((void**)&h->d_emit_perm3, sizeof(int32_t) * (size_t)n));
+        int32_t* d_ep3 = h->d_emit_perm3; const int32_t* d_cls = h->d_flop_cls; unsigned long long* d_c4 = c4.as<unsigned long long>();
+        KK_LAUNCH((spgemm_split_stored_kernel<int32_t>), (unsigned)ceil_div(n, kBlock), kBlock, 0, st, n, list, d_cls, d_ep3, d_c4);
+        unsigned long long h_c4[2] = {0, 0};
+        KK_HIP(hipMemcpyAsync(h_c4, c4.p, sizeof h_c4, hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+        h->n_emit_sort = (int64_t)h_c4[0]; h->emit3_src = list; h->emit3_n = n;
+      }
+      nsort = h->n_emit_sort; list = h->d_emit_perm3;
+      if (nsort) KK_LAUNCH((spgemm_emit_sort_kernel<OffT>), (unsigned)nsort, kBlock, 0, st, list, rmA, entA, rmB, entB, rmC, entC);
+      h->sorted_used = nsort;
+    }
+    if (n - nsort) return launch_dense_cols<OffT, true>(n - nsort, list + nsort, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, h->nnzB, sg, st, nullptr, nullptr,
+                                                        BitmapStore(), win_cap);
+    return KKAMD_OK;
+  };
   if (nb(4)) {
     const int32_t* dperm = h->d_perm + off.off[4];
     // entries(C) of every dense row, column-sorted
@@ -2264,11 +2395,10 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
           KK_LAUNCH((spgemm_copy_pool_kernel<OffT>), (unsigned)np, kBlock, 0, st, rest, d_po, d_pl, rmC, entC);
         }
       }
-      if (nr - np && (rc = launch_dense_cols<OffT, true>(nr - np, rest + np, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, h->nnzB, sg, st, nullptr, nullptr,
-                                                         BitmapStore(), (int64_t)g_spgemm.emit_win_bits))) return rc;
+      if (nr - np && (rc = emit_walk(nr - np, rest + np, (int64_t)g_spgemm.emit_win_bits))) return rc;
       h->bitmaps_used = ns; h->pooled_used = np;
     }
-    else if ((rc = launch_dense_cols<OffT, true>(nb(4), dperm, rmA, entA, rmB, entB, (OffT*)nullptr, rmC, entC, k, h->nnzB, sg, st))) return rc;
+    else if ((rc = emit_walk(nb(4), dperm, (int64_t)0))) return rc;
 #define KK_VALS2(HH, NTT, GG, LAA, GRID, PERM, CAP)                                                                                     \
   do {                                                                                                                                  \
     if (g_spgemm.val_steps == 3)                                                                                                        \
@@ -2447,6 +2577,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
   else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
   else if (k == "spgemm_val_tiny_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_tiny_cnt: %d is negative", value); g_spgemm.val_tiny_cnt = value; }
+  else if (k == "spgemm_emit_sort") g_spgemm.emit_sort = value != 0;
   else if (k == "spgemm_val_steps") { if (value < 1 || value > 3) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_steps: %d is not 1, 2 or 3", value); g_spgemm.val_steps = value; }
   else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
   else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;
@@ -2474,6 +2605,7 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (!h) return KKAMD_OK;
   if (h->d_sizes) (void)hipFree(h->d_sizes);
   if (h->d_perm) (void)hipFree(h->d_perm);
+  if (h->d_flop_cls) (void)hipFree(h->d_flop_cls);
   kk::free_bitmap_store(h);
   if (h->d_hub_items) (void)hipFree(h->d_hub_items);
   if (h->d_hub_multi) (void)hipFree(h->d_hub_multi);
@@ -2655,6 +2787,7 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 12: *value = h->bitmaps_used; break;
     case 13: *value = h->bm_stored; break;
     case 14: *value = h->pooled_used; break;
+    case 15: *value = h->sorted_used; break;
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
   return KKAMD_OK;

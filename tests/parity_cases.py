@@ -408,6 +408,53 @@ def check_spgemm_val_steps(be):
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_val_steps", 1))
 
 
+def check_spgemm_sorted_emission(be):
+    """Rows of C with more than 256 entries out of at most 2048 products: entries(C) sorted in LDS (`spgemm_emit_sort`, default) instead
+    of walking the products through a 2^20-column bitmap.  A rows of more than 256 entries (two chunks of lists), duplicates among
+    the products, rows above the product limit next to them (bitmap kernel), short rows (wave kernel); same C with the knob off."""
+    rng = np.random.default_rng(23)
+    nb, k = 3000, 50000
+    lens = np.concatenate([np.full(1000, 3), np.full(2000, 20)])
+    rm = np.zeros(nb + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    ent = np.concatenate([np.sort(rng.choice(k, size=l, replace=False)) for l in lens]).astype(np.int32)
+    B = oracle.Crs(nb, k, rm, ent, 1 + 49 * rng.random(rm[-1]))
+    rows = []
+    for i in range(40):
+        rows.append(np.sort(rng.choice(np.arange(1000, 3000), size=int(rng.integers(20, 90)), replace=False)))    # 400 .. 1800 products
+    rows.append(np.sort(rng.choice(1000, size=300, replace=False)))                                            # 300 lists of 3: two chunks
+    rows.append(np.sort(rng.choice(np.arange(1000, 3000), size=102, replace=False)))                           # 2040 products: just inside
+    rows.append(np.sort(rng.choice(np.arange(1000, 3000), size=104, replace=False)))                           # 2080: the bitmap kernel
+    rows.append(np.sort(rng.choice(np.arange(1000, 3000), size=400, replace=False)))                           # 8000 products
+    rows.append(np.array([5, 1500]))                                                                            # 23 products: wave kernel
+    rows.append(np.array([], dtype=np.int64))
+    rows.append(np.concatenate([np.full(1, 1200), np.sort(rng.choice(np.arange(1000, 3000), size=30, replace=False))]))   # (unsorted A row, maybe a duplicate column)
+    arm = np.zeros(len(rows) + 1, dtype=np.int64); np.cumsum([len(r) for r in rows], out=arm[1:])
+    A = oracle.Crs(len(rows), nb, arm, np.concatenate(rows).astype(np.int32), 1 + 49 * rng.random(arm[-1]))
+    gold = oracle.spgemm(A, B)
+    sizes = np.diff(gold.row_map)
+    assert (sizes[:42] > 256).all()
+    for on in (1, 0):
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_emit_sort", on))
+        try:
+            for odt in (np.int32, np.int64):
+                kh = kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+                Ad, Bd = dev(be, A, offset_dtype=odt), dev(be, B, offset_dtype=odt)
+                Cm = kk.spgemm_symbolic(kh, Ad, False, Bd, False)
+                kk.spgemm_numeric(kh, Ad, False, Bd, False, Cm)
+                sh = kh.get_spgemm_handle()
+                assert (sh.get(15) >= 42) == bool(on), sh.get(15)
+                rm_, ent_, val_ = Cm.to_host()
+                ok, msg = oracle.is_same_matrix(oracle.Crs(A.nrows, B.ncols, rm_.astype(np.int64), ent_, val_.astype(np.float64)), gold)
+                assert ok, msg
+                kk.spgemm_numeric(kh, Ad, False, Bd, False, Cm)            # reuse: entries kept
+                assert sh.get(11) == 1
+                rm2, ent2, val2 = Cm.to_host()
+                assert np.array_equal(ent_, ent2) and np.allclose(val_, val2, rtol=1e-13)
+                kh.destroy_spgemm_handle()
+        finally:
+            kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_emit_sort", 1))
+
+
 def randomized(A0, seed=5):
     """values re-drawn in [1,50) as the reference's SpGEMM tests do (Test_Sparse_spgemm.hpp:62-72)"""
     rng = np.random.default_rng(seed)

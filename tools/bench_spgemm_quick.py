@@ -11,8 +11,18 @@ def set_defaults(spec):
         if kv: kk._capi.check(kk.torch_backend().lib, kk.torch_backend().lib.kkamd_set_default(kv.split("=")[0].encode(), int(kv.split("=")[1])))
 set_defaults(os.environ.get("KK_DEFAULTS", ""))
 sweep = os.environ.get("KK_SWEEP", "").split(";")
-for scale in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "18").split(",")]:
-    R = oracle.rmat(scale, 16)
+def case_matrix(name):
+    """an R-MAT scale ("18"), "feN" = 27-point FE Laplacian N^3, "fdN" = 7-point, "rndN" = N rows of 20 uniformly random columns"""
+    if name.startswith("fe") or name.startswith("fd"):
+        n = int(name[2:])
+        fe = name[1] == "e"
+        return "%s %d^3" % ("27-pt FE" if fe else "7-pt FD", n), oracle.laplace3d("FE" if fe else "FD", n, n, n)
+    if name.startswith("rnd"):
+        n = int(name[3:])
+        return "uniform random %d x 20" % n, oracle.random_crs(n, n, 20, variance=0, seed=3, sorted_rows=True)
+    return "R-MAT scale %d ef 16" % int(name), oracle.rmat(int(name), 16)
+for name in (sys.argv[1] if len(sys.argv) > 1 else "18").split(","):
+    label, R = case_matrix(name)
     M = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, offset_dtype=np.int64)
     for sw in sweep:
         set_defaults(sw)
@@ -33,6 +43,6 @@ for scale in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "18").split
             kh.destroy_spgemm_handle(); del Cm
         b_num = R.nnz * 12 + (R.nrows + 1) * 8 + mults * 12 + nnzC * 12 + (R.nrows + 1) * 8
         b_sym = R.nnz * 4 + (R.nrows + 1) * 8 + mults * 4 + (R.nrows + 1) * 8
-        print(json.dumps({"case": "R-MAT scale %d ef 16" % scale, "mults": mults, "nnzC": nnzC, "symbolic_ms": round(best[1] * 1e3, 3),
+        print(json.dumps({"case": label, "mults": mults, "nnzC": nnzC, "symbolic_ms": round(best[1] * 1e3, 3),
                           "numeric_ms": round(best[2] * 1e3, 3), "numeric_reuse_ms": round(best[3] * 1e3, 3), "entries_kept": best[4], "rows_from_bitmaps": src[0], "rows_from_lists": src[1], "numeric_frac_of_gather_model": round(b_num / best[2] / 8e12, 4),
                           "symbolic_frac_of_gather_model": round(b_sym / best[1] / 8e12, 4), "defaults": ",".join(v for v in (os.environ.get("KK_DEFAULTS", ""), sw) if v)}), flush=True)
