@@ -830,6 +830,31 @@ __device__ __forceinline__ int emit_bits_by_wave(const kk_u64* __restrict__ bm, 
 // with store instructions whose 64 lanes write 64 CONSECUTIVE entries.  With the direct form every lane writes its own run of up to
 // 64 entries, i.e. every store instruction is 64 four-byte pieces in 64 different lines: on R-MAT scale 20 the stored bitmaps emit
 // 8e9 entries = 8e9 L2 write requests in 27.9 ms -- the L2's request rate, not its bandwidth (32 GB at 1.15 TB/s).
+// Inclusive prefix sum of one int per lane across the wave, on the VECTOR unit: six DPP adds (row_shr 1, 2, 4, 8, then lane 15 / lane 31
+// of the rows before broadcast into the rows after).  __shfl_up compiles to ds_bpermute_b32, which occupies the LDS unit: the bitmap
+// emission kernel issued 700 of them per workgroup pass and kept the LDS unit 84 % busy (profiles/round4/spgemm_s20_sq_counters.txt).
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v, int lane) {
+#ifdef KK_EMU
+  for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(v, (unsigned)o, 64); if (lane >= o) v += nb; }
+  return v;
+#else
+  (void)lane;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1 (zeros shifted in at the start of every row of 16)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+#endif
+}
+__device__ __forceinline__ int wave_last_lane_i32(int v) {
+#ifdef KK_EMU
+  return __shfl(v, 63, 64);
+#else
+  return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
 __device__ __forceinline__ int emit_bits_by_wave_staged(const kk_u64* __restrict__ bm, int words, int64_t col0, int64_t pos0, int32_t* __restrict__ entC, int* s_wave,
                                                         int32_t* __restrict__ stage /* [1024] of this wave */) {
   constexpr int NW = kDenseBlock / 64, NB = 16;
@@ -855,9 +880,8 @@ __device__ __forceinline__ int emit_bits_by_wave_staged(const kk_u64* __restrict
       const unsigned half = (lane & 2) ? hi : lo;
       unsigned piece = (lane & 1) ? (half >> 16) : (half & 0xffffu);
       const int pc = __popc(piece);
-      int inc = pc;
-      for (int o = 1; o < 64; o <<= 1) { const int nb_ = __shfl_up(inc, (unsigned)o, 64); if (lane >= o) inc += nb_; }
-      const int total = __shfl(inc, 63, 64);
+      const int inc = wave_inclusive_scan_i32(pc, lane);
+      const int total = wave_last_lane_i32(inc);
       if (total == 0) continue;                            // uniform
       int at = inc - pc;
       const int c0 = (int)(col0 + ((int64_t)(w0 + i * 64 + src)) * 64 + 16 * (lane & 3));
