@@ -356,6 +356,21 @@ def check_spgemm_kept_structure(be):
     B = fz.hubby(rng, n, k, 3000, 0, 3000)            # rows of B: 0 .. 6000 entries
     A = fz.hubby(rng, 10, n, 3, 2, 20)                # rows of A: 0 .. 6 entries, two of about 20
     gold = oracle.spgemm(A, B)
+    # rows of C that are 30 .. 100 % dense (kept bitmaps whose 64-word steps hold more than a wave's 1024 staging slots: halves, quarters)
+    kd = 8192
+    lens = rng.integers(1500, 6000, size=30)
+    rmd = np.zeros(31, dtype=np.int64); np.cumsum(lens, out=rmd[1:])
+    Bd0 = oracle.Crs(30, kd, rmd, np.concatenate([np.sort(rng.choice(kd, size=l, replace=False)) for l in lens]).astype(np.int32), 1 + 49 * rng.random(rmd[-1]))
+    rows_d = [np.sort(rng.choice(30, size=c, replace=False)) for c in (1, 2, 3, 6, 12, 30)]
+    armd = np.zeros(len(rows_d) + 1, dtype=np.int64); np.cumsum([len(r) for r in rows_d], out=armd[1:])
+    Ad0 = oracle.Crs(len(rows_d), 30, armd, np.concatenate(rows_d).astype(np.int32), 1 + 49 * rng.random(armd[-1]))
+    got_d = check_spgemm(be, Ad0, Bd0)
+    assert np.diff(got_d.row_map).max() > 8000 and np.diff(got_d.row_map).min() >= 1500
+    kh = kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+    Cd = kk.spgemm_symbolic(kh, dev(be, Ad0), False, dev(be, Bd0), False)
+    kk.spgemm_numeric(kh, dev(be, Ad0), False, dev(be, Bd0), False, Cd)
+    assert kh.get_spgemm_handle().get(12) >= 4, kh.get_spgemm_handle().get(12)          # written from kept bitmaps
+    kh.destroy_spgemm_handle()
     for lists in (1, 0):
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_keep_lists", lists))
         try:
