@@ -2088,7 +2088,8 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   h->mults = (int64_t)h_stats[0]; h->max_row_flops = (int64_t)h_stats[1];
   h->sg_log2 = pick_sg_log2(nnzB, n); h->nnzB = nnzB;
   if (h->d_flop_cls) { (void)hipFree(h->d_flop_cls); h->d_flop_cls = nullptr; }
-  if (g_spgemm.emit_sort && hipMalloc((void**)&h->d_flop_cls, sizeof(int32_t) * (size_t)m) == hipSuccess) {
+  // (only when some row can land in the numeric phase's dense bin at all: more products than the wave kernel's table takes entries)
+  if (g_spgemm.emit_sort && h->max_row_flops > (int64_t)(kWaveTable / 2) && hipMalloc((void**)&h->d_flop_cls, sizeof(int32_t) * (size_t)m) == hipSuccess) {
     int32_t* d_cls = h->d_flop_cls; const int64_t* d_fl = h->d_sizes;
     KK_LAUNCH(spgemm_flop_class_kernel, (unsigned)ceil_div(m, kBlock), kBlock, 0, st, m, d_fl, d_cls);
   } else { (void)hipGetLastError(); h->d_flop_cls = nullptr; }

@@ -38,7 +38,7 @@ def run(be, budget, seed0=0, max_cases=None):
                 if rng.random() < 0.4:     # rows of C with a few hundred to a few thousand entries out of about as many products: wave table, LDS sort, bitmap
                     k = int(rng.integers(20000, 200000))
                     B = hubby(rng, n, k, int(rng.integers(5, 40)), 0, 1)
-                    A = hubby(rng, int(rng.integers(5, 80)), n, int(rng.integers(8, 50)), int(rng.integers(0, 3)), min(n, int(rng.integers(60, 300))))
+                    A = hubby(rng, int(rng.integers(5, 80)), n, min(int(rng.integers(8, 50)), n // 2 - 1), int(rng.integers(0, 3)), min(n, int(rng.integers(60, 300))))
                 else:
                     B = hubby(rng, n, k, int(rng.integers(2, 30)), int(rng.integers(1, 6)), int(rng.integers(500, 20000)))
                     A = hubby(rng, int(rng.integers(3, 60)), n, int(rng.integers(1, 8)), int(rng.integers(0, 3)), n)
