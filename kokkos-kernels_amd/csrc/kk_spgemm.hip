@@ -576,6 +576,32 @@ __device__ __forceinline__ void flat_columns_quads(int64_t row, const OffT* __re
   }
 }
 
+// Inclusive prefix sum of one int per lane across the wave, on the VECTOR unit: six DPP adds (row_shr 1, 2, 4, 8, then lane 15 / lane 31
+// of the rows before broadcast into the rows after).  __shfl_up compiles to ds_bpermute_b32, which occupies the LDS unit: the bitmap
+// emission kernel issued 700 of them per workgroup pass and kept the LDS unit 84 % busy (profiles/round4/spgemm_s20_sq_counters.txt).
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v, int lane) {
+#ifdef KK_EMU
+  for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(v, (unsigned)o, 64); if (lane >= o) v += nb; }
+  return v;
+#else
+  (void)lane;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1 (zeros shifted in at the start of every row of 16)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+#endif
+}
+__device__ __forceinline__ int wave_last_lane_i32(int v) {
+#ifdef KK_EMU
+  return __shfl(v, 63, 64);
+#else
+  return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
+__device__ __forceinline__ int wave_sum_i32(int v, int lane) { return wave_last_lane_i32(wave_inclusive_scan_i32(v, lane)); }
 // Wave-wide flat iteration (wave-per-row kernels): the same idea as flat_products for one wave -- lane l looks up the
 // l-th A entry of the row (all B row lookups of up to 64 entries in ONE dependent chain instead of one chain per group
 // of entries), a shuffle scan turns the lengths into product offsets kept in wave-private LDS, then lane (q mod 64)
@@ -594,9 +620,8 @@ __device__ __forceinline__ void wave_flat_products(bool active, int64_t row, con
     long long b0 = 0;
     int len = 0;
     if (lane < n) { const int32_t c = entA[chunk + lane]; b0 = (long long)rmB[c]; len = (int)((long long)(endB ? endB[c] : rmB[c + 1]) - b0); }
-    int inc = len;
-    for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(inc, (unsigned)o, 64); if (lane >= o) inc += nb; }
-    const int tot = __shfl(inc, 63, 64);
+    const int inc = wave_inclusive_scan_i32(len, lane);      // (on the vector unit: a shuffle is an LDS instruction, and the wave-per-row
+    const int tot = wave_last_lane_i32(inc);                 //  kernels keep the LDS unit 50-70 % busy on stencil products)
     KK_WAVE_SYNC();                       // the previous chunk's readers are done
     sc.pre[lane] = inc - len; sc.b0[lane] = b0;
     if (lane == 0) sc.pre[64] = tot;
@@ -734,26 +759,39 @@ __global__ __launch_bounds__(NT) void spgemm_symc_block_kernel(int64_t nbin, con
 
 // ------------------------------------------------------------------------------------------------
 // 3. symbolic kernels
+// The table of a row is as large as the row needs (a power of two of at least 3 times its products, 64 .. kSymWaveTable slots):
+// a 7-point stencil times itself has 49 products per row, and clearing 2048 slots for them was most of what the row cost the LDS unit
+// (3.4 M rows of 7-pt 150^3: LDS 73 % busy, 55 LDS instructions per row of which 32 cleared the table).
 template <class OffT>
 __global__ __launch_bounds__(kBlock) void spgemm_sym_wave_kernel(int64_t nbin, const int32_t* __restrict__ perm,
                                                                  const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                  const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
-                                                                 OffT* __restrict__ counts, int sg_log2) {
+                                                                 OffT* __restrict__ counts, const int64_t* __restrict__ flops) {
   constexpr int H = kSymWaveTable;
-  __shared__ int tab[kBlock / 64][H];
+  __shared__ __attribute__((aligned(16))) int tab[kBlock / 64][H];
   __shared__ WaveFlatScratch s_wf[kBlock / 64];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
-  for (int i = lane; i < H; i += 64) tab[w][i] = -1;
-  __syncthreads();
-  int cnt = 0;
   const bool active = idx < nbin;
   const int64_t row = active ? (int64_t)perm[idx] : 0;
+  int hrow = H;
+  if (flops) {                                             // wave-uniform
+    const int64_t need = active ? 3 * flops[row] : 0;       // (1.5 x: uniform random 1e6 x 20, 400 products per row, symbolic 3.6 -> 4.3 ms -- probe collisions)
+    hrow = 64;
+    while (hrow < H && (int64_t)hrow < need) hrow <<= 1;
+  }
   int* mytab = tab[w];
+  {
+    int4* t4 = reinterpret_cast<int4*>(mytab);
+    int4 empty; empty.x = -1; empty.y = -1; empty.z = -1; empty.w = -1;
+    for (int i = lane; i < hrow / 4; i += 64) t4[i] = empty;
+  }
+  KK_WAVE_SYNC();                                          // the table is the wave's own: no workgroup barrier
+  int cnt = 0;
+  const int mask = hrow - 1;
   wave_flat_products<OffT, NoVals>(active, row, rmA, entA, rmB, entB, (const NoVals*)nullptr, lane, s_wf[w],
-                                   [&](int64_t, int64_t, int c) { cnt += hash_insert_key(mytab, H - 1, c) ? 1 : 0; });
-  (void)sg_log2;
-  cnt = group_sum(cnt, 64);
+                                   [&](int64_t, int64_t, int c) { cnt += hash_insert_key(mytab, mask, c) ? 1 : 0; });
+  cnt = wave_sum_i32(cnt, lane);
   if (idx < nbin && lane == 0) counts[row] = (OffT)cnt;
 }
 
@@ -830,31 +868,6 @@ __device__ __forceinline__ int emit_bits_by_wave(const kk_u64* __restrict__ bm, 
 // with store instructions whose 64 lanes write 64 CONSECUTIVE entries.  With the direct form every lane writes its own run of up to
 // 64 entries, i.e. every store instruction is 64 four-byte pieces in 64 different lines: on R-MAT scale 20 the stored bitmaps emit
 // 8e9 entries = 8e9 L2 write requests in 27.9 ms -- the L2's request rate, not its bandwidth (32 GB at 1.15 TB/s).
-// Inclusive prefix sum of one int per lane across the wave, on the VECTOR unit: six DPP adds (row_shr 1, 2, 4, 8, then lane 15 / lane 31
-// of the rows before broadcast into the rows after).  __shfl_up compiles to ds_bpermute_b32, which occupies the LDS unit: the bitmap
-// emission kernel issued 700 of them per workgroup pass and kept the LDS unit 84 % busy (profiles/round4/spgemm_s20_sq_counters.txt).
-__device__ __forceinline__ int wave_inclusive_scan_i32(int v, int lane) {
-#ifdef KK_EMU
-  for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(v, (unsigned)o, 64); if (lane >= o) v += nb; }
-  return v;
-#else
-  (void)lane;
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1 (zeros shifted in at the start of every row of 16)
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-  return v;
-#endif
-}
-__device__ __forceinline__ int wave_last_lane_i32(int v) {
-#ifdef KK_EMU
-  return __shfl(v, 63, 64);
-#else
-  return __builtin_amdgcn_readlane(v, 63);
-#endif
-}
 // (Measured and not kept: every lane laying down the set bits of its OWN 64-bit word -- no shuffles at all, one prefix sum per 64 words,
 // steps above 1024 entries taken in halves or quarters of the lanes: R-MAT scale 20 numeric 193.7 -> 200.9 ms; the 16-bit pieces below
 // keep the divergent loop at 16 trips at most.)
@@ -1202,28 +1215,36 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_wave_kernel(int64_t nbin, c
                                                                  const OffT* __restrict__ rmC, int32_t* __restrict__ entC,
                                                                  VT* __restrict__ valC, int sg_log2) {
   constexpr int H = kWaveTable;
-  __shared__ int keys[kBlock / 64][H];
-  __shared__ VT vals[kBlock / 64][H];
+  __shared__ __attribute__((aligned(16))) int keys[kBlock / 64][H];
+  __shared__ __attribute__((aligned(16))) VT vals[kBlock / 64][H];
   __shared__ int ckey[kBlock / 64][H / 2];
   __shared__ WaveFlatScratch s_wf[kBlock / 64];
   __shared__ unsigned short cslot[kBlock / 64][H / 2];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
-  for (int i = lane; i < H; i += 64) { keys[w][i] = -1; vals[w][i] = VT(0); }
-  __syncthreads();
+  const bool active = idx < nbin;
+  const int64_t row = active ? (int64_t)perm[idx] : 0;
+  // the row's table: a power of two of at least four times its entries (known exactly: row_map of C), 64 .. H slots -- clearing and
+  // compacting 512 slots for the 25 entries of a 7-point stencil product was most of the row's LDS work
+  int hrow = 64;
   {
-    const bool active = idx < nbin;
-    const int64_t row = active ? (int64_t)perm[idx] : 0;
+    const int64_t need = active ? 4 * ((int64_t)rmC[row + 1] - (int64_t)rmC[row]) : 0;
+    while (hrow < H && (int64_t)hrow < need) hrow <<= 1;
+  }
+  for (int i = lane; i < hrow; i += 64) { keys[w][i] = -1; vals[w][i] = VT(0); }
+  KK_WAVE_SYNC();                                          // tables and scratch are the wave's own: no workgroup barrier
+  {
     int* mk = keys[w]; VT* mv = vals[w];
+    const int mask = hrow - 1;
     wave_flat_products<OffT, VT>(active, row, rmA, entA, rmB, entB, valB, lane, s_wf[w],
-                                 [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(mk, mv, H - 1, c, valA[a] * bv); });
+                                 [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(mk, mv, mask, c, valA[a] * bv); });
     (void)sg_log2;
   }
-  __syncthreads();
+  KK_WAVE_SYNC();
   // compact the occupied slots (ballot + prefix), then rank-by-counting over the compact list only: keys are unique,
   // so rank = number of smaller keys.  ceil(n/64) * n compares per wave instead of 8 * 512 over the whole table.
   int n = 0;
-  for (int s0 = 0; s0 < H; s0 += 64) {
+  for (int s0 = 0; s0 < hrow; s0 += 64) {
     const int key        = keys[w][s0 + lane];
     const kk_u64 occ     = __ballot(key >= 0);
     if (key >= 0) {
@@ -1235,7 +1256,6 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_wave_kernel(int64_t nbin, c
   }
   KK_WAVE_SYNC();
   if (idx < nbin) {
-    const int64_t row  = perm[idx];
     const int64_t base = (int64_t)rmC[row];
     for (int i = lane; i < n; i += 64) {
       const int key = ckey[w][i];
@@ -2165,7 +2185,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   } else {
     if ((rc = make_bins(m, h->d_sizes, k, g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
     if (nb(1)) KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
-                         (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, sg);
+                         (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
     if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
                          (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
     if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
