@@ -37,6 +37,13 @@ def lib():
         if not _os.path.exists(LIB_PATH):
             raise RuntimeError("libkkamd.so is missing (%s): run __graft_entry__.build(); "
                                "kokkos-kernels_amd has no CPU fallback" % LIB_PATH)
+        # torch first: its wheel carries its own HIP runtime, and a process that maps libkkamd.so (linked against /opt/rocm's) before
+        # torch ends up with a runtime that finds no device ("no ROCm-capable device is detected" from the first kkamd call --
+        # seen with `python __graft_entry__.py smoke`, which builds, loads the library and only then imports torch)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = _capi.bind(_C.CDLL(LIB_PATH))
     return _lib
 
