@@ -24,12 +24,14 @@ def hubby(rng, n, ncols, base, nhubs, hublen, sort=True):
     return oracle.Crs(n, ncols, rm, ent, 1 + 49 * rng.random(rm[-1]))
 
 
-def run(be, budget, seed0=0, max_cases=None):
-    """runs random cases until `budget` seconds are over (or max_cases); returns (cases passed, per-kind counts, last seed)"""
+def run(be, budget, seed0=0, max_cases=None, kinds=None):
+    """runs random cases until `budget` seconds are over (or max_cases); returns (cases passed, per-kind counts, last seed).
+    kinds: only these kinds (indices into KINDS) are run, the others' seeds are skipped"""
     t_end = time.time() + budget
     n_ok = 0; case = 0; per_kind = [0] * 8
     while time.time() < t_end and (max_cases is None or case < max_cases):
         rng = np.random.default_rng(seed0 + case); kind = case % 8; case += 1
+        if kinds is not None and kind not in kinds: continue
         odt = np.int64 if rng.random() < 0.5 else np.int32
         vdt = np.float32 if rng.random() < 0.3 else np.float64
         try:
