@@ -109,6 +109,9 @@ struct SpgemmTuning {
                                   // R-MAT scale 20 numeric / reuse: 0: 221.7 / 184.7 ms, 8192: 217.6 / 180.7, 32768: 213.8 / 176.6, 65536: 211.1 / 174.6, 131072: 216.4 / 179.5, all: 219.0 / 182.3)
   int val_tiny_cnt   = 32768;     // ... and at most this many (and kValLaTiny entries in the A row) the lightest one: 128 work-items, 1024-slot table (0 = none;
                                   // R-MAT scale 20 numeric / reuse with the light shape at 65536: 0: 212.0 / 175.2 ms, 2048: 210.0 / 172.8, 8192: 208.4 / 171.6, 32768: 207.5 / 170.9)
+  int quad_rows      = 1;         // wave-per-row kernels with four rows of the list per wave, 16 lanes each: 1 = when EVERY row of the product is small (at most kQuadFlops products /
+                                  // kQuadNnz entries; 7-pt FD 150^3: symbolic 3.54 -> 1.94 ms, numeric 4.24 -> 1.97), 2 = always (waves with a larger row do their four rows one after
+                                  // the other: 27-pt FE 100^3 numeric 4.04 -> 5.03 ms, which is why 1 is the default), 0 = never
   int emit_sort      = 1;         // entries(C) of the dense-bin rows with at most kEmitSortCap products: sorted in LDS, 256 work-items per row (0 = the bitmap kernel)
   int val_steps      = 1;         // steps of a window's product walk a work-item of the flat value kernel keeps in flight (1..3)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
@@ -602,6 +605,75 @@ __device__ __forceinline__ int wave_last_lane_i32(int v) {
 #endif
 }
 __device__ __forceinline__ int wave_sum_i32(int v, int lane) { return wave_last_lane_i32(wave_inclusive_scan_i32(v, lane)); }
+// Inclusive prefix sum inside every ROW of 16 lanes (a DPP row): four adds on the vector unit.  All 64 lanes call it.
+__device__ __forceinline__ int row16_inclusive_scan_i32(int v, int lane) {
+#ifdef KK_EMU
+  for (int o = 1; o < 16; o <<= 1) { const int nb = __shfl_up(v, (unsigned)o, 16); if ((lane & 15) >= o) v += nb; }
+  return v;
+#else
+  (void)lane;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+  return v;
+#endif
+}
+// FOUR ROWS PER WAVE (rows with a few dozen products: a 7-point stencil times itself has 49, the A P of a multigrid set-up 7 .. 100):
+// lanes 16 g .. 16 g + 15 walk the products of the g-th row.  The control flow is the WAVE's -- every loop runs as long as the longest
+// of the four rows needs (__any), lanes with nothing to do are masked -- so that the prefix sums and ballots inside stay wave-wide
+// operations.  f as in wave_flat_products.  sc: the group's own scratch.
+struct Group16Scratch { int pre[17]; int pad_[3]; long long b0[16]; };
+template <class OffT, class VT, class F>
+__device__ __forceinline__ void group16_flat_products(bool active, int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                      const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                      const VT* __restrict__ valB, int lane, Group16Scratch& sc, F f) {
+  constexpr bool kVals = !std::is_same<VT, NoVals>::value;
+  constexpr int U = kProdUnroll;
+  const int gl = lane & 15;
+  int64_t a_beg = 0, a_end = 0;
+  if (active) { a_beg = (int64_t)rmA[row]; a_end = (int64_t)rmA[row + 1]; }
+  for (int64_t off = 0; __any(a_beg + off < a_end); off += 16) {
+    const int64_t chunk = a_beg + off;
+    const int n = chunk < a_end ? (int)(a_end - chunk < 16 ? a_end - chunk : 16) : 0;
+    long long b0 = 0;
+    int len = 0;
+    if (gl < n) { const int32_t c = entA[chunk + gl]; b0 = (long long)rmB[c]; len = (int)((long long)rmB[c + 1] - b0); }
+    const int inc = row16_inclusive_scan_i32(len, lane);
+    KK_WAVE_SYNC();                       // the previous chunk's readers are done
+    sc.pre[gl] = inc - len; sc.b0[gl] = b0;
+    if (gl == 15) sc.pre[16] = inc;
+    KK_WAVE_SYNC();
+    const int tot = sc.pre[16];
+    for (int base = 0; __any(base < tot); base += 16 * U) {
+      int col[U], seg[U];
+      long long jj[U];
+      typename std::conditional<kVals, VT, int>::type bv[U];
+      KK_UNROLL
+      for (int u = 0; u < U; ++u) {
+        const int q = base + u * 16 + gl;
+        seg[u] = 0; jj[u] = 0;
+        if (q < tot) {                    // (tot > 0 implies n >= 1)
+          int lo = 0, len2 = n;
+          while (len2 > 1) { const int half = len2 >> 1; lo += (sc.pre[lo + half] <= q) ? half : 0; len2 -= half; }
+          seg[u] = lo;
+          jj[u] = sc.b0[lo] + (q - sc.pre[lo]);
+        }
+      }
+      KK_UNROLL
+      for (int u = 0; u < U; ++u) {       // unconditional loads (entry 0 of B exists when some group of the wave has products)
+        col[u] = entB[jj[u]];
+        if constexpr (kVals) bv[u] = valB[jj[u]];
+      }
+      KK_UNROLL
+      for (int u = 0; u < U; ++u)
+        if (base + u * 16 + gl < tot) {
+          if constexpr (kVals) f(chunk + seg[u], col[u], bv[u]);
+          else f(chunk + seg[u], (int64_t)jj[u], col[u]);
+        }
+    }
+  }
+}
 // Wave-wide flat iteration (wave-per-row kernels): the same idea as flat_products for one wave -- lane l looks up the
 // l-th A entry of the row (all B row lookups of up to 64 entries in ONE dependent chain instead of one chain per group
 // of entries), a shuffle scan turns the lengths into product offsets kept in wave-private LDS, then lane (q mod 64)
@@ -763,24 +835,16 @@ __global__ __launch_bounds__(NT) void spgemm_symc_block_kernel(int64_t nbin, con
 // a 7-point stencil times itself has 49 products per row, and clearing 2048 slots for them was most of what the row cost the LDS unit
 // (3.4 M rows of 7-pt 150^3: LDS 73 % busy, 55 LDS instructions per row of which 32 cleared the table).
 template <class OffT>
-__global__ __launch_bounds__(kBlock) void spgemm_sym_wave_kernel(int64_t nbin, const int32_t* __restrict__ perm,
-                                                                 const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
-                                                                 const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
-                                                                 OffT* __restrict__ counts, const int64_t* __restrict__ flops) {
+__device__ __forceinline__ void sym_wave_row(bool active, int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                             const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, OffT* __restrict__ counts,
+                                             const int64_t* __restrict__ flops, int* mytab, WaveFlatScratch& wf, int lane) {
   constexpr int H = kSymWaveTable;
-  __shared__ __attribute__((aligned(16))) int tab[kBlock / 64][H];
-  __shared__ WaveFlatScratch s_wf[kBlock / 64];
-  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
-  const bool active = idx < nbin;
-  const int64_t row = active ? (int64_t)perm[idx] : 0;
   int hrow = H;
   if (flops) {                                             // wave-uniform
     const int64_t need = active ? 3 * flops[row] : 0;       // (1.5 x: uniform random 1e6 x 20, 400 products per row, symbolic 3.6 -> 4.3 ms -- probe collisions)
     hrow = 64;
     while (hrow < H && (int64_t)hrow < need) hrow <<= 1;
   }
-  int* mytab = tab[w];
   {
     int4* t4 = reinterpret_cast<int4*>(mytab);
     int4 empty; empty.x = -1; empty.y = -1; empty.z = -1; empty.w = -1;
@@ -789,10 +853,63 @@ __global__ __launch_bounds__(kBlock) void spgemm_sym_wave_kernel(int64_t nbin, c
   KK_WAVE_SYNC();                                          // the table is the wave's own: no workgroup barrier
   int cnt = 0;
   const int mask = hrow - 1;
-  wave_flat_products<OffT, NoVals>(active, row, rmA, entA, rmB, entB, (const NoVals*)nullptr, lane, s_wf[w],
+  wave_flat_products<OffT, NoVals>(active, row, rmA, entA, rmB, entB, (const NoVals*)nullptr, lane, wf,
                                    [&](int64_t, int64_t, int c) { cnt += hash_insert_key(mytab, mask, c) ? 1 : 0; });
   cnt = wave_sum_i32(cnt, lane);
-  if (idx < nbin && lane == 0) counts[row] = (OffT)cnt;
+  if (active && lane == 0) counts[row] = (OffT)cnt;
+}
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_sym_wave_kernel(int64_t nbin, const int32_t* __restrict__ perm,
+                                                                 const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                 const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                                 OffT* __restrict__ counts, const int64_t* __restrict__ flops) {
+  __shared__ __attribute__((aligned(16))) int tab[kBlock / 64][kSymWaveTable];
+  __shared__ WaveFlatScratch s_wf[kBlock / 64];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
+  const bool active = idx < nbin;
+  const int64_t row = active ? (int64_t)perm[idx] : 0;
+  sym_wave_row<OffT>(active, row, rmA, entA, rmB, entB, counts, flops, tab[w], s_wf[w], lane);
+}
+// A wave takes FOUR consecutive rows of the bin's list.  When none of them has more than kQuadFlops products, 16 lanes take each
+// (group16_flat_products, a 256-slot table per row inside the wave's table); otherwise the wave does the four rows one after the other
+// as above.
+constexpr int kQuadFlops = 64;
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_sym_quad_kernel(int64_t nbin, const int32_t* __restrict__ perm,
+                                                                 const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                 const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                                 OffT* __restrict__ counts, const int64_t* __restrict__ flops) {
+  __shared__ __attribute__((aligned(16))) int tab[kBlock / 64][kSymWaveTable];
+  __shared__ WaveFlatScratch s_wf[kBlock / 64];
+  __shared__ Group16Scratch s_g[kBlock / 16];
+  static_assert(kSymWaveTable >= 4 * 256, "four 256-slot tables inside a wave's table");
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, g = lane >> 4, gl = lane & 15;
+  const int64_t first = ((int64_t)blockIdx.x * (kBlock / 64) + w) * 4;         // the wave's first position in the list
+  const bool act = first + g < nbin;
+  const int64_t row = act ? (int64_t)perm[first + g] : 0;
+  const int64_t fl = act ? flops[row] : 0;
+  if (!__any(fl > (int64_t)kQuadFlops)) {                  // wave-uniform
+    int* gtab = tab[w] + g * 256;
+    {
+      int4* t4 = reinterpret_cast<int4*>(gtab);
+      int4 empty; empty.x = -1; empty.y = -1; empty.z = -1; empty.w = -1;
+      for (int i = gl; i < 64; i += 16) t4[i] = empty;
+    }
+    KK_WAVE_SYNC();
+    int cnt = 0;
+    group16_flat_products<OffT, NoVals>(act, row, rmA, entA, rmB, entB, (const NoVals*)nullptr, lane, s_g[t >> 4],
+                                        [&](int64_t, int64_t, int c) { cnt += hash_insert_key(gtab, 255, c) ? 1 : 0; });
+    cnt = row16_inclusive_scan_i32(cnt, lane);
+    if (act && gl == 15) counts[row] = (OffT)cnt;
+  } else {
+    for (int r = 0; r < 4; ++r) {
+      const bool a = first + r < nbin;
+      const int64_t rw = a ? (int64_t)perm[first + r] : 0;
+      sym_wave_row<OffT>(a, rw, rmA, entA, rmB, entB, counts, flops, tab[w], s_wf[w], lane);
+      KK_WAVE_SYNC();                                      // the next row clears the table
+    }
+  }
 }
 
 template <class OffT, int H, int NT>
@@ -1208,6 +1325,52 @@ __global__ __launch_bounds__(kBlock) void spgemm_split_stored_kernel(int64_t nd,
 // ------------------------------------------------------------------------------------------------
 // 4. numeric kernels
 template <class OffT, class VT>
+__device__ __forceinline__ void num_wave_row(bool active, int64_t row, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                             const VT* __restrict__ valA, const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                             const VT* __restrict__ valB, const OffT* __restrict__ rmC, int32_t* __restrict__ entC,
+                                             VT* __restrict__ valC, int* mk, VT* mv, int* ck, unsigned short* cs, WaveFlatScratch& wf, int lane) {
+  constexpr int H = kWaveTable;
+  // the row's table: a power of two of at least four times its entries (known exactly: row_map of C), 64 .. H slots -- clearing and
+  // compacting 512 slots for the 25 entries of a 7-point stencil product was most of the row's LDS work
+  int hrow = 64;
+  {
+    const int64_t need = active ? 4 * ((int64_t)rmC[row + 1] - (int64_t)rmC[row]) : 0;
+    while (hrow < H && (int64_t)hrow < need) hrow <<= 1;
+  }
+  for (int i = lane; i < hrow; i += 64) { mk[i] = -1; mv[i] = VT(0); }
+  KK_WAVE_SYNC();                                          // tables and scratch are the wave's own: no workgroup barrier
+  {
+    const int mask = hrow - 1;
+    wave_flat_products<OffT, VT>(active, row, rmA, entA, rmB, entB, valB, lane, wf,
+                                 [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(mk, mv, mask, c, valA[a] * bv); });
+  }
+  KK_WAVE_SYNC();
+  // compact the occupied slots (ballot + prefix), then rank-by-counting over the compact list only: keys are unique,
+  // so rank = number of smaller keys.  ceil(n/64) * n compares per wave instead of 8 * 512 over the whole table.
+  int n = 0;
+  for (int s0 = 0; s0 < hrow; s0 += 64) {
+    const int key        = mk[s0 + lane];
+    const kk_u64 occ     = __ballot(key >= 0);
+    if (key >= 0) {
+      const int pos = n + __popcll(occ & ((1ull << lane) - 1ull));
+      ck[pos] = key;
+      cs[pos] = (unsigned short)(s0 + lane);
+    }
+    n += __popcll(occ);
+  }
+  KK_WAVE_SYNC();
+  if (active) {
+    const int64_t base = (int64_t)rmC[row];
+    for (int i = lane; i < n; i += 64) {
+      const int key = ck[i];
+      int rank = 0;
+      for (int q = 0; q < n; ++q) rank += (ck[q] < key) ? 1 : 0;
+      entC[base + rank] = key;
+      valC[base + rank] = mv[cs[i]];
+    }
+  }
+}
+template <class OffT, class VT>
 __global__ __launch_bounds__(kBlock) void spgemm_num_wave_kernel(int64_t nbin, const int32_t* __restrict__ perm,
                                                                  const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                  const VT* __restrict__ valA, const OffT* __restrict__ rmB,
@@ -1224,45 +1387,68 @@ __global__ __launch_bounds__(kBlock) void spgemm_num_wave_kernel(int64_t nbin, c
   const int64_t idx = (int64_t)blockIdx.x * (kBlock / 64) + w;
   const bool active = idx < nbin;
   const int64_t row = active ? (int64_t)perm[idx] : 0;
-  // the row's table: a power of two of at least four times its entries (known exactly: row_map of C), 64 .. H slots -- clearing and
-  // compacting 512 slots for the 25 entries of a 7-point stencil product was most of the row's LDS work
-  int hrow = 64;
-  {
-    const int64_t need = active ? 4 * ((int64_t)rmC[row + 1] - (int64_t)rmC[row]) : 0;
-    while (hrow < H && (int64_t)hrow < need) hrow <<= 1;
-  }
-  for (int i = lane; i < hrow; i += 64) { keys[w][i] = -1; vals[w][i] = VT(0); }
-  KK_WAVE_SYNC();                                          // tables and scratch are the wave's own: no workgroup barrier
-  {
-    int* mk = keys[w]; VT* mv = vals[w];
-    const int mask = hrow - 1;
-    wave_flat_products<OffT, VT>(active, row, rmA, entA, rmB, entB, valB, lane, s_wf[w],
-                                 [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(mk, mv, mask, c, valA[a] * bv); });
-    (void)sg_log2;
-  }
-  KK_WAVE_SYNC();
-  // compact the occupied slots (ballot + prefix), then rank-by-counting over the compact list only: keys are unique,
-  // so rank = number of smaller keys.  ceil(n/64) * n compares per wave instead of 8 * 512 over the whole table.
-  int n = 0;
-  for (int s0 = 0; s0 < hrow; s0 += 64) {
-    const int key        = keys[w][s0 + lane];
-    const kk_u64 occ     = __ballot(key >= 0);
-    if (key >= 0) {
-      const int pos = n + __popcll(occ & ((1ull << lane) - 1ull));
-      ckey[w][pos]  = key;
-      cslot[w][pos] = (unsigned short)(s0 + lane);
+  (void)sg_log2;
+  num_wave_row<OffT, VT>(active, row, rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, keys[w], vals[w], ckey[w], cslot[w], s_wf[w], lane);
+}
+// Four consecutive rows of the list per wave (see spgemm_sym_quad_kernel): when none of them has more than kQuadNnz entries, 16 lanes
+// take each with a 128-slot key + value table inside the wave's; the rows leave sorted by the same rank-by-counting.
+constexpr int kQuadNnz = 32;
+template <class OffT, class VT>
+__global__ __launch_bounds__(kBlock) void spgemm_num_quad_kernel(int64_t nbin, const int32_t* __restrict__ perm,
+                                                                 const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+                                                                 const VT* __restrict__ valA, const OffT* __restrict__ rmB,
+                                                                 const int32_t* __restrict__ entB, const VT* __restrict__ valB,
+                                                                 const OffT* __restrict__ rmC, int32_t* __restrict__ entC,
+                                                                 VT* __restrict__ valC) {
+  constexpr int H = kWaveTable, HG = H / 4;
+  static_assert(HG >= 4 * kQuadNnz, "a group's table holds four times its entries");
+  __shared__ __attribute__((aligned(16))) int keys[kBlock / 64][H];
+  __shared__ __attribute__((aligned(16))) VT vals[kBlock / 64][H];
+  __shared__ int ckey[kBlock / 64][H / 2];
+  __shared__ WaveFlatScratch s_wf[kBlock / 64];
+  __shared__ Group16Scratch s_g[kBlock / 16];
+  __shared__ unsigned short cslot[kBlock / 64][H / 2];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, g = lane >> 4, gl = lane & 15;
+  const int64_t first = ((int64_t)blockIdx.x * (kBlock / 64) + w) * 4;
+  const bool act = first + g < nbin;
+  const int64_t row = act ? (int64_t)perm[first + g] : 0;
+  const int64_t base = act ? (int64_t)rmC[row] : 0;
+  const int64_t nnz = act ? (int64_t)rmC[row + 1] - base : 0;
+  if (!__any(nnz > (int64_t)kQuadNnz)) {                   // wave-uniform
+    int* mk = keys[w] + g * HG; VT* mv = vals[w] + g * HG;
+    int* ck = ckey[w] + g * (HG / 2); unsigned short* cs = cslot[w] + g * (HG / 2);
+    for (int i = gl; i < HG; i += 16) { mk[i] = -1; mv[i] = VT(0); }
+    KK_WAVE_SYNC();
+    group16_flat_products<OffT, VT>(act, row, rmA, entA, rmB, entB, valB, lane, s_g[t >> 4],
+                                    [&](int64_t a, int c, VT bv) { hash_accumulate<VT>(mk, mv, HG - 1, c, valA[a] * bv); });
+    KK_WAVE_SYNC();
+    int n = 0;                                             // the group's entries so far (the same in its 16 lanes)
+    for (int s0 = 0; s0 < HG; s0 += 16) {
+      const int key = mk[s0 + gl];
+      const unsigned occ = (unsigned)((__ballot(key >= 0) >> (16 * g)) & 0xffffull);
+      if (key >= 0) {
+        const int pos = n + __popc(occ & ((1u << gl) - 1u));
+        if (pos < HG / 2) { ck[pos] = key; cs[pos] = (unsigned short)(s0 + gl); }
+      }
+      n += __popc(occ);
     }
-    n += __popcll(occ);
-  }
-  KK_WAVE_SYNC();
-  if (idx < nbin) {
-    const int64_t base = (int64_t)rmC[row];
-    for (int i = lane; i < n; i += 64) {
-      const int key = ckey[w][i];
-      int rank = 0;
-      for (int q = 0; q < n; ++q) rank += (ckey[w][q] < key) ? 1 : 0;
-      entC[base + rank] = key;
-      valC[base + rank] = vals[w][cslot[w][i]];
+    KK_WAVE_SYNC();
+    if (n > HG / 2) n = HG / 2;                            // (cannot happen: at most kQuadNnz entries)
+    if (act) {
+      for (int i = gl; i < n; i += 16) {
+        const int key = ck[i];
+        int rank = 0;
+        for (int q = 0; q < n; ++q) rank += (ck[q] < key) ? 1 : 0;
+        entC[base + rank] = key;
+        valC[base + rank] = mv[cs[i]];
+      }
+    }
+  } else {
+    for (int r = 0; r < 4; ++r) {
+      const bool a = first + r < nbin;
+      const int64_t rw = a ? (int64_t)perm[first + r] : 0;
+      num_wave_row<OffT, VT>(a, rw, rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, keys[w], vals[w], ckey[w], cslot[w], s_wf[w], lane);
+      KK_WAVE_SYNC();
     }
   }
 }
@@ -2184,8 +2370,12 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     }
   } else {
     if ((rc = make_bins(m, h->d_sizes, k, g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
-    if (nb(1)) KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
-                         (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
+    if (nb(1) && (g_spgemm.quad_rows == 2 || (g_spgemm.quad_rows == 1 && h->max_row_flops <= (int64_t)kQuadFlops)))
+      KK_LAUNCH((spgemm_sym_quad_kernel<OffT>), (unsigned)ceil_div(nb(1), 4 * (kBlock / 64)), kBlock, 0, st, nb(1),
+                (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
+    else if (nb(1))
+      KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
+                (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
     if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
                          (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
     if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
@@ -2357,8 +2547,12 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
            "(LDS value windows %lld, LDS hub windows %lld, HBM accumulator %lld)\n", h->algorithm == 1 ? "SPGEMM_KK_DENSE" : "SPGEMM_KK",
            (long long)nb(1), (long long)nb(2), (long long)nb(3), (long long)nb(4), (long long)h->n_dense_lds, (long long)h->n_dense_hub_lds,
            (long long)(nb(4) - h->n_dense_lds - h->n_dense_hub_lds));
-  if (nb(1)) KK_LAUNCH((spgemm_num_wave_kernel<OffT, VT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
-                       (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
+  if (nb(1) && (g_spgemm.quad_rows == 2 || (g_spgemm.quad_rows == 1 && h->max_row_nnz > 0 && h->max_row_nnz <= (int64_t)kQuadNnz)))
+    KK_LAUNCH((spgemm_num_quad_kernel<OffT, VT>), (unsigned)ceil_div(nb(1), 4 * (kBlock / 64)), kBlock, 0, st, nb(1),
+              (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC);
+  else if (nb(1))
+    KK_LAUNCH((spgemm_num_wave_kernel<OffT, VT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
+              (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
   if (nb(2)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkS>), (unsigned)nb(2), kBlock, 0, st, nb(2),
                        (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
   if (nb(3)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkL>), (unsigned)nb(3), kBlock, 0, st, nb(3),
@@ -2626,6 +2820,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
   else if (k == "spgemm_val_tiny_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_tiny_cnt: %d is negative", value); g_spgemm.val_tiny_cnt = value; }
   else if (k == "spgemm_emit_sort") g_spgemm.emit_sort = value != 0;
+  else if (k == "spgemm_quad_rows") { if (value < 0 || value > 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_quad_rows: %d is not 0, 1 or 2", value); g_spgemm.quad_rows = value; }
   else if (k == "spgemm_val_steps") { if (value < 1 || value > 3) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_steps: %d is not 1, 2 or 3", value); g_spgemm.val_steps = value; }
   else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
   else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;

@@ -470,6 +470,43 @@ def check_spgemm_sorted_emission(be):
             kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_emit_sort", 1))
 
 
+def check_spgemm_quad_rows(be):
+    """Wave-per-row kernels with four rows of the list per wave (`spgemm_quad_rows`): stencil products whose rows all have a few
+    dozen products (16 lanes per row), lists whose length is no multiple of four, waves that mix small and larger rows (they fall back to
+    one row after the other), A rows of more than 16 entries on 1-entry rows of B (two chunks per group), empty rows; same C with the knob off."""
+    rng = np.random.default_rng(29)
+    cases = []
+    A7 = randomized(oracle.laplace3d("FD", 9, 7, 5)); cases.append((A7, A7))                      # 315 rows, 49 products at most
+    A9 = randomized(oracle.laplace2d("FE", 13, 11)); cases.append((A9, A9))                       # 143 rows, 81 products: above the limit, wave path
+    # restriction-like P (1 .. 3 entries per row) and A P: 7 .. 81 products per row, 3 .. 40 entries
+    A27 = randomized(oracle.laplace3d("FE", 9, 7, 5))
+    lens = rng.integers(1, 4, size=A27.ncols)
+    rm = np.zeros(A27.ncols + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    P = oracle.Crs(A27.ncols, 60, rm, np.concatenate([np.sort(rng.choice(60, size=l, replace=False)) for l in lens]).astype(np.int32), 1 + 49 * rng.random(rm[-1]))
+    cases.append((A27, P))
+    # mixed: every fifth row of A is long (200 entries on 1-entry rows of B: 200 products, two chunks of 16 do not apply -- wave path), the others tiny;
+    # and a row of 40 entries on 1-entry rows (40 products, three chunks of a group)
+    nb = 500
+    B1 = oracle.Crs(nb, 4000, np.arange(nb + 1, dtype=np.int64), rng.integers(0, 4000, size=nb).astype(np.int32), 1 + 49 * rng.random(nb))
+    rows = []
+    for i in range(41):
+        if i % 5 == 4: rows.append(np.sort(rng.choice(nb, size=200, replace=False)))
+        elif i == 7: rows.append(np.sort(rng.choice(nb, size=40, replace=False)))
+        elif i == 11: rows.append(np.array([], dtype=np.int64))
+        else: rows.append(np.sort(rng.choice(nb, size=int(rng.integers(1, 17)), replace=False)))
+    arm = np.zeros(len(rows) + 1, dtype=np.int64); np.cumsum([len(r) for r in rows], out=arm[1:])
+    Am = oracle.Crs(len(rows), nb, arm, np.concatenate(rows).astype(np.int32), 1 + 49 * rng.random(arm[-1]))
+    cases.append((Am, B1))
+    try:
+        for on in (2, 1, 0):         # 2: always (waves with a larger row fall back), 1: only when every row of the product is small (default), 0: never
+            kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_quad_rows", on))
+            for A, B in cases:
+                check_spgemm(be, A, B)
+            check_spgemm(be, A7, A7, offset_dtype=np.int64, value_dtype=np.float32)
+    finally:
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_quad_rows", 1))
+
+
 def randomized(A0, seed=5):
     """values re-drawn in [1,50) as the reference's SpGEMM tests do (Test_Sparse_spgemm.hpp:62-72)"""
     rng = np.random.default_rng(seed)

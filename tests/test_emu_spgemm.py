@@ -199,6 +199,10 @@ def test_spgemm_entries_sorted_in_lds(be):
     pc.check_spgemm_sorted_emission(be)
 
 
+def test_spgemm_four_rows_per_wave(be):
+    pc.check_spgemm_quad_rows(be)
+
+
 def test_spgemm_issue402(be):
     g = np.load(os.path.join(GOLD, "matrix_issue402.npz"))
     A0 = oracle.Crs(1813, 1813, g["row_map"], g["entries"], g["values"])

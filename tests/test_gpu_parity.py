@@ -516,6 +516,10 @@ def test_spgemm_entries_sorted_in_lds(be):
     pc.check_spgemm_sorted_emission(be)
 
 
+def test_spgemm_four_rows_per_wave(be):
+    pc.check_spgemm_quad_rows(be)
+
+
 def test_row_partitioned_spgemm_through_the_c_abi(be):
     """kkamd_dist_spgemm_* on the GPU: work-balanced partition from the device, the four slabs of C computed one after the other
     concatenate to the oracle's product (R-MAT scale 12), numeric reuse on every slab, a slab of the wrong height refused"""
