@@ -193,8 +193,8 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *          "spgemm_emit_sort" (1: entries(C) of rows with more than 256 entries out of at most 2048 products are sorted in LDS, eight rows
  *          per CU; 0: they take the bitmap kernel like every other dense row), "spgemm_col_quads" (0 / 4 / 8: 16-byte loads of entries(B) per
  *          work-item and step in the bitmap kernels), "spgemm_val_steps" (1..3 steps of a window's product walk in flight in the flat
- *          value kernel; measured neutral), "spgemm_quad_rows" (wave-per-row kernels with four rows per wave, 16 lanes each: 1 = when every row
- *          of the product has at most 64 products (symbolic) / 32 entries (numeric) -- stencil and multigrid products --, 2 = always, 0 = never).
+ *          value kernel; measured neutral), "spgemm_quad_rows" (wave-per-row kernels with four rows per wave, 16 lanes each: 1 = for the rows
+ *          with at most 64 products (symbolic) / 32 entries (numeric) -- stencil and multigrid products --, 2 = for every row of the wave bin, 0 = never).
  * Knobs that switch parts of kernels OFF ("ablate", "lds_pad_kb", "struct_lds_pad_kb", "spgemm_debug") exist only in the
  * measurement build libkkamd_ablate.so (csrc: make ablate, -DKK_ABLATE); libkkamd.so answers KKAMD_ERR_INVALID_ARG. */
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value);

@@ -109,9 +109,9 @@ struct SpgemmTuning {
                                   // R-MAT scale 20 numeric / reuse: 0: 221.7 / 184.7 ms, 8192: 217.6 / 180.7, 32768: 213.8 / 176.6, 65536: 211.1 / 174.6, 131072: 216.4 / 179.5, all: 219.0 / 182.3)
   int val_tiny_cnt   = 32768;     // ... and at most this many (and kValLaTiny entries in the A row) the lightest one: 128 work-items, 1024-slot table (0 = none;
                                   // R-MAT scale 20 numeric / reuse with the light shape at 65536: 0: 212.0 / 175.2 ms, 2048: 210.0 / 172.8, 8192: 208.4 / 171.6, 32768: 207.5 / 170.9)
-  int quad_rows      = 1;         // wave-per-row kernels with four rows of the list per wave, 16 lanes each: 1 = when EVERY row of the product is small (at most kQuadFlops products /
-                                  // kQuadNnz entries; 7-pt FD 150^3: symbolic 3.54 -> 1.94 ms, numeric 4.24 -> 1.97), 2 = always (waves with a larger row do their four rows one after
-                                  // the other: 27-pt FE 100^3 numeric 4.04 -> 5.03 ms, which is why 1 is the default), 0 = never
+  int quad_rows      = 1;         // wave-per-row kernels with four rows of the list per wave, 16 lanes each: 1 = for the rows of the wave bin with at most kQuadFlops products /
+                                  // kQuadNnz entries (the bin's list is split when it mixes sizes; 7-pt FD 150^3: symbolic 3.54 -> 1.94 ms, numeric 4.24 -> 1.97), 2 = for every row of the
+                                  // bin (waves with a larger row do their four rows one after the other: 27-pt FE 100^3 numeric 4.04 -> 5.03 ms, which is why 1 is the default), 0 = never
   int emit_sort      = 1;         // entries(C) of the dense-bin rows with at most kEmitSortCap products: sorted in LDS, 256 work-items per row (0 = the bitmap kernel)
   int val_steps      = 1;         // steps of a window's product walk a work-item of the flat value kernel keeps in flight (1..3)
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
@@ -2129,6 +2129,7 @@ struct kkamd_spgemm_handle {
   int32_t* d_hub_items = nullptr; int64_t n_hub_items = 0;      // (index, pass) pairs of the hub rows: one workgroup each
   int32_t* d_hub_multi = nullptr; int64_t n_hub_multi = 0;      // indices of the hub rows with several passes (zeroed before the launch)
   bool hub_from_mid = false;       // the dense bin is cut [<= kValLa | <= kValLa2 | rest]: flat kernel twice, hub kernel for the rest
+  int64_t n_wave_quad = 0;         // leading rows of the numeric wave bin that share waves four at a time (at most kQuadNnz entries each)
   int64_t n_dense_tiny = 0;        // leading rows of the dense bin that take the flat value kernel's lightest shape,
   int64_t n_dense_small = 0;       // rows after them that take its light shape (few entries in C and in A)
   int64_t n_dense_lds = 0;         // leading rows of the dense bin taken by the LDS value kernel,
@@ -2272,6 +2273,25 @@ static void free_bitmap_store(kkamd_spgemm_handle* h) {
 }
 static double words_mb(int words) { return (double)words * 8.0 / 1048576.0; }
 
+// the rows of list[0 .. n) whose size (sizes[row]) is at most cnt_max are moved to its front (the others follow in reverse order); *n_small = how many
+template <class OffT>
+static int split_list_by_size(int32_t* list, int64_t n, const OffT* rmA, const int64_t* sizes, int64_t cnt_max, int64_t* n_small, hipStream_t st) {
+  *n_small = 0;
+  if (n <= 0) return KKAMD_OK;
+  DevBuf tmp_b, cnt_b;
+  unsigned long long h_cnt[2] = {0, 0};
+  KK_HIP(tmp_b.alloc(sizeof(int32_t) * (size_t)n));
+  KK_HIP(cnt_b.alloc(2 * sizeof(unsigned long long)));
+  int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
+  KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
+  KK_HIP(hipMemcpyAsync(d_tmp, list, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  KK_LAUNCH((spgemm_split_small_kernel<OffT>), (unsigned)ceil_div(n, kBlock), kBlock, 0, st, n, (const int32_t*)d_tmp, rmA, sizes, (int64_t)INT64_MAX, cnt_max, list, d_cnt);
+  KK_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  *n_small = (int64_t)h_cnt[0];
+  return KKAMD_OK;
+}
+
 template <class OffT>
 static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t k, const void* rmA_, const int32_t* entA,
                           const void* rmB_, const int32_t* entB, void* rmC_, int64_t nnzB, int64_t* c_nnz, hipStream_t st) {
@@ -2370,12 +2390,20 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     }
   } else {
     if ((rc = make_bins(m, h->d_sizes, k, g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
-    if (nb(1) && (g_spgemm.quad_rows == 2 || (g_spgemm.quad_rows == 1 && h->max_row_flops <= (int64_t)kQuadFlops)))
-      KK_LAUNCH((spgemm_sym_quad_kernel<OffT>), (unsigned)ceil_div(nb(1), 4 * (kBlock / 64)), kBlock, 0, st, nb(1),
-                (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
-    else if (nb(1))
-      KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
-                (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
+    if (nb(1)) {
+      // the rows of this bin with at most kQuadFlops products share waves four at a time; when the product mixes them with larger rows
+      // the bin's list is split first (small rows to the front)
+      int32_t* wlist = h->d_perm + off.off[1];
+      int64_t nq = 0;
+      if (g_spgemm.quad_rows == 2 || (g_spgemm.quad_rows == 1 && h->max_row_flops <= (int64_t)kQuadFlops)) nq = nb(1);
+      else if (g_spgemm.quad_rows == 1 && (rc = split_list_by_size<OffT>(wlist, nb(1), rmA, (const int64_t*)h->d_sizes, (int64_t)kQuadFlops, &nq, st))) return rc;
+      if (nq)
+        KK_LAUNCH((spgemm_sym_quad_kernel<OffT>), (unsigned)ceil_div(nq, 4 * (kBlock / 64)), kBlock, 0, st, nq,
+                  (const int32_t*)wlist, rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
+      if (nb(1) - nq)
+        KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1) - nq, kBlock / 64), kBlock, 0, st, nb(1) - nq,
+                  (const int32_t*)(wlist + nq), rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
+    }
     if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
                          (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
     if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
@@ -2532,6 +2560,14 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         h->n_dense_tiny = got[0]; h->n_dense_small = got[1];
       }
     }
+    h->n_wave_quad = 0;
+    {
+      const int64_t nw = h->num_off.off[2] - h->num_off.off[1];
+      if (nw > 0 && !dense_alg) {
+        if (g_spgemm.quad_rows == 2 || (g_spgemm.quad_rows == 1 && h->max_row_nnz > 0 && h->max_row_nnz <= (int64_t)kQuadNnz)) h->n_wave_quad = nw;
+        else if (g_spgemm.quad_rows == 1 && (rc = split_list_by_size<OffT>(h->d_perm + h->num_off.off[1], nw, rmA, (const int64_t*)h->d_sizes, (int64_t)kQuadNnz, &h->n_wave_quad, st))) return rc;
+      }
+    }
     h->numeric_bins_ready = true;
     if (h->d_emit_perm) { (void)hipFree(h->d_emit_perm); h->d_emit_perm = nullptr; h->n_emit_stored = 0; }
     if (h->d_emit_perm2) { (void)hipFree(h->d_emit_perm2); h->d_emit_perm2 = nullptr; h->n_emit_pooled = 0; }
@@ -2547,12 +2583,15 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
            "(LDS value windows %lld, LDS hub windows %lld, HBM accumulator %lld)\n", h->algorithm == 1 ? "SPGEMM_KK_DENSE" : "SPGEMM_KK",
            (long long)nb(1), (long long)nb(2), (long long)nb(3), (long long)nb(4), (long long)h->n_dense_lds, (long long)h->n_dense_hub_lds,
            (long long)(nb(4) - h->n_dense_lds - h->n_dense_hub_lds));
-  if (nb(1) && (g_spgemm.quad_rows == 2 || (g_spgemm.quad_rows == 1 && h->max_row_nnz > 0 && h->max_row_nnz <= (int64_t)kQuadNnz)))
-    KK_LAUNCH((spgemm_num_quad_kernel<OffT, VT>), (unsigned)ceil_div(nb(1), 4 * (kBlock / 64)), kBlock, 0, st, nb(1),
-              (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC);
-  else if (nb(1))
-    KK_LAUNCH((spgemm_num_wave_kernel<OffT, VT>), (unsigned)ceil_div(nb(1), kBlock / 64), kBlock, 0, st, nb(1),
-              (const int32_t*)(h->d_perm + off.off[1]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
+  if (nb(1)) {
+    const int64_t nq = h->n_wave_quad < nb(1) ? h->n_wave_quad : nb(1);
+    const int32_t* wlist = h->d_perm + off.off[1];
+    if (nq)
+      KK_LAUNCH((spgemm_num_quad_kernel<OffT, VT>), (unsigned)ceil_div(nq, 4 * (kBlock / 64)), kBlock, 0, st, nq, wlist, rmA, entA, valA, rmB, entB, valB, rmC, entC, valC);
+    if (nb(1) - nq)
+      KK_LAUNCH((spgemm_num_wave_kernel<OffT, VT>), (unsigned)ceil_div(nb(1) - nq, kBlock / 64), kBlock, 0, st, nb(1) - nq, wlist + nq, rmA, entA, valA, rmB, entB, valB,
+                rmC, entC, valC, sg);
+  }
   if (nb(2)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkS>), (unsigned)nb(2), kBlock, 0, st, nb(2),
                        (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, valA, rmB, entB, valB, rmC, entC, valC, sg);
   if (nb(3)) KK_LAUNCH((spgemm_num_block_kernel<OffT, VT, kNumBlkL>), (unsigned)nb(3), kBlock, 0, st, nb(3),
