@@ -387,8 +387,11 @@ def main():
     x_shard = torch.randint(-20, 20, (rows_per_rank,), device=dev, generator=g).double()
     y_shard = torch.randint(-20, 20, (rows_per_rank,), device=dev, generator=g).double()
     alpha, beta = 1.0, args.beta
+    # N = 1 with a named exchange: the one rank still goes through the row-partitioned operator and the library's own RCCL transport
+    # (a one-rank communicator: ncclAllGather in place / groups without peers) -- the N-rank code path and its keys on one GPU
+    use_dist = world > 1 or (args.exchange != "auto" and not emu)
 
-    if world == 1:
+    if not use_dist:
         handle = kk.SPMVHandle(args.algo)
         for kv in args.knob:
             k, v = kv.split("="); handle.set(k, int(v))
@@ -402,7 +405,7 @@ def main():
         for kv in args.knob:                       # the slab plans are created inside the library: knobs go in as defaults
             k, v = kv.split("="); kk._capi.check(lib_, lib_.kkamd_set_default(k.encode(), int(v)))
         op = DistSpmv(A, offsets, rank, algo=args.algo, exchange=args.exchange, overlap=not args.no_overlap,
-                      to_backend=tb if emu else None)
+                      to_backend=tb if emu else None, transport="rccl" if world == 1 else None)
         xl = op.x_local(); xl.copy_(x_shard); x_shard = xl      # x lives in the operator's window: no per-step copy
         def step(ev0, ev1):
             op.apply(alpha, x_shard, beta, y_shard, events=(ev0, ev1))
@@ -446,7 +449,10 @@ def main():
 
     # ---- N > 1: what each exchange costs (outside the timed region above): halo and all-gather steps, and the exchange alone ----
     xchg = None
-    if world > 1:
+    def all_reduce_(t, how):
+        if dist is not None: dist.all_reduce(t, op=how)
+    RED_MIN, RED_MAX = (dist.ReduceOp.MIN, dist.ReduceOp.MAX) if dist is not None else (None, None)
+    if use_dist:
         def timed(fn, n=max(3, min(args.steps, 20))):
             fn(); barrier()
             t_ = time.perf_counter()
@@ -462,12 +468,13 @@ def main():
             if other in ops: continue
             o_new, ok_ = None, 1.0
             try:
-                o_new = DistSpmv(A, offsets, rank, algo=args.algo, exchange=other, overlap=not args.no_overlap, to_backend=tb if emu else None)
+                o_new = DistSpmv(A, offsets, rank, algo=args.algo, exchange=other, overlap=not args.no_overlap, to_backend=tb if emu else None,
+                                 transport="rccl" if world == 1 else None)
             except Exception as e:                 # e.g. not enough memory for another operator: report what there is
                 ok_ = 0.0
                 xchg.setdefault("notes", []).append("no %s operator on rank %d: %s" % (other, rank, str(e)[:120]))
             okt = torch.tensor([ok_], device=dev, dtype=torch.float64)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)          # an operator only counts when EVERY rank has it (else the collectives would not match)
+            all_reduce_(okt, RED_MIN)          # an operator only counts when EVERY rank has it (else the collectives would not match)
             if okt.item() == 1.0: ops[other] = o_new
             else:
                 del o_new
@@ -479,14 +486,14 @@ def main():
             t_x = timed(lambda: o.apply(alpha, xs_, beta, y_shard, what=1))
             t_l = timed(lambda: o.apply(alpha, xs_, beta, y_shard, what=2))
             tt = torch.tensor([t_step, t_x, t_l], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            all_reduce_(tt, RED_MAX)
             xchg[name] = {"step_ms": round(tt[0].item(), 5), "exchange_only_ms": round(tt[1].item(), 5), "local_spmv_only_ms": round(tt[2].item(), 5),
                           "bytes_received_per_gpu": o.exchange_bytes, "aggregate_GFLOPs": round(2.0 * nnz_global / (tt[0].item() * 1e-3) / 1e9, 1)}
         ops.clear()
 
     # ---- sanity inside the bench: A*1 over the slab must be the row-sum vector (0 interior, 1 boundary) ----
     chk = torch.empty(rows_per_rank, dtype=torch.float64, device=dev)
-    if world == 1:
+    if not use_dist:
         ones = torch.ones(nrows_global, dtype=torch.float64, device=dev)
         kk.spmv(handle, "N", 1.0, A, tb(ones), 0.0, tb(chk))
     else:
@@ -519,7 +526,7 @@ def main():
                        "partition": ("1-D row slabs; x exchange = %s over RCCL/xGMI, %d bytes received per GPU per SpMV%s"
                                      % (op.exchange_mode, op.exchange_bytes,
                                         "; %d interior rows overlap the exchange" % op.interior_rows if op.query("parts") > 1 else ""))
-                                    if world > 1 else "single GPU",
+                                    if use_dist else "single GPU",
                        "knobs": args.knob},
             "achieved_hbm_GBps_per_gpu": round(achieved, 1),
             "spmv_kernel_ms": round(kern_ms, 5),
@@ -533,7 +540,7 @@ def main():
         # What the plan really streams: the analysis replaces the 4-byte column indices by 16-bit codes or, on locally
         # Toeplitz tiles, by one small record per tile; "achieved" / "frac" stay on the CRS algorithmic bytes.
         try:
-            h_ = handle if world == 1 else None
+            h_ = handle if not use_dist else None
             if h_ is not None and h_.query("window_codes"):
                 tile_ = h_.query("tile"); tiles_ = h_.query("tiles")
                 pat_, code_, plain_ = h_.query("pattern_tiles"), h_.query("code_tiles"), h_.query("plain_tiles")
@@ -569,7 +576,7 @@ def main():
         # Memory-side traffic comes from rocprofv3 PMC passes of this same command (it cannot be counted live); the file is
         # stamped with the hash of the kernel sources it was measured on and is IGNORED when that differs from the sources here.
         out["roofline"]["kernel_source_sha"] = kernel_source_sha()
-        if world == 1 and not args.n and not args.knob and os.path.exists(PMC_FILE):
+        if not use_dist and not args.n and not args.knob and os.path.exists(PMC_FILE):
             try:
                 d = json.load(open(PMC_FILE))
                 if d.get("kernel_source_sha") != out["roofline"]["kernel_source_sha"]:
@@ -600,7 +607,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         # ---- the other SURVEY 8(d) metrics, driver-visible: config 3 (SpMV_MV) and config 4 (SpGEMM), each under its share of the cap
-        if world == 1 and not emu and not args.n and args.extras_seconds > 0:
+        if not use_dist and not emu and not args.n and args.extras_seconds > 0:
             t_x = time.perf_counter()
             del x_shard, y_shard, chk
             try:

@@ -249,8 +249,16 @@ typedef struct {
 } kkamd_transport_t;
 
 int kkamd_dist_unique_id(void* id128);
+/* Preflight of the built-in RCCL transport on the calling rank alone (no counterpart in the reference, which has no distributed
+ * layer: cmake/fake_tribits.cmake:210 runs every test with NUM_MPI_PROCS 1): binds librccl, forms a ONE-rank communicator and runs
+ * every entry point the N-rank exchanges use -- ncclAllGather in place and out of place, a group of ncclSend / ncclRecv to itself,
+ * an empty group -- on `bytes` of device data that are compared afterwards.  A binding or ABI problem shows as an error code here
+ * instead of a hang in the first exchange of an N-rank job. */
+int kkamd_dist_transport_selftest(int64_t bytes, kkamd_stream_t stream);
+/* world == 1 with id128 given and exchange != 0: the one-rank job still forms its RCCL communicator and runs the forced exchange
+ * through it (the in-place ncclAllGather of one shard; groups with no peers) -- the N-rank code path on one GPU. */
 int kkamd_dist_spmv_create(kkamd_dist_spmv_t** op, const kkamd_crs_t* A_local, const int64_t* row_offsets /* host, world + 1 */,
-                           int world, int rank, const void* id128 /* NULL with a transport or world == 1 */,
+                           int world, int rank, const void* id128 /* NULL with a transport; optional when world == 1 */,
                            const kkamd_transport_t* transport /* NULL = RCCL */, int algorithm, int exchange, int overlap,
                            int vector_type, kkamd_stream_t stream);
 int kkamd_dist_spmv_destroy(kkamd_dist_spmv_t* op);

@@ -12,7 +12,7 @@ EXPORTS = [
     "kkamd_spmv", "kkamd_spmv_mv", "kkamd_spmv_struct", "kkamd_sort_and_merge", "kkamd_transpose", "kkamd_spmv_plan_set", "kkamd_spmv_plan_values_changed", "kkamd_spmv_plan_query", "kkamd_spmv_plan_export", "kkamd_set_default", "kkamd_spgemm_create",
     "kkamd_spgemm_destroy", "kkamd_spgemm_set", "kkamd_spgemm_symbolic", "kkamd_spgemm_numeric", "kkamd_spgemm_get", "kkamd_spgemm_get_hint", "kkamd_sort_crs",
     "kkamd_exclusive_scan", "kkamd_gen_laplace", "kkamd_gen_laplace_rows", "kkamd_bench_read",
-    "kkamd_dist_unique_id", "kkamd_dist_spmv_create", "kkamd_dist_spmv_destroy", "kkamd_dist_spmv_x_local", "kkamd_dist_spmv_apply",
+    "kkamd_dist_unique_id", "kkamd_dist_transport_selftest", "kkamd_dist_spmv_create", "kkamd_dist_spmv_destroy", "kkamd_dist_spmv_x_local", "kkamd_dist_spmv_apply",
     "kkamd_dist_spmv_query",
     "kkamd_dist_spgemm_partition", "kkamd_dist_spgemm_create", "kkamd_dist_spgemm_destroy", "kkamd_dist_spgemm_handle", "kkamd_dist_spgemm_symbolic",
     "kkamd_dist_spgemm_numeric", "kkamd_dist_spgemm_query",
@@ -76,6 +76,7 @@ def bind(lib):
     lib.kkamd_gen_laplace_rows.argtypes = [ci, ci, i64, i64, i64, i64, i64, vp, vp, vp, ci, ci, C.POINTER(i64), vp]
     lib.kkamd_bench_read.argtypes = [vp, i64, ci, ci, ci, vp, vp]
     lib.kkamd_dist_unique_id.argtypes = [vp]
+    lib.kkamd_dist_transport_selftest.argtypes = [i64, vp]
     lib.kkamd_dist_spmv_create.argtypes = [C.POINTER(vp), C.POINTER(CrsDesc), C.POINTER(i64), ci, ci, vp, C.POINTER(Transport), ci, ci, ci, ci, vp]
     lib.kkamd_dist_spmv_destroy.argtypes = [vp]
     lib.kkamd_dist_spmv_x_local.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

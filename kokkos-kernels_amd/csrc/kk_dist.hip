@@ -228,7 +228,9 @@ static int dist_setup(kkamd_dist_spmv* op, int exchange, int overlap, hipStream_
   std::vector<OffT> h_rm((size_t)op->A.num_rows + 1);
   KK_HIP(hipMemcpyAsync(h_rm.data(), op->A.d_row_map, sizeof(OffT) * h_rm.size(), hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
-  if (world == 1) { op->mode = 0; return dist_add_part<OffT>(op, 0, op->A.num_rows, h_rm, st); }
+  // one rank: nothing to exchange -- unless the caller asked for the built-in RCCL transport with a forced exchange (id128 given,
+  // world = 1): then the one-rank communicator runs the same calls an N-rank job makes (ncclAllGather in place; a group with no peers)
+  if (world == 1 && !(op->own_comm && exchange != 0)) { op->mode = 0; return dist_add_part<OffT>(op, 0, op->A.num_rows, h_rm, st); }
   // column range of the slab, exchanged once: every rank learns what every rank needs
   DevBuf mm, all;
   KK_HIP(mm.alloc(2 * sizeof(int64_t))); KK_HIP(all.alloc(2 * sizeof(int64_t) * (size_t)world));
@@ -437,6 +439,51 @@ int kkamd_dist_unique_id(void* id128) {
   return KKAMD_OK;
 }
 
+// Preflight of the built-in transport on ONE rank: binds librccl, forms a one-rank communicator and runs every entry point the
+// N-rank exchanges use -- ncclAllGather in place, and a group of ncclSend / ncclRecv to itself -- on `bytes` of device data that are
+// checked afterwards.  A job can call it on every rank before the first operator is created: a binding or ABI problem then shows
+// as an error code here, not as a hang in the first exchange.
+int kkamd_dist_transport_selftest(int64_t bytes, kkamd_stream_t stream) {
+  if (bytes < 1) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_transport_selftest: bytes must be positive");
+#ifdef KK_EMU
+  (void)stream;
+  return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_dist_transport_selftest: RCCL is not available under the emulator");
+#else
+  if (!kk::rccl().ok) return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_dist: librccl.so.1 could not be loaded");
+  hipStream_t st = kk::to_hip(stream);
+  kk::Rccl::UniqueId id;
+  KK_NCCL(kk::rccl().GetUniqueId(&id));
+  kk::RcclCtx ctx; ctx.world = 1; ctx.rank = 0;
+  KK_NCCL(kk::rccl().CommInitRank(&ctx.comm, 1, id, 0));
+  struct Guard { kk::RcclCtx& c; ~Guard() { if (c.comm) (void)kk::rccl().CommDestroy(c.comm); } } guard{ctx};
+  kk::DevBuf a, b;
+  KK_HIP(a.alloc((size_t)bytes)); KK_HIP(b.alloc((size_t)bytes));
+  std::vector<unsigned char> h((size_t)bytes), back((size_t)bytes);
+  for (int64_t i = 0; i < bytes; ++i) h[(size_t)i] = (unsigned char)((i * 131 + 7) & 0xff);
+  KK_HIP(hipMemcpyAsync(a.p, h.data(), (size_t)bytes, hipMemcpyHostToDevice, st));
+  KK_HIP(hipMemsetAsync(b.p, 0, (size_t)bytes, st));
+  // 1. the all-gather of one rank, in place (send == recv + rank * bytes), then out of place
+  int rc = kk::rccl_all_gather(&ctx, a.p, a.p, bytes, reinterpret_cast<kkamd_stream_t>(st));
+  if (rc) return rc;
+  if ((rc = kk::rccl_all_gather(&ctx, a.p, b.p, bytes, reinterpret_cast<kkamd_stream_t>(st)))) return rc;
+  KK_HIP(hipMemcpyAsync(back.data(), b.p, (size_t)bytes, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  if (std::memcmp(h.data(), back.data(), (size_t)bytes) != 0) return kk::fail(KKAMD_ERR_HIP, "kkamd_dist_transport_selftest: ncclAllGather returned other bytes than it was given");
+  // 2. a group with one send and one receive, peer = this rank (what the halo exchanges do between neighbours)
+  KK_HIP(hipMemsetAsync(b.p, 0, (size_t)bytes, st));
+  const void* sp[1] = {a.p}; void* rp[1] = {b.p}; const int64_t nb[1] = {bytes}; const int peer[1] = {0};
+  if ((rc = kk::rccl_exchange(&ctx, 1, sp, nb, peer, 1, rp, nb, peer, reinterpret_cast<kkamd_stream_t>(st)))) return rc;
+  // 3. an empty group (a rank whose slab needs nothing from anybody)
+  if ((rc = kk::rccl_exchange(&ctx, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, reinterpret_cast<kkamd_stream_t>(st)))) return rc;
+  KK_HIP(hipMemcpyAsync(back.data(), b.p, (size_t)bytes, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  if (std::memcmp(h.data(), back.data(), (size_t)bytes) != 0) return kk::fail(KKAMD_ERR_HIP, "kkamd_dist_transport_selftest: the grouped ncclSend / ncclRecv to self returned other bytes than were sent");
+  const int e = kk::rccl().CommDestroy(ctx.comm); ctx.comm = nullptr;
+  if (e != 0) return kk::fail(KKAMD_ERR_HIP, "ncclCommDestroy failed: %s", kk::rccl().GetErrorString(e));
+  return KKAMD_OK;
+#endif
+}
+
 int kkamd_dist_spmv_create(kkamd_dist_spmv_t** out, const kkamd_crs_t* A_local, const int64_t* row_offsets, int world, int rank,
                            const void* id128, const kkamd_transport_t* transport, int algorithm, int exchange, int overlap,
                            int vector_type, kkamd_stream_t stream) {
@@ -462,7 +509,7 @@ int kkamd_dist_spmv_create(kkamd_dist_spmv_t** out, const kkamd_crs_t* A_local, 
   if (transport) {
     if (!transport->all_gather || !transport->exchange) return bail(kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: incomplete transport"));
     op->tr = *transport;
-  } else if (world > 1) {
+  } else if (world > 1 || (id128 && exchange != 0)) {
     if (!kk::rccl().ok) return bail(kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_dist: librccl.so.1 could not be loaded"));
     if (!id128) return bail(kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: the built-in RCCL transport needs the unique id of kkamd_dist_unique_id"));
     kk::Rccl::UniqueId id; std::memcpy(id.internal, id128, 128);
@@ -475,7 +522,7 @@ int kkamd_dist_spmv_create(kkamd_dist_spmv_t** out, const kkamd_crs_t* A_local, 
   if (hipMalloc(&op->d_x_full, xbytes) != hipSuccess) return bail(kk::fail(KKAMD_ERR_ALLOC, "kkamd_dist_spmv_create: out of device memory for x (%zu bytes)", xbytes));
   // zero once: entries outside the slab's column range are never read, but must not be garbage NaNs for beta = 0 sanity checks
   if (hipMemsetAsync(op->d_x_full, 0, xbytes, st) != hipSuccess) return bail(kk::fail(KKAMD_ERR_HIP, "hipMemsetAsync failed"));
-  if (world > 1) {
+  if (world > 1 || op->own_comm) {
     if (hipStreamCreateWithFlags(&op->comm_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&op->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&op->ev_done, hipEventDisableTiming) != hipSuccess)
       return bail(kk::fail(KKAMD_ERR_HIP, "kkamd_dist_spmv_create: could not create the communication stream"));

@@ -119,6 +119,8 @@ struct SpgemmTuning {
   int col_quads      = 4;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads, 4 or 8 per work-item and step (0 = one 4-byte load per product)
   int val_hub_flat   = 0;         // 1 = A rows above kValLa through the flat value kernel too (measured slower, see numeric_typed)
   int val_kernel     = 2;         // dense rows with short A rows: 2 = flat walk with the lists cut per window group (default), 1 = wave-per-list streaming
+  int pool_keep      = 0;         // 1 = the process-wide store of bitmaps / entry lists outlives the last handle (hosts that run large products back to back,
+                                  // one handle at a time: an allocation of GBs per product is not free); 0 = destroying the last handle returns it to the device
 };
 static SpgemmTuning g_spgemm;
 
@@ -1193,13 +1195,17 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_emit_bitmap_kernel(const i
   if (staged) (void)emit_bits_by_wave_staged(store + (size_t)row_slot[row] * (size_t)words, words, 0, (int64_t)rmC[row], entC, s_wave, s_stage[threadIdx.x >> 6]);
   else (void)emit_bits_by_wave(store + (size_t)row_slot[row] * (size_t)words, words, 0, (int64_t)rmC[row], entC, s_wave);
 }
-// rows of a bin whose size (products) reaches thr
+// rows of a bin whose size (products) reaches thr -> count[0]; count[1] = a bound on the ENTRIES of all rows of the bin (a row has at
+// most as many entries as products, and at most kcols): what the entry lists kept for the numeric phase can need at most
 __global__ __launch_bounds__(kBlock) void spgemm_count_ge_kernel(int64_t n, const int32_t* __restrict__ perm, const int64_t* __restrict__ sizes, int64_t thr,
-                                                                unsigned long long* __restrict__ count) {
+                                                                int64_t kcols, unsigned long long* __restrict__ count) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool q = i < n && sizes[perm[i]] >= thr;
+  const int64_t sz = i < n ? sizes[perm[i]] : 0;
+  const bool q = i < n && sz >= thr;
   const kk_u64 m = __ballot(q);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+  const long long bound = group_sum((long long)(sz < kcols ? sz : kcols), 64);
+  if ((threadIdx.x & 63) == 0 && bound) atomicAdd(count + 1, (unsigned long long)bound);
 }
 // rows of the dense bin: those with a stored bitmap first, the others from the end
 template <class OffT>
@@ -2222,9 +2228,11 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
 // such a buffer is not free: every third or so symbolic phase took 1.3-1.6 s instead of 66 ms with an allocation per handle.  The
 // buffer is therefore kept in a process-wide pool between uses (one user at a time; a second concurrent handle allocates its own);
 // kkamd_release_scratch() gives it back.
-struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; std::mutex m; };
-// kkamd_release_scratch() gives the buffer back at any time; a host that never calls it keeps at most one store (an eighth of the HBM
-// that was free when it was sized) until the process ends.  Kokkos-based hosts: INTEGRATION.md registers kkamd_release_scratch with
+struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; int live_handles = 0; std::mutex m; };
+// Destroying the LAST live handle returns the buffer to the device (knob "spgemm_pool_keep" 1: it outlives the handles, for hosts that run
+// large products back to back one handle at a time); kkamd_release_scratch() gives it back at any time.  Its size: the bitmaps of the rows
+// that can qualify (at most an eighth of the HBM that was free when it was sized) plus the entry lists the other dense rows can need (at
+// most a tenth).  Kokkos-based hosts: INTEGRATION.md registers kkamd_release_scratch with
 // Kokkos::push_finalize_hook; the C++ drop-in's Kokkos::finalize() calls it.
 static BmPool& bm_pool() { static BmPool pool; return pool; }
 int release_bitmap_pool();
@@ -2421,24 +2429,29 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
           { BmPool& pool = bm_pool(); std::lock_guard<std::mutex> g(pool.m); int dev_ = -1;
             if (!pool.in_use && pool.p && hipGetDevice(&dev_) == hipSuccess && dev_ == pool.device) pooled = pool.bytes; }
           int64_t cap = (int64_t)((free_b + pooled) / 8) / ((int64_t)words * 8);
+          unsigned long long list_bound = ~0ull;                   // entries the lists of the bin's rows can hold between them
           {
             // no more slots than rows that can qualify: a row's products bound its entries, so only rows of the bin with at least
             // k / 32 products can have k / 32 entries
             DevBuf qc;
-            unsigned long long h_q = 0;
-            if (qc.alloc(sizeof(unsigned long long)) == hipSuccess && hipMemsetAsync(qc.p, 0, sizeof(unsigned long long), st) == hipSuccess) {
+            unsigned long long h_qq[2] = {0, 0};
+            if (qc.alloc(2 * sizeof(unsigned long long)) == hipSuccess && hipMemsetAsync(qc.p, 0, 2 * sizeof(unsigned long long), st) == hipSuccess) {
               unsigned long long* d_q = qc.as<unsigned long long>(); const int32_t* d_bin = h->d_perm + off.off[4]; const int64_t* d_fl = h->d_sizes;
-              KK_LAUNCH(spgemm_count_ge_kernel, (unsigned)ceil_div(nb(4), kBlock), kBlock, 0, st, nb(4), d_bin, d_fl, k / 32, d_q);
-              if (hipMemcpyAsync(&h_q, d_q, sizeof h_q, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); h_q = (unsigned long long)nb(4); }
-            } else { (void)hipGetLastError(); h_q = (unsigned long long)nb(4); }
-            if (cap > (int64_t)h_q) cap = (int64_t)h_q;
+              KK_LAUNCH(spgemm_count_ge_kernel, (unsigned)ceil_div(nb(4), kBlock), kBlock, 0, st, nb(4), d_bin, d_fl, k / 32, k, d_q);
+              if (hipMemcpyAsync(h_qq, d_q, sizeof h_qq, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); h_qq[0] = (unsigned long long)nb(4); h_qq[1] = ~0ull; }
+            } else { (void)hipGetLastError(); h_qq[0] = (unsigned long long)nb(4); h_qq[1] = ~0ull; }
+            if (cap > (int64_t)h_qq[0]) cap = (int64_t)h_qq[0];
+            list_bound = h_qq[1];
           }
           if (cap > nb(4)) cap = nb(4);
-          // behind the bitmaps, room for the ENTRY LISTS of the rows whose bitmap is not kept: a tenth of the free HBM (the caller still
-          // has entries(C) and values(C) to allocate between the phases)
+          // behind the bitmaps, room for the ENTRY LISTS of the rows whose bitmap is not kept: what those lists can hold at most (4 bytes
+          // per product of the bin's rows, a row capped at k), but no more than a tenth of the free HBM (the caller still has entries(C)
+          // and values(C) to allocate between the phases)
           const size_t store_need = cap >= 1 ? (size_t)cap * (size_t)words * 8 : 0;
-          const size_t pool_need = g_spgemm.keep_lists ? (((size_t)((double)(free_b + pooled) / 10.0)) & ~(size_t)255) : 0;
-          const size_t got = cap >= 1 ? take_bitmap_store(h, store_need + pool_need) : 0;
+          size_t pool_need = g_spgemm.keep_lists ? (((size_t)((double)(free_b + pooled) / 10.0)) & ~(size_t)255) : 0;
+          if (list_bound != ~0ull && (unsigned long long)pool_need / 4 > list_bound) pool_need = ((size_t)list_bound * 4 + 255) & ~(size_t)255;
+          size_t got = cap >= 1 ? take_bitmap_store(h, store_need + pool_need) : 0;
+          if (got == 0 && cap >= 1 && pool_need > 0) got = take_bitmap_store(h, store_need);      // no room for both: the bitmaps alone
           const size_t got_store = got < store_need ? got : store_need;
           cap = (int64_t)(got_store / ((size_t)words * 8));
           const int64_t pool_cap = (int64_t)((got - got_store) / sizeof(int32_t));
@@ -2859,6 +2872,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
   else if (k == "spgemm_val_tiny_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_tiny_cnt: %d is negative", value); g_spgemm.val_tiny_cnt = value; }
   else if (k == "spgemm_emit_sort") g_spgemm.emit_sort = value != 0;
+  else if (k == "spgemm_pool_keep") g_spgemm.pool_keep = value != 0;
   else if (k == "spgemm_quad_rows") { if (value < 0 || value > 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_quad_rows: %d is not 0, 1 or 2", value); g_spgemm.quad_rows = value; }
   else if (k == "spgemm_val_steps") { if (value < 1 || value > 3) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_steps: %d is not 1, 2 or 3", value); g_spgemm.val_steps = value; }
   else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
@@ -2880,6 +2894,7 @@ extern "C" {
 int kkamd_spgemm_create(kkamd_spgemm_handle_t** handle) {
   if (!handle) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_create: null output pointer");
   *handle = new (std::nothrow) kkamd_spgemm_handle();
+  if (*handle) { kk::BmPool& pool = kk::bm_pool(); std::lock_guard<std::mutex> g(pool.m); ++pool.live_handles; }
   return *handle ? KKAMD_OK : kk::fail(KKAMD_ERR_ALLOC, "kkamd_spgemm_create: out of host memory");
 }
 
@@ -2892,6 +2907,10 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (h->d_hub_items) (void)hipFree(h->d_hub_items);
   if (h->d_hub_multi) (void)hipFree(h->d_hub_multi);
   delete h;
+  // the last handle gone: the pooled store (GBs) goes back to the device unless the host asked to keep it ("spgemm_pool_keep")
+  bool last = false;
+  { kk::BmPool& pool = kk::bm_pool(); std::lock_guard<std::mutex> g(pool.m); last = --pool.live_handles <= 0; if (pool.live_handles < 0) pool.live_handles = 0; }
+  if (last && !kk::g_spgemm.pool_keep) (void)kk::release_bitmap_pool();
   return KKAMD_OK;
 }
 

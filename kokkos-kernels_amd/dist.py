@@ -216,6 +216,11 @@ class _DeviceView:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+def transport_selftest(backend, nbytes=1 << 20):
+    """preflight of the library's built-in RCCL transport on this rank alone (kkamd_dist_transport_selftest)"""
+    check(backend.lib, backend.lib.kkamd_dist_transport_selftest(int(nbytes), backend.stream()))
+
+
 class DistSpmv:
     def __init__(self, A_local, offsets, rank, group=None, algo="SPMV_DEFAULT", to_backend=None, exchange="auto",
                  overlap=True, dtype=np.float64, transport=None):
@@ -236,6 +241,14 @@ class DistSpmv:
         self._transport = None
         id_buf = None
         tr_ptr = None
+        if transport == "rccl" and self.world == 1:
+            # one rank, the library's own RCCL transport all the same (with a forced exchange the one-rank communicator runs the calls
+            # an N-rank job makes: the N-rank code path on one GPU)
+            raw = (C.c_char * 128)()
+            check(self.lib, self.lib.kkamd_dist_unique_id(raw))
+            id_buf = (C.c_char * 128).from_buffer_copy(raw.raw)
+        elif transport == "rccl":
+            transport = None
         if self.world > 1 and transport is not None:
             self._transport = transport            # a caller-supplied kkamd_transport_t holder (object with a .struct)
             tr_ptr = C.byref(transport.struct)

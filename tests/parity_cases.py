@@ -392,6 +392,61 @@ def check_spgemm_kept_structure(be):
             kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_keep_lists", 1))
 
 
+def check_spgemm_pool_release(be):
+    """The process-wide store of bitmaps / entry lists (GBs on large products) goes back to the device when the LAST SpGEMM handle is
+    destroyed (round-4 review: a plain C caller kept it for ever); with "spgemm_pool_keep" 1 it outlives the handles and
+    kkamd_release_scratch returns it.  Also: the store is sized by what the product can need, not by a flat share of the free memory."""
+    import torch
+    import fuzz_cases as fz
+    rng = np.random.default_rng(5)
+    n, k = 60, 400000
+    B = fz.hubby(rng, n, k, 3000, 0, 3000)
+    A = fz.hubby(rng, 10, n, 3, 2, 20)
+    Ad, Bd = dev(be, A), dev(be, B)
+    kk._capi.check(be.lib, be.lib.kkamd_release_scratch())
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+
+    def run(keep_a_second_handle=False):
+        kh = kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+        other = None
+        if keep_a_second_handle:
+            other = kk.KokkosKernelsHandle(be); other.create_spgemm_handle("SPGEMM_KK")
+        Cm = kk.spgemm_symbolic(kh, Ad, False, Bd, False)
+        held = torch.cuda.mem_get_info()[0]                   # free memory while the handle holds its store
+        kk.spgemm_numeric(kh, Ad, False, Bd, False, Cm)
+        assert kh.get_spgemm_handle().get(12) + kh.get_spgemm_handle().get(14) > 0           # the store was used
+        del Cm
+        kh.destroy_spgemm_handle()
+        return held, other
+
+    free0 = torch.cuda.mem_get_info()[0]
+    held, _ = run()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - held < (1 << 30), "store of %d MB for a product with 6e4 multiplications" % ((free0 - held) >> 20)    # (it was a tenth of the free HBM)
+    assert free0 - free1 < (8 << 20), "the last handle is gone and %d MB are still held" % ((free0 - free1) >> 20)
+    # a second live handle keeps the pool (the next product of the job will use it) ...
+    _, other = run(keep_a_second_handle=True)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free2 = torch.cuda.mem_get_info()[0]
+    other.destroy_spgemm_handle()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free3 = torch.cuda.mem_get_info()[0]
+    assert free3 >= free2 and free0 - free3 < (8 << 20), (free0, free2, free3)
+    # ... and so does the knob, until kkamd_release_scratch
+    kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 1))
+    try:
+        run()
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        free4 = torch.cuda.mem_get_info()[0]
+        kk._capi.check(be.lib, be.lib.kkamd_release_scratch())
+        torch.cuda.synchronize()
+        free5 = torch.cuda.mem_get_info()[0]
+        assert free5 >= free4 and free0 - free5 < (8 << 20), (free0, free4, free5)
+    finally:
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 0))
+
+
 def check_spgemm_val_steps(be):
     """Flat value kernel with 2 and 3 steps of a window's product walk in flight (`spgemm_val_steps`): rows of C whose windows hold several
     steps of products (lists that overlap heavily), in the lightest shape (128 work-items: a step is 512 products), the 512-work-item shape

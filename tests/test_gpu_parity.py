@@ -504,8 +504,52 @@ def test_dist_operator_on_device_with_loopback_transport(be):
     del op
 
 
+def test_builtin_rccl_transport_on_one_rank(be):
+    """The library's OWN RCCL transport (kk::Rccl in kk_dist.hip: nine nccl* entry points bound with dlsym and called through
+    hand-declared signatures) executed on the one GPU of the box -- no kkamd_transport_t anywhere:
+      * kkamd_dist_transport_selftest: ncclGetUniqueId, ncclCommInitRank(nranks = 1), ncclAllGather in place and out of place, a group
+        of ncclSend / ncclRecv to self, an empty group, ncclCommDestroy -- payload compared byte for byte;
+      * kkamd_dist_spmv_* with world = 1 and every exchange forced through the one-rank communicator: the all-gather is the in-place
+        ncclAllGather of the one shard, the halos are groups without peers, the peer-to-peer all-gather runs its two barrier
+        collectives -- y against oracle.spmv_serial, x changing between the calls.
+    SURVEY 8(e): the reference has no distributed layer to compare with; north_star's RCCL all-gather of x is the contract."""
+    import torch
+    import oracle
+    from kokkos_kernels_amd.dist import DistSpmv, transport_selftest
+    for nbytes in (8, 4097, 1 << 22):
+        transport_selftest(be, nbytes)
+    A0 = oracle.laplace3d("FE", 24, 20, 16)
+    n = A0.nrows
+    A = pc.kk.CrsMatrix.from_host(n, n, A0.row_map, A0.entries, A0.values, backend=be)
+    rng = np.random.default_rng(11)
+    x = rng.random(n); y0 = rng.random(n)
+    tol = 10 * np.finfo(np.float64).eps * 27 * 32
+    for mode in ("allgather", "halo", "halo_set", "allgather_p2p"):
+        op = DistSpmv(A, [0, n], 0, exchange=mode, transport="rccl")
+        assert op.exchange_mode == mode, (mode, op.exchange_mode)
+        for scale, alpha, beta in ((1.0, 2.0, 0.5), (3.0, 1.0, 0.0), (-1.0, 1.0, 1.0)):
+            xs = torch.from_numpy(scale * x).cuda(); ys = torch.from_numpy(y0.copy()).cuda()
+            op.apply(alpha, xs, beta, ys)
+            torch.cuda.synchronize()
+            exp = oracle.spmv_serial("N", A0, alpha, scale * x, beta, y0.copy())
+            assert float(np.abs(ys.cpu().numpy() - exp).max()) <= tol * 3, mode
+        xl = op.x_local(); xl.copy_(torch.from_numpy(x).cuda())       # x kept in the operator's window: ncclAllGather strictly in place
+        ys = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        op.apply(1.0, xl, 0.0, ys); torch.cuda.synchronize()
+        assert float(np.abs(ys.cpu().numpy() - oracle.spmv_serial("N", A0, 1.0, x, 0.0, y0.copy())).max()) <= tol, mode
+        del op
+    # auto at world = 1 stays local (no communicator is formed)
+    op = DistSpmv(A, [0, n], 0, exchange="auto", transport="rccl")
+    assert op.exchange_mode == "local"
+    del op
+
+
 def test_spgemm_structure_kept_by_the_symbolic_phase(be):
     pc.check_spgemm_kept_structure(be)
+
+
+def test_spgemm_pool_returns_with_the_last_handle(be):
+    pc.check_spgemm_pool_release(be)
 
 
 def test_spgemm_value_walk_steps_in_flight(be):
