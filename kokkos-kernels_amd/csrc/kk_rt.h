@@ -10,6 +10,7 @@
     kk_emu::launch(dim3(grid), dim3(block), (size_t)(smem), [=]() { kernel(__VA_ARGS__); }); \
   } while (0)
 #define KK_NT_LOAD(p) (*(p))
+#define KK_NT_STORE(p, v) (*(p) = (v))
 #define KK_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(kk_emu::S().dyn_smem)
 #define KK_DEVICE_ONLY(...)
 #define KK_UNROLL
@@ -28,6 +29,7 @@
 #define KK_LAUNCH(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (size_t)(smem), stream, __VA_ARGS__)
 #define KK_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define KK_NT_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #define KK_DYN_SMEM(T, name)                                            \
   extern __shared__ __attribute__((aligned(16))) char kk_dyn_smem_[];   \
   T* name = reinterpret_cast<T*>(kk_dyn_smem_)

@@ -119,6 +119,12 @@ struct SpgemmTuning {
   int col_quads      = 4;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads, 4 or 8 per work-item and step (0 = one 4-byte load per product)
   int val_hub_flat   = 0;         // 1 = A rows above kValLa through the flat value kernel too (measured slower, see numeric_typed)
   int val_kernel     = 2;         // dense rows with short A rows: 2 = flat walk with the lists cut per window group (default), 1 = wave-per-list streaming
+  int block          = 1;         // rows of C that are dense (or have more lists than the flat kernel's shapes) through the column-block value kernel (0 = windows only)
+  int block_w        = 16384;     // its columns per block (a power of two; 16384 = 128 KB of fp64 sums)
+  int block_min_pct  = 12;        // ... rows with at least this percentage of the columns (R-MAT scale 20: 12 % = rows above 125 K entries) ...
+  int block_la_pct   = 3;         // ... or at least this percentage and more than kValLa lists
+  int nt             = 0;         // value kernels of the dense rows: entries(C) / values(C) through nontemporal loads / stores
+  int sort_rows      = 1;         // the row lists of the dense kernels are ordered by size, largest first (0 = the order the binning left)
   int pool_keep      = 0;         // 1 = the process-wide store of bitmaps / entry lists outlives the last handle (hosts that run large products back to back,
                                   // one handle at a time: an allocation of GBs per product is not free); 0 = destroying the last handle returns it to the device
 };
@@ -1560,6 +1566,42 @@ __global__ __launch_bounds__(kBlock) void spgemm_split_dense_kernel(int64_t nd, 
   }
 }
 
+// ORDER of a list of rows by size, largest first, in quarter-octave classes (a counting sort: histogram, scan of 256 classes, scatter;
+// the order inside a class is whatever the atomics give).  Rows that run at the same time then have similar sizes: the heaviest rows
+// start first (no long tail behind a late hub row), and rows of similar density walk their windows over similar column ranges at
+// similar times -- the segments of B's long rows one of them fetched are still in the XCD's L2 when its neighbours ask for them.
+constexpr int kSizeClasses = 256;
+__device__ __forceinline__ int size_class_desc(int64_t sz) {      // 0 = the largest sizes
+  if (sz < 1) return kSizeClasses - 1;
+  const int lg = 63 - __clzll((unsigned long long)sz);           // floor(log2)
+  const int frac = lg >= 2 ? (int)((sz >> (lg - 2)) & 3) : 0;    // two bits below the leading one
+  const int c = lg * 4 + frac;                                   // 0 .. 255
+  return kSizeClasses - 1 - (c < kSizeClasses ? c : kSizeClasses - 1);
+}
+__global__ __launch_bounds__(kBlock) void spgemm_size_hist_kernel(int64_t n, const int32_t* __restrict__ list, const int64_t* __restrict__ sizes,
+                                                                  unsigned* __restrict__ hist) {
+  __shared__ unsigned s_h[kSizeClasses];
+  for (int i = threadIdx.x; i < kSizeClasses; i += kBlock) s_h[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) atomicAdd(&s_h[size_class_desc(sizes[list[i]])], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSizeClasses; i += kBlock) if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+__global__ __launch_bounds__(kSizeClasses) void spgemm_size_scan_kernel(unsigned* __restrict__ hist /* in: counts, out: start of every class */) {
+  __shared__ unsigned s_w[kSizeClasses / 64];
+  const unsigned v = hist[threadIdx.x];
+  unsigned tot;
+  const unsigned ex = block_exclusive_scan_n<unsigned, kSizeClasses>(v, &tot, s_w);
+  hist[threadIdx.x] = ex;
+}
+__global__ __launch_bounds__(kBlock) void spgemm_size_scatter_kernel(int64_t n, const int32_t* __restrict__ in, const int64_t* __restrict__ sizes,
+                                                                     unsigned* __restrict__ cursor, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int32_t row = in[i];
+    out[atomicAdd(&cursor[size_class_desc(sizes[row])], 1u)] = row;
+  }
+}
+
 // ... and the rows of the first group once more: SMALL ones (at most cnt_max entries in the row of C and la_max in the row of A) first, the
 // others from the back.  The small rows get the flat value kernel's light shape (256 work-items, 2048-slot table, 38 KB of LDS: four
 // workgroups per CU instead of two): on R-MAT scale 20 245 K of the 454 K rows of this group have 257 .. 8 K entries -- unions of two
@@ -1573,6 +1615,32 @@ __global__ __launch_bounds__(kBlock) void spgemm_split_small_kernel(int64_t nd, 
   int32_t row = 0;
   int cls     = -1;
   if (i < nd) { row = perm_in[i]; cls = ((int64_t)rmA[row + 1] - (int64_t)rmA[row] <= la_max && sizes[row] <= cnt_max) ? 0 : 1; }
+  for (int c = 0; c < 2; ++c) {
+    const kk_u64 m = __ballot(cls == c);
+    unsigned long long start = 0;
+    if (lane == 0 && m) start = atomicAdd(&counters[c], (unsigned long long)__popcll(m));
+    start = __shfl(start, 0, 64);
+    if (cls == c) {
+      const int64_t r = (int64_t)start + __popcll(m & ((1ull << lane) - 1ull));
+      perm_out[c == 0 ? r : nd - 1 - r] = row;
+    }
+  }
+}
+
+// the dense bin as [ other rows | rows for the column-block value kernel ]: A rows above la_min entries or rows of C with at least cnt_min entries
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_split_block_kernel(int64_t nd, const int32_t* __restrict__ perm_in, const OffT* __restrict__ rmA,
+                                                                    const int64_t* __restrict__ sizes, int64_t la_min, int64_t cnt_min, int64_t cnt_floor,
+                                                                    int32_t* __restrict__ perm_out, unsigned long long* __restrict__ counters /*[2]*/) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane  = threadIdx.x & 63;
+  int32_t row = 0;
+  int cls     = -1;
+  if (i < nd) {
+    row = perm_in[i];
+    const int64_t la = (int64_t)rmA[row + 1] - (int64_t)rmA[row], cnt = sizes[row];
+    cls = (cnt >= cnt_min || (la > la_min && cnt >= cnt_floor)) ? 1 : 0;
+  }
   for (int c = 0; c < 2; ++c) {
     const kk_u64 m = __ballot(cls == c);
     unsigned long long start = 0;
@@ -1783,8 +1851,11 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
                                                                        const VT* __restrict__ valA, const OffT* __restrict__ rmB,
                                                                        const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                        const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
-                                                                       VT* __restrict__ valC, int cap KK_DBG_PARAM) {
+                                                                       VT* __restrict__ valC, int cap_nt, int64_t nnzB KK_DBG_PARAM) {
   static_assert(NT >= LA, "one work-item per list in the scan");
+  // bit 30 of the argument: entries(C) / values(C) -- read once, written once -- go through nontemporal loads and stores, so that they do not
+  // push the rows of B out of the caches on their way (knob spgemm_nt)
+  const int cap = cap_nt & 0xFFFFFF; const bool nt = (cap_nt >> 30) & 1;
   __shared__ int hk[H];
   __shared__ VT hv[H];
   __shared__ long long s_cur[LA];     // first unconsumed entry of list a (index into entries / values of B)
@@ -1795,6 +1866,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
   __shared__ int s_whi[G];
   __shared__ int s_wave[NT / 64];
   constexpr int U   = kProdUnroll;
+  constexpr int UV  = 8;                       // entries of a list per unit of the vector walk (ST == 0)
   constexpr int KPT = (H / 2 + NT - 1) / NT;   // C entries of a window per work-item
   const int t = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
@@ -1813,7 +1885,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
     }
     int curk[KPT], slot[KPT];
     KK_UNROLL
-    for (int q = 0; q < KPT; ++q) { const int i = t + q * NT; curk[q] = (i < cap && i < cnt) ? entC[base + i] : -1; }
+    for (int q = 0; q < KPT; ++q) { const int i = t + q * NT; curk[q] = (i < cap && i < cnt) ? (nt ? KK_NT_LOAD(entC + base + i) : entC[base + i]) : -1; }
     __syncthreads();
     for (int64_t gdone = 0; gdone < cnt; gdone += (int64_t)G * cap) {
       const int ng = (int)((cnt - gdone + cap - 1) / cap < G ? (cnt - gdone + cap - 1) / cap : G);     // windows in this group
@@ -1847,13 +1919,14 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
         KK_UNROLL
         for (int q = 0; q < KPT; ++q) {
           const int i = t + q * NT;
-          nxtk[q]     = (i < cap && done + cap + i < cnt) ? entC[base + done + cap + i] : -1;
+          nxtk[q]     = (i < cap && done + cap + i < cnt) ? (nt ? KK_NT_LOAD(entC + base + done + cap + i) : entC[base + done + cap + i]) : -1;
         }
         // in-window counts of the lists -> product offsets
         const int from = (t < la_c && g > 0) ? s_pos[g - 1][t] : 0;
         const int n_in = t < la_c ? s_pos[g][t] - from : 0;
         int tot;
-        const int excl = block_exclusive_scan_n<int, NT>(n_in, &tot, s_wave);     // two barriers: the table is built when it returns
+        // ST == 0: the unit of the walk is a run of up to UV consecutive entries of ONE list (see below): the scan counts units
+        const int excl = block_exclusive_scan_n<int, NT>(ST == 0 ? (n_in + UV - 1) / UV : n_in, &tot, s_wave);     // two barriers: the table is built when it returns
         if (t < la_c) s_pre[t] = excl;
         if (t == 0) s_pre[la_c] = tot;
         __syncthreads();
@@ -1862,10 +1935,53 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
           while (len2 > 1) { const int half = len2 >> 1; lo += (s_pre[lo + half] <= q) ? half : 0; len2 -= half; }
           return lo;
         };
+        if constexpr (ST == 0) {
+          // VECTOR WALK: work-item u of a step takes unit u -- entries 8 i .. 8 i + 7 of one list's piece inside the window -- with two
+          // 16-byte loads of columns and four of values (global loads need 4-byte alignment only): one search per EIGHT products
+          // instead of one per four, three times fewer load instructions per product, twice the bytes in flight per work-item, and the
+          // lanes of a wave that share a list read one contiguous run (64 lanes = 2 KB of columns).  A list's last unit reads past
+          // the list's piece (masked), never past the arrays (the few units that would take the guarded loads).
+          if (!KK_DBG(4096)) for (int ubase = 0; ubase < tot; ubase += NT) {
+            const int u = ubase + t;
+            int cnt_u = 0;
+            long long first = 0;
+            VT ava = VT(0);
+            if (u < tot) {
+              const int a = find(u);
+              const int fr = g > 0 ? s_pos[g - 1][a] : 0;
+              const int k0 = (u - s_pre[a]) * UV;
+              cnt_u = s_pos[g][a] - fr - k0; cnt_u = cnt_u < UV ? cnt_u : UV;
+              first = s_cur[a] + fr + k0;
+              ava = s_av[a];
+            }
+            int cc[UV];
+            VT vv[UV];
+            if (first + UV <= (long long)nnzB) {
+              typedef int kk_i4 __attribute__((vector_size(16)));
+              kk_i4 c4[UV / 4];
+              KK_UNROLL
+              for (int e = 0; e < UV / 4; ++e) __builtin_memcpy(&c4[e], entB + first + 4 * e, 16);
+              KK_UNROLL
+              for (int e = 0; e < UV; ++e) vv[e] = valB[first + e];        // (consecutive: the compiler merges them into 16-byte loads)
+              KK_UNROLL
+              for (int e = 0; e < UV; ++e) cc[e] = c4[e / 4][e % 4];
+            } else {
+              KK_UNROLL
+              for (int e = 0; e < UV; ++e) { const long long j = first + e < (long long)nnzB ? first + e : (long long)nnzB - 1; cc[e] = entB[j]; vv[e] = valB[j]; }
+            }
+            KK_UNROLL
+            for (int e = 0; e < UV; ++e)
+              if (e < cnt_u && !KK_DBG(8192)) {
+                const int hh = vt_find<H>(hk, cc[e]);
+                if (hh >= 0) KK_ATOMIC_FADD(&hv[hh], ava * vv[e]);
+              }
+          }
+        } else
         if (!KK_DBG(4096)) for (int pbase = 0; pbase < tot; pbase += NT * U * ST) {
-          int col[ST][U];
-          VT bv[ST][U], av[ST][U];
-          long long jj[ST][U];
+          constexpr int STN = ST > 0 ? ST : 1;
+          int col[STN][U];
+          VT bv[STN][U], av[STN][U];
+          long long jj[STN][U];
           KK_UNROLL
           for (int s = 0; s < ST; ++s) {
             KK_UNROLL
@@ -1914,7 +2030,8 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
         for (int q = 0; q < KPT; ++q) {
           if (slot[q] >= 0) {
             VT* out = valC + base + done + t + q * NT;
-            *out = first_pass ? hv[slot[q]] : *out + hv[slot[q]];
+            const VT sum = first_pass ? hv[slot[q]] : *out + hv[slot[q]];
+            if (nt) KK_NT_STORE(out, sum); else *out = sum;
             hk[slot[q]] = -1; hv[slot[q]] = VT(0);
           }
           curk[q] = nxtk[q];
@@ -1950,7 +2067,8 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
                                                                       const VT* __restrict__ valA, const OffT* __restrict__ rmB,
                                                                       const int32_t* __restrict__ entB, const VT* __restrict__ valB,
                                                                       const OffT* __restrict__ rmC, const int32_t* __restrict__ entC,
-                                                                      VT* __restrict__ valC, int cap, const int32_t* __restrict__ items) {
+                                                                      VT* __restrict__ valC, int cap_nt, const int32_t* __restrict__ items) {
+  const int cap = cap_nt & 0xFFFFFF; const bool nt = (cap_nt >> 30) & 1;      // (see spgemm_dense_vals2_kernel)
   constexpr int H = kValTable, NT = kDenseBlock, KPT = (H / 2 + NT - 1) / NT, SG = KK_HUB_SG, NSUB = NT / SG, US = KK_HUB_US, EL = KK_HUB_EL;
   constexpr unsigned long long kSgMask = (1ull << SG) - 1ull;
   __shared__ int hk[H];
@@ -2003,7 +2121,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
     KK_UNROLL
     for (int q = 0; q < KPT; ++q) {
       const int i = t + q * NT;
-      nxtk[q]     = (i < cap && done + cap + i < cnt) ? entC[base + done + cap + i] : -1;
+      nxtk[q]     = (i < cap && done + cap + i < cnt) ? (nt ? KK_NT_LOAD(entC + base + done + cap + i) : entC[base + done + cap + i]) : -1;
     }
     __syncthreads();
     const int whi = s_whi;
@@ -2093,7 +2211,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_hub_vals_kernel(const int3
       if (slot[q] >= 0) {
         VT* out = valC + base + done + t + q * NT;
         if (shared_row) KK_ATOMIC_FADD(out, hv[slot[q]]);        // global_atomic_add_f64 into the row's (zeroed) values
-        else *out = first_pass ? hv[slot[q]] : *out + hv[slot[q]];
+        else { const VT sum = first_pass ? hv[slot[q]] : *out + hv[slot[q]]; if (nt) KK_NT_STORE(out, sum); else *out = sum; }
         hk[slot[q]] = -1; hv[slot[q]] = VT(0);
       }
       curk[q] = nxtk[q];
@@ -2116,6 +2234,137 @@ __global__ __launch_bounds__(kBlock) void spgemm_zero_rows_kernel(const int32_t*
   for (int64_t i = (int64_t)rmC[row] + threadIdx.x; i < (int64_t)rmC[row + 1]; i += kBlock) valC[i] = VT(0);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// DENSE rows, values, by COLUMN BLOCKS (round 5; the reference's dense accumulator where it pays, impl_speed.hpp:28-150 and the
+// selection rule impl_kkmem.hpp:1259-1300, re-cut for 160 KB of LDS).  The columns are cut into blocks of W (16384: a direct-indexed
+// fp64 accumulator of 128 KB); a work unit is (row of C, column block) and is INDEPENDENT of every other unit: no cursors carried from
+// window to window, no hash, no probe, no search at run time --
+//   * an index of B, built once per handle and B (spgemm_bidx_kernel): bidx[cb][j] = entries of row j of B with a column below cb W, so
+//     the piece of list (A entry) a inside block cb is rmB[j] + bidx[cb][j] .. rmB[j] + bidx[cb + 1][j]: two gathers, no binary search
+//     (the windowed kernels cut every list at every window by a lower-bound search in HBM: 13 of the 28 ms of the 1024-list shape);
+//   * an index of C for the class's rows (spgemm_cidx_kernel): where block cb starts in the row's sorted entries(C);
+//   * the products of a unit are walked in units of eight entries of one list (16-byte loads, one search in LDS per eight products)
+//     and added with ds_add_f64 at acc[column - cb W]; the sums leave by reading entries(C) of the block and gathering from acc.
+// An A row of any length is taken NT lists at a time into the same accumulator (no passes over windows, no atomics on values(C): the
+// hub rows' sums are deterministic up to the order of the LDS adds), and the launch is block-major: the workgroups in flight at any
+// time work on the same few column blocks, whose pieces of B's long rows stay in the XCDs' L2.
+// For rows at least 1/32 dense (or with more lists than the flat kernel's shapes hold): R-MAT scale 20, 37 % of the products.
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_bidx_kernel(int64_t nB, int nblk, int wshift, const OffT* __restrict__ rmB, const int32_t* __restrict__ entB,
+                                                             unsigned* __restrict__ bidx /* [nblk + 1][nB] */) {
+  // thread = (block boundary cb, row j), j fastest: coalesced row_map reads and index writes
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (int64_t)(nblk + 1) * nB) return;
+  const int cb = (int)(i / nB);
+  const int64_t j = i - (int64_t)cb * nB;
+  const int64_t b0 = (int64_t)rmB[j];
+  const int len = (int)((int64_t)rmB[j + 1] - b0);
+  const long long bound = (long long)cb << wshift;               // first column of block cb
+  int lo = 0, hi = len;
+  if (cb == 0) hi = 0;
+  else if (cb == nblk) lo = len;
+  else while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)entB[b0 + mid] < bound) lo = mid + 1; else hi = mid; }
+  bidx[i] = (unsigned)lo;
+}
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_cidx_kernel(int64_t nrows, const int32_t* __restrict__ perm, int nblk, int wshift, const OffT* __restrict__ rmC,
+                                                             const int32_t* __restrict__ entC, unsigned* __restrict__ cidx /* [nrows][nblk + 1] */) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nrows * (int64_t)(nblk + 1)) return;
+  const int64_t r = i / (nblk + 1);
+  const int cb = (int)(i - r * (nblk + 1));
+  const int64_t row = perm[r], b0 = (int64_t)rmC[row];
+  const long long len = (long long)rmC[row + 1] - b0;
+  const long long bound = (long long)cb << wshift;
+  long long lo = 0, hi = len;
+  if (cb == 0) hi = 0;
+  else if (cb == nblk) lo = len;
+  else while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)entC[b0 + mid] < bound) lo = mid + 1; else hi = mid; }
+  cidx[i] = (unsigned)lo;
+}
+template <class OffT, class VT, int NT>
+__global__ __launch_bounds__(NT) void spgemm_block_vals_kernel(int64_t nrows, const int32_t* __restrict__ perm, int nblk, int wshift, int64_t nB,
+                                                               const unsigned* __restrict__ bidx, const unsigned* __restrict__ cidx,
+                                                               const OffT* __restrict__ rmA, const int32_t* __restrict__ entA, const VT* __restrict__ valA,
+                                                               const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, const VT* __restrict__ valB,
+                                                               int64_t nnzB, const OffT* __restrict__ rmC, const int32_t* __restrict__ entC, VT* __restrict__ valC) {
+  KK_DYN_SMEM(VT, acc);                      // [W]
+  __shared__ long long s_p0[NT];             // first entry of list a inside the block (index into entries / values of B)
+  __shared__ int s_n[NT];                    // entries of it inside the block
+  __shared__ int s_pre[NT + 1];              // unit offsets of the lists
+  __shared__ VT s_av[NT];
+  __shared__ int s_wave[NT / 64];
+  constexpr int UV = 8;
+  const int t = threadIdx.x;
+  // block-major (the grid is rows x blocks, x fastest): all rows of block 0, then all rows of block 1, ...
+  const int cb = (int)blockIdx.y;
+  const int64_t r = (int64_t)blockIdx.x;
+  (void)nrows;
+  const unsigned e0 = cidx[r * (nblk + 1) + cb], e1 = cidx[r * (nblk + 1) + cb + 1];
+  if (e0 == e1) return;                      // no entry of C here: no product either (uniform)
+  const int64_t row = perm[r];
+  const int W = 1 << wshift;
+  const int c0 = cb << wshift;
+  for (int i = t; i < W; i += NT) acc[i] = VT(0);
+  const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
+  const unsigned* bx0 = bidx + (int64_t)cb * nB;
+  const unsigned* bx1 = bx0 + nB;
+  for (int64_t ach = 0; ach < la; ach += NT) {
+    const int la_c = (int)(la - ach < NT ? la - ach : NT);
+    int n_in = 0;
+    if (t < la_c) {
+      const int32_t kc = entA[a0 + ach + t];
+      const unsigned f = bx0[kc], l = bx1[kc];
+      n_in = (int)(l - f);
+      s_p0[t] = (long long)rmB[kc] + f; s_n[t] = n_in; s_av[t] = valA[a0 + ach + t];
+    }
+    int tot;
+    const int excl = block_exclusive_scan_n<int, NT>((n_in + UV - 1) / UV, &tot, s_wave);    // (its barriers also publish the zeroed accumulator)
+    if (t < la_c) s_pre[t] = excl;
+    if (t == 0) s_pre[la_c] = tot;
+    __syncthreads();
+    auto find = [&](int q) {               // largest a in [0, la_c) with pre[a] <= q
+      int lo = 0, len2 = la_c;
+      while (len2 > 1) { const int half = len2 >> 1; lo += (s_pre[lo + half] <= q) ? half : 0; len2 -= half; }
+      return lo;
+    };
+    for (int ubase = 0; ubase < tot; ubase += NT) {
+      const int u = ubase + t;
+      int cnt_u = 0;
+      long long first = 0;
+      VT ava = VT(0);
+      if (u < tot) {
+        const int a = find(u);
+        const int k0 = (u - s_pre[a]) * UV;
+        cnt_u = s_n[a] - k0; cnt_u = cnt_u < UV ? cnt_u : UV;
+        first = s_p0[a] + k0;
+        ava = s_av[a];
+      }
+      int cc[UV];
+      VT vv[UV];
+      if (first + UV <= (long long)nnzB) {
+        typedef int kk_i4 __attribute__((vector_size(16)));
+        kk_i4 c4[UV / 4];
+        KK_UNROLL
+        for (int e = 0; e < UV / 4; ++e) __builtin_memcpy(&c4[e], entB + first + 4 * e, 16);
+        KK_UNROLL
+        for (int e = 0; e < UV; ++e) vv[e] = valB[first + e];
+        KK_UNROLL
+        for (int e = 0; e < UV; ++e) cc[e] = c4[e / 4][e % 4];
+      } else {
+        KK_UNROLL
+        for (int e = 0; e < UV; ++e) { const long long j = first + e < (long long)nnzB ? first + e : (long long)nnzB - 1; cc[e] = entB[j]; vv[e] = valB[j]; }
+      }
+      KK_UNROLL
+      for (int e = 0; e < UV; ++e)
+        if (e < cnt_u) KK_ATOMIC_FADD(&acc[cc[e] - c0], ava * vv[e]);
+    }
+    __syncthreads();                       // the next chunk of lists overwrites the descriptors; after the last one: the sums are complete
+  }
+  const int64_t base = (int64_t)rmC[row];
+  for (unsigned i = e0 + t; i < e1; i += NT) valC[base + i] = acc[entC[base + i] - c0];
+}
 // ------------------------------------------------------------------------------------------------
 }  // namespace kk
 
@@ -2164,6 +2413,10 @@ struct kkamd_spgemm_handle {
   bool entries_valid = false;      // entries(C) as the last numeric call left them are still what entC_ptr holds (numeric reuse)
   bool entries_reused = false;     // the last numeric call kept them
   const void *entC_ptr = nullptr, *rmC_ptr = nullptr;
+  // column-block value kernel: rows of the dense bin's tail, the index of B (kept while B's arrays are the same) and of the rows' entries(C)
+  int64_t n_dense_block = 0;
+  unsigned* d_bidx = nullptr; const void* bidx_rmB = nullptr; const void* bidx_entB = nullptr; int64_t bidx_nB = 0; int bidx_nblk = 0, bidx_wshift = 0;
+  unsigned* d_cidx = nullptr; bool cidx_ready = false;
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -2300,6 +2553,24 @@ static int split_list_by_size(int32_t* list, int64_t n, const OffT* rmA, const i
   return KKAMD_OK;
 }
 
+// list[0 .. n) reordered by sizes[row], largest first (quarter-octave classes; see spgemm_size_hist_kernel)
+static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hipStream_t st) {
+  if (n < 2 || !g_spgemm.sort_rows) return KKAMD_OK;
+  DevBuf tmp_b, hist_b;
+  KK_HIP(tmp_b.alloc(sizeof(int32_t) * (size_t)n));
+  KK_HIP(hist_b.alloc(sizeof(unsigned) * kSizeClasses));
+  int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned* d_hist = hist_b.as<unsigned>();
+  KK_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * kSizeClasses, st));
+  KK_HIP(hipMemcpyAsync(d_tmp, list, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  const int64_t nbk = ceil_div(n, kBlock);
+  const unsigned grid = (unsigned)(nbk < 1024 ? nbk : 1024);
+  KK_LAUNCH(spgemm_size_hist_kernel, grid, kBlock, 0, st, n, (const int32_t*)d_tmp, sizes, d_hist);
+  KK_LAUNCH(spgemm_size_scan_kernel, 1, kSizeClasses, 0, st, d_hist);
+  KK_LAUNCH(spgemm_size_scatter_kernel, grid, kBlock, 0, st, n, (const int32_t*)d_tmp, sizes, d_hist, list);
+  KK_HIP(hipStreamSynchronize(st));          // the scratch buffers go out of scope
+  return KKAMD_OK;
+}
+
 template <class OffT>
 static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t k, const void* rmA_, const int32_t* entA,
                           const void* rmB_, const int32_t* entB, void* rmC_, int64_t nnzB, int64_t* c_nnz, hipStream_t st) {
@@ -2417,6 +2688,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
                          (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
     if (nb(4)) {
+      if ((rc = order_list_by_size(h->d_perm + off.off[4], nb(4), (const int64_t*)h->d_sizes, st))) return rc;      // by products, largest first
       // keep the bitmaps of rows with at least k / 32 entries (the bitmap is then no larger than the row's entries) when one LDS
       // window covers the columns and an eighth of the free HBM holds them: R-MAT scale 20, 87 K rows (83 % of the products), 11 GB
       BitmapStore bs;
@@ -2536,7 +2808,29 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       KK_HIP(cnt_b.alloc(2 * sizeof(unsigned long long)));
       int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
       int32_t* seg = h->d_perm + h->num_off.off[4];
-      int64_t lo = 0, len = nd;
+      // the tail of the bin: rows for the column-block value kernel (dense rows, and rows with more lists than the flat shapes hold)
+      h->n_dense_block = 0; h->cidx_ready = false;
+      if (g_spgemm.block && h->dense_lds && g_spgemm.val_kernel == 2 && k >= 64) {
+        int wshift = 6;
+        while ((1 << wshift) < g_spgemm.block_w) ++wshift;
+        const int64_t nblk = ceil_div(k, (int64_t)1 << wshift);
+        size_t free_b = 0, total_b = 0;
+        const bool fits = nblk <= 65535 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)(nblk + 1) * (size_t)h->n * 4 <= free_b / 16;
+        (void)hipGetLastError();
+        if (fits) {
+          KK_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
+          KK_HIP(hipMemcpyAsync(d_tmp, seg, sizeof(int32_t) * (size_t)nd, hipMemcpyDeviceToDevice, st));
+          const int64_t cnt_min = (k * g_spgemm.block_min_pct + 99) / 100, cnt_floor = (k * g_spgemm.block_la_pct + 99) / 100;
+          KK_LAUNCH((spgemm_split_block_kernel<OffT>), (unsigned)ceil_div(nd, kBlock), kBlock, 0, st, nd, (const int32_t*)d_tmp, rmA, (const int64_t*)h->d_sizes,
+                    (int64_t)kValLa, cnt_min > 1 ? cnt_min : 1, cnt_floor > 1 ? cnt_floor : 1, seg, d_cnt);
+          KK_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
+          KK_HIP(hipStreamSynchronize(st));
+          h->n_dense_block = (int64_t)h_cnt[1];
+          if (h->n_dense_block * kDenseBlock >= ((int64_t)1 << 32)) h->n_dense_block = 0;      // (a grid dimension holds 2^32 work-items; the split stays: every row is still in the bin once)
+          if ((rc = order_list_by_size(seg + (nd - h->n_dense_block), h->n_dense_block, (const int64_t*)h->d_sizes, st))) return rc;
+        }
+      }
+      int64_t lo = 0, len = nd - h->n_dense_block;
       // (B sorted: the hub value kernel takes A rows of any length, kHubLa entries per pass; hub_chunked 0 = rows above kHubLa accumulate in HBM)
       // flat value kernel (default): [A row <= kValLa | <= kValLa2 (the flat kernel, 1024 lists per pass) | the rest (hub kernel in passes)]
       h->hub_from_mid = h->dense_lds && g_spgemm.val_kernel == 2 && g_spgemm.val_mid && g_spgemm.hub_chunked;
@@ -2572,6 +2866,12 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         }
         h->n_dense_tiny = got[0]; h->n_dense_small = got[1];
       }
+      // every launch's rows largest first (the hub rows' (row, pass) items are ordered by passes further down)
+      if (h->dense_lds && g_spgemm.val_kernel == 2) {
+        const int64_t cuts[5] = {0, h->n_dense_tiny, h->n_dense_tiny + h->n_dense_small, first[0], first[0] + first[1]};
+        for (int sgi = 0; sgi < 4; ++sgi)
+          if ((rc = order_list_by_size(seg + cuts[sgi], cuts[sgi + 1] - cuts[sgi], (const int64_t*)h->d_sizes, st))) return rc;
+      }
     }
     h->n_wave_quad = 0;
     {
@@ -2593,9 +2893,9 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   auto nb = [&](int b) { return off.off[b + 1] - off.off[b]; };
   if (h->verbose)
     KK_VERBOSE("\tkkamd spgemm numeric (%s): rows per kernel -- wave hash %lld, block hash small %lld, block hash large %lld, dense rows %lld "
-           "(LDS value windows %lld, LDS hub windows %lld, HBM accumulator %lld)\n", h->algorithm == 1 ? "SPGEMM_KK_DENSE" : "SPGEMM_KK",
-           (long long)nb(1), (long long)nb(2), (long long)nb(3), (long long)nb(4), (long long)h->n_dense_lds, (long long)h->n_dense_hub_lds,
-           (long long)(nb(4) - h->n_dense_lds - h->n_dense_hub_lds));
+           "(column blocks %lld, LDS value windows %lld, LDS hub windows %lld, HBM accumulator %lld)\n", h->algorithm == 1 ? "SPGEMM_KK_DENSE" : "SPGEMM_KK",
+           (long long)nb(1), (long long)nb(2), (long long)nb(3), (long long)nb(4), (long long)h->n_dense_block, (long long)h->n_dense_lds, (long long)h->n_dense_hub_lds,
+           (long long)(nb(4) - h->n_dense_block - h->n_dense_lds - h->n_dense_hub_lds));
   if (nb(1)) {
     const int64_t nq = h->n_wave_quad < nb(1) ? h->n_wave_quad : nb(1);
     const int32_t* wlist = h->d_perm + off.off[1];
@@ -2695,18 +2995,52 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     else if ((rc = emit_walk(nb(4), dperm, (int64_t)0))) return rc;
 #define KK_VALS2(HH, NTT, GG, LAA, GRID, PERM, CAP)                                                                                     \
   do {                                                                                                                                  \
-    if (g_spgemm.val_steps == 3)                                                                                                        \
+    if (g_spgemm.val_steps == 0)                                                                                                        \
+      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 0>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
+                rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                             \
+    else if (g_spgemm.val_steps == 3)                                                                                                        \
       KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 3>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
-                rmC, (const int32_t*)entC, valC, CAP KK_DBG_ARG);                                                                        \
+                rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                                                                        \
     else if (g_spgemm.val_steps == 2)                                                                                                   \
       KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 2>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
-                rmC, (const int32_t*)entC, valC, CAP KK_DBG_ARG);                                                                        \
+                rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                                                                        \
     else                                                                                                                                \
       KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 1>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
-                rmC, (const int32_t*)entC, valC, CAP KK_DBG_ARG);                                                                        \
+                rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                                                                        \
   } while (0)
-    const int64_t n_lds = h->n_dense_lds; int64_t n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_lds - n_hubl;
+    const int64_t n_blk = h->n_dense_block;
+    const int64_t n_lds = h->n_dense_lds; int64_t n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_blk - n_lds - n_hubl;
     const bool flat_vals = g_spgemm.val_kernel == 2 && h->dense_lds;
+    if (n_blk) {
+      // column-block value kernel: the index of B (kept while B's arrays and the block grid are the same), the index of these rows'
+      // entries(C) (once per symbolic phase: it depends on the structure only), then one workgroup per (row, block), block-major
+      int wshift = 6;
+      while ((1 << wshift) < g_spgemm.block_w) ++wshift;
+      const int nblk = (int)ceil_div(k, (int64_t)1 << wshift);
+      const int64_t nB = h->n;
+      const int32_t* bperm = dperm + (nb(4) - n_blk);
+      if (!h->d_bidx || h->bidx_rmB != rmB_ || h->bidx_entB != (const void*)entB || h->bidx_nB != nB || h->bidx_nblk != nblk || h->bidx_wshift != wshift) {
+        if (h->d_bidx) { (void)hipFree(h->d_bidx); h->d_bidx = nullptr; }
+        KK_HIP(hipMalloc((void**)&h->d_bidx, sizeof(unsigned) * (size_t)(nblk + 1) * (size_t)nB));
+        unsigned* d_bx = h->d_bidx;
+        KK_LAUNCH((spgemm_bidx_kernel<OffT>), (unsigned)ceil_div((int64_t)(nblk + 1) * nB, kBlock), kBlock, 0, st, nB, nblk, wshift, rmB, entB, d_bx);
+        h->bidx_rmB = rmB_; h->bidx_entB = entB; h->bidx_nB = nB; h->bidx_nblk = nblk; h->bidx_wshift = wshift;
+      }
+      if (!h->cidx_ready) {
+        if (h->d_cidx) { (void)hipFree(h->d_cidx); h->d_cidx = nullptr; }
+        KK_HIP(hipMalloc((void**)&h->d_cidx, sizeof(unsigned) * (size_t)(nblk + 1) * (size_t)n_blk));
+        unsigned* d_cx = h->d_cidx;
+        KK_LAUNCH((spgemm_cidx_kernel<OffT>), (unsigned)ceil_div((int64_t)(nblk + 1) * n_blk, kBlock), kBlock, 0, st, n_blk, bperm, nblk, wshift, rmC, (const int32_t*)entC, d_cx);
+        h->cidx_ready = true;
+      }
+      const size_t smem = sizeof(VT) << wshift;
+#ifndef KK_EMU
+      KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_block_vals_kernel<OffT, VT, kDenseBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#endif
+      const unsigned* d_bx = h->d_bidx; const unsigned* d_cx = h->d_cidx;
+      KK_LAUNCH((spgemm_block_vals_kernel<OffT, VT, kDenseBlock>), dim3((unsigned)n_blk, (unsigned)nblk), kDenseBlock, smem, st, n_blk, bperm, nblk, wshift, nB, d_bx, d_cx,
+                rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC);
+    }
     if (flat_vals && g_spgemm.val_hub_flat) {
       // measured and not kept as the default: A rows above kValLa through the flat kernel, kValLa lists per pass (R-MAT scale 20:
       // numeric 353 -> 479 ms -- with thousands of lists a group of windows costs 8 x 512 searches per pass and a pass finds a
@@ -2759,10 +3093,10 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         const int32_t* d_items = h->d_hub_items; const int32_t* d_multi = h->d_hub_multi;
         if (h->n_hub_multi) KK_LAUNCH((spgemm_zero_rows_kernel<OffT, VT>), (unsigned)h->n_hub_multi, kBlock, 0, st, hperm, d_multi, rmC, valC);
         KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)h->n_hub_items, kDenseBlock, 0, st, hperm, rmA, entA, valA, rmB, entB, valB,
-                  rmC, (const int32_t*)entC, valC, cap, d_items);
+                  rmC, (const int32_t*)entC, valC, cap | (g_spgemm.nt ? (1 << 30) : 0), d_items);
       } else {
         KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)n_hub, kDenseBlock, 0, st, hperm, rmA, entA, valA, rmB, entB, valB,
-                  rmC, (const int32_t*)entC, valC, cap, (const int32_t*)nullptr);
+                  rmC, (const int32_t*)entC, valC, cap | (g_spgemm.nt ? (1 << 30) : 0), (const int32_t*)nullptr);
       }
       n_hub = 0;
     }
@@ -2776,7 +3110,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       int cap = g_spgemm.val_cap;
       cap = cap < 64 ? 64 : (cap > kValTable / 2 ? kValTable / 2 : cap);
       KK_LAUNCH((spgemm_hub_vals_kernel<OffT, VT>), (unsigned)n_hubl, kDenseBlock, 0, st, dperm + n_lds, rmA, entA, valA, rmB, entB, valB,
-                rmC, (const int32_t*)entC, valC, cap, (const int32_t*)nullptr);
+                rmC, (const int32_t*)entC, valC, cap | (g_spgemm.nt ? (1 << 30) : 0), (const int32_t*)nullptr);
     }
     if (n_lds) {
       int cap = g_spgemm.val_cap;
@@ -2873,8 +3207,14 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_val_tiny_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_tiny_cnt: %d is negative", value); g_spgemm.val_tiny_cnt = value; }
   else if (k == "spgemm_emit_sort") g_spgemm.emit_sort = value != 0;
   else if (k == "spgemm_pool_keep") g_spgemm.pool_keep = value != 0;
+  else if (k == "spgemm_sort_rows") g_spgemm.sort_rows = value != 0;
+  else if (k == "spgemm_nt") g_spgemm.nt = value != 0;
+  else if (k == "spgemm_block") g_spgemm.block = value != 0;
+  else if (k == "spgemm_block_w") { if (value < 64 || value > 16384 || (value & (value - 1))) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_w: %d is not a power of two in [64, 16384]", value); g_spgemm.block_w = value; }
+  else if (k == "spgemm_block_min_pct") { if (value < 0 || value > 100) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_min_pct: 0 .. 100"); g_spgemm.block_min_pct = value; }
+  else if (k == "spgemm_block_la_pct") { if (value < 0 || value > 100) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_la_pct: 0 .. 100"); g_spgemm.block_la_pct = value; }
   else if (k == "spgemm_quad_rows") { if (value < 0 || value > 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_quad_rows: %d is not 0, 1 or 2", value); g_spgemm.quad_rows = value; }
-  else if (k == "spgemm_val_steps") { if (value < 1 || value > 3) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_steps: %d is not 1, 2 or 3", value); g_spgemm.val_steps = value; }
+  else if (k == "spgemm_val_steps") { if (value < 0 || value > 3) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_steps: %d is not 0 (vector walk), 1, 2 or 3", value); g_spgemm.val_steps = value; }
   else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
   else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;
@@ -2906,6 +3246,8 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   kk::free_bitmap_store(h);
   if (h->d_hub_items) (void)hipFree(h->d_hub_items);
   if (h->d_hub_multi) (void)hipFree(h->d_hub_multi);
+  if (h->d_bidx) (void)hipFree(h->d_bidx);
+  if (h->d_cidx) (void)hipFree(h->d_cidx);
   delete h;
   // the last handle gone: the pooled store (GBs) goes back to the device unless the host asked to keep it ("spgemm_pool_keep")
   bool last = false;
@@ -2933,6 +3275,8 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
   }
   h->m = m; h->n = n; h->k = k; h->offset_type = offset_type; h->rmA = d_row_mapA; h->rmB = d_row_mapB;
   h->symbolic_called = false; h->numeric_called = false; h->numeric_bins_ready = false; h->entries_valid = false;
+  if (h->d_bidx) { (void)hipFree(h->d_bidx); h->d_bidx = nullptr; }     // a new symbolic phase may bring another B in the same arrays
+  h->cidx_ready = false; h->n_dense_block = 0;
   kk::free_bitmap_store(h); h->bitmaps_used = 0;
   h->c_nnz = 0; h->mults = 0; h->max_row_flops = 0; h->max_row_nnz = 0;
   // empty product: zero row_map (:100-107; the rocSPARSE wrapper memsets too)
@@ -3089,6 +3433,7 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 13: *value = h->bm_stored; break;
     case 14: *value = h->pooled_used; break;
     case 15: *value = h->sorted_used; break;
+    case 16: *value = h->n_dense_block; break;       // rows of the last numeric call's bins that take the column-block value kernel
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
   return KKAMD_OK;

@@ -447,8 +447,50 @@ def check_spgemm_pool_release(be):
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 0))
 
 
+def check_spgemm_block_kernel(be):
+    """Column-block value kernel (round 5, `spgemm_block`): rows of C that are dense, or have more lists than the flat kernel's shapes
+    hold, accumulate per (row, column block) in a direct-indexed LDS accumulator, with the pieces of every list taken from an index of
+    B.  Cases: k not a multiple of the block width, blocks with no entry of a row, an A row of 2500 lists (three chunks of lists into
+    one accumulator), a row that is 100 % dense, lists that end B's arrays (guarded 16-byte loads), empty B rows inside an A row,
+    numeric reuse (the index of B is kept), 64-bit offsets and fp32.  Block widths 256 (many blocks), 4096 and the default."""
+    rng = np.random.default_rng(23)
+    n, k = 2600, 9000 + 37
+    lens = rng.integers(0, 40, size=n); lens[:6] = (k, 3000, 2500, 0, 1, 700); lens[-1] = 1501
+    rm = np.zeros(n + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    ent = np.concatenate([np.sort(rng.choice(k, size=l, replace=False)) for l in lens]).astype(np.int32)
+    B = oracle.Crs(n, k, rm, ent, 1 + 49 * rng.random(rm[-1]))
+    rows = [np.arange(0, 2500),                          # 2500 lists, 100 % dense (contains row 0 of B)
+            np.array([1, 2, 5, n - 1]),                  # four long lists: ~50 % dense
+            np.arange(6, 700),                           # 694 short lists (more than the flat shapes take), ~2 entries per 256-column block ...
+            np.array([3, 4]), np.array([n - 1]), np.array([], dtype=np.int64),
+            np.sort(rng.choice(n, size=600, replace=False))]
+    arm = np.zeros(len(rows) + 1, dtype=np.int64); np.cumsum([len(r) for r in rows], out=arm[1:])
+    A = oracle.Crs(len(rows), n, arm, np.concatenate(rows).astype(np.int32), 1 + 49 * rng.random(arm[-1]))
+    try:
+        for w, odt, vdt in ((256, np.int32, np.float64), (4096, np.int64, np.float64), (16384, np.int32, np.float32), (256, np.int64, np.float32)):
+            kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block_w", w))
+            check_spgemm(be, A, B, offset_dtype=odt, value_dtype=vdt)
+        # the rows really went there (and stay away with the knob off: same C)
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block_w", 1024))
+        for on in (1, 0):
+            kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block", on))
+            kh = kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+            Ad, Bd = dev(be, A), dev(be, B)
+            Cm = kk.spgemm_symbolic(kh, Ad, False, Bd, False)
+            kk.spgemm_numeric(kh, Ad, False, Bd, False, Cm)
+            assert (kh.get_spgemm_handle().get(16) >= 3) == bool(on), kh.get_spgemm_handle().get(16)
+            rm_, ent_, val_ = Cm.to_host()
+            ok, msg = oracle.is_same_matrix(oracle.Crs(A.nrows, B.ncols, rm_.astype(np.int64), ent_, val_.astype(np.float64)), oracle.spgemm(A, B))
+            assert ok, msg
+            kh.destroy_spgemm_handle()
+    finally:
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block", 1))
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block_w", 16384))
+
+
 def check_spgemm_val_steps(be):
-    """Flat value kernel with 2 and 3 steps of a window's product walk in flight (`spgemm_val_steps`): rows of C whose windows hold several
+    """Flat value kernel with its vector walk (`spgemm_val_steps` 0: units of eight entries of one list, 16-byte loads) and with 2 and 3
+    steps of a window's scalar product walk in flight: rows of C whose windows hold several
     steps of products (lists that overlap heavily), in the lightest shape (128 work-items: a step is 512 products), the 512-work-item shape
     (more than 256 lists) and next to rows whose windows end inside the first step.  The last row of B is one of the long lists and
     nnz(B) is not a multiple of 4: the bitmap kernels' 16-byte walk takes the array's last, partial quad from its tail registers."""
@@ -467,7 +509,7 @@ def check_spgemm_val_steps(be):
         ent = np.concatenate([np.sort(rng.choice(k, size=l, replace=False)) for l in lens]).astype(np.int32)
         return oracle.Crs(n, k, rm, ent, 1 + 49 * rng.random(rm[-1]))
     try:
-        for steps, last_len in ((2, 6001), (3, 6002), (1, 6003)):
+        for steps, last_len in ((0, 6001), (0, 6007), (2, 6001), (3, 6002), (1, 6003)):      # 0 = the vector walk (units of 8 entries of one list; the last list ends the arrays)
             B = make_b(last_len)
             assert B.nnz % 4 == last_len % 4 != 0
             kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_val_steps", steps))

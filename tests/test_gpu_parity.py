@@ -552,6 +552,10 @@ def test_spgemm_pool_returns_with_the_last_handle(be):
     pc.check_spgemm_pool_release(be)
 
 
+def test_spgemm_column_block_value_kernel(be):
+    pc.check_spgemm_block_kernel(be)
+
+
 def test_spgemm_value_walk_steps_in_flight(be):
     pc.check_spgemm_val_steps(be)
 

@@ -6,12 +6,12 @@ export TMPDIR=/tmp KKAMD_LIBRARY=libkkamd_ablate.so KK_REPS=1
 cd /tmp
 for d in ${2:-0}; do
   rm -rf /tmp/abl_$d
-  KK_DEFAULTS=spgemm_debug=$d timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl_$d -o p -- python $R/tools/bench_spgemm_quick.py $SCALE > /dev/null 2>&1
+  KK_DEFAULTS=spgemm_debug=$d${KK_EXTRA:+,$KK_EXTRA} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl_$d -o p -- python $R/tools/bench_spgemm_quick.py $SCALE > /dev/null 2>&1
   echo "== spgemm_debug=$d" >> $OUT
   python - >> $OUT <<PY
 import csv,glob
 f=glob.glob("/tmp/abl_$d/**/p_kernel_stats.csv",recursive=True)
-for r in list(csv.DictReader(open(f[0])))[:8] if f else []: print("%-70s calls %s avg %.2f ms" % (r["Name"][:70], r["Calls"], float(r["AverageNs"])/1e6))
+for r in list(csv.DictReader(open(f[0])))[:9] if f else []: print("%-70s calls %s avg %.2f ms" % (r["Name"][:70], r["Calls"], float(r["AverageNs"])/1e6))
 PY
 done
 cat $OUT
