@@ -113,7 +113,8 @@ struct SpgemmTuning {
                                   // kQuadNnz entries (the bin's list is split when it mixes sizes; 7-pt FD 150^3: symbolic 3.54 -> 1.94 ms, numeric 4.24 -> 1.97), 2 = for every row of the
                                   // bin (waves with a larger row do their four rows one after the other: 27-pt FE 100^3 numeric 4.04 -> 5.03 ms, which is why 1 is the default), 0 = never
   int emit_sort      = 1;         // entries(C) of the dense-bin rows with at most kEmitSortCap products: sorted in LDS, 256 work-items per row (0 = the bitmap kernel)
-  int val_steps      = 1;         // steps of a window's product walk a work-item of the flat value kernel keeps in flight (1..3)
+  int val_steps      = 0;         // the flat value kernel's product walk: 0 = vector walk (units of eight entries of one list, 16-byte loads; default: R-MAT scale 20 reuse
+                                  // 159.7 -> 149.4 ms), 1..3 = scalar walk with that many steps of a window in flight
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
   int col_quads      = 4;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads, 4 or 8 per work-item and step (0 = one 4-byte load per product)
@@ -121,8 +122,9 @@ struct SpgemmTuning {
   int val_kernel     = 2;         // dense rows with short A rows: 2 = flat walk with the lists cut per window group (default), 1 = wave-per-list streaming
   int block          = 1;         // rows of C that are dense (or have more lists than the flat kernel's shapes) through the column-block value kernel (0 = windows only)
   int block_w        = 16384;     // its columns per block (a power of two; 16384 = 128 KB of fp64 sums)
-  int block_min_pct  = 12;        // ... rows with at least this percentage of the columns (R-MAT scale 20: 12 % = rows above 125 K entries) ...
+  int block_min_pct  = 20;        // ... rows with at least this percentage of the columns (R-MAT scale 20 reuse: 6 %: 136.5 ms, 9 %: 122.3, 12 %: 117.1, 18-25 %: 115.9) ...
   int block_la_pct   = 3;         // ... or at least this percentage and more than kValLa lists
+  int list_staged    = 1;         // symbolic: the entry lists kept for the numeric phase are written wave by wave, 64 consecutive words per round (0 = every lane writes its own run)
   int nt             = 0;         // value kernels of the dense rows: entries(C) / values(C) through nontemporal loads / stores
   int sort_rows      = 1;         // the row lists of the dense kernels are ordered by size, largest first (0 = the order the binning left)
   int pool_keep      = 0;         // 1 = the process-wide store of bitmaps / entry lists outlives the last handle (hosts that run large products back to back,
@@ -231,11 +233,17 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_long_kernel(int64_t m, co
 template <class OffT>
 __global__ __launch_bounds__(kBlock) void rows_sorted_kernel(int64_t n, const OffT* __restrict__ rm,
                                                              const int32_t* __restrict__ ent, int* __restrict__ unsorted) {
-  const int lane = threadIdx.x & 7;
+  // the entries are STREAMED (coalesced: a work-item per pair of neighbours); a descent is fine when it crosses a row boundary, which a
+  // binary search of the row map decides -- once per row on sorted input.  (8 lanes per row read the array at 35 GB/s: 1.9 ms of every
+  // symbolic phase on R-MAT scale 20.)
+  const int64_t nnz = n > 0 ? (int64_t)rm[n] : 0;
   bool bad = false;
-  for (int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 8; row < n; row += (int64_t)gridDim.x * (kBlock / 8)) {
-    const int64_t e = (int64_t)rm[row + 1];
-    for (int64_t j = (int64_t)rm[row] + lane; j + 1 < e; j += 8) bad |= ent[j] > ent[j + 1];
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j + 1 < nnz; j += (int64_t)gridDim.x * kBlock) {
+    if (ent[j] > ent[j + 1]) {
+      int64_t lo = 0, hi = n;                       // is j + 1 the first entry of a row?  (first row whose start is >= j + 1)
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)rm[mid] < j + 1) lo = mid + 1; else hi = mid; }
+      bad |= !(lo <= n && (int64_t)rm[lo] == j + 1);
+    }
   }
   if (bad) *unsorted = 1;
 }
@@ -610,6 +618,13 @@ __device__ __forceinline__ int wave_last_lane_i32(int v) {
   return __shfl(v, 63, 64);
 #else
   return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
+__device__ __forceinline__ int wave_first_lane_i32(int v) {
+#ifdef KK_EMU
+  return __shfl(v, 0, 64);
+#else
+  return __builtin_amdgcn_readlane(v, 0);
 #endif
 }
 __device__ __forceinline__ int wave_sum_i32(int v, int lane) { return wave_last_lane_i32(wave_inclusive_scan_i32(v, lane)); }
@@ -1047,6 +1062,7 @@ struct BitmapStore {                 // where the symbolic count kernel may leav
   long long* pool_off = nullptr;     // [m], -1 = not written
   unsigned long long* pool_cursor = nullptr;
   long long pool_cap = 0;
+  int list_staged = 1;               // the lists are written wave by wave, 64 consecutive words per round (0 = every lane its own run of words)
 };
 template <class OffT, bool EMIT, int Q = 4>
 __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const int32_t* __restrict__ perm,
@@ -1067,7 +1083,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
   const int t       = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
   int64_t total     = 0;
-  int ch_a = 0, ch_z = 0, ch_excl = 0;                             // (count only) the work-item's run of words in the last window and its offset
+  int ch_a = 0, ch_z = 0, ch_excl = 0, ch_per = 0;                 // (count only) the work-item's run of words in the last window, its offset and the words per work-item
   (void)sg_log2;
   for (int64_t c0 = 0; c0 < k; c0 += win_bits) {
     const int nbits  = (int)((k - c0 < (int64_t)win_bits) ? k - c0 : (int64_t)win_bits);
@@ -1116,7 +1132,7 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
         for (int wd = a; wd < z; ++wd) cnt += __popcll(bm[wd]);
         int tot;
         const int excl = block_exclusive_scan_n<int, kDenseBlock>(cnt, &tot, s_wave);
-        ch_a = a; ch_z = z; ch_excl = excl;
+        ch_a = a; ch_z = z; ch_excl = excl; ch_per = per;
         if (EMIT && !KK_DBG(1)) {
           int64_t pos = (int64_t)rmC[row] + total + excl;
           for (int wd = a; wd < z; ++wd) {
@@ -1179,10 +1195,35 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
       if (poff >= 0) {
         // (staging the list in LDS -- the product walk's scratch -- and writing it out in whole lines, 6144 entries per round, measured
         // slower: dense_cols<false> 70 -> 115 ms on R-MAT scale 20.  Each work-item writes the entries of its run of words where they stand.)
-        int32_t* dst = bs.pool + poff + ch_excl;
-        for (int wd = ch_a; wd < ch_z; ++wd) {
-          kk_u64 v = bm[wd];
-          while (v) { const int bit = __ffsll(v) - 1; *dst++ = (int32_t)((int64_t)wd * 64 + bit); v &= v - 1; }
+        if (bs.list_staged) {
+          // The count gave every work-item a contiguous run of `per` words, so a WAVE holds 64 per consecutive words and its entries
+          // start at the offset of its first lane.  For the emission the wave takes them 64 at a time -- lane l the l-th word of the
+          // round: consecutive LDS words (no bank conflict), a prefix sum of the popcounts on the vector unit, and the lanes' entries
+          // of a round follow each other in the list: on the sparse bitmaps these rows have (one or two bits per word) the 64 lanes of
+          // a store instruction write one or two lines.  (Every lane writing the entries of its own run of `per` words: 64 different
+          // lines per store instruction, 17 of the symbolic phase's 62 ms on R-MAT scale 20.  Passing the wave's entries through a small
+          // wave-private LDS buffer instead serialises the lanes of a wave whose words are dense: 60 -> 232 ms.)
+          const int lane = t & 63;
+          const int per = ch_per;
+          const int wave_w0 = wave_first_lane_i32(ch_a);               // first word of the wave (the runs ascend with the lanes)
+          const int w_end = s_max >> 6;                                // last touched word of the row
+          int run = wave_first_lane_i32(ch_excl);
+          int32_t* dst = bs.pool + poff;
+          for (int i = 0; i < per; ++i) {                              // (uniform)
+            const int wd = wave_w0 + i * 64 + lane;
+            kk_u64 v = wd <= w_end ? bm[wd] : 0ull;
+            const int pc = __popcll(v);
+            const int inc = wave_inclusive_scan_i32(pc, lane);
+            int pos = run + inc - pc;
+            while (v) { const int bit = __ffsll(v) - 1; dst[pos++] = (int32_t)(wd * 64 + bit); v &= v - 1; }
+            run += wave_last_lane_i32(inc);
+          }
+        } else {
+          int32_t* dst = bs.pool + poff + ch_excl;
+          for (int wd = ch_a; wd < ch_z; ++wd) {
+            kk_u64 v = bm[wd];
+            while (v) { const int bit = __ffsll(v) - 1; *dst++ = (int32_t)((int64_t)wd * 64 + bit); v &= v - 1; }
+          }
         }
         if (t == 0) bs.pool_off[row] = poff;
       }
@@ -1596,9 +1637,20 @@ __global__ __launch_bounds__(kSizeClasses) void spgemm_size_scan_kernel(unsigned
 }
 __global__ __launch_bounds__(kBlock) void spgemm_size_scatter_kernel(int64_t n, const int32_t* __restrict__ in, const int64_t* __restrict__ sizes,
                                                                      unsigned* __restrict__ cursor, int32_t* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const int32_t row = in[i];
-    out[atomicAdd(&cursor[size_class_desc(sizes[row])], 1u)] = row;
+  // workgroup-aggregated cursors: a class's rows of this workgroup take their places with one global atomic (the rows of a product
+  // crowd into a few classes: one global atomic per row was 0.43 ms per call on R-MAT scale 20)
+  __shared__ unsigned s_cnt[kSizeClasses], s_base[kSizeClasses];
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += (int64_t)gridDim.x * kBlock) {       // uniform trip count
+    for (int c = threadIdx.x; c < kSizeClasses; c += kBlock) s_cnt[c] = 0;
+    __syncthreads();
+    const int64_t i = i0 + threadIdx.x;
+    int32_t row = 0; int cls = 0; unsigned local = 0;
+    if (i < n) { row = in[i]; cls = size_class_desc(sizes[row]); local = atomicAdd(&s_cnt[cls], 1u); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < kSizeClasses; c += kBlock) s_base[c] = s_cnt[c] ? atomicAdd(&cursor[c], s_cnt[c]) : 0u;
+    __syncthreads();
+    if (i < n) out[s_base[cls] + local] = row;
+    __syncthreads();
   }
 }
 
@@ -2735,7 +2787,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
             if (pool_cap > 0 && hipMalloc((void**)&h->d_pool_off, sizeof(long long) * (size_t)m) == hipSuccess &&
                 hipMemsetAsync(h->d_pool_off, 0xFF, sizeof(long long) * (size_t)m, st) == hipSuccess) {
               h->d_ent_pool = (int32_t*)((char*)h->d_bm_store + got_store); h->pool_cap = pool_cap;
-              bs.pool = h->d_ent_pool; bs.pool_off = h->d_pool_off; bs.pool_cursor = h->d_bm_counter + 1; bs.pool_cap = pool_cap;
+              bs.pool = h->d_ent_pool; bs.pool_off = h->d_pool_off; bs.pool_cursor = h->d_bm_counter + 1; bs.pool_cap = pool_cap; bs.list_staged = g_spgemm.list_staged;
             } else (void)hipGetLastError();
           } else { (void)hipGetLastError(); free_bitmap_store(h); }
         } else (void)hipGetLastError();
@@ -3034,12 +3086,22 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         h->cidx_ready = true;
       }
       const size_t smem = sizeof(VT) << wshift;
-#ifndef KK_EMU
-      KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_block_vals_kernel<OffT, VT, kDenseBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-#endif
       const unsigned* d_bx = h->d_bidx; const unsigned* d_cx = h->d_cidx;
-      KK_LAUNCH((spgemm_block_vals_kernel<OffT, VT, kDenseBlock>), dim3((unsigned)n_blk, (unsigned)nblk), kDenseBlock, smem, st, n_blk, bperm, nblk, wshift, nB, d_bx, d_cx,
-                rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC);
+      // blocks of 16384 columns: one workgroup of 1024 per CU around 128 KB of sums; narrower blocks: 512 work-items, two (or more) workgroups per CU
+#ifndef KK_EMU
+#define KK_BLK_ATTR(NTT) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_block_vals_kernel<OffT, VT, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
+#else
+#define KK_BLK_ATTR(NTT) (void)0
+#endif
+#define KK_BLK(NTT)                                                                                                                          \
+      do {                                                                                                                                   \
+        KK_BLK_ATTR(NTT);                                                                                                                    \
+        KK_LAUNCH((spgemm_block_vals_kernel<OffT, VT, NTT>), dim3((unsigned)n_blk, (unsigned)nblk), NTT, smem, st, n_blk, bperm, nblk, wshift, nB, d_bx, d_cx, \
+                  rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC);                                               \
+      } while (0)
+      if (wshift >= 14) KK_BLK(kDenseBlock); else KK_BLK(kValBlock);
+#undef KK_BLK
+#undef KK_BLK_ATTR
     }
     if (flat_vals && g_spgemm.val_hub_flat) {
       // measured and not kept as the default: A rows above kValLa through the flat kernel, kValLa lists per pass (R-MAT scale 20:
@@ -3209,6 +3271,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_pool_keep") g_spgemm.pool_keep = value != 0;
   else if (k == "spgemm_sort_rows") g_spgemm.sort_rows = value != 0;
   else if (k == "spgemm_nt") g_spgemm.nt = value != 0;
+  else if (k == "spgemm_list_staged") g_spgemm.list_staged = value != 0;
   else if (k == "spgemm_block") g_spgemm.block = value != 0;
   else if (k == "spgemm_block_w") { if (value < 64 || value > 16384 || (value & (value - 1))) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_w: %d is not a power of two in [64, 16384]", value); g_spgemm.block_w = value; }
   else if (k == "spgemm_block_min_pct") { if (value < 0 || value > 100) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_min_pct: 0 .. 100"); g_spgemm.block_min_pct = value; }
