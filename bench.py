@@ -120,9 +120,12 @@ def bench_spmv_mv(kk, torch, A, budget_s, cpu):
             else torch.full((nv, rows), float("nan"), dtype=torch.float64, device="cuda").t()
         h = kk.SPMVHandle("SPMV_DEFAULT")
         fn = lambda: kk.spmv(h, "N", 1.0, A, Xl, 0.0, Y)
-        for _ in range(5): fn()
+        torch.cuda.synchronize(); t_first = time.perf_counter(); fn(); torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t_first) * 1e3            # the handle's first call: analysis (plan creation) + one product
+        for _ in range(4): fn()
         torch.cuda.synchronize()
         r = _fenced(fn, torch.cuda.synchronize, 20)
+        r["first_call_ms"] = round(first_ms, 3); r["plan_create_ms"] = round(first_ms - r["mean_ms"], 3)
         if ref is None: ref = Y.clone()
         else: assert float((Y - ref).abs().max()) == 0.0, "spmv_mv: layouts disagree"
         r.update(GFLOPs=round(2.0 * nnz * nv / r["mean_ms"] / 1e6, 1), achieved_GBps=round(alg / r["mean_ms"] / 1e6, 1),
@@ -164,9 +167,12 @@ def bench_spmv_mv_off_lattice(kk, torch, budget_s):
             Y = torch.zeros(rows, nv, dtype=torch.float64, device="cuda") if layout == "right" else torch.zeros(nv, rows, dtype=torch.float64, device="cuda").t()
             h = kk.SPMVHandle("SPMV_DEFAULT")
             fn = lambda: kk.spmv(h, "N", 1.0, A, Xl, 0.0, Y)
-            for _ in range(3): fn()
+            torch.cuda.synchronize(); t_first = time.perf_counter(); fn(); torch.cuda.synchronize()
+            first_ms = (time.perf_counter() - t_first) * 1e3        # analysis (plan creation, for the matrix-core kernel its tile descriptors) + one product
+            for _ in range(2): fn()
             torch.cuda.synchronize()
             r = _fenced(fn, torch.cuda.synchronize, 20)
+            r["first_call_ms"] = round(first_ms, 3); r["plan_create_ms"] = round(first_ms - r["mean_ms"], 3)
             r.update(frac=round(alg / r["mean_ms"] / 1e6 / HBM_PEAK_GBPS, 4), kernel=_mv_kernel_name(h))
             if h.query("mv5_tiles"): r["mfma_instructions_per_call"] = h.query("mv5_blocks"); r["operand_fill"] = h.query("mv5_fill_permille") / 1000
             case["layout_" + layout] = r
@@ -229,20 +235,15 @@ def bench_rank1_gather_bound(kk, torch):
     return out
 
 
-def bench_spgemm(kk, torch, budget_s, cpu, scale=20):
-    """BASELINE config 4 family: C = A*A on R-MAT (edge factor 16, 64-bit offsets), the largest scale whose C fits one GPU
-    (scale 20: nnz(C) 9.69e9 = 116 GB; scale 22 as specified needs 863 GB).  Per repetition a fresh handle: symbolic, numeric,
-    numeric again on the same handle (the reference's reuse case).  Gather model of SURVEY 8(d): symbolic nnz(A)*4 + mults*4 +
-    2 row maps, numeric nnz(A)*12 + mults*12 + nnz(C)*12 + 2 row maps, against 8 TB/s."""
+def _spgemm_case(kk, torch, scale, t_start, budget_s, reps=3):
+    """C = A*A on R-MAT `scale`: one warm-up, then `reps` repetitions with a fresh handle each (symbolic, numeric, numeric again on the same handle)"""
     import numpy as np
     import oracle
-    t_start = time.perf_counter()
-    if torch.cuda.mem_get_info()[0] < 170 * 2**30: scale = 18
     R = oracle.rmat(scale, 16)
     M = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, offset_dtype=np.int64)
     sync = torch.cuda.synchronize
     runs = []
-    for rep in range(4):                       # repetition 0 is the warm-up (first use of every kernel), not counted
+    for rep in range(reps + 1):                # repetition 0 is the warm-up (first use of every kernel), not counted
         kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle()
         sync(); t0 = time.perf_counter()
         Cm = kk.spgemm_symbolic(kh, M, False, M, False)
@@ -251,7 +252,7 @@ def bench_spgemm(kk, torch, budget_s, cpu, scale=20):
         sync(); t2 = time.perf_counter()
         kk.spgemm_numeric(kh, M, False, M, False, Cm)
         sync(); t3 = time.perf_counter()
-        sh = kh.get_spgemm_handle(); mults = sh.get(1); nnzC = Cm.nnz()
+        sh = kh.get_spgemm_handle(); mults = sh.get(1); nnzC = Cm.nnz(); nblk_rows = sh.get(16)
         if rep > 0: runs.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
         kh.destroy_spgemm_handle(); del Cm
         if runs and time.perf_counter() - t_start > budget_s: break
@@ -263,14 +264,31 @@ def bench_spgemm(kk, torch, budget_s, cpu, scale=20):
            "symbolic_ms": round(sym, 3), "numeric_ms": round(num, 3), "numeric_reuse_ms": round(reuse, 3), "total_ms": round(sym + num, 3),
            "min_ms": {"symbolic": round(min(r[0] for r in runs), 3), "numeric": round(min(r[1] for r in runs), 3), "numeric_reuse": round(min(r[2] for r in runs), 3)},
            "GFLOPs": round(2.0 * mults / (sym + num) / 1e6, 1), "numeric_GFLOPs": round(2.0 * mults / num / 1e6, 1),
+           "rows_through_column_block_kernel": nblk_rows,
            "roofline": {"bound": "hbm", "model": "gather model, SURVEY 8(d)", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "symbolic": {"bytes": b_sym, "achieved": round(b_sym / sym / 1e6, 1), "frac": round(b_sym / sym / 1e6 / HBM_PEAK_GBPS, 4)},
                         "numeric": {"bytes": b_num, "achieved": round(b_num / num / 1e6, 1), "frac": round(b_num / num / 1e6 / HBM_PEAK_GBPS, 4)},
                         "numeric_reuse": {"bytes": b_num - nnzC * 4, "achieved": round((b_num - nnzC * 4) / reuse / 1e6, 1),
                                           "frac": round((b_num - nnzC * 4) / reuse / 1e6 / HBM_PEAK_GBPS, 4)}}}
     del M
+    return out
+
+
+def bench_spgemm(kk, torch, budget_s, cpu, scale=20):
+    """BASELINE config 4 family: C = A*A on R-MAT (edge factor 16, 64-bit offsets), the largest scale whose C fits one GPU
+    (scale 20: nnz(C) 9.69e9 = 116 GB; scale 22 as specified needs 863 GB).  Per repetition a fresh handle: symbolic, numeric,
+    numeric again on the same handle (the reference's reuse case).  Gather model of SURVEY 8(d): symbolic nnz(A)*4 + mults*4 +
+    2 row maps, numeric nnz(A)*12 + mults*12 + nnz(C)*12 + 2 row maps, against 8 TB/s.  The CPU baseline (OpenMP port of SPGEMM_KK)
+    runs on scale 18 -- nnz(C) at scale 20 is 116 GB on the host --, so the GPU's scale-18 times stand beside it ("same_matrix_as_cpu_baseline")."""
+    t_start = time.perf_counter()
+    if torch.cuda.mem_get_info()[0] < 170 * 2**30: scale = 18
+    out = _spgemm_case(kk, torch, scale, t_start, budget_s)
+    if scale != 18:
+        out["same_matrix_as_cpu_baseline"] = _spgemm_case(kk, torch, 18, t_start, budget_s)
     if cpu and time.perf_counter() - t_start < budget_s:
         out["cpu_baseline"] = cpu_baseline_spgemm()
+        ref18 = out.get("same_matrix_as_cpu_baseline", out)
+        out["cpu_baseline"]["gpu_over_cpu_same_matrix"] = round(ref18["GFLOPs"] / out["cpu_baseline"]["value"], 1)
     return out
 
 
@@ -417,6 +435,9 @@ def main():
 
     evs = [(Event(enable_timing=True), Event(enable_timing=True)) for _ in range(args.steps)]
     w0, w1 = Event(enable_timing=True), Event(enable_timing=True)
+    # the handle's FIRST call (outside the W warm-up steps and the timed region): analysis of the matrix (plan creation) + one SpMV
+    device_sync(); t_first = time.perf_counter(); step(w0, w1); device_sync()
+    first_call_ms = (time.perf_counter() - t_first) * 1e3
     for _ in range(args.warmup):
         step(w0, w1)
     barrier()
@@ -597,6 +618,8 @@ def main():
                                                              "FETCH_SIZE x2 per MI355X_MICROARCH.md)" % os.path.relpath(PMC_FILE, ROOT))
             except Exception:
                 pass
+        out["first_call_ms"] = round(first_call_ms, 3)
+        out["plan_create_ms"] = round(first_call_ms - ms_step, 3)      # what a solver that re-creates its handle pays again (the handle-less overloads do)
         if per_call:
             out["per_call_ms"] = {"mean": round(sum(per_call) / len(per_call), 5) if world == 1 else round(ms_step, 5),
                                   "min": round(pc_min, 5), "max": round(pc_max, 5)}

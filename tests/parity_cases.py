@@ -447,6 +447,32 @@ def check_spgemm_pool_release(be):
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 0))
 
 
+def galerkin_operands(n):
+    """27-point FE Laplacian n^3 (n even), P of a 2 x 2 x 2 aggregation (one entry per row), R = P^T and A P (by the oracle)"""
+    A = oracle.laplace3d("FE", n, n, n)
+    i = np.arange(n); c = n // 2
+    ci = (i[:, None, None] // 2) * c * c + (i[None, :, None] // 2) * c + (i[None, None, :] // 2)
+    nf = n ** 3
+    P = oracle.Crs(nf, c ** 3, np.arange(nf + 1, dtype=np.int64), ci.reshape(-1).astype(np.int32), np.ones(nf))
+    order = np.argsort(P.entries, kind="stable")                                       # R = P^T: coarse node -> its (up to) eight fine nodes
+    rrm = np.zeros(c ** 3 + 1, dtype=np.int64); np.cumsum(np.bincount(P.entries, minlength=c ** 3), out=rrm[1:])
+    R = oracle.Crs(c ** 3, nf, rrm, order.astype(np.int32), np.ones(nf))
+    return A, P, R, oracle.spgemm(A, P)
+
+
+def check_spgemm_galerkin(be):
+    """The two products of a Galerkin coarse operator R A P (Test_Sparse_spgemm.hpp:491-504 lists rectangular shapes; the perf driver
+    KokkosSparse_spgemm.cpp:372-423 takes any pair): A P -- 27 products and 1 .. 8 entries per row, a rectangular B with one entry per
+    row -- and R (A P) -- up to 216 products and 27 entries per row: a product whose wave bin mixes the four-rows-per-wave kernels with the
+    one-row kernels.  Structure bit-exact, values to 1e-7, numeric reuse, both offset widths."""
+    A, P, R, AP = galerkin_operands(12)
+    got = check_spgemm(be, A, P)
+    assert got.nnz == AP.nnz
+    C = check_spgemm(be, R, AP, offset_dtype=np.int64)
+    assert 8 <= np.diff(C.row_map).min() and np.diff(C.row_map).max() == 27
+    check_spgemm(be, R, AP, value_dtype=np.float32)
+
+
 def check_spgemm_block_kernel(be):
     """Column-block value kernel (round 5, `spgemm_block`): rows of C that are dense, or have more lists than the flat kernel's shapes
     hold, accumulate per (row, column block) in a direct-indexed LDS accumulator, with the pieces of every list taken from an index of

@@ -191,6 +191,10 @@ def test_spgemm_structure_kept_by_the_symbolic_phase(be):
     pc.check_spgemm_kept_structure(be)
 
 
+def test_spgemm_galerkin_products(be):
+    pc.check_spgemm_galerkin(be)
+
+
 def test_spgemm_column_block_value_kernel(be):
     pc.check_spgemm_block_kernel(be)
 

@@ -552,6 +552,10 @@ def test_spgemm_pool_returns_with_the_last_handle(be):
     pc.check_spgemm_pool_release(be)
 
 
+def test_spgemm_galerkin_products(be):
+    pc.check_spgemm_galerkin(be)
+
+
 def test_spgemm_column_block_value_kernel(be):
     pc.check_spgemm_block_kernel(be)
 
