@@ -122,7 +122,9 @@ struct SpgemmTuning {
   int val_kernel     = 2;         // dense rows with short A rows: 2 = flat walk with the lists cut per window group (default), 1 = wave-per-list streaming
   int block          = 1;         // rows of C that are dense (or have more lists than the flat kernel's shapes) through the column-block value kernel (0 = windows only)
   int block_w        = 16384;     // its columns per block (a power of two; 16384 = 128 KB of fp64 sums)
-  int block_min_pct  = 20;        // ... rows with at least this percentage of the columns (R-MAT scale 20 reuse: 6 %: 136.5 ms, 9 %: 122.3, 12 %: 117.1, 18-25 %: 115.9) ...
+  int items          = 1;         // the column-block class as ITEMS (groups of blocks with a position-indexed accumulator, dense blocks direct); 0 = one workgroup per (row, block)
+  int item_cap       = 6144;      // entries of C per rank item (48 KB of sums; with the 16 KB of packed words two workgroups per CU)
+  int block_min_pct  = 4;         // ... rows with at least this percentage of the columns (R-MAT scale 20 reuse, items: 20 %: 109.0 ms, 9 %: 101.1, 6 %: 98.1, 4 %: 96.7, 3 %: 96.7, 2 %: 99.4, 1 %: 107.7; one workgroup per (row, block): 6 %: 136.5, 12 %: 117.1, 20 %: 115.9) ...
   int block_la_pct   = 3;         // ... or at least this percentage and more than kValLa lists
   int list_staged    = 1;         // symbolic: the entry lists kept for the numeric phase are written wave by wave, 64 consecutive words per round (0 = every lane writes its own run)
   int nt             = 0;         // value kernels of the dense rows: entries(C) / values(C) through nontemporal loads / stores
@@ -2417,6 +2419,164 @@ __global__ __launch_bounds__(NT) void spgemm_block_vals_kernel(int64_t nrows, co
   const int64_t base = (int64_t)rmC[row];
   for (unsigned i = e0 + t; i < e1; i += NT) valC[base + i] = acc[entC[base + i] - c0];
 }
+
+// ITEMS.  The column-block kernel above gives every (row, 16384-column block) a workgroup and 128 KB of sums whatever the block holds;
+// on rows that are 6 .. 12 % dense a block holds one or two thousand entries and the windowed kernels were faster (R-MAT scale 20
+// reuse: 117 ms with the rows above 12 % in blocks, 136.5 with the rows above 6 %).  Here the unit is an ITEM built from the index of
+// the row's entries(C):
+//   * consecutive blocks of a row are grouped while the group holds at most `cap` entries (and at most kItemMaxBlocks blocks): a RANK
+//     item.  Its accumulator is indexed by the entry's POSITION in the row: a packed word per 32 columns of the group -- the columns'
+//     bits in the low half, the number of entries before them in the high half -- turns a product's column into its position with one
+//     8-byte LDS read and a popcount, and the sums leave as one contiguous run of values(C).  16 KB of words + 8 bytes per entry:
+//     two workgroups per CU, and a sparse stretch of a row costs one item, not four;
+//   * a block that alone holds more than `cap` entries (more than 37 % dense) stays a DIRECT item: the column-indexed accumulator.
+// Items are ordered by their first block, so the launch is block-major as before.  (row index in the class, first block | end block << 16)
+constexpr int kItemMaxBlocks = 4;
+__global__ __launch_bounds__(kBlock) void spgemm_items_build_kernel(int64_t nrows, int nblk, const unsigned* __restrict__ cidx, unsigned cap, int fill,
+                                                                   unsigned* __restrict__ n_rank /* [nrows + 1] counts, then offsets */, unsigned* __restrict__ n_direct,
+                                                                   int2* __restrict__ out_rank, int2* __restrict__ out_direct) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= nrows) return;
+  const unsigned* cx = cidx + r * (nblk + 1);
+  unsigned nr = 0, nd = 0;
+  const unsigned o_r = fill ? n_rank[r] : 0u, o_d = fill ? n_direct[r] : 0u;
+  int cb = 0;
+  while (cb < nblk) {
+    const unsigned e0 = cx[cb], e1 = cx[cb + 1];
+    if (e1 == e0) { ++cb; continue; }                                  // no entry of C in this block: no product either
+    if (e1 - e0 > cap) {
+      if (fill) out_direct[o_d + nd] = int2{(int)r, cb | ((cb + 1) << 16)};
+      ++nd; ++cb; continue;
+    }
+    int g1 = cb + 1;
+    while (g1 < nblk && g1 - cb < kItemMaxBlocks && cx[g1 + 1] - e0 <= cap) ++g1;
+    if (fill) out_rank[o_r + nr] = int2{(int)r, cb | (g1 << 16)};
+    ++nr; cb = g1;
+  }
+  if (!fill) { n_rank[r] = nr; n_direct[r] = nd; }
+}
+// counting sort of items by their first block: histogram, (serial) scan of the nblk + 1 counters, scatter
+__global__ __launch_bounds__(kBlock) void spgemm_items_hist_kernel(int64_t n, const int2* __restrict__ items, unsigned* __restrict__ hist) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) atomicAdd(&hist[items[i].y & 0xffff], 1u);
+}
+__global__ void spgemm_items_scan_kernel(int nblk, unsigned* __restrict__ hist) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned run = 0; for (int b = 0; b < nblk; ++b) { const unsigned c = hist[b]; hist[b] = run; run += c; } }
+}
+__global__ __launch_bounds__(kBlock) void spgemm_items_scatter_kernel(int64_t n, const int2* __restrict__ items, unsigned* __restrict__ cursor, int2* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) { const int2 it = items[i]; out[atomicAdd(&cursor[it.y & 0xffff], 1u)] = it; }
+}
+
+template <class OffT, class VT, int NT, bool RANK>
+__global__ __launch_bounds__(NT) void spgemm_item_vals_kernel(const int2* __restrict__ items, const int32_t* __restrict__ perm, int nblk, int wshift, int64_t nB,
+                                                              const unsigned* __restrict__ bidx, const unsigned* __restrict__ cidx,
+                                                              const OffT* __restrict__ rmA, const int32_t* __restrict__ entA, const VT* __restrict__ valA,
+                                                              const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, const VT* __restrict__ valB,
+                                                              int64_t nnzB, const OffT* __restrict__ rmC, const int32_t* __restrict__ entC, VT* __restrict__ valC) {
+  KK_DYN_SMEM(char, smem);                   // RANK: [packed words of kItemMaxBlocks blocks][sums by position];  direct: [sums by column of one block]
+  __shared__ long long s_p0[NT];             // first entry of list a inside the item's columns (index into entries / values of B)
+  __shared__ int s_n[NT];                    // entries of it inside them
+  __shared__ int s_pre[NT + 1];              // unit offsets of the lists
+  __shared__ VT s_av[NT];
+  __shared__ int s_wave[NT / 64];
+  constexpr int UV = 8;
+  const int t = threadIdx.x;
+  const int2 it = items[blockIdx.x];
+  const int64_t r = it.x;
+  const int cb0 = it.y & 0xffff, cb1 = (int)((unsigned)it.y >> 16);
+  const unsigned e0 = cidx[r * (nblk + 1) + cb0], e1 = cidx[r * (nblk + 1) + cb1];
+  const int ne = (int)(e1 - e0);
+  const int64_t row = perm[r];
+  const int64_t base = (int64_t)rmC[row] + e0;
+  const int c0 = cb0 << wshift;
+  kk_u64* rank = reinterpret_cast<kk_u64*>(smem);
+  VT* sums = RANK ? reinterpret_cast<VT*>(smem + ((size_t)kItemMaxBlocks << (wshift - 5)) * 8) : reinterpret_cast<VT*>(smem);
+  if constexpr (RANK) {
+    const int nw = (cb1 - cb0) << (wshift - 5);
+    for (int i = t; i < nw; i += NT) rank[i] = 0ull;
+    for (int i = t; i < ne; i += NT) sums[i] = VT(0);
+    __syncthreads();
+    unsigned* r32 = reinterpret_cast<unsigned*>(rank);
+    for (int i = t; i < ne; i += NT) { const unsigned c = (unsigned)(entC[base + i] - c0); atomicOr(&r32[(c >> 5) * 2], 1u << (c & 31u)); }
+    __syncthreads();
+    // entries before every word: a contiguous run of words per work-item, one workgroup scan
+    const int per = (nw + NT - 1) / NT;
+    const int a = t * per, z = a + per < nw ? a + per : nw;
+    int cnt = 0;
+    for (int w = a; w < z; ++w) cnt += __popc(r32[2 * w]);
+    int tot;
+    int run = block_exclusive_scan_n<int, NT>(cnt, &tot, s_wave);
+    for (int w = a; w < z; ++w) { r32[2 * w + 1] = (unsigned)run; run += __popc(r32[2 * w]); }
+  } else {
+    const int W = 1 << wshift;
+    for (int i = t; i < W; i += NT) sums[i] = VT(0);
+  }
+  const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
+  const unsigned* bx0 = bidx + (int64_t)cb0 * nB;
+  const unsigned* bx1 = bidx + (int64_t)cb1 * nB;
+  for (int64_t ach = 0; ach < la; ach += NT) {
+    const int la_c = (int)(la - ach < NT ? la - ach : NT);
+    int n_in = 0;
+    if (t < la_c) {
+      const int32_t kc = entA[a0 + ach + t];
+      const unsigned f = bx0[kc], l = bx1[kc];
+      n_in = (int)(l - f);
+      s_p0[t] = (long long)rmB[kc] + f; s_n[t] = n_in; s_av[t] = valA[a0 + ach + t];
+    }
+    int tot;
+    const int excl = block_exclusive_scan_n<int, NT>((n_in + UV - 1) / UV, &tot, s_wave);    // (its barriers also publish the accumulator / the words)
+    if (t < la_c) s_pre[t] = excl;
+    if (t == 0) s_pre[la_c] = tot;
+    __syncthreads();
+    auto find = [&](int q) {               // largest a in [0, la_c) with pre[a] <= q
+      int lo = 0, len2 = la_c;
+      while (len2 > 1) { const int half = len2 >> 1; lo += (s_pre[lo + half] <= q) ? half : 0; len2 -= half; }
+      return lo;
+    };
+    for (int ubase = 0; ubase < tot; ubase += NT) {
+      const int u = ubase + t;
+      int cnt_u = 0;
+      long long first = 0;
+      VT ava = VT(0);
+      if (u < tot) {
+        const int a = find(u);
+        const int k0 = (u - s_pre[a]) * UV;
+        cnt_u = s_n[a] - k0; cnt_u = cnt_u < UV ? cnt_u : UV;
+        first = s_p0[a] + k0;
+        ava = s_av[a];
+      }
+      int cc[UV];
+      VT vv[UV];
+      if (first + UV <= (long long)nnzB) {
+        typedef int kk_i4 __attribute__((vector_size(16)));
+        kk_i4 c4[UV / 4];
+        KK_UNROLL
+        for (int e = 0; e < UV / 4; ++e) __builtin_memcpy(&c4[e], entB + first + 4 * e, 16);
+        KK_UNROLL
+        for (int e = 0; e < UV; ++e) vv[e] = valB[first + e];
+        KK_UNROLL
+        for (int e = 0; e < UV; ++e) cc[e] = c4[e / 4][e % 4];
+      } else {
+        KK_UNROLL
+        for (int e = 0; e < UV; ++e) { const long long j = first + e < (long long)nnzB ? first + e : (long long)nnzB - 1; cc[e] = entB[j]; vv[e] = valB[j]; }
+      }
+      KK_UNROLL
+      for (int e = 0; e < UV; ++e)
+        if (e < cnt_u) {
+          const unsigned c = (unsigned)(cc[e] - c0);
+          if constexpr (RANK) {
+            const kk_u64 pw = rank[c >> 5];
+            const int pos = (int)(pw >> 32) + __popc((unsigned)pw & ((1u << (c & 31u)) - 1u));
+            KK_ATOMIC_FADD(&sums[pos], ava * vv[e]);
+          } else KK_ATOMIC_FADD(&sums[c], ava * vv[e]);
+        }
+    }
+    __syncthreads();                       // the next chunk of lists overwrites the descriptors; after the last one: the sums are complete
+  }
+  if constexpr (RANK) { for (int i = t; i < ne; i += NT) valC[base + i] = sums[i]; }
+  else { for (int i = t; i < ne; i += NT) valC[base + i] = sums[entC[base + i] - c0]; }
+}
 // ------------------------------------------------------------------------------------------------
 }  // namespace kk
 
@@ -2469,6 +2629,7 @@ struct kkamd_spgemm_handle {
   int64_t n_dense_block = 0;
   unsigned* d_bidx = nullptr; const void* bidx_rmB = nullptr; const void* bidx_entB = nullptr; int64_t bidx_nB = 0; int bidx_nblk = 0, bidx_wshift = 0;
   unsigned* d_cidx = nullptr; bool cidx_ready = false;
+  int2* d_items_rank = nullptr; int2* d_items_direct = nullptr; int64_t n_items_rank = 0, n_items_direct = 0; bool items_ready = false;
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -2861,7 +3022,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
       int32_t* seg = h->d_perm + h->num_off.off[4];
       // the tail of the bin: rows for the column-block value kernel (dense rows, and rows with more lists than the flat shapes hold)
-      h->n_dense_block = 0; h->cidx_ready = false;
+      h->n_dense_block = 0; h->cidx_ready = false; h->items_ready = false;
       if (g_spgemm.block && h->dense_lds && g_spgemm.val_kernel == 2 && k >= 64) {
         int wshift = 6;
         while ((1 << wshift) < g_spgemm.block_w) ++wshift;
@@ -3087,6 +3248,64 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       }
       const size_t smem = sizeof(VT) << wshift;
       const unsigned* d_bx = h->d_bidx; const unsigned* d_cx = h->d_cidx;
+      const bool use_items = g_spgemm.items && nblk <= 4096 && wshift >= 5;
+      if (use_items && !h->items_ready) {
+        // the class's items, once per symbolic phase (they depend on the structure of C only): count, scan, fill, order by first block
+        if (h->d_items_rank) { (void)hipFree(h->d_items_rank); h->d_items_rank = nullptr; }
+        if (h->d_items_direct) { (void)hipFree(h->d_items_direct); h->d_items_direct = nullptr; }
+        h->n_items_rank = 0; h->n_items_direct = 0;
+        DevBuf nr_b, nd_b, hist_b, tmp_r, tmp_d;
+        KK_HIP(nr_b.alloc(sizeof(unsigned) * (size_t)(n_blk + 1))); KK_HIP(nd_b.alloc(sizeof(unsigned) * (size_t)(n_blk + 1)));
+        unsigned* d_nr = nr_b.as<unsigned>(); unsigned* d_nd = nd_b.as<unsigned>();
+        KK_HIP(hipMemsetAsync(d_nr, 0, sizeof(unsigned) * (size_t)(n_blk + 1), st)); KK_HIP(hipMemsetAsync(d_nd, 0, sizeof(unsigned) * (size_t)(n_blk + 1), st));
+        const unsigned cap_items = (unsigned)g_spgemm.item_cap;
+        const unsigned bgrid = (unsigned)ceil_div(n_blk, kBlock);
+        KK_LAUNCH(spgemm_items_build_kernel, bgrid, kBlock, 0, st, n_blk, nblk, d_cx, cap_items, 0, d_nr, d_nd, (int2*)nullptr, (int2*)nullptr);
+        if ((rc = exclusive_scan_inplace<unsigned>(d_nr, n_blk + 1, st))) return rc;
+        if ((rc = exclusive_scan_inplace<unsigned>(d_nd, n_blk + 1, st))) return rc;
+        unsigned h_tot[2] = {0, 0};
+        KK_HIP(hipMemcpyAsync(&h_tot[0], d_nr + n_blk, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        KK_HIP(hipMemcpyAsync(&h_tot[1], d_nd + n_blk, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+        KK_HIP(tmp_r.alloc(sizeof(int2) * (size_t)(h_tot[0] ? h_tot[0] : 1))); KK_HIP(tmp_d.alloc(sizeof(int2) * (size_t)(h_tot[1] ? h_tot[1] : 1)));
+        KK_HIP(hipMalloc((void**)&h->d_items_rank, sizeof(int2) * (size_t)(h_tot[0] ? h_tot[0] : 1)));
+        KK_HIP(hipMalloc((void**)&h->d_items_direct, sizeof(int2) * (size_t)(h_tot[1] ? h_tot[1] : 1)));
+        int2* t_r = tmp_r.as<int2>(); int2* t_d = tmp_d.as<int2>();
+        KK_LAUNCH(spgemm_items_build_kernel, bgrid, kBlock, 0, st, n_blk, nblk, d_cx, cap_items, 1, d_nr, d_nd, t_r, t_d);
+        KK_HIP(hist_b.alloc(sizeof(unsigned) * (size_t)(nblk + 1)));
+        unsigned* d_hist = hist_b.as<unsigned>();
+        for (int which = 0; which < 2; ++which) {
+          const int64_t n_it = h_tot[which];
+          if (!n_it) continue;
+          const int2* src = which == 0 ? t_r : t_d; int2* dst = which == 0 ? h->d_items_rank : h->d_items_direct;
+          KK_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * (size_t)(nblk + 1), st));
+          KK_LAUNCH(spgemm_items_hist_kernel, (unsigned)ceil_div(n_it, kBlock), kBlock, 0, st, n_it, src, d_hist);
+          KK_LAUNCH(spgemm_items_scan_kernel, 1, 64, 0, st, nblk, d_hist);
+          KK_LAUNCH(spgemm_items_scatter_kernel, (unsigned)ceil_div(n_it, kBlock), kBlock, 0, st, n_it, src, d_hist, dst);
+        }
+        KK_HIP(hipStreamSynchronize(st));              // the scratch buffers go out of scope
+        h->n_items_rank = h_tot[0]; h->n_items_direct = h_tot[1]; h->items_ready = true;
+        if (h->verbose) KK_VERBOSE("\tkkamd spgemm numeric: column-block class: %lld rows as %lld position-indexed items (<= %u entries, <= %d blocks) and %lld column-indexed blocks\n",
+                                   (long long)n_blk, (long long)h->n_items_rank, cap_items, kItemMaxBlocks, (long long)h->n_items_direct);
+      }
+      if (use_items) {
+        const int2* d_ir = h->d_items_rank; const int2* d_id = h->d_items_direct;
+        if (h->n_items_direct) {
+#ifndef KK_EMU
+          KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_item_vals_kernel<OffT, VT, kDenseBlock, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+#endif
+          KK_LAUNCH((spgemm_item_vals_kernel<OffT, VT, kDenseBlock, false>), (unsigned)h->n_items_direct, kDenseBlock, smem, st, d_id, bperm, nblk, wshift, nB, d_bx, d_cx,
+                    rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC);
+        }
+        if (h->n_items_rank) {
+          const size_t smem_r = (((size_t)kItemMaxBlocks << (wshift - 5)) * 8) + sizeof(VT) * (size_t)g_spgemm.item_cap;
+#ifndef KK_EMU
+          KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_item_vals_kernel<OffT, VT, kValBlock, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r));
+#endif
+          KK_LAUNCH((spgemm_item_vals_kernel<OffT, VT, kValBlock, true>), (unsigned)h->n_items_rank, kValBlock, smem_r, st, d_ir, bperm, nblk, wshift, nB, d_bx, d_cx,
+                    rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC);
+        }
+      } else {
       // blocks of 16384 columns: one workgroup of 1024 per CU around 128 KB of sums; narrower blocks: 512 work-items, two (or more) workgroups per CU
 #ifndef KK_EMU
 #define KK_BLK_ATTR(NTT) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_block_vals_kernel<OffT, VT, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem))
@@ -3102,6 +3321,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       if (wshift >= 14) KK_BLK(kDenseBlock); else KK_BLK(kValBlock);
 #undef KK_BLK
 #undef KK_BLK_ATTR
+      }
     }
     if (flat_vals && g_spgemm.val_hub_flat) {
       // measured and not kept as the default: A rows above kValLa through the flat kernel, kValLa lists per pass (R-MAT scale 20:
@@ -3273,6 +3493,8 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_nt") g_spgemm.nt = value != 0;
   else if (k == "spgemm_list_staged") g_spgemm.list_staged = value != 0;
   else if (k == "spgemm_block") g_spgemm.block = value != 0;
+  else if (k == "spgemm_items") g_spgemm.items = value != 0;
+  else if (k == "spgemm_item_cap") { if (value < 64 || value > 16384) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_item_cap: 64 .. 16384"); g_spgemm.item_cap = value; }
   else if (k == "spgemm_block_w") { if (value < 64 || value > 16384 || (value & (value - 1))) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_w: %d is not a power of two in [64, 16384]", value); g_spgemm.block_w = value; }
   else if (k == "spgemm_block_min_pct") { if (value < 0 || value > 100) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_min_pct: 0 .. 100"); g_spgemm.block_min_pct = value; }
   else if (k == "spgemm_block_la_pct") { if (value < 0 || value > 100) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_la_pct: 0 .. 100"); g_spgemm.block_la_pct = value; }
@@ -3311,6 +3533,8 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (h->d_hub_multi) (void)hipFree(h->d_hub_multi);
   if (h->d_bidx) (void)hipFree(h->d_bidx);
   if (h->d_cidx) (void)hipFree(h->d_cidx);
+  if (h->d_items_rank) (void)hipFree(h->d_items_rank);
+  if (h->d_items_direct) (void)hipFree(h->d_items_direct);
   delete h;
   // the last handle gone: the pooled store (GBs) goes back to the device unless the host asked to keep it ("spgemm_pool_keep")
   bool last = false;
@@ -3339,7 +3563,7 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
   h->m = m; h->n = n; h->k = k; h->offset_type = offset_type; h->rmA = d_row_mapA; h->rmB = d_row_mapB;
   h->symbolic_called = false; h->numeric_called = false; h->numeric_bins_ready = false; h->entries_valid = false;
   if (h->d_bidx) { (void)hipFree(h->d_bidx); h->d_bidx = nullptr; }     // a new symbolic phase may bring another B in the same arrays
-  h->cidx_ready = false; h->n_dense_block = 0;
+  h->cidx_ready = false; h->items_ready = false; h->n_dense_block = 0;
   kk::free_bitmap_store(h); h->bitmaps_used = 0;
   h->c_nnz = 0; h->mults = 0; h->max_row_flops = 0; h->max_row_nnz = 0;
   // empty product: zero row_map (:100-107; the rocSPARSE wrapper memsets too)
@@ -3496,7 +3720,9 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 13: *value = h->bm_stored; break;
     case 14: *value = h->pooled_used; break;
     case 15: *value = h->sorted_used; break;
-    case 16: *value = h->n_dense_block; break;       // rows of the last numeric call's bins that take the column-block value kernel
+    case 16: *value = h->n_dense_block; break;
+    case 17: *value = h->n_items_rank; break;        // ... of which as position-indexed items / column-indexed blocks
+    case 18: *value = h->n_items_direct; break;       // rows of the last numeric call's bins that take the column-block value kernel
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);
   }
   return KKAMD_OK;

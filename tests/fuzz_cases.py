@@ -34,6 +34,10 @@ def run(be, budget, seed0=0, max_cases=None, kinds=None):
         if kinds is not None and kind not in kinds: continue
         odt = np.int64 if rng.random() < 0.5 else np.int32
         vdt = np.float32 if rng.random() < 0.3 else np.float64
+        if kind in (0, 1, 2, 6):    # SpGEMM kinds: the column-block class under random block widths, item capacities and forms (round 5)
+            spgemm_knobs = {b"spgemm_block_w": int(rng.choice([64, 256, 1024, 16384, 16384])), b"spgemm_item_cap": int(rng.choice([64, 300, 6144, 6144])),
+                            b"spgemm_items": int(rng.choice([0, 1, 1])), b"spgemm_block_min_pct": int(rng.choice([1, 4, 20])), b"spgemm_val_steps": int(rng.choice([0, 0, 1]))}
+            for k_, v_ in spgemm_knobs.items(): kk._capi.check(be.lib, be.lib.kkamd_set_default(k_, v_))
         try:
             if kind == 0:      # SpGEMM, skewed: few long rows of A against hub rows of B
                 n = int(rng.integers(50, 400)); k = int(rng.integers(3000, 60000))
@@ -127,6 +131,10 @@ def run(be, budget, seed0=0, max_cases=None, kinds=None):
         except Exception as ex:
             print("FAILED case %d (seed %d, kind %d): %r" % (case - 1, seed0 + case - 1, kind, ex), flush=True)
             raise
+        finally:
+            if kind in (0, 1, 2, 6):
+                for k_, v_ in ((b"spgemm_block_w", 16384), (b"spgemm_item_cap", 6144), (b"spgemm_items", 1), (b"spgemm_block_min_pct", 4), (b"spgemm_val_steps", 0)):
+                    kk._capi.check(be.lib, be.lib.kkamd_set_default(k_, v_))
     return n_ok, per_kind, seed0 + case - 1
 
 

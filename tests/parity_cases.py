@@ -493,9 +493,17 @@ def check_spgemm_block_kernel(be):
     arm = np.zeros(len(rows) + 1, dtype=np.int64); np.cumsum([len(r) for r in rows], out=arm[1:])
     A = oracle.Crs(len(rows), n, arm, np.concatenate(rows).astype(np.int32), 1 + 49 * rng.random(arm[-1]))
     try:
-        for w, odt, vdt in ((256, np.int32, np.float64), (4096, np.int64, np.float64), (16384, np.int32, np.float32), (256, np.int64, np.float32)):
+        # items: groups of blocks with a position-indexed accumulator (cap: entries per group; 64 forces the dense blocks to stay column-indexed
+        # items next to groups), or (items 0) one workgroup per (row, block)
+        for w, odt, vdt, items, cap in ((256, np.int32, np.float64, 1, 6144), (256, np.int32, np.float64, 1, 64), (256, np.int64, np.float64, 1, 200),
+                                        (4096, np.int64, np.float64, 1, 1000), (16384, np.int32, np.float32, 1, 6144), (256, np.int64, np.float32, 1, 100),
+                                        (256, np.int32, np.float64, 0, 6144), (4096, np.int64, np.float32, 0, 6144)):
             kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block_w", w))
+            kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_items", items))
+            kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_item_cap", cap))
             check_spgemm(be, A, B, offset_dtype=odt, value_dtype=vdt)
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_item_cap", 100))
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_items", 1))
         # the rows really went there (and stay away with the knob off: same C)
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block_w", 1024))
         for on in (1, 0):
@@ -505,6 +513,7 @@ def check_spgemm_block_kernel(be):
             Cm = kk.spgemm_symbolic(kh, Ad, False, Bd, False)
             kk.spgemm_numeric(kh, Ad, False, Bd, False, Cm)
             assert (kh.get_spgemm_handle().get(16) >= 3) == bool(on), kh.get_spgemm_handle().get(16)
+            if on: assert kh.get_spgemm_handle().get(17) + kh.get_spgemm_handle().get(18) > 0, (kh.get_spgemm_handle().get(17), kh.get_spgemm_handle().get(18))
             rm_, ent_, val_ = Cm.to_host()
             ok, msg = oracle.is_same_matrix(oracle.Crs(A.nrows, B.ncols, rm_.astype(np.int64), ent_, val_.astype(np.float64)), oracle.spgemm(A, B))
             assert ok, msg
@@ -512,6 +521,8 @@ def check_spgemm_block_kernel(be):
     finally:
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block", 1))
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block_w", 16384))
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_items", 1))
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_item_cap", 6144))
 
 
 def check_spgemm_val_steps(be):
