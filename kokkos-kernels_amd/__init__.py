@@ -37,15 +37,31 @@ def lib():
         if not _os.path.exists(LIB_PATH):
             raise RuntimeError("libkkamd.so is missing (%s): run __graft_entry__.build(); "
                                "kokkos-kernels_amd has no CPU fallback" % LIB_PATH)
-        # torch first: its wheel carries its own HIP runtime, and a process that maps libkkamd.so (linked against /opt/rocm's) before
-        # torch ends up with a runtime that finds no device ("no ROCm-capable device is detected" from the first kkamd call --
-        # seen with `python __graft_entry__.py smoke`, which builds, loads the library and only then imports torch)
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # Load order: torch's wheel carries its own HIP runtime, and a process that maps libkkamd.so (linked against /opt/rocm's) BEFORE
+        # torch ends up with a runtime that finds no device ("no ROCm-capable device is detected" from the first kkamd call -- seen with
+        # `python __graft_entry__.py smoke`, which builds, loads the library and only then imports torch).  torch is imported first only
+        # when this process uses it anyway (already imported, or KKAMD_IMPORT_TORCH=1 / the torch backend asks for it): a host without
+        # torch pays nothing, and a process in the bad order gets an error that names the cause (device_check below).
+        import sys as _sys
+        if "torch" not in _sys.modules and _os.environ.get("KKAMD_IMPORT_TORCH", "") == "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         _lib = _capi.bind(_C.CDLL(LIB_PATH))
     return _lib
+
+
+def device_check():
+    """Raises with the load-order explanation when the library's HIP runtime sees no device although the machine has one."""
+    import ctypes as C
+    name = C.create_string_buffer(64); gfx = C.c_int(0); cus = C.c_int(0)
+    rc = lib().kkamd_device_info(name, 64, C.byref(gfx), C.byref(cus))
+    if rc != 0 or cus.value <= 0:
+        raise RuntimeError("libkkamd.so sees no GPU (%s).  If this process also uses PyTorch-ROCm, torch must be imported BEFORE the library is "
+                           "loaded (its wheel carries its own HIP runtime; see INTEGRATION.md, 'load order'): import torch first, or set "
+                           "KKAMD_IMPORT_TORCH=1." % lib().kkamd_last_error().decode(errors="replace"))
+    return name.value.decode(), bool(gfx.value), cus.value
 
 
 from .sparse import (CrsMatrix, SPMVHandle, KokkosKernelsHandle, spmv, spmv_struct, sort_and_merge_matrix, transpose_matrix, spgemm_symbolic, spgemm_numeric, spgemm,  # noqa: E402,F401

@@ -88,6 +88,8 @@ constexpr int kValLa2     = 1024;     // ... of the flat value kernel's second s
 constexpr int kValLong    = 128;      // B rows at least this long are streamed by a whole wave
 constexpr int kHubLa      = 4096;     // A rows up to this long keep cursor + next column in LDS (hub value kernel)
 
+constexpr int kItemMaxBlocks = 4;     // column blocks per rank item (default of the knob spgemm_item_blocks)
+
 struct SpgemmTuning {
   int win_bits       = 1 << 20;   // columns per LDS bitmap window (128 KB); rows wider than this take several passes
   int val_cap        = kValCap;   // C entries per value window
@@ -123,6 +125,7 @@ struct SpgemmTuning {
   int block          = 1;         // rows of C that are dense (or have more lists than the flat kernel's shapes) through the column-block value kernel (0 = windows only)
   int block_w        = 16384;     // its columns per block (a power of two; 16384 = 128 KB of fp64 sums)
   int items          = 1;         // the column-block class as ITEMS (groups of blocks with a position-indexed accumulator, dense blocks direct); 0 = one workgroup per (row, block)
+  int item_blocks    = kItemMaxBlocks;   // column blocks per rank item at most (4 x 16384 columns = 16 KB of packed words)
   int item_cap       = 6144;      // entries of C per rank item (48 KB of sums; with the 16 KB of packed words two workgroups per CU)
   int block_min_pct  = 4;         // ... rows with at least this percentage of the columns (R-MAT scale 20 reuse, items: 20 %: 109.0 ms, 9 %: 101.1, 6 %: 98.1, 4 %: 96.7, 3 %: 96.7, 2 %: 99.4, 1 %: 107.7; one workgroup per (row, block): 6 %: 136.5, 12 %: 117.1, 20 %: 115.9) ...
   int block_la_pct   = 3;         // ... or at least this percentage and more than kValLa lists
@@ -2431,8 +2434,7 @@ __global__ __launch_bounds__(NT) void spgemm_block_vals_kernel(int64_t nrows, co
 //     two workgroups per CU, and a sparse stretch of a row costs one item, not four;
 //   * a block that alone holds more than `cap` entries (more than 37 % dense) stays a DIRECT item: the column-indexed accumulator.
 // Items are ordered by their first block, so the launch is block-major as before.  (row index in the class, first block | end block << 16)
-constexpr int kItemMaxBlocks = 4;
-__global__ __launch_bounds__(kBlock) void spgemm_items_build_kernel(int64_t nrows, int nblk, const unsigned* __restrict__ cidx, unsigned cap, int fill,
+__global__ __launch_bounds__(kBlock) void spgemm_items_build_kernel(int64_t nrows, int nblk, const unsigned* __restrict__ cidx, unsigned cap, int maxblk, int fill,
                                                                    unsigned* __restrict__ n_rank /* [nrows + 1] counts, then offsets */, unsigned* __restrict__ n_direct,
                                                                    int2* __restrict__ out_rank, int2* __restrict__ out_direct) {
   const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -2449,23 +2451,39 @@ __global__ __launch_bounds__(kBlock) void spgemm_items_build_kernel(int64_t nrow
       ++nd; ++cb; continue;
     }
     int g1 = cb + 1;
-    while (g1 < nblk && g1 - cb < kItemMaxBlocks && cx[g1 + 1] - e0 <= cap) ++g1;
+    while (g1 < nblk && g1 - cb < maxblk && cx[g1 + 1] - e0 <= cap) ++g1;
     if (fill) out_rank[o_r + nr] = int2{(int)r, cb | (g1 << 16)};
     ++nr; cb = g1;
   }
   if (!fill) { n_rank[r] = nr; n_direct[r] = nd; }
 }
 // counting sort of items by their first block: histogram, (serial) scan of the nblk + 1 counters, scatter
-__global__ __launch_bounds__(kBlock) void spgemm_items_hist_kernel(int64_t n, const int2* __restrict__ items, unsigned* __restrict__ hist) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) atomicAdd(&hist[items[i].y & 0xffff], 1u);
+__global__ __launch_bounds__(kBlock) void spgemm_items_hist_kernel(int64_t n, const int2* __restrict__ items, int nblk, unsigned* __restrict__ hist) {
+  // (workgroup-aggregated: the items of a product crowd into a few dozen first blocks)
+  __shared__ unsigned s_h[4096];
+  for (int b = threadIdx.x; b < nblk; b += kBlock) s_h[b] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) atomicAdd(&s_h[items[i].y & 0xffff], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < nblk; b += kBlock) if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
 }
 __global__ void spgemm_items_scan_kernel(int nblk, unsigned* __restrict__ hist) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned run = 0; for (int b = 0; b < nblk; ++b) { const unsigned c = hist[b]; hist[b] = run; run += c; } }
 }
-__global__ __launch_bounds__(kBlock) void spgemm_items_scatter_kernel(int64_t n, const int2* __restrict__ items, unsigned* __restrict__ cursor, int2* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) { const int2 it = items[i]; out[atomicAdd(&cursor[it.y & 0xffff], 1u)] = it; }
+__global__ __launch_bounds__(kBlock) void spgemm_items_scatter_kernel(int64_t n, const int2* __restrict__ items, int nblk, unsigned* __restrict__ cursor, int2* __restrict__ out) {
+  __shared__ unsigned s_h[4096], s_b[4096];
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += (int64_t)gridDim.x * kBlock) {      // uniform trip count
+    for (int b = threadIdx.x; b < nblk; b += kBlock) s_h[b] = 0;
+    __syncthreads();
+    const int64_t i = i0 + threadIdx.x;
+    int2 it = int2{0, 0}; unsigned local = 0;
+    if (i < n) { it = items[i]; local = atomicAdd(&s_h[it.y & 0xffff], 1u); }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nblk; b += kBlock) s_b[b] = s_h[b] ? atomicAdd(&cursor[b], s_h[b]) : 0u;
+    __syncthreads();
+    if (i < n) out[s_b[it.y & 0xffff] + local] = it;
+    __syncthreads();
+  }
 }
 
 template <class OffT, class VT, int NT, bool RANK>
@@ -2473,8 +2491,8 @@ __global__ __launch_bounds__(NT) void spgemm_item_vals_kernel(const int2* __rest
                                                               const unsigned* __restrict__ bidx, const unsigned* __restrict__ cidx,
                                                               const OffT* __restrict__ rmA, const int32_t* __restrict__ entA, const VT* __restrict__ valA,
                                                               const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, const VT* __restrict__ valB,
-                                                              int64_t nnzB, const OffT* __restrict__ rmC, const int32_t* __restrict__ entC, VT* __restrict__ valC) {
-  KK_DYN_SMEM(char, smem);                   // RANK: [packed words of kItemMaxBlocks blocks][sums by position];  direct: [sums by column of one block]
+                                                              int64_t nnzB, const OffT* __restrict__ rmC, const int32_t* __restrict__ entC, VT* __restrict__ valC, int maxblk) {
+  KK_DYN_SMEM(char, smem);                   // RANK: [packed words of maxblk blocks][sums by position];  direct: [sums by column of one block]
   __shared__ long long s_p0[NT];             // first entry of list a inside the item's columns (index into entries / values of B)
   __shared__ int s_n[NT];                    // entries of it inside them
   __shared__ int s_pre[NT + 1];              // unit offsets of the lists
@@ -2491,7 +2509,18 @@ __global__ __launch_bounds__(NT) void spgemm_item_vals_kernel(const int2* __rest
   const int64_t base = (int64_t)rmC[row] + e0;
   const int c0 = cb0 << wshift;
   kk_u64* rank = reinterpret_cast<kk_u64*>(smem);
-  VT* sums = RANK ? reinterpret_cast<VT*>(smem + ((size_t)kItemMaxBlocks << (wshift - 5)) * 8) : reinterpret_cast<VT*>(smem);
+  VT* sums = RANK ? reinterpret_cast<VT*>(smem + ((size_t)maxblk << (wshift - 5)) * 8) : reinterpret_cast<VT*>(smem);
+  const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
+  const unsigned* bx0 = bidx + (int64_t)cb0 * nB;
+  const unsigned* bx1 = bidx + (int64_t)cb1 * nB;
+  // the first chunk of lists is requested NOW: entries(A) -> index of B / row_map(B) is a chain of two round trips that needs nothing of
+  // the accumulator's set-up below and completes behind it
+  long long pf_p0 = 0; int pf_n = 0; VT pf_av = VT(0);
+  if ((int64_t)t < la) {
+    const int32_t kc = entA[a0 + t];
+    const unsigned f = bx0[kc], l = bx1[kc];
+    pf_n = (int)(l - f); pf_p0 = (long long)rmB[kc] + f; pf_av = valA[a0 + t];
+  }
   if constexpr (RANK) {
     const int nw = (cb1 - cb0) << (wshift - 5);
     for (int i = t; i < nw; i += NT) rank[i] = 0ull;
@@ -2512,13 +2541,12 @@ __global__ __launch_bounds__(NT) void spgemm_item_vals_kernel(const int2* __rest
     const int W = 1 << wshift;
     for (int i = t; i < W; i += NT) sums[i] = VT(0);
   }
-  const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
-  const unsigned* bx0 = bidx + (int64_t)cb0 * nB;
-  const unsigned* bx1 = bidx + (int64_t)cb1 * nB;
   for (int64_t ach = 0; ach < la; ach += NT) {
     const int la_c = (int)(la - ach < NT ? la - ach : NT);
     int n_in = 0;
-    if (t < la_c) {
+    if (ach == 0) {
+      if (t < la_c) { n_in = pf_n; s_p0[t] = pf_p0; s_n[t] = pf_n; s_av[t] = pf_av; }
+    } else if (t < la_c) {
       const int32_t kc = entA[a0 + ach + t];
       const unsigned f = bx0[kc], l = bx1[kc];
       n_in = (int)(l - f);
@@ -3260,7 +3288,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         KK_HIP(hipMemsetAsync(d_nr, 0, sizeof(unsigned) * (size_t)(n_blk + 1), st)); KK_HIP(hipMemsetAsync(d_nd, 0, sizeof(unsigned) * (size_t)(n_blk + 1), st));
         const unsigned cap_items = (unsigned)g_spgemm.item_cap;
         const unsigned bgrid = (unsigned)ceil_div(n_blk, kBlock);
-        KK_LAUNCH(spgemm_items_build_kernel, bgrid, kBlock, 0, st, n_blk, nblk, d_cx, cap_items, 0, d_nr, d_nd, (int2*)nullptr, (int2*)nullptr);
+        KK_LAUNCH(spgemm_items_build_kernel, bgrid, kBlock, 0, st, n_blk, nblk, d_cx, cap_items, g_spgemm.item_blocks, 0, d_nr, d_nd, (int2*)nullptr, (int2*)nullptr);
         if ((rc = exclusive_scan_inplace<unsigned>(d_nr, n_blk + 1, st))) return rc;
         if ((rc = exclusive_scan_inplace<unsigned>(d_nd, n_blk + 1, st))) return rc;
         unsigned h_tot[2] = {0, 0};
@@ -3271,7 +3299,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         KK_HIP(hipMalloc((void**)&h->d_items_rank, sizeof(int2) * (size_t)(h_tot[0] ? h_tot[0] : 1)));
         KK_HIP(hipMalloc((void**)&h->d_items_direct, sizeof(int2) * (size_t)(h_tot[1] ? h_tot[1] : 1)));
         int2* t_r = tmp_r.as<int2>(); int2* t_d = tmp_d.as<int2>();
-        KK_LAUNCH(spgemm_items_build_kernel, bgrid, kBlock, 0, st, n_blk, nblk, d_cx, cap_items, 1, d_nr, d_nd, t_r, t_d);
+        KK_LAUNCH(spgemm_items_build_kernel, bgrid, kBlock, 0, st, n_blk, nblk, d_cx, cap_items, g_spgemm.item_blocks, 1, d_nr, d_nd, t_r, t_d);
         KK_HIP(hist_b.alloc(sizeof(unsigned) * (size_t)(nblk + 1)));
         unsigned* d_hist = hist_b.as<unsigned>();
         for (int which = 0; which < 2; ++which) {
@@ -3279,14 +3307,16 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
           if (!n_it) continue;
           const int2* src = which == 0 ? t_r : t_d; int2* dst = which == 0 ? h->d_items_rank : h->d_items_direct;
           KK_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * (size_t)(nblk + 1), st));
-          KK_LAUNCH(spgemm_items_hist_kernel, (unsigned)ceil_div(n_it, kBlock), kBlock, 0, st, n_it, src, d_hist);
+          const int64_t nbk_it = ceil_div(n_it, kBlock);
+          const unsigned g_it = (unsigned)(nbk_it < 2048 ? nbk_it : 2048);
+          KK_LAUNCH(spgemm_items_hist_kernel, g_it, kBlock, 0, st, n_it, src, nblk, d_hist);
           KK_LAUNCH(spgemm_items_scan_kernel, 1, 64, 0, st, nblk, d_hist);
-          KK_LAUNCH(spgemm_items_scatter_kernel, (unsigned)ceil_div(n_it, kBlock), kBlock, 0, st, n_it, src, d_hist, dst);
+          KK_LAUNCH(spgemm_items_scatter_kernel, g_it, kBlock, 0, st, n_it, src, nblk, d_hist, dst);
         }
         KK_HIP(hipStreamSynchronize(st));              // the scratch buffers go out of scope
         h->n_items_rank = h_tot[0]; h->n_items_direct = h_tot[1]; h->items_ready = true;
         if (h->verbose) KK_VERBOSE("\tkkamd spgemm numeric: column-block class: %lld rows as %lld position-indexed items (<= %u entries, <= %d blocks) and %lld column-indexed blocks\n",
-                                   (long long)n_blk, (long long)h->n_items_rank, cap_items, kItemMaxBlocks, (long long)h->n_items_direct);
+                                   (long long)n_blk, (long long)h->n_items_rank, cap_items, g_spgemm.item_blocks, (long long)h->n_items_direct);
       }
       if (use_items) {
         const int2* d_ir = h->d_items_rank; const int2* d_id = h->d_items_direct;
@@ -3295,15 +3325,15 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
           KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_item_vals_kernel<OffT, VT, kDenseBlock, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
           KK_LAUNCH((spgemm_item_vals_kernel<OffT, VT, kDenseBlock, false>), (unsigned)h->n_items_direct, kDenseBlock, smem, st, d_id, bperm, nblk, wshift, nB, d_bx, d_cx,
-                    rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC);
+                    rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC, 1);
         }
         if (h->n_items_rank) {
-          const size_t smem_r = (((size_t)kItemMaxBlocks << (wshift - 5)) * 8) + sizeof(VT) * (size_t)g_spgemm.item_cap;
+          const size_t smem_r = (((size_t)g_spgemm.item_blocks << (wshift - 5)) * 8) + sizeof(VT) * (size_t)g_spgemm.item_cap;
 #ifndef KK_EMU
           KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_item_vals_kernel<OffT, VT, kValBlock, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r));
 #endif
           KK_LAUNCH((spgemm_item_vals_kernel<OffT, VT, kValBlock, true>), (unsigned)h->n_items_rank, kValBlock, smem_r, st, d_ir, bperm, nblk, wshift, nB, d_bx, d_cx,
-                    rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC);
+                    rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC, g_spgemm.item_blocks);
         }
       } else {
       // blocks of 16384 columns: one workgroup of 1024 per CU around 128 KB of sums; narrower blocks: 512 work-items, two (or more) workgroups per CU
@@ -3494,6 +3524,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_list_staged") g_spgemm.list_staged = value != 0;
   else if (k == "spgemm_block") g_spgemm.block = value != 0;
   else if (k == "spgemm_items") g_spgemm.items = value != 0;
+  else if (k == "spgemm_item_blocks") { if (value < 1 || value > 16) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_item_blocks: 1 .. 16"); g_spgemm.item_blocks = value; }
   else if (k == "spgemm_item_cap") { if (value < 64 || value > 16384) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_item_cap: 64 .. 16384"); g_spgemm.item_cap = value; }
   else if (k == "spgemm_block_w") { if (value < 64 || value > 16384 || (value & (value - 1))) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_w: %d is not a power of two in [64, 16384]", value); g_spgemm.block_w = value; }
   else if (k == "spgemm_block_min_pct") { if (value < 0 || value > 100) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_min_pct: 0 .. 100"); g_spgemm.block_min_pct = value; }

@@ -871,9 +871,17 @@ static bool transpose_fits(kkamd_spmv_plan* p, const kkamd_crs_t* A) {
   if (p->t_failed) return false;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
-  const double need = (double)A->nnz * (4.0 + sizeof(OffT) + sizeof(AT) + 16.0) + (double)A->num_cols * sizeof(OffT);
+  // structure, permutation, values, 16 bytes per nonzero while it is built -- and, under exact value tracking (the default), the shadow copy
+  // of A.values the comparison needs
+  const bool shadow = p->tune.values_tracking == 0 && p->tune.explicit_transpose != 2;
+  const double need = (double)A->nnz * (4.0 + sizeof(OffT) + sizeof(AT) + 16.0 + (shadow ? (double)sizeof(AT) : 0.0)) + (double)A->num_cols * sizeof(OffT);
   if (need > (double)free_b / 8.0) { p->t_failed = true; return false; }
   return true;
+}
+// knobs that belong to the handle's own re-ordered copies and are not passed on to the plan of its cached transpose
+static bool knob_stays_with_parent(const std::string& k) {
+  return k == "colslab" || k == "colslab_shift" || k == "colslab_min_knnz" || k == "colslab_const" || k == "explicit_transpose" ||
+         k == "explicit_transpose_min_knnz" || k == "values_tracking";
 }
 template <class OffT, class AT>
 static int ensure_transpose(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st) {
@@ -907,10 +915,17 @@ static int ensure_transpose(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_
   if (rc != KKAMD_OK) { fail_clean(); return rc; }
   KK_LAUNCH((invert_perm_kernel<OffT>), grid, kBlock, 0, st, (const double*)d_tmp, (OffT*)p->d_t_perm, A->nnz);     // d_t_perm: position of A's entry i in A^T
   p->t_fp_valid = false; p->t_shadow_valid = false; p->t_stale = true;          // the first refresh moves every value
+  // exact tracking: the shadow copy is part of the transpose (budgeted in transpose_fits), not an allocation on the first tracked call
+  if (p->tune.values_tracking == 0 && p->tune.explicit_transpose != 2 && !p->d_t_shadow && !p->t_shadow_failed &&
+      hipMalloc(&p->d_t_shadow, sizeof(AT) * nnz) != hipSuccess) { (void)hipGetLastError(); p->d_t_shadow = nullptr; p->t_shadow_failed = true; }
   if (hipStreamSynchronize(st) != hipSuccess) return fail_clean();
   (void)hipFree(d_iota); (void)hipFree(d_tmp); d_iota = d_tmp = nullptr;
   kkamd_crs_t At{A->num_cols, A->num_rows, A->nnz, p->d_t_rm, p->d_t_ent, p->d_t_val, A->offset_type, A->value_type};
-  rc = kkamd_spmv_plan_create(&p->t_plan, &At, p->algorithm, reinterpret_cast<kkamd_stream_t>(st));
+  // what the caller set on the handle holds for its transposed modes too (a forced rank-2 kernel, mv5 / mv6 off, check_entries, ...):
+  // the transpose's plan is created with the handle's knobs, except those of the handle's own re-ordered copies
+  std::vector<const char*> t_keys; std::vector<int> t_vals;
+  for (const auto& kv : p->set_log) if (!knob_stays_with_parent(kv.first)) { t_keys.push_back(kv.first.c_str()); t_vals.push_back(kv.second); }
+  rc = kkamd_spmv_plan_create_knobs(&p->t_plan, &At, p->algorithm, t_keys.data(), t_vals.data(), (int)t_keys.size(), reinterpret_cast<kkamd_stream_t>(st));
   if (rc != KKAMD_OK) { fail_clean(); return rc; }
   p->t_plan->tune.colslab = 0;            // A^T's values are this plan's own copy: no second re-ordered copy to keep current behind it
   p->t_plan->tune.explicit_transpose = 0;
@@ -1461,6 +1476,7 @@ int kkamd_spmv_plan_create_knobs(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A,
   for (int i = 0; i < nknobs; ++i) {                           // this plan's knobs, applied before the analysis they shape
     if (!keys || !values) { delete p; return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_create_knobs: null knob arrays"); }
     if ((rc = kk::set_tuning(p->tune, keys[i], values[i]))) { delete p; return rc; }
+    p->set_log.emplace_back(std::string(keys[i]), values[i]);   // (what the plan of a cached transpose will be created with)
   }
   {
     int dev = 0; hipDeviceProp_t prop;
@@ -1498,8 +1514,19 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan) {
   return KKAMD_OK;
 }
 
+static int plan_set_impl(kkamd_spmv_plan_t* plan, const char* key, int value);
 int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
   if (!plan) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_set: null plan");
+  int rc = plan_set_impl(plan, key, value);
+  if (rc) return rc;
+  const std::string k(key ? key : "");
+  if (!kk::knob_stays_with_parent(k)) {
+    plan->set_log.emplace_back(k, value);
+    if (plan->t_plan) rc = plan_set_impl(plan->t_plan, key, value);      // modes T / H run the mode-N dispatch on the cached transpose's own plan
+  }
+  return rc;
+}
+static int plan_set_impl(kkamd_spmv_plan_t* plan, const char* key, int value) {
   const kk::SpmvTuning old = plan->tune;
   int rc = kk::set_tuning(plan->tune, key, value);
   if (rc) return rc;
@@ -1562,6 +1589,10 @@ int kkamd_spmv_plan_values_changed(kkamd_spmv_plan_t* plan) {
 int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_t* value) {
   if (!plan || !key || !value) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spmv_plan_query: null argument");
   const std::string k(key);
+  if (k.rfind("transpose_plan_", 0) == 0) {        // "transpose_plan_<key>": the same query on the plan of the cached transpose (0 while there is none)
+    if (!plan->t_plan) { *value = 0; return KKAMD_OK; }
+    return kkamd_spmv_plan_query(plan->t_plan, k.c_str() + 15, value);
+  }
   if (k == "tile") *value = plan->tile;
   else if (k == "tiles") *value = plan->nblocks;
   else if (k == "window_codes") *value = plan->d_tinfo ? 1 : 0;
@@ -1571,6 +1602,10 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "staged_tiles") *value = plan->d_tinfo ? plan->staged_tiles : 0;
   else if (k == "pattern_tiles") *value = plan->d_pmeta ? plan->pat_tiles : 0;
   else if (k == "plan_bytes") *value = (int64_t)plan->plan_bytes;
+  else if (k == "transpose_bytes") {            // the cached transpose of modes T / H: structure, permutation, values, fingerprints and the shadow copy of exact tracking
+    const int64_t ob = plan->offset_type == KKAMD_I64 ? 8 : 4, vb = plan->value_type == KKAMD_F64 ? 8 : 4;
+    *value = plan->t_ready ? plan->nnz * (4 + ob + vb) + (plan->num_cols + 1) * ob + 16 * kk::values_fp_tiles(plan->nnz) + (plan->d_t_shadow ? plan->nnz * vb : 0) : 0;
+  }
   else if (k == "transpose_cached") *value = plan->t_ready ? 1 : 0;
   else if (k == "mv_tiles") *value = kk::mv_plan_query(plan->mv, 0);
   else if (k == "mv_staged_tiles") *value = kk::mv_plan_query(plan->mv, 1);

@@ -363,7 +363,8 @@ int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_kn
   const size_t off_b = A->offset_type == KKAMD_I64 ? 8 : 4, val_b = A->value_type == KKAMD_F64 ? 8 : 4;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
-  const double need = (double)A->nnz * (8.0 + val_b + off_b) + 8.0 * (double)ceil_div(A->num_cols, (int64_t)1 << shift) * (double)ceil_div(A->nnz, (int64_t)kCsTile);
+  // (+ val_b: the shadow copy of A.values that exact value tracking, the default, compares against at every call)
+  const double need = (double)A->nnz * (8.0 + 2.0 * val_b + off_b) + 8.0 * (double)ceil_div(A->num_cols, (int64_t)1 << shift) * (double)ceil_div(A->nnz, (int64_t)kCsTile);
   if (need > (double)free_b / 4.0) return KKAMD_OK;
   const bool o64 = A->offset_type == KKAMD_I64;
   if (A->value_type == KKAMD_F64) return o64 ? cs_build_typed<int64_t, double>(out, A, shift, st) : cs_build_typed<int32_t, double>(out, A, shift, st);

@@ -84,7 +84,10 @@ __global__ __launch_bounds__(kBlock) void mv5_tile_kernel(int64_t nrows, const O
   __shared__ int s_bad;
   __shared__ int s_wave[kBlock / 64];
   const int t = threadIdx.x;
-  const int64_t tile = (int64_t)blockIdx.x * tile_stride;        // (stride > 1: the sampling pass of the analysis)
+  // (stride > 1: the sampling pass of the analysis.  The sample's tiles are JITTERED inside their strides -- a hash of the sample
+  // index -- so that a matrix with periodic structure, e.g. interface rows every N tiles of a multi-dof lattice, is not sampled in phase)
+  const int64_t tile = tile_stride > 1 ? (int64_t)blockIdx.x * tile_stride + (int64_t)(((unsigned)blockIdx.x * 2654435761u) >> 8) % tile_stride
+                                        : (int64_t)blockIdx.x;
   const int64_t row0 = tile * kMv5Rows, rowN = (row0 + kMv5Rows < nrows) ? row0 + kMv5Rows : nrows;
   if (t <= kMv5Rows) s_rm[t] = (long long)row_map[(row0 + t < rowN) ? row0 + t : rowN];
   if (t == 0) s_bad = 0;

@@ -3,6 +3,9 @@
 // rank-2 (kk_spmv_mv.hip) and multi-GPU (kk_dist.hip) translation units.
 #pragma once
 #include "kk_common.h"
+#include <string>
+#include <utility>
+#include <vector>
 
 // Measurement build (-DKK_ABLATE, tools/ only): parts of the kernel can be switched off through an extra kernel argument.
 // In the product build the argument does not exist and every KK_ABL(bit) folds to false.
@@ -98,6 +101,9 @@ struct kkamd_mv5_plan;  // kk_spmv_mvblk.hip
 struct kkamd_mv6_plan;  // kk_spmv_mvnnz.hip
 
 struct kkamd_spmv_plan {
+  // knobs the caller set on this handle, in order: replayed on the plan of the cached transpose when that is created (and forwarded to it
+  // afterwards), so that a kernel choice forced on a handle also holds for its modes T / H
+  std::vector<std::pair<std::string, int>> set_log;
   int64_t num_rows = 0, num_cols = 0, nnz = 0;
   const void* row_map = nullptr;
   int offset_type = 0, value_type = 1, algorithm = 0;

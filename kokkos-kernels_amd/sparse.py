@@ -27,8 +27,10 @@ _TORCH_BACKEND = None
 def torch_backend():
     global _TORCH_BACKEND
     if _TORCH_BACKEND is None:
-        import torch
-        from . import lib
+        import torch                     # (before the library is loaded: see lib() on the load order)
+        from . import lib, device_check
+        if torch.cuda.is_available():
+            device_check()               # the library's own runtime must see the device too (it does not when it was loaded before torch)
         if not torch.cuda.is_available():
             raise RuntimeError("kokkos-kernels_amd needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU path")

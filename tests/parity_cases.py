@@ -189,6 +189,31 @@ def check_mv6(be, light=False):
         assert h.query("mv6_chunks") == 0
 
 
+def check_transpose_plan_inherits_knobs(be):
+    """Modes T / H of an analysed handle run the mode-N dispatch on the plan of its cached transpose: what the caller set on the handle --
+    a forced rank-2 kernel, the nonzero-split kernel switched off -- must hold there too, whether it was set before the transpose exists
+    (replayed at its creation) or afterwards (forwarded); round-4 advisor finding."""
+    lib = be.lib
+    kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 0))
+    try:
+        name, A0 = mv6_cases()[0]
+        At0 = oracle.transpose(A0)
+        # the transpose of this matrix is one the nonzero-split kernel takes by default ...
+        h = check_spmv_mv(be, A0, 16, "T", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=50.0, knobs={"mv6": 2})
+        assert h.query("transpose_plan_mv6_chunks") == -(-At0.nnz // 128), h.query("transpose_plan_mv6_chunks")
+        # ... a handle with the gather kernel forced BEFORE the first transposed call keeps it away from the transpose's plan ...
+        h = check_spmv_mv(be, A0, 16, "T", 1.0, 0.5, "C", "C", algo="SPMV_DEFAULT", max_val=50.0, knobs={"mv6": 2, "mv_kernel": 2})
+        assert h.query("transpose_plan_tile") > 0 and h.query("transpose_plan_mv6_chunks") == 0
+        # ... and setting it AFTERWARDS reaches the existing transposed plan
+        h = check_spmv_mv(be, A0, 16, "T", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=50.0, knobs={"mv6": 2})
+        assert h.query("transpose_plan_mv6_chunks") > 0
+        h.set("mv6", 0)
+        assert h.query("transpose_plan_mv6_chunks") == 0
+        assert h.query("transpose_bytes") >= At0.nnz * (4 + 4 + 8 + 8)          # structure, permutation, values and the shadow copy of exact tracking
+    finally:
+        kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 1000))
+
+
 def check_values_tracking(be):
     """The re-ordered value copies of a plan (cached transpose, column-slab copy) under the three "values_tracking" policies: 0 exact
     (default), 1 notify (SPMVHandle.values_changed), 2 fingerprints.  A.values is rewritten in place between calls: one value, every value,

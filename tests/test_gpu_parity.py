@@ -239,6 +239,10 @@ def test_check_entries_knob(be):
     pc.check_entries_guard(be)
 
 
+def test_transposed_plan_inherits_the_handles_knobs(be):
+    pc.check_transpose_plan_inherits_knobs(be)
+
+
 def test_values_tracking_policies(be):
     # exact (default) / notify / fingerprints for the cached transpose and the column-slab copy; kkamd_spmv_plan_values_changed
     pc.check_values_tracking(be)
