@@ -204,10 +204,11 @@ def cpu_baseline_mv(nv, n=300, min_seconds=6.0):
 
 
 def bench_rank1_gather_bound(kk, torch):
-    """Rank-1 SpMV off the stencil: uniform random columns, 5e6 rows x 20 (1e8 nonzeros, x = 40 MB), fp64.  The default
-    handle (the deterministic CRS stream kernel: the column-slab copy is opt-in since round 4), the copy when asked for (knob colslab 1: it
-    is selected by timing; its values follow A.values exactly through a shadow comparison) and the copy with the caller notifying value
-    changes (values_tracking 1: no per-call pass); fractions are CRS bytes (nnz*12 + (rows+1)*4 + cols*8 + rows*8) at 8 TB/s."""
+    """Rank-1 SpMV off the stencil: uniform random columns, 5e6 rows x 20 (1e8 nonzeros, x = 40 MB), fp64.
+    The CRS stream kernel (colslab 0), the default handle (round 5: the DETERMINISTIC column-slab form, chosen by rule at the first call
+    -- per-slab partial sums, no atomics, bit-stable; its values follow A.values exactly through a shadow comparison), the same with the
+    caller notifying value changes (no per-call pass), and the atomic forms of round 3 / 4 (opt-in); fractions are CRS bytes
+    (nnz*12 + (rows+1)*4 + cols*8 + rows*8) at 8 TB/s."""
     n, k = 5_000_000, 20
     g = torch.Generator(device="cuda"); g.manual_seed(11)
     c = torch.sort(torch.randint(0, n, (n, k), device="cuda", generator=g), dim=1).values
@@ -218,7 +219,8 @@ def bench_rank1_gather_bound(kk, torch):
     alg = A.nnz() * 12 + (n + 1) * 4 + 2 * n * 8
     out = {"workload": "spmv_crs_uniform_random_5e6x20_fp64", "nnz": A.nnz(), "algorithmic_bytes_per_call": alg, "peak_GBps": HBM_PEAK_GBPS}
     ref = None
-    for tag, knobs in (("default_handle", {}), ("column_slab_copy_opt_in", {"colslab": 1}), ("column_slab_copy_caller_notifies", {"colslab": 2, "values_tracking": 1})):
+    for tag, knobs in (("crs_kernel", {"colslab": 0}), ("default_handle", {}), ("default_handle_caller_notifies", {"values_tracking": 1}),
+                       ("column_slab_copy_opt_in", {"colslab": 1}), ("column_slab_copy_caller_notifies", {"colslab": 2, "values_tracking": 1})):
         h = kk.SPMVHandle("SPMV_DEFAULT")
         for k_, v_ in knobs.items(): h.set(k_, v_)
         fn = lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y)
@@ -230,6 +232,11 @@ def bench_rank1_gather_bound(kk, torch):
         r["max_rel_diff_vs_crs"] = float(((y - ref).abs().max() / ref.abs().max()).item())
         assert r["max_rel_diff_vs_crs"] < 1e-12, "rank-1 gather-bound case: kernels disagree"
         if tag == "column_slab_copy_opt_in": r["column_slab_copy_selected"] = int(h.query("colslab")); r["selection_us_crs_vs_copy"] = [h.query("colslab_crs_us"), h.query("colslab_us")]
+        if tag in ("default_handle", "crs_kernel"):
+            r["column_slab_form"] = int(h.query("colslab")); r["deterministic"] = bool(h.query("colslab_deterministic")) or not h.query("colslab")
+            r["lines_of_x_per_nonzero_sampled"] = h.query("colslab_lines_permille") / 1000
+            y_a = y.clone(); fn(); torch.cuda.synchronize()
+            r["bit_stable_across_calls"] = bool((y_a == y).all().item())
         out[tag] = r
         del h
     return out

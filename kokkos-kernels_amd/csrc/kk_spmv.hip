@@ -1023,13 +1023,35 @@ int transpose_view(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st, 
 template <class OffT, class AT, class YT>
 static int colslab_select(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const YT* x, hipStream_t st) {
   plan->cs_tried = true;
-  const bool force = plan->tune.colslab == 2;
+  const int mode = plan->tune.colslab;
+  const bool force = mode == 2 || mode == 4, det = mode >= 3;
   if (!force) {
     const int64_t plain = plan->d_tinfo ? plan->plain_tiles : plan->nblocks;
     if (A->nnz < (int64_t)plan->tune.colslab_min_knnz * 1000 || (double)A->num_cols * sizeof(YT) < 16.0 * 1048576.0 || 2 * plain < plan->nblocks) return KKAMD_OK;
+    if (det) {
+      // the rule (no timing): sampled windows of the matrix name nearly one 128-byte line of x per nonzero
+      int rc0 = cs_gather_ratio(A, (int)sizeof(YT), st, &plan->cs_ratio);
+      if (rc0) return rc0;
+      if (g_verbose) printf("kkamd_spmv: %.3f distinct lines of x per nonzero in the sampled windows: %s\n", plan->cs_ratio, plan->cs_ratio * 100.0 >= (double)plan->tune.colslab_min_pct ? "column-slab form (deterministic)" : "CRS kernel");
+      if (plan->cs_ratio * 100.0 < (double)plan->tune.colslab_min_pct) return KKAMD_OK;
+      // ... and the slab form must pay by bytes: it streams 16 B per nonzero (+ 16 B under exact value tracking) and writes and reads a
+      // partial sum per (slab, row) -- whole lines of a [slabs][rows] array, half empty when the rows are short (weight 1.5) -- against one
+      // 128-byte line of x per missing nonzero through the fabric.  Rates fitted on one MI355X (uniform random 5e6 x 20: 1.32 ms slab form
+      // against 1.75 ms CRS; 2e7 x 8: 3.85 against 3.27 -- the rule must say no there): 4.24 TB/s and 6.95 TB/s, 10 % margin.
+      int sh = plan->tune.colslab_shift > 0 ? plan->tune.colslab_shift : (sizeof(YT) == 8 ? 18 : 19);
+      while (ceil_div(A->num_cols, (int64_t)1 << sh) > 64) ++sh;
+      const double nslabs = (double)ceil_div(A->num_cols, (int64_t)1 << sh);
+      const bool exact = plan->tune.values_tracking == 0 && !plan->tune.colslab_const;
+      const double cost_slab = (double)A->nnz * (16.0 + (exact ? 16.0 : 0.0)) + 1.5 * nslabs * (double)A->num_rows * 2.0 * sizeof(YT);
+      const double cost_crs = (double)A->nnz * plan->cs_ratio * 128.0;
+      if (cost_slab / 4.24e12 * 1.1 >= cost_crs / 6.95e12) {
+        if (g_verbose) printf("kkamd_spmv: the column-slab form would move %.2f GB against %.2f GB of x lines: CRS kernel\n", cost_slab / 1e9, cost_crs / 1e9);
+        return KKAMD_OK;
+      }
+    }
   }
-  int rc = cs_build(&plan->cs, A, (int)sizeof(YT), plan->tune.colslab_shift, st);
-  if (rc || !plan->cs || force) return rc;
+  int rc = cs_build(&plan->cs, A, (int)sizeof(YT), plan->tune.colslab_shift, st, det);
+  if (rc || !plan->cs || force || det) return rc;
 #ifdef KK_EMU
   cs_plan_destroy(plan->cs); plan->cs = nullptr;                 // nothing to time under the emulator
   return KKAMD_OK;
@@ -1204,7 +1226,8 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "window_codes_min_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.window_codes_min_pct = value; }
   else if (k == "pattern_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.pattern_codes = value; }
   else if (k == "pattern_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.pattern_codes_min_knnz = value; }
-  else if (k == "colslab") { if (value < 0 || value > 2) return bad("in 0..2"); t.colslab = value; }
+  else if (k == "colslab") { if (value < 0 || value > 4) return bad("in 0..4"); t.colslab = value; }
+  else if (k == "colslab_min_pct") { if (value < 0 || value > 100) return bad("in 0..100"); t.colslab_min_pct = value; }
   else if (k == "colslab_min_knnz") { if (value < 0) return bad("non-negative"); t.colslab_min_knnz = value; }
   else if (k == "colslab_shift") { if (value != 0 && (value < 2 || value > 30)) return bad("0 or in 2..30"); t.colslab_shift = value; }
   else if (k == "values_tracking") { if (value < 0 || value > 2) return bad("in 0..2"); t.values_tracking = value; }
@@ -1629,6 +1652,8 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "colslab_slabs") *value = kk::cs_plan_query(plan->cs, 0);
   else if (k == "colslab_shift") *value = kk::cs_plan_query(plan->cs, 1);
   else if (k == "colslab_bytes") *value = kk::cs_plan_query(plan->cs, 2);
+  else if (k == "colslab_deterministic") *value = kk::cs_plan_query(plan->cs, 3);
+  else if (k == "colslab_lines_permille") *value = (int64_t)(plan->cs_ratio * 1000.0 + 0.5);
   else if (k == "colslab_crs_us") *value = (int64_t)(plan->cs_crs_us + 0.5);
   else if (k == "colslab_us") *value = (int64_t)(plan->cs_us + 0.5);
   else if (k == "march_workgroups") *value = plan->tune.march ? kk::mv4_plan_query(plan->mv4, 5) : 0;

@@ -42,6 +42,17 @@ struct kkamd_cs_plan {
   void* d_shadow = nullptr;              // [nnz] A.values as the copy last saw them (values_tracking 0; allocated on first use)
   bool fp_valid = false, shadow_valid = false, shadow_failed = false, stale = false;
   size_t bytes = 0;
+  // DETERMINISTIC form (round 5): no atomics.  Per-slab partial sums of every row, y_part[slab][row]; which slabs a row has entries in;
+  // and, per chunk of the slab-order stream (a wave's kCsDetChunk entries), the pieces of the runs that a chunk boundary cuts.
+  bool det = false;
+  int64_t nrows = 0, nchunks = 0;
+  unsigned long long* d_mask = nullptr;  // [nrows] bit s: the row has entries in slab s (nslabs <= 64)
+  void* d_part = nullptr;                // [nslabs][nrows] vector type
+  void* d_head = nullptr;                // [nchunks] vector type: the chunk's first run when it continues the previous chunk's last
+  void* d_tail = nullptr;                // [nchunks] ... its last run when the next chunk continues it
+  long long* d_tkey = nullptr;           // [nchunks] slab * nrows + row of that last run
+  int* d_cflag = nullptr;                // [nchunks] bit 0: the head piece exists, bit 1: the tail piece exists, bit 2: the whole chunk is one run cut at both ends
+  size_t part_bytes = 0;
 };
 
 namespace kk {
@@ -50,6 +61,7 @@ constexpr int kCsPer      = 16;                 // entries per work-item of a so
 constexpr int kCsTile     = kBlock * kCsPer;    // 4096
 constexpr int kCsMaxSlabs = 256;
 constexpr int kCsU        = 8;                  // entries per work-item of the SpMV kernel
+constexpr int kDenseThreads = 1024;
 
 // ------------------------------------------------------------------------------------------------
 // stable counting sort by slab, pass 1: entries per (slab, tile), slab-major so that one prefix sum gives every (slab, tile) its start
@@ -292,9 +304,176 @@ __global__ __launch_bounds__(kBlock) void cs_spmv_kernel(int64_t nnz, const int3
 }
 
 // ------------------------------------------------------------------------------------------------
+// DETERMINISTIC slab SpMV (no atomics, no timing, the same bits on every run; round-4 review item 7).  The reference's native mode-N
+// kernel is deterministic (sparse/impl/KokkosSparse_spmv_impl.hpp:134-165); the atomic form above is not, which is why it was opt-in.
+//   pass 1 (cs_det_kernel): a wave takes kCsDetChunk consecutive entries of the slab-order stream, 64 at a time.  Inside the 64 the runs of
+//     one (slab, row) are folded by a fixed shuffle tree into their first lane; the last run of every 64 is carried (wave-uniform
+//     registers) into the next 64; a run that ends inside the chunk is STORED to y_part[slab][row] -- every (slab, row) has exactly one
+//     writer.  The chunk's first run when it continues the previous chunk's, and its last run when the next chunk continues it, go to
+//     the chunk's head / tail slot;
+//   pass 2 (cs_det_fix_kernel): the chunk in which a cut run BEGINS adds its tail piece and the head pieces of the following chunks, in
+//     chunk order, and stores the run;
+//   pass 3 (cs_det_reduce_kernel): y[r] = beta y[r] + alpha * (sum over the slabs the row has entries in, ascending): the slab mask of
+//     the row says which partial sums exist (nothing is zero-filled per call).
+constexpr int kCsDetU = 8;                          // rounds of 64 entries per wave
+constexpr int kCsDetChunk = 64 * kCsDetU;
+__global__ __launch_bounds__(kBlock) void cs_mask_kernel(int64_t nnz, const int32_t* __restrict__ row, const int32_t* __restrict__ col, int shift,
+                                                         unsigned long long* __restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nnz) return;
+  const int slab = col[i] >> shift;
+  if (i == 0 || row[i - 1] != row[i] || (col[i - 1] >> shift) != slab) atomicOr(&mask[row[i]], 1ull << slab);       // the first entry of a run
+}
+template <class AT, class YT>
+__global__ __launch_bounds__(kBlock) void cs_det_kernel(int64_t nnz, int64_t nrows, const int32_t* __restrict__ row, const int32_t* __restrict__ col,
+                                                        const AT* __restrict__ val, int shift, const YT* __restrict__ x, YT* __restrict__ part,
+                                                        YT* __restrict__ head, YT* __restrict__ tail, long long* __restrict__ tkey, int* __restrict__ cflag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t i0 = chunk * kCsDetChunk;
+  if (i0 >= nnz) return;                                          // the whole wave leaves
+  const int64_t i1 = i0 + kCsDetChunk < nnz ? i0 + kCsDetChunk : nnz;
+  auto key_at = [&](int64_t i) { return (long long)(col[i] >> shift) * nrows + row[i]; };
+  const long long prev_key = i0 > 0 ? key_at(i0 - 1) : -1, next_key = i1 < nnz ? key_at(i1) : -1;
+  // the OPEN run: the last run of the rounds so far, which the next round may continue (wave-uniform registers)
+  bool open = false, open_fp = false;                             // open_fp: it began at the chunk's first entry and continues the previous chunk's last run
+  long long open_key = -1;
+  YT open_sum = YT(0);
+  int flags = 0;
+  // all rounds' triples, then all their x gathers, are requested before the first round is folded (unconditional loads at clamped
+  // indices: a round at a time was a chain of two memory round trips per round)
+  int32_t cu[kCsDetU], ru[kCsDetU];
+  AT vu[kCsDetU];
+  YT xu[kCsDetU];
+  KK_UNROLL
+  for (int u = 0; u < kCsDetU; ++u) {
+    int64_t ic = i0 + (int64_t)u * 64 + lane;
+    ic = ic < i1 ? ic : i1 - 1;
+    cu[u] = col[ic]; ru[u] = row[ic]; vu[u] = val[ic];
+  }
+  KK_UNROLL
+  for (int u = 0; u < kCsDetU; ++u) xu[u] = x[cu[u]];
+  KK_UNROLL
+  for (int u = 0; u < kCsDetU; ++u) {
+    const int64_t ib = i0 + (int64_t)u * 64;
+    if (ib >= i1) break;                                          // uniform
+    const int64_t i = ib + lane;
+    const bool ok = i < i1;
+    const int32_t c = cu[u], r = ru[u];
+    const long long key = ok ? (long long)(c >> shift) * nrows + r : -3;
+    YT s = ok ? (YT)vu[u] * xu[u] : YT(0);
+    // runs of one key inside the 64 fold into their first lane (a fixed tree: the same order on every run)
+    const long long kp = __shfl_up(key, 1, 64);
+    const bool hd = lane == 0 || kp != key;
+    const unsigned long long heads = __ballot(hd);
+    const unsigned long long rest = lane == 63 ? 0ull : heads >> (lane + 1);
+    const int end = rest ? lane + __ffsll(rest) : 64;             // first lane of the next run
+    for (int o = 1; o < 64; o <<= 1) {
+      const YT t = __shfl_down(s, o, 64);
+      if (lane + o < end) s += t;
+    }
+    const int n_ok = (int)(i1 - ib < 64 ? i1 - ib : 64);
+    const int last_head = 63 - __clzll((long long)(heads & (n_ok == 64 ? ~0ull : ((1ull << n_ok) - 1ull))));      // head lane of the round's last run
+    const long long first_key = __shfl(key, 0, 64);
+    bool r1_fp;                                                   // the round's first run continues the previous chunk
+    if (open && first_key == open_key) { if (lane == 0) s = open_sum + s; r1_fp = open_fp; }          // the open run goes on (the earlier piece first)
+    else {
+      if (open) {                                                 // it ended with the previous round
+        if (lane == 0) { if (open_fp) head[chunk] = open_sum; else part[open_key] = open_sum; }
+        if (open_fp) flags |= 1;
+      }
+      r1_fp = u == 0 && first_key == prev_key;
+    }
+    // every run but the round's last ends inside the round: its head lane stores it -- the one writer of that (slab, row)
+    if (hd && ok && lane != last_head) { if (lane == 0 && r1_fp) head[chunk] = s; else part[key] = s; }
+    if (last_head != 0 && r1_fp) flags |= 1;
+    open = true;
+    open_key = __shfl(key, last_head, 64); open_sum = __shfl(s, last_head, 64);
+    open_fp = last_head == 0 ? r1_fp : false;
+  }
+  if (open_key == next_key) {                                     // the next chunk continues the last run
+    if (open_fp) { if (lane == 0) head[chunk] = open_sum; flags |= 1 | 4; }                     // ... and the previous chunk began it: a whole-chunk piece
+    else { if (lane == 0) { tail[chunk] = open_sum; tkey[chunk] = open_key; } flags |= 2; }     // the run BEGINS in this chunk: pass 2 sums it here
+  } else {
+    if (lane == 0) { if (open_fp) head[chunk] = open_sum; else part[open_key] = open_sum; }
+    if (open_fp) flags |= 1;
+  }
+  if (lane == 0) cflag[chunk] = flags;
+}
+template <class YT>
+__global__ __launch_bounds__(kBlock) void cs_det_fix_kernel(int64_t nchunks, const YT* __restrict__ head, const YT* __restrict__ tail, const long long* __restrict__ tkey,
+                                                            const int* __restrict__ cflag, YT* __restrict__ part) {
+  const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (w >= nchunks || !(cflag[w] & 2)) return;                    // only a chunk in which a cut run BEGINS does the sum
+  YT sum = tail[w];
+  for (int64_t c = w + 1; c < nchunks; ++c) {                     // its pieces: the head slots of the following chunks, while they are whole
+    sum += head[c];
+    if (!(cflag[c] & 4)) break;
+  }
+  part[tkey[w]] = sum;
+}
+template <class YT>
+__global__ __launch_bounds__(kBlock) void cs_det_reduce_kernel(int64_t nrows, int nslabs, const unsigned long long* __restrict__ mask, const YT* __restrict__ part,
+                                                               YT* __restrict__ y, YT alpha, YT beta) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= nrows) return;
+  const unsigned long long m = mask[r];
+  YT sum = YT(0);
+  for (int s = 0; s < nslabs; ++s) if ((m >> s) & 1ull) sum += part[(int64_t)s * nrows + r];
+  y[r] = (beta == YT(0)) ? alpha * sum : beta * y[r] + alpha * sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Is the x gather of the CRS kernel cache-defeating?  A RULE, not a timing (the deterministic form is chosen at the first call without
+// running anything twice): eight windows of 32768 consecutive nonzeros spread over the matrix -- about what one XCD's 4 MB L2 holds in
+// 128-byte lines of x while it streams its share of the matrix -- and in each the number of DISTINCT lines of x its columns name (a
+// 512 K-bit set in LDS; line ids beyond that are hashed, which can only undercount).  distinct / nonzeros near 1 means every nonzero
+// pulls its own line through the fabric (uniform random columns: 0.95); hub columns, bands and stencils repeat lines (R-MAT scale 22: 0.6).
+constexpr int kCsWin = 32768, kCsWins = 8, kCsSetWords = 16384;      // 16384 x 32 bits
+__global__ __launch_bounds__(kDenseThreads) void cs_distinct_lines_kernel(int64_t nnz, const int32_t* __restrict__ ent, int line_shift, unsigned long long* __restrict__ out /*[2]*/) {
+  __shared__ unsigned s_set[kCsSetWords];
+  __shared__ unsigned s_new;
+  for (int i = threadIdx.x; i < kCsSetWords; i += kDenseThreads) s_set[i] = 0u;
+  if (threadIdx.x == 0) s_new = 0u;
+  __syncthreads();
+  const int64_t nwin = gridDim.x;
+  const int64_t span = nnz > (int64_t)kCsWin ? nnz - kCsWin : 0;
+  const int64_t b0 = nwin > 1 ? (span / (nwin - 1)) * blockIdx.x : 0;
+  const int64_t b1 = b0 + kCsWin < nnz ? b0 + kCsWin : nnz;
+  unsigned mine = 0;
+  for (int64_t i = b0 + threadIdx.x; i < b1; i += kDenseThreads) {
+    const unsigned line = (unsigned)ent[i] >> line_shift;
+    const unsigned h = line < (unsigned)(kCsSetWords * 32) ? line : (line * 2654435761u) >> 13;          // (hashed beyond the set's size)
+    const unsigned bit = 1u << (h & 31u);
+    const unsigned old = atomicOr(&s_set[(h >> 5) & (kCsSetWords - 1)], bit);
+    mine += (old & bit) ? 0u : 1u;
+  }
+  atomicAdd(&s_new, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) { atomicAdd(&out[0], (unsigned long long)s_new); atomicAdd(&out[1], (unsigned long long)(b1 - b0)); }
+}
+// *ratio = distinct lines of x per nonzero over the sampled windows (0 when nothing could be measured)
+int cs_gather_ratio(const kkamd_crs_t* A, int x_elem, hipStream_t st, double* ratio) {
+  *ratio = 0.0;
+  if (A->nnz <= 0) return KKAMD_OK;
+  DevBuf cnt;
+  if (cnt.alloc(2 * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
+  unsigned long long* d_c = cnt.as<unsigned long long>();
+  KK_HIP(hipMemsetAsync(d_c, 0, 2 * sizeof(unsigned long long), st));
+  const int nwin = A->nnz >= (int64_t)kCsWin * kCsWins ? kCsWins : 1;
+  KK_LAUNCH(cs_distinct_lines_kernel, (unsigned)nwin, kDenseThreads, 0, st, A->nnz, (const int32_t*)A->d_entries, x_elem == 8 ? 4 : 5, d_c);
+  KK_LAUNCH_CHECK();
+  unsigned long long h[2] = {0, 0};
+  KK_HIP(hipMemcpyAsync(h, d_c, sizeof h, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  if (h[1]) *ratio = (double)h[0] / (double)h[1];
+  return KKAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 void cs_plan_destroy(kkamd_cs_plan* cs) {
   if (!cs) return;
-  void* bufs[] = {cs->d_row, cs->d_col, cs->d_val, cs->d_dst, cs->d_fp, cs->d_shadow};
+  void* bufs[] = {cs->d_row, cs->d_col, cs->d_val, cs->d_dst, cs->d_fp, cs->d_shadow, cs->d_mask, cs->d_part, cs->d_head, cs->d_tail, cs->d_tkey, cs->d_cflag};
   for (void* b : bufs) if (b) (void)hipFree(b);
   delete cs;
 }
@@ -308,12 +487,13 @@ int64_t cs_plan_query(const kkamd_cs_plan* cs, int what) {
     case 0: return cs->nslabs;
     case 1: return cs->shift;
     case 2: return (int64_t)cs->bytes;
+    case 3: return cs->det ? 1 : 0;
     default: return 0;
   }
 }
 
 template <class OffT, class AT>
-static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, hipStream_t st) {
+static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, int x_elem, bool det, hipStream_t st) {
   *out = nullptr;
   const int64_t nnz = A->nnz;
   kkamd_cs_plan* cs = new (std::nothrow) kkamd_cs_plan();
@@ -343,12 +523,26 @@ static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, 
             (const AT*)A->d_values, shift, nslabs, nbits, ntiles, (const int64_t*)H, o_row, o_col, o_val, dst);
   // the scatter kernel copied the values: the copy is current, nothing is recorded yet (the first tracked call fills shadow / fingerprints)
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return give_up();
+  if (det) {
+    // the deterministic form's state: slab mask per row, per-slab partial sums, the cut runs' pieces per chunk
+    cs->det = true; cs->nrows = A->num_rows; cs->nchunks = ceil_div(nnz, (int64_t)kCsDetChunk);
+    cs->part_bytes = (size_t)cs->nslabs * (size_t)A->num_rows * (size_t)x_elem;
+    if (cs->nslabs > 64 || hipMalloc((void**)&cs->d_mask, sizeof(unsigned long long) * (size_t)A->num_rows) != hipSuccess ||
+        hipMalloc(&cs->d_part, cs->part_bytes) != hipSuccess || hipMalloc(&cs->d_head, (size_t)x_elem * (size_t)cs->nchunks) != hipSuccess ||
+        hipMalloc(&cs->d_tail, (size_t)x_elem * (size_t)cs->nchunks) != hipSuccess || hipMalloc((void**)&cs->d_tkey, sizeof(long long) * (size_t)cs->nchunks) != hipSuccess ||
+        hipMalloc((void**)&cs->d_cflag, sizeof(int) * (size_t)cs->nchunks) != hipSuccess || hipMemsetAsync(cs->d_mask, 0, sizeof(unsigned long long) * (size_t)A->num_rows, st) != hipSuccess)
+      return give_up();
+    unsigned long long* d_mask = cs->d_mask; const int32_t* c_row = cs->d_row; const int32_t* c_col = cs->d_col;
+    KK_LAUNCH(cs_mask_kernel, (unsigned)ceil_div(nnz, (int64_t)kBlock), kBlock, 0, st, nnz, c_row, c_col, shift, d_mask);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return give_up();
+    cs->bytes += sizeof(unsigned long long) * (size_t)A->num_rows + cs->part_bytes + (size_t)cs->nchunks * (2 * (size_t)x_elem + 12);
+  }
   *out = cs;
   return KKAMD_OK;
 }
 
 // Builds the slab-order copy (nullptr in *out when HBM cannot hold it).  x_elem: bytes per x element (sizes the slabs).
-int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st) {
+int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st, bool det) {
   *out = nullptr;
   if (A->nnz <= 0 || A->num_rows <= 0 || A->num_cols <= 0) return KKAMD_OK;
   int shift = shift_knob;
@@ -359,16 +553,17 @@ int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_kn
     const double per_row = (double)A->nnz / (double)A->num_rows;
     for (int widen = 0; widen < 2 && per_row * (double)((int64_t)1 << shift) < 0.5 * (double)A->num_cols; ++widen) ++shift;
   }
-  while (ceil_div(A->num_cols, (int64_t)1 << shift) > kCsMaxSlabs) ++shift;
+  while (ceil_div(A->num_cols, (int64_t)1 << shift) > (det ? 64 : kCsMaxSlabs)) ++shift;      // (the deterministic form keeps a 64-bit slab mask per row)
   const size_t off_b = A->offset_type == KKAMD_I64 ? 8 : 4, val_b = A->value_type == KKAMD_F64 ? 8 : 4;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
   // (+ val_b: the shadow copy of A.values that exact value tracking, the default, compares against at every call)
   const double need = (double)A->nnz * (8.0 + 2.0 * val_b + off_b) + 8.0 * (double)ceil_div(A->num_cols, (int64_t)1 << shift) * (double)ceil_div(A->nnz, (int64_t)kCsTile);
-  if (need > (double)free_b / 4.0) return KKAMD_OK;
+  const double need_det = det ? (double)ceil_div(A->num_cols, (int64_t)1 << shift) * (double)A->num_rows * x_elem + 8.0 * (double)A->num_rows : 0.0;
+  if (need + need_det > (double)free_b / 4.0) return KKAMD_OK;
   const bool o64 = A->offset_type == KKAMD_I64;
-  if (A->value_type == KKAMD_F64) return o64 ? cs_build_typed<int64_t, double>(out, A, shift, st) : cs_build_typed<int32_t, double>(out, A, shift, st);
-  return o64 ? cs_build_typed<int64_t, float>(out, A, shift, st) : cs_build_typed<int32_t, float>(out, A, shift, st);
+  if (A->value_type == KKAMD_F64) return o64 ? cs_build_typed<int64_t, double>(out, A, shift, x_elem, det, st) : cs_build_typed<int32_t, double>(out, A, shift, x_elem, det, st);
+  return o64 ? cs_build_typed<int64_t, float>(out, A, shift, x_elem, det, st) : cs_build_typed<int32_t, float>(out, A, shift, x_elem, det, st);
 }
 
 template <class OffT, class AT, class YT>
@@ -379,9 +574,22 @@ static int cs_apply_typed(kkamd_cs_plan* cs, const kkamd_crs_t* A, const YT* x, 
   int rc = values_track(tracking < 0 ? 1 : tracking, tracking < 0, A->offset_type, A->value_type, nnz, A->d_values, cs->d_dst, o_val, cs->d_fp, &cs->d_shadow,
                         &cs->fp_valid, &cs->shadow_valid, &cs->shadow_failed, &cs->stale, st);
   if (rc) return rc;
+  const int32_t* row = cs->d_row; const int32_t* col = cs->d_col; const int shift = cs->shift;
+  if (cs->det) {
+    if (cs->part_bytes != (size_t)cs->nslabs * (size_t)A->num_rows * sizeof(YT))
+      return fail(KKAMD_ERR_STATE, "kkamd_spmv: the column-slab copy was built for another vector type");
+    YT* part = (YT*)cs->d_part; YT* head = (YT*)cs->d_head; YT* tail = (YT*)cs->d_tail; long long* tkey = cs->d_tkey; int* cflag = cs->d_cflag;
+    const int64_t nchunks = cs->nchunks, nrows = A->num_rows; const int nslabs = cs->nslabs; const unsigned long long* mask = cs->d_mask;
+    KK_LAUNCH((cs_det_kernel<AT, YT>), (unsigned)ceil_div(nchunks, (int64_t)(kBlock / 64)), kBlock, 0, st, nnz, nrows, row, col, (const AT*)o_val, shift, x, part, head, tail, tkey, cflag);
+    KK_LAUNCH_CHECK();
+    KK_LAUNCH((cs_det_fix_kernel<YT>), (unsigned)ceil_div(nchunks, (int64_t)kBlock), kBlock, 0, st, nchunks, (const YT*)head, (const YT*)tail, (const long long*)tkey, (const int*)cflag, part);
+    KK_LAUNCH_CHECK();
+    KK_LAUNCH((cs_det_reduce_kernel<YT>), (unsigned)ceil_div(nrows, (int64_t)kBlock), kBlock, 0, st, nrows, nslabs, mask, (const YT*)part, y, alpha, beta);
+    KK_LAUNCH_CHECK();
+    return KKAMD_OK;
+  }
   rc = launch_scale<YT>(y, A->num_rows, 1, 1, 0, beta, st);
   if (rc) return rc;
-  const int32_t* row = cs->d_row; const int32_t* col = cs->d_col; const int shift = cs->shift;
   KK_LAUNCH((cs_spmv_kernel<AT, YT>), (unsigned)ceil_div(nnz, (int64_t)kBlock * kCsU), kBlock, 0, st, nnz, row, col, (const AT*)o_val, shift, x, y, alpha);
   KK_LAUNCH_CHECK();
   return KKAMD_OK;

@@ -64,11 +64,13 @@ struct SpmvTuning {
   int pattern_codes = 1;           // staged-x tiles: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one
                                    // (27-pt 300^3 1.349 -> 1.267 ms, 7-pt 400^3 1.025 -> 0.940 ms), 2 = whenever any tile has one, 0 = never
   int pattern_codes_min_knnz = 10000;  // ... from this many thousand nnz (5-pt 1000^2, 5e6 nnz: 17.5 -> 18.3 us with the records)
-  int colslab = 0;                 // rank 1, mode N, matrices whose x gather defeats the caches (kk_spmv_colslab.hip): 0 (default) = never: its
-                                   // products reach y through atomics (results vary in the last bits from run to run, the reference's are
-                                   // deterministic) and its selection times kernels inside the first call; 1 = build the column-slab copy at the
-                                   // first call when the analysis says "gather-bound", time both kernels and keep the faster; 2 = always use
-                                   // the copy (tests)
+  int colslab = 3;                 // rank 1, mode N, matrices whose x gather defeats the caches (kk_spmv_colslab.hip): a column-slab copy of the matrix.
+                                   // 3 (default) = the DETERMINISTIC form (per-slab partial sums of every row, added in slab order: no atomics, the
+                                   // same bits on every run), chosen by a RULE at the first call -- the analysis says "no column structure", x is
+                                   // several L2s large and sampled windows of the matrix name nearly one line of x per nonzero (colslab_min_pct) --
+                                   // nothing is timed; 4 = always the deterministic form (tests); 1 = the atomic form, chosen by timing both kernels
+                                   // inside the first call (results vary in the last bits from run to run); 2 = always the atomic form (tests); 0 = never
+  int colslab_min_pct = 85;        // ... the rule of 3: distinct lines of x per nonzero, in percent, from which the gather counts as cache-defeating
   int colslab_min_knnz = 20000;    // ... from this many thousand nnz
   int colslab_shift = 0;           // ... log2 of the columns per slab (0 = 2 MB of x)
   int check_entries = 0;           // debug aid: 1 = every call hashes the matrix's column array and compares it with the hash the analysis saw (one
@@ -158,6 +160,7 @@ struct kkamd_spmv_plan {
   kkamd_cs_plan* cs = nullptr;
   bool cs_tried = false;
   double cs_crs_us = 0.0, cs_us = 0.0;     // what the selection measured, kept when the copy lost and was freed
+  double cs_ratio = 0.0;                   // distinct lines of x per nonzero the selection rule of the deterministic form measured
   int mv2_rb = 0;
   bool mv2_tried = false, mv_period_known = false;
   int64_t mv_period = 0;
@@ -189,13 +192,14 @@ int  mv6_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream_t st)
 int  mv6_spmv(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t ldx, double* Y, int64_t ys0, int64_t ys1,
               int64_t nvec, double alpha, double beta, hipStream_t st);   // X row-major, ldx even, 16-byte aligned
 void cs_plan_destroy(kkamd_cs_plan* cs);
-int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes
-int  cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st);
+int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes, 3 deterministic form
+int  cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st, bool det = false);   // det: the deterministic form (per-slab partial sums, no atomics)
 int  cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, int tracking, hipStream_t st);
 int64_t values_fp_tiles(int64_t nnz);
 // keeps a re-ordered copy of A.values (o_val[dst[i]] = val[i]) current under the "values_tracking" policy (kk_spmv_colslab.hip)
 int  values_track(int tracking, bool promise, int offset_type, int value_type, int64_t nnz, const void* val, const void* dst, void* o_val,
                   unsigned long long* fp, void** shadow, bool* fp_valid, bool* shadow_valid, bool* shadow_failed, bool* stale, hipStream_t st);
+int  cs_gather_ratio(const kkamd_crs_t* A, int x_elem, hipStream_t st, double* ratio);   // distinct 128-byte lines of x per nonzero over sampled windows
 void cs_mark_stale(kkamd_cs_plan* cs);
 void cs_reset_tracking(kkamd_cs_plan* cs);
 // modes T / H of an analysed handle: the cached transpose (built on first use, values brought up to date) as a matrix + its plan;

@@ -214,6 +214,54 @@ def check_transpose_plan_inherits_knobs(be):
         kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 1000))
 
 
+def check_colslab_deterministic(be):
+    """The DETERMINISTIC column-slab form of rank-1 mode N (round 5; `colslab` 4 forces it, 3 -- the default -- chooses it by rule): per-slab
+    partial sums of every row, stored by exactly one writer, cut runs summed in chunk order, slabs added in ascending order -- no atomics.
+    Cases: rows longer than a wave's chunk of 512 entries inside ONE slab (runs cut by several chunk boundaries: head / tail / whole-chunk
+    pieces), empty rows, rows with one entry per slab, duplicate columns, a matrix wider than tall, the last chunk shorter than a round,
+    beta != 0, NaN in y with beta = 0, fp32 values / vectors, 64-bit offsets, value changes under exact tracking -- and the SAME BITS
+    from two handles and from repeated calls."""
+    import struct
+    rng = np.random.default_rng(4)
+    n, k = 1200, 5000
+    lens = rng.integers(0, 12, size=n); lens[3] = 1700; lens[4] = 0; lens[5] = 3000; lens[700] = 4999; lens[n - 1] = 530
+    rm = np.zeros(n + 1, dtype=np.int64); np.cumsum(lens, out=rm[1:])
+    ent = np.concatenate([np.sort(rng.choice(k, size=l, replace=False)) for l in lens]).astype(np.int32)
+    ent[rm[5]:rm[5] + 2000] = np.sort(rng.integers(0, 60, size=2000))                 # 2000 entries (duplicates) of one row inside the first slab: a run over four chunks
+    A0 = oracle.Crs(n, k, rm, ent, 1 + 49 * rng.random(rm[-1]))
+    wide = oracle.random_crs(300, 9000, 40, variance=10, seed=6)
+    for M in (A0, wide):
+        for shift in (6, 9, 13):
+            kn = {"colslab": 4, "colslab_shift": shift}
+            h = check_spmv(be, M, "N", 1.5, 0.5, "SPMV_DEFAULT", knobs=kn, max_val=50.0, expect={"colslab": 1, "colslab_deterministic": 1})
+            assert h.query("colslab_slabs") <= 64
+            check_spmv(be, M, "N", 1.0, 0.0, "SPMV_DEFAULT", knobs=kn, max_val=50.0, nans=True)
+        check_spmv(be, M, "N", -1.0, 2.0, "SPMV_DEFAULT", knobs={"colslab": 4, "colslab_shift": 7}, max_val=50.0, offset_dtype=np.int64, value_dtype=np.float32)
+        check_spmv(be, M, "N", 1.0, 1.0, "SPMV_DEFAULT", knobs={"colslab": 4, "colslab_shift": 7, "colslab_const": 1}, max_val=50.0, value_dtype=np.float32, vec_dtype=np.float32)
+    # the same bits: two handles, repeated calls, after a value change and back
+    A = dev(be, A0)
+    x = rng.random(k); xd = be.from_numpy(x)
+    outs = []
+    for rep in range(2):
+        h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("colslab", 4); h.set("colslab_shift", 6)
+        yd = be.from_numpy(np.zeros(n))
+        for call in range(2):
+            kk.spmv(h, "N", 1.0, A, xd, 0.0, yd)
+            outs.append(be.to_numpy(yd).copy())
+        assert h.query("colslab_deterministic") == 1
+    for o in outs[1:]:
+        assert o.tobytes() == outs[0].tobytes(), "the deterministic column-slab form gave different bits"
+    exp = oracle.spmv_serial("N", A0, 1.0, x, 0.0, np.zeros(n))
+    np.testing.assert_allclose(outs[0], exp, rtol=1e-11, atol=1e-9)
+    v = A0.values.copy(); v[::7] *= -2.0
+    A.values[:] = be.from_numpy(v)                                # exact tracking (default): the copy follows
+    kk.spmv(h, "N", 1.0, A, xd, 0.0, yd)
+    exp2 = oracle.spmv_serial("N", oracle.Crs(n, k, rm, ent, v), 1.0, x, 0.0, np.zeros(n))
+    np.testing.assert_allclose(be.to_numpy(yd), exp2, rtol=1e-11, atol=1e-9)
+    # the rule of the default handle says no on a small matrix (x is not several L2s large): nothing is built
+    check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 1})
+
+
 def check_values_tracking(be):
     """The re-ordered value copies of a plan (cached transpose, column-slab copy) under the three "values_tracking" policies: 0 exact
     (default), 1 notify (SPMVHandle.values_changed), 2 fingerprints.  A.values is rewritten in place between calls: one value, every value,

@@ -115,7 +115,7 @@ def test_knob_validation(be):
     kk = kk_loader.load()
     A0 = oracle.random_crs(3000, 3000, 9, seed=1)
     for key, val in (("xcd_remap", 3), ("xcd_remap", 6), ("mv_remap", 12), ("nnz_per_thread", 5), ("stream_variant", 2), ("ablate", 1),
-                     ("lds_pad_kb", 8), ("nontemporal", 1), ("kernel", 7), ("window_codes", 9), ("colslab", 3), ("colslab_shift", 1), ("colslab_shift", 31),
+                     ("lds_pad_kb", 8), ("nontemporal", 1), ("kernel", 7), ("window_codes", 9), ("colslab", 5), ("colslab_shift", 1), ("colslab_shift", 31),
                      ("colslab_const", 2), ("colslab_min_knnz", -1), ("mv4_xcol", 2), ("mv4_2d", -1)):
         h = kk.SPMVHandle("SPMV_DEFAULT"); h.set(key, val)
         with pytest.raises(kk.KkamdError):
@@ -209,6 +209,10 @@ def test_mv5_matrix_core(be):
 
 def test_check_entries_knob(be):
     pc.check_entries_guard(be)
+
+
+def test_column_slab_deterministic_form(be):
+    pc.check_colslab_deterministic(be)
 
 
 def test_transposed_plan_inherits_the_handles_knobs(be):
@@ -558,7 +562,8 @@ def test_column_slab_copy(be):
         pc.check_spmv(be, A0, "T", 1.0, 0.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0)          # mode T never takes the copy of A
     # the automatic mode does nothing on a small matrix, and nothing at all under the emulator (there is nothing to time)
     h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 1}, expect={"colslab": 0, "colslab_tried": 1})
-    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 0})       # opt-in: the default handle never builds the copy
+    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 1})       # the default handle applies its rule (deterministic form): a small matrix says no
+    h = pc.check_spmv(be, cases[0], "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 0}, expect={"colslab": 0, "colslab_tried": 0})
 
 
 def test_column_slab_follows_value_changes(be):

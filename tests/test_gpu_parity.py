@@ -239,6 +239,10 @@ def test_check_entries_knob(be):
     pc.check_entries_guard(be)
 
 
+def test_column_slab_deterministic_form(be):
+    pc.check_colslab_deterministic(be)
+
+
 def test_transposed_plan_inherits_the_handles_knobs(be):
     pc.check_transpose_plan_inherits_knobs(be)
 
@@ -972,7 +976,8 @@ def test_column_slab_copy(be):
         pc.check_spmv(be, A0, "N", 1.0, 1.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6, "colslab_const": 1}, max_val=50.0, value_dtype=np.float32, vec_dtype=np.float32)
         pc.check_spmv(be, A0, "T", 1.0, 0.0, "SPMV_DEFAULT", knobs={"colslab": 2, "colslab_shift": 6}, max_val=50.0)
     pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 1}, expect={"colslab": 0, "colslab_tried": 1})       # small matrix: the gates say no
-    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 0})       # opt-in: the default handle never builds the copy
+    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 1})       # the default handle applies its rule (deterministic form): a small matrix says no
+    pc.check_spmv(be, base, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, knobs={"colslab": 0}, expect={"colslab": 0, "colslab_tried": 0})
 
 
 def test_column_slab_follows_value_changes(be):

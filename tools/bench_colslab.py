@@ -43,14 +43,18 @@ for name, A in matrices():
     x = torch.rand(nc, device=dev, dtype=torch.float64); y = torch.zeros(nr, device=dev, dtype=torch.float64); y0 = torch.zeros_like(y)
     out = {"matrix": name, "rows": nr, "nnz": nnz}
     alg = nnz * 12 + (nr + 1) * 4 + nc * 8 + nr * 8
-    for tag, knobs in (("crs_stream", {"colslab": 0}), ("default", {}), ("colslab_forced", {"colslab": 2}), ("colslab_const_values", {"colslab": 2, "colslab_const": 1})):
+    for tag, knobs in (("crs_stream", {"colslab": 0}), ("default", {}), ("det_forced", {"colslab": 4}), ("det_forced_notified_values", {"colslab": 4, "values_tracking": 1}),
+                       ("det_forced_8MB_slabs", {"colslab": 4, "colslab_shift": 20}),
+                       ("colslab_forced", {"colslab": 2}), ("colslab_const_values", {"colslab": 2, "colslab_const": 1})):
         h = kk.SPMVHandle("SPMV_DEFAULT")
         for k_, v_ in knobs.items(): h.set(k_, v_)
         kk.spmv(h, "N", 1.0, A, x, 0.0, y)
         if tag == "crs_stream": y0.copy_(y)
         ms = timeit(lambda: kk.spmv(h, "N", 1.0, A, x, 0.0, y))
         out[tag + "_ms"] = round(ms, 4); out[tag + "_frac_8TBps_crs_bytes"] = round(alg / ms / 1e6 / 8000, 3)
-        if tag == "default": out["default_kept_copy"] = h.query("colslab"); out["selection_us_crs_vs_copy"] = [h.query("colslab_crs_us"), h.query("colslab_us")]
+        if tag == "default":
+            out["default_kept_copy"] = h.query("colslab"); out["default_deterministic_form"] = h.query("colslab_deterministic"); out["lines_of_x_per_nonzero"] = h.query("colslab_lines_permille") / 1000
+            y1 = y.clone(); kk.spmv(h, "N", 1.0, A, x, 0.0, y); out["default_bit_stable"] = bool((y1 == y).all().item())
         if tag == "colslab_forced": out["slabs"] = h.query("colslab_slabs"); out["copy_bytes_per_nnz"] = round(h.query("colslab_bytes") / nnz, 2)
         out.setdefault("max_rel_diff_vs_crs", 0.0)
         out["max_rel_diff_vs_crs"] = max(out["max_rel_diff_vs_crs"], float(((y - y0).abs().max() / y0.abs().max()).item()))
