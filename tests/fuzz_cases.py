@@ -62,7 +62,7 @@ def run(be, budget, seed0=0, max_cases=None, kinds=None):
                 for algo in (None, "SPMV_DEFAULT", "SPMV_MERGE_PATH"):
                     for mode in "NT":
                         # analysed handles also through the column-slab copy (forced: slabs of 2^4 .. 2^12 columns) and the fingerprint-refreshed transpose
-                        kn = {"colslab": 2, "colslab_shift": int(rng.integers(4, 13)), "colslab_const": int(rng.integers(0, 2)), "explicit_transpose_min_knnz": 0} if algo and rng.random() < 0.5 else None
+                        kn = {"colslab": int(rng.choice([2, 4, 4])), "colslab_shift": int(rng.integers(4, 13)), "colslab_const": int(rng.integers(0, 2)), "explicit_transpose_min_knnz": 0} if algo and rng.random() < 0.5 else None
                         pc.check_spmv(be, M, mode, float(rng.integers(-3, 4)), float(rng.integers(-2, 3)), algo=algo, offset_dtype=odt, max_val=50.0, seed=case, knobs=kn)
                 # rank 2 on the same matrix: the nonzero-split kernel (forced, or chosen by the long-row share), the gather kernels, and modes T / H
                 # through the cached transpose under a random value-tracking policy
