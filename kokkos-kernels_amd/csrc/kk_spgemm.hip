@@ -132,8 +132,8 @@ struct SpgemmTuning {
   int list_staged    = 1;         // symbolic: the entry lists kept for the numeric phase are written wave by wave, 64 consecutive words per round (0 = every lane writes its own run)
   int nt             = 0;         // value kernels of the dense rows: entries(C) / values(C) through nontemporal loads / stores
   int sort_rows      = 1;         // the row lists of the dense kernels are ordered by size, largest first (0 = the order the binning left)
-  int pool_keep      = 0;         // 1 = the process-wide store of bitmaps / entry lists outlives the last handle (hosts that run large products back to back,
-                                  // one handle at a time: an allocation of GBs per product is not free); 0 = destroying the last handle returns it to the device
+  int pool_keep      = 0;         // the process-wide store of bitmaps / entry lists when the last handle is destroyed: 0 = returned to the device after the process's
+                                  // first product, kept once the process has come back for it (see BmPool); 1 = always kept; 2 = always returned
 };
 static SpgemmTuning g_spgemm;
 
@@ -235,24 +235,23 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_long_kernel(int64_t m, co
   }
 }
 // are the rows of a CRS graph column-sorted (non-strict)?  8 lanes per row; *unsorted is set to 1 otherwise.
+// are the rows of a CRS graph column-sorted (non-strict)?  *unsorted is set to 1 otherwise.  The entries are STREAMED (coalesced: a
+// work-item per pair of neighbours); a descent is fine when it crosses a row boundary, which a bitmap of the row starts decides (one bit
+// per entry, set by rows_mark_kernel).  (8 lanes per row read the array at 35 GB/s on R-MAT scale 20: 1.9 ms of every symbolic phase; a
+// binary search of the row map at every descent instead of the bitmap cost 0.5 ms on stencil matrices, whose rows end every 7 - 27 entries.)
 template <class OffT>
-__global__ __launch_bounds__(kBlock) void rows_sorted_kernel(int64_t n, const OffT* __restrict__ rm,
-                                                             const int32_t* __restrict__ ent, int* __restrict__ unsorted) {
-  // the entries are STREAMED (coalesced: a work-item per pair of neighbours); a descent is fine when it crosses a row boundary, which a
-  // binary search of the row map decides -- once per row on sorted input.  (8 lanes per row read the array at 35 GB/s: 1.9 ms of every
-  // symbolic phase on R-MAT scale 20.)
-  const int64_t nnz = n > 0 ? (int64_t)rm[n] : 0;
+__global__ __launch_bounds__(kBlock) void rows_mark_kernel(int64_t n, const OffT* __restrict__ rm, unsigned* __restrict__ starts) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n) return;
+  const int64_t p = (int64_t)rm[r];
+  if ((int64_t)rm[r + 1] > p) atomicOr(&starts[p >> 5], 1u << (p & 31));          // the first entry of a row that has one
+}
+__global__ __launch_bounds__(kBlock) void rows_sorted_kernel(int64_t nnz, const int32_t* __restrict__ ent, const unsigned* __restrict__ starts, int* __restrict__ unsorted) {
   bool bad = false;
-  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j + 1 < nnz; j += (int64_t)gridDim.x * kBlock) {
-    if (ent[j] > ent[j + 1]) {
-      int64_t lo = 0, hi = n;                       // is j + 1 the first entry of a row?  (first row whose start is >= j + 1)
-      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)rm[mid] < j + 1) lo = mid + 1; else hi = mid; }
-      bad |= !(lo <= n && (int64_t)rm[lo] == j + 1);
-    }
-  }
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j + 1 < nnz; j += (int64_t)gridDim.x * kBlock)
+    if (ent[j] > ent[j + 1]) bad |= !((starts[(j + 1) >> 5] >> ((j + 1) & 31)) & 1u);
   if (bad) *unsorted = 1;
 }
-
 // sum of the per-row counts (before the scan) in 64 bits: a 32-bit row_map must not wrap silently
 template <class OffT> __global__ void sum_counts_kernel(int64_t m, const OffT* __restrict__ counts, unsigned long long* out) {
   unsigned long long s = 0;
@@ -2722,9 +2721,14 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
 // such a buffer is not free: every third or so symbolic phase took 1.3-1.6 s instead of 66 ms with an allocation per handle.  The
 // buffer is therefore kept in a process-wide pool between uses (one user at a time; a second concurrent handle allocates its own);
 // kkamd_release_scratch() gives it back.
-struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; int live_handles = 0; std::mutex m; };
-// Destroying the LAST live handle returns the buffer to the device (knob "spgemm_pool_keep" 1: it outlives the handles, for hosts that run
-// large products back to back one handle at a time); kkamd_release_scratch() gives it back at any time.  Its size: the bitmaps of the rows
+struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; int live_handles = 0; bool released_once = false, sticky = false; std::mutex m; };
+// Who keeps it (knob "spgemm_pool_keep" 0, the default): a process's FIRST product returns the buffer to the device when its last handle is
+// destroyed -- a one-shot caller gets its memory back without knowing about the pool.  A process that comes back for the buffer after such
+// a release is a repeat user: from then on the buffer outlives the handles (until kkamd_release_scratch), because giving GBs back and
+// asking for them again is not cheap on this runtime: hipMalloc of 14 GB returns in 0.3 ms most of the time and in 0.6 - 1.5 s every second
+// or third time after a hipFree (tools/probes/probe_malloc.hip, profiles/round5/probe_malloc.txt) -- with a release per handle the
+// symbolic phase of R-MAT scale 20 took 1.7 s in two of three repetitions.  1 = always keep, 2 = always return with the last handle.
+// kkamd_release_scratch() gives it back at any time.  Its size: the bitmaps of the rows
 // that can qualify (at most an eighth of the HBM that was free when it was sized) plus the entry lists the other dense rows can need (at
 // most a tenth).  Kokkos-based hosts: INTEGRATION.md registers kkamd_release_scratch with
 // Kokkos::push_finalize_hook; the C++ drop-in's Kokkos::finalize() calls it.
@@ -2744,6 +2748,7 @@ static size_t take_bitmap_store(kkamd_spgemm_handle* h, size_t need) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
   if (!pool.in_use && (pool.p == nullptr || pool.device == dev)) {      // the pool belongs to the device that filled it first
+    if (pool.p == nullptr && pool.released_once) pool.sticky = true;      // back for more after a release: a repeat user (see BmPool)
     if (pool.bytes < need / 2 + 1) {
       if (pool.p) { (void)hipFree(pool.p); pool.p = nullptr; pool.bytes = 0; }
       if (hipMalloc(&pool.p, need) != hipSuccess) { (void)hipGetLastError(); pool.p = nullptr; return 0; }
@@ -2846,8 +2851,16 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     KK_HIP(flag.alloc(sizeof(int)));
     int* d_flag = flag.as<int>();
     KK_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
-    const int64_t nbk = ceil_div(n * 8, kBlock);
-    KK_LAUNCH((rows_sorted_kernel<OffT>), (unsigned)(nbk < 8192 ? nbk : 8192), kBlock, 0, st, n, rmB, entB, d_flag);
+    DevBuf starts_b;
+    const size_t sw = (size_t)(nnzB / 32 + 2);
+    KK_HIP(starts_b.alloc(sizeof(unsigned) * sw));
+    unsigned* d_starts = starts_b.as<unsigned>();
+    KK_HIP(hipMemsetAsync(d_starts, 0, sizeof(unsigned) * sw, st));
+    if (n > 0 && nnzB > 1) {
+      KK_LAUNCH((rows_mark_kernel<OffT>), (unsigned)ceil_div(n, kBlock), kBlock, 0, st, n, rmB, d_starts);
+      const int64_t nbk = ceil_div(nnzB, kBlock);
+      KK_LAUNCH(rows_sorted_kernel, (unsigned)(nbk < 8192 ? nbk : 8192), kBlock, 0, st, nnzB, entB, (const unsigned*)d_starts, d_flag);
+    }
     KK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
     h->b_sorted = h_flag == 0;
@@ -3518,7 +3531,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_keep_lists") g_spgemm.keep_lists = value != 0;
   else if (k == "spgemm_val_tiny_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_tiny_cnt: %d is negative", value); g_spgemm.val_tiny_cnt = value; }
   else if (k == "spgemm_emit_sort") g_spgemm.emit_sort = value != 0;
-  else if (k == "spgemm_pool_keep") g_spgemm.pool_keep = value != 0;
+  else if (k == "spgemm_pool_keep") { if (value < 0 || value > 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_pool_keep: 0 (first product returns the store, repeat users keep it), 1 (keep) or 2 (return)"); g_spgemm.pool_keep = value; }
   else if (k == "spgemm_sort_rows") g_spgemm.sort_rows = value != 0;
   else if (k == "spgemm_nt") g_spgemm.nt = value != 0;
   else if (k == "spgemm_list_staged") g_spgemm.list_staged = value != 0;
@@ -3568,9 +3581,15 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (h->d_items_direct) (void)hipFree(h->d_items_direct);
   delete h;
   // the last handle gone: the pooled store (GBs) goes back to the device unless the host asked to keep it ("spgemm_pool_keep")
-  bool last = false;
-  { kk::BmPool& pool = kk::bm_pool(); std::lock_guard<std::mutex> g(pool.m); last = --pool.live_handles <= 0; if (pool.live_handles < 0) pool.live_handles = 0; }
-  if (last && !kk::g_spgemm.pool_keep) (void)kk::release_bitmap_pool();
+  bool release = false;
+  {
+    kk::BmPool& pool = kk::bm_pool(); std::lock_guard<std::mutex> g(pool.m);
+    const bool last = --pool.live_handles <= 0;
+    if (pool.live_handles < 0) pool.live_handles = 0;
+    release = last && pool.p && (kk::g_spgemm.pool_keep == 2 || (kk::g_spgemm.pool_keep == 0 && !pool.sticky));
+    if (release) pool.released_once = true;
+  }
+  if (release) (void)kk::release_bitmap_pool();
   return KKAMD_OK;
 }
 

@@ -492,23 +492,24 @@ def check_spgemm_pool_release(be):
         kh.destroy_spgemm_handle()
         return held, other
 
-    free0 = torch.cuda.mem_get_info()[0]
-    held, _ = run()
-    torch.cuda.synchronize(); torch.cuda.empty_cache()
-    free1 = torch.cuda.mem_get_info()[0]
-    assert free0 - held < (1 << 30), "store of %d MB for a product with 6e4 multiplications" % ((free0 - held) >> 20)    # (it was a tenth of the free HBM)
-    assert free0 - free1 < (8 << 20), "the last handle is gone and %d MB are still held" % ((free0 - free1) >> 20)
-    # a second live handle keeps the pool (the next product of the job will use it) ...
-    _, other = run(keep_a_second_handle=True)
-    torch.cuda.synchronize(); torch.cuda.empty_cache()
-    free2 = torch.cuda.mem_get_info()[0]
-    other.destroy_spgemm_handle()
-    torch.cuda.synchronize(); torch.cuda.empty_cache()
-    free3 = torch.cuda.mem_get_info()[0]
-    assert free3 >= free2 and free0 - free3 < (8 << 20), (free0, free2, free3)
-    # ... and so does the knob, until kkamd_release_scratch
-    kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 1))
+    kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 2))       # always returned with the last handle
     try:
+        free0 = torch.cuda.mem_get_info()[0]
+        held, _ = run()
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        free1 = torch.cuda.mem_get_info()[0]
+        assert free0 - held < (1 << 30), "store of %d MB for a product with 6e4 multiplications" % ((free0 - held) >> 20)    # (it was a tenth of the free HBM)
+        assert free0 - free1 < (8 << 20), "the last handle is gone and %d MB are still held" % ((free0 - free1) >> 20)
+        # a second live handle keeps the pool (the next product of the job will use it) until it is destroyed too
+        _, other = run(keep_a_second_handle=True)
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        free2 = torch.cuda.mem_get_info()[0]
+        other.destroy_spgemm_handle()
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        free3 = torch.cuda.mem_get_info()[0]
+        assert free3 >= free2 and free0 - free3 < (8 << 20), (free0, free2, free3)
+        # 1 = it outlives the handles until kkamd_release_scratch
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 1))
         run()
         torch.cuda.synchronize(); torch.cuda.empty_cache()
         free4 = torch.cuda.mem_get_info()[0]
@@ -516,6 +517,13 @@ def check_spgemm_pool_release(be):
         torch.cuda.synchronize()
         free5 = torch.cuda.mem_get_info()[0]
         assert free5 >= free4 and free0 - free5 < (8 << 20), (free0, free4, free5)
+        # 0 (default): whatever the process did before, after a release the next product's store is returned or kept -- and kkamd_release_scratch
+        # always returns it
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 0))
+        run(); run()
+        kk._capi.check(be.lib, be.lib.kkamd_release_scratch())
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        assert free0 - torch.cuda.mem_get_info()[0] < (8 << 20)
     finally:
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_pool_keep", 0))
 
