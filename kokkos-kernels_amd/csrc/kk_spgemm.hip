@@ -235,21 +235,40 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_long_kernel(int64_t m, co
   }
 }
 // are the rows of a CRS graph column-sorted (non-strict)?  8 lanes per row; *unsorted is set to 1 otherwise.
-// are the rows of a CRS graph column-sorted (non-strict)?  *unsorted is set to 1 otherwise.  The entries are STREAMED (coalesced: a
-// work-item per pair of neighbours); a descent is fine when it crosses a row boundary, which a bitmap of the row starts decides (one bit
-// per entry, set by rows_mark_kernel).  (8 lanes per row read the array at 35 GB/s on R-MAT scale 20: 1.9 ms of every symbolic phase; a
-// binary search of the row map at every descent instead of the bitmap cost 0.5 ms on stencil matrices, whose rows end every 7 - 27 entries.)
+// are the rows of a CRS graph column-sorted (non-strict)?  *unsorted is set to 1 otherwise.  Rows of up to kSortedLong entries: 8 lanes per
+// row (stencils and the body of a graph: 0.04 ms on 7-pt 150^3); longer rows: every workgroup looks at kBlock rows and walks the long ones
+// among them with all its work-items (with 8 lanes on every row the hub rows of R-MAT scale 20 made this 1.9 ms of every symbolic phase;
+// streaming the entries with a search of the row map at every descent was fast there and 0.3 - 0.5 ms on stencils, whose rows end every
+// 7 - 27 entries; a bitmap of the row starts cost an allocation per call).
+constexpr int kSortedLong = 256;
 template <class OffT>
-__global__ __launch_bounds__(kBlock) void rows_mark_kernel(int64_t n, const OffT* __restrict__ rm, unsigned* __restrict__ starts) {
-  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= n) return;
-  const int64_t p = (int64_t)rm[r];
-  if ((int64_t)rm[r + 1] > p) atomicOr(&starts[p >> 5], 1u << (p & 31));          // the first entry of a row that has one
-}
-__global__ __launch_bounds__(kBlock) void rows_sorted_kernel(int64_t nnz, const int32_t* __restrict__ ent, const unsigned* __restrict__ starts, int* __restrict__ unsorted) {
+__global__ __launch_bounds__(kBlock) void rows_sorted_kernel(int64_t n, const OffT* __restrict__ rm,
+                                                             const int32_t* __restrict__ ent, int* __restrict__ unsorted) {
+  const int lane = threadIdx.x & 7;
   bool bad = false;
-  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j + 1 < nnz; j += (int64_t)gridDim.x * kBlock)
-    if (ent[j] > ent[j + 1]) bad |= !((starts[(j + 1) >> 5] >> ((j + 1) & 31)) & 1u);
+  for (int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / 8; row < n; row += (int64_t)gridDim.x * (kBlock / 8)) {
+    const int64_t b = (int64_t)rm[row], e = (int64_t)rm[row + 1];
+    if (e - b > kSortedLong) continue;
+    for (int64_t j = b + lane; j + 1 < e; j += 8) bad |= ent[j] > ent[j + 1];
+  }
+  if (bad) *unsorted = 1;
+}
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void rows_sorted_long_kernel(int64_t n, const OffT* __restrict__ rm, const int32_t* __restrict__ ent, int* __restrict__ unsorted) {
+  __shared__ int s_long[kBlock];
+  __shared__ int s_n;
+  const int64_t r0 = (int64_t)blockIdx.x * kBlock;
+  const int64_t mine = r0 + threadIdx.x;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  if (mine < n && (int64_t)rm[mine + 1] - (int64_t)rm[mine] > kSortedLong) s_long[atomicAdd(&s_n, 1)] = threadIdx.x;
+  __syncthreads();
+  bool bad = false;
+  const int n_long = s_n;
+  for (int i = 0; i < n_long; ++i) {
+    const int64_t row = r0 + s_long[i], b = (int64_t)rm[row], e = (int64_t)rm[row + 1];
+    for (int64_t j = b + threadIdx.x; j + 1 < e; j += kBlock) bad |= ent[j] > ent[j + 1];
+  }
   if (bad) *unsorted = 1;
 }
 // sum of the per-row counts (before the scan) in 64 bits: a 32-bit row_map must not wrap silently
@@ -1632,18 +1651,31 @@ __global__ __launch_bounds__(kBlock) void spgemm_size_hist_kernel(int64_t n, con
   __syncthreads();
   for (int i = threadIdx.x; i < kSizeClasses; i += kBlock) if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
 }
-__global__ __launch_bounds__(kSizeClasses) void spgemm_size_scan_kernel(unsigned* __restrict__ hist /* in: counts, out: start of every class */) {
+__global__ __launch_bounds__(kSizeClasses) void spgemm_size_scan_kernel(unsigned* __restrict__ hist /* in: counts, out: start of every class; [kSizeClasses]: 1 = leave the order alone */) {
   __shared__ unsigned s_w[kSizeClasses / 64];
+  __shared__ int s_lo, s_hi;
+  if (threadIdx.x == 0) { s_lo = kSizeClasses; s_hi = -1; }
+  __syncthreads();
   const unsigned v = hist[threadIdx.x];
+  if (v) { atomicMin(&s_lo, (int)threadIdx.x); atomicMax(&s_hi, (int)threadIdx.x); }
   unsigned tot;
   const unsigned ex = block_exclusive_scan_n<unsigned, kSizeClasses>(v, &tot, s_w);
   hist[threadIdx.x] = ex;
+  __syncthreads();
+  // rows of (nearly) one size -- a stencil, uniform random rows: at most two neighbouring quarter-octave classes -- keep the order they
+  // have: it is the row order, and neighbouring rows of C are neighbours in memory (the atomics of the scatter would scramble them:
+  // uniform random 1e6 x 20, numeric reuse 4.19 -> 4.54 ms)
+  if (threadIdx.x == 0) hist[kSizeClasses] = (s_hi - s_lo <= 1) ? 1u : 0u;
 }
 __global__ __launch_bounds__(kBlock) void spgemm_size_scatter_kernel(int64_t n, const int32_t* __restrict__ in, const int64_t* __restrict__ sizes,
                                                                      unsigned* __restrict__ cursor, int32_t* __restrict__ out) {
   // workgroup-aggregated cursors: a class's rows of this workgroup take their places with one global atomic (the rows of a product
   // crowd into a few classes: one global atomic per row was 0.43 ms per call on R-MAT scale 20)
   __shared__ unsigned s_cnt[kSizeClasses], s_base[kSizeClasses];
+  if (cursor[kSizeClasses]) {                                    // (uniform) one size: the list stays as it is
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = in[i];
+    return;
+  }
   for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n; i0 += (int64_t)gridDim.x * kBlock) {       // uniform trip count
     for (int c = threadIdx.x; c < kSizeClasses; c += kBlock) s_cnt[c] = 0;
     __syncthreads();
@@ -1923,12 +1955,18 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
   __shared__ int s_wave[NT / 64];
   constexpr int U   = kProdUnroll;
   constexpr int UV  = 8;                       // entries of a list per unit of the vector walk (ST == 0)
+  constexpr int STN = ST > 0 ? ST : 1;         // steps in flight of the scalar walk
   constexpr int KPT = (H / 2 + NT - 1) / NT;   // C entries of a window per work-item
   const int t = threadIdx.x;
   const int64_t row = perm[blockIdx.x];
   const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
   const int64_t base = (int64_t)rmC[row], cnt = (int64_t)rmC[row + 1] - base;
   for (int i = t; i < H; i += NT) { hk[i] = -1; hv[i] = VT(0); }
+  // ST == 0: the vector walk -- for rows whose lists are long enough to fill its units of eight entries: at least 32 entries of C per list
+  // of the row (workgroup-uniform).  Rows made of many short lists (the product of two uniform random matrices: 20 lists of 20 products
+  // each) keep the scalar walk, one step in flight: their units would be a third empty and a work-item would probe eight times in a row
+  // (uniform random 1e6 x 20: numeric reuse 4.19 -> 4.54 ms with the vector walk on every row).
+  const bool vec = ST == 0 && cnt >= 32 * la;
   // A rows longer than LA are taken LA lists at a time: every pass walks all windows of the row, the first one stores
   // its sums, the others add theirs (the same workgroup, one pass after the other: no atomics)
   for (int64_t ach = 0; ach < la; ach += LA) {
@@ -1982,7 +2020,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
         const int n_in = t < la_c ? s_pos[g][t] - from : 0;
         int tot;
         // ST == 0: the unit of the walk is a run of up to UV consecutive entries of ONE list (see below): the scan counts units
-        const int excl = block_exclusive_scan_n<int, NT>(ST == 0 ? (n_in + UV - 1) / UV : n_in, &tot, s_wave);     // two barriers: the table is built when it returns
+        const int excl = block_exclusive_scan_n<int, NT>(vec ? (n_in + UV - 1) / UV : n_in, &tot, s_wave);     // two barriers: the table is built when it returns
         if (t < la_c) s_pre[t] = excl;
         if (t == 0) s_pre[la_c] = tot;
         __syncthreads();
@@ -1991,7 +2029,7 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
           while (len2 > 1) { const int half = len2 >> 1; lo += (s_pre[lo + half] <= q) ? half : 0; len2 -= half; }
           return lo;
         };
-        if constexpr (ST == 0) {
+        if (vec) {
           // VECTOR WALK: work-item u of a step takes unit u -- entries 8 i .. 8 i + 7 of one list's piece inside the window -- with two
           // 16-byte loads of columns and four of values (global loads need 4-byte alignment only): one search per EIGHT products
           // instead of one per four, three times fewer load instructions per product, twice the bytes in flight per work-item, and the
@@ -2033,13 +2071,12 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
               }
           }
         } else
-        if (!KK_DBG(4096)) for (int pbase = 0; pbase < tot; pbase += NT * U * ST) {
-          constexpr int STN = ST > 0 ? ST : 1;
+        if (!KK_DBG(4096)) for (int pbase = 0; pbase < tot; pbase += NT * U * STN) {
           int col[STN][U];
           VT bv[STN][U], av[STN][U];
           long long jj[STN][U];
           KK_UNROLL
-          for (int s = 0; s < ST; ++s) {
+          for (int s = 0; s < STN; ++s) {
             KK_UNROLL
             for (int u = 0; u < U; ++u) jj[s][u] = -1;
             if (s > 0 && pbase + s * NT * U >= tot) continue;                  // uniform: the window ends before this step
@@ -2066,12 +2103,12 @@ __global__ __launch_bounds__(NT) void spgemm_dense_vals2_kernel(const int32_t* _
           // has to branch around makes it wait for all loads in flight before the next one is issued -- the walk then pays one memory
           // round trip per load instead of one per step
           KK_UNROLL
-          for (int s = 0; s < ST; ++s) {
+          for (int s = 0; s < STN; ++s) {
             KK_UNROLL
             for (int u = 0; u < U; ++u) { const long long j = jj[s][u] >= 0 ? jj[s][u] : 0; col[s][u] = entB[j]; bv[s][u] = valB[j]; }
           }
           KK_UNROLL
-          for (int s = 0; s < ST; ++s) {
+          for (int s = 0; s < STN; ++s) {
             KK_UNROLL
             for (int u = 0; u < U; ++u)
               if (jj[s][u] >= 0 && !KK_DBG(8192)) {
@@ -2801,12 +2838,12 @@ static int split_list_by_size(int32_t* list, int64_t n, const OffT* rmA, const i
 
 // list[0 .. n) reordered by sizes[row], largest first (quarter-octave classes; see spgemm_size_hist_kernel)
 static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hipStream_t st) {
-  if (n < 2 || !g_spgemm.sort_rows) return KKAMD_OK;
+  if (n < 4096 || !g_spgemm.sort_rows) return KKAMD_OK;          // (a short list finishes in one wave of workgroups whatever its order)
   DevBuf tmp_b, hist_b;
   KK_HIP(tmp_b.alloc(sizeof(int32_t) * (size_t)n));
-  KK_HIP(hist_b.alloc(sizeof(unsigned) * kSizeClasses));
+  KK_HIP(hist_b.alloc(sizeof(unsigned) * (kSizeClasses + 1)));
   int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned* d_hist = hist_b.as<unsigned>();
-  KK_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * kSizeClasses, st));
+  KK_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * (kSizeClasses + 1), st));
   KK_HIP(hipMemcpyAsync(d_tmp, list, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
   const int64_t nbk = ceil_div(n, kBlock);
   const unsigned grid = (unsigned)(nbk < 1024 ? nbk : 1024);
@@ -2851,15 +2888,10 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     KK_HIP(flag.alloc(sizeof(int)));
     int* d_flag = flag.as<int>();
     KK_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), st));
-    DevBuf starts_b;
-    const size_t sw = (size_t)(nnzB / 32 + 2);
-    KK_HIP(starts_b.alloc(sizeof(unsigned) * sw));
-    unsigned* d_starts = starts_b.as<unsigned>();
-    KK_HIP(hipMemsetAsync(d_starts, 0, sizeof(unsigned) * sw, st));
     if (n > 0 && nnzB > 1) {
-      KK_LAUNCH((rows_mark_kernel<OffT>), (unsigned)ceil_div(n, kBlock), kBlock, 0, st, n, rmB, d_starts);
-      const int64_t nbk = ceil_div(nnzB, kBlock);
-      KK_LAUNCH(rows_sorted_kernel, (unsigned)(nbk < 8192 ? nbk : 8192), kBlock, 0, st, nnzB, entB, (const unsigned*)d_starts, d_flag);
+      const int64_t nbk = ceil_div(n * 8, kBlock);
+      KK_LAUNCH((rows_sorted_kernel<OffT>), (unsigned)(nbk < 8192 ? nbk : 8192), kBlock, 0, st, n, rmB, entB, d_flag);
+      KK_LAUNCH((rows_sorted_long_kernel<OffT>), (unsigned)ceil_div(n, kBlock), kBlock, 0, st, n, rmB, entB, d_flag);
     }
     KK_HIP(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
