@@ -2694,6 +2694,7 @@ struct kkamd_spgemm_handle {
   unsigned* d_bidx = nullptr; const void* bidx_rmB = nullptr; const void* bidx_entB = nullptr; int64_t bidx_nB = 0; int bidx_nblk = 0, bidx_wshift = 0;
   unsigned* d_cidx = nullptr; bool cidx_ready = false;
   int2* d_items_rank = nullptr; int2* d_items_direct = nullptr; int64_t n_items_rank = 0, n_items_direct = 0; bool items_ready = false;
+  int idx_nblk = 0, idx_wshift = 0, items_cap = 0, items_blocks = 0;      // what the two indices / the items were built for (the knobs are process-wide and may change between calls)
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -3312,7 +3313,10 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         KK_LAUNCH((spgemm_bidx_kernel<OffT>), (unsigned)ceil_div((int64_t)(nblk + 1) * nB, kBlock), kBlock, 0, st, nB, nblk, wshift, rmB, entB, d_bx);
         h->bidx_rmB = rmB_; h->bidx_entB = entB; h->bidx_nB = nB; h->bidx_nblk = nblk; h->bidx_wshift = wshift;
       }
+      if (h->idx_nblk != nblk || h->idx_wshift != wshift) { h->cidx_ready = false; h->items_ready = false; }
+      if (h->items_cap != g_spgemm.item_cap || h->items_blocks != g_spgemm.item_blocks) h->items_ready = false;
       if (!h->cidx_ready) {
+        h->idx_nblk = nblk; h->idx_wshift = wshift;
         if (h->d_cidx) { (void)hipFree(h->d_cidx); h->d_cidx = nullptr; }
         KK_HIP(hipMalloc((void**)&h->d_cidx, sizeof(unsigned) * (size_t)(nblk + 1) * (size_t)n_blk));
         unsigned* d_cx = h->d_cidx;
@@ -3359,7 +3363,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
           KK_LAUNCH(spgemm_items_scatter_kernel, g_it, kBlock, 0, st, n_it, src, nblk, d_hist, dst);
         }
         KK_HIP(hipStreamSynchronize(st));              // the scratch buffers go out of scope
-        h->n_items_rank = h_tot[0]; h->n_items_direct = h_tot[1]; h->items_ready = true;
+        h->n_items_rank = h_tot[0]; h->n_items_direct = h_tot[1]; h->items_ready = true; h->items_cap = g_spgemm.item_cap; h->items_blocks = g_spgemm.item_blocks;
         if (h->verbose) KK_VERBOSE("\tkkamd spgemm numeric: column-block class: %lld rows as %lld position-indexed items (<= %u entries, <= %d blocks) and %lld column-indexed blocks\n",
                                    (long long)n_blk, (long long)h->n_items_rank, cap_items, g_spgemm.item_blocks, (long long)h->n_items_direct);
       }

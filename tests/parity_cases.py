@@ -598,6 +598,16 @@ def check_spgemm_block_kernel(be):
             rm_, ent_, val_ = Cm.to_host()
             ok, msg = oracle.is_same_matrix(oracle.Crs(A.nrows, B.ncols, rm_.astype(np.int64), ent_, val_.astype(np.float64)), oracle.spgemm(A, B))
             assert ok, msg
+            if on:      # the (process-wide) knobs change under a live handle: numeric reuse rebuilds its indices and items for the new grid
+                for w2, cap2 in ((256, 64), (4096, 6144)):
+                    kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block_w", w2))
+                    kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_item_cap", cap2))
+                    kk.spgemm_numeric(kh, Ad, False, Bd, False, Cm)
+                    rm_, ent_, val_ = Cm.to_host()
+                    ok, msg = oracle.is_same_matrix(oracle.Crs(A.nrows, B.ncols, rm_.astype(np.int64), ent_, val_.astype(np.float64)), oracle.spgemm(A, B))
+                    assert ok, (w2, cap2, msg)
+                kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block_w", 1024))
+                kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_item_cap", 100))
             kh.destroy_spgemm_handle()
     finally:
         kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_block", 1))
