@@ -1238,7 +1238,11 @@ __global__ __launch_bounds__(kDenseBlock) void spgemm_dense_cols_kernel(const in
             const int pc = __popcll(v);
             const int inc = wave_inclusive_scan_i32(pc, lane);
             int pos = run + inc - pc;
-            while (v) { const int bit = __ffsll(v) - 1; dst[pos++] = (int32_t)(wd * 64 + bit); v &= v - 1; }
+            // the two 32-bit halves one after the other: five vector instructions per bit instead of twelve for the 64-bit find-first / clear
+            unsigned lo32 = (unsigned)v, hi32 = (unsigned)(v >> 32);
+            const int cbase = wd * 64;
+            while (lo32) { dst[pos++] = cbase + (__ffs((int)lo32) - 1); lo32 &= lo32 - 1u; }
+            while (hi32) { dst[pos++] = cbase + 32 + (__ffs((int)hi32) - 1); hi32 &= hi32 - 1u; }
             run += wave_last_lane_i32(inc);
           }
         } else {
