@@ -117,8 +117,8 @@ __global__ __launch_bounds__(kBlock) void mv5_tile_kernel(int64_t nrows, const O
   // The tile's columns in ascending order.  Its (up to) 16 rows ARE ascending runs, so four rounds of pairwise MERGES do it: an entry's
   // place in the merged pair is its place in its own run plus the number of smaller entries (for the second run: not larger) of the
   // partner, a binary search in LDS -- two barriers per round, eight in all.  (The bitonic network this replaces needed 45 - 66
-  // barrier-separated stages for 512 - 2048 keys: 7.5 ms of the 9 ms the analysis of a 2e6-row block-diagonal matrix took; a tile whose
-  // rows do not ascend is refused above / was refused by the counting pass, so the merge never sees one.)
+  // barrier-separated stages for 512 - 2048 keys; a tile whose rows do not ascend is refused above / was refused by the counting
+  // pass, so the merge never sees one that matters: its result is not used.)
   {
     int* src = s_key; int* dst = s_uni;
     for (int w = 1; w < kMv5Rows; w <<= 1) {
@@ -175,7 +175,9 @@ __global__ __launch_bounds__(kBlock) void mv5_tile_kernel(int64_t nrows, const O
     if (t == 0) {
       const bool on = !s_bad && (long long)n * 100 >= (long long)min_fill_pct * nb * 64;
       blk[tile] = on ? nb : 0;
-      if (on) {
+      // the totals: here for the sample only (1024 tiles); the full pass leaves them to mv5_stats_kernel -- five atomics per tile on one
+      // cache line were 6 of the 7.5 ms this pass took on 125,000 described tiles
+      if (on && tile_stride > 1) {
         atomicAdd(&stats[0], (unsigned long long)nb); atomicAdd(&stats[1], (unsigned long long)n); atomicAdd(&stats[2], 1ull);
         atomicAdd(&stats[3], (unsigned long long)(rowN - row0)); atomicMax(&stats[4], (unsigned long long)n);
       }
@@ -196,6 +198,38 @@ __global__ __launch_bounds__(kBlock) void mv5_tile_kernel(int64_t nrows, const O
   __syncthreads();
   for (int u = t; u < 4 * nb; u += kBlock) cols[4 * b0 + u] = u < nU ? s_uni[u] : -1;
   for (int b = t; b < nb; b += kBlock) masks[b0 + b] = (unsigned long long)s_mask[2 * b] | ((unsigned long long)s_mask[2 * b + 1] << 32);
+}
+
+// totals over the described tiles of the full counting pass (blk[tile] = column blocks of the tile, 0 = not described): [0] blocks,
+// [1] entries, [2] tiles, [3] rows, [4] the largest tile's entries -- one set of atomics per workgroup of 256 tiles
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv5_stats_kernel(int64_t ntiles, int64_t nrows, const OffT* __restrict__ row_map, const int64_t* __restrict__ blk,
+                                                           unsigned long long* __restrict__ stats) {
+  __shared__ unsigned long long s_acc[5];
+  const int t = threadIdx.x;
+  if (t < 5) s_acc[t] = 0ull;
+  __syncthreads();
+  const int64_t tile = (int64_t)blockIdx.x * kBlock + t;
+  unsigned long long nb = 0, n = 0, on = 0, rows = 0;
+  if (tile < ntiles) {
+    nb = (unsigned long long)blk[tile];
+    if (nb) {
+      const int64_t row0 = tile * kMv5Rows, rowN = (row0 + kMv5Rows < nrows) ? row0 + kMv5Rows : nrows;
+      n = (unsigned long long)(row_map[rowN] - row_map[row0]); on = 1ull; rows = (unsigned long long)(rowN - row0);
+    }
+  }
+  unsigned long long mx = n;
+  for (int o = 32; o > 0; o >>= 1) {
+    nb += __shfl_xor(nb, o, 64); on += __shfl_xor(on, o, 64); rows += __shfl_xor(rows, o, 64);
+    const unsigned long long m2 = __shfl_xor(mx, o, 64); mx = m2 > mx ? m2 : mx;
+    n += __shfl_xor(n, o, 64);
+  }
+  if ((t & 63) == 0 && on) {
+    atomicAdd(&s_acc[0], nb); atomicAdd(&s_acc[1], n); atomicAdd(&s_acc[2], on); atomicAdd(&s_acc[3], rows); atomicMax(&s_acc[4], mx);
+  }
+  __syncthreads();
+  if (t < 4 && s_acc[2]) atomicAdd(&stats[t], s_acc[t]);
+  if (t == 4 && s_acc[2]) atomicMax(&stats[4], s_acc[4]);
 }
 
 // rows of the tiles that are not described (any order)
@@ -410,6 +444,9 @@ static int mv5_plan_build_t(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStre
   }
   KK_LAUNCH((mv5_tile_kernel<OffT, false>), (unsigned)ntiles, kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries,
             min_fill, p->d_blk_off, (int32_t*)nullptr, (unsigned long long*)nullptr, d_stats, (int64_t)1);
+  KK_LAUNCH_CHECK();
+  KK_LAUNCH((mv5_stats_kernel<OffT>), (unsigned)ceil_div(ntiles, kBlock), kBlock, 0, st, ntiles, A->num_rows, (const OffT*)A->d_row_map,
+            (const int64_t*)p->d_blk_off, d_stats);
   KK_LAUNCH_CHECK();
   int rc = exclusive_scan_inplace<int64_t>(p->d_blk_off, ntiles + 1, st);
   if (rc) return rc;
