@@ -115,17 +115,17 @@ constexpr int kWinMeta = 64, kWinChunks = 32;
 template <int NPT>
 __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const int32_t* __restrict__ entries,
                                                            uint16_t* __restrict__ wcode, int32_t* __restrict__ wmeta,
-                                                           int32_t* __restrict__ tinfo, int* __restrict__ counts, int allow_stage) {
+                                                           int32_t* __restrict__ tinfo, int allow_stage) {
   // Per tile (tinfo[b]): kTilePlain when the tile needs more than 16 windows (it keeps reading entries), kTileCodes when
-  // its used column ranges exceed the LDS x window, kTileStaged otherwise.  counts[mode] = tiles of that mode.
-  constexpr int TILE = kBlock * NPT, STEPS = NPT / 2, SPAN = kBlock * 2;
+  // its used column ranges exceed the LDS x window, kTileStaged otherwise (tile_mode_hist_kernel counts the modes afterwards).
+  constexpr int TILE = kBlock * NPT, STEPS = NPT / 2, SPAN = kBlock * 2, NW = kBlock / 64;
   __shared__ int s_base[kWinCount];
-  __shared__ int s_len[kWinCount];
+  __shared__ int s_nch[kWinCount];                           // 64-column chunks of every window up to its last used one
   __shared__ int s_off[kWinCount + 1];
-  __shared__ unsigned s_bits[128];                           // used columns of the window being formed
-  __shared__ int s_zero;
-  __shared__ int s_min;
-  const int t = threadIdx.x;
+  __shared__ int s_wmin[NW];                                 // per wave: smallest uncovered column / used chunks of the window being formed
+  __shared__ unsigned long long s_wmask[NW];
+  __shared__ int s_flag;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t b = blockIdx.x, s = b * TILE;
   int c[NPT];
   KK_UNROLL
@@ -138,81 +138,99 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
   // Pass 0 ends a window at the first run of 64 unused columns (64-aligned from its base), so that windows hug the
   // contiguous column runs a tile really touches (27-pt: nine runs of ~80) and the staged x window stays small; if that
   // needs more than 16 windows, pass 1 takes full 4096-column windows.
+  // Both questions -- the smallest uncovered column, the used 64-column chunks of the window (a 64-bit mask: 4096 / 64) -- are answered
+  // in registers, reduced across the wave with lane exchanges and across the four waves through four LDS words: two barriers per
+  // window.  (Round 4 marked every used column in an LDS bitmap and took the window lengths with an LDS atomic per entry: a tile's
+  // entries sit in a few words, so the 64 lanes of every ds_or / ds_max went through the LDS one after the other -- 4 of the 6.7 ms
+  // this kernel took on C2; and since a window's slots are padded to whole chunks, only the chunk count was ever used.)
   bool uncovered = false;
   for (int pass = 0; pass < 2; ++pass) {                       // workgroup-uniform control flow throughout
     long long bound = 0;                                       // columns < bound are covered
     for (int w = 0; w < kWinCount; ++w) {
-      if (t == 0) { s_min = INT_MAX; s_zero = 64; }
-      if (t < 128) s_bits[t] = 0u;
-      __syncthreads();
       int m = INT_MAX;
       KK_UNROLL
       for (int k = 0; k < NPT; ++k) if (c[k] >= 0 && (long long)c[k] >= bound && c[k] < m) m = c[k];
-      if (m != INT_MAX) atomicMin(&s_min, m);
+      for (int o = 32; o > 0; o >>= 1) { const int m2 = __shfl_xor(m, o, 64); m = m2 < m ? m2 : m; }
+      if (lane == 0) s_wmin[wave] = m;
       __syncthreads();
-      const int base = s_min;
+      int base = s_wmin[0];
+      KK_UNROLL
+      for (int q = 1; q < NW; ++q) base = s_wmin[q] < base ? s_wmin[q] : base;
       if (base == INT_MAX) {                                   // everything is covered: the unused windows repeat the last base
-        if (t == 0) for (int q = w; q < kWinCount; ++q) s_base[q] = q ? s_base[q - 1] : 0;
-        __syncthreads();
+        if (t == 0) for (int q = w; q < kWinCount; ++q) { s_base[q] = q ? s_base[q - 1] : 0; s_nch[q] = 0; }
         break;
       }
-      long long span = (1 << kWinBits);
-      if (pass == 0) {
-        KK_UNROLL
-        for (int k = 0; k < NPT; ++k) {
-          const long long d = (long long)c[k] - base;
-          if (c[k] >= 0 && d >= 0 && d < (1 << kWinBits)) atomicOr(&s_bits[d >> 5], 1u << (d & 31));
-        }
-        __syncthreads();
-        if (t < 64 && s_bits[2 * t] == 0u && s_bits[2 * t + 1] == 0u) atomicMin(&s_zero, t);
-        __syncthreads();
-        span = 64ll * s_zero;
+      unsigned long long used = 0ull;
+      KK_UNROLL
+      for (int k = 0; k < NPT; ++k) {
+        const long long d = (long long)c[k] - base;
+        if (c[k] >= 0 && d >= 0 && d < (1 << kWinBits)) used |= 1ull << (d >> 6);
       }
-      if (t == 0) s_base[w] = base;
-      bound = (long long)base + span;
+      for (int o = 32; o > 0; o >>= 1) used |= __shfl_xor(used, o, 64);
+      if (lane == 0) s_wmask[wave] = used;
       __syncthreads();
+      used = s_wmask[0];
+      KK_UNROLL
+      for (int q = 1; q < NW; ++q) used |= s_wmask[q];
+      int nch;                                                 // chunk 0 holds the base itself: nch >= 1
+      if (pass == 0) nch = (~used == 0ull) ? 64 : __ffsll(~used) - 1;                 // up to the first unused chunk
+      else           nch = 64 - __clzll((long long)used);                             // up to the last used one
+      if (t == 0) { s_base[w] = base; s_nch[w] = nch; }
+      bound = (long long)base + (pass == 0 ? 64ll * nch : (long long)(1 << kWinBits));
     }
     uncovered = false;
     KK_UNROLL
     for (int k = 0; k < NPT; ++k) uncovered |= (c[k] >= 0 && (long long)c[k] >= bound);
-    if (t == 0) s_min = 0;
+    __syncthreads();                                           // (also: s_base / s_nch of the last window, and the words of the break above)
+    if (t == 0) s_flag = 0;
     __syncthreads();
-    if (uncovered) atomicOr(&s_min, 1);
+    if (__ballot(uncovered) != 0ull && lane == 0) s_flag = 1;
     __syncthreads();
-    const int any = s_min;
-    __syncthreads();
+    const int any = s_flag;
     if (!any) break;
   }
-  if (t == 0) s_min = 0;
-  __syncthreads();
-  if (uncovered) atomicOr(&s_min, 1);
-  __syncthreads();
-  const bool plain = s_min != 0;                               // workgroup-uniform
-  if (plain) {
-    if (t == 0) { tinfo[b] = kTilePlain; atomicAdd(counts + kTilePlain, 1); }
+  if (s_flag != 0) {                                           // workgroup-uniform: the last pass left columns uncovered
+    if (t == 0) tinfo[b] = kTilePlain;
     return;
   }
-  if (t < kWinCount) s_len[t] = 0;
-  __syncthreads();
-  uint16_t* out = wcode + s + (int64_t)t * NPT;
+  int sb[kWinCount];
+  KK_UNROLL
+  for (int q = 0; q < kWinCount; ++q) sb[q] = s_base[q];
+  unsigned code[NPT];
   KK_UNROLL
   for (int k = 0; k < NPT; ++k) {
     int w = 0;
-    for (int q = 1; q < kWinCount; ++q) if (s_base[q] <= c[k] && s_base[q] > s_base[q - 1]) w = q;
-    const int d = c[k] - s_base[w];
+    KK_UNROLL
+    for (int q = 1; q < kWinCount; ++q) if (sb[q] <= c[k] && sb[q] > sb[q - 1]) w = q;
+    int bw = sb[0];
+    KK_UNROLL
+    for (int q = 1; q < kWinCount; ++q) bw = (w == q) ? sb[q] : bw;
+    const int d = c[k] - bw;
     const bool ok = (c[k] >= 0 && d >= 0 && d < (1 << kWinBits));
-    out[k] = ok ? (uint16_t)((w << kWinBits) | d) : (uint16_t)0;
-    if (ok) atomicMax(&s_len[w], d + 1);
+    code[k] = ok ? (unsigned)((w << kWinBits) | d) : 0u;
   }
-  __syncthreads();
-  // LDS slots of the used part of every window, padded to whole 64-slot chunks
+  // work-item t's NPT codes are contiguous (2 NPT bytes): 16-byte stores where the count allows
+  uint16_t* out = wcode + s + (int64_t)t * NPT;
+  if constexpr (NPT % 8 == 0) {
+    KK_UNROLL
+    for (int k = 0; k < NPT; k += 8) {
+      kk_u32x4 v;
+      v[0] = code[k] | (code[k + 1] << 16); v[1] = code[k + 2] | (code[k + 3] << 16);
+      v[2] = code[k + 4] | (code[k + 5] << 16); v[3] = code[k + 6] | (code[k + 7] << 16);
+      *reinterpret_cast<kk_u32x4*>(out + k) = v;
+    }
+  } else {
+    KK_UNROLL
+    for (int k = 0; k < NPT; k += 2) *reinterpret_cast<unsigned*>(out + k) = code[k] | (code[k + 1] << 16);
+  }
+  // LDS slots of the used part of every window, in whole 64-slot chunks
   if (t == 0) {
     int off = 0;
-    for (int w = 0; w < kWinCount; ++w) { s_off[w] = off; off += (s_len[w] + 63) & ~63; }
+    for (int w = 0; w < kWinCount; ++w) { s_off[w] = off; off += 64 * s_nch[w]; }
     s_off[kWinCount] = off;
     constexpr int CAP = TILE < kWinChunks * 64 ? TILE : kWinChunks * 64;
     const int mode = (off > CAP || !allow_stage) ? kTileCodes : kTileStaged;
-    tinfo[b] = mode; atomicAdd(counts + mode, 1);
+    tinfo[b] = mode;
   }
   __syncthreads();
   int32_t* meta = wmeta + b * kWinMeta;
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void win_build_kernel(int64_t nnz, const in
   if (t < kWinChunks) {
     const int slot = t * 64;
     int col = -1;
-    for (int w = 0; w < kWinCount; ++w) if (slot >= s_off[w] && slot < s_off[w] + ((s_len[w] + 63) & ~63)) col = s_base[w] + (slot - s_off[w]);
+    for (int w = 0; w < kWinCount; ++w) if (slot >= s_off[w] && slot < s_off[w] + 64 * s_nch[w]) col = s_base[w] + (slot - s_off[w]);
     meta[2 * kWinCount + t] = col;
   }
 }
@@ -240,8 +258,7 @@ template <class OffT, int NPT>
 __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const OffT* __restrict__ row_map,
                                                            const int32_t* __restrict__ blk_info,
                                                            const uint16_t* __restrict__ wcode, const int32_t* __restrict__ wmeta,
-                                                           int32_t* __restrict__ tinfo, int32_t* __restrict__ pmeta,
-                                                           int* __restrict__ count) {
+                                                           int32_t* __restrict__ tinfo, int32_t* __restrict__ pmeta) {
   constexpr int TILE = kBlock * NPT, STEPS = NPT / 2, SPAN = kBlock * 2;
   __shared__ unsigned short s_slot[TILE];
   __shared__ unsigned char s_head[TILE + 2];
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const Of
     if (t >= 1) out[t] = sb;                                  // starts of segments 1..7 (segment 0 starts at 0)
     out[kPatRec + 4 * t + 0] = sb; out[kPatRec + 4 * t + 1] = -rs32; out[kPatRec + 4 * t + 2] = L32; out[kPatRec + 4 * t + 3] = __float_as_int(M);
   }
-  if (t == 0) { out[0] = nseg; tinfo[b] = kTilePattern; atomicAdd(count, 1); }
+  if (t == 0) { out[0] = nseg; tinfo[b] = kTilePattern; }
   if (t < kPatSeg * kPatLen) {
     const int g = t / kPatLen, k = t % kPatLen;
     int val = 0;
@@ -327,6 +344,23 @@ __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const Of
 }
 
 // Which tiles keep per-nonzero codes (modes 1, 2, and 3 when the records are not used) -> flags for the scan; demotes unused records.
+// counts[m] = tiles whose mode (tinfo & 3) is m.  (The build kernels used to count with one atomic per tile: 177,000 atomics on one
+// address are 2 ms on C2, the read of the tile table is microseconds.)
+__global__ __launch_bounds__(kBlock) void tile_mode_hist_kernel(int64_t nblocks, const int32_t* __restrict__ tinfo, int* __restrict__ counts) {
+  __shared__ int s_c[4];
+  const int t = threadIdx.x;
+  if (t < 4) s_c[t] = 0;
+  __syncthreads();
+  const int64_t b = (int64_t)blockIdx.x * kBlock + t;
+  const int mode = b < nblocks ? (tinfo[b] & 3) : -1;
+  for (int m = 0; m < 4; ++m) {
+    const int c = __popcll(__ballot(mode == m));
+    if ((t & 63) == 0 && c) atomicAdd(&s_c[m], c);
+  }
+  __syncthreads();
+  if (t < 4 && s_c[t]) atomicAdd(counts + t, s_c[t]);
+}
+
 __global__ void code_flag_kernel(int64_t nblocks, int32_t* __restrict__ tinfo, int32_t* __restrict__ flag, int use_pat) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b > nblocks) return;
@@ -1290,9 +1324,11 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
   KK_HIP(hipMemsetAsync(counts.p, 0, 8 * sizeof(int), st));
   const int allow_stage = p->tune.window_codes != 2;
   const int32_t* ent = (const int32_t*)p->entries;
-  if (npt == 16)     { KK_LAUNCH((win_build_kernel<16>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, d_counts, allow_stage); }
-  else if (npt == 8) { KK_LAUNCH((win_build_kernel<8>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, d_counts, allow_stage); }
-  else               { KK_LAUNCH((win_build_kernel<4>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, d_counts, allow_stage); }
+  if (npt == 16)     { KK_LAUNCH((win_build_kernel<16>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, allow_stage); }
+  else if (npt == 8) { KK_LAUNCH((win_build_kernel<8>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, allow_stage); }
+  else               { KK_LAUNCH((win_build_kernel<4>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, allow_stage); }
+  if (hipGetLastError() != hipSuccess) return give_up();
+  KK_LAUNCH(tile_mode_hist_kernel, (unsigned)ceil_div((int64_t)nb, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, d_counts);
   if (hipGetLastError() != hipSuccess) return give_up();
   int h[8] = {0};
   KK_HIP(hipMemcpyAsync(h, counts.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1312,13 +1348,15 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
     int* d_cnt = d_counts + 4;
 #define KK_PAT_BUILD(OT, N)                                                                                                  \
   KK_LAUNCH((pat_build_kernel<OT, N>), (unsigned)nb, kBlock, 0, st, A->nnz, (const OT*)A->d_row_map,                        \
-            (const int32_t*)p->d_blk_row, d_full, (const int32_t*)wbase, tinfo, p->d_pmeta, d_cnt)
+            (const int32_t*)p->d_blk_row, d_full, (const int32_t*)wbase, tinfo, p->d_pmeta)
     if (npt == 16) { if (o64) { KK_PAT_BUILD(int64_t, 16); } else { KK_PAT_BUILD(int32_t, 16); } }
     else           { if (o64) { KK_PAT_BUILD(int64_t, 8); } else { KK_PAT_BUILD(int32_t, 8); } }
 #undef KK_PAT_BUILD
     if (hipGetLastError() != hipSuccess) return give_up();
+    KK_LAUNCH(tile_mode_hist_kernel, (unsigned)ceil_div((int64_t)nb, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, d_cnt);
+    if (hipGetLastError() != hipSuccess) return give_up();
     int h_cnt = 0;
-    KK_HIP(hipMemcpyAsync(&h_cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipMemcpyAsync(&h_cnt, d_cnt + kTilePattern, sizeof(int), hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
     n_pat   = h_cnt;
     use_pat = p->tune.pattern_codes >= 2 ? n_pat > 0 : (double)n_pat >= 0.9 * (double)nb;
