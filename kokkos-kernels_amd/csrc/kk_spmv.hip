@@ -1115,6 +1115,7 @@ static int colslab_select(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const YT*
 #endif
 }
 
+static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st, int force_npt);
 template <class OffT, class AT, class YT>
 static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, double alpha_d, const void* dx,
                       double beta_d, void* dy, hipStream_t st) {
@@ -1127,6 +1128,12 @@ static int spmv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans, d
     if (rc) return rc;
     if (tplan) return spmv_typed<OffT, AT, YT>(tplan, &At, false, alpha_d, dx, beta_d, dy, st);
     return run_transpose<OffT, AT, YT>(A, x, y, alpha, beta, st);
+  }
+  if (plan && plan->rank1_deferred) {                          // knob defer_rank1: the first rank-1 call of a handle that began with rank 2
+    plan->rank1_deferred = false;
+    plan->tune.defer_rank1 = 0;
+    const int rc = build_analysis(plan, A, st, 0);
+    if (rc) return rc;
   }
   if constexpr (sizeof(YT) == 8) {
     // lattice stencils: the plane-marching kernel reads no column index and fetches x once per patch plane (knob march)
@@ -1266,6 +1273,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "colslab_shift") { if (value != 0 && (value < 2 || value > 30)) return bad("0 or in 2..30"); t.colslab_shift = value; }
   else if (k == "values_tracking") { if (value < 0 || value > 2) return bad("in 0..2"); t.values_tracking = value; }
   else if (k == "check_entries") { if (value != 0 && value != 1) return bad("0 or 1"); t.check_entries = value; }
+  else if (k == "defer_rank1") { if (value != 0 && value != 1) return bad("0 or 1"); t.defer_rank1 = value; }
   else if (k == "colslab_const") { if (value != 0 && value != 1) return bad("0 or 1"); t.colslab_const = value; }
   else if (k == "transient_min_knnz") { if (value < 0) return bad("non-negative"); t.transient_min_knnz = value; }
   else if (k == "explicit_transpose") { if (value < 0 || value > 2) return bad("in 0..2"); t.explicit_transpose = value; }
@@ -1404,9 +1412,10 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
   return KKAMD_OK;
 }
 
-static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st, int force_npt = 0) {
+static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st, int force_npt) {
   if (p->d_blk_row) KK_HIP(hipStreamSynchronize(st));
   free_analysis(p);
+  p->rank1_deferred = false;
   if (p->algorithm == KKAMD_SPMV_FAST_SETUP || p->tune.kernel == 1 || A->nnz == 0 || A->num_rows == 0) return KKAMD_OK;
   int npt = p->tune.nnz_per_thread;
   const bool f64v = A->value_type == KKAMD_F64;
@@ -1426,6 +1435,11 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
   if (npt == 4 && !f64v) npt = 8;                              // 1024-nnz tiles are instantiated for fp64 values only
   p->tile    = kBlock * npt;
   p->nblocks = ceil_div(A->nnz, p->tile);
+  if (p->tune.defer_rank1 && !force_npt) {                     // a rank-2 caller: the rank-1 plan is built by the first rank-1 call, if one comes
+    p->rank1_deferred = true;
+    p->nblocks = 0;
+    return KKAMD_OK;
+  }
   if (hipMalloc((void**)&p->d_blk_row, sizeof(int32_t) * (size_t)(p->nblocks + 1)) != hipSuccess ||
       hipMalloc(&p->d_carry, (size_t)16 * (size_t)p->nblocks) != hipSuccess) {
     free_analysis(p);
@@ -1439,7 +1453,7 @@ static int build_analysis(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t 
     if ((rc = build_codes(p, A, st, npt, auto_npt && !force_npt, &redo))) return rc;
     if (redo) return build_analysis(p, A, st, redo);
     if (!p->d_tinfo && auto_npt && !force_npt && f64v && npt != ((A->nnz < 200000000) ? 8 : 16))
-      return build_analysis(p, A, st);                         // no codes after all (win_failed is set): the plain kernel's tile size
+      return build_analysis(p, A, st, 0);                      // no codes after all (win_failed is set): the plain kernel's tile size
   }
   KK_HIP(hipStreamSynchronize(st));   // setup is synchronous, like the vendor analysis it replaces
   return KKAMD_OK;
@@ -1544,7 +1558,7 @@ int kkamd_spmv_plan_create_knobs(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A,
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       p->num_cus = prop.multiProcessorCount;
   }
-  rc = kk::build_analysis(p, A, kk::to_hip(stream));
+  rc = kk::build_analysis(p, A, kk::to_hip(stream), 0);
   if (rc) { kkamd_spmv_plan_destroy(p); return rc; }
   *plan = p;
   return KKAMD_OK;
@@ -1602,7 +1616,7 @@ static int plan_set_impl(kkamd_spmv_plan_t* plan, const char* key, int value) {
     A.num_rows = plan->num_rows; A.num_cols = plan->num_cols; A.nnz = plan->nnz; A.d_row_map = plan->row_map;
     A.d_entries = plan->entries; A.offset_type = plan->offset_type; A.value_type = plan->value_type;
     if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream));
-    return kk::build_analysis(plan, &A, plan->last_stream);
+    return kk::build_analysis(plan, &A, plan->last_stream, 0);
   }
   if (t.mv_order != old.mv_order || t.mv_strip_min_kb != old.mv_strip_min_kb || t.mv_strip_l2_kb != old.mv_strip_l2_kb) {
     if (plan->d_mv2_order) { if (plan->used) KK_HIP(hipStreamSynchronize(plan->last_stream)); KK_HIP(hipFree(plan->d_mv2_order)); plan->d_mv2_order = nullptr; }

@@ -73,6 +73,9 @@ struct SpmvTuning {
   int colslab_min_pct = 85;        // ... the rule of 3: distinct lines of x per nonzero, in percent, from which the gather counts as cache-defeating
   int colslab_min_knnz = 20000;    // ... from this many thousand nnz
   int colslab_shift = 0;           // ... log2 of the columns per slab (0 = 2 MB of x)
+  int defer_rank1 = 0;             // 1 = the rank-1 analysis (tiles, window codes, pattern records: 5 ms on 27-pt 300^3) waits for the first rank-1
+                                   // call; set by a caller whose first call is rank 2 (the Python SPMVHandle does: the reference's handle is set up
+                                   // by its first spmv call too, for that call's rank).  Queries of the rank-1 plan return 0 until then.
   int check_entries = 0;           // debug aid: 1 = every call hashes the matrix's column array and compares it with the hash the analysis saw (one
                                    // extra pass over entries and a stream synchronisation per call): a structure edited in place under a live handle
                                    // is reported (KKAMD_ERR_STATE) instead of silently multiplied with the old analysis
@@ -138,6 +141,7 @@ struct kkamd_spmv_plan {
   kkamd_spmv_plan* t_plan = nullptr;
   void* d_t_shadow = nullptr;    // A.values as the transpose last saw them (values_tracking 0)
   bool t_ready = false, t_failed = false, t_fp_valid = false, t_shadow_valid = false, t_shadow_failed = false, t_stale = true;
+  bool rank1_deferred = false;   // knob defer_rank1: `tile` is set (the handle counts as analysed) but nothing of the rank-1 plan is built yet
   bool win_failed = false;       // the codes are not worth it on this matrix (or HBM cannot hold them): plain entries
   // rank-2 analysis (LDS-staged X tiles), built by the first rank-2 call that can use it
   kkamd_mv_plan* mv = nullptr;

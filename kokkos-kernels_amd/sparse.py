@@ -149,8 +149,12 @@ class SPMVHandle:
         check(self.backend.lib, self.backend.lib.kkamd_spmv_plan_export(self._plan, what.encode(), out.ctypes.data_as(C.c_void_p), int(count)))
         return out
 
-    def _ensure(self, A):
+    def _ensure(self, A, rank2=False):
         if self._plan is None:
+            if rank2 and "defer_rank1" not in self._pending:
+                # the reference's handle is set up by its first spmv call, for that call's rank (spmv_handle.hpp:280-349): a handle that
+                # begins with rank 2 leaves the rank-1 analysis to the first rank-1 call, if one ever comes
+                self._pending["defer_rank1"] = 1
             self.backend = A.backend
             lib = A.backend.lib
             p = C.c_void_p()
@@ -199,7 +203,7 @@ def spmv(*args):
     if xc != yc or (not trans and (n != xr or m != yr)) or (trans and (m != xr or n != yr)):
         raise RuntimeError("KokkosSparse::spmv: Dimensions do not match%s: , A: %d x %d, x: %d x %d, y: %d x %d"
                            % (" (transpose)" if trans else "", m, n, xr, xc, yr, yc))
-    plan = handle._ensure(A) if handle is not None else None
+    plan = handle._ensure(A, rank2=(len(x.shape) == 2 and xc > 1)) if handle is not None else None
     d = A.desc()
     vt = _scalar_type(y)
     if len(x.shape) == 1:

@@ -214,6 +214,55 @@ def check_transpose_plan_inherits_knobs(be):
         kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 1000))
 
 
+def check_rank2_first_handle_defers_rank1(be):
+    """A handle whose first call is rank 2 (more than one column) leaves the rank-1 analysis -- tiles, window codes, pattern records -- to
+    the first rank-1 call (knob defer_rank1, set by SPMVHandle; the reference's handle is set up by its first call, for that call's rank,
+    KokkosSparse_spmv_handle.hpp:280-349): rank 2, rank 1, rank 2 again on one handle, modes N and T, each against the oracle; the rank-1
+    plan does not exist before the rank-1 call and does afterwards; a handle that begins with rank 1 is analysed at once, as before; the
+    knob can be switched off on the handle."""
+    lib = be.lib
+    kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 0))
+    try:
+        for A0 in (oracle.laplace3d("FE", 9, 8, 7), oracle.random_crs(900, 700, 14, variance=6, seed=21)):
+            A = dev(be, A0)
+            rng = np.random.default_rng(5)
+            for mode in ("N", "T"):
+                trans = mode == "T"
+                nin, nout = (A0.nrows, A0.ncols) if trans else (A0.ncols, A0.nrows)
+                X = np.asarray(rng.random((nin, 6)), order="C"); Y0 = np.asarray(rng.random((nout, 6)), order="C")
+                x = rng.random(nin); y0 = rng.random(nout)
+                tol2 = oracle.spmv_max_error(A0, 1.5, 0.5) * (max(1.0, np.bincount(A0.entries, minlength=A0.ncols).max() / max(np.diff(A0.row_map).max(), 1)) if trans else 1.0)
+                h = kk.SPMVHandle("SPMV_DEFAULT")
+                key = "transpose_plan_tiles" if trans else "tiles"
+                def rank2():
+                    Yd = _to_dev_2d(be, Y0)
+                    kk.spmv(h, mode, 1.5, A, _to_dev_2d(be, X), 0.5, Yd)
+                    exp = oracle.spmv_mv_serial(mode, A0, 1.5, X, 0.5, Y0.copy(order="K"))
+                    assert np.abs(_to_host_2d(be, Yd) - exp).max() <= tol2, (mode, "rank 2")
+                def rank1():
+                    yd = be.from_numpy(y0)
+                    kk.spmv(h, mode, 1.5, A, be.from_numpy(x), 0.5, yd)
+                    exp = oracle.spmv_serial(mode, A0, 1.5, x, 0.5, y0.copy())
+                    assert np.abs(be.to_numpy(yd) - exp).max() <= tol2, (mode, "rank 1")
+                rank2()
+                assert h.query("tile") > 0 and h.query("tiles") == 0, (h.query("tile"), h.query("tiles"))      # analysed handle, no rank-1 plan yet
+                if trans: assert h.query("transpose_plan_tile") > 0 and h.query(key) == 0
+                rank1()
+                assert h.query(key) > 0, (mode, h.query(key))
+                rank2(); rank1()
+                # rank 1 first: analysed at creation
+                h = kk.SPMVHandle("SPMV_DEFAULT")
+                rank1()
+                assert h.query(key) > 0
+                rank2()
+                # the knob switched off by the caller
+                h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("defer_rank1", 0)
+                rank2()
+                assert h.query("tiles") > 0
+    finally:
+        kk._capi.check(lib, lib.kkamd_set_default(b"explicit_transpose_min_knnz", 1000))
+
+
 def check_colslab_deterministic(be):
     """The DETERMINISTIC column-slab form of rank-1 mode N (round 5; `colslab` 4 forces it, 3 -- the default -- chooses it by rule): per-slab
     partial sums of every row, stored by exactly one writer, cut runs summed in chunk order, slabs added in ascending order -- no atomics.

@@ -219,6 +219,10 @@ def test_transposed_plan_inherits_the_handles_knobs(be):
     pc.check_transpose_plan_inherits_knobs(be)
 
 
+def test_handle_that_begins_with_rank2_defers_the_rank1_analysis(be):
+    pc.check_rank2_first_handle_defers_rank1(be)
+
+
 def test_values_tracking_policies(be):
     # exact (default) / notify / fingerprints for the cached transpose and the column-slab copy; kkamd_spmv_plan_values_changed
     pc.check_values_tracking(be)
