@@ -2526,12 +2526,32 @@ __global__ __launch_bounds__(kBlock) void spgemm_items_scatter_kernel(int64_t n,
   }
 }
 
+// What an item's workgroup needs before it can ask for anything else, in one 32-byte record (built once per symbolic phase from the ordered
+// items): its blocks, its entries of C and where they start, its row of A.  (Read from the item, the class list, the index of C and the two
+// row maps these were three dependent trips to memory at the start of every one of 1.5 million workgroups on R-MAT scale 20.)
+struct alignas(16) ItemHead { int cbs; int ne; long long base; long long a0; int la; int pad; };
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_items_head_kernel(int64_t n, const int2* __restrict__ items, const int32_t* __restrict__ perm, int nblk,
+                                                                  const unsigned* __restrict__ cidx, const OffT* __restrict__ rmA, const OffT* __restrict__ rmC,
+                                                                  ItemHead* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int2 it = items[i];
+  const int64_t r = it.x;
+  const int cb0 = it.y & 0xffff, cb1 = (int)((unsigned)it.y >> 16);
+  const unsigned e0 = cidx[r * (nblk + 1) + cb0], e1 = cidx[r * (nblk + 1) + cb1];
+  const int64_t row = perm[r];
+  ItemHead hd;
+  hd.cbs = it.y; hd.ne = (int)(e1 - e0); hd.base = (long long)rmC[row] + e0; hd.a0 = (long long)rmA[row]; hd.la = (int)((int64_t)rmA[row + 1] - (int64_t)rmA[row]); hd.pad = 0;
+  out[i] = hd;
+}
+
 template <class OffT, class VT, int NT, bool RANK>
-__global__ __launch_bounds__(NT) void spgemm_item_vals_kernel(const int2* __restrict__ items, const int32_t* __restrict__ perm, int nblk, int wshift, int64_t nB,
-                                                              const unsigned* __restrict__ bidx, const unsigned* __restrict__ cidx,
-                                                              const OffT* __restrict__ rmA, const int32_t* __restrict__ entA, const VT* __restrict__ valA,
+__global__ __launch_bounds__(NT) void spgemm_item_vals_kernel(const ItemHead* __restrict__ items, int wshift, int64_t nB,
+                                                              const unsigned* __restrict__ bidx,
+                                                              const int32_t* __restrict__ entA, const VT* __restrict__ valA,
                                                               const OffT* __restrict__ rmB, const int32_t* __restrict__ entB, const VT* __restrict__ valB,
-                                                              int64_t nnzB, const OffT* __restrict__ rmC, const int32_t* __restrict__ entC, VT* __restrict__ valC, int maxblk) {
+                                                              int64_t nnzB, const int32_t* __restrict__ entC, VT* __restrict__ valC, int maxblk) {
   KK_DYN_SMEM(char, smem);                   // RANK: [packed words of maxblk blocks][sums by position];  direct: [sums by column of one block]
   __shared__ long long s_p0[NT];             // first entry of list a inside the item's columns (index into entries / values of B)
   __shared__ int s_n[NT];                    // entries of it inside them
@@ -2540,17 +2560,14 @@ __global__ __launch_bounds__(NT) void spgemm_item_vals_kernel(const int2* __rest
   __shared__ int s_wave[NT / 64];
   constexpr int UV = 8;
   const int t = threadIdx.x;
-  const int2 it = items[blockIdx.x];
-  const int64_t r = it.x;
-  const int cb0 = it.y & 0xffff, cb1 = (int)((unsigned)it.y >> 16);
-  const unsigned e0 = cidx[r * (nblk + 1) + cb0], e1 = cidx[r * (nblk + 1) + cb1];
-  const int ne = (int)(e1 - e0);
-  const int64_t row = perm[r];
-  const int64_t base = (int64_t)rmC[row] + e0;
+  const ItemHead hd = items[blockIdx.x];
+  const int cb0 = hd.cbs & 0xffff, cb1 = (int)((unsigned)hd.cbs >> 16);
+  const int ne = hd.ne;
+  const int64_t base = hd.base;
   const int c0 = cb0 << wshift;
   kk_u64* rank = reinterpret_cast<kk_u64*>(smem);
   VT* sums = RANK ? reinterpret_cast<VT*>(smem + ((size_t)maxblk << (wshift - 5)) * 8) : reinterpret_cast<VT*>(smem);
-  const int64_t a0 = (int64_t)rmA[row], la = (int64_t)rmA[row + 1] - a0;
+  const int64_t a0 = hd.a0, la = hd.la;
   const unsigned* bx0 = bidx + (int64_t)cb0 * nB;
   const unsigned* bx1 = bidx + (int64_t)cb1 * nB;
   // the first chunk of lists is requested NOW: entries(A) -> index of B / row_map(B) is a chain of two round trips that needs nothing of
@@ -2562,12 +2579,20 @@ __global__ __launch_bounds__(NT) void spgemm_item_vals_kernel(const int2* __rest
     pf_n = (int)(l - f); pf_p0 = (long long)rmB[kc] + f; pf_av = valA[a0 + t];
   }
   if constexpr (RANK) {
+    // (the item's entries of C -- twelve per work-item at the default capacity -- are asked for before the accumulator is cleared, not
+    // behind the barrier that follows it)
+    constexpr int EP = 12;
+    int ec[EP];
+    KK_UNROLL
+    for (int e = 0; e < EP; ++e) { const int i = t + e * NT; ec[e] = i < ne ? entC[base + i] : 0; }
     const int nw = (cb1 - cb0) << (wshift - 5);
     for (int i = t; i < nw; i += NT) rank[i] = 0ull;
     for (int i = t; i < ne; i += NT) sums[i] = VT(0);
     __syncthreads();
     unsigned* r32 = reinterpret_cast<unsigned*>(rank);
-    for (int i = t; i < ne; i += NT) { const unsigned c = (unsigned)(entC[base + i] - c0); atomicOr(&r32[(c >> 5) * 2], 1u << (c & 31u)); }
+    KK_UNROLL
+    for (int e = 0; e < EP; ++e) if (t + e * NT < ne) { const unsigned c = (unsigned)(ec[e] - c0); atomicOr(&r32[(c >> 5) * 2], 1u << (c & 31u)); }
+    for (int i = t + EP * NT; i < ne; i += NT) { const unsigned c = (unsigned)(entC[base + i] - c0); atomicOr(&r32[(c >> 5) * 2], 1u << (c & 31u)); }
     __syncthreads();
     // entries before every word: a contiguous run of words per work-item, one workgroup scan
     const int per = (nw + NT - 1) / NT;
@@ -2697,7 +2722,7 @@ struct kkamd_spgemm_handle {
   int64_t n_dense_block = 0;
   unsigned* d_bidx = nullptr; const void* bidx_rmB = nullptr; const void* bidx_entB = nullptr; int64_t bidx_nB = 0; int bidx_nblk = 0, bidx_wshift = 0;
   unsigned* d_cidx = nullptr; bool cidx_ready = false;
-  int2* d_items_rank = nullptr; int2* d_items_direct = nullptr; int64_t n_items_rank = 0, n_items_direct = 0; bool items_ready = false;
+  kk::ItemHead* d_items_rank = nullptr; kk::ItemHead* d_items_direct = nullptr; int64_t n_items_rank = 0, n_items_direct = 0; bool items_ready = false;
   int idx_nblk = 0, idx_wshift = 0, items_cap = 0, items_blocks = 0;      // what the two indices / the items were built for (the knobs are process-wide and may change between calls)
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
@@ -3349,8 +3374,10 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         KK_HIP(hipMemcpyAsync(&h_tot[1], d_nd + n_blk, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         KK_HIP(hipStreamSynchronize(st));
         KK_HIP(tmp_r.alloc(sizeof(int2) * (size_t)(h_tot[0] ? h_tot[0] : 1))); KK_HIP(tmp_d.alloc(sizeof(int2) * (size_t)(h_tot[1] ? h_tot[1] : 1)));
-        KK_HIP(hipMalloc((void**)&h->d_items_rank, sizeof(int2) * (size_t)(h_tot[0] ? h_tot[0] : 1)));
-        KK_HIP(hipMalloc((void**)&h->d_items_direct, sizeof(int2) * (size_t)(h_tot[1] ? h_tot[1] : 1)));
+        DevBuf ord_r, ord_d;                       // the items ordered by first block; what the value kernels read are the heads made of them
+        KK_HIP(ord_r.alloc(sizeof(int2) * (size_t)(h_tot[0] ? h_tot[0] : 1))); KK_HIP(ord_d.alloc(sizeof(int2) * (size_t)(h_tot[1] ? h_tot[1] : 1)));
+        KK_HIP(hipMalloc((void**)&h->d_items_rank, sizeof(ItemHead) * (size_t)(h_tot[0] ? h_tot[0] : 1)));
+        KK_HIP(hipMalloc((void**)&h->d_items_direct, sizeof(ItemHead) * (size_t)(h_tot[1] ? h_tot[1] : 1)));
         int2* t_r = tmp_r.as<int2>(); int2* t_d = tmp_d.as<int2>();
         KK_LAUNCH(spgemm_items_build_kernel, bgrid, kBlock, 0, st, n_blk, nblk, d_cx, cap_items, g_spgemm.item_blocks, 1, d_nr, d_nd, t_r, t_d);
         KK_HIP(hist_b.alloc(sizeof(unsigned) * (size_t)(nblk + 1)));
@@ -3358,13 +3385,15 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
         for (int which = 0; which < 2; ++which) {
           const int64_t n_it = h_tot[which];
           if (!n_it) continue;
-          const int2* src = which == 0 ? t_r : t_d; int2* dst = which == 0 ? h->d_items_rank : h->d_items_direct;
+          const int2* src = which == 0 ? t_r : t_d; int2* dst = which == 0 ? ord_r.as<int2>() : ord_d.as<int2>();
           KK_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * (size_t)(nblk + 1), st));
           const int64_t nbk_it = ceil_div(n_it, kBlock);
           const unsigned g_it = (unsigned)(nbk_it < 2048 ? nbk_it : 2048);
           KK_LAUNCH(spgemm_items_hist_kernel, g_it, kBlock, 0, st, n_it, src, nblk, d_hist);
           KK_LAUNCH(spgemm_items_scan_kernel, 1, 64, 0, st, nblk, d_hist);
           KK_LAUNCH(spgemm_items_scatter_kernel, g_it, kBlock, 0, st, n_it, src, nblk, d_hist, dst);
+          KK_LAUNCH((spgemm_items_head_kernel<OffT>), (unsigned)nbk_it, kBlock, 0, st, n_it, (const int2*)dst, bperm, nblk, d_cx, rmA, rmC,
+                    which == 0 ? h->d_items_rank : h->d_items_direct);
         }
         KK_HIP(hipStreamSynchronize(st));              // the scratch buffers go out of scope
         h->n_items_rank = h_tot[0]; h->n_items_direct = h_tot[1]; h->items_ready = true; h->items_cap = g_spgemm.item_cap; h->items_blocks = g_spgemm.item_blocks;
@@ -3372,21 +3401,21 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
                                    (long long)n_blk, (long long)h->n_items_rank, cap_items, g_spgemm.item_blocks, (long long)h->n_items_direct);
       }
       if (use_items) {
-        const int2* d_ir = h->d_items_rank; const int2* d_id = h->d_items_direct;
+        const ItemHead* d_ir = h->d_items_rank; const ItemHead* d_id = h->d_items_direct;
         if (h->n_items_direct) {
 #ifndef KK_EMU
           KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_item_vals_kernel<OffT, VT, kDenseBlock, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 #endif
-          KK_LAUNCH((spgemm_item_vals_kernel<OffT, VT, kDenseBlock, false>), (unsigned)h->n_items_direct, kDenseBlock, smem, st, d_id, bperm, nblk, wshift, nB, d_bx, d_cx,
-                    rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC, 1);
+          KK_LAUNCH((spgemm_item_vals_kernel<OffT, VT, kDenseBlock, false>), (unsigned)h->n_items_direct, kDenseBlock, smem, st, d_id, wshift, nB, d_bx,
+                    entA, valA, rmB, entB, valB, h->nnzB, (const int32_t*)entC, valC, 1);
         }
         if (h->n_items_rank) {
           const size_t smem_r = (((size_t)g_spgemm.item_blocks << (wshift - 5)) * 8) + sizeof(VT) * (size_t)g_spgemm.item_cap;
 #ifndef KK_EMU
           KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_item_vals_kernel<OffT, VT, kValBlock, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r));
 #endif
-          KK_LAUNCH((spgemm_item_vals_kernel<OffT, VT, kValBlock, true>), (unsigned)h->n_items_rank, kValBlock, smem_r, st, d_ir, bperm, nblk, wshift, nB, d_bx, d_cx,
-                    rmA, entA, valA, rmB, entB, valB, h->nnzB, rmC, (const int32_t*)entC, valC, g_spgemm.item_blocks);
+          KK_LAUNCH((spgemm_item_vals_kernel<OffT, VT, kValBlock, true>), (unsigned)h->n_items_rank, kValBlock, smem_r, st, d_ir, wshift, nB, d_bx,
+                    entA, valA, rmB, entB, valB, h->nnzB, (const int32_t*)entC, valC, g_spgemm.item_blocks);
         }
       } else {
       // blocks of 16384 columns: one workgroup of 1024 per CU around 128 KB of sums; narrower blocks: 512 work-items, two (or more) workgroups per CU

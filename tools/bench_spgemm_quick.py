@@ -55,6 +55,8 @@ for name in (sys.argv[1] if len(sys.argv) > 1 else "18").split(","):
         for rep in range(int(os.environ.get("KK_REPS", "3"))):
             kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle()
             if os.environ.get("KK_VERBOSE") and rep == 0: kh.get_spgemm_handle().set("verbose", 1)
+            for kv in os.environ.get("KK_HANDLE_OPTS", "").split(","):            # handle options, e.g. KK_HANDLE_OPTS=compression=2
+                if kv: kh.get_spgemm_handle().set(kv.split("=")[0], float(kv.split("=")[1]) if "." in kv.split("=")[1] else int(kv.split("=")[1]))
             torch.cuda.synchronize(); t0 = time.perf_counter()
             Cm = kk.spgemm_symbolic(kh, MA, False, MB, False)
             torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -77,4 +79,4 @@ for name in (sys.argv[1] if len(sys.argv) > 1 else "18").split(","):
         print(json.dumps({"case": label, "mults": mults, "nnzC": nnzC, "symbolic_ms": round(best[1] * 1e3, 3),
                           "numeric_ms": round(best[2] * 1e3, 3), "numeric_reuse_ms": round(best[3] * 1e3, 3), "entries_kept": best[4], "rows_from_bitmaps": src[0], "rows_from_lists": src[1],
                           "rows_column_blocks": src[2], "numeric_frac_of_gather_model": round(b_num / max(best[2], 1e-9) / 8e12, 4), "reuse_frac_of_gather_model": round(b_num / max(best[3], 1e-9) / 8e12, 4),
-                          "symbolic_frac_of_gather_model": round(b_sym / best[1] / 8e12, 4), "defaults": ",".join(v for v in (os.environ.get("KK_DEFAULTS", ""), sw) if v)}), flush=True)
+                          "symbolic_frac_of_gather_model": round(b_sym / best[1] / 8e12, 4), "defaults": ",".join(v for v in (os.environ.get("KK_DEFAULTS", ""), sw, os.environ.get("KK_HANDLE_OPTS", "")) if v)}), flush=True)
