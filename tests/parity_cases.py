@@ -694,7 +694,7 @@ def check_spgemm_val_steps(be):
             assert np.diff(got.row_map)[0] > 5461
         check_spgemm(be, A, B, offset_dtype=np.int64, value_dtype=np.float32)
     finally:
-        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_val_steps", 1))
+        kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_val_steps", 0))      # (the default: the vector walk)
 
 
 def check_spgemm_sorted_emission(be):
