@@ -280,6 +280,17 @@ def test_mv_long_rows(be):
     assert h.query("mv_long_rows") == 0
 
 
+def test_mv4_widths_beyond_one_block(be):
+    # every width from 17 to 47 on a lattice matrix: full passes of 16 columns + one partial pass, row-major and column-major multivectors in turn,
+    # beta = 0 over NaNs and beta != 0 (round-4 review item 8 asks for the parity of these widths whatever their speed)
+    name, A0, _ = pc.mv4_cases()[0]
+    for nvec in range(17, 48):
+        xo, yo = (("C", "C"), ("F", "F"), ("C", "F"))[nvec % 3]
+        beta = 0.0 if nvec % 2 else 0.5
+        h = pc.check_spmv_mv(be, A0, nvec, "N", 1.5, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0), seed=nvec)
+        assert h.query("mv4_workgroups") > 0, nvec
+
+
 def test_mv4_duplicate_entries(be):
     # a lattice row that stores one column twice must never become the plane-marching pattern, and a row
     # with a duplicate must go to the gather rows (the reference sums duplicates); rank 2 and the rank-1 marching kernel
