@@ -940,9 +940,9 @@ __global__ __launch_bounds__(kBlock) void mv4_rows_kernel(int64_t n_list, const 
 // (XROW: pieces past the block re-read its last piece); anything else goes element by element.
 template <class OffT, class AT, int NG, unsigned PRES, bool BETA0, int XM, bool PART = false>
 __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask, const AT* __restrict__ values, Mv4Groups G,
-                                                                  const double* __restrict__ X, int64_t xs0, int64_t xs1, double* __restrict__ Y,
+                                                                  const double* __restrict__ X0, int64_t xs0, int64_t xs1, double* __restrict__ Y0,
                                                                   int64_t ys0, int64_t ys1, double alpha, double beta, int y_vec_ok, int nx,
-                                                                  int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc, int ncv) {
+                                                                  int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc, int ncv, int ncb) {
   constexpr bool XROW = XM == 1;                       // row-major X, 16-byte pieces
   constexpr bool XT   = XM == 2;                       // column-major X (unit stride along the rows): pieces dealt out column-wise, slab rows swizzled
   constexpr int RI = kMv4RI, RJ = kMv4RJ, W = RI + 2, SLABR = (RJ + 2) * W, SLABB = SLABR * 128, NT = kMv4Threads;
@@ -958,7 +958,13 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
   char* ring = smem;
   AT* abuf   = reinterpret_cast<AT*>(smem + 4 * (size_t)SLABB);
   const int t = threadIdx.x, rs = t >> 3, line = rs / RI, ii = rs % RI, c = t & 7;
-  const int64_t b = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring patches of one k-chunk meet in one XCD's L2
+  // ncb blocks of 16 right-hand sides in one launch: the workgroups of one (patch, k-chunk) for the ncb blocks are neighbours in the launch
+  // order, so they run side by side in one XCD and the matrix's values, which all of them read, cross HBM -> L2 once for the ncb of them
+  const int64_t bb = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring patches of one k-chunk meet in one XCD's L2
+  const int64_t b = ncb > 1 ? bb / ncb : bb;
+  const int64_t cblk = ncb > 1 ? bb - b * ncb : 0;
+  const double* __restrict__ X = X0 + cblk * 16 * xs1;
+  double* __restrict__ Y = Y0 + cblk * 16 * ys1;
   const int64_t npatch = npi * npj;
   const int64_t ch = b / npatch, p = b % npatch;
   const int i0 = (int)(p % npi) * RI, j0 = (int)(p / npi) * RJ;
@@ -1314,7 +1320,7 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
 
 template <class OffT, class AT>
 static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
-                      double alpha, double beta, hipStream_t st, int ncv = 16) {
+                      double alpha, double beta, hipStream_t st, int ncv = 16, int ncb = 1) {
   const kkamd_mv4_plan* m = plan->mv4;
   const size_t slabs = 4 * (size_t)((kMv4RJ + 2) * (kMv4RI + 2) * 128), rows = kMv4Threads / 8;
   const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
@@ -1327,9 +1333,9 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   do {                                                                                                                          \
     const size_t lds = slabs + 4 * rows * mv4_pitch(3 * NE + (NE & 1), (int)sizeof(AT)) * sizeof(AT);                            \
     KK_MV4_ATTR(NE, FL, B0, XR, PT);                                                                                              \
-    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR, PT>), (unsigned)(m->npi * m->npj * m->nchunk), kMv4Threads, lds, st,        \
+    KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR, PT>), (unsigned)(m->npi * m->npj * m->nchunk * ncb), kMv4Threads, lds, st,  \
               (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values, m->grp, X, xs0, xs1, Y, ys0, ys1, alpha, \
-              beta, yv, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc, ncv);                                          \
+              beta, yv, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc, ncv, ncb);                                     \
   } while (0)
 #define KK_MV4(NE, FL)                                                                                                          \
   do {                                                                                                                          \
@@ -1356,9 +1362,12 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
 #undef KK_MV4_ATTR
   KK_LAUNCH_CHECK();
   if (m->n_nc > 0) {
-    KK_LAUNCH((mv4_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
-              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, X, xs0, xs1, Y, ys0, ys1, alpha, beta, ncv);
-    KK_LAUNCH_CHECK();
+    for (int q = 0; q < ncb; ++q) {
+      const double* Xq = X + (int64_t)q * 16 * xs1; double* Yq = Y + (int64_t)q * 16 * ys1;
+      KK_LAUNCH((mv4_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
+                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xq, xs0, xs1, Yq, ys0, ys1, alpha, beta, ncv);
+      KK_LAUNCH_CHECK();
+    }
   }
   return KKAMD_OK;
 }
@@ -1616,10 +1625,16 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
           if (rc) return rc;
         }
         if (plan->mv4) {
+          // the full blocks of 16 columns in ONE launch (their workgroups side by side: the values cross HBM once), at most what a grid holds
           int64_t c0 = 0;
-          for (; c0 + 16 <= nvec; c0 += 16) {
-            int rc = launch_mv4<OffT, AT>(plan, A, (const double*)X + c0 * xs1, xs0, xs1, (double*)Y + c0 * ys1, ys0, ys1, (double)alpha, (double)beta, st);
+          const int64_t wgs = plan->mv4->npi * plan->mv4->npj * plan->mv4->nchunk;
+          while (c0 + 16 <= nvec) {
+            int64_t ncb = (nvec - c0) / 16;
+            if (ncb > 8) ncb = 8;
+            while (ncb > 1 && wgs * ncb > (int64_t)INT32_MAX) --ncb;
+            int rc = launch_mv4<OffT, AT>(plan, A, (const double*)X + c0 * xs1, xs0, xs1, (double*)Y + c0 * ys1, ys0, ys1, (double)alpha, (double)beta, st, 16, (int)ncb);
             if (rc) return rc;
+            c0 += 16 * ncb;
           }
           if (c0 == nvec) return KKAMD_OK;
           // the last nvec % 16 columns (or a multivector narrower than 16): one pass of the partial-block form of the kernel

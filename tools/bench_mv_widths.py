@@ -12,11 +12,11 @@ def timeit(fn, it=8):
     return a.elapsed_time(b) / it
 A = kk.laplace_matrix("FE", 300, 300, 300)
 nnz, rows = A.nnz(), A.numRows()
-for nv in (4, 8, 12, 24, 32, 40):
+for nv in ([int(w) for w in os.environ["KK_WIDTHS"].split(",")] if os.environ.get("KK_WIDTHS") else (4, 8, 12, 24, 32, 40)):
     X = torch.rand(rows, nv, dtype=torch.float64, device="cuda"); Y = torch.zeros(rows, nv, dtype=torch.float64, device="cuda")
     alg = nnz * 12 + (rows + 1) * 4 + 2 * rows * nv * 8
     res = {}
-    for name, knobs in (("default", {}), ("gather (mv_kernel 2)", {"mv_kernel": 2})):
+    for name, knobs in ((("default", {}),) if os.environ.get("KK_NO_GATHER") else (("default", {}), ("gather (mv_kernel 2)", {"mv_kernel": 2}))):
         h = kk.SPMVHandle("SPMV_DEFAULT")
         for k, v in knobs.items(): h.set(k, v)
         ms = timeit(lambda: kk.spmv(h, "N", 1.0, A, X, 0.0, Y))
