@@ -942,7 +942,7 @@ template <class OffT, class AT, int NG, unsigned PRES, bool BETA0, int XM, bool 
 __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __restrict__ arow, const uint32_t* __restrict__ amask, const AT* __restrict__ values, Mv4Groups G,
                                                                   const double* __restrict__ X0, int64_t xs0, int64_t xs1, double* __restrict__ Y0,
                                                                   int64_t ys0, int64_t ys1, double alpha, double beta, int y_vec_ok, int nx,
-                                                                  int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc, int ncv, int ncb) {
+                                                                  int ny, int nz, int64_t S1, int64_t S2, int64_t npi, int64_t npj, int kc, int ncv_last, int ncb) {
   constexpr bool XROW = XM == 1;                       // row-major X, 16-byte pieces
   constexpr bool XT   = XM == 2;                       // column-major X (unit stride along the rows): pieces dealt out column-wise, slab rows swizzled
   constexpr int RI = kMv4RI, RJ = kMv4RJ, W = RI + 2, SLABR = (RJ + 2) * W, SLABB = SLABR * 128, NT = kMv4Threads;
@@ -965,6 +965,10 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
   const int64_t cblk = ncb > 1 ? bb - b * ncb : 0;
   const double* __restrict__ X = X0 + cblk * 16 * xs1;
   double* __restrict__ Y = Y0 + cblk * 16 * ys1;
+  // (PART with several blocks: the blocks before the last are full ones in the partial form -- a width that is no multiple of 16 in ONE
+  // launch, so that the blocks' workgroups also share the X rows: with a row pitch of 192 or 320 bytes a block's 128 bytes of a row are
+  // parts of two lines, and the other parts belong to the neighbour block)
+  const int ncv = (PART && cblk != ncb - 1) ? 16 : ncv_last;
   const int64_t npatch = npi * npj;
   const int64_t ch = b / npatch, p = b % npatch;
   const int i0 = (int)(p % npi) * RI, j0 = (int)(p / npi) * RJ;
@@ -1364,8 +1368,9 @@ static int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const d
   if (m->n_nc > 0) {
     for (int q = 0; q < ncb; ++q) {
       const double* Xq = X + (int64_t)q * 16 * xs1; double* Yq = Y + (int64_t)q * 16 * ys1;
+      const int ncv_q = q == ncb - 1 ? ncv : 16;
       KK_LAUNCH((mv4_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
-                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xq, xs0, xs1, Yq, ys0, ys1, alpha, beta, ncv);
+                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xq, xs0, xs1, Yq, ys0, ys1, alpha, beta, ncv_q);
       KK_LAUNCH_CHECK();
     }
   }
@@ -1628,6 +1633,14 @@ static int spmv_mv_typed(kkamd_spmv_plan* plan, const kkamd_crs_t* A, bool trans
           // the full blocks of 16 columns in ONE launch (their workgroups side by side: the values cross HBM once), at most what a grid holds
           int64_t c0 = 0;
           const int64_t wgs = plan->mv4->npi * plan->mv4->npj * plan->mv4->nchunk;
+          // a width that is no multiple of 16 (17 .. 128 columns, an even remainder or an X that is not row-major): all its blocks in one
+          // launch of the partial-block form -- the values once, and the lines of X the blocks share once
+          {
+            const int64_t nb = ceil_div(nvec, (int64_t)16), rem = nvec % 16;
+            const bool xrow = xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0);
+            if (rem != 0 && nb >= 2 && nb <= 8 && (rem % 2 == 0 || !xrow) && wgs * nb <= (int64_t)INT32_MAX && plan->tune.mv4_min_nvec <= 16)
+              return launch_mv4<OffT, AT>(plan, A, (const double*)X, xs0, xs1, (double*)Y, ys0, ys1, (double)alpha, (double)beta, st, (int)rem, (int)nb);
+          }
           while (c0 + 16 <= nvec) {
             int64_t ncb = (nvec - c0) / 16;
             if (ncb > 8) ncb = 8;
