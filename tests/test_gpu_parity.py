@@ -289,6 +289,18 @@ def test_mv4_widths_beyond_one_block(be):
         beta = 0.0 if nvec % 2 else 0.5
         h = pc.check_spmv_mv(be, A0, nvec, "N", 1.5, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0), seed=nvec)
         assert h.query("mv4_workgroups") > 0, nvec
+    # the other lattice matrices (truncated stencils, rows left to the gather rows, a 2-D lattice), wider multivectors: up to eight blocks
+    # share a launch (128 columns), beyond that the blocks go eight at a time; 64-bit offsets; mode T through the cached transpose
+    cases = [c[:2] for c in pc.mv4_cases()[1:4]] + [("9-pt 70 x 128", oracle.laplace2d("FE", 70, 128))]
+    for ci, (name, A1) in enumerate(cases):
+        for nvec in (18, 24, 33, 40, 64, 100, 128, 129, 136, 150):
+            xo, yo = (("C", "C"), ("F", "F"), ("F", "C"))[(nvec + ci) % 3]
+            beta = 0.5 if (nvec + ci) % 2 else 0.0
+            h = pc.check_spmv_mv(be, A1, nvec, "N", -1.0, beta, xo, yo, algo="SPMV_DEFAULT", max_val=32.0, nans=(beta == 0.0), seed=nvec + 7 * ci,
+                                 offset_dtype=np.int64 if nvec % 3 == 0 else np.int32)
+            assert h.query("mv4_workgroups") > 0, (name, nvec)
+    pc.check_spmv_mv(be, A0, 40, "T", 1.0, 0.0, "C", "C", algo="SPMV_DEFAULT", max_val=32.0, knobs={"explicit_transpose_min_knnz": 0})
+    pc.check_spmv_mv(be, A0, 24, "T", 2.0, 0.5, "F", "F", algo="SPMV_DEFAULT", max_val=32.0, knobs={"explicit_transpose_min_knnz": 0})
 
 
 def test_mv4_duplicate_entries(be):
