@@ -39,13 +39,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a plain copy reaches
-PMC_FILE = os.path.join(ROOT, "profiles", "round5", "bench_n1_pmc_hbm.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "round6", "bench_n1_pmc_hbm.json")
+MV_PMC_FILE = os.path.join(ROOT, "profiles", "round6", "mv4_pmc_hbm.json")
 
 
 def kernel_source_sha(unit="kk_spmv.hip"):
     """sha256 over one kernel translation unit and the headers every unit shares: stamps every committed counter file, so that
     bench.py can tell whether the traffic figure it quotes was measured on the code it is running (.git does not travel to
-    the GPU box).  The rank-1 SpMV the bench times lives in kk_spmv.hip."""
+    the GPU box).  The rank-1 SpMV the bench times lives in kk_spmv.hip, config 3's kernels in kk_spmv_mv.hip, SpGEMM in kk_spgemm.hip:
+    a file is stamped with the hash of the unit it measures (tools/extract_profiles.py: unit_of_tag)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "kokkos-kernels_amd", "csrc")
@@ -54,10 +56,16 @@ def kernel_source_sha(unit="kk_spmv.hip"):
     return h.hexdigest()[:16]
 
 
+def all_unit_shas():
+    """{unit: sha} for every kernel translation unit (stamped into summaries that span several units, e.g. the whole bench line)"""
+    d = os.path.join(ROOT, "kokkos-kernels_amd", "csrc")
+    return {f: kernel_source_sha(f) for f in sorted(os.listdir(d)) if f.endswith(".hip")}
+
 
 def cpu_baseline(sample_n=300, min_seconds=6.0):
     """Reference host path (port) on the workload's own matrix (27-pt FE Laplacian 300^3; a 160^3 sample only if the host
-    cannot hold it), all usable host cores, about ten seconds of SpMVs."""
+    cannot hold it), all usable host cores, about ten seconds of SpMVs.  N > 1: rank 0 runs it after the timed region on the
+    same 27,000,000-row problem one GPU's slab holds (the other ranks wait at the closing barrier)."""
     # thread placement Kokkos recommends for its OpenMP backend; must be set before the OpenMP runtime starts
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "threads")
@@ -380,7 +388,6 @@ def main():
             def record(self): self.t = time.perf_counter()
             def elapsed_time(self, other): return (other.t - self.t) * 1e3
         device_sync = lambda: None
-        args.no_cpu_baseline = True
     else:
         torch.cuda.set_device(local_rank)
         be, dev, tb, Event, device_sync = None, "cuda", (lambda t: t), torch.cuda.Event, torch.cuda.synchronize
@@ -543,7 +550,8 @@ def main():
         lo = max(0, rank * planes_per_rank - 1); hi = min(nz, (rank + 1) * planes_per_rank + 1)
         x_touched = (hi - lo) * nx * ny
     alg_bytes = nnz_local * 12 + (rows_per_rank + 1) * 4 + x_touched * 8 + rows_per_rank * 8 + (rows_per_rank * 8 if beta != 0 else 0)
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    achieved_events = alg_bytes / (kern_ms * 1e-3) / 1e9     # HIP events around the launches
+    achieved = alg_bytes / (ms_step * 1e-3) / 1e9            # the step's own clock (per-call fence included; N > 1: the exchange too): what "frac" is quoted on
     gflops = 2.0 * nnz_global / (ms_step * 1e-3) / 1e9
 
     if rank == 0:
@@ -559,13 +567,15 @@ def main():
                                         "; %d interior rows overlap the exchange" % op.interior_rows if op.query("parts") > 1 else ""))
                                     if use_dist else "single GPU",
                        "knobs": args.knob},
-            "achieved_hbm_GBps_per_gpu": round(achieved, 1),
+            "achieved_hbm_GBps_per_gpu": round(achieved_events, 1),
             "spmv_kernel_ms": round(kern_ms, 5),
             "protocol": ("per-call fence (KokkosSparse_kk_spmv.cpp:139-167): ms_per_step is the mean over the K calls incl. the fence" if not args.no_fence
                          else "K calls queued back to back between two fences"),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "kk::spmv_stream3_kernel (+ fix-up kernel), HIP events around the launch",
+                         "kernel": "kk::spmv_stream3_kernel (+ fix-up kernel)",
+                         "clock": "algorithmic bytes / ms_per_step (the timed loop's own clock); *_kernel_events: the same bytes / the mean HIP-event time around the launches",
+                         "achieved_kernel_events": round(achieved_events, 1), "frac_kernel_events": round(achieved_events / HBM_PEAK_GBPS, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         # What the plan really streams: the analysis replaces the 4-byte column indices by 16-bit codes or, on locally
@@ -600,7 +610,7 @@ def main():
                 e1_.record(); torch.cuda.synchronize()
                 rd_gbps = nbytes_ * 10 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9
                 out["roofline"]["measured_stream_read_GBps"] = round(rd_gbps, 1)
-                out["roofline"]["frac_of_measured_stream_read"] = round(achieved / rd_gbps, 4)
+                out["roofline"]["frac_of_measured_stream_read"] = round(achieved_events / rd_gbps, 4)
             except Exception as e:
                 out["roofline"]["measured_stream_read_GBps"] = None
                 out["roofline"]["measured_stream_read_error"] = repr(e)[:120]
@@ -637,7 +647,10 @@ def main():
             out["per_call_ms_flushed"] = flushed
         if xchg is not None:
             out["exchange"] = xchg
-        if world == 1 and not args.no_cpu_baseline:
+        if emu:       # control-flow check: the same leg on the emulated grid (a fraction of a second)
+            out["cpu_baseline"] = cpu_baseline(sample_n=n, min_seconds=0.2)
+            out["cpu_baseline"]["sample"] = "EMULATED RUN, tiny grid: " + out["cpu_baseline"]["sample"]
+        elif not args.no_cpu_baseline:     # every GPU count (north_star: the host path "in the same run"); rank 0, after the timed region
             out["cpu_baseline"] = cpu_baseline()
         # ---- the other SURVEY 8(d) metrics, driver-visible: config 3 (SpMV_MV) and config 4 (SpGEMM), each under its share of the cap
         if not use_dist and not emu and not args.n and args.extras_seconds > 0:

@@ -224,7 +224,17 @@ def test_bench_two_process_flow_emulated(launcher):
     assert d["config"]["rows"] == 32 * 32 * 8 and d["config"]["rows_per_gpu"] == 32 * 32 * 4
     assert "halo" in d["config"]["partition"] and "overlap" in d["config"]["partition"], d["config"]["partition"]
     assert "%d bytes" % (32 * 32 * 8) in d["config"]["partition"]            # one 32x32 plane of doubles from the neighbour
-    assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+    # the N > 1 line is as complete as the N = 1 line: roofline (quoted on the step's own clock, the event-clock figure beside it),
+    # the host baseline of the same run, every exchange the library has, the partition
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["frac_kernel_events"] >= 0      # (the emulator runs at MB/s: both round to 0)
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / d["ms_per_step"] / 1e6) <= 0.06 + 1e-3 * rf["achieved"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "GFLOP/s" and cb["value"] > 0 and cb["cores"] >= 1 and "27-pt FE Laplacian" in cb["sample"]
+    assert set(d["exchange"]) >= {"halo", "halo_set", "allgather"}
+    for x in ("halo", "halo_set", "allgather"):
+        assert d["exchange"][x]["step_ms"] > 0 and d["exchange"][x]["bytes_received_per_gpu"] > 0
 
 
 def test_slab_offsets():
