@@ -331,7 +331,11 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* handle, const char* key, double valu
  * of the dense rows from the previous call (numeric reuse), 12 rows whose entries(C) the last numeric call wrote from a bitmap kept by the
  * symbolic phase, 13 bitmaps the symbolic phase holds at this moment (they are freed by the numeric call that uses them), 14 rows whose entries(C) the
  * last numeric call copied from the entry lists the symbolic phase left (dense rows whose bitmap is not kept), 15 rows whose entries(C)
- * the last numeric call sorted in LDS (rows of more than 256 entries out of at most 2048 products). */
+ * the last numeric call sorted in LDS (rows of more than 256 entries out of at most 2048 products), 16 - 18 rows / items of the column-block
+ * value kernel, 19 units (row of C, window of 2^18 columns) the last symbolic phase counted its dense class by (0: none, or row by row),
+ * 20 units whose bitmap it kept for the numeric phase, 21 rows of the class whose every unit kept its structure (bitmap or entry list).
+ * With units, 12 counts the rows whose entries(C) the last numeric call wrote from kept units, 13 the rows held, 14 those of 12 with at
+ * least one unit kept as an entry list. */
 int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);
 /* the recorded value of a hint key (the reference's get_* of the same setter); KKAMD_ERR_INVALID_ARG when the key was never set */
 int kkamd_spgemm_get_hint(kkamd_spgemm_handle_t* handle, const char* key, double* value);

@@ -88,6 +88,7 @@ constexpr int kValLa2     = 1024;     // ... of the flat value kernel's second s
 constexpr int kValLong    = 128;      // B rows at least this long are streamed by a whole wave
 constexpr int kHubLa      = 4096;     // A rows up to this long keep cursor + next column in LDS (hub value kernel)
 
+constexpr int kUnitBitsMaxKnob = 18;  // default of the knob spgemm_unit_bits
 constexpr int kItemMaxBlocks = 4;     // column blocks per rank item (default of the knob spgemm_item_blocks)
 
 struct SpgemmTuning {
@@ -132,6 +133,8 @@ struct SpgemmTuning {
   int list_staged    = 1;         // symbolic: the entry lists kept for the numeric phase are written wave by wave, 64 consecutive words per round (0 = every lane writes its own run)
   int nt             = 0;         // value kernels of the dense rows: entries(C) / values(C) through nontemporal loads / stores
   int sort_rows      = 1;         // the row lists of the dense kernels are ordered by size, largest first (0 = the order the binning left)
+  int sym_units      = 1;         // symbolic phase of the dense class by units (row, window of 2^unit_bits columns): spgemm_sym_unit_kernel; 0 = one workgroup per row (spgemm_dense_cols_kernel)
+  int unit_bits      = kUnitBitsMaxKnob;   // log2 of a unit's columns (6 .. 18; 18 = 32 KB of bitmap, four workgroups of 256 per CU)
   int pool_keep      = 0;         // the process-wide store of bitmaps / entry lists when the last handle is destroyed: 0 = returned to the device after the process's
                                   // first product, kept once the process has come back for it (see BmPool); 1 = always kept; 2 = always returned
 };
@@ -1034,9 +1037,10 @@ __device__ __forceinline__ int emit_bits_by_wave(const kk_u64* __restrict__ bm, 
 // (Measured and not kept: every lane laying down the set bits of its OWN 64-bit word -- no shuffles at all, one prefix sum per 64 words,
 // steps above 1024 entries taken in halves or quarters of the lanes: R-MAT scale 20 numeric 193.7 -> 200.9 ms; the 16-bit pieces below
 // keep the divergent loop at 16 trips at most.)
+template <int NT = kDenseBlock>
 __device__ __forceinline__ int emit_bits_by_wave_staged(const kk_u64* __restrict__ bm, int words, int64_t col0, int64_t pos0, int32_t* __restrict__ entC, int* s_wave,
                                                         int32_t* __restrict__ stage /* [1024] of this wave */) {
-  constexpr int NW = kDenseBlock / 64, NB = 16;
+  constexpr int NW = NT / 64, NB = 16;                     // words <= 1024 NW (2^20 columns for 1024 work-items, 2^18 for 256)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wpw = ((words + NW - 1) / NW + 63) & ~63;
   const int w0 = wave * wpw, w1 = (w0 + wpw < words) ? w0 + wpw : words;
@@ -1291,6 +1295,367 @@ __global__ __launch_bounds__(kBlock) void spgemm_copy_pool_kernel(const int32_t*
   const int32_t* src = pool + pool_off[row];
   for (int64_t i = threadIdx.x; i < n; i += kBlock) entC[b + i] = src[i];
 }
+// ------------------------------------------------------------------------------------------------
+// The dense class by UNITS (round 6).  A unit is (row of C, WINDOW of 2^wb columns): one workgroup of 256 around a 32 KB bitmap
+// (wb = 18), four of them per CU, each independent of every other.  The one-workgroup-per-row kernel above (spgemm_dense_cols_kernel)
+// walked all of a row's products once per window of 2^20 columns (R-MAT scale 22, k = 2^22: four times), kept one row per CU in
+// flight, and spent 49 vector instructions per product at 54 % vector-ALU utilisation with nothing to overlap the per-row latency
+// chains (round-5 profile, R-MAT scale 20: 50 of the symbolic phase's 59 ms).  What makes the windows cheap:
+//   * an index of B at window granularity, built once per symbolic phase (spgemm_bidx_kernel): widx[w][j] = entries of row j of B
+//     with a column below w 2^wb -- and from it an index of A's ENTRIES (spgemm_aw_kernel): aw[w][a] = rmB[j] + widx[w][j] for
+//     j = entries(A)[a].  The piece of list a inside window w is entries(B)[aw[w][a] .. aw[w + 1][a]): a unit reads the bounds of its
+//     pieces with coalesced loads and walks ONLY its own piece of every list;
+//   * units without products are never launched, the others are ordered by their products (heaviest first) and described by a
+//     32-byte HEAD each (row, first list, lists, where its structure goes): head -> bounds -> entries(B) are the only dependent
+//     trips to memory of a unit (the first version chased perm -> row_map(A) -> entries(A) -> row_map(B) / widx -> entries(B) and
+//     took room in its store by returning atomics: 9 us of latency per unit, 1.4 million units on R-MAT scale 20);
+//   * every WAVE owns a contiguous range of the chunk's 16-byte quads and walks it 64 Q quads per step; the list of a step is found by
+//     two wave-uniform searches (first / last quad of the step), and a step that lies inside one list and holds none of its partial end
+//     quads -- nearly all products of an R-MAT row -- runs with no per-entry condition at all: one address, Q 16-byte loads, and per
+//     product two shifts, a mask and one ds_or_b32.  Steps that cross lists take the general form (per-lane search inside the step's
+//     lists, entries masked by their list's bounds);
+//   * the columns of a piece are inside the window by construction: no range test, no minimum / maximum tracking per product;
+//   * the count is a popcount of the unit's words (lane-strided LDS reads, no bank conflicts) kept in registers, from which the
+//     unit's structure leaves for the first numeric call (spgemm_emit_unit_kernel): its bitmap when its products could fill one
+//     (more than a bitmap's bytes / 4), else its entry list -- at an offset fixed before the launch (a prefix sum over
+//     min(4 products, bitmap bytes)): no cursor, no atomics, nothing that can run full.  Per unit, so any k is covered (the per-row
+//     store of rounds 3 - 5 needed k <= 2^20).
+// counts[row] collects the units of a row by one integer atomic each (order-independent: the result is exact).
+constexpr int kUnitNT = 256;
+constexpr int kUnitBitsMax = 20;                                              // 2^18 columns = 32 KB of bitmap for 256 work-items; 2^19 / 2^20: workgroups of 512 / 1024
+__host__ __device__ constexpr int unit_bits_of(int nt) { return nt >= 1024 ? 20 : (nt >= 512 ? 19 : 18); }
+struct alignas(16) UnitHead {
+  long long a_beg;          // first entry of the row of A
+  long long store_off;      // bytes into the store, -1: the unit keeps nothing
+  int n_lists;              // entries of the row of A
+  int unit;                 // rank of the row in the class's list * windows + window
+  int row;
+  int kind;                 // 1: the unit leaves its bitmap, 0: its entry list
+};
+template <int NT> struct UnitScratch {
+  int pre[NT + 2];                     // quad offset of every list piece of the chunk
+  long long lo[NT], hi[NT];            // the piece: entries [lo, hi) of entries(B)
+  long long wave64[NT / 64];
+  int wave32[NT / 64];
+};
+template <class OffT> __device__ __forceinline__ void unit_count_add(OffT* p, int v);
+template <> __device__ __forceinline__ void unit_count_add<int32_t>(int32_t* p, int v) { atomicAdd(reinterpret_cast<int*>(p), v); }
+template <> __device__ __forceinline__ void unit_count_add<int64_t>(int64_t* p, int v) { atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+
+// aw[w][a] = rmB[j] + (entries of row j of B below column w 2^wb), j = entries(A)[a]; aw[0][a] = rmB[j], aw[nwin][a] = rmB[j + 1]
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_aw_kernel(int64_t nnzA, const int32_t* __restrict__ entA, const OffT* __restrict__ rmB, int64_t nB, int nwin,
+                                                          const unsigned* __restrict__ widx /* [nwin + 1][nB], nullptr when nwin == 1 */, long long* __restrict__ aw /* [nwin + 1][nnzA] */) {
+  const int64_t a = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (a >= nnzA) return;
+  const int32_t j = entA[a];
+  const long long b = (long long)rmB[j];
+  aw[a] = b;
+  aw[(size_t)nwin * (size_t)nnzA + a] = (long long)rmB[j + 1];
+  for (int w = 1; w < nwin; ++w) aw[(size_t)w * (size_t)nnzA + a] = b + (long long)widx[(size_t)w * (size_t)nB + j];
+}
+// products of every unit of the class: one wave per row, window by window (the bounds of a window's pieces are two coalesced streams)
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_uprod_kernel(int64_t nrows, const int32_t* __restrict__ perm, const OffT* __restrict__ rmA, int64_t nnzA, int nwin,
+                                                             const long long* __restrict__ aw, long long* __restrict__ uprod /* [nrows * nwin] */) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (r >= nrows) return;                                                  // (the whole wave)
+  const int64_t row = perm[r];
+  const int64_t a0 = (int64_t)rmA[row], a1 = (int64_t)rmA[row + 1];
+  for (int w = 0; w < nwin; ++w) {
+    const long long* lo = aw + (size_t)w * (size_t)nnzA;
+    const long long* hi = lo + (size_t)nnzA;
+    long long sum = 0;
+    for (int64_t a = a0 + lane; a < a1; a += 64) sum += hi[a] - lo[a];
+    sum = group_sum(sum, 64);
+    if (lane == 0) uprod[r * nwin + w] = sum;
+  }
+}
+// the units with products, in any order (they are ordered by size next); count[0] = how many
+__global__ __launch_bounds__(kBlock) void spgemm_unit_compact_kernel(int64_t units, const long long* __restrict__ uprod, int32_t* __restrict__ ulist, unsigned long long* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool q = i < units && uprod[i] > 0;
+  const kk_u64 mk = __ballot(q);
+  const int lane = threadIdx.x & 63;
+  unsigned long long start = 0;
+  if (lane == 0 && mk) start = atomicAdd(count, (unsigned long long)__popcll(mk));
+  start = __shfl(start, 0, 64);
+  if (q) ulist[start + __popcll(mk & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
+// bytes a unit's structure can take: its entry list (4 bytes per product at most) or, when that could exceed it, its bitmap
+__device__ __forceinline__ long long unit_store_bytes(long long prod, long long bm_bytes) {
+  const long long lst = (prod * 4 + 15) & ~15ll;
+  return lst < bm_bytes ? lst : bm_bytes;
+}
+__global__ __launch_bounds__(kBlock) void spgemm_unit_ssize_kernel(int64_t n, const int32_t* __restrict__ ulist, const long long* __restrict__ uprod, long long bm_bytes,
+                                                                  long long* __restrict__ soff /* [n + 1] */) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) soff[i] = unit_store_bytes(uprod[ulist[i]], bm_bytes);
+  if (i == n) soff[i] = 0;
+}
+// soff: exclusive prefix of the sizes.  Heads in launch order; per unit, for the numeric phase: uoff[unit] = (store offset << 1) | kind, or -1.
+// count[0] = units that leave a bitmap, count[1] = bytes of the store in use, count[2] = units without room
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void spgemm_unit_heads_kernel(int64_t n, const int32_t* __restrict__ ulist, const long long* __restrict__ uprod, const long long* __restrict__ soff,
+                                                                  long long bm_bytes, long long budget, int keep_lists, int nwin, const int32_t* __restrict__ perm, const OffT* __restrict__ rmA,
+                                                                  UnitHead* __restrict__ heads, long long* __restrict__ uoff, unsigned long long* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool is_bm = false, none = false; long long used = 0;
+  if (i < n) {
+    const int32_t u = ulist[i];
+    const long long prod = uprod[u];
+    const long long sz = unit_store_bytes(prod, bm_bytes);
+    const int64_t row = perm[u / nwin];
+    UnitHead hd;
+    hd.a_beg = (long long)rmA[row]; hd.n_lists = (int)((long long)rmA[row + 1] - hd.a_beg); hd.unit = u; hd.row = (int)row;
+    hd.kind = prod * 4 > bm_bytes ? 1 : 0;
+    hd.store_off = (soff[i] + sz <= budget && (hd.kind == 1 || keep_lists)) ? soff[i] : -1;
+    heads[i] = hd;
+    uoff[u] = hd.store_off < 0 ? -1 : ((hd.store_off << 1) | (long long)hd.kind);
+    is_bm = hd.store_off >= 0 && hd.kind == 1; none = hd.store_off < 0; used = hd.store_off >= 0 ? sz : 0;
+  }
+  const kk_u64 mb = __ballot(is_bm), mn = __ballot(none);
+  used = group_sum(used, 64);
+  if ((threadIdx.x & 63) == 0) {
+    if (mb) atomicAdd(count, (unsigned long long)__popcll(mb));
+    if (used) atomicAdd(count + 1, (unsigned long long)used);
+    if (mn) atomicAdd(count + 2, (unsigned long long)__popcll(mn));
+  }
+}
+
+template <class OffT, int NT, int Q>
+__global__ __launch_bounds__(NT) void spgemm_sym_unit_kernel(const UnitHead* __restrict__ heads, int nwin, int wb, int64_t k, int64_t nnzA, const long long* __restrict__ aw,
+                                                             const int32_t* __restrict__ entB, int64_t nnzB, OffT* __restrict__ counts, unsigned* __restrict__ ucnt,
+                                                             char* __restrict__ store, int bm_words KK_DBG_PARAM) {
+  // dynamic LDS: the bitmap (bm_words 64-bit words, a multiple of 16) at offset 0 -- a bit's address is then two instructions from its column, with no
+  // base to add --, the scratch behind it
+  KK_DYN_SMEM(kk_u64, bm);
+  UnitScratch<NT>& sc = *reinterpret_cast<UnitScratch<NT>*>(bm + bm_words);
+  constexpr int NW = NT / 64, S = 64 * Q, NB = (((1 << unit_bits_of(NT)) / 64) / NW) / 64;      // 16 rounds of 64 words per wave when counting
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = KK_UNIFORM(t >> 6);
+  const UnitHead hd = heads[blockIdx.x];
+  const unsigned u = (unsigned)hd.unit;
+  const unsigned w = u % (unsigned)nwin;
+  const int64_t c0 = (int64_t)w << wb;
+  const int nbits  = (int)(k - c0 < ((int64_t)1 << wb) ? k - c0 : ((int64_t)1 << wb));
+  const int nwords = (nbits + 63) >> 6;                                   // 64-bit words of the unit's bitmap
+  {
+    int4 zero4; zero4.x = 0; zero4.y = 0; zero4.z = 0; zero4.w = 0;
+    int4* z = reinterpret_cast<int4*>(bm);
+    for (int i = t; i < bm_words >> 1; i += NT) z[i] = zero4;
+  }
+  __syncthreads();
+  unsigned* bm32 = reinterpret_cast<unsigned*>(bm);
+  const unsigned wordmask = (1u << (wb - 5)) - 1u;            // wb >= 6
+  auto mark = [&](int cb) {                        // column -> bit of the window (the piece's columns are inside it): shift, mask, shift, ds_or
+    if (!KK_DBG(256)) atomicOr(&bm32[((unsigned)cb >> 5) & wordmask], 1u << ((unsigned)cb & 31u));
+  };
+  const int64_t a_beg = hd.a_beg, a_end = hd.a_beg + hd.n_lists;
+  const long long* awlo = aw + (size_t)w * (size_t)nnzA;
+  const long long* awhi = awlo + (size_t)nnzA;
+  // every 16-byte load is unconditional (see flat_columns_quads): a quad that does not exist reads quad 0, the one that would reach past
+  // the end of entries(B) reads the last full quad and takes its entries from `tail`.  nnz(B) >= 4 (the caller's condition).
+  const long long last_full = ((nnzB >> 2) - 1) << 2;
+  int tail[3];
+  KK_UNROLL
+  for (int e = 0; e < 3; ++e) { const long long i = last_full + 4 + e; tail[e] = entB[i < nnzB ? i : nnzB - 1]; }
+  for (int64_t chunk = a_beg; chunk < a_end && !KK_DBG(2); chunk += NT) {
+    const int n = (int)(a_end - chunk < NT ? a_end - chunk : NT);
+    long long nq = 0, lo = 0, hi = 0;
+    if (t < n) {
+      lo = awlo[chunk + t]; hi = awhi[chunk + t];
+      if (hi > lo) nq = ((hi + 3) >> 2) - (lo >> 2);
+    }
+    long long tot64;
+    const long long excl = block_exclusive_scan_n<long long, NT>(nq, &tot64, sc.wave64);
+    if (t < n) { sc.lo[t] = lo; sc.hi[t] = hi; }
+    if (tot64 > (long long)INT_MAX - 2 * S) {           // (pieces with 8e9 entries between them: not a real case) -- list by list, entry by entry
+      __syncthreads();
+      for (int a = 0; a < n; ++a) for (long long i = sc.lo[a] + t; i < sc.hi[a]; i += NT) mark(entB[i]);
+      __syncthreads();
+      continue;
+    }
+    const int tot = (int)tot64;
+    if (t < n) sc.pre[t] = (int)excl;
+    if (t == 0) sc.pre[n] = tot;
+    __syncthreads();
+    if (tot > 0) {
+      const int nsteps = (tot + S - 1) / S;
+      const int s_beg = (int)(((long long)nsteps * wave) / NW), s_end = (int)(((long long)nsteps * (wave + 1)) / NW);
+      // largest s in [from, n) with pre[s] <= q (lists without quads share their successor's offset: the search steps over them)
+      auto ufind = [&](int from, int q) {
+        int at = from, len = n - from;
+        while (len > 1) { const int half = len >> 1; at += (sc.pre[at + half] <= q) ? half : 0; len -= half; }
+        return at;
+      };
+      int seg = 0;
+      for (int step = s_beg; step < s_end; ++step) {
+        const int qw0 = step * S;
+        const int qw1 = (qw0 + S <= tot ? qw0 + S : tot) - 1;            // first / last quad of the wave's step
+        seg = KK_UNIFORM(ufind(seg, qw0));
+        const int seg_hi = KK_UNIFORM(ufind(seg, qw1));
+        const int q0 = qw0 + lane * Q;
+        bool inside = false;
+        long long ebase = 0;
+        if (seg == seg_hi && qw0 + S <= tot) {                           // (uniform) one list, a full step
+          const long long llo = sc.lo[seg], lhi = sc.hi[seg];
+          ebase = ((llo >> 2) - (long long)sc.pre[seg]) << 2;            // quad q of the chunk starts at entry ebase + 4 q
+          inside = ebase + 4ll * qw0 >= llo && ebase + 4ll * (qw0 + S) <= lhi;      // neither of the list's partial end quads
+        }
+        if (inside) {
+          const int4* src = reinterpret_cast<const int4*>(entB + ebase) + q0;
+          int4 v[Q];
+          KK_UNROLL
+          for (int uu = 0; uu < Q; ++uu) v[uu] = src[uu];
+          KK_UNROLL
+          for (int uu = 0; uu < Q; ++uu) { mark(v[uu].x); mark(v[uu].y); mark(v[uu].z); mark(v[uu].w); }
+        } else {
+          long long at[Q];
+          int elo[Q], ehi[Q];
+          int4 v[Q];
+          KK_UNROLL
+          for (int uu = 0; uu < Q; ++uu) { at[uu] = 0; elo[uu] = 0; ehi[uu] = 0; }
+          if (q0 <= qw1) {
+            int sg = seg, len = seg_hi - seg + 1;                        // the lane's first quad: a search inside the step's lists
+            while (len > 1) { const int half = len >> 1; sg += (sc.pre[sg + half] <= q0) ? half : 0; len -= half; }
+            int pre_next = sc.pre[sg + 1];
+            long long sb0 = sc.lo[sg], sb1 = sc.hi[sg];
+            long long qbase = ((sb0 >> 2) - (long long)sc.pre[sg]) << 2;
+            KK_UNROLL
+            for (int uu = 0; uu < Q; ++uu) {
+              const int q = q0 + uu;
+              if (q <= qw1) {
+                if (q >= pre_next) {
+                  do { ++sg; pre_next = sc.pre[sg + 1]; } while (q >= pre_next);   // steps over lists without quads; q < tot = pre[n] ends it
+                  sb0 = sc.lo[sg]; sb1 = sc.hi[sg]; qbase = ((sb0 >> 2) - (long long)sc.pre[sg]) << 2;
+                }
+                at[uu] = qbase + ((long long)q << 2);
+                elo[uu] = sb0 > at[uu] ? (int)(sb0 - at[uu]) : 0;
+                ehi[uu] = sb1 < at[uu] + 4 ? (int)(sb1 - at[uu]) : 4;
+              }
+            }
+          }
+          KK_UNROLL
+          for (int uu = 0; uu < Q; ++uu) v[uu] = *reinterpret_cast<const int4*>(entB + (at[uu] <= last_full ? at[uu] : last_full));
+#ifndef KK_EMU
+          KK_UNROLL
+          for (int uu = 0; uu < Q; ++uu) asm volatile("" : "+v"(v[uu].x), "+v"(v[uu].y), "+v"(v[uu].z), "+v"(v[uu].w));     // the quads stay whole (see flat_columns_quads)
+#endif
+          KK_UNROLL
+          for (int uu = 0; uu < Q; ++uu) {
+            const bool past = at[uu] > last_full;                        // the array's last, partial quad
+            const int col[4] = {past ? tail[0] : v[uu].x, past ? tail[1] : v[uu].y, past ? tail[2] : v[uu].z, v[uu].w};
+            KK_UNROLL
+            for (int e = 0; e < 4; ++e) if (e >= elo[uu] && e < ehi[uu]) mark(col[e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  // count: every wave owns a contiguous range of the words and reads it 64 words at a time, lane l the l-th (8-byte reads at consecutive
+  // addresses); the words stay in registers for what follows
+  const int wpw = ((nwords + NW - 1) / NW + 63) & ~63;
+  const int w0 = wave * wpw, w1 = (w0 + wpw < nwords) ? w0 + wpw : nwords;
+  kk_u64 wd[NB];
+  int wsum = 0;
+  KK_UNROLL
+  for (int i = 0; i < NB; ++i) { const int idx = w0 + i * 64 + lane; wd[i] = (i * 64 < wpw && idx < w1) ? bm[idx] : 0ull; wsum += __popcll(wd[i]); }
+  wsum = wave_sum_i32(wsum, lane);
+  if (lane == 0) sc.wave32[wave] = wsum;
+  __syncthreads();
+  int tot = 0, before = 0;
+  for (int i = 0; i < NW; ++i) { const int sv = sc.wave32[i]; if (i < wave) before += sv; tot += sv; }
+  if (t == 0) { ucnt[u] = (unsigned)tot; if (tot) unit_count_add<OffT>(counts + hd.row, tot); }
+  if (tot == 0 || hd.store_off < 0 || KK_DBG(4)) return;                  // (uniform)
+  if (hd.kind == 1) {
+    kk_u64* dst = reinterpret_cast<kk_u64*>(store + hd.store_off);
+    KK_UNROLL
+    for (int i = 0; i < NB; ++i) { const int idx = w0 + i * 64 + lane; if (i * 64 < wpw && idx < w1) dst[idx] = wd[i]; }
+  } else {
+    // the unit's entries in ascending order: a wave takes its words 64 at a time (lane l the l-th), a prefix sum of the popcounts on the
+    // vector unit places every word's bits, rounds without a set bit are skipped
+    int32_t* dst = reinterpret_cast<int32_t*>(store + hd.store_off);
+    int run = before;
+    KK_UNROLL
+    for (int i = 0; i < NB; ++i) {
+      if (i * 64 >= wpw) break;                                          // uniform
+      const kk_u64 v = wd[i];
+      if (__ballot(v != 0ull) == 0ull) continue;                         // uniform
+      const int pc = __popcll(v);
+      const int inc = wave_inclusive_scan_i32(pc, lane);
+      int pos = run + inc - pc;
+      unsigned lo32 = (unsigned)v, hi32 = (unsigned)(v >> 32);
+      const int cbase = (int)(c0 + (int64_t)(w0 + i * 64 + lane) * 64);
+      if (!KK_DBG(1)) {
+        while (lo32) { dst[pos++] = cbase + (__ffs((int)lo32) - 1); lo32 &= lo32 - 1u; }
+        while (hi32) { dst[pos++] = cbase + 32 + (__ffs((int)hi32) - 1); hi32 &= hi32 - 1u; }
+      }
+      run += wave_last_lane_i32(inc);
+    }
+  }
+}
+
+// entries(C) of a unit whose structure the symbolic phase kept (first numeric call): a copy of its list, or the set bits of its bitmap in
+// ascending order through wave-private LDS (whole-line stores, emit_bits_by_wave_staged).  Units of rows the numeric phase does not
+// treat as dense (at most min_nnz entries: their hash kernels write entries and values together) and of rows with a unit that kept
+// nothing (unit_row < 0: the row walks its products, spgemm_dense_cols_kernel<EMIT>) return at once.
+template <class OffT, int NT>
+__global__ __launch_bounds__(NT) void spgemm_emit_unit_kernel(const UnitHead* __restrict__ heads, const int32_t* __restrict__ unit_row, int nwin, int wb, int64_t k,
+                                                              const unsigned* __restrict__ ucnt, const unsigned* __restrict__ ucoff, const char* __restrict__ store,
+                                                              const OffT* __restrict__ rmC, int32_t* __restrict__ entC, int64_t min_nnz) {
+  __shared__ int s_wave[NT / 64];
+  __shared__ int32_t s_stage[NT / 64][1024];
+  const UnitHead hd = heads[blockIdx.x];
+  const unsigned u = (unsigned)hd.unit;
+  const unsigned cnt = ucnt[u];
+  const unsigned coff = ucoff[u];
+  const int32_t ur = unit_row[hd.row];
+  const int64_t rbeg = (int64_t)rmC[hd.row], rend = (int64_t)rmC[hd.row + 1];
+  if (cnt == 0 || ur < 0 || hd.store_off < 0 || rend - rbeg <= min_nnz) return;
+  const int64_t base = rbeg + coff;
+  if (hd.kind == 0) {
+    const int32_t* src = reinterpret_cast<const int32_t*>(store + hd.store_off);
+    for (unsigned i = threadIdx.x; i < cnt; i += NT) entC[base + i] = src[i];
+  } else {
+    const unsigned w = u % (unsigned)nwin;
+    const int64_t c0 = (int64_t)w << wb;
+    const int nbits = (int)(k - c0 < ((int64_t)1 << wb) ? k - c0 : ((int64_t)1 << wb));
+    (void)emit_bits_by_wave_staged<NT>(reinterpret_cast<const kk_u64*>(store + hd.store_off), (nbits + 63) >> 6, c0, base, entC, s_wave, s_stage[threadIdx.x >> 6]);
+  }
+}
+// rows of the class whose every unit with entries left its structure: unit_row[row] = rank of the row in the class's list (bit 30: at least one of
+// its units left an entry list, not a bitmap); ucoff[unit] = entries of the row's units before it; count[0] = those rows.  unit_row is preset to -1.
+__global__ __launch_bounds__(kBlock) void spgemm_unit_rows_kernel(int64_t nrows, const int32_t* __restrict__ perm, int nwin, const unsigned* __restrict__ ucnt,
+                                                                 const long long* __restrict__ uoff, unsigned* __restrict__ ucoff, int32_t* __restrict__ unit_row,
+                                                                 unsigned long long* __restrict__ count) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool ok = r < nrows, lists = false;
+  if (ok) {
+    bool any = false;
+    unsigned run = 0;
+    for (int w = 0; w < nwin; ++w) {
+      const unsigned c = ucnt[r * nwin + w];
+      const long long o = uoff[r * nwin + w];
+      ucoff[r * nwin + w] = run; run += c;
+      if (c) { any = true; if (o < 0) ok = false; else if ((o & 1) == 0) lists = true; }
+    }
+    ok = ok && any;
+    if (ok) unit_row[perm[r]] = (int32_t)r | (lists ? (1 << 30) : 0);
+  }
+  const kk_u64 mk = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && mk) atomicAdd(count, (unsigned long long)__popcll(mk));
+}
+__global__ __launch_bounds__(kBlock) void spgemm_count_flag_kernel(int64_t n, const int32_t* __restrict__ list, const int32_t* __restrict__ unit_row, unsigned long long* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool q = i < n && (unit_row[list[i]] & (1 << 30)) != 0 && unit_row[list[i]] >= 0;
+  const kk_u64 mk = __ballot(q);
+  if ((threadIdx.x & 63) == 0 && mk) atomicAdd(count, (unsigned long long)__popcll(mk));
+}
+
 // entries(C) of a row with FEW PRODUCTS (at most kEmitSortCap, known from the symbolic phase's row flops) but more entries than the
 // wave kernel's table holds: the products' columns are laid down in LDS, sorted by a bitonic network and written without their
 // duplicates -- 256 work-items and 11 KB of LDS per row, so that eight rows share a CU.  The bitmap kernel gives every such row a
@@ -2724,6 +3089,12 @@ struct kkamd_spgemm_handle {
   unsigned* d_cidx = nullptr; bool cidx_ready = false;
   kk::ItemHead* d_items_rank = nullptr; kk::ItemHead* d_items_direct = nullptr; int64_t n_items_rank = 0, n_items_direct = 0; bool items_ready = false;
   int idx_nblk = 0, idx_wshift = 0, items_cap = 0, items_blocks = 0;      // what the two indices / the items were built for (the knobs are process-wide and may change between calls)
+  // the dense class by units (spgemm_sym_unit_kernel): the class's rows in the order the units were numbered, entries and store offset of every unit;
+  // d_row_slot holds unit_row (rank of a row whose units all kept their structure, or -1)
+  bool unit_mode = false; int unit_nwin = 0, unit_wb = 0; int64_t unit_rows = 0, unit_rows_kept = 0, unit_bitmaps = 0;
+  int64_t last_units = 0, last_unit_bitmaps = 0, last_unit_rows_kept = 0;      // of the last symbolic phase (kkamd_spgemm_get 19 - 21; they outlive the store)
+  int32_t* d_unit_perm = nullptr; unsigned* d_ucnt = nullptr; unsigned* d_ucoff = nullptr; long long* d_uoff = nullptr;
+  kk::UnitHead* d_heads = nullptr; int64_t n_heads = 0;       // the units with products, in launch order
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -2834,6 +3205,13 @@ static void free_bitmap_store(kkamd_spgemm_handle* h) {
     else (void)hipFree(h->d_bm_store);
   }
   h->bm_pooled = false;
+  if (h->d_unit_perm) (void)hipFree(h->d_unit_perm);
+  if (h->d_ucnt) (void)hipFree(h->d_ucnt);
+  if (h->d_ucoff) (void)hipFree(h->d_ucoff);
+  if (h->d_uoff) (void)hipFree(h->d_uoff);
+  if (h->d_heads) (void)hipFree(h->d_heads);
+  h->d_unit_perm = nullptr; h->d_ucnt = nullptr; h->d_ucoff = nullptr; h->d_uoff = nullptr; h->d_heads = nullptr; h->n_heads = 0;
+  h->unit_mode = false; h->unit_rows = 0; h->unit_rows_kept = 0; h->unit_bitmaps = 0;
   if (h->d_row_slot) (void)hipFree(h->d_row_slot);
   if (h->d_bm_counter) (void)hipFree(h->d_bm_counter);
   if (h->d_emit_perm) (void)hipFree(h->d_emit_perm);
@@ -2881,6 +3259,126 @@ static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hi
   KK_LAUNCH(spgemm_size_scan_kernel, 1, kSizeClasses, 0, st, d_hist);
   KK_LAUNCH(spgemm_size_scatter_kernel, grid, kBlock, 0, st, n, (const int32_t*)d_tmp, sizes, d_hist, list);
   KK_HIP(hipStreamSynchronize(st));          // the scratch buffers go out of scope
+  return KKAMD_OK;
+}
+
+// The dense class of the symbolic phase by units (spgemm_sym_unit_kernel).  *ran = false: the prerequisites do not hold (B with unsorted
+// rows under more than one window, entries(B) not 16-byte aligned, fewer than four entries, more units than a grid holds, no memory
+// for the indices) and the caller takes the one-workgroup-per-row kernel.
+template <class OffT>
+static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* list, int64_t m, int64_t n, int64_t k, const OffT* rmA, const int32_t* entA,
+                          const OffT* rmB, const int32_t* entB, int64_t nnzB, OffT* rmC, hipStream_t st, bool* ran) {
+  *ran = false;
+  int wb = g_spgemm.unit_bits;
+  if (wb > kUnitBitsMax) wb = kUnitBitsMax;
+  if (wb < 6) wb = 6;
+  const int nt = wb <= 18 ? 256 : (wb == 19 ? 512 : 1024);
+  const int64_t nwin64 = ceil_div(k, (int64_t)1 << wb);
+  const int64_t nnzA = h->nnzA;
+  if (!g_spgemm.sym_units || nnzB < 4 || ((uintptr_t)entB % 16) != 0 || nrows <= 0 || nrows >= ((int64_t)1 << 30)) return KKAMD_OK;
+  if (nwin64 > 1 && !h->b_sorted) return KKAMD_OK;
+  if (nwin64 > 4096 || nrows * nwin64 >= ((int64_t)1 << 31)) return KKAMD_OK;
+  const int nwin = (int)nwin64;
+  const int64_t units = nrows * nwin;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
+  size_t pooled = 0;                                       // what the pool holds is not "used" memory -- when it is free and on this device
+  { BmPool& pool = bm_pool(); std::lock_guard<std::mutex> g(pool.m); int dev_ = -1;
+    if (!pool.in_use && pool.p && hipGetDevice(&dev_) == hipSuccess && dev_ == pool.device) pooled = pool.bytes; }
+  const size_t widx_bytes = nwin > 1 ? sizeof(unsigned) * (size_t)(nwin + 1) * (size_t)n : 0;
+  const size_t aw_bytes = sizeof(long long) * (size_t)(nwin + 1) * (size_t)nnzA;
+  const size_t unit_bytes = (size_t)units * (8 + 4 + 4 + 8 + 4 + 8 + 32) + (size_t)nrows * 4 + (size_t)m * 4;
+  if (widx_bytes + aw_bytes + unit_bytes > (free_b + pooled) / 8) return KKAMD_OK;
+  free_bitmap_store(h);
+  // temporaries of this phase (free themselves): the two indices, products and launch order of the units; kept for the numeric phase: heads, counts, offsets
+  DevBuf widx_b, aw_b, uprod_b, ulist_b, soff_b, cnt_b;
+  if (aw_b.alloc(aw_bytes) != hipSuccess || uprod_b.alloc(sizeof(long long) * (size_t)units) != hipSuccess || ulist_b.alloc(sizeof(int32_t) * (size_t)units) != hipSuccess ||
+      cnt_b.alloc(8 * sizeof(unsigned long long)) != hipSuccess || (widx_bytes && widx_b.alloc(widx_bytes) != hipSuccess) ||
+      hipMalloc((void**)&h->d_unit_perm, sizeof(int32_t) * (size_t)nrows) != hipSuccess || hipMalloc((void**)&h->d_ucnt, sizeof(unsigned) * (size_t)units) != hipSuccess ||
+      hipMalloc((void**)&h->d_ucoff, sizeof(unsigned) * (size_t)units) != hipSuccess || hipMalloc((void**)&h->d_uoff, sizeof(long long) * (size_t)units) != hipSuccess ||
+      hipMalloc((void**)&h->d_row_slot, sizeof(int32_t) * (size_t)m) != hipSuccess) {
+    (void)hipGetLastError(); free_bitmap_store(h); return KKAMD_OK;
+  }
+  unsigned* d_wx = widx_b.as<unsigned>(); long long* d_aw = aw_b.as<long long>(); long long* d_up = uprod_b.as<long long>(); int32_t* d_ul = ulist_b.as<int32_t>();
+  unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
+  KK_HIP(hipMemcpyAsync(h->d_unit_perm, list, sizeof(int32_t) * (size_t)nrows, hipMemcpyDeviceToDevice, st));     // the numeric phase bins the rows again in d_perm
+  KK_HIP(hipMemsetAsync(h->d_uoff, 0xFF, sizeof(long long) * (size_t)units, st));
+  KK_HIP(hipMemsetAsync(h->d_ucnt, 0, sizeof(unsigned) * (size_t)units, st));
+  KK_HIP(hipMemsetAsync(h->d_row_slot, 0xFF, sizeof(int32_t) * (size_t)m, st));
+  KK_HIP(hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), st));
+  const int32_t* d_perm_u = h->d_unit_perm;
+  if (nwin > 1) KK_LAUNCH((spgemm_bidx_kernel<OffT>), (unsigned)ceil_div((int64_t)(nwin + 1) * n, kBlock), kBlock, 0, st, n, nwin, wb, rmB, entB, d_wx);
+  KK_LAUNCH((spgemm_aw_kernel<OffT>), (unsigned)ceil_div(nnzA, kBlock), kBlock, 0, st, nnzA, entA, rmB, n, nwin, (const unsigned*)d_wx, d_aw);
+  KK_LAUNCH((spgemm_uprod_kernel<OffT>), (unsigned)ceil_div(nrows, kBlock / 64), kBlock, 0, st, nrows, d_perm_u, rmA, nnzA, nwin, (const long long*)d_aw, d_up);
+  KK_LAUNCH(spgemm_unit_compact_kernel, (unsigned)ceil_div(units, kBlock), kBlock, 0, st, units, (const long long*)d_up, d_ul, d_cnt);
+  unsigned long long h_n = 0;
+  KK_HIP(hipMemcpyAsync(&h_n, d_cnt, sizeof h_n, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));
+  const int64_t nu = (int64_t)h_n;                           // units with products
+  h->unit_mode = true; h->unit_nwin = nwin; h->unit_wb = wb; h->unit_rows = nrows; h->n_heads = nu;
+  h->last_units = nu;
+  if (nu == 0) { *ran = true; return KKAMD_OK; }
+  int rc;
+  if ((rc = order_list_by_size(d_ul, nu, (const int64_t*)d_up, st))) return rc;               // heaviest units first
+  // where every unit's structure goes: a prefix sum over min(4 products, bitmap bytes); the store is at most 0.225 of the free HBM (an eighth
+  // for bitmaps and a tenth for lists until round 5), units past it keep nothing (the lightest: they come last) and their rows walk
+  // their products again in the numeric phase
+  const int64_t win_cols = nwin > 1 ? ((int64_t)1 << wb) : k;
+  const int words = (int)ceil_div(win_cols, (int64_t)64);
+  const int bm_words = (words + 15) & ~15;
+  const long long bm_bytes = (long long)words * 8;
+  long long budget = 0, total_need = 0;
+  KK_HIP(soff_b.alloc(sizeof(long long) * (size_t)(nu + 1)));
+  long long* d_so = soff_b.as<long long>();
+  if (hipMalloc((void**)&h->d_heads, sizeof(UnitHead) * (size_t)nu) != hipSuccess) { (void)hipGetLastError(); free_bitmap_store(h); return KKAMD_OK; }
+  KK_LAUNCH(spgemm_unit_ssize_kernel, (unsigned)ceil_div(nu + 1, kBlock), kBlock, 0, st, nu, (const int32_t*)d_ul, (const long long*)d_up, bm_bytes, d_so);
+  if ((rc = exclusive_scan_inplace<long long>(d_so, nu + 1, st))) return rc;
+  if (g_spgemm.keep_bitmaps && k >= 64) {
+    KK_HIP(hipMemcpyAsync(&total_need, d_so + nu, sizeof(long long), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    size_t want = (size_t)((double)(free_b + pooled) * 0.225);
+    if ((long long)want > total_need) want = (size_t)total_need;
+    want = (want + 255) & ~(size_t)255;
+    const size_t got = want ? take_bitmap_store(h, want) : 0;
+    budget = (long long)got;
+  }
+  UnitHead* d_hd = h->d_heads;
+  KK_LAUNCH((spgemm_unit_heads_kernel<OffT>), (unsigned)ceil_div(nu, kBlock), kBlock, 0, st, nu, (const int32_t*)d_ul, (const long long*)d_up, (const long long*)d_so,
+            bm_bytes, budget, g_spgemm.keep_lists, nwin, d_perm_u, rmA, d_hd, h->d_uoff, d_cnt + 1);
+  char* d_store = (char*)h->d_bm_store;
+  unsigned* d_uc = h->d_ucnt;
+#ifndef KK_EMU
+#define KK_UNIT_ATTR(NTT) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_sym_unit_kernel<OffT, NTT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)bm_words * 8 + sizeof(UnitScratch<NTT>))))
+#else
+#define KK_UNIT_ATTR(NTT) (void)0
+#endif
+#define KK_UNIT(NTT)                                                                                                                                        \
+  do {                                                                                                                                                      \
+    KK_UNIT_ATTR(NTT);                                                                                                                                      \
+    KK_LAUNCH((spgemm_sym_unit_kernel<OffT, NTT, 4>), (unsigned)nu, NTT, (size_t)bm_words * 8 + sizeof(UnitScratch<NTT>), st, (const UnitHead*)d_hd, nwin, wb, k, nnzA, \
+              (const long long*)d_aw, entB, nnzB, rmC, d_uc, d_store, bm_words KK_DBG_ARG);                                                                 \
+  } while (0)
+  if (nt == 256) KK_UNIT(256); else if (nt == 512) KK_UNIT(512); else KK_UNIT(1024);
+#undef KK_UNIT
+#undef KK_UNIT_ATTR
+  {
+    const long long* d_uo = h->d_uoff; unsigned* d_co = h->d_ucoff; int32_t* d_ur = h->d_row_slot;
+    KK_LAUNCH(spgemm_unit_rows_kernel, (unsigned)ceil_div(nrows, kBlock), kBlock, 0, st, nrows, d_perm_u, nwin, (const unsigned*)d_uc, d_uo, d_co, d_ur, d_cnt + 4);
+  }
+  unsigned long long h_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  KK_HIP(hipMemcpyAsync(h_c, d_cnt, sizeof h_c, hipMemcpyDeviceToHost, st));
+  KK_HIP(hipStreamSynchronize(st));                              // (also: the temporaries go out of scope)
+  h->unit_bitmaps = (int64_t)h_c[1]; h->pool_used = (int64_t)h_c[2]; h->unit_rows_kept = (int64_t)h_c[4];
+  h->bm_words = words;
+  h->last_unit_bitmaps = h->unit_bitmaps; h->last_unit_rows_kept = h->unit_rows_kept;
+  h->bm_stored = h->unit_rows_kept;                              // kkamd_spgemm_get 13: rows whose structure the symbolic phase holds
+  if (h->verbose)
+    KK_VERBOSE("\tkkamd spgemm symbolic: dense class by units: %lld rows x %d windows of 2^%d columns = %lld units with products; kept for the numeric phase: %lld unit bitmaps, "
+               "%.1f MB of structure in all (%.1f MB wanted, %lld units without room), %lld rows complete\n",
+               (long long)nrows, nwin, wb, (long long)nu, (long long)h->unit_bitmaps, 1e-6 * (double)h->pool_used, 1e-6 * (double)total_need, (long long)h_c[3], (long long)h->unit_rows_kept);
+  if (h->unit_rows_kept == 0) free_bitmap_store(h);              // nothing to hand over: the store and the unit arrays go back at once
+  *ran = true;
   return KKAMD_OK;
 }
 
@@ -3009,6 +3507,10 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
       // window covers the columns and an eighth of the free HBM holds them: R-MAT scale 20, 87 K rows (83 % of the products), 11 GB
       BitmapStore bs;
       free_bitmap_store(h);
+      bool by_units = false;
+      if ((rc = symbolic_units<OffT>(h, nb(4), h->d_perm + off.off[4], m, n, k, rmA, entA, rmB, entB, nnzB, rmC, st, &by_units))) return rc;
+      if (by_units) {}
+      else {
       if (g_spgemm.keep_bitmaps && k <= (int64_t)g_spgemm.win_bits && k >= 4096) {
         size_t free_b = 0, total_b = 0;
         const int words = (int)ceil_div(k, (int64_t)64);
@@ -3068,6 +3570,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
         if (h->verbose && bs.pool) KK_VERBOSE("\tkkamd spgemm symbolic: entry lists kept for the numeric phase: %.1f of %.1f MB\n", 4e-6 * (double)h->pool_used, 4e-6 * (double)h->pool_cap);
         if (h->bm_stored == 0 && h->pool_used == 0) free_bitmap_store(h);
         if (h->verbose) KK_VERBOSE("\tkkamd spgemm symbolic: bitmaps of %lld rows kept for the numeric phase (%.1f MB)\n", (long long)h->bm_stored, (double)h->bm_stored * words_mb(h->bm_words));
+      }
       }
     }
   }
@@ -3265,6 +3768,33 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     const int32_t* dperm = h->d_perm + off.off[4];
     // entries(C) of every dense row, column-sorted
     if (keep_entries) h->entries_reused = true;
+    else if (h->unit_mode && h->unit_rows_kept > 0 && h->algorithm == 0) {
+      // the symbolic phase's units: rows whose every unit kept its structure are written unit by unit (bitmaps, entry lists); the others walk their products
+      if (!h->d_emit_perm) {
+        DevBuf c2;
+        KK_HIP(c2.alloc(3 * sizeof(unsigned long long)));
+        KK_HIP(hipMemsetAsync(c2.p, 0, 3 * sizeof(unsigned long long), st));
+        KK_HIP(hipMalloc((void**)&h->d_emit_perm, sizeof(int32_t) * (size_t)nb(4)));
+        int32_t* d_ep = h->d_emit_perm; const int32_t* d_rs = h->d_row_slot; unsigned long long* d_c2 = c2.as<unsigned long long>();
+        KK_LAUNCH((spgemm_split_stored_kernel<int32_t>), (unsigned)ceil_div(nb(4), kBlock), kBlock, 0, st, nb(4), dperm, d_rs, d_ep, d_c2);
+        KK_LAUNCH(spgemm_count_flag_kernel, (unsigned)ceil_div(nb(4), kBlock), kBlock, 0, st, nb(4), dperm, d_rs, d_c2 + 2);
+        unsigned long long h_c2[3] = {0, 0, 0};
+        KK_HIP(hipMemcpyAsync(h_c2, c2.p, sizeof h_c2, hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+        h->n_emit_stored = (int64_t)h_c2[0]; h->n_emit_pooled = (int64_t)h_c2[2];
+      }
+      const int64_t ns = h->n_emit_stored, nr = nb(4) - ns;
+      if (ns && h->n_heads) {
+        const UnitHead* d_hd = h->d_heads; const int32_t* d_ur = h->d_row_slot; const unsigned* d_uc = h->d_ucnt; const unsigned* d_co = h->d_ucoff;
+        const char* d_st = (const char*)h->d_bm_store;
+        const int64_t min_nnz = (h->dense_lds ? kNumLimitsSorted : kNumLimits).lim[3];
+#define KK_EMIT_UNIT(NTT) KK_LAUNCH((spgemm_emit_unit_kernel<OffT, NTT>), (unsigned)h->n_heads, NTT, 0, st, d_hd, d_ur, h->unit_nwin, h->unit_wb, k, d_uc, d_co, d_st, rmC, entC, min_nnz)
+        if (h->unit_wb <= 18) KK_EMIT_UNIT(256); else if (h->unit_wb == 19) KK_EMIT_UNIT(512); else KK_EMIT_UNIT(1024);
+#undef KK_EMIT_UNIT
+      }
+      if (nr && (rc = emit_walk(nr, h->d_emit_perm + ns, (int64_t)g_spgemm.emit_win_bits))) return rc;
+      h->bitmaps_used = ns; h->pooled_used = h->n_emit_pooled;
+    }
     else if (h->d_bm_store && (h->bm_stored > 0 || h->pool_used > 0) && h->algorithm == 0) {
       // rows whose bitmap the symbolic phase kept are written from it; the others walk their products
       if (!h->d_emit_perm) {
@@ -3564,7 +4094,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
   hipError_t e2 = hipStreamSynchronize(st);   // the reference's numeric phase fences too (impl_kkmem.hpp:1440,1467)
   if (e != hipSuccess || e2 != hipSuccess) { h->entries_valid = false; return fail(KKAMD_ERR_HIP, "spgemm numeric failed: %s", hipGetErrorString(e != hipSuccess ? e : e2)); }
   h->entries_valid = true; h->entC_ptr = entC; h->rmC_ptr = rmC_;
-  if (h->d_bm_store) { const int64_t used = h->bitmaps_used; free_bitmap_store(h); h->bitmaps_used = used; }    // entries(C) are written: the bitmaps (GBs) are not needed again
+  if (h->d_bm_store || h->unit_mode) { const int64_t used = h->bitmaps_used; free_bitmap_store(h); h->bitmaps_used = used; }    // entries(C) are written: the bitmaps (GBs) are not needed again
   return KKAMD_OK;
 }
 
@@ -3602,6 +4132,8 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_emit_sort") g_spgemm.emit_sort = value != 0;
   else if (k == "spgemm_pool_keep") { if (value < 0 || value > 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_pool_keep: 0 (first product returns the store, repeat users keep it), 1 (keep) or 2 (return)"); g_spgemm.pool_keep = value; }
   else if (k == "spgemm_sort_rows") g_spgemm.sort_rows = value != 0;
+  else if (k == "spgemm_sym_units") g_spgemm.sym_units = value != 0;
+  else if (k == "spgemm_unit_bits") { if (value < 6 || value > kUnitBitsMax) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_unit_bits: 6 .. %d", kUnitBitsMax); g_spgemm.unit_bits = value; }
   else if (k == "spgemm_nt") g_spgemm.nt = value != 0;
   else if (k == "spgemm_list_staged") g_spgemm.list_staged = value != 0;
   else if (k == "spgemm_block") g_spgemm.block = value != 0;
@@ -3683,7 +4215,7 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
   h->symbolic_called = false; h->numeric_called = false; h->numeric_bins_ready = false; h->entries_valid = false;
   if (h->d_bidx) { (void)hipFree(h->d_bidx); h->d_bidx = nullptr; }     // a new symbolic phase may bring another B in the same arrays
   h->cidx_ready = false; h->items_ready = false; h->n_dense_block = 0;
-  kk::free_bitmap_store(h); h->bitmaps_used = 0;
+  kk::free_bitmap_store(h); h->bitmaps_used = 0; h->last_units = 0; h->last_unit_bitmaps = 0; h->last_unit_rows_kept = 0;
   h->c_nnz = 0; h->mults = 0; h->max_row_flops = 0; h->max_row_nnz = 0;
   // empty product: zero row_map (:100-107; the rocSPARSE wrapper memsets too)
   int64_t nnzA = 0, nnzB = 0;
@@ -3840,6 +4372,9 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 14: *value = h->pooled_used; break;
     case 15: *value = h->sorted_used; break;
     case 16: *value = h->n_dense_block; break;
+    case 19: *value = h->last_units; break;           // units (row, window) of the last symbolic phase's dense class (0: the class was empty or went row by row)
+    case 20: *value = h->last_unit_bitmaps; break;    // ... of which kept their bitmap for the numeric phase
+    case 21: *value = h->last_unit_rows_kept; break;  // rows of the class whose every unit kept its structure
     case 17: *value = h->n_items_rank; break;        // ... of which as position-indexed items / column-indexed blocks
     case 18: *value = h->n_items_direct; break;       // rows of the last numeric call's bins that take the column-block value kernel
     default: return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_get: unknown query %d", what);

@@ -514,6 +514,72 @@ def check_spgemm_kept_structure(be):
             kk._capi.check(be.lib, be.lib.kkamd_set_default(b"spgemm_keep_lists", 1))
 
 
+def check_spgemm_units(be, light=False):
+    """Round 6: the symbolic phase counts its dense class by UNITS (row of C, window of 2^unit_bits columns; an index of B at window
+    granularity cuts every list).  Windows of 64 .. 2^18 columns over products whose rows are sparse, dense, a single list, hundreds of
+    lists (several chunks of 256), lists shorter than a quad, empty pieces in most windows; 32- and 64-bit offsets; with the bitmaps,
+    the lists or both switched off; against the one-workgroup-per-row kernel (spgemm_sym_units 0).  Structure identical to the oracle's
+    every time (check_spgemm), and the queries say the units were used."""
+    import fuzz_cases as fz
+    rng = np.random.default_rng(61)
+    setd = lambda key, v: kk._capi.check(be.lib, be.lib.kkamd_set_default(key, v))
+    # (a) hub lists next to short ones, k not a multiple of any window; (b) dense rows; (c) an A row of 700 lists (three chunks), B rows of 0 .. 30 entries
+    n, k = 60, 100003
+    B = fz.hubby(rng, n, k, 2500, 0, 2500)
+    A = fz.hubby(rng, 10, n, 3, 2, 20)
+    kd = 8192
+    lens = rng.integers(1500, 6000, size=30)
+    rmd = np.zeros(31, dtype=np.int64); np.cumsum(lens, out=rmd[1:])
+    Bd = oracle.Crs(30, kd, rmd, np.concatenate([np.sort(rng.choice(kd, size=l, replace=False)) for l in lens]).astype(np.int32), 1 + 49 * rng.random(rmd[-1]))
+    rows_d = [np.sort(rng.choice(30, size=c, replace=False)) for c in (1, 2, 3, 6, 12, 30)]
+    armd = np.zeros(len(rows_d) + 1, dtype=np.int64); np.cumsum([len(r) for r in rows_d], out=armd[1:])
+    Ad = oracle.Crs(len(rows_d), 30, armd, np.concatenate(rows_d).astype(np.int32), 1 + 49 * rng.random(armd[-1]))
+    Bs = randomized(oracle.random_crs(900, 30000, 14, variance=14, seed=23, sorted_rows=True))
+    cols = np.sort(rng.choice(900, size=700, replace=False)).astype(np.int32)
+    As = oracle.Crs(3, 900, np.array([0, 700, 703, 1100]), np.concatenate([cols, [1, 5, 9], np.sort(rng.choice(900, size=397, replace=False))]).astype(np.int32), 1 + 49 * rng.random(1100))
+    cases = [(A, B, "hubs"), (Ad, Bd, "dense"), (As, Bs, "many short lists")]
+    try:
+        for bits in ((6, 12, 18) if light else (6, 9, 12, 15, 18)):
+            setd(b"spgemm_unit_bits", bits)
+            for A0, B0, name in cases:
+                if bits == 6 and name == "hubs" : continue               # 1563 windows x 10 rows of one word each: slow under the emulator, nothing new
+                for odt in (np.int32, np.int64):
+                    got = check_spgemm(be, A0, B0, offset_dtype=odt, reuse=(bits == 12))
+                kh = kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+                Am, Bm = dev(be, A0), dev(be, B0)
+                Cm = kk.spgemm_symbolic(kh, Am, False, Bm, False)
+                sh = kh.get_spgemm_handle()
+                nwin = -(-B0.ncols // (1 << bits))
+                assert sh.get(19) > 0 and sh.get(19) % nwin == 0, (name, bits, sh.get(19), nwin)          # class rows x windows
+                assert sh.get(21) > 0 and sh.get(13) == sh.get(21), (name, bits, sh.get(21), sh.get(13))
+                if name == "dense" and bits >= 9: assert sh.get(20) > 0, (bits, sh.get(20))               # units at least 1/32 dense keep bitmaps
+                kk.spgemm_numeric(kh, Am, False, Bm, False, Cm)
+                assert sh.get(12) > 0 and sh.get(13) == 0, (name, bits, sh.get(12), sh.get(13))
+                kh.destroy_spgemm_handle()
+        setd(b"spgemm_unit_bits", 10)
+        for bm, ls in ((0, 1), (1, 0), (0, 0)):
+            setd(b"spgemm_keep_bitmaps", bm); setd(b"spgemm_keep_lists", ls)
+            for A0, B0, name in cases:
+                check_spgemm(be, A0, B0, offset_dtype=np.int64, reuse=False)
+        setd(b"spgemm_keep_bitmaps", 1); setd(b"spgemm_keep_lists", 1)
+        setd(b"spgemm_sym_units", 0)                                      # the row-by-row kernel is still there (B with unsorted rows under several windows takes it)
+        for A0, B0, name in cases:
+            check_spgemm(be, A0, B0, reuse=False)
+        setd(b"spgemm_sym_units", 1)
+        # B with unsorted rows: one window -> units without an index; several windows -> row by row
+        ent, val = B.entries.copy(), B.values.copy()
+        for i in range(B.nrows):
+            lo, hi = B.row_map[i], B.row_map[i + 1]
+            q = rng.permutation(hi - lo)
+            ent[lo:hi], val[lo:hi] = ent[lo:hi][q], val[lo:hi][q]
+        Bu = oracle.Crs(B.nrows, B.ncols, B.row_map, ent, val)
+        for bits in (18, 12):
+            setd(b"spgemm_unit_bits", bits)
+            check_spgemm(be, A, Bu, reuse=False)
+    finally:
+        setd(b"spgemm_unit_bits", 18); setd(b"spgemm_keep_bitmaps", 1); setd(b"spgemm_keep_lists", 1); setd(b"spgemm_sym_units", 1)
+
+
 def check_spgemm_pool_release(be):
     """The process-wide store of bitmaps / entry lists (GBs on large products) goes back to the device when the LAST SpGEMM handle is
     destroyed (round-4 review: a plain C caller kept it for ever); with "spgemm_pool_keep" 1 it outlives the handles and

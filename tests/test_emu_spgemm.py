@@ -191,6 +191,10 @@ def test_spgemm_structure_kept_by_the_symbolic_phase(be):
     pc.check_spgemm_kept_structure(be)
 
 
+def test_spgemm_symbolic_by_units(be):
+    pc.check_spgemm_units(be, light=True)
+
+
 def test_spgemm_galerkin_products(be):
     pc.check_spgemm_galerkin(be)
 

@@ -583,6 +583,10 @@ def test_spgemm_structure_kept_by_the_symbolic_phase(be):
     pc.check_spgemm_kept_structure(be)
 
 
+def test_spgemm_symbolic_by_units(be):
+    pc.check_spgemm_units(be)
+
+
 def test_spgemm_pool_returns_with_the_last_handle(be):
     pc.check_spgemm_pool_release(be)
 
