@@ -56,11 +56,22 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(T* __restrict__ d, i
 }
 
 // in-place exclusive scan of d[0..n): d[i] := sum of the old d[0..i).
-template <class T> static int exclusive_scan_inplace(T* d, int64_t n, hipStream_t st) {
+// ws: optional workspace of at least scan_workspace_items(n) items -- the scan then allocates nothing, frees nothing (a hipFree waits for the
+// whole device) and does not synchronise the stream.
+inline int64_t scan_workspace_items(int64_t n) { int64_t tot = 0; while (n > kScanTile) { n = ceil_div(n, kScanTile); tot += n; } return tot + 1; }
+template <class T> static int exclusive_scan_inplace(T* d, int64_t n, hipStream_t st, T* ws = nullptr) {
   if (n <= 0) return KKAMD_OK;
   const int64_t nb = ceil_div(n, kScanTile);
   if (nb == 1) {
     KK_LAUNCH((scan_apply_kernel<T>), 1u, kBlock, 0, st, d, n, (const T*)nullptr);
+    KK_LAUNCH_CHECK();
+    return KKAMD_OK;
+  }
+  if (ws) {
+    KK_LAUNCH((scan_reduce_kernel<T>), (unsigned)nb, kBlock, 0, st, (const T*)d, n, ws);
+    const int rc = exclusive_scan_inplace<T>(ws, nb, st, ws + nb);
+    if (rc) return rc;
+    KK_LAUNCH((scan_apply_kernel<T>), (unsigned)nb, kBlock, 0, st, d, n, (const T*)ws);
     KK_LAUNCH_CHECK();
     return KKAMD_OK;
   }

@@ -36,6 +36,7 @@
 #include "kk_common.h"
 #include "kk_scan.h"
 #include <climits>
+#include <chrono>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -1321,6 +1322,9 @@ __global__ __launch_bounds__(kBlock) void spgemm_copy_pool_kernel(const int32_t*
 //     min(4 products, bitmap bytes)): no cursor, no atomics, nothing that can run full.  Per unit, so any k is covered (the per-row
 //     store of rounds 3 - 5 needed k <= 2^20).
 // counts[row] collects the units of a row by one integer atomic each (order-independent: the result is exact).
+#ifndef KK_UQ
+#define KK_UQ 4
+#endif
 constexpr int kUnitNT = 256;
 constexpr int kUnitBitsMax = 20;                                              // 2^18 columns = 32 KB of bitmap for 256 work-items; 2^19 / 2^20: workgroups of 512 / 1024
 __host__ __device__ constexpr int unit_bits_of(int nt) { return nt >= 1024 ? 20 : (nt >= 512 ? 19 : 18); }
@@ -1333,8 +1337,10 @@ struct alignas(16) UnitHead {
   int kind;                 // 1: the unit leaves its bitmap, 0: its entry list
 };
 template <int NT> struct UnitScratch {
-  int pre[NT + 2];                     // quad offset of every list piece of the chunk
-  long long lo[NT], hi[NT];            // the piece: entries [lo, hi) of entries(B)
+  int gpre[NT + 2];                    // offset of every list piece of the chunk in LANE-STEPS (4 aligned quads of one piece)
+  int nq[NT];                          // aligned quads the piece touches
+  int ends[NT];                        // entries of the piece's first quad before its start | (entries of its last quad that belong to it) << 4
+  long long fq[NT];                    // the piece's first quad: entries(B) index >> 2
   long long wave64[NT / 64];
   int wave32[NT / 64];
 };
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_unit_heads_kernel(int64_t n, co
 }
 
 template <class OffT, int NT, int Q>
-__global__ __launch_bounds__(NT) void spgemm_sym_unit_kernel(const UnitHead* __restrict__ heads, int nwin, int wb, int64_t k, int64_t nnzA, const long long* __restrict__ aw,
+__global__ __launch_bounds__(NT, 4) void spgemm_sym_unit_kernel(const UnitHead* __restrict__ heads, int nwin, int wb, int64_t k, int64_t nnzA, const long long* __restrict__ aw,
                                                              const int32_t* __restrict__ entB, int64_t nnzB, OffT* __restrict__ counts, unsigned* __restrict__ ucnt,
                                                              char* __restrict__ store, int bm_words KK_DBG_PARAM) {
   // dynamic LDS: the bitmap (bm_words 64-bit words, a multiple of 16) at offset 0 -- a bit's address is then two instructions from its column, with no
@@ -1451,6 +1457,9 @@ __global__ __launch_bounds__(NT) void spgemm_sym_unit_kernel(const UnitHead* __r
   const unsigned wordmask = (1u << (wb - 5)) - 1u;            // wb >= 6
   auto mark = [&](int cb) {                        // column -> bit of the window (the piece's columns are inside it): shift, mask, shift, ds_or
     if (!KK_DBG(256)) atomicOr(&bm32[((unsigned)cb >> 5) & wordmask], 1u << ((unsigned)cb & 31u));
+#if defined(KK_ABLATE) && !defined(KK_EMU)
+    else asm volatile("" :: "v"(cb));               // (measurement build: the column, and the load behind it, stay alive without the atomic)
+#endif
   };
   const int64_t a_beg = hd.a_beg, a_end = hd.a_beg + hd.n_lists;
   const long long* awlo = aw + (size_t)w * (size_t)nnzA;
@@ -1461,96 +1470,129 @@ __global__ __launch_bounds__(NT) void spgemm_sym_unit_kernel(const UnitHead* __r
   int tail[3];
   KK_UNROLL
   for (int e = 0; e < 3; ++e) { const long long i = last_full + 4 + e; tail[e] = entB[i < nnzB ? i : nnzB - 1]; }
+  // The unit of the walk is a LANE-STEP: four consecutive aligned quads (64 bytes) of ONE piece, taken by one lane (a piece's last lane-step is
+  // padded: six entries per piece on average against pieces of 500).  A wave-step is 64 lane-steps; every wave owns a contiguous range of the
+  // chunk's wave-steps.
+  //   * RUNS of interior wave-steps -- all 64 lane-steps inside one piece, none holding one of its partial end quads -- are walked three
+  //     steps deep with nothing searched or tested inside (where a run ends is arithmetic on the piece's bounds);
+  //   * a general wave-step finds a lane's piece by one search inside the step's pieces (whose range two uniform searches gave) and masks
+  //     entries only in a piece's first and last quad.
+  // Lanes that set bits in one instruction are 16 entries of a sorted list apart: neighbouring lanes rarely meet in one 32-bit word.  (Measured
+  // and not kept: 16 lanes on 16 consecutive quads, four such groups of quads per lane -- whole-line loads, but the lanes of an instruction
+  // then sit 4 entries apart and their ds_or_b32 collide in the same words: R-MAT scale 20 symbolic 40.0 -> 44.2 ms.)
+  // The first version assigned quads regardless of pieces: a lane's four quads crossed pieces, every quad carried its own piece tracking and
+  // every entry two comparisons -- 34 vector instructions per product over the whole kernel at 67 % vector-ALU utilisation (R-MAT scale 20),
+  // three quarters of the products in such steps.
   for (int64_t chunk = a_beg; chunk < a_end && !KK_DBG(2); chunk += NT) {
     const int n = (int)(a_end - chunk < NT ? a_end - chunk : NT);
-    long long nq = 0, lo = 0, hi = 0;
+    long long ng = 0, lo = 0, hi = 0;
+    int nq = 0;
     if (t < n) {
       lo = awlo[chunk + t]; hi = awhi[chunk + t];
-      if (hi > lo) nq = ((hi + 3) >> 2) - (lo >> 2);
+      if (hi > lo) {
+        const long long nq64 = ((hi + 3) >> 2) - (lo >> 2);
+        ng = (nq64 + 3) >> 2;
+        nq = nq64 > (long long)INT_MAX ? INT_MAX : (int)nq64;
+      }
     }
     long long tot64;
-    const long long excl = block_exclusive_scan_n<long long, NT>(nq, &tot64, sc.wave64);
-    if (t < n) { sc.lo[t] = lo; sc.hi[t] = hi; }
-    if (tot64 > (long long)INT_MAX - 2 * S) {           // (pieces with 8e9 entries between them: not a real case) -- list by list, entry by entry
+    const long long excl = block_exclusive_scan_n<long long, NT>(ng, &tot64, sc.wave64);
+    if (tot64 > (long long)(INT_MAX >> 3)) {            // (pieces with 1e10 entries between them: not a real case) -- list by list, entry by entry
+      if (t < n) sc.fq[t] = lo;
       __syncthreads();
-      for (int a = 0; a < n; ++a) for (long long i = sc.lo[a] + t; i < sc.hi[a]; i += NT) mark(entB[i]);
+      for (int a = 0; a < n; ++a) { const long long l0 = sc.fq[a], l1 = awhi[chunk + a]; for (long long i = l0 + t; i < l1; i += NT) mark(entB[i]); }
       __syncthreads();
       continue;
     }
-    const int tot = (int)tot64;
-    if (t < n) sc.pre[t] = (int)excl;
-    if (t == 0) sc.pre[n] = tot;
+    const int tot = (int)tot64;                         // lane-steps of the chunk
+    if (t < n) { sc.gpre[t] = (int)excl; sc.nq[t] = nq; sc.fq[t] = lo >> 2; sc.ends[t] = (int)(lo & 3) | ((int)(((hi - 1) & 3) + 1) << 4); }
+    if (t == 0) sc.gpre[n] = tot;
     __syncthreads();
     if (tot > 0) {
-      const int nsteps = (tot + S - 1) / S;
+      constexpr int GS = 64;                            // lane-steps per wave-step
+      const int nsteps = (tot + GS - 1) / GS;
       const int s_beg = (int)(((long long)nsteps * wave) / NW), s_end = (int)(((long long)nsteps * (wave + 1)) / NW);
-      // largest s in [from, n) with pre[s] <= q (lists without quads share their successor's offset: the search steps over them)
+      // largest s in [from, n) with gpre[s] <= q (pieces without quads share their successor's offset: the search steps over them)
       auto ufind = [&](int from, int q) {
         int at = from, len = n - from;
-        while (len > 1) { const int half = len >> 1; at += (sc.pre[at + half] <= q) ? half : 0; len -= half; }
+        while (len > 1) { const int half = len >> 1; at += (sc.gpre[at + half] <= q) ? half : 0; len -= half; }
         return at;
       };
-      int seg = 0;
-      for (int step = s_beg; step < s_end; ++step) {
-        const int qw0 = step * S;
-        const int qw1 = (qw0 + S <= tot ? qw0 + S : tot) - 1;            // first / last quad of the wave's step
-        seg = KK_UNIFORM(ufind(seg, qw0));
-        const int seg_hi = KK_UNIFORM(ufind(seg, qw1));
-        const int q0 = qw0 + lane * Q;
-        bool inside = false;
-        long long ebase = 0;
-        if (seg == seg_hi && qw0 + S <= tot) {                           // (uniform) one list, a full step
-          const long long llo = sc.lo[seg], lhi = sc.hi[seg];
-          ebase = ((llo >> 2) - (long long)sc.pre[seg]) << 2;            // quad q of the chunk starts at entry ebase + 4 q
-          inside = ebase + 4ll * qw0 >= llo && ebase + 4ll * (qw0 + S) <= lhi;      // neither of the list's partial end quads
+      // The wave-steps run TWO DEEP: a step is looked up and its quads requested one step before its bits are set (a wave doing
+      // "look up, load, wait, sixteen atomics" one step at a time had nothing outstanding most of the time: with four waves per SIMD the
+      // general steps of R-MAT scale 20 ran at 1.7e12 products/s, their latency chain, whatever their instruction count).
+      struct Stage { int4 v[4]; int left; int pq0; int en; };            // left: quads of the lane's piece from its first quad on (<= 0: no lane-step)
+      int seg = s_beg < s_end ? KK_UNIFORM(ufind(0, s_beg * GS)) : 0;
+      int seg_pre = 0, seg_next = -1, sa = 0, sb = 0;                    // of the piece `seg`: its lane-steps, its interior wave-steps [sa, sb)
+      long long seg_fq = 0;
+      auto issue = [&](int step, Stage& st) {                            // (uniform control flow)
+        const int gw0 = step * GS;
+        if (gw0 >= seg_next) {                                           // (seg_next = -1: look the piece up again)
+          if (gw0 >= sc.gpre[seg + 1]) seg = KK_UNIFORM(ufind(seg, gw0));
+          seg_pre = KK_UNIFORM(sc.gpre[seg]); seg_next = KK_UNIFORM(sc.gpre[seg + 1]);
+          const int en_ = KK_UNIFORM(sc.ends[seg]), nqs_ = KK_UNIFORM(sc.nq[seg]);
+          // interior lane-steps of the piece: [j_lo, j_hi) -- after the one with a partial first quad, before the one with a partial or missing last quad
+          const int j_lo = (en_ & 15) ? 1 : 0, j_hi = (nqs_ - ((en_ >> 4) != 4 ? 1 : 0)) >> 2;
+          sa = (seg_pre + j_lo + GS - 1) / GS; sb = (seg_pre + j_hi) / GS;
+          seg_fq = sc.fq[seg];
         }
-        if (inside) {
-          const int4* src = reinterpret_cast<const int4*>(entB + ebase) + q0;
-          int4 v[Q];
-          KK_UNROLL
-          for (int uu = 0; uu < Q; ++uu) v[uu] = src[uu];
-          KK_UNROLL
-          for (int uu = 0; uu < Q; ++uu) { mark(v[uu].x); mark(v[uu].y); mark(v[uu].z); mark(v[uu].w); }
+        long long aq0 = 0;                                               // the lane's first quad (a lane without a lane-step reads quads 0 .. 3)
+        st.left = 0; st.pq0 = 0; st.en = 0x40;
+        if (step >= sa && step < sb) {                                   // interior: all 64 lane-steps in this piece, every quad whole
+          st.pq0 = (gw0 - seg_pre + lane) << 2; st.left = INT_MAX;
+          aq0 = seg_fq + st.pq0;
         } else {
-          long long at[Q];
-          int elo[Q], ehi[Q];
-          int4 v[Q];
+          const int gw1 = (gw0 + GS <= tot ? gw0 + GS : tot) - 1;        // the step's last lane-step
+          const int seg_hi = gw1 < seg_next ? seg : KK_UNIFORM(ufind(seg, gw1));
+          const int ls = gw0 + lane;
+          if (ls <= gw1) {
+            int sg = seg, len = seg_hi - seg + 1;                        // the lane's piece: a search inside the step's pieces
+            while (len > 1) { const int half = len >> 1; sg += (sc.gpre[sg + half] <= ls) ? half : 0; len -= half; }
+            st.pq0 = (ls - sc.gpre[sg]) << 2; st.en = sc.ends[sg];
+            st.left = sc.nq[sg] - st.pq0;
+            aq0 = sc.fq[sg] + st.pq0;
+          }
+          if (seg_hi != seg) { seg = seg_hi; seg_next = -1; }             // the next step looks its piece up again
+        }
+        // every 16-byte load is unconditional; the one quad that would reach past the end of entries(B) -- its last 1 .. 3 entries when nnz(B) is
+        // no multiple of 4 -- reads the last full quad instead and takes its entries from `tail`
+        const bool any_past = __any(((aq0 + 3) << 2) > last_full);
+        KK_UNROLL
+        for (int uu = 0; uu < 4; ++uu) st.v[uu] = reinterpret_cast<const int4*>(entB)[any_past && ((aq0 + uu) << 2) > last_full ? (last_full >> 2) : aq0 + uu];
+        if (any_past) {                                                  // (uniform; once per product at most)
           KK_UNROLL
-          for (int uu = 0; uu < Q; ++uu) { at[uu] = 0; elo[uu] = 0; ehi[uu] = 0; }
-          if (q0 <= qw1) {
-            int sg = seg, len = seg_hi - seg + 1;                        // the lane's first quad: a search inside the step's lists
-            while (len > 1) { const int half = len >> 1; sg += (sc.pre[sg + half] <= q0) ? half : 0; len -= half; }
-            int pre_next = sc.pre[sg + 1];
-            long long sb0 = sc.lo[sg], sb1 = sc.hi[sg];
-            long long qbase = ((sb0 >> 2) - (long long)sc.pre[sg]) << 2;
-            KK_UNROLL
-            for (int uu = 0; uu < Q; ++uu) {
-              const int q = q0 + uu;
-              if (q <= qw1) {
-                if (q >= pre_next) {
-                  do { ++sg; pre_next = sc.pre[sg + 1]; } while (q >= pre_next);   // steps over lists without quads; q < tot = pre[n] ends it
-                  sb0 = sc.lo[sg]; sb1 = sc.hi[sg]; qbase = ((sb0 >> 2) - (long long)sc.pre[sg]) << 2;
-                }
-                at[uu] = qbase + ((long long)q << 2);
-                elo[uu] = sb0 > at[uu] ? (int)(sb0 - at[uu]) : 0;
-                ehi[uu] = sb1 < at[uu] + 4 ? (int)(sb1 - at[uu]) : 4;
-              }
+          for (int uu = 0; uu < 4; ++uu) if (((aq0 + uu) << 2) > last_full) { st.v[uu].x = tail[0]; st.v[uu].y = tail[1]; st.v[uu].z = tail[2]; }
+        }
+      };
+      auto retire = [&](Stage& st) {
+#ifndef KK_EMU
+        KK_UNROLL
+        for (int uu = 0; uu < 4; ++uu) asm volatile("" : "+v"(st.v[uu].x), "+v"(st.v[uu].y), "+v"(st.v[uu].z), "+v"(st.v[uu].w));     // the quads stay whole (see flat_columns_quads)
+#endif
+        const int left = st.left, en = st.en;
+        if (left >= 4 && !(st.pq0 == 0 && (en & 15)) && !(left == 4 && (en >> 4) != 4)) {     // four whole quads
+          KK_UNROLL
+          for (int uu = 0; uu < 4; ++uu) { mark(st.v[uu].x); mark(st.v[uu].y); mark(st.v[uu].z); mark(st.v[uu].w); }
+        } else {
+          KK_UNROLL
+          for (int uu = 0; uu < 4; ++uu) {
+            if (uu < left) {
+              const int elo = (st.pq0 + uu == 0) ? (en & 15) : 0, ehi = (uu == left - 1) ? (en >> 4) : 4;
+              const int col[4] = {st.v[uu].x, st.v[uu].y, st.v[uu].z, st.v[uu].w};
+              KK_UNROLL
+              for (int e = 0; e < 4; ++e) if (e >= elo && e < ehi) mark(col[e]);
             }
           }
-          KK_UNROLL
-          for (int uu = 0; uu < Q; ++uu) v[uu] = *reinterpret_cast<const int4*>(entB + (at[uu] <= last_full ? at[uu] : last_full));
-#ifndef KK_EMU
-          KK_UNROLL
-          for (int uu = 0; uu < Q; ++uu) asm volatile("" : "+v"(v[uu].x), "+v"(v[uu].y), "+v"(v[uu].z), "+v"(v[uu].w));     // the quads stay whole (see flat_columns_quads)
-#endif
-          KK_UNROLL
-          for (int uu = 0; uu < Q; ++uu) {
-            const bool past = at[uu] > last_full;                        // the array's last, partial quad
-            const int col[4] = {past ? tail[0] : v[uu].x, past ? tail[1] : v[uu].y, past ? tail[2] : v[uu].z, v[uu].w};
-            KK_UNROLL
-            for (int e = 0; e < 4; ++e) if (e >= elo[uu] && e < ehi[uu]) mark(col[e]);
-          }
         }
+      };
+      Stage p0, p1;
+      int nxt = s_beg, done = s_beg;
+      if (nxt < s_end) issue(nxt++, p0);
+      if (nxt < s_end) issue(nxt++, p1);
+      while (done < s_end) {                                             // (uniform)
+        retire(p0); ++done;
+        if (nxt < s_end) issue(nxt++, p0);
+        if (done < s_end) { retire(p1); ++done; if (nxt < s_end) issue(nxt++, p1); }
       }
     }
     __syncthreads();
@@ -3095,6 +3137,8 @@ struct kkamd_spgemm_handle {
   int64_t last_units = 0, last_unit_bitmaps = 0, last_unit_rows_kept = 0;      // of the last symbolic phase (kkamd_spgemm_get 19 - 21; they outlive the store)
   int32_t* d_unit_perm = nullptr; unsigned* d_ucnt = nullptr; unsigned* d_ucoff = nullptr; long long* d_uoff = nullptr;
   kk::UnitHead* d_heads = nullptr; int64_t n_heads = 0;       // the units with products, in launch order
+  // a second stream for the symbolic phase: the kernels of the rows with few products (wave / block hash kernels) run beside the dense class
+  hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -3244,10 +3288,18 @@ static int split_list_by_size(int32_t* list, int64_t n, const OffT* rmA, const i
   return KKAMD_OK;
 }
 
+// hipFree waits for the whole device: a temporary freed in the middle of a phase would wait for the kernels running beside it on the
+// phase's second stream.  Such temporaries are handed to a Deferred list and freed when the phase is over.
+struct Deferred {
+  std::vector<void*> ptrs;
+  void take(DevBuf& b) { if (b.p) ptrs.push_back(b.release()); }
+  ~Deferred() { for (void* q : ptrs) (void)hipFree(q); }
+};
 // list[0 .. n) reordered by sizes[row], largest first (quarter-octave classes; see spgemm_size_hist_kernel)
-static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hipStream_t st) {
+static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hipStream_t st, Deferred* later = nullptr) {
   if (n < 4096 || !g_spgemm.sort_rows) return KKAMD_OK;          // (a short list finishes in one wave of workgroups whatever its order)
   DevBuf tmp_b, hist_b;
+  struct Hand { Deferred* d; DevBuf &a, &b; ~Hand() { if (d) { d->take(a); d->take(b); } } } hand{later, tmp_b, hist_b};
   KK_HIP(tmp_b.alloc(sizeof(int32_t) * (size_t)n));
   KK_HIP(hist_b.alloc(sizeof(unsigned) * (kSizeClasses + 1)));
   int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned* d_hist = hist_b.as<unsigned>();
@@ -3267,8 +3319,14 @@ static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hi
 // for the indices) and the caller takes the one-workgroup-per-row kernel.
 template <class OffT>
 static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* list, int64_t m, int64_t n, int64_t k, const OffT* rmA, const int32_t* entA,
-                          const OffT* rmB, const int32_t* entB, int64_t nnzB, OffT* rmC, hipStream_t st, bool* ran) {
+                          const OffT* rmB, const int32_t* entB, int64_t nnzB, OffT* rmC, hipStream_t st, bool* ran, Deferred* later) {
   *ran = false;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {                       // (verbose: where the host-side time of the phase goes; adds stream synchronisations)
+    if (h->verbose < 2) return;
+    (void)hipStreamSynchronize(st);
+    KK_VERBOSE("\t\tunits %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
   int wb = g_spgemm.unit_bits;
   if (wb > kUnitBitsMax) wb = kUnitBitsMax;
   if (wb < 6) wb = 6;
@@ -3292,6 +3350,7 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   free_bitmap_store(h);
   // temporaries of this phase (free themselves): the two indices, products and launch order of the units; kept for the numeric phase: heads, counts, offsets
   DevBuf widx_b, aw_b, uprod_b, ulist_b, soff_b, cnt_b;
+  struct Hand { Deferred* d; DevBuf *b[6]; ~Hand() { if (d) for (DevBuf* x : b) d->take(*x); } } hand{later, {&widx_b, &aw_b, &uprod_b, &ulist_b, &soff_b, &cnt_b}};
   if (aw_b.alloc(aw_bytes) != hipSuccess || uprod_b.alloc(sizeof(long long) * (size_t)units) != hipSuccess || ulist_b.alloc(sizeof(int32_t) * (size_t)units) != hipSuccess ||
       cnt_b.alloc(8 * sizeof(unsigned long long)) != hipSuccess || (widx_bytes && widx_b.alloc(widx_bytes) != hipSuccess) ||
       hipMalloc((void**)&h->d_unit_perm, sizeof(int32_t) * (size_t)nrows) != hipSuccess || hipMalloc((void**)&h->d_ucnt, sizeof(unsigned) * (size_t)units) != hipSuccess ||
@@ -3311,6 +3370,7 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   KK_LAUNCH((spgemm_aw_kernel<OffT>), (unsigned)ceil_div(nnzA, kBlock), kBlock, 0, st, nnzA, entA, rmB, n, nwin, (const unsigned*)d_wx, d_aw);
   KK_LAUNCH((spgemm_uprod_kernel<OffT>), (unsigned)ceil_div(nrows, kBlock / 64), kBlock, 0, st, nrows, d_perm_u, rmA, nnzA, nwin, (const long long*)d_aw, d_up);
   KK_LAUNCH(spgemm_unit_compact_kernel, (unsigned)ceil_div(units, kBlock), kBlock, 0, st, units, (const long long*)d_up, d_ul, d_cnt);
+  lap("allocations + indices + compaction");
   unsigned long long h_n = 0;
   KK_HIP(hipMemcpyAsync(&h_n, d_cnt, sizeof h_n, hipMemcpyDeviceToHost, st));
   KK_HIP(hipStreamSynchronize(st));
@@ -3319,7 +3379,7 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   h->last_units = nu;
   if (nu == 0) { *ran = true; return KKAMD_OK; }
   int rc;
-  if ((rc = order_list_by_size(d_ul, nu, (const int64_t*)d_up, st))) return rc;               // heaviest units first
+  if ((rc = order_list_by_size(d_ul, nu, (const int64_t*)d_up, st, later))) return rc;        // heaviest units first
   // where every unit's structure goes: a prefix sum over min(4 products, bitmap bytes); the store is at most 0.225 of the free HBM (an eighth
   // for bitmaps and a tenth for lists until round 5), units past it keep nothing (the lightest: they come last) and their rows walk
   // their products again in the numeric phase
@@ -3328,11 +3388,11 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   const int bm_words = (words + 15) & ~15;
   const long long bm_bytes = (long long)words * 8;
   long long budget = 0, total_need = 0;
-  KK_HIP(soff_b.alloc(sizeof(long long) * (size_t)(nu + 1)));
+  KK_HIP(soff_b.alloc(sizeof(long long) * (size_t)(nu + 1 + scan_workspace_items(nu + 1))));
   long long* d_so = soff_b.as<long long>();
   if (hipMalloc((void**)&h->d_heads, sizeof(UnitHead) * (size_t)nu) != hipSuccess) { (void)hipGetLastError(); free_bitmap_store(h); return KKAMD_OK; }
   KK_LAUNCH(spgemm_unit_ssize_kernel, (unsigned)ceil_div(nu + 1, kBlock), kBlock, 0, st, nu, (const int32_t*)d_ul, (const long long*)d_up, bm_bytes, d_so);
-  if ((rc = exclusive_scan_inplace<long long>(d_so, nu + 1, st))) return rc;
+  if ((rc = exclusive_scan_inplace<long long>(d_so, nu + 1, st, d_so + nu + 1))) return rc;
   if (g_spgemm.keep_bitmaps && k >= 64) {
     KK_HIP(hipMemcpyAsync(&total_need, d_so + nu, sizeof(long long), hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
@@ -3343,23 +3403,26 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
     const size_t got = want ? take_bitmap_store(h, want) : 0;
     budget = (long long)got;
   }
+  lap("order, sizes, store");
   UnitHead* d_hd = h->d_heads;
   KK_LAUNCH((spgemm_unit_heads_kernel<OffT>), (unsigned)ceil_div(nu, kBlock), kBlock, 0, st, nu, (const int32_t*)d_ul, (const long long*)d_up, (const long long*)d_so,
             bm_bytes, budget, g_spgemm.keep_lists, nwin, d_perm_u, rmA, d_hd, h->d_uoff, d_cnt + 1);
   char* d_store = (char*)h->d_bm_store;
   unsigned* d_uc = h->d_ucnt;
 #ifndef KK_EMU
-#define KK_UNIT_ATTR(NTT) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_sym_unit_kernel<OffT, NTT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)bm_words * 8 + sizeof(UnitScratch<NTT>))))
+#define KK_UNIT_ATTR(NTT) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spgemm_sym_unit_kernel<OffT, NTT, KK_UQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)bm_words * 8 + sizeof(UnitScratch<NTT>))))
 #else
 #define KK_UNIT_ATTR(NTT) (void)0
 #endif
 #define KK_UNIT(NTT)                                                                                                                                        \
   do {                                                                                                                                                      \
     KK_UNIT_ATTR(NTT);                                                                                                                                      \
-    KK_LAUNCH((spgemm_sym_unit_kernel<OffT, NTT, 4>), (unsigned)nu, NTT, (size_t)bm_words * 8 + sizeof(UnitScratch<NTT>), st, (const UnitHead*)d_hd, nwin, wb, k, nnzA, \
+    KK_LAUNCH((spgemm_sym_unit_kernel<OffT, NTT, KK_UQ>), (unsigned)nu, NTT, (size_t)bm_words * 8 + sizeof(UnitScratch<NTT>), st, (const UnitHead*)d_hd, nwin, wb, k, nnzA, \
               (const long long*)d_aw, entB, nnzB, rmC, d_uc, d_store, bm_words KK_DBG_ARG);                                                                 \
   } while (0)
+  lap("heads");
   if (nt == 256) KK_UNIT(256); else if (nt == 512) KK_UNIT(512); else KK_UNIT(1024);
+  lap("unit kernel");
 #undef KK_UNIT
 #undef KK_UNIT_ATTR
   {
@@ -3388,6 +3451,12 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   const OffT* rmA = (const OffT*)rmA_;
   const OffT* rmB = (const OffT*)rmB_;
   OffT* rmC       = (OffT*)rmC_;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (h->verbose < 2) return;
+    (void)hipStreamSynchronize(st);
+    KK_VERBOSE("\t\tsymbolic %-25s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+  };
   KK_HIP(hipMemsetAsync(rmC, 0, sizeof(OffT) * (size_t)(m + 1), st));
   DevBuf stats_b;                            // frees itself on every return
   KK_HIP(stats_b.alloc(2 * sizeof(unsigned long long)));
@@ -3403,6 +3472,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   KK_HIP(hipStreamSynchronize(st));
   h->mults = (int64_t)h_stats[0]; h->max_row_flops = (int64_t)h_stats[1];
   h->sg_log2 = pick_sg_log2(nnzB, n); h->nnzB = nnzB;
+  lap("row flops");
   if (h->d_flop_cls) { (void)hipFree(h->d_flop_cls); h->d_flop_cls = nullptr; }
   // (only when some row can land in the numeric phase's dense bin at all: more products than the wave kernel's table takes entries)
   if (g_spgemm.emit_sort && h->max_row_flops > (int64_t)(kWaveTable / 2) && hipMalloc((void**)&h->d_flop_cls, sizeof(int32_t) * (size_t)m) == hipSuccess) {
@@ -3425,6 +3495,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     KK_HIP(hipStreamSynchronize(st));
     h->b_sorted = h_flag == 0;
   }
+  lap("flop classes + sortedness");
   // B compression (a18): 32-column sets with bit masks; kept when it removes >= 15 % of the symbolic insertions
   DevBuf setB_b, maskB_b, endB_b;
   h->compressed = false; h->compressed_mults = h->mults;
@@ -3483,32 +3554,57 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     }
   } else {
     if ((rc = make_bins(m, h->d_sizes, k, g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
+    // When there is a dense class, the kernels of the other rows go to a second stream and run beside it (they are bound by their
+    // latency chains and leave most of the chip idle: 5 of the symbolic phase's 40 ms on R-MAT scale 20 when they ran first on the one stream).
+    // The caller's stream waits for them before the counts are scanned.
+    Deferred later;                                            // (declared before the join below: freed after the second stream has been waited for)
+    hipStream_t sx = st;
+    bool forked = false;
+    int64_t nq = 0;
+    int32_t* wlist = h->d_perm + off.off[1];
     if (nb(1)) {
       // the rows of this bin with at most kQuadFlops products share waves four at a time; when the product mixes them with larger rows
       // the bin's list is split first (small rows to the front)
-      int32_t* wlist = h->d_perm + off.off[1];
-      int64_t nq = 0;
       if (g_spgemm.quad_rows == 2 || (g_spgemm.quad_rows == 1 && h->max_row_flops <= (int64_t)kQuadFlops)) nq = nb(1);
       else if (g_spgemm.quad_rows == 1 && (rc = split_list_by_size<OffT>(wlist, nb(1), rmA, (const int64_t*)h->d_sizes, (int64_t)kQuadFlops, &nq, st))) return rc;
+    }
+    if (nb(4) && (nb(1) || nb(2) || nb(3))) {
+      if (!h->aux && (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipGetLastError();
+        if (h->aux) { (void)hipStreamDestroy(h->aux); h->aux = nullptr; }
+        if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
+      }
+      if (h->aux && hipEventRecord(h->ev_fork, st) == hipSuccess && hipStreamWaitEvent(h->aux, h->ev_fork, 0) == hipSuccess) { sx = h->aux; forked = true; }
+      else (void)hipGetLastError();
+    }
+    if (nb(1)) {
       if (nq)
-        KK_LAUNCH((spgemm_sym_quad_kernel<OffT>), (unsigned)ceil_div(nq, 4 * (kBlock / 64)), kBlock, 0, st, nq,
+        KK_LAUNCH((spgemm_sym_quad_kernel<OffT>), (unsigned)ceil_div(nq, 4 * (kBlock / 64)), kBlock, 0, sx, nq,
                   (const int32_t*)wlist, rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
       if (nb(1) - nq)
-        KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1) - nq, kBlock / 64), kBlock, 0, st, nb(1) - nq,
+        KK_LAUNCH((spgemm_sym_wave_kernel<OffT>), (unsigned)ceil_div(nb(1) - nq, kBlock / 64), kBlock, 0, sx, nb(1) - nq,
                   (const int32_t*)(wlist + nq), rmA, entA, rmB, entB, rmC, (const int64_t*)h->d_sizes);
     }
-    if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, st, nb(2),
+    if (nb(2)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkS, kBlock>), (unsigned)nb(2), kBlock, 0, sx, nb(2),
                          (const int32_t*)(h->d_perm + off.off[2]), rmA, entA, rmB, entB, rmC, sg);
-    if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, st, nb(3),
+    if (nb(3)) KK_LAUNCH((spgemm_sym_block_kernel<OffT, kSymBlkL, kDenseBlock>), (unsigned)nb(3), kDenseBlock, 0, sx, nb(3),
                          (const int32_t*)(h->d_perm + off.off[3]), rmA, entA, rmB, entB, rmC, sg);
+    if (forked) {                                              // (recorded now; the caller's stream waits for it after the dense class)
+      if (hipEventRecord(h->ev_join, h->aux) != hipSuccess) { (void)hipGetLastError(); KK_HIP(hipStreamSynchronize(h->aux)); forked = false; }
+    }
+    lap("bins + small-row kernels queued");
+    struct Join { kkamd_spgemm_handle* h; hipStream_t st; bool on; ~Join() { if (on) { if (hipStreamWaitEvent(st, h->ev_join, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(h->aux); } } } } join{h, st, forked};
     if (nb(4)) {
-      if ((rc = order_list_by_size(h->d_perm + off.off[4], nb(4), (const int64_t*)h->d_sizes, st))) return rc;      // by products, largest first
+      if ((rc = order_list_by_size(h->d_perm + off.off[4], nb(4), (const int64_t*)h->d_sizes, st, &later))) return rc;      // by products, largest first
       // keep the bitmaps of rows with at least k / 32 entries (the bitmap is then no larger than the row's entries) when one LDS
       // window covers the columns and an eighth of the free HBM holds them: R-MAT scale 20, 87 K rows (83 % of the products), 11 GB
       BitmapStore bs;
       free_bitmap_store(h);
       bool by_units = false;
-      if ((rc = symbolic_units<OffT>(h, nb(4), h->d_perm + off.off[4], m, n, k, rmA, entA, rmB, entB, nnzB, rmC, st, &by_units))) return rc;
+      lap("class ordered");
+      if ((rc = symbolic_units<OffT>(h, nb(4), h->d_perm + off.off[4], m, n, k, rmA, entA, rmB, entB, nnzB, rmC, st, &by_units, &later))) return rc;
+      lap("dense class");
       if (by_units) {}
       else {
       if (g_spgemm.keep_bitmaps && k <= (int64_t)g_spgemm.win_bits && k >= 4096) {
@@ -3590,6 +3686,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     if (h_tot > (unsigned long long)INT32_MAX)
       return fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: nnz(C) = %llu overflows 32-bit offsets; use 64-bit offsets", h_tot);
   }
+  lap("before the scan");
   rc = (e == hipSuccess) ? exclusive_scan_inplace<OffT>(rmC, m + 1, st) : fail(KKAMD_ERR_HIP, "spgemm symbolic launch failed: %s", hipGetErrorString(e));
   OffT total = 0;
   if (rc == KKAMD_OK) {
@@ -4177,6 +4274,9 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (h->d_hub_items) (void)hipFree(h->d_hub_items);
   if (h->d_hub_multi) (void)hipFree(h->d_hub_multi);
   if (h->d_bidx) (void)hipFree(h->d_bidx);
+  if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->d_cidx) (void)hipFree(h->d_cidx);
   if (h->d_items_rank) (void)hipFree(h->d_items_rank);
   if (h->d_items_direct) (void)hipFree(h->d_items_direct);
@@ -4320,7 +4420,7 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* h, const char* key, double value) {
     if (!(value > 0.0 && value <= 1.0)) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_set: compression cut-off must be in (0, 1]");
     h->compression_cutoff = value;
   } else if (k == "verbose") {
-    h->verbose = value != 0;
+    h->verbose = value < 0 ? 0 : (int)value;          // 2: also host-side stage times of the symbolic phase (adds stream synchronisations)
   } else if (k == "entries_computed") {
     // the reference's SPGEMMHandle::are_entries_computed() as the caller sees it: 0 = entries(C) must be written again by the next
     // numeric call (the caller re-allocated or overwrote them); 1 = leave the decision to the handle (it keeps them only when it

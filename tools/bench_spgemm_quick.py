@@ -54,7 +54,7 @@ for name in (sys.argv[1] if len(sys.argv) > 1 else "18").split(","):
         best = None
         for rep in range(int(os.environ.get("KK_REPS", "3"))):
             kh = kk.KokkosKernelsHandle(); kh.create_spgemm_handle()
-            if os.environ.get("KK_VERBOSE") and rep == 0: kh.get_spgemm_handle().set("verbose", 1)
+            if os.environ.get("KK_VERBOSE") and rep == int(os.environ.get("KK_VERBOSE_REP", "0")): kh.get_spgemm_handle().set("verbose", int(os.environ["KK_VERBOSE"]))
             for kv in os.environ.get("KK_HANDLE_OPTS", "").split(","):            # handle options, e.g. KK_HANDLE_OPTS=compression=2
                 if kv: kh.get_spgemm_handle().set(kv.split("=")[0], float(kv.split("=")[1]) if "." in kv.split("=")[1] else int(kv.split("=")[1]))
             torch.cuda.synchronize(); t0 = time.perf_counter()
