@@ -292,6 +292,66 @@ def _spgemm_case(kk, torch, scale, t_start, budget_s, reps=3):
     return out
 
 
+def _spgemm_c4_slabs(kk, torch, t_start, budget_s, world=8, scale=22, verbose=0, ranks=None):
+    """BASELINE config 4 as specified (R-MAT scale 22, edge factor 16) does not fit one GPU (nnz(C) = 7.2e10 = 863 GB); one rank's slab of the
+    8-GPU row partition does (B replicated, no data-path communication: SURVEY 8e).  kkamd_dist_spgemm_partition(world = 8) cuts A into slabs of
+    near-equal multiplications; the slab with the fewest rows (hub rows) and the one with the most rows (the largest piece of C) are timed through
+    kkamd_dist_spgemm_symbolic / _numeric: two warm-ups, then the mean of two repetitions with a fresh operator each.  What an 8-GPU run would take is the
+    slowest slab (no exchange)."""
+    import numpy as np
+    import oracle
+    from kokkos_kernels_amd.dist import DistSpgemm
+    R = oracle.rmat(scale, 16)
+    M = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, offset_dtype=np.int64)
+    be = M.backend
+    sync = torch.cuda.synchronize
+    offsets, mults = DistSpgemm.partition(M, M, world)
+    rows = [offsets[r + 1] - offsets[r] for r in range(world)]
+    out = {"workload": "spgemm_AxA_rmat_scale%d_ef16_fp64_row_slabs_of_%d_B_replicated" % (scale, world), "rows": R.nrows, "nnz_A": R.nnz,
+           "multiplications": int(sum(mults)), "multiplications_per_rank": [int(v) for v in mults], "rows_per_rank": rows,
+           "balance_max_over_mean": round(max(mults) / (sum(mults) / world), 4), "slabs": {}}
+    for rank in (ranks if ranks is not None else sorted({int(np.argmin(rows)), int(np.argmax(rows))})):
+        if time.perf_counter() - t_start > budget_s: out["slabs"]["rank %d" % rank] = {"skipped": "time cap"}; continue
+        o0, o1 = offsets[rank], offsets[rank + 1]
+        e0, e1 = int(R.row_map[o0]), int(R.row_map[o1])
+        Sd = kk.CrsMatrix(o1 - o0, R.ncols, (M.graph.row_map[o0:o1 + 1] - M.graph.row_map[o0]).contiguous(), M.graph.entries[e0:e1], M.values[e0:e1], backend=be)
+        runs = []
+        WARM = 2            # (as in _spgemm_case: the first use of every kernel, and the product after it, in which the library's store is sized for this slab)
+        for rep in range(WARM + 2):
+            op = DistSpgemm(offsets, rank, be)
+            if verbose and rep == WARM + 1: op.set("verbose", verbose)
+            sync(); t0 = time.perf_counter()
+            Cm = op.symbolic(Sd, M)
+            sync(); t1 = time.perf_counter()
+            op.numeric(Sd, M, Cm)
+            sync(); t2 = time.perf_counter()
+            op.numeric(Sd, M, Cm)
+            sync(); t3 = time.perf_counter()
+            nnzC = Cm.nnz()
+            if rep >= WARM: runs.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+            del Cm, op          # (the slab of C stays in torch's cache for the next repetition: returning 100+ GB to the runtime and asking for them
+                                # again stalls the next hipMalloc by seconds, profiles/round5/probe_malloc.txt)
+        torch.cuda.empty_cache()
+        sym, num, reuse = (sum(r[i] for r in runs) / len(runs) for i in range(3))
+        nnzA_s, mu = e1 - e0, int(mults[rank])
+        b_sym = nnzA_s * 4 + (o1 - o0 + 1) * 16 + (R.nrows + 1) * 8 + mu * 4
+        b_num = nnzA_s * 12 + (o1 - o0 + 1) * 16 + (R.nrows + 1) * 8 + mu * 12 + nnzC * 12
+        out["slabs"]["rank %d" % rank] = {
+            "rows": o1 - o0, "nnz_A_slab": nnzA_s, "multiplications": mu, "nnz_C_slab": nnzC, "C_slab_GB": round(nnzC * 12e-9, 1),
+            "symbolic_ms": round(sym, 3), "numeric_ms": round(num, 3), "numeric_reuse_ms": round(reuse, 3),
+            "GFLOPs": round(2.0 * mu / (sym + num) / 1e6, 1),
+            "roofline": {"bound": "hbm", "model": "gather model, SURVEY 8(d)", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "symbolic_frac": round(b_sym / sym / 1e6 / HBM_PEAK_GBPS, 4), "numeric_frac": round(b_num / num / 1e6 / HBM_PEAK_GBPS, 4),
+                         "numeric_reuse_frac": round((b_num - nnzC * 4) / reuse / 1e6 / HBM_PEAK_GBPS, 4)}}
+        del Sd
+    done = [v for v in out["slabs"].values() if "symbolic_ms" in v]
+    if done:
+        out["slowest_slab_ms"] = {"symbolic": max(v["symbolic_ms"] for v in done), "numeric": max(v["numeric_ms"] for v in done)}
+        out["projected_8gpu_GFLOPs_if_every_slab_took_the_slowest_time"] = round(2.0 * sum(mults) / (out["slowest_slab_ms"]["symbolic"] + out["slowest_slab_ms"]["numeric"]) / 1e6, 1)
+    del M
+    return out
+
+
 def bench_spgemm(kk, torch, budget_s, cpu, scale=20):
     """BASELINE config 4 family: C = A*A on R-MAT (edge factor 16, 64-bit offsets), the largest scale whose C fits one GPU
     (scale 20: nnz(C) 9.69e9 = 116 GB; scale 22 as specified needs 863 GB).  Per repetition a fresh handle: symbolic, numeric,
@@ -307,6 +367,15 @@ def bench_spgemm(kk, torch, budget_s, cpu, scale=20):
         out["cpu_baseline"] = cpu_baseline_spgemm()
         ref18 = out.get("same_matrix_as_cpu_baseline", out)
         out["cpu_baseline"]["gpu_over_cpu_same_matrix"] = round(ref18["GFLOPs"] / out["cpu_baseline"]["value"], 1)
+    # config 4 at its stated scale: one rank's slab of R-MAT scale 22 (needs most of the GPU: after everything else, when the time cap leaves a minute)
+    torch.cuda.empty_cache()
+    if scale != 18 and torch.cuda.mem_get_info()[0] >= 220 * 2**30 and budget_s - (time.perf_counter() - t_start) >= 45:
+        try:
+            out["c4_slab_of_8"] = _spgemm_c4_slabs(kk, torch, t_start, budget_s)
+        except Exception as e:
+            out["c4_slab_of_8"] = {"error": repr(e)[:200]}
+    else:
+        out["c4_slab_of_8"] = {"skipped": "time cap or memory"}
     return out
 
 

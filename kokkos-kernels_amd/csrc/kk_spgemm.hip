@@ -1394,17 +1394,38 @@ __device__ __forceinline__ long long unit_store_bytes(long long prod, long long 
   const long long lst = (prod * 4 + 15) & ~15ll;
   return lst < bm_bytes ? lst : bm_bytes;
 }
+// A row's structure is of use only when ALL its units keep theirs: room is given out row by row, in the class's order (heaviest rows first).
+// rbytes[r] = what row r's units take together ([nrows] = 0); after an exclusive scan, row r is kept when rbytes[r + 1] <= budget.
+__global__ __launch_bounds__(kBlock) void spgemm_unit_rowbytes_kernel(int64_t nrows, int nwin, const long long* __restrict__ uprod, long long bm_bytes, int keep_lists,
+                                                                     long long* __restrict__ rbytes /* [nrows + 1] */, unsigned char* __restrict__ rnone /* [nrows]: keeps nothing whatever the room */) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r > nrows) return;
+  long long sum = 0;
+  bool none = false;
+  if (r < nrows)
+    for (int w = 0; w < nwin; ++w) {
+      const long long prod = uprod[r * nwin + w];
+      if (prod > 0) { if (!keep_lists && prod * 4 <= bm_bytes) none = true; sum += unit_store_bytes(prod, bm_bytes); }   // (lists switched off: a row with a list unit keeps nothing)
+    }
+  rbytes[r] = none ? 0 : sum;
+  if (r < nrows) rnone[r] = none ? 1 : 0;
+}
 __global__ __launch_bounds__(kBlock) void spgemm_unit_ssize_kernel(int64_t n, const int32_t* __restrict__ ulist, const long long* __restrict__ uprod, long long bm_bytes,
-                                                                  long long* __restrict__ soff /* [n + 1] */) {
+                                                                  int nwin, const long long* __restrict__ rscan /* exclusive scan of rbytes */, const unsigned char* __restrict__ rnone, long long budget,
+                                                                  long long* __restrict__ soff /* [n + 1] */, unsigned char* __restrict__ drop /* [n]: the unit's row keeps nothing */) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) soff[i] = unit_store_bytes(uprod[ulist[i]], bm_bytes);
+  if (i < n) {
+    const int32_t u = ulist[i];
+    const bool keep = rscan[(int64_t)(u / nwin) + 1] <= budget && !rnone[u / nwin];
+    soff[i] = keep ? unit_store_bytes(uprod[u], bm_bytes) : 0; drop[i] = keep ? 0 : 1;
+  }
   if (i == n) soff[i] = 0;
 }
 // soff: exclusive prefix of the sizes.  Heads in launch order; per unit, for the numeric phase: uoff[unit] = (store offset << 1) | kind, or -1.
 // count[0] = units that leave a bitmap, count[1] = bytes of the store in use, count[2] = units without room
 template <class OffT>
 __global__ __launch_bounds__(kBlock) void spgemm_unit_heads_kernel(int64_t n, const int32_t* __restrict__ ulist, const long long* __restrict__ uprod, const long long* __restrict__ soff,
-                                                                  long long bm_bytes, long long budget, int keep_lists, int nwin, const int32_t* __restrict__ perm, const OffT* __restrict__ rmA,
+                                                                  long long bm_bytes, const unsigned char* __restrict__ drop, int nwin, const int32_t* __restrict__ perm, const OffT* __restrict__ rmA,
                                                                   UnitHead* __restrict__ heads, long long* __restrict__ uoff, unsigned long long* __restrict__ count) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   bool is_bm = false, none = false; long long used = 0;
@@ -1416,7 +1437,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_unit_heads_kernel(int64_t n, co
     UnitHead hd;
     hd.a_beg = (long long)rmA[row]; hd.n_lists = (int)((long long)rmA[row + 1] - hd.a_beg); hd.unit = u; hd.row = (int)row;
     hd.kind = prod * 4 > bm_bytes ? 1 : 0;
-    hd.store_off = (soff[i] + sz <= budget && (hd.kind == 1 || keep_lists)) ? soff[i] : -1;
+    hd.store_off = drop[i] ? -1 : soff[i];
     heads[i] = hd;
     uoff[u] = hd.store_off < 0 ? -1 : ((hd.store_off << 1) | (long long)hd.kind);
     is_bm = hd.store_off >= 0 && hd.kind == 1; none = hd.store_off < 0; used = hd.store_off >= 0 ? sz : 0;
@@ -3314,6 +3335,19 @@ static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hi
   return KKAMD_OK;
 }
 
+// the handle's second stream and its two events, created at first use; false when the runtime refuses
+static bool ensure_aux(kkamd_spgemm_handle* h) {
+  if (h->aux) return true;
+  if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    if (h->aux) { (void)hipStreamDestroy(h->aux); h->aux = nullptr; }
+    if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
+    if (h->ev_join) { (void)hipEventDestroy(h->ev_join); h->ev_join = nullptr; }
+    return false;
+  }
+  return true;
+}
 // The dense class of the symbolic phase by units (spgemm_sym_unit_kernel).  *ran = false: the prerequisites do not hold (B with unsorted
 // rows under more than one window, entries(B) not 16-byte aligned, fewer than four entries, more units than a grid holds, no memory
 // for the indices) and the caller takes the one-workgroup-per-row kernel.
@@ -3381,20 +3415,24 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   int rc;
   if ((rc = order_list_by_size(d_ul, nu, (const int64_t*)d_up, st, later))) return rc;        // heaviest units first
   // where every unit's structure goes: a prefix sum over min(4 products, bitmap bytes); the store is at most 0.225 of the free HBM (an eighth
-  // for bitmaps and a tenth for lists until round 5), units past it keep nothing (the lightest: they come last) and their rows walk
-  // their products again in the numeric phase
+  // for bitmaps and a tenth for lists until round 5).  Room is given out by ROW, heaviest rows first (a row's structure is of use only when
+  // all its units keep theirs): the rows past it keep nothing and walk their products again in the numeric phase
   const int64_t win_cols = nwin > 1 ? ((int64_t)1 << wb) : k;
   const int words = (int)ceil_div(win_cols, (int64_t)64);
   const int bm_words = (words + 15) & ~15;
   const long long bm_bytes = (long long)words * 8;
   long long budget = 0, total_need = 0;
-  KK_HIP(soff_b.alloc(sizeof(long long) * (size_t)(nu + 1 + scan_workspace_items(nu + 1))));
+  const int64_t so_items = nu + 1 + scan_workspace_items(nu + 1), rb_items = nrows + 1 + scan_workspace_items(nrows + 1);
+  KK_HIP(soff_b.alloc(sizeof(long long) * (size_t)(so_items + rb_items) + (size_t)nu + (size_t)nrows));
   long long* d_so = soff_b.as<long long>();
+  long long* d_rb = d_so + so_items;
+  unsigned char* d_drop = reinterpret_cast<unsigned char*>(d_rb + rb_items);
+  unsigned char* d_rnone = d_drop + nu;
   if (hipMalloc((void**)&h->d_heads, sizeof(UnitHead) * (size_t)nu) != hipSuccess) { (void)hipGetLastError(); free_bitmap_store(h); return KKAMD_OK; }
-  KK_LAUNCH(spgemm_unit_ssize_kernel, (unsigned)ceil_div(nu + 1, kBlock), kBlock, 0, st, nu, (const int32_t*)d_ul, (const long long*)d_up, bm_bytes, d_so);
-  if ((rc = exclusive_scan_inplace<long long>(d_so, nu + 1, st, d_so + nu + 1))) return rc;
+  KK_LAUNCH(spgemm_unit_rowbytes_kernel, (unsigned)ceil_div(nrows + 1, kBlock), kBlock, 0, st, nrows, nwin, (const long long*)d_up, bm_bytes, g_spgemm.keep_lists, d_rb, d_rnone);
+  if ((rc = exclusive_scan_inplace<long long>(d_rb, nrows + 1, st, d_rb + nrows + 1))) return rc;
   if (g_spgemm.keep_bitmaps && k >= 64) {
-    KK_HIP(hipMemcpyAsync(&total_need, d_so + nu, sizeof(long long), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipMemcpyAsync(&total_need, d_rb + nrows, sizeof(long long), hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
     size_t want = (size_t)((double)(free_b + pooled) * 0.225);
@@ -3403,10 +3441,13 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
     const size_t got = want ? take_bitmap_store(h, want) : 0;
     budget = (long long)got;
   }
+  KK_LAUNCH(spgemm_unit_ssize_kernel, (unsigned)ceil_div(nu + 1, kBlock), kBlock, 0, st, nu, (const int32_t*)d_ul, (const long long*)d_up, bm_bytes, nwin,
+            (const long long*)d_rb, (const unsigned char*)d_rnone, budget, d_so, d_drop);
+  if ((rc = exclusive_scan_inplace<long long>(d_so, nu + 1, st, d_so + nu + 1))) return rc;
   lap("order, sizes, store");
   UnitHead* d_hd = h->d_heads;
   KK_LAUNCH((spgemm_unit_heads_kernel<OffT>), (unsigned)ceil_div(nu, kBlock), kBlock, 0, st, nu, (const int32_t*)d_ul, (const long long*)d_up, (const long long*)d_so,
-            bm_bytes, budget, g_spgemm.keep_lists, nwin, d_perm_u, rmA, d_hd, h->d_uoff, d_cnt + 1);
+            bm_bytes, (const unsigned char*)d_drop, nwin, d_perm_u, rmA, d_hd, h->d_uoff, d_cnt + 1);
   char* d_store = (char*)h->d_bm_store;
   unsigned* d_uc = h->d_ucnt;
 #ifndef KK_EMU
@@ -3569,13 +3610,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
       else if (g_spgemm.quad_rows == 1 && (rc = split_list_by_size<OffT>(wlist, nb(1), rmA, (const int64_t*)h->d_sizes, (int64_t)kQuadFlops, &nq, st))) return rc;
     }
     if (nb(4) && (nb(1) || nb(2) || nb(3))) {
-      if (!h->aux && (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)) {
-        (void)hipGetLastError();
-        if (h->aux) { (void)hipStreamDestroy(h->aux); h->aux = nullptr; }
-        if (h->ev_fork) { (void)hipEventDestroy(h->ev_fork); h->ev_fork = nullptr; }
-      }
-      if (h->aux && hipEventRecord(h->ev_fork, st) == hipSuccess && hipStreamWaitEvent(h->aux, h->ev_fork, 0) == hipSuccess) { sx = h->aux; forked = true; }
+      if (ensure_aux(h) && hipEventRecord(h->ev_fork, st) == hipSuccess && hipStreamWaitEvent(h->aux, h->ev_fork, 0) == hipSuccess) { sx = h->aux; forked = true; }
       else (void)hipGetLastError();
     }
     if (nb(1)) {
@@ -3861,6 +3896,14 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
                                                         BitmapStore(), win_cap);
     return KKAMD_OK;
   };
+  auto emit_units = [&](hipStream_t sq, int) {
+    const UnitHead* d_hd = h->d_heads; const int32_t* d_ur = h->d_row_slot; const unsigned* d_uc = h->d_ucnt; const unsigned* d_co = h->d_ucoff;
+    const char* d_st = (const char*)h->d_bm_store;
+    const int64_t min_nnz = (h->dense_lds ? kNumLimitsSorted : kNumLimits).lim[3];
+#define KK_EMIT_UNIT(NTT) KK_LAUNCH((spgemm_emit_unit_kernel<OffT, NTT>), (unsigned)h->n_heads, NTT, 0, sq, d_hd, d_ur, h->unit_nwin, h->unit_wb, k, d_uc, d_co, d_st, rmC, entC, min_nnz)
+    if (h->unit_wb <= 18) KK_EMIT_UNIT(256); else if (h->unit_wb == 19) KK_EMIT_UNIT(512); else KK_EMIT_UNIT(1024);
+#undef KK_EMIT_UNIT
+  };
   if (nb(4)) {
     const int32_t* dperm = h->d_perm + off.off[4];
     // entries(C) of every dense row, column-sorted
@@ -3882,12 +3925,9 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
       }
       const int64_t ns = h->n_emit_stored, nr = nb(4) - ns;
       if (ns && h->n_heads) {
-        const UnitHead* d_hd = h->d_heads; const int32_t* d_ur = h->d_row_slot; const unsigned* d_uc = h->d_ucnt; const unsigned* d_co = h->d_ucoff;
-        const char* d_st = (const char*)h->d_bm_store;
-        const int64_t min_nnz = (h->dense_lds ? kNumLimitsSorted : kNumLimits).lim[3];
-#define KK_EMIT_UNIT(NTT) KK_LAUNCH((spgemm_emit_unit_kernel<OffT, NTT>), (unsigned)h->n_heads, NTT, 0, st, d_hd, d_ur, h->unit_nwin, h->unit_wb, k, d_uc, d_co, d_st, rmC, entC, min_nnz)
-        if (h->unit_wb <= 18) KK_EMIT_UNIT(256); else if (h->unit_wb == 19) KK_EMIT_UNIT(512); else KK_EMIT_UNIT(1024);
-#undef KK_EMIT_UNIT
+        // (Measured and not kept: the units of the column-block rows first and the others' on the second stream beside the column-block value kernels --
+        // the two 13 ms halves overlapped, and the value kernel beside the second took 26.3 instead of 13.5 ms: both live on the memory system.)
+        emit_units(st, -1);
       }
       if (nr && (rc = emit_walk(nr, h->d_emit_perm + ns, (int64_t)g_spgemm.emit_win_bits))) return rc;
       h->bitmaps_used = ns; h->pooled_used = h->n_emit_pooled;

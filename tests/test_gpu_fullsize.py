@@ -202,6 +202,82 @@ def test_spgemm_rmat_s20_without_a_host_copy_of_c(be):
           % (nnz, rel1, rel2))
 
 
+def test_c4_slabs_of_8_rmat_s22(be):
+    """BASELINE config 4 AS SPECIFIED -- C = A*A on R-MAT scale 22, edge factor 16 -- at its stated scale on one GPU: the product does not fit a
+    GPU (nnz(C) = 7.2e10 = 863 GB), one rank's slab of the 8-GPU row partition does (rows of C are independent given all of B; B
+    replicated).  kkamd_dist_spgemm_partition(world = 8) cuts A into slabs of near-equal multiplications; the slab with the FEWEST rows (the
+    hub rows: densest rows of C) and the one with the MOST rows (the largest slab of C: 10.6e9 entries, 127 GB) go through
+    kkamd_dist_spgemm_symbolic / _numeric.  Checked per slab: (1) row_map bit-exact against the OpenMP KKMEM symbolic kernel of the oracle on those
+    rows; (2) every row strictly ascending, columns inside [0, k); (3) C_slab x == A_slab (A x) for a positive and a mixed-sign probe (ties every
+    value to its column); (4) numeric again on the same operator with new values of the slab (reuse: entries untouched, C' x == A' (A x))."""
+    import torch
+    from kokkos_kernels_amd.dist import DistSpgemm
+    if torch.cuda.mem_get_info()[0] < 200 * 2**30:
+        pytest.skip("needs 200 GB of free HBM")
+    world = 8
+    R = oracle.rmat(22, 16)
+    A = pc.dev(be, R, offset_dtype=np.int64)
+    offsets, mults = DistSpgemm.partition(A, A, world)
+    assert offsets[0] == 0 and offsets[-1] == R.nrows and all(b > a for a, b in zip(offsets, offsets[1:]))
+    tot = oracle.spgemm_mults(R, R)[0]
+    assert sum(mults) == tot and max(mults) <= 1.02 * tot / world, (mults, tot)          # balanced by multiplications (contiguous slabs: to within one row's products)
+    rows = [offsets[r + 1] - offsets[r] for r in range(world)]
+    rng = np.random.default_rng(22)
+    x = 0.5 + rng.random(R.ncols)
+    xs = (0.5 + rng.random(R.ncols)) * np.where(rng.random(R.ncols) < 0.5, -1.0, 1.0)
+    ax = oracle.spmv_omp(R.row_map, R.entries, R.values, 1.0, x, 0.0, np.zeros(R.nrows))            # B = A
+    axs = oracle.spmv_omp(R.row_map, R.entries, R.values, 1.0, xs, 0.0, np.zeros(R.nrows))
+    axa = oracle.spmv_omp(R.row_map, R.entries, R.values, 1.0, np.abs(xs), 0.0, np.zeros(R.nrows))
+    xd, xsd = torch.from_numpy(x).cuda(), torch.from_numpy(xs).cuda()
+    for rank in (int(np.argmin(rows)), int(np.argmax(rows))):
+        o0, o1 = offsets[rank], offsets[rank + 1]
+        e0, e1 = int(R.row_map[o0]), int(R.row_map[o1])
+        S = oracle.Crs(o1 - o0, R.ncols, (R.row_map[o0:o1 + 1] - R.row_map[o0]).copy(), R.entries[e0:e1], R.values[e0:e1])
+        Sd = pc.kk.CrsMatrix(S.nrows, S.ncols, (A.graph.row_map[o0:o1 + 1] - A.graph.row_map[o0]).contiguous(), A.graph.entries[e0:e1], A.values[e0:e1], backend=be)
+        op = DistSpgemm(offsets, rank, be)
+        Cd = op.symbolic(Sd, A)
+        assert op.query("rows_local") == S.nrows and op.query("mults_local") == mults[rank]
+        rm_gold = oracle.spgemm_symbolic_kkmem_omp(S, R)
+        assert Cd.nnz() == int(rm_gold[-1]) == op.query("c_nnz_local"), (rank, Cd.nnz(), int(rm_gold[-1]))
+        assert torch.equal(Cd.graph.row_map.cpu(), torch.from_numpy(rm_gold)), "rank %d: row_map differs from the KKMEM symbolic kernel's" % rank
+        op.numeric(Sd, A, Cd)
+        ent, rm, nnz = Cd.graph.entries, Cd.graph.row_map, Cd.nnz()
+        lo = int(ent.min().item()); hi = int(ent.max().item())
+        assert lo >= 0 and hi < R.ncols, (lo, hi)
+        starts = torch.zeros(nnz + 1, dtype=torch.bool, device="cuda")
+        starts[rm] = True
+        for s0 in range(0, nnz - 1, 1 << 28):                                 # chunked: no 40-GB temporaries
+            e = min(nnz - 1, s0 + (1 << 28))
+            assert bool(((ent[s0 + 1:e + 1] > ent[s0:e]) | starts[s0 + 1:e + 1]).all().item()), "rank %d: a row of C is not strictly ascending near entry %d" % (rank, s0)
+        del starts
+
+        def check(Sh, tag):
+            gold = oracle.spmv_omp(Sh.row_map, Sh.entries, Sh.values, 1.0, ax, 0.0, np.zeros(Sh.nrows))
+            yd = torch.full((Sh.nrows,), float("nan"), dtype=torch.float64, device="cuda")
+            pc.kk.spmv("N", 1.0, Cd, xd, 0.0, yd)
+            got = yd.cpu().numpy()
+            den = np.abs(gold) + np.abs(got)
+            rel = float((np.abs(got - gold) / np.where(den > 0, den, 1.0)).max())
+            assert rel <= 1e-12, "rank %d %s: C x differs from A (A x): max rel %g" % (rank, tag, rel)
+            golds = oracle.spmv_omp(Sh.row_map, Sh.entries, Sh.values, 1.0, axs, 0.0, np.zeros(Sh.nrows))
+            norm = oracle.spmv_omp(Sh.row_map, Sh.entries, Sh.values, 1.0, axa, 0.0, np.zeros(Sh.nrows))      # sum_j |C_ij| |x_j|
+            pc.kk.spmv("N", 1.0, Cd, xsd, 0.0, yd)
+            rels = float((np.abs(yd.cpu().numpy() - golds) / np.where(norm > 0, norm, 1.0)).max())
+            assert rels <= 1e-12, "rank %d %s: mixed-sign probe: max error relative to the row norm %g" % (rank, tag, rels)
+            return max(rel, rels)
+        rel1 = check(S, "numeric")
+        ent_sum = int(ent[::1009].to(torch.int64).sum().item())
+        S2 = oracle.Crs(S.nrows, S.ncols, S.row_map, S.entries, 1.0 + 49.0 * rng.random(S.nnz))
+        Sd2 = pc.kk.CrsMatrix(S.nrows, S.ncols, Sd.graph.row_map, Sd.graph.entries, torch.from_numpy(S2.values).cuda(), backend=be)
+        op.numeric(Sd2, A, Cd)
+        assert int(Cd.graph.entries[::1009].to(torch.int64).sum().item()) == ent_sum, "rank %d: numeric reuse changed entries(C)" % rank
+        rel2 = check(S2, "numeric reuse")
+        print("C4 slab %d of %d (R-MAT s22): %d rows, %d multiplications, nnz(C) %d (%.1f GB): row_map identical to the KKMEM symbolic kernel, rows ascending, C x vs A (A x) %.2e / %.2e (reuse)"
+              % (rank, world, S.nrows, mults[rank], nnz, nnz * 12e-9, rel1, rel2))
+        del Cd, op, Sd, Sd2, ent, rm
+        torch.cuda.empty_cache()
+
+
 def _check_unstructured(be, A0, name, expect_codes=None):
     import torch
     rng = np.random.default_rng(3)
