@@ -117,8 +117,6 @@ struct SpgemmTuning {
                                   // kQuadNnz entries (the bin's list is split when it mixes sizes; 7-pt FD 150^3: symbolic 3.54 -> 1.94 ms, numeric 4.24 -> 1.97), 2 = for every row of the
                                   // bin (waves with a larger row do their four rows one after the other: 27-pt FE 100^3 numeric 4.04 -> 5.03 ms, which is why 1 is the default), 0 = never
   int emit_sort      = 1;         // entries(C) of the dense-bin rows with at most kEmitSortCap products: sorted in LDS, 256 work-items per row (0 = the bitmap kernel)
-  int val_steps      = 0;         // the flat value kernel's product walk: 0 = vector walk (units of eight entries of one list, 16-byte loads; default: R-MAT scale 20 reuse
-                                  // 159.7 -> 149.4 ms), 1..3 = scalar walk with that many steps of a window in flight
   int val_mid        = 1;         // A rows of kValLa + 1 .. kValLa2 entries through the flat value kernel's 1024-list shape (0 = the hub kernel)
   int hub_chunked    = 1;         // A rows above kHubLa entries: 1 = the LDS hub value kernel in passes of kHubLa entries, 0 = L2 atomics into a k-wide HBM accumulator
   int col_quads      = 4;         // dense-row bitmap kernels read entries(B) as aligned 16-byte quads, 4 or 8 per work-item and step (0 = one 4-byte load per product)
@@ -1326,7 +1324,9 @@ __global__ __launch_bounds__(kBlock) void spgemm_copy_pool_kernel(const int32_t*
 #define KK_UQ 4
 #endif
 constexpr int kUnitNT = 256;
-constexpr int kUnitBitsMax = 20;                                              // 2^18 columns = 32 KB of bitmap for 256 work-items; 2^19 / 2^20: workgroups of 512 / 1024
+constexpr int kUnitBitsMax = 18;                                              // 2^18 columns = 32 KB of bitmap for 256 work-items: four workgroups per CU
+// (Measured and not kept: windows of 2^19 / 2^20 columns around workgroups of 512 / 1024 -- R-MAT scale 20 symbolic 39.1 / 48.7 ms against 40.0, scale 18 6.2 / 8.0
+// against 5.4; the template takes the workgroup size, only 256 is instantiated.)
 __host__ __device__ constexpr int unit_bits_of(int nt) { return nt >= 1024 ? 20 : (nt >= 512 ? 19 : 18); }
 struct alignas(16) UnitHead {
   long long a_beg;          // first entry of the row of A
@@ -3214,7 +3214,7 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
     KK_LAUNCH((spgemm_dense_cols_kernel<OffT, EMIT, QQ>), (unsigned)nrows, kDenseBlock, smem, st, perm, rmA, entA, rmB, entB, counts,  \
               rmC, entC, k, (int)win, sg, g_spgemm.emit_chunked, endB, maskB, quads, bs KK_DBG_ARG);                                  \
   } while (0)
-  if (g_spgemm.col_quads == 8) KK_DC(8); else KK_DC(4);
+  KK_DC(4);                                                   // (8 quads per work-item and step measured slower, 72.3 against 71.1 ms in round 4: not instantiated any more)
 #undef KK_DC
 #undef KK_DC_ATTR
   return KKAMD_OK;
@@ -3364,7 +3364,6 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   int wb = g_spgemm.unit_bits;
   if (wb > kUnitBitsMax) wb = kUnitBitsMax;
   if (wb < 6) wb = 6;
-  const int nt = wb <= 18 ? 256 : (wb == 19 ? 512 : 1024);
   const int64_t nwin64 = ceil_div(k, (int64_t)1 << wb);
   const int64_t nnzA = h->nnzA;
   if (!g_spgemm.sym_units || nnzB < 4 || ((uintptr_t)entB % 16) != 0 || nrows <= 0 || nrows >= ((int64_t)1 << 30)) return KKAMD_OK;
@@ -3462,7 +3461,7 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
               (const long long*)d_aw, entB, nnzB, rmC, d_uc, d_store, bm_words KK_DBG_ARG);                                                                 \
   } while (0)
   lap("heads");
-  if (nt == 256) KK_UNIT(256); else if (nt == 512) KK_UNIT(512); else KK_UNIT(1024);
+  KK_UNIT(256);
   lap("unit kernel");
 #undef KK_UNIT
 #undef KK_UNIT_ATTR
@@ -3901,7 +3900,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     const char* d_st = (const char*)h->d_bm_store;
     const int64_t min_nnz = (h->dense_lds ? kNumLimitsSorted : kNumLimits).lim[3];
 #define KK_EMIT_UNIT(NTT) KK_LAUNCH((spgemm_emit_unit_kernel<OffT, NTT>), (unsigned)h->n_heads, NTT, 0, sq, d_hd, d_ur, h->unit_nwin, h->unit_wb, k, d_uc, d_co, d_st, rmC, entC, min_nnz)
-    if (h->unit_wb <= 18) KK_EMIT_UNIT(256); else if (h->unit_wb == 19) KK_EMIT_UNIT(512); else KK_EMIT_UNIT(1024);
+    KK_EMIT_UNIT(256);
 #undef KK_EMIT_UNIT
   };
   if (nb(4)) {
@@ -3978,18 +3977,8 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     else if ((rc = emit_walk(nb(4), dperm, (int64_t)0))) return rc;
 #define KK_VALS2(HH, NTT, GG, LAA, GRID, PERM, CAP)                                                                                     \
   do {                                                                                                                                  \
-    if (g_spgemm.val_steps == 0)                                                                                                        \
-      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 0>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
-                rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                             \
-    else if (g_spgemm.val_steps == 3)                                                                                                        \
-      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 3>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
-                rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                                                                        \
-    else if (g_spgemm.val_steps == 2)                                                                                                   \
-      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 2>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
-                rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                                                                        \
-    else                                                                                                                                \
-      KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 1>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
-                rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                                                                        \
+    KK_LAUNCH((spgemm_dense_vals2_kernel<OffT, VT, HH, NTT, GG, LAA, 0>), (unsigned)(GRID), NTT, 0, st, PERM, rmA, entA, valA, rmB, entB, valB, \
+              rmC, (const int32_t*)entC, valC, (CAP) | (g_spgemm.nt ? (1 << 30) : 0), h->nnzB KK_DBG_ARG);                             \
   } while (0)
     const int64_t n_blk = h->n_dense_block;
     const int64_t n_lds = h->n_dense_lds; int64_t n_hubl = h->n_dense_hub_lds, n_hub = nb(4) - n_blk - n_lds - n_hubl;
@@ -4260,7 +4249,7 @@ int spgemm_set_default(const char* key, int value) {
 #endif
   else if (k == "spgemm_val_shape") g_spgemm.val_shape = value;
   else if (k == "spgemm_val_hub_flat") g_spgemm.val_hub_flat = value != 0;
-  else if (k == "spgemm_col_quads") { if (value != 0 && value != 1 && value != 4 && value != 8) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_col_quads: %d is not 0, 4 or 8", value); g_spgemm.col_quads = value == 1 ? 4 : value; }
+  else if (k == "spgemm_col_quads") { if (value != 0 && value != 1 && value != 4) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_col_quads: %d is not 0 or 4", value); g_spgemm.col_quads = value == 1 ? 4 : value; }
   else if (k == "spgemm_hub_chunked") g_spgemm.hub_chunked = value != 0;
   else if (k == "spgemm_val_mid") g_spgemm.val_mid = value != 0;
   else if (k == "spgemm_keep_bitmaps") g_spgemm.keep_bitmaps = value != 0;
@@ -4281,7 +4270,6 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_block_min_pct") { if (value < 0 || value > 100) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_min_pct: 0 .. 100"); g_spgemm.block_min_pct = value; }
   else if (k == "spgemm_block_la_pct") { if (value < 0 || value > 100) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_block_la_pct: 0 .. 100"); g_spgemm.block_la_pct = value; }
   else if (k == "spgemm_quad_rows") { if (value < 0 || value > 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_quad_rows: %d is not 0, 1 or 2", value); g_spgemm.quad_rows = value; }
-  else if (k == "spgemm_val_steps") { if (value < 0 || value > 3) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_steps: %d is not 0 (vector walk), 1, 2 or 3", value); g_spgemm.val_steps = value; }
   else if (k == "spgemm_val_small_cnt") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_val_small_cnt: %d is negative", value); g_spgemm.val_small_cnt = value; }
   else if (k == "spgemm_emit_staged") g_spgemm.emit_staged = value != 0;
   else if (k == "spgemm_sym_large") g_spgemm.sym_large = value != 0;

@@ -36,7 +36,7 @@ def run(be, budget, seed0=0, max_cases=None, kinds=None):
         vdt = np.float32 if rng.random() < 0.3 else np.float64
         if kind in (0, 1, 2, 6):    # SpGEMM kinds: the column-block class under random block widths, item capacities and forms (round 5)
             spgemm_knobs = {b"spgemm_block_w": int(rng.choice([64, 256, 1024, 16384, 16384])), b"spgemm_item_cap": int(rng.choice([64, 300, 6144, 6144])),
-                            b"spgemm_items": int(rng.choice([0, 1, 1])), b"spgemm_block_min_pct": int(rng.choice([1, 4, 20])), b"spgemm_val_steps": int(rng.choice([0, 0, 1]))}
+                            b"spgemm_items": int(rng.choice([0, 1, 1])), b"spgemm_block_min_pct": int(rng.choice([1, 4, 20])), b"spgemm_unit_bits": int(rng.choice([8, 11, 14, 18, 18]))}
             for k_, v_ in spgemm_knobs.items(): kk._capi.check(be.lib, be.lib.kkamd_set_default(k_, v_))
         try:
             if kind == 0:      # SpGEMM, skewed: few long rows of A against hub rows of B
@@ -133,7 +133,7 @@ def run(be, budget, seed0=0, max_cases=None, kinds=None):
             raise
         finally:
             if kind in (0, 1, 2, 6):
-                for k_, v_ in ((b"spgemm_block_w", 16384), (b"spgemm_item_cap", 6144), (b"spgemm_items", 1), (b"spgemm_block_min_pct", 4), (b"spgemm_val_steps", 0)):
+                for k_, v_ in ((b"spgemm_block_w", 16384), (b"spgemm_item_cap", 6144), (b"spgemm_items", 1), (b"spgemm_block_min_pct", 4), (b"spgemm_unit_bits", 18)):
                     kk._capi.check(be.lib, be.lib.kkamd_set_default(k_, v_))
     return n_ok, per_kind, seed0 + case - 1
 

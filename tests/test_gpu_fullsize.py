@@ -212,6 +212,9 @@ def test_c4_slabs_of_8_rmat_s22(be):
     value to its column); (4) numeric again on the same operator with new values of the slab (reuse: entries untouched, C' x == A' (A x))."""
     import torch
     from kokkos_kernels_amd.dist import DistSpgemm
+    import gc
+    gc.collect(); torch.cuda.empty_cache()                                   # (the tests before this one leave 100+ GB in torch's cache and the library's store of the last product)
+    pc.kk._capi.check(be.lib, be.lib.kkamd_release_scratch())
     if torch.cuda.mem_get_info()[0] < 200 * 2**30:
         pytest.skip("needs 200 GB of free HBM")
     world = 8
