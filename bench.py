@@ -257,7 +257,7 @@ def _spgemm_case(kk, torch, scale, t_start, budget_s, reps=3):
     R = oracle.rmat(scale, 16)
     M = kk.CrsMatrix.from_host(R.nrows, R.ncols, R.row_map, R.entries, R.values, offset_dtype=np.int64)
     sync = torch.cuda.synchronize
-    runs = []
+    runs = []; warm = []
     WARM = 2        # not counted: the first use of every kernel, and the product after it -- the library returns its store of bitmaps / entry lists
                     # to the device with a process's first product and keeps it once the process comes back for more (a hipMalloc of GBs after a
                     # hipFree stalls for a second every other time on this runtime: profiles/round5/probe_malloc.txt)
@@ -272,6 +272,7 @@ def _spgemm_case(kk, torch, scale, t_start, budget_s, reps=3):
         sync(); t3 = time.perf_counter()
         sh = kh.get_spgemm_handle(); mults = sh.get(1); nnzC = Cm.nnz(); nblk_rows = sh.get(16)
         if rep >= WARM: runs.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+        else: warm.append([round((t1 - t0) * 1e3, 3), round((t2 - t1) * 1e3, 3), round((t3 - t2) * 1e3, 3)])
         kh.destroy_spgemm_handle(); del Cm
         if runs and time.perf_counter() - t_start > budget_s: break
     sym, num, reuse = (sum(r[i] for r in runs) / len(runs) for i in range(3))
@@ -283,6 +284,9 @@ def _spgemm_case(kk, torch, scale, t_start, budget_s, reps=3):
            "min_ms": {"symbolic": round(min(r[0] for r in runs), 3), "numeric": round(min(r[1] for r in runs), 3), "numeric_reuse": round(min(r[2] for r in runs), 3)},
            "GFLOPs": round(2.0 * mults / (sym + num) / 1e6, 1), "numeric_GFLOPs": round(2.0 * mults / num / 1e6, 1),
            "rows_through_column_block_kernel": nblk_rows,
+           "first_two_products_of_the_process_ms": {"what": "[symbolic, numeric, numeric reuse] of the two warm-up products: the first loads the code objects and sizes the "
+                                                     "library's store of kept structure, the second may pay the runtime's slow hipMalloc after the store was returned "
+                                                     "(knob spgemm_pool_keep; profiles/round5/probe_malloc.txt)", "products": warm},
            "roofline": {"bound": "hbm", "model": "gather model, SURVEY 8(d)", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "symbolic": {"bytes": b_sym, "achieved": round(b_sym / sym / 1e6, 1), "frac": round(b_sym / sym / 1e6 / HBM_PEAK_GBPS, 4)},
                         "numeric": {"bytes": b_num, "achieved": round(b_num / num / 1e6, 1), "frac": round(b_num / num / 1e6 / HBM_PEAK_GBPS, 4)},
@@ -430,7 +434,7 @@ def main():
                          "tests/emu, a tiny grid -- to exercise the multi-process control flow without GPUs (numbers are meaningless)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1, halo exchange: do not split the slab into interior / boundary rows (no compute-communication overlap)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "halo_set", "allgather", "allgather_p2p"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "halo", "halo_set", "allgather", "allgather_collective", "allgather_p2p"],
                     help="N > 1: how the x entries a slab references reach it (auto = column-range halo when it is smaller)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -571,7 +575,7 @@ def main():
         # every exchange the library has, side by side: the column-range halo, the column-set halo, the all-gather through the
         # collective and the all-gather by peer-to-peer pulls (the fallback if RCCL's schedule is a ring; it maps
         # device memory between processes, so not under --emulate)
-        for other in ("halo", "halo_set", "allgather") + (() if emu else ("allgather_p2p",)):
+        for other in ("halo", "halo_set", "allgather", "allgather_collective") + (() if emu else ("allgather_p2p",)):
             if other in ops: continue
             o_new, ok_ = None, 1.0
             try:
@@ -596,6 +600,9 @@ def main():
             all_reduce_(tt, RED_MAX)
             xchg[name] = {"step_ms": round(tt[0].item(), 5), "exchange_only_ms": round(tt[1].item(), 5), "local_spmv_only_ms": round(tt[2].item(), 5),
                           "bytes_received_per_gpu": o.exchange_bytes, "aggregate_GFLOPs": round(2.0 * nnz_global / (tt[0].item() * 1e-3) / 1e9, 1)}
+            if name == "allgather":          # the operator's own choice among its all-gather forms, and the times it was made on
+                xchg[name]["form_chosen"] = ("collective", "send_receive", "p2p_pulls")[o.allgather_form] if o.allgather_form >= 0 else None
+                xchg[name]["form_us_at_creation"] = o.allgather_us
         ops.clear()
 
     # ---- sanity inside the bench: A*1 over the slab must be the row-sum vector (0 interior, 1 boundary) ----

@@ -34,6 +34,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <chrono>
+#include <cstring>
 #include <vector>
 #ifndef KK_EMU
 #include <dlfcn.h>
@@ -173,6 +175,12 @@ struct kkamd_dist_spmv {
   std::vector<hipStream_t> p2p_stream; std::vector<hipEvent_t> p2p_event;
   hipEvent_t ev_b1 = nullptr;
   void* d_tok = nullptr;
+  // all-gather (mode 2 / 3): the form in use -- 0 the transport's collective, 1 every shard to every peer point to point (the transport's
+  // send / receive groups), 2 peer-to-peer pulls of mapped memory -- and what one exchange of each form took when the operator timed them
+  // at its creation (exchange 5; microseconds, maximum over the ranks; -1: not available / not timed)
+  int ag_form = 0;
+  double ag_us[3] = {-1.0, -1.0, -1.0};
+  bool ag_selected = false;
   struct Part { kkamd_crs_t A{}; kkamd_spmv_plan_t* plan = nullptr; void* d_rm = nullptr; int64_t row0 = 0; };
   std::vector<Part> parts;                   // whole slab, or interior first and then the boundary parts
 };
@@ -195,6 +203,33 @@ static void dist_free(kkamd_dist_spmv* op) {
   if (op->comm_stream) (void)hipStreamDestroy(op->comm_stream);
   if (op->own_comm && op->rccl_ctx.comm && rccl().ok) (void)rccl().CommDestroy(op->rccl_ctx.comm);
   delete op;
+}
+
+// One all-gather of the x shards in the given form, queued on the communication stream cs (see kkamd_dist_spmv::ag_form).
+static int dist_allgather(kkamd_dist_spmv* op, int form, const void* x_local, int64_t mrows, hipStream_t cs) {
+  kkamd_stream_t kcs = reinterpret_cast<kkamd_stream_t>(cs);
+  if (form == 2) {
+    // barrier (every shard is in place), world - 1 concurrent pulls on their own streams, barrier (nobody still reads a shard)
+    char* tok = (char*)op->d_tok;
+    int rc = op->tr.all_gather(op->tr.ctx, tok, tok + 8, 8, kcs);
+    if (rc) return rc;
+    KK_HIP(hipEventRecord(op->ev_b1, cs));
+    size_t q = 0;
+    for (int p = 0; p < op->world; ++p) {
+      if (p == op->rank) continue;
+      const int64_t off = (int64_t)op->elem * op->offsets[p], len = (int64_t)op->elem * (op->offsets[p + 1] - op->offsets[p]);
+      hipStream_t s2 = op->p2p_stream[q];
+      KK_HIP(hipStreamWaitEvent(s2, op->ev_b1, 0));
+      if (len > 0) KK_HIP(hipMemcpyAsync((char*)op->d_x_full + off, (const char*)op->peer_x[(size_t)p] + off, (size_t)len, hipMemcpyDeviceToDevice, s2));
+      KK_HIP(hipEventRecord(op->p2p_event[q], s2));
+      KK_HIP(hipStreamWaitEvent(cs, op->p2p_event[q], 0));
+      ++q;
+    }
+    return op->tr.all_gather(op->tr.ctx, tok, tok + 8, 8, kcs);
+  }
+  if (form == 0 && op->equal) return op->tr.all_gather(op->tr.ctx, x_local, op->d_x_full, (int64_t)op->elem * mrows, kcs);
+  return op->tr.exchange(op->tr.ctx, (int)op->send_peer.size(), op->send_ptr.data(), op->send_bytes.data(), op->send_peer.data(),
+                         (int)op->recv_peer.size(), op->recv_ptr.data(), op->recv_bytes.data(), op->recv_peer.data(), kcs);
 }
 
 template <class OffT>
@@ -297,24 +332,26 @@ static int dist_setup(kkamd_dist_spmv* op, int exchange, int overlap, hipStream_
   // auto: the range halo when it moves less than half of the all-gather (contiguous pieces straight into x, no pack / scatter
   // kernels); else the set halo when THAT moves less than half of the all-gather; else the all-gather
   int chosen = exchange;
-  if (exchange == 0) chosen = frac < 0.5 ? 1 : (sfrac < 0.5 ? 4 : 2);
-  if (chosen == 2 || chosen == 3) {
-    op->mode = chosen; op->exchange_bytes = full_bytes;
+  if (exchange == 0) chosen = frac < 0.5 ? 1 : (sfrac < 0.5 ? 4 : 5);     // (an all-gather picks its own form: exchange 5)
+  if (chosen == 2 || chosen == 3 || chosen == 5) {
+    op->exchange_bytes = full_bytes;
     op->send_ptr.clear(); op->send_bytes.clear(); op->send_peer.clear(); op->recv_ptr.clear(); op->recv_bytes.clear(); op->recv_peer.clear();
-    if (chosen == 2 && !op->equal) {                           // unequal shards: every shard to every peer, point to point
-      for (int p = 0; p < world; ++p) {
-        if (p == me) continue;
-        op->send_ptr.push_back(xf + es * me0); op->send_bytes.push_back(es * (me1 - me0)); op->send_peer.push_back(p);
-        op->recv_ptr.push_back(xf + es * op->offsets[p]); op->recv_bytes.push_back(es * (op->offsets[p + 1] - op->offsets[p])); op->recv_peer.push_back(p);
-      }
+    // every shard to every peer, point to point (what unequal shards always use, and one of the forms exchange 5 times)
+    for (int p = 0; p < world; ++p) {
+      if (p == me) continue;
+      op->send_ptr.push_back(xf + es * me0); op->send_bytes.push_back(es * (me1 - me0)); op->send_peer.push_back(p);
+      op->recv_ptr.push_back(xf + es * op->offsets[p]); op->recv_bytes.push_back(es * (op->offsets[p + 1] - op->offsets[p])); op->recv_peer.push_back(p);
     }
-    if (chosen == 3) {
-#ifdef KK_EMU
-      return fail(KKAMD_ERR_UNSUPPORTED, "kkamd_dist: the peer-to-peer all-gather maps device memory between processes (hipIpc): not under the emulator");
-#else
-      // every rank's x buffer, mapped once: 64-byte handles through the transport
-      hipIpcMemHandle_t mine;
-      KK_HIP(hipIpcGetMemHandle(&mine, op->d_x_full));
+    op->ag_form = chosen == 3 ? 2 : (op->equal ? 0 : 1);
+    op->mode = chosen == 3 ? 3 : 2;
+    bool p2p_ok = false;
+#ifndef KK_EMU
+    if (chosen == 3 || (chosen == 5 && world > 1)) {
+      // every rank's x buffer, mapped once: 64-byte handles through the transport.  Every step every rank takes is a step all ranks take (a rank
+      // whose mapping fails still joins the collectives and says so in its flag): exchange 3 fails on every rank, exchange 5 goes on without this form
+      hipIpcMemHandle_t mine; memset(&mine, 0, sizeof mine);
+      bool ok = hipIpcGetMemHandle(&mine, op->d_x_full) == hipSuccess;
+      if (!ok) (void)hipGetLastError();
       static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
       DevBuf hs, ha;
       KK_HIP(hs.alloc(64)); KK_HIP(ha.alloc(64 * (size_t)world));
@@ -325,21 +362,67 @@ static int dist_setup(kkamd_dist_spmv* op, int exchange, int overlap, hipStream_
       KK_HIP(hipStreamSynchronize(st));
       op->peer_x.assign((size_t)world, nullptr);
       op->peer_x[(size_t)me] = op->d_x_full;
-      for (int p = 0; p < world; ++p) {
+      for (int p = 0; p < world && ok; ++p) {
         if (p == me) continue;
-        if (hipIpcOpenMemHandle(&op->peer_x[(size_t)p], handles[(size_t)p], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
-          (void)hipGetLastError();
-          return fail(KKAMD_ERR_HIP, "kkamd_dist: hipIpcOpenMemHandle of rank %d's x buffer failed (HSA_ENABLE_IPC_MODE_LEGACY=0 set? peer access between the devices?)", p);
-        }
+        if (hipIpcOpenMemHandle(&op->peer_x[(size_t)p], handles[(size_t)p], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); op->peer_x[(size_t)p] = nullptr; ok = false; break; }
         hipStream_t s2 = nullptr; hipEvent_t e2 = nullptr;
-        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess)
-          return fail(KKAMD_ERR_HIP, "kkamd_dist: could not create a copy stream");
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
         op->p2p_stream.push_back(s2); op->p2p_event.push_back(e2);
       }
-      KK_HIP(hipEventCreateWithFlags(&op->ev_b1, hipEventDisableTiming));
+      if (ok && hipEventCreateWithFlags(&op->ev_b1, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ok = false; }
       KK_HIP(hipMalloc(&op->d_tok, 8 * (size_t)(world + 1)));
       KK_HIP(hipMemsetAsync(op->d_tok, 0, 8 * (size_t)(world + 1), st));
+      // does EVERY rank have its mappings?  (8-byte flags through the same token buffer)
+      unsigned long long flag = ok ? 1ull : 0ull;
+      DevBuf fl; KK_HIP(fl.alloc(8 * (size_t)(world + 1)));
+      KK_HIP(hipMemcpyAsync(fl.p, &flag, 8, hipMemcpyHostToDevice, st));
+      if ((rc = op->tr.all_gather(op->tr.ctx, fl.p, (char*)fl.p + 8, 8, reinterpret_cast<kkamd_stream_t>(st)))) return rc;
+      std::vector<unsigned long long> flags((size_t)world);
+      KK_HIP(hipMemcpyAsync(flags.data(), (char*)fl.p + 8, 8 * (size_t)world, hipMemcpyDeviceToHost, st));
+      KK_HIP(hipStreamSynchronize(st));
+      p2p_ok = true;
+      for (unsigned long long f : flags) p2p_ok = p2p_ok && f == 1ull;
+      if (chosen == 3 && !p2p_ok)
+        return fail(KKAMD_ERR_HIP, "kkamd_dist: mapping the ranks' x buffers into each other failed on some rank (HSA_ENABLE_IPC_MODE_LEGACY=0 set? peer access between the devices?)");
+    }
+#else
+    if (chosen == 3) return fail(KKAMD_ERR_UNSUPPORTED, "kkamd_dist: the peer-to-peer all-gather maps device memory between processes (hipIpc): not under the emulator");
 #endif
+    if (chosen == 5 && world > 1) {
+      // "validate RCCL's algorithm choice ... fall back to peer-to-peer".  One warm-up and two timed exchanges of every form the
+      // transport and the runtime offer, on the communication stream, all ranks in step; the form with the smallest maximum over the ranks stays.
+      void* x_local = (char*)op->d_x_full + es * me0;
+      const int64_t mrows_ = me1 - me0;
+      DevBuf tb; KK_HIP(tb.alloc(24 * (size_t)(world + 1)));
+      double mine_us[3] = {-1.0, -1.0, -1.0};
+      for (int form = 0; form < 3; ++form) {
+        if ((form == 0 && !op->equal) || (form == 2 && !p2p_ok)) continue;
+        for (int it = 0; it < 3; ++it) {
+          KK_HIP(hipStreamSynchronize(op->comm_stream));
+          const auto t0 = std::chrono::steady_clock::now();
+          if ((rc = dist_allgather(op, form, x_local, mrows_, op->comm_stream))) return rc;
+          KK_HIP(hipStreamSynchronize(op->comm_stream));
+          const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+          if (it == 1 || (it == 2 && us < mine_us[form])) mine_us[form] = us;       // the better of the two timed ones
+        }
+      }
+      KK_HIP(hipMemcpyAsync(tb.p, mine_us, 24, hipMemcpyHostToDevice, st));
+      if ((rc = op->tr.all_gather(op->tr.ctx, tb.p, (char*)tb.p + 24, 24, reinterpret_cast<kkamd_stream_t>(st)))) return rc;
+      std::vector<double> all((size_t)3 * world);
+      KK_HIP(hipMemcpyAsync(all.data(), (char*)tb.p + 24, 24 * (size_t)world, hipMemcpyDeviceToHost, st));
+      KK_HIP(hipStreamSynchronize(st));
+      int best = -1;
+      for (int form = 0; form < 3; ++form) {
+        double mx = -1.0; bool have = true;
+        for (int p = 0; p < world; ++p) { const double v = all[(size_t)3 * p + form]; if (v < 0) have = false; else if (v > mx) mx = v; }
+        op->ag_us[form] = have ? mx : -1.0;
+        if (have && (best < 0 || mx < op->ag_us[best])) best = form;
+      }
+      op->ag_form = best < 0 ? (op->equal ? 0 : 1) : best;
+      op->mode = op->ag_form == 2 ? 3 : 2;
+      op->ag_selected = true;
+      if (g_verbose) printf("kkamd_dist rank %d: all-gather of %lld bytes per rank: collective %.0f us, send / receive %.0f us, peer-to-peer pulls %.0f us -> form %d\n",
+                            me, (long long)(es * mrows_), op->ag_us[0], op->ag_us[1], op->ag_us[2], op->ag_form);
     }
     return dist_add_part<OffT>(op, 0, op->A.num_rows, h_rm, st);
   }
@@ -492,8 +575,8 @@ int kkamd_dist_spmv_create(kkamd_dist_spmv_t** out, const kkamd_crs_t* A_local, 
   int rc = kk::check_crs(A_local);
   if (rc) return rc;
   if (!row_offsets || world < 1 || rank < 0 || rank >= world) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: bad partition");
-  if (exchange < 0 || exchange > 4)
-    return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: exchange %d is not 0 (auto), 1 (halo, column range), 2 (all-gather), 3 (all-gather by peer-to-peer pulls) or 4 (halo, column set)", exchange);
+  if (exchange < 0 || exchange > 5)
+    return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: exchange %d is not 0 (auto), 1 (halo, column range), 2 (all-gather, the transport's collective), 3 (all-gather by peer-to-peer pulls), 5 (all-gather, the fastest form timed at creation) or 4 (halo, column set)", exchange);
   if (vector_type != KKAMD_F32 && vector_type != KKAMD_F64) return kk::fail(KKAMD_ERR_UNSUPPORTED, "kkamd_dist_spmv_create: unsupported vector_type %d", vector_type);
   for (int r = 0; r < world; ++r) if (row_offsets[r + 1] < row_offsets[r]) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_dist_spmv_create: row offsets must ascend");
   if (row_offsets[0] != 0 || A_local->num_rows != row_offsets[rank + 1] - row_offsets[rank])
@@ -547,6 +630,11 @@ int kkamd_dist_spmv_query(const kkamd_dist_spmv_t* op, const char* key, int64_t*
   const std::string k(key);
   if (k == "exchange") *value = op->mode;                        // 0 local, 1 halo (range), 2 all-gather, 3 all-gather peer to peer, 4 halo (set)
   else if (k == "exchange_bytes") *value = op->exchange_bytes;   // bytes this rank receives per SpMV
+  else if (k == "allgather_form") *value = (op->mode == 2 || op->mode == 3) ? (op->mode == 3 ? 2 : op->ag_form) : -1;   // 0 collective, 1 send / receive, 2 peer-to-peer pulls
+  else if (k == "allgather_selected") *value = op->ag_selected ? 1 : 0;                                                // the operator timed the forms at its creation
+  else if (k == "allgather_us_collective") *value = (int64_t)op->ag_us[0];
+  else if (k == "allgather_us_sendrecv") *value = (int64_t)op->ag_us[1];
+  else if (k == "allgather_us_p2p") *value = (int64_t)op->ag_us[2];
   else if (k == "interior_rows") *value = op->interior_rows;     // rows computed while the halo is in flight
   else if (k == "parts") *value = (int64_t)op->parts.size();
   else if (k == "sends") *value = (int64_t)op->send_peer.size();
@@ -580,23 +668,8 @@ int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_s
       KK_HIP(hipEventRecord(op->ev_ready, st));                  // x_local is in place, and earlier SpMVs are done with the halo
       KK_HIP(hipStreamWaitEvent(cs, op->ev_ready, 0));
       kkamd_stream_t kcs = reinterpret_cast<kkamd_stream_t>(cs);
-      if (op->mode == 3) {
-        // barrier (every shard is in place), world - 1 concurrent pulls on their own streams, barrier (nobody still reads a shard)
-        char* tok = (char*)op->d_tok;
-        if ((rc = op->tr.all_gather(op->tr.ctx, tok, tok + 8, 8, kcs))) return rc;
-        KK_HIP(hipEventRecord(op->ev_b1, cs));
-        size_t q = 0;
-        for (int p = 0; p < op->world; ++p) {
-          if (p == op->rank) continue;
-          const int64_t off = (int64_t)op->elem * op->offsets[p], len = (int64_t)op->elem * (op->offsets[p + 1] - op->offsets[p]);
-          hipStream_t s2 = op->p2p_stream[q];
-          KK_HIP(hipStreamWaitEvent(s2, op->ev_b1, 0));
-          if (len > 0) KK_HIP(hipMemcpyAsync((char*)op->d_x_full + off, (const char*)op->peer_x[(size_t)p] + off, (size_t)len, hipMemcpyDeviceToDevice, s2));
-          KK_HIP(hipEventRecord(op->p2p_event[q], s2));
-          KK_HIP(hipStreamWaitEvent(cs, op->p2p_event[q], 0));
-          ++q;
-        }
-        rc = op->tr.all_gather(op->tr.ctx, tok, tok + 8, 8, kcs);
+      if (op->mode == 2 || op->mode == 3) {
+        rc = kk::dist_allgather(op, op->mode == 3 ? 2 : op->ag_form, x_local, mrows, cs);
       } else if (op->mode == 4) {
         // pack what the peers asked for, the packed pieces travel point to point, scatter what arrived into the full-length x
         const int64_t ns = op->n_send_idx, nn = op->n_need;
@@ -612,8 +685,7 @@ int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_s
           if (op->elem == 8) KK_LAUNCH((kk::scatter_idx_kernel<uint64_t>), (unsigned)kk::ceil_div(nn, kk::kBlock), kk::kBlock, 0, cs, (const uint64_t*)unpack, ncol, nn, (uint64_t*)xfull);
           else KK_LAUNCH((kk::scatter_idx_kernel<uint32_t>), (unsigned)kk::ceil_div(nn, kk::kBlock), kk::kBlock, 0, cs, (const uint32_t*)unpack, ncol, nn, (uint32_t*)xfull);
         }
-      } else if (op->mode == 2 && op->equal) rc = op->tr.all_gather(op->tr.ctx, x_local, op->d_x_full, (int64_t)op->elem * mrows, kcs);
-      else rc = op->tr.exchange(op->tr.ctx, (int)op->send_peer.size(), op->send_ptr.data(), op->send_bytes.data(), op->send_peer.data(),
+      } else rc = op->tr.exchange(op->tr.ctx, (int)op->send_peer.size(), op->send_ptr.data(), op->send_bytes.data(), op->send_peer.data(),
                                 (int)op->recv_peer.size(), op->recv_ptr.data(), op->recv_bytes.data(), op->recv_peer.data(), kcs);
       if (rc) return rc;
       KK_HIP(hipEventRecord(op->ev_done, cs));

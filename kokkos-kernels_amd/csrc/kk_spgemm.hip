@@ -134,6 +134,8 @@ struct SpgemmTuning {
   int sort_rows      = 1;         // the row lists of the dense kernels are ordered by size, largest first (0 = the order the binning left)
   int sym_units      = 1;         // symbolic phase of the dense class by units (row, window of 2^unit_bits columns): spgemm_sym_unit_kernel; 0 = one workgroup per row (spgemm_dense_cols_kernel)
   int unit_bits      = kUnitBitsMaxKnob;   // log2 of a unit's columns (6 .. 18; 18 = 32 KB of bitmap, four workgroups of 256 per CU)
+  int store_cap_mb   = 0;         // upper bound, in MB, on the store of kept structure (bitmaps / entry lists of the symbolic phase) a product may take; 0 = none beyond the
+                                  // share of the free HBM the library takes by itself (0.225).  A host that interleaves its own allocations sets it; rows past it walk their products again
   int pool_keep      = 0;         // the process-wide store of bitmaps / entry lists when the last handle is destroyed: 0 = returned to the device after the process's
                                   // first product, kept once the process has come back for it (see BmPool); 1 = always kept; 2 = always returned
 };
@@ -3224,7 +3226,8 @@ static int launch_dense_cols(int64_t nrows, const int32_t* perm, const OffT* rmA
 // such a buffer is not free: every third or so symbolic phase took 1.3-1.6 s instead of 66 ms with an allocation per handle.  The
 // buffer is therefore kept in a process-wide pool between uses (one user at a time; a second concurrent handle allocates its own);
 // kkamd_release_scratch() gives it back.
-struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; int live_handles = 0; bool released_once = false, sticky = false; std::mutex m; };
+struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; int live_handles = 0; bool released_once = false, sticky = false; std::mutex m;
+                size_t high_water = 0; };          // the most the process-wide buffer has held (kkamd_spgemm_get 23)
 // Who keeps it (knob "spgemm_pool_keep" 0, the default): a process's FIRST product returns the buffer to the device when its last handle is
 // destroyed -- a one-shot caller gets its memory back without knowing about the pool.  A process that comes back for the buffer after such
 // a release is a repeat user: from then on the buffer outlives the handles (until kkamd_release_scratch), because giving GBs back and
@@ -3246,6 +3249,7 @@ int release_bitmap_pool() {
 // `need` bytes for a handle's store: the pool's buffer when it is free (grown when it is less than half of what is wanted), else
 // an allocation of the handle's own.  Returns the bytes obtained (possibly fewer than asked for: the caller lowers its row cap).
 static size_t take_bitmap_store(kkamd_spgemm_handle* h, size_t need) {
+  if (g_spgemm.store_cap_mb > 0 && need > (size_t)g_spgemm.store_cap_mb << 20) need = (size_t)g_spgemm.store_cap_mb << 20;
   BmPool& pool = bm_pool();
   std::lock_guard<std::mutex> g(pool.m);
   int dev = 0;
@@ -3256,6 +3260,7 @@ static size_t take_bitmap_store(kkamd_spgemm_handle* h, size_t need) {
       if (pool.p) { (void)hipFree(pool.p); pool.p = nullptr; pool.bytes = 0; }
       if (hipMalloc(&pool.p, need) != hipSuccess) { (void)hipGetLastError(); pool.p = nullptr; return 0; }
       pool.bytes = need; pool.device = dev;
+      if (need > pool.high_water) pool.high_water = need;
     }
     pool.in_use = true; h->bm_pooled = true; h->d_bm_store = pool.p;
     return pool.bytes < need ? pool.bytes : need;
@@ -3777,6 +3782,9 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
           KK_HIP(hipStreamSynchronize(st));
           h->n_dense_block = (int64_t)h_cnt[1];
           if (h->n_dense_block * kDenseBlock >= ((int64_t)1 << 32)) h->n_dense_block = 0;      // (a grid dimension holds 2^32 work-items; the split stays: every row is still in the bin once)
+          // the class's own index of C ((blocks + 1) x rows x 4 bytes) and its items (at most one 32-byte head and two 8-byte records per row and block)
+          // must fit beside the index of B: a small block width or a large k with many class rows makes them GBs.  No room: the rows keep the windowed kernels.
+          if ((double)(nblk + 1) * (double)h->n_dense_block * (4.0 + 48.0) + (double)(nblk + 1) * (double)h->n * 4.0 > (double)free_b / 8.0) h->n_dense_block = 0;
           if ((rc = order_list_by_size(seg + (nd - h->n_dense_block), h->n_dense_block, (const int64_t*)h->d_sizes, st))) return rc;
         }
       }
@@ -4258,6 +4266,7 @@ int spgemm_set_default(const char* key, int value) {
   else if (k == "spgemm_emit_sort") g_spgemm.emit_sort = value != 0;
   else if (k == "spgemm_pool_keep") { if (value < 0 || value > 2) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_pool_keep: 0 (first product returns the store, repeat users keep it), 1 (keep) or 2 (return)"); g_spgemm.pool_keep = value; }
   else if (k == "spgemm_sort_rows") g_spgemm.sort_rows = value != 0;
+  else if (k == "spgemm_store_cap_mb") { if (value < 0) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_store_cap_mb: %d is negative", value); g_spgemm.store_cap_mb = value; }
   else if (k == "spgemm_sym_units") g_spgemm.sym_units = value != 0;
   else if (k == "spgemm_unit_bits") { if (value < 6 || value > kUnitBitsMax) return fail(KKAMD_ERR_INVALID_ARG, "spgemm_unit_bits: 6 .. %d", kUnitBitsMax); g_spgemm.unit_bits = value; }
   else if (k == "spgemm_nt") g_spgemm.nt = value != 0;
@@ -4500,6 +4509,8 @@ int kkamd_spgemm_get(kkamd_spgemm_handle_t* h, int what, int64_t* value) {
     case 14: *value = h->pooled_used; break;
     case 15: *value = h->sorted_used; break;
     case 16: *value = h->n_dense_block; break;
+    case 22: { kk::BmPool& pool = kk::bm_pool(); std::lock_guard<std::mutex> g(pool.m); *value = (int64_t)pool.bytes; } break;        // bytes the process-wide store holds now
+    case 23: { kk::BmPool& pool = kk::bm_pool(); std::lock_guard<std::mutex> g(pool.m); *value = (int64_t)pool.high_water; } break;   // ... and the most it has held
     case 19: *value = h->last_units; break;           // units (row, window) of the last symbolic phase's dense class (0: the class was empty or went row by row)
     case 20: *value = h->last_unit_bitmaps; break;    // ... of which kept their bitmap for the numeric phase
     case 21: *value = h->last_unit_rows_kept; break;  // rows of the class whose every unit kept its structure

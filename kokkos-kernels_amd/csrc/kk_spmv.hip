@@ -914,7 +914,7 @@ static bool transpose_fits(kkamd_spmv_plan* p, const kkamd_crs_t* A) {
 }
 // knobs that belong to the handle's own re-ordered copies and are not passed on to the plan of its cached transpose
 static bool knob_stays_with_parent(const std::string& k) {
-  return k == "colslab" || k == "colslab_shift" || k == "colslab_min_knnz" || k == "colslab_const" || k == "explicit_transpose" ||
+  return k == "colslab" || k == "colslab_shift" || k == "colslab_rate_pct" || k == "colslab_min_knnz" || k == "colslab_const" || k == "explicit_transpose" ||
          k == "explicit_transpose_min_knnz" || k == "values_tracking";
 }
 template <class OffT, class AT>
@@ -965,6 +965,16 @@ static int ensure_transpose(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_
   p->t_plan->tune.explicit_transpose = 0;
   p->t_ready = true;
   return KKAMD_OK;
+}
+
+// the cached transpose and its plan are given up (a knob the parent took could not be applied to the transpose's plan): the next T / H call
+// builds them again from the parent's knobs
+static void drop_transpose(kkamd_spmv_plan* p) {
+  if (p->used) (void)hipStreamSynchronize(p->last_stream);
+  if (p->t_plan) { (void)kkamd_spmv_plan_destroy(p->t_plan); p->t_plan = nullptr; }
+  void** bufs[] = {&p->d_t_rm, (void**)&p->d_t_ent, &p->d_t_perm, (void**)&p->d_t_fp, &p->d_t_shadow, &p->d_t_val};
+  for (void** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
+  p->t_ready = false; p->t_fp_valid = false; p->t_shadow_valid = false; p->t_stale = true;
 }
 
 template <class OffT> static int analyse(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st);
@@ -1072,13 +1082,14 @@ static int colslab_select(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const YT*
       // partial sum per (slab, row) -- whole lines of a [slabs][rows] array, half empty when the rows are short (weight 1.5) -- against one
       // 128-byte line of x per missing nonzero through the fabric.  Rates fitted on one MI355X (uniform random 5e6 x 20: 1.32 ms slab form
       // against 1.75 ms CRS; 2e7 x 8: 3.85 against 3.27 -- the rule must say no there): 4.24 TB/s and 6.95 TB/s, 10 % margin.
-      int sh = plan->tune.colslab_shift > 0 ? plan->tune.colslab_shift : (sizeof(YT) == 8 ? 18 : 19);
-      while (ceil_div(A->num_cols, (int64_t)1 << sh) > 64) ++sh;
+      const int sh = cs_pick_shift(A, (int)sizeof(YT), plan->tune.colslab_shift, true);        // the slabs cs_build will make
       const double nslabs = (double)ceil_div(A->num_cols, (int64_t)1 << sh);
       const bool exact = plan->tune.values_tracking == 0 && !plan->tune.colslab_const;
       const double cost_slab = (double)A->nnz * (16.0 + (exact ? 16.0 : 0.0)) + 1.5 * nslabs * (double)A->num_rows * 2.0 * sizeof(YT);
       const double cost_crs = (double)A->nnz * plan->cs_ratio * 128.0;
-      if (cost_slab / 4.24e12 * 1.1 >= cost_crs / 6.95e12) {
+      // the two kernels' rates on their own bytes, fitted on one MI355X (4.24 and 6.95 TB/s: the slab form's streams against the lines the CRS
+      // kernel's gathers pull); what decides is their RATIO, a knob in percent (default 61) for parts or clocks where it lies elsewhere
+      if (cost_slab * 1.1 >= cost_crs * (0.01 * (double)plan->tune.colslab_rate_pct)) {
         if (g_verbose) printf("kkamd_spmv: the column-slab form would move %.2f GB against %.2f GB of x lines: CRS kernel\n", cost_slab / 1e9, cost_crs / 1e9);
         return KKAMD_OK;
       }
@@ -1271,6 +1282,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "colslab_min_pct") { if (value < 0 || value > 100) return bad("in 0..100"); t.colslab_min_pct = value; }
   else if (k == "colslab_min_knnz") { if (value < 0) return bad("non-negative"); t.colslab_min_knnz = value; }
   else if (k == "colslab_shift") { if (value != 0 && (value < 2 || value > 30)) return bad("0 or in 2..30"); t.colslab_shift = value; }
+  else if (k == "colslab_rate_pct") { if (value < 1 || value > 1000) return bad("in 1..1000"); t.colslab_rate_pct = value; }
   else if (k == "values_tracking") { if (value < 0 || value > 2) return bad("in 0..2"); t.values_tracking = value; }
   else if (k == "check_entries") { if (value != 0 && value != 1) return bad("0 or 1"); t.check_entries = value; }
   else if (k == "defer_rank1") { if (value != 0 && value != 1) return bad("0 or 1"); t.defer_rank1 = value; }
@@ -1596,8 +1608,15 @@ int kkamd_spmv_plan_set(kkamd_spmv_plan_t* plan, const char* key, int value) {
   if (rc) return rc;
   const std::string k(key ? key : "");
   if (!kk::knob_stays_with_parent(k)) {
-    plan->set_log.emplace_back(k, value);
-    if (plan->t_plan) rc = plan_set_impl(plan->t_plan, key, value);      // modes T / H run the mode-N dispatch on the cached transpose's own plan
+    // one entry per key, the last value (a caller that toggles a knob every iteration must not grow the log, and the transpose, created later,
+    // replays it once per key)
+    bool seen = false;
+    for (auto& kv : plan->set_log) if (kv.first == k) { kv.second = value; seen = true; break; }
+    if (!seen) plan->set_log.emplace_back(k, value);
+    // modes T / H run the mode-N dispatch on the cached transpose's own plan.  A knob that the parent took is valid there too; if its
+    // side effects fail on the transpose (no memory for a new analysis, ...) the transpose is dropped -- the next T / H call builds it
+    // again from the parent's knobs -- rather than left with other knobs than its parent
+    if (plan->t_plan && plan_set_impl(plan->t_plan, key, value) != KKAMD_OK) kk::drop_transpose(plan);
   }
   return rc;
 }

@@ -541,10 +541,8 @@ static int cs_build_typed(kkamd_cs_plan** out, const kkamd_crs_t* A, int shift, 
   return KKAMD_OK;
 }
 
-// Builds the slab-order copy (nullptr in *out when HBM cannot hold it).  x_elem: bytes per x element (sizes the slabs).
-int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st, bool det) {
-  *out = nullptr;
-  if (A->nnz <= 0 || A->num_rows <= 0 || A->num_cols <= 0) return KKAMD_OK;
+// log2 of the columns per slab the copy is built with (also what the selection rule of kk_spmv.hip prices: one place for both)
+int cs_pick_shift(const kkamd_crs_t* A, int x_elem, int shift_knob, bool det) {
   int shift = shift_knob;
   if (shift <= 0) {
     // 2 MB of x per slab; up to 8 MB when the rows are so short that a slab would hold less than half an entry per row (the
@@ -554,6 +552,13 @@ int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_kn
     for (int widen = 0; widen < 2 && per_row * (double)((int64_t)1 << shift) < 0.5 * (double)A->num_cols; ++widen) ++shift;
   }
   while (ceil_div(A->num_cols, (int64_t)1 << shift) > (det ? 64 : kCsMaxSlabs)) ++shift;      // (the deterministic form keeps a 64-bit slab mask per row)
+  return shift;
+}
+// Builds the slab-order copy (nullptr in *out when HBM cannot hold it).  x_elem: bytes per x element (sizes the slabs).
+int cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st, bool det) {
+  *out = nullptr;
+  if (A->nnz <= 0 || A->num_rows <= 0 || A->num_cols <= 0) return KKAMD_OK;
+  const int shift = cs_pick_shift(A, x_elem, shift_knob, det);
   const size_t off_b = A->offset_type == KKAMD_I64 ? 8 : 4, val_b = A->value_type == KKAMD_F64 ? 8 : 4;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return KKAMD_OK; }
@@ -576,8 +581,23 @@ static int cs_apply_typed(kkamd_cs_plan* cs, const kkamd_crs_t* A, const YT* x, 
   if (rc) return rc;
   const int32_t* row = cs->d_row; const int32_t* col = cs->d_col; const int shift = cs->shift;
   if (cs->det) {
-    if (cs->part_bytes != (size_t)cs->nslabs * (size_t)A->num_rows * sizeof(YT))
-      return fail(KKAMD_ERR_STATE, "kkamd_spmv: the column-slab copy was built for another vector type");
+    if (cs->part_bytes != (size_t)cs->nslabs * (size_t)A->num_rows * sizeof(YT)) {
+      // the handle's first call had another vector type (the CRS kernels take either on one handle, so must this form): the per-slab
+      // partial sums and the chunk heads / tails are sized again for this one
+      KK_HIP(hipStreamSynchronize(st));
+      if (cs->d_part) (void)hipFree(cs->d_part);
+      if (cs->d_head) (void)hipFree(cs->d_head);
+      if (cs->d_tail) (void)hipFree(cs->d_tail);
+      cs->d_part = cs->d_head = cs->d_tail = nullptr;
+      const size_t want = (size_t)cs->nslabs * (size_t)A->num_rows * sizeof(YT);
+      if (hipMalloc(&cs->d_part, want) != hipSuccess || hipMalloc(&cs->d_head, sizeof(YT) * (size_t)cs->nchunks) != hipSuccess ||
+          hipMalloc(&cs->d_tail, sizeof(YT) * (size_t)cs->nchunks) != hipSuccess) {
+        (void)hipGetLastError(); cs->part_bytes = 0;
+        return fail(KKAMD_ERR_ALLOC, "kkamd_spmv: no memory for the column-slab form's partial sums in this vector type");
+      }
+      cs->bytes += want; cs->bytes -= cs->part_bytes;
+      cs->part_bytes = want;
+    }
     YT* part = (YT*)cs->d_part; YT* head = (YT*)cs->d_head; YT* tail = (YT*)cs->d_tail; long long* tkey = cs->d_tkey; int* cflag = cs->d_cflag;
     const int64_t nchunks = cs->nchunks, nrows = A->num_rows; const int nslabs = cs->nslabs; const unsigned long long* mask = cs->d_mask;
     KK_LAUNCH((cs_det_kernel<AT, YT>), (unsigned)ceil_div(nchunks, (int64_t)(kBlock / 64)), kBlock, 0, st, nnz, nrows, row, col, (const AT*)o_val, shift, x, part, head, tail, tkey, cflag);

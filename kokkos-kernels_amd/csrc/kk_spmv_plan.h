@@ -73,6 +73,7 @@ struct SpmvTuning {
   int colslab_min_pct = 85;        // ... the rule of 3: distinct lines of x per nonzero, in percent, from which the gather counts as cache-defeating
   int colslab_min_knnz = 20000;    // ... from this many thousand nnz
   int colslab_shift = 0;           // ... log2 of the columns per slab (0 = 2 MB of x)
+  int colslab_rate_pct = 61;       // ... the selection rule's price ratio: bytes per second of the slab form / of the CRS kernel's x lines, in percent (4.24 / 6.95 TB/s on MI355X)
   int defer_rank1 = 0;             // 1 = the rank-1 analysis (tiles, window codes, pattern records: 5 ms on 27-pt 300^3) waits for the first rank-1
                                    // call; set by a caller whose first call is rank 2 (the Python SPMVHandle does: the reference's handle is set up
                                    // by its first spmv call too, for that call's rank).  Queries of the rank-1 plan return 0 until then.
@@ -197,6 +198,7 @@ int  mv6_spmv(kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int6
               int64_t nvec, double alpha, double beta, hipStream_t st);   // X row-major, ldx even, 16-byte aligned
 void cs_plan_destroy(kkamd_cs_plan* cs);
 int64_t cs_plan_query(const kkamd_cs_plan* cs, int what);   // 0 slabs, 1 log2 columns per slab, 2 bytes, 3 deterministic form
+int  cs_pick_shift(const kkamd_crs_t* A, int x_elem, int shift_knob, bool det);   // log2 of the columns per slab cs_build uses
 int  cs_build(kkamd_cs_plan** out, const kkamd_crs_t* A, int x_elem, int shift_knob, hipStream_t st, bool det = false);   // det: the deterministic form (per-slab partial sums, no atomics)
 int  cs_apply(kkamd_cs_plan* cs, const kkamd_crs_t* A, int vector_type, const void* x, void* y, double alpha, double beta, int tracking, hipStream_t st);
 int64_t values_fp_tiles(int64_t nnz);

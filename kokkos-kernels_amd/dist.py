@@ -20,7 +20,9 @@ from . import _capi
 from ._capi import check
 from .sparse import _ALGOS, _scalar_type
 
-_EXCHANGE = {"auto": 0, "halo": 1, "allgather": 2, "allgather_p2p": 3, "halo_set": 4}
+# "allgather": the operator times the forms it has at its creation -- the transport's collective, every shard to every peer point to point, peer-to-peer
+# pulls of mapped memory -- and keeps the fastest; "allgather_collective" / "allgather_p2p" force one form (measurement)
+_EXCHANGE = {"auto": 0, "halo": 1, "allgather_collective": 2, "allgather_p2p": 3, "halo_set": 4, "allgather": 5}
 
 
 def slab_offsets(nrows, world, align=1):
@@ -274,6 +276,10 @@ class DistSpmv:
         self._op = op
         self.exchange_mode = ("local", "halo", "allgather", "allgather_p2p", "halo_set")[self.query("exchange")]
         self.exchange_bytes = self.query("exchange_bytes")
+        # all-gather: the form in use (0 collective, 1 send / receive, 2 peer-to-peer pulls; -1: no all-gather) and, when the operator chose it itself,
+        # what one exchange of every form took at creation (microseconds, maximum over the ranks; -1: form not available)
+        self.allgather_form = self.query("allgather_form")
+        self.allgather_us = {k: self.query("allgather_us_" + k) for k in ("collective", "sendrecv", "p2p")} if self.query("allgather_selected") else None
         self.interior_rows = self.query("interior_rows")
 
     def query(self, key):

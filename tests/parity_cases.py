@@ -307,6 +307,23 @@ def check_colslab_deterministic(be):
     kk.spmv(h, "N", 1.0, A, xd, 0.0, yd)
     exp2 = oracle.spmv_serial("N", oracle.Crs(n, k, rm, ent, v), 1.0, x, 0.0, np.zeros(n))
     np.testing.assert_allclose(be.to_numpy(yd), exp2, rtol=1e-11, atol=1e-9)
+    # one handle, BOTH vector types (round-5 advice: the partial-sum buffers were sized by the first call's type and the other type got
+    # KKAMD_ERR_STATE; the CRS kernels take either on one handle): a float matrix with fp64 vectors, then fp32 vectors, then fp64 again
+    v32 = v.astype(np.float32)
+    A32 = dev(be, oracle.Crs(n, k, rm, ent, v32.astype(np.float64)), value_dtype=np.float32)
+    h32 = kk.SPMVHandle("SPMV_DEFAULT"); h32.set("colslab", 4); h32.set("colslab_shift", 6)
+    exp64 = oracle.spmv_serial("N", oracle.Crs(n, k, rm, ent, v32.astype(np.float64)), 1.0, x, 0.0, np.zeros(n))
+    x32 = x.astype(np.float32)
+    exp32 = oracle.spmv_serial("N", oracle.Crs(n, k, rm, ent, v32.astype(np.float64)), 1.0, x32.astype(np.float64), 0.0, np.zeros(n))
+    for vec32 in (False, True, False):
+        if vec32:
+            y32 = be.from_numpy(np.zeros(n, dtype=np.float32))
+            kk.spmv(h32, "N", 1.0, A32, be.from_numpy(x32), 0.0, y32)
+            np.testing.assert_allclose(be.to_numpy(y32).astype(np.float64), exp32, rtol=2e-4, atol=1e-2)
+        else:
+            kk.spmv(h32, "N", 1.0, A32, xd, 0.0, yd)
+            np.testing.assert_allclose(be.to_numpy(yd), exp64, rtol=1e-11, atol=1e-9)
+        assert h32.query("colslab_deterministic") == 1
     # the rule of the default handle says no on a small matrix (x is not several L2s large): nothing is built
     check_spmv(be, A0, "N", 1.0, 0.0, "SPMV_DEFAULT", max_val=50.0, expect={"colslab": 0, "colslab_tried": 1})
 
@@ -576,7 +593,23 @@ def check_spgemm_units(be, light=False):
         for bits in (18, 12):
             setd(b"spgemm_unit_bits", bits)
             check_spgemm(be, A, Bu, reuse=False)
+        # a cap on the store (knob spgemm_store_cap_mb, for hosts that interleave their own allocations): room goes to the heaviest rows, the
+        # others walk their products again in the numeric phase -- the same C; the queries report what the process-wide store holds and has held
+        setd(b"spgemm_unit_bits", 12); setd(b"spgemm_store_cap_mb", 1)
+        kk._capi.check(be.lib, be.lib.kkamd_release_scratch())
+        kh = kk.KokkosKernelsHandle(be); kh.create_spgemm_handle("SPGEMM_KK")
+        Am, Bm = dev(be, Ad), dev(be, Bd)
+        Cm = kk.spgemm_symbolic(kh, Am, False, Bm, False)
+        sh = kh.get_spgemm_handle()
+        assert 0 < sh.get(22) <= 1 << 20 and sh.get(23) >= sh.get(22), (sh.get(22), sh.get(23))
+        assert 0 < sh.get(21) < Ad.nrows, sh.get(21)                       # some rows complete, not all (the dense product wants 1.5 MB)
+        kk.spgemm_numeric(kh, Am, False, Bm, False, Cm)
+        rm_, ent_, val_ = Cm.to_host()
+        ok, msg = oracle.is_same_matrix(oracle.Crs(Ad.nrows, Bd.ncols, rm_.astype(np.int64), ent_, val_.astype(np.float64)), oracle.spgemm(Ad, Bd))
+        assert ok, msg
+        kh.destroy_spgemm_handle()
     finally:
+        setd(b"spgemm_store_cap_mb", 0)
         setd(b"spgemm_unit_bits", 18); setd(b"spgemm_keep_bitmaps", 1); setd(b"spgemm_keep_lists", 1); setd(b"spgemm_sym_units", 1)
 
 

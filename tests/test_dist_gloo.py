@@ -54,23 +54,23 @@ def _worker(rank, world, port, ragged, exchange, ret):
     op.apply(1.0, xl, 0.0, y2)
     err = max(err, float(np.abs(y2.numpy() - oracle.spmv_serial("N", A0, 3.0, x, 0.0, np.zeros(n))[r0:r1]).max()))
     tol = oracle.spmv_max_error(A0, 3.0, 0.5, max_val=32.0)
-    ret[rank] = (ok_gen, err, tol, op.exchange_mode, op.exchange_bytes, op.interior_rows, op.query("parts"))
+    ret[rank] = (ok_gen, err, tol, op.exchange_mode, op.exchange_bytes, op.interior_rows, op.query("parts"), op.allgather_form, op.allgather_us, all(offs[i + 1] - offs[i] == offs[1] - offs[0] for i in range(world)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["auto", "allgather"])
+@pytest.mark.parametrize("exchange", ["auto", "allgather", "allgather_collective"])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_row_partitioned_spmv_world2(ragged, exchange):
     import torch.multiprocessing as mp
     world = 2
-    port = 29500 + (os.getpid() % 2000) + (7 if ragged else 0) + (13 if exchange == "auto" else 0)
+    port = 29500 + (os.getpid() % 2000) + (7 if ragged else 0) + (13 if exchange == "auto" else (29 if exchange == "allgather" else 0))
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_worker, args=(world, port, ragged, exchange, ret), nprocs=world, join=True)
         assert len(ret) == world
         for r in range(world):
-            ok_gen, err, tol, mode, nbytes, interior, parts = ret[r]
+            ok_gen, err, tol, mode, nbytes, interior, parts, ag_form, ag_us, equal = ret[r]
             assert ok_gen, "slab generator mismatch on rank %d" % r
             assert err <= tol, "rank %d: %g > %g" % (r, err, tol)
             if exchange == "auto" and not ragged:
@@ -81,7 +81,13 @@ def test_row_partitioned_spmv_world2(ragged, exchange):
                 # (boundaries may move a few rows inward so the views start on 16-byte aligned entries)
                 assert parts == 2 and (planes - 1) * 72 - 16 <= interior <= (planes - 1) * 72, (parts, interior)
             if exchange == "allgather":
-                assert mode == "allgather"
+                # the operator timed the forms it has (no mapped memory between processes under the emulator) and every rank kept the same one:
+                # equal shards -> the collective or the point-to-point form; unequal shards (both partitions of this test) have no collective form
+                assert mode == "allgather" and ag_us is not None and ag_us["p2p"] == -1 and ag_us["sendrecv"] >= 0, (mode, ag_us)
+                assert (ag_us["collective"] == -1) == (not equal) and ag_form in ((0, 1) if equal else (1,)), (equal, ag_form, ag_us)
+                assert ag_form == ret[0][7] and ag_us == ret[0][8]
+            if exchange == "allgather_collective":
+                assert mode == "allgather" and ag_us is None and ag_form == (0 if equal else 1), (mode, ag_form, ag_us)
 
 
 def _scattered_matrix(n, seed=5):
@@ -235,6 +241,11 @@ def test_bench_two_process_flow_emulated(launcher):
     assert set(d["exchange"]) >= {"halo", "halo_set", "allgather"}
     for x in ("halo", "halo_set", "allgather"):
         assert d["exchange"][x]["step_ms"] > 0 and d["exchange"][x]["bytes_received_per_gpu"] > 0
+    # the all-gather operator chose its form itself from what it timed at its creation (equal shards: the collective and the point-to-point form; no
+    # mapped memory between processes under the emulator)
+    ag = d["exchange"]["allgather"]
+    assert ag["form_chosen"] in ("collective", "send_receive") and ag["form_us_at_creation"]["collective"] >= 0 and ag["form_us_at_creation"]["sendrecv"] >= 0 \
+        and ag["form_us_at_creation"]["p2p"] == -1, ag
 
 
 def test_slab_offsets():

@@ -24,7 +24,7 @@ be = kk.torch_backend()
 res = {"workload": "spmv_crs_27pt_FE_laplacian_600x600x600_rank3_of_8_slab", "rows": rows, "nnz": A.nnz()}
 alg = A.nnz() * 12 + (rows + 1) * 4 + (planes + 2) * plane * 8 + rows * 8
 res["algorithmic_bytes_per_call"] = alg
-for exchange in ("halo", "allgather"):
+for exchange in ("halo", "allgather_collective"):
     tr = Loopback(x, offsets, rank, ranges)
     op = DistSpmv(A, offsets, rank, transport=tr, exchange=exchange)
     p_full = C.c_void_p(); kk._capi.check(be.lib, be.lib.kkamd_dist_spmv_x_local(op._op, None, C.byref(p_full))); tr.base = p_full.value
