@@ -785,9 +785,6 @@ static const int32_t* mv2_order(kkamd_spmv_plan* plan, const kkamd_crs_t* A, int
 }  // namespace kk
 #include "kk_spmv_mv4.h"
 namespace kk {
-#define KK_MV4_EXTERN(OT, AT_) extern template int launch_mv4<OT, AT_>(const kkamd_spmv_plan*, const kkamd_crs_t*, const double*, int64_t, int64_t, double*, int64_t, int64_t, double, double, hipStream_t, int, int)
-KK_MV4_EXTERN(int32_t, double); KK_MV4_EXTERN(int32_t, float); KK_MV4_EXTERN(int64_t, double); KK_MV4_EXTERN(int64_t, float);
-#undef KK_MV4_EXTERN
 
 void mv4_plan_destroy(kkamd_mv4_plan* p) {
   if (!p) return;
@@ -809,56 +806,7 @@ int64_t mv4_plan_query(const kkamd_mv4_plan* p, int what) {
   }
 }
 
-// A row CONFORMS when its entries are, in order, a subset of the reference row's (col[q'] = r + off[q]), every entry it holds
-// points inside the lattice and every entry it lacks points outside: interior rows hold them all, rows on a lattice boundary
-// of a truncated stencil hold the rest, anything else (wrap-around couplings, extra or missing interior entries) does not
-// conform.  arow[r] = row_map[r] and amask[r] = the entries held, or -1 and 0; *count = rows that do not conform.
-template <class OffT>
-__global__ __launch_bounds__(kBlock) void mv4_verify_kernel(int64_t nrows, const OffT* __restrict__ row_map, const int32_t* __restrict__ entries,
-                                                            Mv4Tab offs, Mv4Tab steps, int nx, int ny, int nz, OffT* __restrict__ arow,
-                                                            uint32_t* __restrict__ amask, unsigned long long* __restrict__ count) {
-  // The entries of the workgroup's 256 rows are one contiguous piece of the array: it is copied into LDS with coalesced loads and every
-  // work-item walks its row there (row pitch 27 words: no bank conflicts) -- a work-item reading its own row from memory, entry by
-  // entry, made this kernel 6.5 ms on C3 (27e6 rows), as long as two SpMV_MV calls.  Pieces that do not fit (rows longer than the
-  // stencil: they will not conform anyway) are read where they lie.
-  constexpr int CAP = kBlock * kMv4MaxL;
-  __shared__ int s_ent[CAP];
-  const int64_t r0 = (int64_t)blockIdx.x * kBlock, r = r0 + threadIdx.x;
-  const int64_t rN = r0 + kBlock < nrows ? r0 + kBlock : nrows;
-  const int64_t a0 = (int64_t)row_map[r0], a1 = (int64_t)row_map[rN];
-  const bool staged = a1 - a0 <= CAP;                          // workgroup-uniform
-  if (staged) {
-    for (int64_t p = threadIdx.x; p < a1 - a0; p += kBlock) s_ent[p] = entries[a0 + p];
-    __syncthreads();
-  }
-  if (r >= nrows) return;
-  const int64_t b = (int64_t)row_map[r], len = (int64_t)row_map[r + 1] - b;
-  const int i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((int64_t)nx * ny));
-  auto inside = [&](int q) {                           // steps.e[q] = (dk + 1) | (dj + 1) << 2 | (di + 1) << 4
-    const int s = steps.e[q], kk = k + (s & 3) - 1, jj = j + ((s >> 2) & 3) - 1, ii = i + ((s >> 4) & 3) - 1;
-    return kk >= 0 && kk < nz && jj >= 0 && jj < ny && ii >= 0 && ii < nx;
-  };
-  bool ok = len >= 1 && len <= offs.n;
-  uint32_t mask = 0;
-  int q = 0;
-  for (int64_t a = 0; ok && a < len; ++a) {
-    const int64_t d = (int64_t)(staged ? s_ent[b - a0 + a] : entries[b + a]) - r;
-    while (q < offs.n && offs.e[q] != d) ++q;          // in order: the packed position of an entry is the count of held entries before it
-    ok = q < offs.n && inside(q);
-    if (ok) mask |= 1u << q++;
-  }
-  for (int z = 0; ok && z < offs.n; ++z) ok = ((mask >> z) & 1u) || !inside(z);
-  arow[r]  = ok ? (OffT)b : (OffT)-1;
-  amask[r] = ok ? mask : 0u;
-  if (!ok) atomicAdd(count, 1ull);
-}
-template <class OffT>
-__global__ __launch_bounds__(kBlock) void mv4_list_kernel(int64_t nrows, const OffT* __restrict__ arow, int32_t* __restrict__ list,
-                                                          unsigned long long* __restrict__ cursor) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < nrows && arow[r] < 0) list[atomicAdd(cursor, 1ull)] = (int32_t)r;
-}
-
+// (mv4_verify_kernel and mv4_list_kernel, the analysis kernels, live in kk_spmv_mv4.h and are instantiated in kk_spmv_mv4_aux.hip: launch_mv4_verify / launch_mv4_list)
 // floor((d + s / 2) / s): the lattice step an offset d makes along a stride s
 static inline int64_t mv4_round_div(int64_t d, int64_t s) {
   const int64_t v = d + s / 2;
@@ -941,15 +889,14 @@ static int mv4_plan_build(kkamd_spmv_plan* plan, const kkamd_crs_t* A, hipStream
     steps.e[q] = (int)((dk + 1) | ((dj + 1) << 2) | ((di + 1) << 4));
   }
   uint32_t* d_amask = m->d_amask;
-  KK_LAUNCH((mv4_verify_kernel<OffT>), (unsigned)ceil_div(A->num_rows, kBlock), kBlock, 0, st, A->num_rows, (const OffT*)A->d_row_map,
-            (const int32_t*)A->d_entries, offs, steps, m->nx, m->ny, m->nz, d_arow, d_amask, d_cnt);
+  launch_mv4_verify<OffT>(A->num_rows, (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, offs, steps, m->nx, m->ny, m->nz, d_arow, d_amask, d_cnt, st);
   unsigned long long h_bad = 0;
   if (hipMemcpyAsync(&h_bad, d_cnt, sizeof h_bad, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return drop();
   m->n_nc = (int64_t)h_bad;
   if ((double)m->n_nc > 0.5 * (double)A->num_rows) return drop();               // mostly irregular: not this kernel's matrix
   if (hipMalloc((void**)&m->d_nc, sizeof(int32_t) * (size_t)(m->n_nc > 0 ? m->n_nc : 1)) != hipSuccess) return drop();
   int32_t* d_nc = m->d_nc;
-  KK_LAUNCH((mv4_list_kernel<OffT>), (unsigned)ceil_div(A->num_rows, kBlock), kBlock, 0, st, A->num_rows, (const OffT*)d_arow, d_nc, d_cnt + 1);
+  launch_mv4_list<OffT>(A->num_rows, (const OffT*)d_arow, d_nc, d_cnt + 1, st);
   if (hipStreamSynchronize(st) != hipSuccess) return drop();
   // the kernel's view of the stencil: groups (dk, di), in ascending order of that key, of up to three entries dj = -1, 0, 1
   m->grp.n = offs.n; m->grp.ng = 0;

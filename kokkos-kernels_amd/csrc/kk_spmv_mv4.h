@@ -2,7 +2,7 @@
 // In a header since round 6: the 192 instantiations of the kernel (offsets x matrix values x stencil x beta x X layout x partial block, 20 KB of
 // code each) were 3.9 of the 6.5 MB of the rank-2 code object, which the runtime loads whole at the first rank-2 call of a process (19 of
 // the 27 ms of config 3's first call).  Every (offset type, value type) pair is now instantiated in a translation unit of its own
-// (kk_spmv_mv4_*.hip: explicit instantiations of launch_mv4), i.e. in a code object of its own, loaded when first launched.
+// and every stencil pattern (kk_spmv_mv4_*.hip: explicit instantiations of launch_mv4_stencil), i.e. in a code object of its own, loaded when first launched.
 #pragma once
 #include "kk_spmv_plan.h"
 #include <climits>
@@ -361,58 +361,173 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
   }
 }
 
-template <class OffT, class AT>
-int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
-                      double alpha, double beta, hipStream_t st, int ncv = 16, int ncb = 1) {
-  const kkamd_mv4_plan* m = plan->mv4;
+// A row CONFORMS when its entries are, in order, a subset of the reference row's (col[q'] = r + off[q]), every entry it holds
+// points inside the lattice and every entry it lacks points outside: interior rows hold them all, rows on a lattice boundary
+// of a truncated stencil hold the rest, anything else (wrap-around couplings, extra or missing interior entries) does not
+// conform.  arow[r] = row_map[r] and amask[r] = the entries held, or -1 and 0; *count = rows that do not conform.
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv4_verify_kernel(int64_t nrows, const OffT* __restrict__ row_map, const int32_t* __restrict__ entries,
+                                                            Mv4Tab offs, Mv4Tab steps, int nx, int ny, int nz, OffT* __restrict__ arow,
+                                                            uint32_t* __restrict__ amask, unsigned long long* __restrict__ count) {
+  // The entries of the workgroup's 256 rows are one contiguous piece of the array: it is copied into LDS with coalesced loads and every
+  // work-item walks its row there (row pitch 27 words: no bank conflicts) -- a work-item reading its own row from memory, entry by
+  // entry, made this kernel 6.5 ms on C3 (27e6 rows), as long as two SpMV_MV calls.  Pieces that do not fit (rows longer than the
+  // stencil: they will not conform anyway) are read where they lie.
+  constexpr int CAP = kBlock * kMv4MaxL;
+  __shared__ int s_ent[CAP];
+  const int64_t r0 = (int64_t)blockIdx.x * kBlock, r = r0 + threadIdx.x;
+  const int64_t rN = r0 + kBlock < nrows ? r0 + kBlock : nrows;
+  const int64_t a0 = (int64_t)row_map[r0], a1 = (int64_t)row_map[rN];
+  const bool staged = a1 - a0 <= CAP;                          // workgroup-uniform
+  if (staged) {
+    for (int64_t p = threadIdx.x; p < a1 - a0; p += kBlock) s_ent[p] = entries[a0 + p];
+    __syncthreads();
+  }
+  if (r >= nrows) return;
+  const int64_t b = (int64_t)row_map[r], len = (int64_t)row_map[r + 1] - b;
+  const int i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((int64_t)nx * ny));
+  auto inside = [&](int q) {                           // steps.e[q] = (dk + 1) | (dj + 1) << 2 | (di + 1) << 4
+    const int s = steps.e[q], kk = k + (s & 3) - 1, jj = j + ((s >> 2) & 3) - 1, ii = i + ((s >> 4) & 3) - 1;
+    return kk >= 0 && kk < nz && jj >= 0 && jj < ny && ii >= 0 && ii < nx;
+  };
+  bool ok = len >= 1 && len <= offs.n;
+  uint32_t mask = 0;
+  int q = 0;
+  for (int64_t a = 0; ok && a < len; ++a) {
+    const int64_t d = (int64_t)(staged ? s_ent[b - a0 + a] : entries[b + a]) - r;
+    while (q < offs.n && offs.e[q] != d) ++q;          // in order: the packed position of an entry is the count of held entries before it
+    ok = q < offs.n && inside(q);
+    if (ok) mask |= 1u << q++;
+  }
+  for (int z = 0; ok && z < offs.n; ++z) ok = ((mask >> z) & 1u) || !inside(z);
+  arow[r]  = ok ? (OffT)b : (OffT)-1;
+  amask[r] = ok ? mask : 0u;
+  if (!ok) atomicAdd(count, 1ull);
+}
+template <class OffT>
+__global__ __launch_bounds__(kBlock) void mv4_list_kernel(int64_t nrows, const OffT* __restrict__ arow, int32_t* __restrict__ list,
+                                                          unsigned long long* __restrict__ cursor) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nrows && arow[r] < 0) list[atomicAdd(cursor, 1ull)] = (int32_t)r;
+}
+
+template <class OffT>
+int launch_mv4_verify(int64_t nrows, const OffT* row_map, const int32_t* entries, Mv4Tab offs, Mv4Tab steps, int nx, int ny, int nz, OffT* arow, uint32_t* amask,
+                      unsigned long long* count, hipStream_t st)
+#ifdef KK_MV4_INSTANTIATE
+{
+  KK_LAUNCH((mv4_verify_kernel<OffT>), (unsigned)ceil_div(nrows, kBlock), kBlock, 0, st, nrows, row_map, entries, offs, steps, nx, ny, nz, arow, amask, count);
+  return KKAMD_OK;
+}
+#else
+;
+#endif
+template <class OffT>
+int launch_mv4_list(int64_t nrows, const OffT* arow, int32_t* list, unsigned long long* count, hipStream_t st)
+#ifdef KK_MV4_INSTANTIATE
+{
+  KK_LAUNCH((mv4_list_kernel<OffT>), (unsigned)ceil_div(nrows, kBlock), kBlock, 0, st, nrows, arow, list, count);
+  return KKAMD_OK;
+}
+#else
+;
+#endif
+#ifndef KK_MV4_INSTANTIATE
+extern template int launch_mv4_verify<int32_t>(int64_t, const int32_t*, const int32_t*, Mv4Tab, Mv4Tab, int, int, int, int32_t*, uint32_t*, unsigned long long*, hipStream_t);
+extern template int launch_mv4_verify<int64_t>(int64_t, const int64_t*, const int32_t*, Mv4Tab, Mv4Tab, int, int, int, int64_t*, uint32_t*, unsigned long long*, hipStream_t);
+extern template int launch_mv4_list<int32_t>(int64_t, const int32_t*, int32_t*, unsigned long long*, hipStream_t);
+extern template int launch_mv4_list<int64_t>(int64_t, const int64_t*, int32_t*, unsigned long long*, hipStream_t);
+#endif
+
+// The launch in three layers, so that a process loads only the code it runs (a code object is loaded whole at the first launch of one of its kernels):
+//   launch_mv4_stencil<OffT, AT, NE, FL>   the twelve instantiations of the kernel for ONE stencil pattern (beta = 0 or not, X layout, partial block):
+//                                          one translation unit per (types, stencil) -- kk_spmv_mv4_<types>_<stencil>.hip, 0.3 MB of code each;
+//   launch_mv4_rows<OffT, AT>              the gather kernel for the rows outside the stencil, and launch_mv4_verify<OffT>, the analysis kernels:
+//                                          kk_spmv_mv4_aux.hip;
+//   launch_mv4<OffT, AT>                   picks the stencil (inline, instantiates nothing).
+template <class OffT, class AT, int NE, unsigned FL>
+int launch_mv4_stencil(const kkamd_mv4_plan* m, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+                       double alpha, double beta, hipStream_t st, int ncv, int ncb, bool xrow, bool xcol)
+#ifdef KK_MV4_INSTANTIATE
+{
   const size_t slabs = 4 * (size_t)((kMv4RJ + 2) * (kMv4RI + 2) * 128), rows = kMv4Threads / 8;
   const int yv = (ys1 == 1 && (ys0 % 2 == 0) && ((uintptr_t)Y % 16 == 0)) ? 1 : 0;
+  const bool part = ncv < 16;
 #ifndef KK_EMU
-#define KK_MV4_ATTR(NE, FL, B0, XR, PT) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR, PT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+#define KK_MV4_ATTR(B0, XR, PT) KK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR, PT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
 #else
-#define KK_MV4_ATTR(NE, FL, B0, XR, PT) (void)0
+#define KK_MV4_ATTR(B0, XR, PT) (void)0
 #endif
-#define KK_MV4B(NE, FL, B0, XR, PT)                                                                                                \
+#define KK_MV4B(B0, XR, PT)                                                                                                        \
   do {                                                                                                                          \
     const size_t lds = slabs + 4 * rows * mv4_pitch(3 * NE + (NE & 1), (int)sizeof(AT)) * sizeof(AT);                            \
-    KK_MV4_ATTR(NE, FL, B0, XR, PT);                                                                                              \
+    KK_MV4_ATTR(B0, XR, PT);                                                                                                      \
     KK_LAUNCH((spmv_mv4_kernel<OffT, AT, NE, FL, B0, XR, PT>), (unsigned)(m->npi * m->npj * m->nchunk * ncb), kMv4Threads, lds, st,  \
               (const OffT*)m->d_arow, (const uint32_t*)m->d_amask, (const AT*)A->d_values, m->grp, X, xs0, xs1, Y, ys0, ys1, alpha, \
               beta, yv, m->nx, m->ny, m->nz, m->S1, m->S2, m->npi, m->npj, m->kc, ncv, ncb);                                     \
   } while (0)
-#define KK_MV4(NE, FL)                                                                                                          \
-  do {                                                                                                                          \
-    if (part) {                                                                                                                 \
-      if (beta == 0.0) { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, true, 1, true); else if (xcol) KK_MV4B(NE, FL, true, 2, true); else KK_MV4B(NE, FL, true, 0, true); }   \
-      else { if (xrow && ncv % 2 == 0) KK_MV4B(NE, FL, false, 1, true); else if (xcol) KK_MV4B(NE, FL, false, 2, true); else KK_MV4B(NE, FL, false, 0, true); }             \
-    }                                                                                                                           \
-    else if (beta == 0.0) { if (xrow) KK_MV4B(NE, FL, true, 1, false); else if (xcol) KK_MV4B(NE, FL, true, 2, false); else KK_MV4B(NE, FL, true, 0, false); }    \
-    else { if (xrow) KK_MV4B(NE, FL, false, 1, false); else if (xcol) KK_MV4B(NE, FL, false, 2, false); else KK_MV4B(NE, FL, false, 0, false); }                 \
-  } while (0)
-  const bool part = ncv < 16;
+  if (part) {
+    if (beta == 0.0) { if (xrow && ncv % 2 == 0) KK_MV4B(true, 1, true); else if (xcol) KK_MV4B(true, 2, true); else KK_MV4B(true, 0, true); }
+    else { if (xrow && ncv % 2 == 0) KK_MV4B(false, 1, true); else if (xcol) KK_MV4B(false, 2, true); else KK_MV4B(false, 0, true); }
+  }
+  else if (beta == 0.0) { if (xrow) KK_MV4B(true, 1, false); else if (xcol) KK_MV4B(true, 2, false); else KK_MV4B(true, 0, false); }
+  else { if (xrow) KK_MV4B(false, 1, false); else if (xcol) KK_MV4B(false, 2, false); else KK_MV4B(false, 0, false); }
+#undef KK_MV4B
+#undef KK_MV4_ATTR
+  KK_LAUNCH_CHECK();
+  return KKAMD_OK;
+}
+#else
+;
+#endif
+
+template <class OffT, class AT>
+int launch_mv4_rows(const kkamd_mv4_plan* m, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+                    double alpha, double beta, hipStream_t st, int ncv, int ncb)
+#ifdef KK_MV4_INSTANTIATE
+{
+  for (int q = 0; q < ncb; ++q) {
+    const double* Xq = X + (int64_t)q * 16 * xs1; double* Yq = Y + (int64_t)q * 16 * ys1;
+    const int ncv_q = q == ncb - 1 ? ncv : 16;
+    KK_LAUNCH((mv4_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
+              (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xq, xs0, xs1, Yq, ys0, ys1, alpha, beta, ncv_q);
+    KK_LAUNCH_CHECK();
+  }
+  return KKAMD_OK;
+}
+#else
+;
+#endif
+
+constexpr unsigned kMv4Pat27 = 0x7FFFFFFu;              // 9 groups x {-1, 0, 1}: the 27-point stencil
+constexpr unsigned kMv4Pat7  = 2u | 2u << 3 | 7u << 6 | 2u << 9 | 2u << 12;   // (dk, di) = (-1,0) (0,-1) (0,0) (0,1) (1,0): the 7-point stencil
+#define KK_MV4_FOR_ALL(F) F(int32_t, double) F(int32_t, float) F(int64_t, double) F(int64_t, float)
+#define KK_MV4_DECL(OT, AT_)                                                                                                                                \
+  extern template int launch_mv4_stencil<OT, AT_, 9, kMv4Pat27>(const kkamd_mv4_plan*, const kkamd_crs_t*, const double*, int64_t, int64_t, double*, int64_t, int64_t, double, double, hipStream_t, int, int, bool, bool); \
+  extern template int launch_mv4_stencil<OT, AT_, 5, kMv4Pat7>(const kkamd_mv4_plan*, const kkamd_crs_t*, const double*, int64_t, int64_t, double*, int64_t, int64_t, double, double, hipStream_t, int, int, bool, bool);  \
+  extern template int launch_mv4_stencil<OT, AT_, 5, 0u>(const kkamd_mv4_plan*, const kkamd_crs_t*, const double*, int64_t, int64_t, double*, int64_t, int64_t, double, double, hipStream_t, int, int, bool, bool);        \
+  extern template int launch_mv4_stencil<OT, AT_, 9, 0u>(const kkamd_mv4_plan*, const kkamd_crs_t*, const double*, int64_t, int64_t, double*, int64_t, int64_t, double, double, hipStream_t, int, int, bool, bool);        \
+  extern template int launch_mv4_rows<OT, AT_>(const kkamd_mv4_plan*, const kkamd_crs_t*, const double*, int64_t, int64_t, double*, int64_t, int64_t, double, double, hipStream_t, int, int);
+#ifndef KK_MV4_INSTANTIATE
+KK_MV4_FOR_ALL(KK_MV4_DECL)
+#endif
+#undef KK_MV4_DECL
+
+template <class OffT, class AT>
+inline int launch_mv4(const kkamd_spmv_plan* plan, const kkamd_crs_t* A, const double* X, int64_t xs0, int64_t xs1, double* Y, int64_t ys0, int64_t ys1,
+                      double alpha, double beta, hipStream_t st, int ncv = 16, int ncb = 1) {
+  const kkamd_mv4_plan* m = plan->mv4;
   const bool xrow = xs1 == 1 && (xs0 % 2 == 0) && ((uintptr_t)X % 16 == 0);
   const bool xcol = xs0 == 1 && plan->tune.mv4_xcol;   // column-major X: the column-wise piece order with swizzled slab rows
   unsigned pat = 0;                                    // 3 bits per group: which of dj = -1, 0, 1 it holds
   for (int g = 0; g < m->grp.ng; ++g) pat |= (unsigned)m->grp.pres[g] << (3 * g);
-  constexpr unsigned kPat27 = 0x7FFFFFFu;              // 9 groups x {-1, 0, 1}: the 27-point stencil
-  constexpr unsigned kPat7  = 2u | 2u << 3 | 7u << 6 | 2u << 9 | 2u << 12;   // (dk, di) = (-1,0) (0,-1) (0,0) (0,1) (1,0): the 7-point stencil
-  if (m->grp.ng == 9 && pat == kPat27) KK_MV4(9, kPat27);
-  else if (m->grp.ng == 5 && pat == kPat7) KK_MV4(5, kPat7);
-  else if (m->grp.ng <= 5) KK_MV4(5, 0u);
-  else KK_MV4(9, 0u);
-#undef KK_MV4B
-#undef KK_MV4
-#undef KK_MV4_ATTR
-  KK_LAUNCH_CHECK();
-  if (m->n_nc > 0) {
-    for (int q = 0; q < ncb; ++q) {
-      const double* Xq = X + (int64_t)q * 16 * xs1; double* Yq = Y + (int64_t)q * 16 * ys1;
-      const int ncv_q = q == ncb - 1 ? ncv : 16;
-      KK_LAUNCH((mv4_rows_kernel<OffT, AT>), (unsigned)ceil_div(m->n_nc * 16, (int64_t)kBlock), kBlock, 0, st, m->n_nc, (const int32_t*)m->d_nc,
-                (const OffT*)A->d_row_map, (const int32_t*)A->d_entries, (const AT*)A->d_values, Xq, xs0, xs1, Yq, ys0, ys1, alpha, beta, ncv_q);
-      KK_LAUNCH_CHECK();
-    }
-  }
+  int rc;
+  if (m->grp.ng == 9 && pat == kMv4Pat27) rc = launch_mv4_stencil<OffT, AT, 9, kMv4Pat27>(m, A, X, xs0, xs1, Y, ys0, ys1, alpha, beta, st, ncv, ncb, xrow, xcol);
+  else if (m->grp.ng == 5 && pat == kMv4Pat7) rc = launch_mv4_stencil<OffT, AT, 5, kMv4Pat7>(m, A, X, xs0, xs1, Y, ys0, ys1, alpha, beta, st, ncv, ncb, xrow, xcol);
+  else if (m->grp.ng <= 5) rc = launch_mv4_stencil<OffT, AT, 5, 0u>(m, A, X, xs0, xs1, Y, ys0, ys1, alpha, beta, st, ncv, ncb, xrow, xcol);
+  else rc = launch_mv4_stencil<OffT, AT, 9, 0u>(m, A, X, xs0, xs1, Y, ys0, ys1, alpha, beta, st, ncv, ncb, xrow, xcol);
+  if (rc) return rc;
+  if (m->n_nc > 0) return launch_mv4_rows<OffT, AT>(m, A, X, xs0, xs1, Y, ys0, ys1, alpha, beta, st, ncv, ncb);
   return KKAMD_OK;
 }
 
