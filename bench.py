@@ -139,10 +139,35 @@ def bench_spmv_mv(kk, torch, A, budget_s, cpu):
         r.update(GFLOPs=round(2.0 * nnz * nv / r["mean_ms"] / 1e6, 1), achieved_GBps=round(alg / r["mean_ms"] / 1e6, 1),
                  frac=round(alg / r["mean_ms"] / 1e6 / HBM_PEAK_GBPS, 4),
                  kernel=_mv_kernel_name(h))
+        r.update(_mv_traffic(layout, r["mean_ms"]))
         out["layout_" + layout] = r
         del h, Y
     if cpu and time.perf_counter() - t_start < budget_s:
         out["cpu_baseline"] = cpu_baseline_mv(nv)
+    return out
+
+
+def _mv_traffic(layout, mean_ms):
+    """memory-side bytes per launch of the plane-marching kernel from the committed counter file (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
+    of tools/bench_mv4.py; FETCH_SIZE x 2 on gfx950), quoted only when the file was measured on the kernel source this library was built from"""
+    sha = kernel_source_sha("kk_spmv_mv4.h")
+    out = {"traffic": None, "kernel_source_sha": sha}
+    try:
+        d = json.load(open(MV_PMC_FILE))
+        if d.get("kernel_source_sha") != sha:
+            out["traffic_source"] = "%s is stale (measured on kernel source %s): traffic not quoted" % (os.path.relpath(MV_PMC_FILE, ROOT), d.get("kernel_source_sha"))
+            return out
+        tag = ", 1, false>" if layout == "right" else ", 2, false>"          # <.., BETA0, X layout mode, PART>: row-major X = 1, column-major X = 2
+        rd = wr = 0.0
+        for k, v in d.get("counters", {}).items():
+            if "spmv_mv4_kernel" in k and tag in k:
+                if "FETCH_SIZE" in k: rd = v["mean_KB"] * 1024 * 2
+                if "WRITE_SIZE" in k: wr = v["mean_KB"] * 1024
+        if rd and wr:
+            out.update(traffic=int(rd + wr), moved_frac=round((rd + wr) / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                       traffic_source="%s (FETCH_SIZE x 2 + WRITE_SIZE per launch)" % os.path.relpath(MV_PMC_FILE, ROOT))
+    except Exception:
+        pass
     return out
 
 

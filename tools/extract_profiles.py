@@ -10,7 +10,7 @@ out = os.path.join(ROOT, "gpurun_out", "summary", rnd); os.makedirs(out, exist_o
 import bench
 # the translation unit a profile tag measures, by the tag's first word(s): every file is stamped with THAT unit's hash
 # (round 5 stamped "spgemm_s20" and "bench_full" with kk_spmv.hip's: the tags were looked up whole)
-UNIT = (("spgemm", "kk_spgemm.hip"), ("mv4", "kk_spmv_mv.hip"), ("mv5", "kk_spmv_mvblk.hip"), ("mv6", "kk_spmv_mvnnz.hip"), ("mv", "kk_spmv_mv.hip"),
+UNIT = (("spgemm", "kk_spgemm.hip"), ("mv4", "kk_spmv_mv4.h"), ("mv5", "kk_spmv_mvblk.hip"), ("mv6", "kk_spmv_mvnnz.hip"), ("mv", "kk_spmv_mv.hip"),
         ("struct", "kk_spmv_struct.hip"), ("colslab", "kk_spmv_colslab.hip"), ("dist", "kk_dist.hip"), ("bench_full", None), ("bench", "kk_spmv.hip"))
 
 
