@@ -157,7 +157,7 @@ def _mv_traffic(layout, mean_ms):
         if d.get("kernel_source_sha") != sha:
             out["traffic_source"] = "%s is stale (measured on kernel source %s): traffic not quoted" % (os.path.relpath(MV_PMC_FILE, ROOT), d.get("kernel_source_sha"))
             return out
-        tag = ", 1, false>" if layout == "right" else ", 2, false>"          # <.., BETA0, X layout mode, PART>: row-major X = 1, column-major X = 2
+        tag = "true, 1, false>" if layout == "right" else "true, 2, false>"  # <.., BETA0 (the bench runs beta = 0), X layout mode (row-major 1, column-major 2), PART>
         rd = wr = 0.0
         for k, v in d.get("counters", {}).items():
             if "spmv_mv4_kernel" in k and tag in k:
