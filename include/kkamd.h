@@ -151,12 +151,17 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *                       returns KKAMD_ERR_STATE when it differs from what the handle first saw: a structure edited in place under a live
  *                       handle (the pointer comparison of every call cannot see that; rocSPARSE's analysis has the same contract)
  *     "colslab"         mode N on matrices whose x gather defeats the caches (most tiles read plain entries, x is >= 16 MB, from
- *                       "colslab_min_knnz" thousand nonzeros): 0 (default) never; 1 the first call builds a second copy of the matrix in
- *                       column-slab order (entries sorted by 2 MB segments of x, then by row; nnz * (8 + value + offset) bytes),
- *                       times the CRS kernel and the copy ON THE CALLER'S STREAM (the call blocks) and keeps the copy when it is 10 %
- *                       faster; the values follow "values_tracking".  Products reach y through atomics: results agree with the CRS
- *                       kernel to rounding, not bit for bit, and vary in the last bits from run to run -- which is why it is opt-in.
- *                       2 = always (no gates, no timing: tests).  "colslab_shift" log2 of the columns per slab (0 = automatic),
+ *                       "colslab_min_knnz" thousand nonzeros): a second copy of the matrix in column-slab order (entries sorted by 2 MB
+ *                       segments of x, then by row; nnz * (8 + value + offset) bytes) whose values follow "values_tracking".
+ *                       3 (default): the DETERMINISTIC form -- per-slab partial sums of every row with one writer each, slabs added in
+ *                       ascending order: no atomics, the same bits on every run --, chosen at the first call by a RULE, nothing is timed:
+ *                       sampled windows of the matrix name at least "colslab_min_pct" (85) percent of a 128-byte line of x per nonzero,
+ *                       and the bytes the slab form streams, priced at "colslab_rate_pct" (61: its rate over the rate at which the CRS
+ *                       kernel's gathers pull lines, 4.24 / 6.95 TB/s measured on MI355X) of the lines the CRS kernel would pull, are
+ *                       fewer by 10 %; 4 always the deterministic form (tests); 1 the ATOMIC form (products reach y through atomics:
+ *                       results agree with the CRS kernel to rounding and vary in the last bits from run to run), chosen by timing both
+ *                       kernels ON THE CALLER'S STREAM inside the first call (the call blocks), kept when 10 % faster; 2 always the
+ *                       atomic form (tests); 0 never.  "colslab_shift" log2 of the columns per slab (0 = automatic),
  *                       "colslab_const" 1 = the caller promises constant matrix values (no tracking pass)
  *   SpMV, rank 2
  *     "mv6"             nonzero-split kernel (kk_spmv_mvnnz.hip; analysed plan, fp64 vectors): the nonzeros are cut into chunks of 128 per
@@ -191,9 +196,13 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *   SpGEMM (kkamd_set_default only) "spgemm_win_bits" (columns per LDS bitmap pass), "spgemm_val_cap", "spgemm_val_shape",
  *          "spgemm_val_la", "spgemm_force_unsorted", "spgemm_emit_chunked" (test hooks for alternative code paths);
  *          "spgemm_emit_sort" (1: entries(C) of rows with more than 256 entries out of at most 2048 products are sorted in LDS, eight rows
- *          per CU; 0: they take the bitmap kernel like every other dense row), "spgemm_col_quads" (0 / 4 / 8: 16-byte loads of entries(B) per
- *          work-item and step in the bitmap kernels), "spgemm_val_steps" (1..3 steps of a window's product walk in flight in the flat
- *          value kernel; measured neutral), "spgemm_quad_rows" (wave-per-row kernels with four rows per wave, 16 lanes each: 1 = for the rows
+ *          per CU; 0: they take the bitmap kernel like every other dense row), "spgemm_col_quads" (0 / 4: 16-byte loads of entries(B) per
+ *          work-item and step in the row-by-row bitmap kernels), "spgemm_sym_units" (1, default: the symbolic phase counts its dense class
+ *          by units = (row of C, window of columns), each a workgroup of its own around a 32 KB LDS bitmap, described by heads built from an
+ *          index of B and of A's entries at window granularity; 0: one workgroup per row, as before round 6), "spgemm_unit_bits" (log2 of a
+ *          unit's window, 6..18, default 18; small values are for tests), "spgemm_store_cap_mb" (upper limit, in MB, of the structure the
+ *          symbolic phase keeps for the first numeric call; 0 = default: 0.225 of the free HBM; room goes to the heaviest rows first and
+ *          rows past the limit walk their products again in the numeric phase), "spgemm_quad_rows" (wave-per-row kernels with four rows per wave, 16 lanes each: 1 = for the rows
  *          with at most 64 products (symbolic) / 32 entries (numeric) -- stencil and multigrid products --, 2 = for every row of the wave bin, 0 = never).
  * Knobs that switch parts of kernels OFF ("ablate", "lds_pad_kb", "struct_lds_pad_kb", "spgemm_debug") exist only in the
  * measurement build libkkamd_ablate.so (csrc: make ablate, -DKK_ABLATE); libkkamd.so answers KKAMD_ERR_INVALID_ARG. */
@@ -232,7 +241,10 @@ int kkamd_spmv_plan_export(const kkamd_spmv_plan_t* plan, const char* what, void
  *             by peer-to-peer pulls (every rank maps the others' x buffers through hipIpc once and pulls world - 1 shards with
  *             concurrent copies between two 8-byte barrier collectives: all 7 xGMI links at once, no ring), 4 halo by column SET
  *             (the general importer: exactly the x entries the slab's off-slab columns name -- per-peer index lists agreed once,
- *             a pack kernel, point-to-point pieces, a scatter kernel);
+ *             a pack kernel, point-to-point pieces, a scatter kernel), 5 all-gather in the form the operator picks BY TIMING at
+ *             creation: every form the transport and the runtime offer (the collective; every shard to every peer point to point;
+ *             peer-to-peer pulls) runs one warm-up and two timed exchanges with all ranks in step, and the form with the smallest
+ *             maximum over the ranks stays.  Since round 6 the auto rule's all-gather is 5; 2 and 3 remain as forced forms;
  *   overlap   1: rows that reference only the rank's own x entries are computed while the halo is in flight.
  * Transport: by default RCCL, bound at run time from the librccl.so.1 already in the process; rank 0 obtains the 128-byte id
  * with kkamd_dist_unique_id and the host's launcher (MPI, torch.distributed, a file) hands it to every rank.  A host that
@@ -270,7 +282,9 @@ int kkamd_dist_spmv_x_local(kkamd_dist_spmv_t* op, void** d_x_local, void** d_x_
  * (measurement aids: 1 and 2 split a step into its two costs). */
 int kkamd_dist_spmv_apply(kkamd_dist_spmv_t* op, double alpha, const void* d_x_shard, double beta, void* d_y_shard, int what,
                           kkamd_stream_t stream);
-/* "exchange" (0 local, 1 halo by column range, 2 all-gather, 3 all-gather by peer-to-peer pulls, 4 halo by column set), "exchange_bytes"
+/* "exchange" (0 local, 1 halo by column range, 2 all-gather, 3 all-gather by peer-to-peer pulls, 4 halo by column set, 5 all-gather in
+ * the timed form: "allgather_selected" 1, "allgather_form" 0 collective / 1 send-receive / 2 peer-to-peer pulls,
+ * "allgather_us_collective" / "_sendrecv" / "_p2p" the maximum over the ranks measured at creation, -1 = form not offered), "exchange_bytes"
  * (received per SpMV), "interior_rows", "parts", "sends", "recvs", "part0_rows" (rows of the interior view, or of the slab when it is
  * not split) and "part0_<key>" = kkamd_spmv_plan_query(<key>) of that view's plan (e.g. "part0_pattern_tiles") */
 int kkamd_dist_spmv_query(const kkamd_dist_spmv_t* op, const char* key, int64_t* value);
@@ -333,7 +347,9 @@ int kkamd_spgemm_set(kkamd_spgemm_handle_t* handle, const char* key, double valu
  * last numeric call copied from the entry lists the symbolic phase left (dense rows whose bitmap is not kept), 15 rows whose entries(C)
  * the last numeric call sorted in LDS (rows of more than 256 entries out of at most 2048 products), 16 - 18 rows / items of the column-block
  * value kernel, 19 units (row of C, window of 2^18 columns) the last symbolic phase counted its dense class by (0: none, or row by row),
- * 20 units whose bitmap it kept for the numeric phase, 21 rows of the class whose every unit kept its structure (bitmap or entry list).
+ * 20 units whose bitmap it kept for the numeric phase, 21 rows of the class whose every unit kept its structure (bitmap or entry list),
+ * 22 bytes the process-wide store of kept structure holds at this moment, 23 the most it has held (process-wide; both are independent of
+ * the handle passed; kkamd_release_scratch returns the store to the device).
  * With units, 12 counts the rows whose entries(C) the last numeric call wrote from kept units, 13 the rows held, 14 those of 12 with at
  * least one unit kept as an entry list. */
 int kkamd_spgemm_get(kkamd_spgemm_handle_t* handle, int what, int64_t* value);

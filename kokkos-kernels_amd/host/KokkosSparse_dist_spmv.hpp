@@ -11,7 +11,8 @@
 
 namespace KokkosSparse { namespace Experimental {
 
-enum DistExchange { DIST_EXCHANGE_AUTO = 0, DIST_EXCHANGE_HALO = 1, DIST_EXCHANGE_ALLGATHER = 2, DIST_EXCHANGE_ALLGATHER_P2P = 3, DIST_EXCHANGE_HALO_SET = 4 };
+enum DistExchange { DIST_EXCHANGE_AUTO = 0, DIST_EXCHANGE_HALO = 1, DIST_EXCHANGE_ALLGATHER = 2, DIST_EXCHANGE_ALLGATHER_P2P = 3, DIST_EXCHANGE_HALO_SET = 4,
+                    DIST_EXCHANGE_ALLGATHER_TIMED = 5 /* the form of the all-gather is chosen by timing at creation (include/kkamd.h) */ };
 
 template <class AMatrix>
 class DistributedSpMV {

@@ -1,13 +1,13 @@
 """Every figure of the round's results tables comes from a committed measurement file (tools/tables_from_profiles.py builds the tables
-from profiles/round5/); this test regenerates them and fails when profiles/round5/TABLES.md, or the marked copy of it in DESIGN.md /
-BASELINE.md, differs -- and checks the figures quoted in prose (profiles/round5/quoted.json: text, file, key, value) to 1 %.
+from profiles/round6/); this test regenerates them and fails when profiles/round6/TABLES.md, or the marked copy of it in DESIGN.md /
+BASELINE.md, differs -- and checks the figures quoted in prose (profiles/round6/quoted.json: text, file, key, value) to 1 %.
 Round-4 review: "docs quote better numbers than the committed evidence"."""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-ROUND = "round5"
+ROUND = "round6"
 
 
 def test_tables_equal_the_committed_files():
