@@ -137,7 +137,10 @@ int kkamd_spmv_struct(const kkamd_crs_t* A, char mode, int stencil_type, int ndi
  *                       at least "window_codes_min_pct" percent of the tiles can use them (the others read entries, tile by tile);
  *                       "stream_variant" 6 attempts the analysis whatever the size (tests), 1 is the default
  *     "pattern_codes"   staged-x tiles: row-pattern records instead of per-nonzero codes; 1 (default) when >= 90 % of the tiles
- *                       decompose, 2 whenever one does, 0 never; from "pattern_codes_min_knnz" thousand nonzeros
+ *                       decompose, 2 whenever one does, 0 never; from "pattern_codes_min_knnz" thousand nonzeros.  "pattern_direct" 1
+ *                       (default): the records are first sought straight in the matrix (rows compared, the window cover over the <= 256
+ *                       column intervals of a tile) and kept when at most one tile in a hundred has none -- those read entries --, no
+ *                       window codes are built (plan of 27-pt 300^3: 6.2 -> 2.5 ms); 0: always by way of the codes.  Query "pattern_direct"
  *     "transient_min_knnz"  handle-less / FAST_SETUP calls analyse on the fly from this many thousand nonzeros (0 never)
  *     "explicit_transpose"  modes T/H with an analysed handle (rank 1 and rank 2): 1 (default) through a transpose cached in the plan when
  *                       it fits an eighth of free HBM, its values follow "values_tracking"; 2 the caller promises constant

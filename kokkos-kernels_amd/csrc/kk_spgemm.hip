@@ -1078,6 +1078,97 @@ __device__ __forceinline__ int emit_bits_by_wave_staged(const kk_u64* __restrict
   }
   return tot;
 }
+// The same for the bitmaps of UNITS (row of C, window of columns), which are sparse: a unit keeps a bitmap when its PRODUCTS could fill one,
+// and on R-MAT a unit's 262144 bits hold 7000 entries on average -- a 16-bit piece holds 0.4, and the four rounds of pieces per 64 words
+// (two lane exchanges, a prefix sum, a store of a few dozen entries each) cost 0.86 vector instructions per entry over the whole kernel, 58 % of
+// the vector unit's time.  Here a lane lays down the set bits of its OWN word: one prefix sum and one store round per 64 words; only
+// rounds that hold more than the wave's 1024 staging slots (every fourth bit set) go by pieces.
+// The kernel's code must stay small: the 16 rounds of a wave are unrolled (the words sit in registers), and with the piece form inlined in
+// every round the kernel was 124 KB of instructions and 126 registers -- twice the instruction cache two CUs share, four waves per SIMD.
+// So the unrolled rounds hold the sparse form only; a pair of rounds with more than 1024 entries is noted (its place in entries(C) in LDS)
+// and taken afterwards by a loop that exists once and reads the pair's words again.
+template <int NT>
+__device__ __forceinline__ int emit_unit_bits_by_wave(const kk_u64* __restrict__ bm, int words, int64_t col0, int64_t pos0, int32_t* __restrict__ entC, int* s_wave,
+                                                      int32_t* __restrict__ stage /* [1024] of this wave */, int* __restrict__ later /* [16] of this wave */) {
+  constexpr int NW = NT / 64, NB = 16;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wpw = ((words + NW - 1) / NW + 63) & ~63;
+  const int w0 = wave * wpw, w1 = (w0 + wpw < words) ? w0 + wpw : words;
+  kk_u64 w[NB];
+  int wsum = 0;
+  KK_UNROLL
+  for (int i = 0; i < NB; ++i) { const int wd = w0 + i * 64 + lane; w[i] = (i * 64 < wpw && wd < w1) ? bm[wd] : 0ull; wsum += __popcll(w[i]); }
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+  if (lane == 0) s_wave[wave] = wsum;
+  __syncthreads();
+  int tot = 0;
+  for (int i = 0; i < NW; ++i) { if (i == wave) pos0 += tot; tot += s_wave[i]; }
+  auto lay = [&](kk_u64 v, int at, int cb) {               // the set bits of the lane's own word, ascending, from stage[at]
+    unsigned lo32 = (unsigned)v, hi32 = (unsigned)(v >> 32);
+    _Pragma("nounroll") while (lo32) { stage[at++] = cb + (__ffs((int)lo32) - 1); lo32 &= lo32 - 1u; }
+    _Pragma("nounroll") while (hi32) { stage[at++] = cb + 32 + (__ffs((int)hi32) - 1); hi32 &= hi32 - 1u; }
+  };
+  auto flush = [&](int64_t at, int n) {                    // stage[0 .. n) -> entries(C), 64 consecutive entries per store instruction
+    KK_WAVE_SYNC();
+    _Pragma("nounroll") for (int q = lane; q < n; q += 64) entC[at + q] = stage[q];
+    KK_WAVE_SYNC();
+  };
+  // two rounds of 64 words share one prefix sum (their popcounts -- at most 64 per lane, 4096 per round -- packed into the halves of one int)
+  unsigned dense = 0u;                                     // (uniform) pairs left for the loop below
+  int rel = 0;                                             // entries of this wave before the round
+  KK_UNROLL
+  for (int i = 0; i < NB; i += 2) {
+    if (i * 64 >= wpw) break;                              // uniform (wpw is a multiple of 64: round i + 1 may lie beyond it and is then all zero)
+    const int pa = __popcll(w[i]), pb = __popcll(w[i + 1]);
+    const int inc = wave_inclusive_scan_i32(pa | (pb << 16), lane);
+    const int last = wave_last_lane_i32(inc);
+    const int ta = last & 0xffff, tb = last >> 16;
+    if (ta + tb == 0) continue;                            // 128 empty words (uniform)
+    if (ta + tb <= 1024) {
+      lay(w[i], (inc & 0xffff) - pa, (int)(col0 + ((int64_t)(w0 + i * 64 + lane)) * 64));
+      lay(w[i + 1], ta + (inc >> 16) - pb, (int)(col0 + ((int64_t)(w0 + i * 64 + 64 + lane)) * 64));
+      flush(pos0 + rel, ta + tb);
+    } else {
+      if (lane == 0) later[i >> 1] = rel;
+      dense |= 1u << (i >> 1);
+    }
+    rel += ta + tb;
+  }
+  KK_WAVE_SYNC();
+  while (dense) {                                          // (uniform)
+    const int pr = __ffs((int)dense) - 1;
+    dense &= dense - 1u;
+    int64_t at = pos0 + later[pr];
+    _Pragma("nounroll") for (int half = 0; half < 2; ++half) {
+      const int wbase = w0 + pr * 128 + half * 64;
+      const kk_u64 v = (wbase + lane < w1) ? bm[wbase + lane] : 0ull;
+      const int pcw = __popcll(v);
+      const int incw = wave_inclusive_scan_i32(pcw, lane);
+      const int totw = wave_last_lane_i32(incw);
+      if (totw == 0) continue;                             // uniform
+      if (totw <= 1024) {
+        lay(v, incw - pcw, (int)(col0 + ((int64_t)(wbase + lane)) * 64));
+        flush(at, totw); at += totw;
+        continue;
+      }
+      _Pragma("nounroll") for (int sub = 0; sub < 4; ++sub) {                  // 16 words = 64 pieces of 16 bits at a time
+        const int src = sub * 16 + (lane >> 2);
+        const unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
+        const unsigned hf = (lane & 2) ? hi : lo;
+        unsigned piece = (lane & 1) ? (hf >> 16) : (hf & 0xffffu);
+        const int pc = __popc(piece);
+        const int inc = wave_inclusive_scan_i32(pc, lane);
+        const int total = wave_last_lane_i32(inc);
+        if (total == 0) continue;                          // uniform
+        int a = inc - pc;
+        const int c0 = (int)(col0 + ((int64_t)(wbase + src)) * 64 + 16 * (lane & 3));
+        _Pragma("nounroll") while (piece) { const int bit = __ffs((int)piece) - 1; stage[a++] = c0 + bit; piece &= piece - 1; }
+        flush(at, total); at += total;
+      }
+    }
+  }
+  return tot;
+}
 struct BitmapStore {                 // where the symbolic count kernel may leave a row's bitmap (words == 0: nowhere)
   kk_u64* words_out = nullptr;       // [cap][words]
   int32_t* row_slot = nullptr;       // [m], -1 = not stored
@@ -1673,6 +1764,7 @@ __global__ __launch_bounds__(NT) void spgemm_emit_unit_kernel(const UnitHead* __
                                                               const unsigned* __restrict__ ucnt, const unsigned* __restrict__ ucoff, const char* __restrict__ store,
                                                               const OffT* __restrict__ rmC, int32_t* __restrict__ entC, int64_t min_nnz) {
   __shared__ int s_wave[NT / 64];
+  __shared__ int s_later[NT / 64][16];
   __shared__ int32_t s_stage[NT / 64][1024];
   const UnitHead hd = heads[blockIdx.x];
   const unsigned u = (unsigned)hd.unit;
@@ -1684,12 +1776,12 @@ __global__ __launch_bounds__(NT) void spgemm_emit_unit_kernel(const UnitHead* __
   const int64_t base = rbeg + coff;
   if (hd.kind == 0) {
     const int32_t* src = reinterpret_cast<const int32_t*>(store + hd.store_off);
-    for (unsigned i = threadIdx.x; i < cnt; i += NT) entC[base + i] = src[i];
+    _Pragma("unroll 4") for (unsigned i = threadIdx.x; i < cnt; i += NT) entC[base + i] = src[i];
   } else {
     const unsigned w = u % (unsigned)nwin;
     const int64_t c0 = (int64_t)w << wb;
     const int nbits = (int)(k - c0 < ((int64_t)1 << wb) ? k - c0 : ((int64_t)1 << wb));
-    (void)emit_bits_by_wave_staged<NT>(reinterpret_cast<const kk_u64*>(store + hd.store_off), (nbits + 63) >> 6, c0, base, entC, s_wave, s_stage[threadIdx.x >> 6]);
+    (void)emit_unit_bits_by_wave<NT>(reinterpret_cast<const kk_u64*>(store + hd.store_off), (nbits + 63) >> 6, c0, base, entC, s_wave, s_stage[threadIdx.x >> 6], s_later[threadIdx.x >> 6]);
   }
 }
 // rows of the class whose every unit with entries left its structure: unit_row[row] = rank of the row in the class's list (bit 30: at least one of

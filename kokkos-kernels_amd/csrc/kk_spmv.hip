@@ -343,6 +343,169 @@ __global__ __launch_bounds__(kBlock) void pat_build_kernel(int64_t nnz, const Of
   }
 }
 
+// The row-pattern record of a tile, DIRECTLY from the matrix (round 6).  On a stencil matrix nearly every tile ends as a pattern tile, and
+// the way there -- win_build_kernel (greedy window cover over the tile's 4096 entries by all four waves, two barriers per window, then a code
+// per entry: 10,000 vector instructions per tile, 4.3 of the 6.2 ms a plan of C2 took) followed by pat_build_kernel on the codes -- computes
+// 2 bytes per nonzero that a pattern tile never reads.  Here the order is turned round: the rows are compared first (entry k of a row = entry
+// k of the row before + 1: one comparison per nonzero out of LDS), which leaves <= kPatSeg segments of <= kPatLen entries; the columns a tile
+// touches are then <= 256 INTERVALS (entry k of a segment's first row, one column further per row), and the same greedy cover runs over those,
+// on one wave, four intervals per lane.  The window meta and the record are what the two kernels would have produced (column adjacency implies
+// slot adjacency, so a tile accepted here is accepted there; the converse fails only where two windows abut in LDS by coincidence).
+// tinfo[b] = kTilePattern, or kTilePlain where the tile has no record: the caller keeps this analysis when at most one tile in a hundred
+// is left plain, otherwise it starts over with the window codes.
+template <class OffT, int NPT>
+__global__ __launch_bounds__(kBlock) void pat_direct_kernel(int64_t nnz, const OffT* __restrict__ row_map, const int32_t* __restrict__ entries,
+                                                            const int32_t* __restrict__ blk_info, int32_t* __restrict__ wmeta,
+                                                            int32_t* __restrict__ tinfo, int32_t* __restrict__ pmeta) {
+  constexpr int TILE = kBlock * NPT, NI = kPatSeg * kPatLen;
+  static_assert(NI == kBlock, "one interval per work-item");
+  __shared__ int s_col[TILE];
+  __shared__ int s_segq[kPatSeg];
+  __shared__ int s_lo[NI], s_hi[NI];
+  __shared__ int s_base[kWinCount], s_nch[kWinCount], s_off[kWinCount + 1];
+  __shared__ int s_nseg, s_bad;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t b = blockIdx.x, s = b * TILE;
+  int32_t* out = pmeta + b * kPatW;
+  if (s + TILE > nnz) { if (t == 0) tinfo[b] = kTilePlain; return; }        // (uniform) the ragged last tile
+  KK_UNROLL
+  for (int k = 0; k < NPT; ++k) s_col[k * kBlock + t] = entries[s + (int64_t)k * kBlock + t];
+  if (t == 0) { s_nseg = 0; s_bad = 0; }
+  const int32_t info0 = blk_info[b], info1 = blk_info[b + 1];
+  const int64_t ra = info0 & 0x7fffffff, rb = info1 & 0x7fffffff;
+  const int has_head = (info0 >> 31) & 1;
+  const int64_t nv = (rb - ra) + has_head;                   // rows with at least their start or their end in this tile
+  __syncthreads();
+  for (int64_t q = t; q < nv; q += kBlock) {
+    const int64_t r  = ra + q - has_head;
+    const int64_t rs = (int64_t)row_map[r] - s, re = (int64_t)row_map[r + 1] - s, L = re - rs;
+    bool head = true;
+    if (L < 1 || L > kPatLen) atomicOr(&s_bad, 1);
+    else if (q > 0) {
+      const int64_t ps = (int64_t)row_map[r - 1] - s;
+      if (rs - ps == L) {
+        head = false;
+        for (int k = 0; k < (int)L; ++k) {
+          const int64_t i0 = ps + k, i1 = rs + k;
+          if (i0 >= 0 && i1 < TILE && s_col[i1] != s_col[i0] + 1) head = true;
+        }
+      }
+    }
+    if (head) { const int idx = atomicAdd(&s_nseg, 1); if (idx < kPatSeg) s_segq[idx] = (int)q; }
+  }
+  __syncthreads();
+  const int nseg = s_nseg;
+  if (s_bad || nseg > kPatSeg || nseg < 1) { if (t == 0) tinfo[b] = kTilePlain; return; }      // (uniform)
+  if (t == 0) {                                               // segment heads in row order
+    for (int a = 1; a < nseg; ++a) { const int v = s_segq[a]; int c = a - 1; while (c >= 0 && s_segq[c] > v) { s_segq[c + 1] = s_segq[c]; --c; } s_segq[c + 1] = v; }
+  }
+  __syncthreads();
+  // interval t = (segment g, entry k): the columns entry k takes over the segment's rows that have it inside the tile; for the record:
+  // the column the entry's slot is derived from (csrc) and the correction (-1 when it is the second row's)
+  int csrc = -1, cadj = 0;
+  {
+    const int g = t / kPatLen, k = t % kPatLen;
+    int lo = INT_MAX, hi = -1;
+    if (g < nseg) {
+      const int q0 = s_segq[g], q1 = (g + 1 < nseg) ? s_segq[g + 1] : (int)nv;
+      const int64_t r0 = ra + q0 - has_head;
+      const int rs0 = (int)((int64_t)row_map[r0] - s), L = (int)((int64_t)row_map[r0 + 1] - s) - rs0;
+      if (k < L) {
+        const int i0 = rs0 + k;                               // row j of the segment has the entry at i0 + j L
+        const int jlo = i0 < 0 ? 1 : 0;
+        int jhi = (TILE - 1 - i0) / L;                        // (i0 < TILE: floor division of a non-negative number)
+        if (i0 >= TILE) jhi = -1;
+        if (jhi > q1 - q0 - 1) jhi = q1 - q0 - 1;
+        if (jlo <= jhi) {
+          const int c = s_col[i0 + jlo * L] - jlo;            // the column entry k would have in row 0
+          lo = c + jlo; hi = c + jhi;
+          csrc = s_col[i0 + jlo * L]; cadj = -jlo;
+        }
+      }
+    }
+    s_lo[t] = lo; s_hi[t] = hi;
+  }
+  __syncthreads();
+  // greedy cover, as in win_build_kernel: pass 0 ends a window at its first unused 64-column chunk, pass 1 takes whole windows
+  if (wave == 0) {
+    int ilo[NI / 64], ihi[NI / 64];
+    KK_UNROLL
+    for (int u = 0; u < NI / 64; ++u) { ilo[u] = s_lo[lane + 64 * u]; ihi[u] = s_hi[lane + 64 * u]; }
+    bool failed = true;
+    for (int pass = 0; pass < 2 && failed; ++pass) {
+      long long bound = 0;
+      int wn = 0;
+      for (; wn < kWinCount; ++wn) {
+        long long m = LLONG_MAX;
+        KK_UNROLL
+        for (int u = 0; u < NI / 64; ++u) if ((long long)ihi[u] >= bound) { const long long c = (long long)ilo[u] > bound ? (long long)ilo[u] : bound; m = c < m ? c : m; }
+        for (int o = 32; o > 0; o >>= 1) { const long long m2 = __shfl_xor(m, o, 64); m = m2 < m ? m2 : m; }
+        if (m == LLONG_MAX) break;                            // (uniform) everything is covered
+        const long long base = m;
+        unsigned long long used = 0ull;
+        KK_UNROLL
+        for (int u = 0; u < NI / 64; ++u) {
+          const long long cl = (long long)ilo[u] > base ? (long long)ilo[u] : base;
+          const long long ch = (long long)ihi[u] < base + (1 << kWinBits) - 1 ? (long long)ihi[u] : base + (1 << kWinBits) - 1;
+          if (cl <= ch) {
+            const int a = (int)((cl - base) >> 6), z = (int)((ch - base) >> 6);
+            used |= ((2ull << z) - 1ull) & ~((1ull << a) - 1ull);
+          }
+        }
+        for (int o = 32; o > 0; o >>= 1) used |= __shfl_xor(used, o, 64);
+        int nch;
+        if (pass == 0) nch = (~used == 0ull) ? 64 : __ffsll(~used) - 1;
+        else           nch = 64 - __clzll((long long)used);
+        if (lane == 0) { s_base[wn] = (int)base; s_nch[wn] = nch; }
+        bound = base + (pass == 0 ? 64ll * nch : (long long)(1 << kWinBits));
+      }
+      bool unc = false;
+      KK_UNROLL
+      for (int u = 0; u < NI / 64; ++u) unc |= ((long long)ihi[u] >= bound);
+      failed = __ballot(unc) != 0ull;
+      if (!failed && lane == 0) {
+        for (int q = wn; q < kWinCount; ++q) { s_base[q] = q ? s_base[q - 1] : 0; s_nch[q] = 0; }
+        int off = 0;
+        for (int w = 0; w < kWinCount; ++w) { s_off[w] = off; off += 64 * s_nch[w]; }
+        s_off[kWinCount] = off;
+      }
+    }
+    if (lane == 0 && failed) s_bad = 1;
+  }
+  __syncthreads();
+  constexpr int CAP = TILE < kWinChunks * 64 ? TILE : kWinChunks * 64;
+  // the x window must fit the LDS window and leave the tail of the product array free for the record (float products: 4 B slots)
+  if (s_bad || s_off[kWinCount] > CAP || s_off[kWinCount] > TILE - kPatW) { if (t == 0) tinfo[b] = kTilePlain; return; }      // (uniform)
+  int32_t* meta = wmeta + b * kWinMeta;
+  if (t < kWinCount) { meta[t] = s_base[t]; meta[kWinCount + t] = s_off[t]; }
+  if (t < kWinChunks) {
+    const int slot = t * 64;
+    int col = -1;
+    for (int w = 0; w < kWinCount; ++w) if (slot >= s_off[w] && slot < s_off[w] + 64 * s_nch[w]) col = s_base[w] + (slot - s_off[w]);
+    meta[2 * kWinCount + t] = col;
+  }
+  if (t < kPatSeg) {
+    int sb = INT_MAX, rs32 = 0, L32 = 1; float M = 1.0f;
+    if (t < nseg) {
+      const int64_t r  = ra + s_segq[t] - has_head;
+      const int64_t rs = (int64_t)row_map[r] - s, L = (int64_t)row_map[r + 1] - s - rs;
+      sb = rs > 0 ? (int)rs : 0; rs32 = (int)rs; L32 = (int)L;
+      M  = 1.0f / (float)L;
+    }
+    if (t >= 1) out[t] = sb;
+    out[kPatRec + 4 * t + 0] = sb; out[kPatRec + 4 * t + 1] = -rs32; out[kPatRec + 4 * t + 2] = L32; out[kPatRec + 4 * t + 3] = __float_as_int(M);
+  }
+  if (t == 0) { out[0] = nseg; tinfo[b] = kTilePattern; }
+  {
+    int val = 0;
+    if (csrc >= 0) {
+      for (int w = 0; w < kWinCount; ++w) if (s_nch[w] > 0 && csrc >= s_base[w] && csrc < s_base[w] + 64 * s_nch[w]) val = s_off[w] + (csrc - s_base[w]);
+      val += cadj;
+    }
+    reinterpret_cast<short*>(out + kPatTab)[t] = (short)val;     // may be -1: the slot before a row that starts in an earlier tile
+  }
+}
+
 // Which tiles keep per-nonzero codes (modes 1, 2, and 3 when the records are not used) -> flags for the scan; demotes unused records.
 // counts[m] = tiles whose mode (tinfo & 3) is m.  (The build kernels used to count with one atomic per tile: 177,000 atomics on one
 // address are 2 ms on C2, the read of the tile table is microseconds.)
@@ -1277,6 +1440,7 @@ static int set_tuning(SpmvTuning& t, const char* key, int value) {
   else if (k == "window_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.window_codes_min_knnz = value; }
   else if (k == "window_codes_min_pct") { if (value < 0 || value > 100) return bad("a percentage"); t.window_codes_min_pct = value; }
   else if (k == "pattern_codes") { if (value < 0 || value > 2) return bad("in 0..2"); t.pattern_codes = value; }
+  else if (k == "pattern_direct") { if (value != 0 && value != 1) return bad("0 or 1"); t.pattern_direct = value; }
   else if (k == "pattern_codes_min_knnz") { if (value < 0) return bad("non-negative"); t.pattern_codes_min_knnz = value; }
   else if (k == "colslab") { if (value < 0 || value > 4) return bad("in 0..4"); t.colslab = value; }
   else if (k == "colslab_min_pct") { if (value < 0 || value > 100) return bad("in 0..100"); t.colslab_min_pct = value; }
@@ -1310,7 +1474,7 @@ static void free_analysis(kkamd_spmv_plan* p) {
   void** bufs[] = {(void**)&p->d_blk_row, &p->d_carry, (void**)&p->d_tinfo, (void**)&p->d_wcode, (void**)&p->d_wbase, (void**)&p->d_pmeta};
   for (void** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
   for (int m = 0; m < 4; ++m) { if (p->d_list[m]) { (void)hipFree(p->d_list[m]); p->d_list[m] = nullptr; } p->n_mode[m] = 0; }
-  p->pat_tiles = p->code_tiles = p->staged_tiles = p->plain_tiles = 0;
+  p->pat_tiles = p->code_tiles = p->staged_tiles = p->plain_tiles = 0; p->pat_direct = false;
   p->tile = 0; p->nblocks = 0; p->plan_bytes = 0;
 }
 
@@ -1332,7 +1496,7 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
     return KKAMD_OK;
   };
   // the codes are an optimisation: if HBM cannot hold them (2 bytes per nonzero while they are built) the plan keeps reading entries
-  if (full.alloc(sizeof(uint16_t) * nb * (size_t)p->tile) != hipSuccess || counts.alloc(8 * sizeof(int)) != hipSuccess ||
+  if (full.alloc(sizeof(uint16_t) * nb * (size_t)p->tile) != hipSuccess || counts.alloc(12 * sizeof(int)) != hipSuccess ||
       flag.alloc(sizeof(int32_t) * (nb + 1)) != hipSuccess || tinfo_b.alloc(sizeof(int32_t) * nb) != hipSuccess ||
       wbase_b.alloc(sizeof(int32_t) * nb * kWinMeta) != hipSuccess)
     return give_up();
@@ -1341,9 +1505,73 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
   uint16_t* d_full = full.as<uint16_t>();                      // raw pointers for the launches (the buffers stay owned above)
   int* d_counts    = counts.as<int>();
   int32_t* d_flag  = flag.as<int32_t>();
-  KK_HIP(hipMemsetAsync(counts.p, 0, 8 * sizeof(int), st));
+  KK_HIP(hipMemsetAsync(counts.p, 0, 12 * sizeof(int), st));
   const int allow_stage = p->tune.window_codes != 2;
   const int32_t* ent = (const int32_t*)p->entries;
+  // the launch lists: the tiles of every mode, ascending (none needed when one mode has every tile).  known[m] >= 0: the count of mode m is
+  // known already (no scan, no copy back for the modes without tiles).  Returns -1 when a launch or an allocation fails.
+  auto make_lists = [&](const int64_t* known, size_t* list_bytes) -> int {
+    for (int m = 0; m < 4; ++m) {
+      if (known && known[m] == 0) { p->n_mode[m] = 0; continue; }
+      if (known && known[m] == (int64_t)nb) { p->n_mode[m] = (int64_t)nb; continue; }
+      KK_LAUNCH(mode_flag_kernel, (unsigned)ceil_div((int64_t)nb + 1, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, d_flag, m);
+      if (hipGetLastError() != hipSuccess) return -1;
+      int rc2 = exclusive_scan_inplace<int32_t>(d_flag, (int64_t)nb + 1, st);
+      if (rc2) { give_up(); return rc2; }
+      int32_t cnt = 0;
+      if (known) cnt = (int32_t)known[m];
+      else {
+        KK_HIP(hipMemcpyAsync(&cnt, d_flag + nb, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        KK_HIP(hipStreamSynchronize(st));
+      }
+      p->n_mode[m] = cnt;
+      if (cnt > 0 && (size_t)cnt < nb) {
+        if (hipMalloc((void**)&p->d_list[m], sizeof(int32_t) * (size_t)cnt) != hipSuccess) return -1;
+        *list_bytes += sizeof(int32_t) * (size_t)cnt;
+        int32_t* d_list_m = p->d_list[m];
+        KK_LAUNCH(mode_scatter_kernel, (unsigned)ceil_div((int64_t)nb, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, (const int32_t*)d_flag, d_list_m, m);
+        if (hipGetLastError() != hipSuccess) return -1;
+      }
+    }
+    return 0;
+  };
+  const bool pat_wanted = p->tune.pattern_codes && (npt == 16 || npt == 8) &&
+                          (p->tune.pattern_codes >= 2 || A->nnz >= (int64_t)p->tune.pattern_codes_min_knnz * 1000);
+  // Row-pattern records straight from the matrix (pat_direct_kernel): kept when at most one tile in a hundred (one, at least) is left
+  // without a record -- those read entries like the tiles of an unanalysed matrix --; otherwise the window codes are built as before.
+  if (pat_wanted && allow_stage && p->tune.pattern_direct && hipMalloc((void**)&p->d_pmeta, sizeof(int32_t) * nb * kPatW) == hipSuccess) {
+    const bool o64 = A->offset_type == KKAMD_I64;
+    int* d_cnt = d_counts + 8;
+#define KK_PAT_DIRECT(OT, N)                                                                                                 \
+  KK_LAUNCH((pat_direct_kernel<OT, N>), (unsigned)nb, kBlock, 0, st, A->nnz, (const OT*)A->d_row_map, ent,                   \
+            (const int32_t*)p->d_blk_row, wbase, tinfo, p->d_pmeta)
+    if (npt == 16) { if (o64) { KK_PAT_DIRECT(int64_t, 16); } else { KK_PAT_DIRECT(int32_t, 16); } }
+    else           { if (o64) { KK_PAT_DIRECT(int64_t, 8); } else { KK_PAT_DIRECT(int32_t, 8); } }
+#undef KK_PAT_DIRECT
+    if (hipGetLastError() != hipSuccess) return give_up();
+    KK_LAUNCH(tile_mode_hist_kernel, (unsigned)ceil_div((int64_t)nb, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, d_cnt);
+    if (hipGetLastError() != hipSuccess) return give_up();
+    int hd[4] = {0, 0, 0, 0};
+    KK_HIP(hipMemcpyAsync(hd, d_cnt, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    const int64_t left = (int64_t)nb - hd[kTilePattern], allowed = (int64_t)nb / 100 > 1 ? (int64_t)nb / 100 : 1;
+    if (hd[kTilePattern] > 0 && left <= allowed) {
+      if (hipMalloc((void**)&p->d_wcode, sizeof(uint16_t) * (size_t)p->tile) != hipSuccess) return give_up();     // (no tile reads codes)
+      const int64_t known[4] = {left, 0, 0, (int64_t)hd[kTilePattern]};
+      size_t list_bytes = 0;
+      int rc2 = make_lists(known, &list_bytes);
+      if (rc2) return rc2 == -1 ? give_up() : rc2;
+      KK_HIP(hipStreamSynchronize(st));
+      p->d_tinfo = (int32_t*)tinfo_b.release(); p->d_wbase = (int32_t*)wbase_b.release();
+      p->plain_tiles = left; p->pat_tiles = hd[kTilePattern]; p->code_tiles = 0; p->staged_tiles = hd[kTilePattern]; p->pat_direct = true;
+      p->plan_bytes += list_bytes + sizeof(int32_t) * nb * (1 + kWinMeta) + sizeof(uint16_t) * (size_t)p->tile + sizeof(int32_t) * nb * kPatW;
+      return KKAMD_OK;
+    }
+    KK_HIP(hipFree(p->d_pmeta)); p->d_pmeta = nullptr;
+  } else {
+    (void)hipGetLastError();
+    if (p->d_pmeta) { (void)hipFree(p->d_pmeta); p->d_pmeta = nullptr; }
+  }
   if (npt == 16)     { KK_LAUNCH((win_build_kernel<16>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, allow_stage); }
   else if (npt == 8) { KK_LAUNCH((win_build_kernel<8>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, allow_stage); }
   else               { KK_LAUNCH((win_build_kernel<4>), (unsigned)nb, kBlock, 0, st, A->nnz, ent, d_full, wbase, tinfo, allow_stage); }
@@ -1361,8 +1589,7 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
   // row-pattern records for the staged tiles
   int64_t n_pat = 0;
   bool use_pat = false;
-  if (n_staged > 0 && p->tune.pattern_codes && (npt == 16 || npt == 8) &&
-      (p->tune.pattern_codes >= 2 || A->nnz >= (int64_t)p->tune.pattern_codes_min_knnz * 1000) &&
+  if (n_staged > 0 && pat_wanted &&
       hipMalloc((void**)&p->d_pmeta, sizeof(int32_t) * nb * kPatW) == hipSuccess) {
     const bool o64 = A->offset_type == KKAMD_I64;
     int* d_cnt = d_counts + 4;
@@ -1399,22 +1626,7 @@ static int build_codes(kkamd_spmv_plan* p, const kkamd_crs_t* A, hipStream_t st,
   if (hipGetLastError() != hipSuccess) return give_up();
   // the launch lists: the tiles of every mode, ascending (none needed when one mode has every tile)
   size_t list_bytes = 0;
-  for (int m = 0; m < 4; ++m) {
-    KK_LAUNCH(mode_flag_kernel, (unsigned)ceil_div((int64_t)nb + 1, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, d_flag, m);
-    if (hipGetLastError() != hipSuccess) return give_up();
-    if ((rc = exclusive_scan_inplace<int32_t>(d_flag, (int64_t)nb + 1, st))) { give_up(); return rc; }
-    int32_t cnt = 0;
-    KK_HIP(hipMemcpyAsync(&cnt, d_flag + nb, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    KK_HIP(hipStreamSynchronize(st));
-    p->n_mode[m] = cnt;
-    if (cnt > 0 && (size_t)cnt < nb) {
-      if (hipMalloc((void**)&p->d_list[m], sizeof(int32_t) * (size_t)cnt) != hipSuccess) return give_up();
-      list_bytes += sizeof(int32_t) * (size_t)cnt;
-      int32_t* d_list_m = p->d_list[m];
-      KK_LAUNCH(mode_scatter_kernel, (unsigned)ceil_div((int64_t)nb, kBlock), kBlock, 0, st, (int64_t)nb, (const int32_t*)tinfo, (const int32_t*)d_flag, d_list_m, m);
-      if (hipGetLastError() != hipSuccess) return give_up();
-    }
-  }
+  if ((rc = make_lists(nullptr, &list_bytes))) return rc == -1 ? give_up() : rc;
   KK_HIP(hipStreamSynchronize(st));
   p->d_tinfo = (int32_t*)tinfo_b.release(); p->d_wbase = (int32_t*)wbase_b.release();
   p->plan_bytes += list_bytes;
@@ -1627,7 +1839,7 @@ static int plan_set_impl(kkamd_spmv_plan_t* plan, const char* key, int value) {
   const kk::SpmvTuning& t = plan->tune;
   if (t.nnz_per_thread != old.nnz_per_thread || t.kernel != old.kernel || t.stream_variant != old.stream_variant ||
       t.window_codes != old.window_codes || t.window_codes_min_knnz != old.window_codes_min_knnz ||
-      t.window_codes_min_pct != old.window_codes_min_pct || t.pattern_codes != old.pattern_codes ||
+      t.window_codes_min_pct != old.window_codes_min_pct || t.pattern_codes != old.pattern_codes || t.pattern_direct != old.pattern_direct ||
       t.pattern_codes_min_knnz != old.pattern_codes_min_knnz) {
     // the tiling or its column analysis changed: redo the analysis from the matrix the plan is bound to
     plan->win_failed = false;
@@ -1718,6 +1930,7 @@ int kkamd_spmv_plan_query(const kkamd_spmv_plan_t* plan, const char* key, int64_
   else if (k == "mv5_other_rows") *value = kk::mv5_plan_query(plan->mv5, 1);
   else if (k == "mv5_blocks") *value = kk::mv5_plan_query(plan->mv5, 2);
   else if (k == "mv5_fill_permille") *value = kk::mv5_plan_query(plan->mv5, 4);
+  else if (k == "pattern_direct") *value = plan->pat_direct ? 1 : 0;
   else if (k == "colslab") *value = plan->cs ? 1 : 0;
   else if (k == "colslab_tried") *value = plan->cs_tried ? 1 : 0;
   else if (k == "colslab_slabs") *value = kk::cs_plan_query(plan->cs, 0);

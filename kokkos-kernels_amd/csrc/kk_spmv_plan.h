@@ -63,6 +63,9 @@ struct SpmvTuning {
   int window_codes_min_pct = 25;   // ... when at least this share of the tiles can use them (the others read entries, per tile)
   int pattern_codes = 1;           // staged-x tiles: 1 = row-pattern records instead of per-nonzero codes when >= 90 % of the tiles have one
                                    // (27-pt 300^3 1.349 -> 1.267 ms, 7-pt 400^3 1.025 -> 0.940 ms), 2 = whenever any tile has one, 0 = never
+  int pattern_direct = 1;          // ... 1 = the records are first sought directly in the matrix (pat_direct_kernel: rows compared, then the window cover over
+                                   // <= 256 column intervals per tile) and the window codes are built only when more than one tile in a hundred has none:
+                                   // plan of 27-pt 300^3 6.2 -> 2.5 ms (first call 7.5 -> 3.8); 0 = always by way of the codes
   int pattern_codes_min_knnz = 10000;  // ... from this many thousand nnz (5-pt 1000^2, 5e6 nnz: 17.5 -> 18.3 us with the records)
   int colslab = 3;                 // rank 1, mode N, matrices whose x gather defeats the caches (kk_spmv_colslab.hip): a column-slab copy of the matrix.
                                    // 3 (default) = the DETERMINISTIC form (per-slab partial sums of every row, added in slab order: no atomics, the
@@ -135,6 +138,7 @@ struct kkamd_spmv_plan {
   int64_t code_tiles = 0;        // tiles that read per-nonzero codes (modes 1, 2)
   int64_t staged_tiles = 0;      // tiles whose x window is staged in LDS (modes 2, 3)
   int64_t pat_tiles = 0;         // tiles decoded from a row-pattern record (mode 3)
+  bool pat_direct = false;       // the records came straight from the matrix (pat_direct_kernel), no window codes were built
   int64_t plain_tiles = 0;       // tiles that read entries (mode 0)
   size_t plan_bytes = 0;         // HBM the analysis keeps
   // modes T/H: explicit transpose cached on first use (structure, permutation into A's values, refreshed values, sub-plan)

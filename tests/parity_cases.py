@@ -973,6 +973,36 @@ def window_code_cases():
     return out
 
 
+def check_pattern_direct(be, cases=None):
+    """Round 6: the row-pattern records straight from the matrix (pat_direct_kernel: rows compared, the window cover over <= 256 column
+    intervals per tile) against the records by way of the window codes (pattern_direct 0): the same tiles get a record, y is the same bit
+    for bit (same records, same order of the sums), the one tile without a record reads entries instead of codes; 32- and 64-bit offsets,
+    both tile sizes, fp32 values.  Matrices with more than one tile in a hundred without a record take the codes either way."""
+    took = 0
+    for name, A0, npt, _ in (cases or pattern_code_cases()):
+        for odt, vdt in ((np.int32, None), (np.int64, np.float32)):
+            res = {}
+            for direct in (1, 0):
+                kn = {"window_codes_min_knnz": 0, "nnz_per_thread": npt, "pattern_codes": 2, "pattern_codes_min_knnz": 0, "pattern_direct": direct}
+                rng = np.random.default_rng(5)
+                x, y0 = rng.random(A0.ncols), rng.random(A0.nrows)
+                A = dev(be, A0, odt, vdt)
+                xd, yd = be.from_numpy(x), be.from_numpy(y0)
+                h = kk.SPMVHandle("SPMV_DEFAULT")
+                for k_, v_ in kn.items(): h.set(k_, v_)
+                kk.spmv(h, "N", 1.5, A, xd, 0.5, yd)
+                res[direct] = (be.to_numpy(yd).copy(), h.query("pattern_direct"), h.query("pattern_tiles"), h.query("plain_tiles"), h.query("code_tiles"), h.query("tiles"))
+                check_spmv(be, A0, "N", 1.5, 0.0, "SPMV_DEFAULT", knobs=kn, max_val=32.0, nans=True, offset_dtype=odt, value_dtype=vdt)
+            (y1, d1, p1, pl1, c1, n1), (y0_, d0, p0, pl0, c0, _) = res[1], res[0]
+            assert d0 == 0 and np.array_equal(y1, y0_), (name, d1, p1, p0)
+            if d1:
+                took += 1
+                assert p1 == p0 and c1 == 0 and pl1 == n1 - p1 and pl1 <= max(1, n1 // 100), (name, p1, p0, pl1, c1, n1)
+            else:
+                assert (p1, pl1, c1) == (p0, pl0, c0), (name, res[1][1:], res[0][1:])
+    assert took >= 4, took
+
+
 def pattern_code_cases():
     """(name, matrix, nnz_per_thread, row-pattern records expected) for the staged SpMV kernel's row-pattern codes."""
     out = []

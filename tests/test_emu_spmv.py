@@ -95,6 +95,10 @@ def test_pattern_codes(be):
                                                                        "pattern_codes_min_knnz": 0}, max_val=32.0, expect={"pattern_tiles": 0})
 
 
+def test_pattern_records_straight_from_the_matrix(be):
+    pc.check_pattern_direct(be)
+
+
 def test_mixed_tiles(be):
     # the column analysis is per tile: tiles the windows cannot cover read entries, the others keep codes / staged x / records
     for name, A0 in pc.mixed_tile_cases():

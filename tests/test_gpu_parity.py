@@ -107,6 +107,21 @@ def test_pattern_codes(be):
                                                                        "pattern_codes_min_knnz": 0}, max_val=32.0, expect={"pattern_tiles": 0})
 
 
+def test_pattern_records_straight_from_the_matrix(be):
+    pc.check_pattern_direct(be)
+    # ... and at a size where a plan is worth timing: 27-pt 120^3 (46.7e6 nonzeros: 2048-nnz tiles by the automatic rule)
+    kk = pc.kk
+    A = kk.laplace_matrix("FE", 120, 120, 120)
+    ys = []
+    for direct in (1, 0):
+        h = kk.SPMVHandle("SPMV_DEFAULT"); h.set("pattern_direct", direct)
+        x = be.from_numpy(np.random.default_rng(3).random(A.numCols())); y = be.from_numpy(np.zeros(A.numRows()))
+        kk.spmv(h, "N", 1.0, A, x, 0.0, y)
+        ys.append(be.to_numpy(y).copy())
+        assert h.query("pattern_direct") == direct and h.query("pattern_tiles") >= 0.99 * h.query("tiles"), (direct, h.query("pattern_tiles"), h.query("tiles"))
+    assert np.array_equal(ys[0], ys[1])
+
+
 def test_mixed_tiles(be):
     # the column analysis is per tile: tiles the windows cannot cover read entries, the others keep codes / staged x / records
     for name, A0 in pc.mixed_tile_cases():
