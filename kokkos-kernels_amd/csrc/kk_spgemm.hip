@@ -282,6 +282,16 @@ template <class OffT> __global__ void sum_counts_kernel(int64_t m, const OffT* _
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
+// ... and with the largest count (the reference's set_max_result_nnz, impl_symbolic.hpp:1501-1505): out[0] += sum, out[1] = max
+template <class OffT> __global__ void sum_max_counts_kernel(int64_t m, const OffT* __restrict__ counts, unsigned long long* out) {
+  unsigned long long s = 0, mx = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long c = (unsigned long long)counts[r];
+    s += c; mx = c > mx ? c : mx;
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); const unsigned long long m2 = __shfl_xor(mx, o, 64); mx = m2 > mx ? m2 : mx; }
+  if ((threadIdx.x & 63) == 0 && s) { atomicAdd(out, s); atomicMax(out + 1, mx); }
+}
 // row size of C from its row_map (numeric binning)
 template <class OffT>
 __global__ void spgemm_rowsize_kernel(int64_t m, const OffT* __restrict__ rmC, int64_t* __restrict__ sizes) {
@@ -3254,6 +3264,12 @@ struct kkamd_spgemm_handle {
   kk::UnitHead* d_heads = nullptr; int64_t n_heads = 0;       // the units with products, in launch order
   // a second stream for the symbolic phase: the kernels of the rows with few products (wave / block hash kernels) run beside the dense class
   hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // 64 counters on the device and their pinned copy on the host: what a phase reads back (statistics of the row flops, sortedness of B, bin counts;
+  // sum and maximum of the row counts) travels in ONE copy per decision point -- a product of a multigrid setup is a dozen launches of a few
+  // microseconds each, and every separate read-back (a temporary, a copy, a synchronisation, a hipFree) cost it 30 - 40 us.  d_scan_ws: workspace of the row_map scan
+  unsigned long long* d_small = nullptr; unsigned long long* h_small = nullptr;
+  void* d_scan_ws = nullptr; size_t scan_ws_bytes = 0;
+  int64_t sizes_cap = 0;           // rows d_sizes / d_perm hold
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -3267,22 +3283,37 @@ static int pick_sg_log2(int64_t nnzB, int64_t n) {
   return l;
 }
 
+constexpr int kSmallSlots = 64, kSmallStats = 0, kSmallFlag = 2, kSmallBins = 8, kSmallSum = 24;      // slots of the handle's counters
+static bool ensure_small(kkamd_spgemm_handle* h) {
+  if (h->d_small && h->h_small) return true;
+  if (!h->d_small && hipMalloc((void**)&h->d_small, kSmallSlots * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); h->d_small = nullptr; return false; }
+  if (!h->h_small && hipHostMalloc((void**)&h->h_small, kSmallSlots * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->h_small = nullptr; return false; }
+  return true;
+}
+// d_cnt: 2 kNumBins counters owned by the caller (zeroed by the caller when `counted`); h_cnt: where their copy on the host goes / is.
+// counted: spgemm_bin_count_kernel has run and h_cnt holds its result.  With d_cnt the function neither allocates nor waits after the scatter.
 static int make_bins(int64_t m, const int64_t* d_sizes, int64_t cap, const BinLimits& L, int32_t* d_perm,
-                     BinOffsets* off, hipStream_t st) {
+                     BinOffsets* off, hipStream_t st, unsigned long long* d_cnt = nullptr, unsigned long long* h_cnt_in = nullptr, bool counted = false) {
   DevBuf cnt_b;                              // frees itself on every return
-  KK_HIP(cnt_b.alloc(sizeof(unsigned long long) * 2 * kNumBins));
-  unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
-  KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * 2 * kNumBins, st));
+  const bool own = d_cnt == nullptr;
+  if (own) {
+    KK_HIP(cnt_b.alloc(sizeof(unsigned long long) * 2 * kNumBins));
+    d_cnt = cnt_b.as<unsigned long long>();
+  }
   const unsigned grid = (unsigned)ceil_div(m, kBlock);
-  KK_LAUNCH(spgemm_bin_count_kernel, grid, kBlock, 0, st, m, d_sizes, cap, L, d_cnt);
-  unsigned long long h_cnt[kNumBins];
-  KK_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, st));
-  KK_HIP(hipStreamSynchronize(st));
+  unsigned long long h_loc[kNumBins];
+  unsigned long long* h_cnt = h_cnt_in ? h_cnt_in : h_loc;
+  if (!counted) {
+    KK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * 2 * kNumBins, st));
+    KK_LAUNCH(spgemm_bin_count_kernel, grid, kBlock, 0, st, m, d_sizes, cap, L, d_cnt);
+    KK_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(unsigned long long) * kNumBins, hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+  }
   off->off[0] = 0;
   for (int b = 0; b < kNumBins; ++b) off->off[b + 1] = off->off[b] + (int64_t)h_cnt[b];
   KK_LAUNCH(spgemm_bin_scatter_kernel, grid, kBlock, 0, st, m, d_sizes, cap, L, *off, d_cnt + kNumBins, d_perm);
   hipError_t e = hipGetLastError();
-  hipError_t e2 = hipStreamSynchronize(st);
+  hipError_t e2 = own ? hipStreamSynchronize(st) : hipSuccess;       // (the temporary is freed on return)
   if (e != hipSuccess || e2 != hipSuccess) return fail(KKAMD_ERR_HIP, "spgemm binning failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
   return KKAMD_OK;
 }
@@ -3595,18 +3626,42 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     KK_VERBOSE("\t\tsymbolic %-25s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
   };
   KK_HIP(hipMemsetAsync(rmC, 0, sizeof(OffT) * (size_t)(m + 1), st));
+  if (!ensure_small(h)) return fail(KKAMD_ERR_ALLOC, "kkamd_spgemm_symbolic: out of memory for the handle's counters");
+  // Without B compression (the default) nothing between the row flops and the bins depends on the host: flops, sortedness of B and the bin
+  // counts are queued together and read back in one copy.
+  const bool merged = !h->compression;
+  const BinLimits& symL = g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge;
   DevBuf stats_b;                            // frees itself on every return
-  KK_HIP(stats_b.alloc(2 * sizeof(unsigned long long)));
-  unsigned long long* d_stats = stats_b.as<unsigned long long>();
-  KK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), st));
+  unsigned long long* d_stats = h->d_small + kSmallStats;
+  if (merged) KK_HIP(hipMemsetAsync(h->d_small, 0, kSmallSlots * sizeof(unsigned long long), st));
+  else {
+    KK_HIP(stats_b.alloc(2 * sizeof(unsigned long long)));
+    d_stats = stats_b.as<unsigned long long>();
+    KK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), st));
+  }
   {
     const int64_t nbk = ceil_div(m * 8, kBlock);
     KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbk < 4096 ? nbk : 4096), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats);
     KK_LAUNCH((spgemm_flops_long_kernel<OffT>), (unsigned)ceil_div(m, kBlock), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats);
   }
   unsigned long long h_stats[2] = {0, 0};
-  KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
-  KK_HIP(hipStreamSynchronize(st));
+  if (merged) {
+    int* d_flag = reinterpret_cast<int*>(h->d_small + kSmallFlag);
+    if (n > 0 && nnzB > 1) {
+      const int64_t nbk = ceil_div(n * 8, kBlock);
+      KK_LAUNCH((rows_sorted_kernel<OffT>), (unsigned)(nbk < 8192 ? nbk : 8192), kBlock, 0, st, n, rmB, entB, d_flag);
+      KK_LAUNCH((rows_sorted_long_kernel<OffT>), (unsigned)ceil_div(n, kBlock), kBlock, 0, st, n, rmB, entB, d_flag);
+    }
+    const int64_t* d_fl = h->d_sizes;
+    KK_LAUNCH(spgemm_bin_count_kernel, (unsigned)ceil_div(m, kBlock), kBlock, 0, st, m, d_fl, k, symL, h->d_small + kSmallBins);
+    KK_HIP(hipMemcpyAsync(h->h_small, h->d_small, kSmallSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+    h_stats[0] = h->h_small[kSmallStats]; h_stats[1] = h->h_small[kSmallStats + 1];
+    h->b_sorted = *reinterpret_cast<const int*>(h->h_small + kSmallFlag) == 0;
+  } else {
+    KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
+    KK_HIP(hipStreamSynchronize(st));
+  }
   h->mults = (int64_t)h_stats[0]; h->max_row_flops = (int64_t)h_stats[1];
   h->sg_log2 = pick_sg_log2(nnzB, n); h->nnzB = nnzB;
   lap("row flops");
@@ -3618,7 +3673,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   } else { (void)hipGetLastError(); h->d_flop_cls = nullptr; }
   int rc;
   // sortedness of B decides how the numeric phase handles dense rows, and whether B can be compressed
-  {
+  if (!merged) {
     DevBuf flag; int h_flag = 0;
     KK_HIP(flag.alloc(sizeof(int)));
     int* d_flag = flag.as<int>();
@@ -3690,7 +3745,7 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
                                                (int32_t*)nullptr, k, (int64_t)0, sg, st, endB, maskB))) return rc;
     }
   } else {
-    if ((rc = make_bins(m, h->d_sizes, k, g_spgemm.sym_large ? kSymLimits : kSymLimitsNoLarge, h->d_perm, &off, st))) return rc;   // a C row cannot exceed k columns
+    if ((rc = make_bins(m, h->d_sizes, k, symL, h->d_perm, &off, st, merged ? h->d_small + kSmallBins : nullptr, merged ? h->h_small + kSmallBins : nullptr, merged))) return rc;   // a C row cannot exceed k columns
     // When there is a dense class, the kernels of the other rows go to a second stream and run beside it (they are bound by their
     // latency chains and leave most of the chip idle: 5 of the symbolic phase's 40 ms on R-MAT scale 20 when they ran first on the one stream).
     // The caller's stream waits for them before the counts are scanned.
@@ -3805,25 +3860,32 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     KK_VERBOSE("\tkkamd spgemm symbolic bins (rows): empty %lld, wave %lld, block-small %lld, block-large %lld, bitmap %lld\n",
            (long long)nb(0), (long long)nb(1), (long long)nb(2), (long long)nb(3), (long long)nb(4));
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && sizeof(OffT) == 4) {                   // 32-bit offsets: nnz(C) must fit before the in-place scan wraps
-    DevBuf tot_b; unsigned long long h_tot = 0;
-    KK_HIP(tot_b.alloc(sizeof(unsigned long long)));
-    unsigned long long* d_tot = tot_b.as<unsigned long long>();
-    KK_HIP(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long), st));
+  if (e != hipSuccess) return fail(KKAMD_ERR_HIP, "spgemm symbolic launch failed: %s", hipGetErrorString(e));
+  // sum (in 64 bits: a 32-bit row_map must not wrap silently) and maximum of the counts, then the scan with the handle's workspace: queued
+  // together, one copy back
+  {
+    const size_t need = sizeof(OffT) * (size_t)scan_workspace_items(m + 1);
+    if (h->scan_ws_bytes < need) {
+      if (h->d_scan_ws) { (void)hipFree(h->d_scan_ws); h->d_scan_ws = nullptr; h->scan_ws_bytes = 0; }
+      KK_HIP(hipMalloc(&h->d_scan_ws, need));
+      h->scan_ws_bytes = need;
+    }
+  }
+  KK_HIP(hipMemsetAsync(h->d_small + kSmallSum, 0, 2 * sizeof(unsigned long long), st));
+  {
     const int64_t nbk = ceil_div(m, kBlock);
-    KK_LAUNCH((sum_counts_kernel<OffT>), (unsigned)(nbk < 4096 ? nbk : 4096), kBlock, 0, st, m, (const OffT*)rmC, d_tot);
-    KK_HIP(hipMemcpyAsync(&h_tot, d_tot, sizeof h_tot, hipMemcpyDeviceToHost, st));
-    KK_HIP(hipStreamSynchronize(st));
-    if (h_tot > (unsigned long long)INT32_MAX)
-      return fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: nnz(C) = %llu overflows 32-bit offsets; use 64-bit offsets", h_tot);
+    KK_LAUNCH((sum_max_counts_kernel<OffT>), (unsigned)(nbk < 4096 ? nbk : 4096), kBlock, 0, st, m, (const OffT*)rmC, h->d_small + kSmallSum);
   }
   lap("before the scan");
-  rc = (e == hipSuccess) ? exclusive_scan_inplace<OffT>(rmC, m + 1, st) : fail(KKAMD_ERR_HIP, "spgemm symbolic launch failed: %s", hipGetErrorString(e));
-  OffT total = 0;
+  rc = exclusive_scan_inplace<OffT>(rmC, m + 1, st, (OffT*)h->d_scan_ws);
+  unsigned long long total = 0;
   if (rc == KKAMD_OK) {
-    hipError_t e1 = hipMemcpyAsync(&total, rmC + m, sizeof(OffT), hipMemcpyDeviceToHost, st);
+    hipError_t e1 = hipMemcpyAsync(h->h_small + kSmallSum, h->d_small + kSmallSum, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
     if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(KKAMD_ERR_HIP, "spgemm symbolic failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    total = h->h_small[kSmallSum]; h->max_row_nnz = (int64_t)h->h_small[kSmallSum + 1];
+    if (rc == KKAMD_OK && sizeof(OffT) == 4 && total > (unsigned long long)INT32_MAX)
+      return fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: nnz(C) = %llu overflows 32-bit offsets; use 64-bit offsets", total);
   }
   if (rc) return rc;
   *c_nnz = (int64_t)total;
@@ -3844,7 +3906,7 @@ static int numeric_typed(kkamd_spgemm_handle* h, int64_t m, int64_t k, const voi
     // accumulator (here: in HBM, one per concurrently processed row) instead of an LDS hash table
     const bool dense_alg = h->algorithm == 1;
     h->dense_lds = h->b_sorted && !g_spgemm.force_unsorted && !dense_alg;
-    if ((rc = make_bins(m, h->d_sizes, INT64_MAX, dense_alg ? kAllDense : (h->dense_lds ? kNumLimitsSorted : kNumLimits), h->d_perm, &h->num_off, st))) return rc;
+    if ((rc = make_bins(m, h->d_sizes, INT64_MAX, dense_alg ? kAllDense : (h->dense_lds ? kNumLimitsSorted : kNumLimits), h->d_perm, &h->num_off, st, ensure_small(h) ? h->d_small + kSmallBins : nullptr, h->h_small ? h->h_small + kSmallBins : nullptr, false))) return rc;
     h->n_dense_lds = 0; h->n_dense_hub_lds = 0;
     const int64_t nd = h->num_off.off[5] - h->num_off.off[4];
     if (nd > 0) {
@@ -4404,6 +4466,9 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (h->d_hub_multi) (void)hipFree(h->d_hub_multi);
   if (h->d_bidx) (void)hipFree(h->d_bidx);
   if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+  if (h->d_small) (void)hipFree(h->d_small);
+  if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->d_scan_ws) (void)hipFree(h->d_scan_ws);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->d_cidx) (void)hipFree(h->d_cidx);
@@ -4466,10 +4531,14 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
   }
   if (!d_entriesA || !d_entriesB) return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: null entries");
   h->nnzA = nnzA;
-  if (h->d_sizes) { (void)hipFree(h->d_sizes); h->d_sizes = nullptr; }
-  if (h->d_perm) { (void)hipFree(h->d_perm); h->d_perm = nullptr; }
-  KK_HIP(hipMalloc((void**)&h->d_sizes, sizeof(int64_t) * (size_t)m));
-  KK_HIP(hipMalloc((void**)&h->d_perm, sizeof(int32_t) * (size_t)m));
+  if (h->sizes_cap < m || !h->d_sizes || !h->d_perm) {
+    if (h->d_sizes) { (void)hipFree(h->d_sizes); h->d_sizes = nullptr; }
+    if (h->d_perm) { (void)hipFree(h->d_perm); h->d_perm = nullptr; }
+    h->sizes_cap = 0;
+    KK_HIP(hipMalloc((void**)&h->d_sizes, sizeof(int64_t) * (size_t)m));
+    KK_HIP(hipMalloc((void**)&h->d_perm, sizeof(int32_t) * (size_t)m));
+    h->sizes_cap = m;
+  }
   int64_t total = 0;
   int rc = offset_type == KKAMD_I64
                ? kk::symbolic_typed<int64_t>(h, m, n, k, d_row_mapA, d_entriesA, d_row_mapB, d_entriesB, d_row_mapC, nnzB, &total, st)
@@ -4477,17 +4546,6 @@ int kkamd_spgemm_symbolic(kkamd_spgemm_handle_t* h, int64_t m, int64_t n, int64_
   if (rc) return rc;
   if (offset_type == KKAMD_I32 && total < 0)
     return kk::fail(KKAMD_ERR_INVALID_ARG, "kkamd_spgemm_symbolic: nnz(C) overflows 32-bit offsets; use 64-bit offsets");
-  // max nnz in a C row (the reference's set_max_result_nnz, impl_symbolic.hpp:1501-1505)
-  kk::DevBuf mx_b; unsigned long long h_mx = 0;
-  KK_HIP(mx_b.alloc(sizeof(unsigned long long)));
-  unsigned long long* d_mx = mx_b.as<unsigned long long>();
-  KK_HIP(hipMemsetAsync(d_mx, 0, sizeof(unsigned long long), st));
-  const int64_t nbk = kk::ceil_div(m, kk::kBlock);
-  if (offset_type == KKAMD_I64) { KK_LAUNCH((kk::max_diff_kernel<int64_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int64_t*)d_row_mapC, d_mx); }
-  else { KK_LAUNCH((kk::max_diff_kernel<int32_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int32_t*)d_row_mapC, d_mx); }
-  KK_HIP(hipMemcpyAsync(&h_mx, d_mx, sizeof h_mx, hipMemcpyDeviceToHost, st));
-  KK_HIP(hipStreamSynchronize(st));
-  h->max_row_nnz = (int64_t)h_mx;
   h->c_nnz = total; h->symbolic_called = true;
   if (c_nnz) *c_nnz = total;
   return KKAMD_OK;
