@@ -72,7 +72,7 @@ namespace kk {
 
 constexpr int kNumBins   = 5;      // 0 empty, 1 wave, 2 block-small, 3 block-large, 4 dense
 constexpr int kHashMul   = 107;
-constexpr int kFlopsLong = 2048;   // rows of A above this many entries get a workgroup in the row-flops pass
+constexpr int kFlopsLong = 512;    // rows of A above this many entries get a workgroup in the row-flops pass
 constexpr int kSymWaveTable = 2048;   // symbolic keys only: 8 KB per wave
 constexpr int kWaveTable = 512;       // numeric keys + values
 constexpr int kSymBlkS = 4096,  kSymBlkL = 16384;   // 64 KB of keys: two workgroups per CU (32768 slots: one; R-MAT s20 symbolic 101 -> 94 ms)
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
                                                               const int32_t* __restrict__ entA,
                                                               const OffT* __restrict__ rmB, int64_t* __restrict__ flops,
                                                               unsigned long long* __restrict__ stats /*[0]=total,[1]=max*/,
+                                                              int32_t* __restrict__ long_list, unsigned long long* __restrict__ long_cnt,
                                                               const OffT* __restrict__ endB = nullptr) {
   __shared__ unsigned long long s_sum, s_max;
   if (threadIdx.x == 0) { s_sum = 0; s_max = 0; }
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
   for (int64_t r0 = (int64_t)blockIdx.x * (kBlock / 8); r0 < m; r0 += stride) {     // workgroup-uniform trip count
     const int64_t row = r0 + threadIdx.x / 8;
     long long f = 0;
-    const bool mine = row < m && (int64_t)rmA[row + 1] - (int64_t)rmA[row] <= kFlopsLong;     // longer rows: spgemm_flops_long_kernel
+    const bool mine = row < m && (int64_t)rmA[row + 1] - (int64_t)rmA[row] <= kFlopsLong;     // longer rows: spgemm_flops_long_kernel, from this list
+    if (row < m && !mine && lane == 0) long_list[atomicAdd(long_cnt, 1ull)] = (int32_t)row;
     if (mine) {
       // four entries per lane and step, their loads independent (R-MAT scale 20: the longest row, 39,580 entries on these 8 lanes, was
       // 5 of the kernel's 7 ms with one entry per step; rows above kFlopsLong entries now get a whole workgroup)
@@ -206,36 +208,35 @@ __global__ __launch_bounds__(kBlock) void spgemm_flops_kernel(int64_t m, const O
   }
 }
 
-// rows of A above kFlopsLong entries: every workgroup looks at kBlock rows and walks the long ones among them with all its
-// work-items (there are few: 211 above 4096 on R-MAT scale 20)
+// rows of A above kFlopsLong entries (at most nnz(A) / kFlopsLong of them: the launch's size), from the list spgemm_flops_kernel left: a
+// workgroup per row.  (Every workgroup looking at kBlock rows and walking the long ones among them put the long rows of a graph, which sit
+// together -- R-MAT: at the indices with few bits set, so that rows a power of two apart are no better than consecutive ones --, into a few
+// workgroups: 1.0 - 1.3 ms on R-MAT scale 20.)
 template <class OffT>
-__global__ __launch_bounds__(kBlock) void spgemm_flops_long_kernel(int64_t m, const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
+__global__ __launch_bounds__(kBlock) void spgemm_flops_long_kernel(const int32_t* __restrict__ long_list, const unsigned long long* __restrict__ long_cnt,
+                                                                   const OffT* __restrict__ rmA, const int32_t* __restrict__ entA,
                                                                    const OffT* __restrict__ rmB, int64_t* __restrict__ flops,
                                                                    unsigned long long* __restrict__ stats, const OffT* __restrict__ endB = nullptr) {
   __shared__ unsigned long long s_part[kBlock / 64];
-  __shared__ int s_long[kBlock];
-  __shared__ int s_n;
-  const int64_t r0 = (int64_t)blockIdx.x * kBlock;
-  const int64_t mine = r0 + threadIdx.x;
-  if (threadIdx.x == 0) s_n = 0;
+  if ((unsigned long long)blockIdx.x >= *long_cnt) return;                       // (uniform)
+  const int64_t row = long_list[blockIdx.x], b = (int64_t)rmA[row], e = (int64_t)rmA[row + 1];
+  long long f = 0;
+  // eight entries per work-item and step, their loads independent (an entry is two dependent trips to memory)
+  for (int64_t a = b + threadIdx.x; a < e; a += 8 * kBlock) {
+    int32_t c[8];
+    KK_UNROLL
+    for (int u = 0; u < 8; ++u) c[u] = a + u * kBlock < e ? entA[a + u * kBlock] : -1;
+    KK_UNROLL
+    for (int u = 0; u < 8; ++u) if (c[u] >= 0) f += (long long)(endB ? endB[c[u]] : rmB[c[u] + 1]) - (long long)rmB[c[u]];
+  }
+  f = group_sum(f, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (unsigned long long)f;
   __syncthreads();
-  if (mine < m && (int64_t)rmA[mine + 1] - (int64_t)rmA[mine] > kFlopsLong) s_long[atomicAdd(&s_n, 1)] = threadIdx.x;
-  __syncthreads();
-  const int n_long = s_n;
-  for (int i = 0; i < n_long; ++i) {
-    const int64_t row = r0 + s_long[i], b = (int64_t)rmA[row], e = (int64_t)rmA[row + 1];
-    long long f = 0;
-    for (int64_t a = b + threadIdx.x; a < e; a += kBlock) { const int32_t c = entA[a]; f += (long long)(endB ? endB[c] : rmB[c + 1]) - (long long)rmB[c]; }
-    f = group_sum(f, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = (unsigned long long)f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long tot = 0;
-      for (int w = 0; w < kBlock / 64; ++w) tot += s_part[w];
-      flops[row] = (int64_t)tot;
-      atomicAdd(&stats[0], tot); atomicMax(&stats[1], tot);
-    }
+  if (threadIdx.x == 0) {
+    unsigned long long tot = 0;
+    for (int w = 0; w < kBlock / 64; ++w) tot += s_part[w];
+    flops[row] = (int64_t)tot;
+    atomicAdd(&stats[0], tot); atomicMax(&stats[1], tot);
   }
 }
 // are the rows of a CRS graph column-sorted (non-strict)?  8 lanes per row; *unsorted is set to 1 otherwise.
@@ -261,8 +262,7 @@ template <class OffT>
 __global__ __launch_bounds__(kBlock) void rows_sorted_long_kernel(int64_t n, const OffT* __restrict__ rm, const int32_t* __restrict__ ent, int* __restrict__ unsorted) {
   __shared__ int s_long[kBlock];
   __shared__ int s_n;
-  const int64_t r0 = (int64_t)blockIdx.x * kBlock;
-  const int64_t mine = r0 + threadIdx.x;
+  const int64_t mine = (int64_t)threadIdx.x * gridDim.x + blockIdx.x;       // rows gridDim.x apart (see spgemm_flops_long_kernel)
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   if (mine < n && (int64_t)rm[mine + 1] - (int64_t)rm[mine] > kSortedLong) s_long[atomicAdd(&s_n, 1)] = threadIdx.x;
@@ -270,8 +270,14 @@ __global__ __launch_bounds__(kBlock) void rows_sorted_long_kernel(int64_t n, con
   bool bad = false;
   const int n_long = s_n;
   for (int i = 0; i < n_long; ++i) {
-    const int64_t row = r0 + s_long[i], b = (int64_t)rm[row], e = (int64_t)rm[row + 1];
-    for (int64_t j = b + threadIdx.x; j + 1 < e; j += kBlock) bad |= ent[j] > ent[j + 1];
+    const int64_t row = (int64_t)s_long[i] * gridDim.x + blockIdx.x, b = (int64_t)rm[row], e = (int64_t)rm[row + 1];
+    for (int64_t j = b + threadIdx.x; j + 1 < e; j += 8 * kBlock) {          // eight independent pairs per work-item and step
+      int32_t x0[8], x1[8];
+      KK_UNROLL
+      for (int u = 0; u < 8; ++u) { const int64_t q = j + u * kBlock; const bool in = q + 1 < e; x0[u] = in ? ent[q] : 0; x1[u] = in ? ent[q + 1] : 0; }
+      KK_UNROLL
+      for (int u = 0; u < 8; ++u) bad |= x0[u] > x1[u];
+    }
   }
   if (bad) *unsorted = 1;
 }
@@ -290,7 +296,14 @@ template <class OffT> __global__ void sum_max_counts_kernel(int64_t m, const Off
     s += c; mx = c > mx ? c : mx;
   }
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); const unsigned long long m2 = __shfl_xor(mx, o, 64); mx = m2 > mx ? m2 : mx; }
-  if ((threadIdx.x & 63) == 0 && s) { atomicAdd(out, s); atomicMax(out + 1, mx); }
+  __shared__ unsigned long long s_s[16], s_m[16];            // one pair of atomics per workgroup (16,000 waves on two addresses were 0.35 of this kernel's 0.38 ms)
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { s_s[wave] = s; s_m[wave] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; ++w) { s += s_s[w]; mx = s_m[w] > mx ? s_m[w] : mx; }
+    if (s) { atomicAdd(out, s); atomicMax(out + 1, mx); }
+  }
 }
 // row size of C from its row_map (numeric binning)
 template <class OffT>
@@ -1463,23 +1476,26 @@ __global__ __launch_bounds__(kBlock) void spgemm_aw_kernel(int64_t nnzA, const i
   aw[(size_t)nwin * (size_t)nnzA + a] = (long long)rmB[j + 1];
   for (int w = 1; w < nwin; ++w) aw[(size_t)w * (size_t)nnzA + a] = b + (long long)widx[(size_t)w * (size_t)nB + j];
 }
-// products of every unit of the class: one wave per row, window by window (the bounds of a window's pieces are two coalesced streams)
+// products of every unit of the class: one wave per unit (the bounds of a window's pieces are two coalesced streams).  (One wave per ROW,
+// window by window, left the class's heaviest rows -- 40,000 lists on R-MAT scale 20, first in the class's order -- to four waves: 0.9 of 1.1 ms.)
 template <class OffT>
 __global__ __launch_bounds__(kBlock) void spgemm_uprod_kernel(int64_t nrows, const int32_t* __restrict__ perm, const OffT* __restrict__ rmA, int64_t nnzA, int nwin,
                                                              const long long* __restrict__ aw, long long* __restrict__ uprod /* [nrows * nwin] */) {
   const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (r >= nrows) return;                                                  // (the whole wave)
+  const int64_t u = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (u >= nrows * nwin) return;                                           // (the whole wave)
+  const int64_t r = u / nwin;
+  const int w = (int)(u - r * nwin);
   const int64_t row = perm[r];
   const int64_t a0 = (int64_t)rmA[row], a1 = (int64_t)rmA[row + 1];
-  for (int w = 0; w < nwin; ++w) {
-    const long long* lo = aw + (size_t)w * (size_t)nnzA;
-    const long long* hi = lo + (size_t)nnzA;
-    long long sum = 0;
-    for (int64_t a = a0 + lane; a < a1; a += 64) sum += hi[a] - lo[a];
-    sum = group_sum(sum, 64);
-    if (lane == 0) uprod[r * nwin + w] = sum;
-  }
+  const long long* lo = aw + (size_t)w * (size_t)nnzA;
+  const long long* hi = lo + (size_t)nnzA;
+  long long s0 = 0, s1 = 0;
+  int64_t a = a0 + lane;
+  for (; a + 64 < a1; a += 128) { s0 += hi[a] - lo[a]; s1 += hi[a + 64] - lo[a + 64]; }
+  if (a < a1) s0 += hi[a] - lo[a];
+  const long long sum = group_sum(s0 + s1, 64);
+  if (lane == 0) uprod[u] = sum;
 }
 // the units with products, in any order (they are ordered by size next); count[0] = how many
 __global__ __launch_bounds__(kBlock) void spgemm_unit_compact_kernel(int64_t units, const long long* __restrict__ uprod, int32_t* __restrict__ ulist, unsigned long long* __restrict__ count) {
@@ -3262,6 +3278,7 @@ struct kkamd_spgemm_handle {
   int64_t last_units = 0, last_unit_bitmaps = 0, last_unit_rows_kept = 0;      // of the last symbolic phase (kkamd_spgemm_get 19 - 21; they outlive the store)
   int32_t* d_unit_perm = nullptr; unsigned* d_ucnt = nullptr; unsigned* d_ucoff = nullptr; long long* d_uoff = nullptr;
   kk::UnitHead* d_heads = nullptr; int64_t n_heads = 0;       // the units with products, in launch order
+  void* d_unit_block = nullptr;    // one allocation behind d_unit_perm, d_ucnt, d_ucoff, d_uoff, d_row_slot and d_heads (six hipMalloc were 0.3 ms of a phase)
   // a second stream for the symbolic phase: the kernels of the rows with few products (wave / block hash kernels) run beside the dense class
   hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // 64 counters on the device and their pinned copy on the host: what a phase reads back (statistics of the row flops, sortedness of B, bin counts;
@@ -3270,6 +3287,7 @@ struct kkamd_spgemm_handle {
   unsigned long long* d_small = nullptr; unsigned long long* h_small = nullptr;
   void* d_scan_ws = nullptr; size_t scan_ws_bytes = 0;
   int64_t sizes_cap = 0;           // rows d_sizes / d_perm hold
+  bool tmp_taken = false;          // the running symbolic phase holds the process-wide buffer of temporaries (take_tmp)
   bool compressed = false;         // what the last symbolic call did
   int64_t compressed_mults = 0;
 };
@@ -3283,7 +3301,7 @@ static int pick_sg_log2(int64_t nnzB, int64_t n) {
   return l;
 }
 
-constexpr int kSmallSlots = 64, kSmallStats = 0, kSmallFlag = 2, kSmallBins = 8, kSmallSum = 24;      // slots of the handle's counters
+constexpr int kSmallSlots = 64, kSmallStats = 0, kSmallFlag = 2, kSmallLong = 3, kSmallBins = 8, kSmallSum = 24;      // slots of the handle's counters
 static bool ensure_small(kkamd_spgemm_handle* h) {
   if (h->d_small && h->h_small) return true;
   if (!h->d_small && hipMalloc((void**)&h->d_small, kSmallSlots * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); h->d_small = nullptr; return false; }
@@ -3362,8 +3380,33 @@ struct BmPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int de
 // most a tenth).  Kokkos-based hosts: INTEGRATION.md registers kkamd_release_scratch with
 // Kokkos::push_finalize_hook; the C++ drop-in's Kokkos::finalize() calls it.
 static BmPool& bm_pool() { static BmPool pool; return pool; }
+// The temporaries of a symbolic phase with a dense class (the two indices, the units' products and order: 0.7 GB at R-MAT scale 20) come
+// from a second process-wide buffer under the same policy: five allocations at the start of the phase and their hipFree at its end -- each
+// waits for the device and unmaps hundreds of MB -- were 1.7 of the phase's 36 ms.  One user at a time; anyone else allocates as before.
+struct TmpPool { void* p = nullptr; size_t bytes = 0; bool in_use = false; int device = -1; std::mutex m; };
+static TmpPool& tmp_pool() { static TmpPool pool; return pool; }
+static void* take_tmp(size_t need) {
+  TmpPool& pool = tmp_pool();
+  std::lock_guard<std::mutex> g(pool.m);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (pool.in_use || (pool.p && pool.device != dev)) return nullptr;
+  if (pool.bytes < need) {
+    if (pool.p) { (void)hipFree(pool.p); pool.p = nullptr; pool.bytes = 0; }
+    if (hipMalloc(&pool.p, need) != hipSuccess) { (void)hipGetLastError(); pool.p = nullptr; return nullptr; }
+    pool.bytes = need; pool.device = dev;
+  }
+  pool.in_use = true;
+  return pool.p;
+}
+static void give_tmp() { TmpPool& pool = tmp_pool(); std::lock_guard<std::mutex> g(pool.m); pool.in_use = false; }
 int release_bitmap_pool();
 int release_bitmap_pool() {
+  {
+    TmpPool& tp = tmp_pool();
+    std::lock_guard<std::mutex> g(tp.m);
+    if (!tp.in_use && tp.p) { (void)hipFree(tp.p); tp.p = nullptr; tp.bytes = 0; }
+  }
   BmPool& pool = bm_pool();
   std::lock_guard<std::mutex> g(pool.m);
   if (!pool.in_use && pool.p) { (void)hipFree(pool.p); pool.p = nullptr; pool.bytes = 0; }
@@ -3398,11 +3441,15 @@ static void free_bitmap_store(kkamd_spgemm_handle* h) {
     else (void)hipFree(h->d_bm_store);
   }
   h->bm_pooled = false;
-  if (h->d_unit_perm) (void)hipFree(h->d_unit_perm);
-  if (h->d_ucnt) (void)hipFree(h->d_ucnt);
-  if (h->d_ucoff) (void)hipFree(h->d_ucoff);
-  if (h->d_uoff) (void)hipFree(h->d_uoff);
-  if (h->d_heads) (void)hipFree(h->d_heads);
+  if (h->d_unit_block) {                                  // the unit arrays are pieces of one allocation (row_slot among them)
+    (void)hipFree(h->d_unit_block); h->d_unit_block = nullptr; h->d_row_slot = nullptr;
+  } else {
+    if (h->d_unit_perm) (void)hipFree(h->d_unit_perm);
+    if (h->d_ucnt) (void)hipFree(h->d_ucnt);
+    if (h->d_ucoff) (void)hipFree(h->d_ucoff);
+    if (h->d_uoff) (void)hipFree(h->d_uoff);
+    if (h->d_heads) (void)hipFree(h->d_heads);
+  }
   h->d_unit_perm = nullptr; h->d_ucnt = nullptr; h->d_ucoff = nullptr; h->d_uoff = nullptr; h->d_heads = nullptr; h->n_heads = 0;
   h->unit_mode = false; h->unit_rows = 0; h->unit_rows_kept = 0; h->unit_bitmaps = 0;
   if (h->d_row_slot) (void)hipFree(h->d_row_slot);
@@ -3445,13 +3492,19 @@ struct Deferred {
   ~Deferred() { for (void* q : ptrs) (void)hipFree(q); }
 };
 // list[0 .. n) reordered by sizes[row], largest first (quarter-octave classes; see spgemm_size_hist_kernel)
-static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hipStream_t st, Deferred* later = nullptr) {
+// scratch: 4 n + 4 (kSizeClasses + 1) bytes of the caller's (then nothing is allocated, nothing waited for)
+static size_t order_list_scratch_bytes(int64_t n) { return sizeof(int32_t) * (size_t)n + sizeof(unsigned) * (kSizeClasses + 1) + 16; }
+static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hipStream_t st, Deferred* later = nullptr, void* scratch = nullptr) {
   if (n < 4096 || !g_spgemm.sort_rows) return KKAMD_OK;          // (a short list finishes in one wave of workgroups whatever its order)
   DevBuf tmp_b, hist_b;
   struct Hand { Deferred* d; DevBuf &a, &b; ~Hand() { if (d) { d->take(a); d->take(b); } } } hand{later, tmp_b, hist_b};
-  KK_HIP(tmp_b.alloc(sizeof(int32_t) * (size_t)n));
-  KK_HIP(hist_b.alloc(sizeof(unsigned) * (kSizeClasses + 1)));
-  int32_t* d_tmp = tmp_b.as<int32_t>(); unsigned* d_hist = hist_b.as<unsigned>();
+  int32_t* d_tmp; unsigned* d_hist;
+  if (scratch) { d_hist = reinterpret_cast<unsigned*>(scratch); d_tmp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(scratch) + ((sizeof(unsigned) * (kSizeClasses + 1) + 15) & ~(size_t)15)); }
+  else {
+    KK_HIP(tmp_b.alloc(sizeof(int32_t) * (size_t)n));
+    KK_HIP(hist_b.alloc(sizeof(unsigned) * (kSizeClasses + 1)));
+    d_tmp = tmp_b.as<int32_t>(); d_hist = hist_b.as<unsigned>();
+  }
   KK_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned) * (kSizeClasses + 1), st));
   KK_HIP(hipMemcpyAsync(d_tmp, list, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
   const int64_t nbk = ceil_div(n, kBlock);
@@ -3459,7 +3512,7 @@ static int order_list_by_size(int32_t* list, int64_t n, const int64_t* sizes, hi
   KK_LAUNCH(spgemm_size_hist_kernel, grid, kBlock, 0, st, n, (const int32_t*)d_tmp, sizes, d_hist);
   KK_LAUNCH(spgemm_size_scan_kernel, 1, kSizeClasses, 0, st, d_hist);
   KK_LAUNCH(spgemm_size_scatter_kernel, grid, kBlock, 0, st, n, (const int32_t*)d_tmp, sizes, d_hist, list);
-  KK_HIP(hipStreamSynchronize(st));          // the scratch buffers go out of scope
+  if (!scratch && !later) KK_HIP(hipStreamSynchronize(st));          // the scratch buffers go out of scope
   return KKAMD_OK;
 }
 
@@ -3512,15 +3565,37 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   // temporaries of this phase (free themselves): the two indices, products and launch order of the units; kept for the numeric phase: heads, counts, offsets
   DevBuf widx_b, aw_b, uprod_b, ulist_b, soff_b, cnt_b;
   struct Hand { Deferred* d; DevBuf *b[6]; ~Hand() { if (d) for (DevBuf* x : b) d->take(*x); } } hand{later, {&widx_b, &aw_b, &uprod_b, &ulist_b, &soff_b, &cnt_b}};
-  if (aw_b.alloc(aw_bytes) != hipSuccess || uprod_b.alloc(sizeof(long long) * (size_t)units) != hipSuccess || ulist_b.alloc(sizeof(int32_t) * (size_t)units) != hipSuccess ||
-      cnt_b.alloc(8 * sizeof(unsigned long long)) != hipSuccess || (widx_bytes && widx_b.alloc(widx_bytes) != hipSuccess) ||
-      hipMalloc((void**)&h->d_unit_perm, sizeof(int32_t) * (size_t)nrows) != hipSuccess || hipMalloc((void**)&h->d_ucnt, sizeof(unsigned) * (size_t)units) != hipSuccess ||
-      hipMalloc((void**)&h->d_ucoff, sizeof(unsigned) * (size_t)units) != hipSuccess || hipMalloc((void**)&h->d_uoff, sizeof(long long) * (size_t)units) != hipSuccess ||
-      hipMalloc((void**)&h->d_row_slot, sizeof(int32_t) * (size_t)m) != hipSuccess) {
-    (void)hipGetLastError(); free_bitmap_store(h); return KKAMD_OK;
+  // ... from the process-wide buffer when it is free (take_tmp), else allocated here
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t soff_max = sizeof(long long) * (size_t)(units + 1 + scan_workspace_items(units + 1) + nrows + 1 + scan_workspace_items(nrows + 1)) + (size_t)units + (size_t)nrows;
+  const size_t arena_need = al(aw_bytes) + al(widx_bytes) + al(sizeof(long long) * (size_t)units) + al(sizeof(int32_t) * (size_t)units) + al(64) + al(soff_max) + al(order_list_scratch_bytes(units));
+  char* arena = h->tmp_taken ? nullptr : reinterpret_cast<char*>(take_tmp(arena_need));
+  size_t apos = 0;
+  auto carve = [&](size_t b) -> void* { void* q = arena + apos; apos += al(b); return q; };
+  void *a_aw = nullptr, *a_wx = nullptr, *a_up = nullptr, *a_ul = nullptr, *a_cnt = nullptr, *a_so = nullptr, *a_ord = nullptr;
+  if (arena) {
+    h->tmp_taken = true;
+    a_aw = carve(aw_bytes); a_wx = carve(widx_bytes); a_up = carve(sizeof(long long) * (size_t)units); a_ul = carve(sizeof(int32_t) * (size_t)units);
+    a_cnt = carve(64); a_so = carve(soff_max); a_ord = carve(order_list_scratch_bytes(units));
   }
-  unsigned* d_wx = widx_b.as<unsigned>(); long long* d_aw = aw_b.as<long long>(); long long* d_up = uprod_b.as<long long>(); int32_t* d_ul = ulist_b.as<int32_t>();
-  unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
+  if ((!arena && (aw_b.alloc(aw_bytes) != hipSuccess || uprod_b.alloc(sizeof(long long) * (size_t)units) != hipSuccess || ulist_b.alloc(sizeof(int32_t) * (size_t)units) != hipSuccess ||
+      cnt_b.alloc(8 * sizeof(unsigned long long)) != hipSuccess || (widx_bytes && widx_b.alloc(widx_bytes) != hipSuccess))) ||
+      hipMalloc(&h->d_unit_block, al(sizeof(UnitHead) * (size_t)units) + al(sizeof(long long) * (size_t)units) + 2 * al(sizeof(unsigned) * (size_t)units) +
+                                  al(sizeof(int32_t) * (size_t)nrows) + al(sizeof(int32_t) * (size_t)m)) != hipSuccess) {
+    (void)hipGetLastError(); h->d_unit_block = nullptr; free_bitmap_store(h); return KKAMD_OK;
+  }
+  {
+    char* q = reinterpret_cast<char*>(h->d_unit_block);
+    h->d_heads = reinterpret_cast<UnitHead*>(q); q += al(sizeof(UnitHead) * (size_t)units);        // (room for every unit; those with products get a head)
+    h->d_uoff = reinterpret_cast<long long*>(q); q += al(sizeof(long long) * (size_t)units);
+    h->d_ucnt = reinterpret_cast<unsigned*>(q); q += al(sizeof(unsigned) * (size_t)units);
+    h->d_ucoff = reinterpret_cast<unsigned*>(q); q += al(sizeof(unsigned) * (size_t)units);
+    h->d_unit_perm = reinterpret_cast<int32_t*>(q); q += al(sizeof(int32_t) * (size_t)nrows);
+    h->d_row_slot = reinterpret_cast<int32_t*>(q);
+  }
+  unsigned* d_wx = arena ? (unsigned*)a_wx : widx_b.as<unsigned>(); long long* d_aw = arena ? (long long*)a_aw : aw_b.as<long long>();
+  long long* d_up = arena ? (long long*)a_up : uprod_b.as<long long>(); int32_t* d_ul = arena ? (int32_t*)a_ul : ulist_b.as<int32_t>();
+  unsigned long long* d_cnt = arena ? (unsigned long long*)a_cnt : cnt_b.as<unsigned long long>();
   KK_HIP(hipMemcpyAsync(h->d_unit_perm, list, sizeof(int32_t) * (size_t)nrows, hipMemcpyDeviceToDevice, st));     // the numeric phase bins the rows again in d_perm
   KK_HIP(hipMemsetAsync(h->d_uoff, 0xFF, sizeof(long long) * (size_t)units, st));
   KK_HIP(hipMemsetAsync(h->d_ucnt, 0, sizeof(unsigned) * (size_t)units, st));
@@ -3529,7 +3604,7 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   const int32_t* d_perm_u = h->d_unit_perm;
   if (nwin > 1) KK_LAUNCH((spgemm_bidx_kernel<OffT>), (unsigned)ceil_div((int64_t)(nwin + 1) * n, kBlock), kBlock, 0, st, n, nwin, wb, rmB, entB, d_wx);
   KK_LAUNCH((spgemm_aw_kernel<OffT>), (unsigned)ceil_div(nnzA, kBlock), kBlock, 0, st, nnzA, entA, rmB, n, nwin, (const unsigned*)d_wx, d_aw);
-  KK_LAUNCH((spgemm_uprod_kernel<OffT>), (unsigned)ceil_div(nrows, kBlock / 64), kBlock, 0, st, nrows, d_perm_u, rmA, nnzA, nwin, (const long long*)d_aw, d_up);
+  KK_LAUNCH((spgemm_uprod_kernel<OffT>), (unsigned)ceil_div(nrows * nwin, kBlock / 64), kBlock, 0, st, nrows, d_perm_u, rmA, nnzA, nwin, (const long long*)d_aw, d_up);
   KK_LAUNCH(spgemm_unit_compact_kernel, (unsigned)ceil_div(units, kBlock), kBlock, 0, st, units, (const long long*)d_up, d_ul, d_cnt);
   lap("allocations + indices + compaction");
   unsigned long long h_n = 0;
@@ -3540,7 +3615,7 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   h->last_units = nu;
   if (nu == 0) { *ran = true; return KKAMD_OK; }
   int rc;
-  if ((rc = order_list_by_size(d_ul, nu, (const int64_t*)d_up, st, later))) return rc;        // heaviest units first
+  if ((rc = order_list_by_size(d_ul, nu, (const int64_t*)d_up, st, later, a_ord))) return rc;        // heaviest units first
   // where every unit's structure goes: a prefix sum over min(4 products, bitmap bytes); the store is at most 0.225 of the free HBM (an eighth
   // for bitmaps and a tenth for lists until round 5).  Room is given out by ROW, heaviest rows first (a row's structure is of use only when
   // all its units keep theirs): the rows past it keep nothing and walk their products again in the numeric phase
@@ -3550,12 +3625,11 @@ static int symbolic_units(kkamd_spgemm_handle* h, int64_t nrows, const int32_t* 
   const long long bm_bytes = (long long)words * 8;
   long long budget = 0, total_need = 0;
   const int64_t so_items = nu + 1 + scan_workspace_items(nu + 1), rb_items = nrows + 1 + scan_workspace_items(nrows + 1);
-  KK_HIP(soff_b.alloc(sizeof(long long) * (size_t)(so_items + rb_items) + (size_t)nu + (size_t)nrows));
-  long long* d_so = soff_b.as<long long>();
+  if (!arena) KK_HIP(soff_b.alloc(sizeof(long long) * (size_t)(so_items + rb_items) + (size_t)nu + (size_t)nrows));
+  long long* d_so = arena ? (long long*)a_so : soff_b.as<long long>();
   long long* d_rb = d_so + so_items;
   unsigned char* d_drop = reinterpret_cast<unsigned char*>(d_rb + rb_items);
   unsigned char* d_rnone = d_drop + nu;
-  if (hipMalloc((void**)&h->d_heads, sizeof(UnitHead) * (size_t)nu) != hipSuccess) { (void)hipGetLastError(); free_bitmap_store(h); return KKAMD_OK; }
   KK_LAUNCH(spgemm_unit_rowbytes_kernel, (unsigned)ceil_div(nrows + 1, kBlock), kBlock, 0, st, nrows, nwin, (const long long*)d_up, bm_bytes, g_spgemm.keep_lists, d_rb, d_rnone);
   if ((rc = exclusive_scan_inplace<long long>(d_rb, nrows + 1, st, d_rb + nrows + 1))) return rc;
   if (g_spgemm.keep_bitmaps && k >= 64) {
@@ -3627,6 +3701,8 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
   };
   KK_HIP(hipMemsetAsync(rmC, 0, sizeof(OffT) * (size_t)(m + 1), st));
   if (!ensure_small(h)) return fail(KKAMD_ERR_ALLOC, "kkamd_spgemm_symbolic: out of memory for the handle's counters");
+  // the process-wide buffer of temporaries goes back when the phase is over and its kernels have run (both streams)
+  struct TmpGuard { kkamd_spgemm_handle* h; hipStream_t st; ~TmpGuard() { if (h->tmp_taken) { (void)hipStreamSynchronize(st); if (h->aux) (void)hipStreamSynchronize(h->aux); give_tmp(); h->tmp_taken = false; } } } tmp_guard{h, st};
   // Without B compression (the default) nothing between the row flops and the bins depends on the host: flops, sortedness of B and the bin
   // counts are queued together and read back in one copy.
   const bool merged = !h->compression;
@@ -3639,10 +3715,15 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     d_stats = stats_b.as<unsigned long long>();
     KK_HIP(hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), st));
   }
+  // rows of A above kFlopsLong entries are listed by the first kernel and walked by the second, a workgroup each (the list borrows d_perm: the bins come later)
+  int32_t* d_long = h->d_perm; unsigned long long* d_long_cnt = h->d_small + kSmallLong;
+  const int64_t n_long_cap = h->nnzA / kFlopsLong + 1;
+  const unsigned n_long_max = (unsigned)(n_long_cap < m ? n_long_cap : m);
   {
     const int64_t nbk = ceil_div(m * 8, kBlock);
-    KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbk < 4096 ? nbk : 4096), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats);
-    KK_LAUNCH((spgemm_flops_long_kernel<OffT>), (unsigned)ceil_div(m, kBlock), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats);
+    if (!merged) KK_HIP(hipMemsetAsync(d_long_cnt, 0, sizeof(unsigned long long), st));
+    KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbk < 4096 ? nbk : 4096), kBlock, 0, st, m, rmA, entA, rmB, h->d_sizes, d_stats, d_long, d_long_cnt);
+    KK_LAUNCH((spgemm_flops_long_kernel<OffT>), n_long_max, kBlock, 0, st, (const int32_t*)d_long, (const unsigned long long*)d_long_cnt, rmA, entA, rmB, h->d_sizes, d_stats);
   }
   unsigned long long h_stats[2] = {0, 0};
   if (merged) {
@@ -3703,8 +3784,9 @@ static int symbolic_typed(kkamd_spgemm_handle* h, int64_t m, int64_t n, int64_t 
     if (cflops.alloc(sizeof(int64_t) * (size_t)m) == hipSuccess) {
       int64_t* d_cf = cflops.as<int64_t>();
       const int64_t nbf = ceil_div(m * 8, kBlock);
-      KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbf < 4096 ? nbf : 4096), kBlock, 0, st, m, rmA, entA, rmB, d_cf, d_stats, (const OffT*)d_end);
-      KK_LAUNCH((spgemm_flops_long_kernel<OffT>), (unsigned)ceil_div(m, kBlock), kBlock, 0, st, m, rmA, entA, rmB, d_cf, d_stats, (const OffT*)d_end);
+      KK_HIP(hipMemsetAsync(d_long_cnt, 0, sizeof(unsigned long long), st));
+      KK_LAUNCH((spgemm_flops_kernel<OffT>), (unsigned)(nbf < 4096 ? nbf : 4096), kBlock, 0, st, m, rmA, entA, rmB, d_cf, d_stats, d_long, d_long_cnt, (const OffT*)d_end);
+      KK_LAUNCH((spgemm_flops_long_kernel<OffT>), n_long_max, kBlock, 0, st, (const int32_t*)d_long, (const unsigned long long*)d_long_cnt, rmA, entA, rmB, d_cf, d_stats, (const OffT*)d_end);
       KK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
       KK_HIP(hipStreamSynchronize(st));
       h->compressed_mults = (int64_t)h_stats[0];
@@ -4481,7 +4563,7 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
     kk::BmPool& pool = kk::bm_pool(); std::lock_guard<std::mutex> g(pool.m);
     const bool last = --pool.live_handles <= 0;
     if (pool.live_handles < 0) pool.live_handles = 0;
-    release = last && pool.p && (kk::g_spgemm.pool_keep == 2 || (kk::g_spgemm.pool_keep == 0 && !pool.sticky));
+    release = last && (pool.p || kk::tmp_pool().p) && (kk::g_spgemm.pool_keep == 2 || (kk::g_spgemm.pool_keep == 0 && !pool.sticky));
     if (release) pool.released_once = true;
   }
   if (release) (void)kk::release_bitmap_pool();
@@ -4686,18 +4768,28 @@ int kkamd_dist_spgemm_partition(int64_t m, const void* d_row_mapA, const int32_t
   hipStream_t st = kk::to_hip(stream);
   std::vector<int64_t> flops((size_t)m);
   if (m > 0) {
-    kk::DevBuf f_b, s_b;
-    KK_HIP(f_b.alloc(sizeof(int64_t) * (size_t)m)); KK_HIP(s_b.alloc(2 * sizeof(unsigned long long)));
-    KK_HIP(hipMemsetAsync(s_b.p, 0, 2 * sizeof(unsigned long long), st));
-    int64_t* d_f = f_b.as<int64_t>(); unsigned long long* d_s = s_b.as<unsigned long long>();
+    kk::DevBuf f_b, s_b, l_b;
+    KK_HIP(f_b.alloc(sizeof(int64_t) * (size_t)m)); KK_HIP(s_b.alloc(3 * sizeof(unsigned long long))); KK_HIP(l_b.alloc(sizeof(int32_t) * (size_t)m));
+    KK_HIP(hipMemsetAsync(s_b.p, 0, 3 * sizeof(unsigned long long), st));
+    int64_t* d_f = f_b.as<int64_t>(); unsigned long long* d_s = s_b.as<unsigned long long>(); int32_t* d_l = l_b.as<int32_t>();
     const int64_t nbk = kk::ceil_div(m * 8, kk::kBlock);
-    const unsigned gl = (unsigned)kk::ceil_div(m, (int64_t)kk::kBlock);
+    // rows above kFlopsLong entries: listed by the first kernel, a workgroup each; at most nnz(A) / kFlopsLong of them
+    int64_t nnzA_h = 0;
+    {
+      unsigned char buf[8] = {0};
+      const size_t osz = offset_type == KKAMD_I64 ? 8 : 4;
+      KK_HIP(hipMemcpyAsync(buf, (const char*)d_row_mapA + osz * (size_t)m, osz, hipMemcpyDeviceToHost, st));
+      KK_HIP(hipStreamSynchronize(st));
+      nnzA_h = offset_type == KKAMD_I64 ? *(int64_t*)buf : (int64_t) * (int32_t*)buf;
+    }
+    const int64_t gl_cap = nnzA_h / kk::kFlopsLong + 1;
+    const unsigned gl = (unsigned)(gl_cap < m ? gl_cap : m);
     if (offset_type == KKAMD_I64) {
-      KK_LAUNCH((kk::spgemm_flops_kernel<int64_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int64_t*)d_row_mapA, d_entriesA, (const int64_t*)d_row_mapB, d_f, d_s);
-      KK_LAUNCH((kk::spgemm_flops_long_kernel<int64_t>), gl, kk::kBlock, 0, st, m, (const int64_t*)d_row_mapA, d_entriesA, (const int64_t*)d_row_mapB, d_f, d_s);
+      KK_LAUNCH((kk::spgemm_flops_kernel<int64_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int64_t*)d_row_mapA, d_entriesA, (const int64_t*)d_row_mapB, d_f, d_s, d_l, d_s + 2);
+      KK_LAUNCH((kk::spgemm_flops_long_kernel<int64_t>), gl, kk::kBlock, 0, st, (const int32_t*)d_l, (const unsigned long long*)(d_s + 2), (const int64_t*)d_row_mapA, d_entriesA, (const int64_t*)d_row_mapB, d_f, d_s);
     } else {
-      KK_LAUNCH((kk::spgemm_flops_kernel<int32_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int32_t*)d_row_mapA, d_entriesA, (const int32_t*)d_row_mapB, d_f, d_s);
-      KK_LAUNCH((kk::spgemm_flops_long_kernel<int32_t>), gl, kk::kBlock, 0, st, m, (const int32_t*)d_row_mapA, d_entriesA, (const int32_t*)d_row_mapB, d_f, d_s);
+      KK_LAUNCH((kk::spgemm_flops_kernel<int32_t>), (unsigned)(nbk < 4096 ? nbk : 4096), kk::kBlock, 0, st, m, (const int32_t*)d_row_mapA, d_entriesA, (const int32_t*)d_row_mapB, d_f, d_s, d_l, d_s + 2);
+      KK_LAUNCH((kk::spgemm_flops_long_kernel<int32_t>), gl, kk::kBlock, 0, st, (const int32_t*)d_l, (const unsigned long long*)(d_s + 2), (const int32_t*)d_row_mapA, d_entriesA, (const int32_t*)d_row_mapB, d_f, d_s);
     }
     KK_HIP(hipMemcpyAsync(flops.data(), d_f, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, st));
     KK_HIP(hipStreamSynchronize(st));
