@@ -1902,18 +1902,43 @@ __global__ __launch_bounds__(kBlock) void spgemm_emit_sort_kernel(const int32_t*
   while (N < filled) N <<= 1;
   for (int i = filled + t; i < N; i += kBlock) s_key[i] = INT_MAX;
   __syncthreads();
-  for (int kk2 = 2; kk2 <= N; kk2 <<= 1) {                       // bitonic network
-    for (int j = kk2 >> 1; j > 0; j >>= 1) {
-      for (int p = t; p < N; p += kBlock) {
-        const int q = p ^ j;
-        if (q > p) {
-          const int x = s_key[p], y = s_key[q];
-          const bool up = (p & kk2) == 0;
-          if ((x > y) == up) { s_key[p] = y; s_key[q] = x; }
+  // Bitonic network.  Every wave owns a chunk of C = N / 4 (at least 64) consecutive slots: the steps whose partners are less than C apart
+  // stay inside a chunk and need no workgroup barrier -- a wave's LDS operations are carried out in order --, which leaves 3 of the 45 steps of
+  // 512 slots (10 of 66 at 2048) with one.  Pair i of a step is (p, p + j), p = i with a 0 inserted at bit log2 j: every work-item has a pair
+  // (with q = p ^ j, q > p as the test half of them idled).  (All 45 steps behind barriers: 11.4 ms for the 10^6 rows of 400 products of
+  // uniform random 10^6 x 20, whose first numeric call is this kernel.)
+  {
+    constexpr int NW = kBlock / 64;
+    const int C = N / NW > 64 ? N / NW : 64;
+    const int lane = t & 63, wave = t >> 6;
+    const int cbase = wave * C;
+    bool was_global = true;                                      // (the fill above ended with a workgroup barrier)
+    for (int kk2 = 2; kk2 <= N; kk2 <<= 1) {
+      for (int j = kk2 >> 1; j > 0; j >>= 1) {
+        if (j < C) {
+          if (was_global) { was_global = false; } else KK_WAVE_SYNC();
+          if (cbase < N) {
+            for (int i = lane; i < C / 2; i += 64) {
+              const int p = cbase + (((i & ~(j - 1)) << 1) | (i & (j - 1))), q = p + j;
+              const int x = s_key[p], y = s_key[q];
+              const bool up = (p & kk2) == 0;
+              if ((x > y) == up) { s_key[p] = y; s_key[q] = x; }
+            }
+          }
+        } else {
+          __syncthreads();
+          for (int i = t; i < N / 2; i += kBlock) {
+            const int p = ((i & ~(j - 1)) << 1) | (i & (j - 1)), q = p + j;
+            const int x = s_key[p], y = s_key[q];
+            const bool up = (p & kk2) == 0;
+            if ((x > y) == up) { s_key[p] = y; s_key[q] = x; }
+          }
+          __syncthreads();
+          was_global = true;
         }
       }
-      __syncthreads();
     }
+    __syncthreads();
   }
   // the distinct columns, in order: work-item t looks at PER consecutive slots
   int flag[PER], cnt = 0;

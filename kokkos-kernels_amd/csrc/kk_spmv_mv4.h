@@ -166,7 +166,12 @@ __global__ __launch_bounds__(kMv4Threads, 1) void spmv_mv4_kernel(const OffT* __
     int xr, part;
     if constexpr (!XT) { g = g < NP ? g : NP - 1; xr = g >> 3; part = g & 7; }
     else {
+#ifdef KK_MV4_XT_RUNS16
       xr = (g >> 7) * 16 + (g & 15); part = (g >> 4) & 7;
+#else
+      part = g / SLABR; xr = g - part * SLABR;           // 64 consecutive lanes on 64 consecutive slab rows of one piece (two slab lines: runs of 272 and 240 bytes)
+      if (part > 7) { part = 7; xr = SLABR; }
+#endif
       if (xr < SLABR) x_live |= 1u << it; else xr = SLABR - 1;
       x_dst[it] = (xr * 8 + (part ^ ((xr % W) & 7))) * 16;
     }
