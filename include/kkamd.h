@@ -95,9 +95,11 @@ int kkamd_spmv_plan_create_knobs(kkamd_spmv_plan_t** plan, const kkamd_crs_t* A,
                                  const int* values, int nknobs, kkamd_stream_t stream);
 int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan);
 /* Frees the calling host thread's scratch of the handle-less route (tile descriptors + carry slots, grown on demand and
- * otherwise kept for the thread's life) and the process-wide buffer the SpGEMM symbolic phase parks row bitmaps in between a
- * symbolic and the numeric call that consumes them (up to an eighth of the free HBM; kept between uses because allocating and
- * freeing GBs per handle costs more than the phase itself). */
+ * otherwise kept for the thread's life) and the two process-wide buffers of the SpGEMM symbolic phase: the store of the structure it
+ * keeps for the first numeric call (bitmaps and entry lists of the dense class's units: at most 0.225 of the free HBM, or
+ * "spgemm_store_cap_mb") and the phase's temporaries (the two indices and the units' products: 0.7 GB at R-MAT scale 20).  Both are
+ * kept between uses under the policy of "spgemm_pool_keep" because allocating and freeing GBs per handle costs more than the phase
+ * itself. */
 int kkamd_release_scratch(void);
 
 /* y := alpha*op(A)*x + beta*y.  mode 'N','C' (== 'N' for real scalars), 'T','H' (== 'T').
