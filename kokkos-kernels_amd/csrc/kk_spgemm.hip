@@ -1738,14 +1738,23 @@ __global__ __launch_bounds__(NT, 4) void spgemm_sym_unit_kernel(const UnitHead* 
     __syncthreads();
   }
   __syncthreads();
-  // count: every wave owns a contiguous range of the words and reads it 64 words at a time, lane l the l-th (8-byte reads at consecutive
-  // addresses); the words stay in registers for what follows
+  // count: every wave owns a contiguous range of the words and reads it 128 words at a time, lane l the words 2 l and 2 l + 1 (16-byte reads at
+  // consecutive addresses); the words stay in registers for what follows.  (64 words per round, a word per lane: the same count, but the entry
+  // lists below took a prefix sum and four loop heads per 64 words -- 6.6 of the kernel's 34 ms on R-MAT scale 20, and most of what a unit of
+  // a few thousand products costs.)
+  static_assert(NB % 2 == 0, "rounds of 128 words");
+  constexpr int NB2 = NB / 2;
   const int wpw = ((nwords + NW - 1) / NW + 63) & ~63;
   const int w0 = wave * wpw, w1 = (w0 + wpw < nwords) ? w0 + wpw : nwords;
-  kk_u64 wd[NB];
+  kk_u64 wa[NB2], wc[NB2];
   int wsum = 0;
   KK_UNROLL
-  for (int i = 0; i < NB; ++i) { const int idx = w0 + i * 64 + lane; wd[i] = (i * 64 < wpw && idx < w1) ? bm[idx] : 0ull; wsum += __popcll(wd[i]); }
+  for (int i = 0; i < NB2; ++i) {
+    const int idx = w0 + i * 128 + 2 * lane;                            // (even; bm holds zeros from nwords to bm_words, a multiple of 16)
+    const bool in = i * 128 < wpw && idx < w1;
+    wa[i] = in ? bm[idx] : 0ull; wc[i] = in ? bm[idx + 1] : 0ull;
+    wsum += __popcll(wa[i]) + __popcll(wc[i]);
+  }
   wsum = wave_sum_i32(wsum, lane);
   if (lane == 0) sc.wave32[wave] = wsum;
   __syncthreads();
@@ -1756,25 +1765,30 @@ __global__ __launch_bounds__(NT, 4) void spgemm_sym_unit_kernel(const UnitHead* 
   if (hd.kind == 1) {
     kk_u64* dst = reinterpret_cast<kk_u64*>(store + hd.store_off);
     KK_UNROLL
-    for (int i = 0; i < NB; ++i) { const int idx = w0 + i * 64 + lane; if (i * 64 < wpw && idx < w1) dst[idx] = wd[i]; }
+    for (int i = 0; i < NB2; ++i) {
+      const int idx = w0 + i * 128 + 2 * lane;
+      if (i * 128 < wpw && idx < w1) { dst[idx] = wa[i]; if (idx + 1 < w1) dst[idx + 1] = wc[i]; }
+    }
   } else {
-    // the unit's entries in ascending order: a wave takes its words 64 at a time (lane l the l-th), a prefix sum of the popcounts on the
-    // vector unit places every word's bits, rounds without a set bit are skipped
+    // the unit's entries in ascending order: a prefix sum of the lanes' popcounts on the vector unit places every lane's bits, rounds without a
+    // set bit are skipped
     int32_t* dst = reinterpret_cast<int32_t*>(store + hd.store_off);
     int run = before;
     KK_UNROLL
-    for (int i = 0; i < NB; ++i) {
-      if (i * 64 >= wpw) break;                                          // uniform
-      const kk_u64 v = wd[i];
-      if (__ballot(v != 0ull) == 0ull) continue;                         // uniform
-      const int pc = __popcll(v);
+    for (int i = 0; i < NB2; ++i) {
+      if (i * 128 >= wpw) break;                                         // uniform
+      const kk_u64 va = wa[i], vc = wc[i];
+      if (__ballot((va | vc) != 0ull) == 0ull) continue;                 // uniform
+      const int pc = __popcll(va) + __popcll(vc);
       const int inc = wave_inclusive_scan_i32(pc, lane);
       int pos = run + inc - pc;
-      unsigned lo32 = (unsigned)v, hi32 = (unsigned)(v >> 32);
-      const int cbase = (int)(c0 + (int64_t)(w0 + i * 64 + lane) * 64);
+      const int cbase = (int)(c0 + (int64_t)(w0 + i * 128 + 2 * lane) * 64);
       if (!KK_DBG(1)) {
-        while (lo32) { dst[pos++] = cbase + (__ffs((int)lo32) - 1); lo32 &= lo32 - 1u; }
-        while (hi32) { dst[pos++] = cbase + 32 + (__ffs((int)hi32) - 1); hi32 &= hi32 - 1u; }
+        unsigned b0 = (unsigned)va, b1 = (unsigned)(va >> 32), b2 = (unsigned)vc, b3 = (unsigned)(vc >> 32);
+        while (b0) { dst[pos++] = cbase + (__ffs((int)b0) - 1); b0 &= b0 - 1u; }
+        while (b1) { dst[pos++] = cbase + 32 + (__ffs((int)b1) - 1); b1 &= b1 - 1u; }
+        while (b2) { dst[pos++] = cbase + 64 + (__ffs((int)b2) - 1); b2 &= b2 - 1u; }
+        while (b3) { dst[pos++] = cbase + 96 + (__ffs((int)b3) - 1); b3 &= b3 - 1u; }
       }
       run += wave_last_lane_i32(inc);
     }
