@@ -97,7 +97,8 @@ int kkamd_spmv_plan_destroy(kkamd_spmv_plan_t* plan);
 /* Frees the calling host thread's scratch of the handle-less route (tile descriptors + carry slots, grown on demand and
  * otherwise kept for the thread's life) and the two process-wide buffers of the SpGEMM symbolic phase: the store of the structure it
  * keeps for the first numeric call (bitmaps and entry lists of the dense class's units: at most 0.225 of the free HBM, or
- * "spgemm_store_cap_mb") and the phase's temporaries (the two indices and the units' products: 0.7 GB at R-MAT scale 20).  Both are
+ * "spgemm_store_cap_mb") and the phase's temporaries (the two indices and the units' products: 0.7 GB at R-MAT scale 20); also the
+ * 512-byte counter blocks (device + pinned host) that destroyed SpGEMM handles leave for the next handle.  The two large buffers are
  * kept between uses under the policy of "spgemm_pool_keep" because allocating and freeing GBs per handle costs more than the phase
  * itself. */
 int kkamd_release_scratch(void);

@@ -3323,7 +3323,7 @@ struct kkamd_spgemm_handle {
   // 64 counters on the device and their pinned copy on the host: what a phase reads back (statistics of the row flops, sortedness of B, bin counts;
   // sum and maximum of the row counts) travels in ONE copy per decision point -- a product of a multigrid setup is a dozen launches of a few
   // microseconds each, and every separate read-back (a temporary, a copy, a synchronisation, a hipFree) cost it 30 - 40 us.  d_scan_ws: workspace of the row_map scan
-  unsigned long long* d_small = nullptr; unsigned long long* h_small = nullptr;
+  unsigned long long* d_small = nullptr; unsigned long long* h_small = nullptr; int small_device = -1;
   void* d_scan_ws = nullptr; size_t scan_ws_bytes = 0;
   int64_t sizes_cap = 0;           // rows d_sizes / d_perm hold
   bool tmp_taken = false;          // the running symbolic phase holds the process-wide buffer of temporaries (take_tmp)
@@ -3341,11 +3341,36 @@ static int pick_sg_log2(int64_t nnzB, int64_t n) {
 }
 
 constexpr int kSmallSlots = 64, kSmallStats = 0, kSmallFlag = 2, kSmallLong = 3, kSmallBins = 8, kSmallSum = 24;      // slots of the handle's counters
+// The counters of destroyed handles wait here for the next handle of the same device (a product of a multigrid setup creates a handle, runs two
+// phases of a few hundred microseconds and destroys it: a hipMalloc + hipHostMalloc and their frees per handle were a fifth of that);
+// kkamd_release_scratch frees them.
+struct SmallPool { struct Item { unsigned long long* d; unsigned long long* h; int device; }; std::vector<Item> items; std::mutex m; };
+static SmallPool& small_pool() { static SmallPool pool; return pool; }
 static bool ensure_small(kkamd_spgemm_handle* h) {
   if (h->d_small && h->h_small) return true;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  {
+    SmallPool& sp = small_pool(); std::lock_guard<std::mutex> g(sp.m);
+    for (size_t i = 0; i < sp.items.size(); ++i)
+      if (sp.items[i].device == dev) { h->d_small = sp.items[i].d; h->h_small = sp.items[i].h; h->small_device = dev; sp.items.erase(sp.items.begin() + (long)i); return true; }
+  }
   if (!h->d_small && hipMalloc((void**)&h->d_small, kSmallSlots * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); h->d_small = nullptr; return false; }
   if (!h->h_small && hipHostMalloc((void**)&h->h_small, kSmallSlots * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->h_small = nullptr; return false; }
+  h->small_device = dev;
   return true;
+}
+static void park_small(kkamd_spgemm_handle* h) {                 // (handle destruction; the handle's streams have been waited for)
+  if (!h->d_small || !h->h_small) { if (h->d_small) (void)hipFree(h->d_small); if (h->h_small) (void)hipHostFree(h->h_small); h->d_small = nullptr; h->h_small = nullptr; return; }
+  SmallPool& sp = small_pool(); std::lock_guard<std::mutex> g(sp.m);
+  if (sp.items.size() < 16) sp.items.push_back({h->d_small, h->h_small, h->small_device});
+  else { (void)hipFree(h->d_small); (void)hipHostFree(h->h_small); }
+  h->d_small = nullptr; h->h_small = nullptr;
+}
+static void release_small_pool() {
+  SmallPool& sp = small_pool(); std::lock_guard<std::mutex> g(sp.m);
+  for (auto& it : sp.items) { (void)hipFree(it.d); (void)hipHostFree(it.h); }
+  sp.items.clear();
 }
 // d_cnt: 2 kNumBins counters owned by the caller (zeroed by the caller when `counted`); h_cnt: where their copy on the host goes / is.
 // counted: spgemm_bin_count_kernel has run and h_cnt holds its result.  With d_cnt the function neither allocates nor waits after the scatter.
@@ -3441,6 +3466,7 @@ static void* take_tmp(size_t need) {
 static void give_tmp() { TmpPool& pool = tmp_pool(); std::lock_guard<std::mutex> g(pool.m); pool.in_use = false; }
 int release_bitmap_pool();
 int release_bitmap_pool() {
+  release_small_pool();
   {
     TmpPool& tp = tmp_pool();
     std::lock_guard<std::mutex> g(tp.m);
@@ -4587,8 +4613,7 @@ int kkamd_spgemm_destroy(kkamd_spgemm_handle_t* h) {
   if (h->d_hub_multi) (void)hipFree(h->d_hub_multi);
   if (h->d_bidx) (void)hipFree(h->d_bidx);
   if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
-  if (h->d_small) (void)hipFree(h->d_small);
-  if (h->h_small) (void)hipHostFree(h->h_small);
+  kk::park_small(h);
   if (h->d_scan_ws) (void)hipFree(h->d_scan_ws);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
